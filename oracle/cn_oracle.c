@@ -1,0 +1,1212 @@
+/*
+ * cn_oracle.c -- TEST INFRASTRUCTURE ONLY (see cn_oracle.h).
+ *
+ * Plain-C float64 restatement of the reference environment step.  ENV = environment_stage_1_nobonus.py,
+ * UTL = utils.py, CROWD = crowd_behaviors/simulate_crowd.py (all under
+ * /root/reference/turtlebot3_rl_sim/src).  Every block cites the lines it follows.
+ *
+ * Semantics pinned here (and by oracle/harness, which runs the reference's own Python):
+ *   - Python-2 integer division at UTL:113 (360/359 == 1) and ENV:577 (len/2)
+ *   - Python-3 round() (correctly rounded, ties-to-even on the exact binary value); differs from
+ *     Python-2 round only on exact dyadic ties such as 0.0625
+ *   - round(np.float64, n) and np.around use numpy's multiply / rint / divide
+ *   - dict iteration = insertion order (uuid4 hash order of Python 2 is unreproducible)
+ *   - time.time() is a virtual clock: sleep(d) adds d; the /scan wait adds scan_latency
+ *   - shapely Point.buffer(r).boundary is the regular 64-gon with vertices at angle -k*pi/32;
+ *     ring/segment intersection is the textbook two-parameter solve below ("parity unpinned":
+ *     shapely/GEOS are not part of the reference tree)
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off -fopenmp).
+ */
+#include "cn_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define TY_NONE 0
+#define TY_W 1
+#define TY_O 2
+#define ST_TRACK_OVERFLOW 1
+#define ST_TTC_ZERO 2
+#define ST_DT_ZERO 4
+
+typedef struct { double x, y; } v2;
+
+typedef struct {
+    v2 pose;
+    double dist;
+    v2 dq[2];
+    int dq_len;
+    double t;     /* time stamp, or a duration after a match (ENV:710) */
+    double speed; /* -1 until matched (ENV:667) */
+    v2 vel;
+} track_t;
+
+typedef struct {
+    /* simulator (no reference source; DESIGN.md "physics") */
+    double rx, ry, ryaw, rv, rw;
+    double* ped_p;
+    double* ped_v;
+    double* ped_init;
+    double* ped_preset;
+    double* ranges;
+    int64_t crowd_ms;
+    /* virtual clock */
+    double clock;
+    /* Env attributes that persist between calls */
+    double wpx, wpy;
+    double prev_dist, prev_head;
+    int done;
+    v2 agent_dq[2];
+    int agent_dq_len;
+    double agent_vel_timestep;
+    double bb;
+    track_t tracks[CNO_MAX_TRACKS];
+    int ntracks;
+    double ego_score_cp;
+    double collision_prob;
+    int ego_viol, social_viol, obst_steps;
+    int ep_success, ep_failure;
+    int ep_step;
+    double ep_return, last_return;
+    int status;
+    int n_confirmed, n_entries;
+} env_t;
+
+struct cno_sim {
+    cno_config cfg;
+    int n, D;
+    env_t* envs;
+    double* lidar_c;
+    double* lidar_s;
+    double poly_c[64], poly_s[64];
+};
+
+static int g_threads = 1;
+
+/* ------------------------------------------------------------------------------------------
+ * numeric helpers
+ * ---------------------------------------------------------------------------------------- */
+
+/* Python 3 round(x, nd): correctly rounded to nd decimals, ties-to-even on the exact value,
+ * then the nearest double of that decimal.  x*p = y + err exactly (fma), so the only case the
+ * rounded product can mislead rint() is y landing exactly on a half-integer. */
+double cno_py_round(double x, int nd)
+{
+    double p = (nd == 3) ? 1000.0 : (nd == 2 ? 100.0 : pow(10.0, nd));
+    if (!isfinite(x)) return x;
+    double y = x * p;
+    double r = rint(y);
+    double d = y - r;
+    if (fabs(d) == 0.5) {
+        double err = fma(x, p, -y);
+        if (err > 0.0) r = y + 0.5;
+        else if (err < 0.0) r = y - 0.5;
+    }
+    return r / p;
+}
+
+/* numpy around / round(np.float64, nd): multiply, rint, divide */
+double cno_np_around(double x, int nd)
+{
+    double p = (nd == 3) ? 1000.0 : (nd == 2 ? 100.0 : pow(10.0, nd));
+    return rint(x * p) / p;
+}
+
+/* Deterministic sin/cos used by the simulator (physics + lidar direction table): only + * fma
+ * and rint, so every IEEE-754 implementation returns the same bits.  Cody-Waite reduction by
+ * pi/2 (three-part constant) followed by the classic degree-13/14 minimax kernels on [-pi/4, pi/4]. */
+void cno_det_sincos(double x, double* sn, double* cs)
+{
+    const double two_over_pi = 6.36619772367581382433e-01;
+    const double p1 = 1.57079632673412561417e+00;  /* first 33 bits of pi/2 */
+    const double p2 = 6.07710050630396597660e-11;  /* next 33 bits */
+    const double p3 = 2.02226624879595063154e-21;  /* remainder */
+    double fn = rint(x * two_over_pi);
+    double r = fma(-fn, p1, x);
+    r = fma(-fn, p2, r);
+    r = fma(-fn, p3, r);
+    double z = r * r;
+    /* sin kernel */
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+                 S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+                 S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    double ps = fma(z, S6, S5);
+    ps = fma(z, ps, S4);
+    ps = fma(z, ps, S3);
+    ps = fma(z, ps, S2);
+    ps = fma(z, ps, S1);
+    double s = fma(r * z, ps, r);
+    /* cos kernel */
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+                 C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+                 C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    double pc = fma(z, C6, C5);
+    pc = fma(z, pc, C4);
+    pc = fma(z, pc, C3);
+    pc = fma(z, pc, C2);
+    pc = fma(z, pc, C1);
+    double c = fma(z * z, pc, fma(-0.5, z, 1.0));
+    long q = (long)fn;
+    switch (q & 3) {
+    case 0: *sn = s;  *cs = c;  break;
+    case 1: *sn = c;  *cs = -s; break;
+    case 2: *sn = -s; *cs = -c; break;
+    default: *sn = -c; *cs = s; break;
+    }
+}
+
+static uint64_t mix64(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+/* counter-based uniform [0,1): stateless, keyed by (seed, global env index, stream, a, b) */
+double cno_rng_u01(uint64_t seed, int64_t env, uint32_t stream, uint32_t a, uint32_t b)
+{
+    uint64_t h = mix64(seed ^ mix64((uint64_t)env));
+    h = mix64(h ^ (((uint64_t)stream << 32) | (uint64_t)a));
+    h = mix64(h ^ (uint64_t)b);
+    return (double)(h >> 11) * (1.0 / 9007199254740992.0);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * simulator: pedestrians (CROWD:98-144 velocity law), diff drive, lidar.
+ * ---------------------------------------------------------------------------------------- */
+
+static double clampd(double x, double lo, double hi) { return fmin(fmax(x, lo), hi); }
+
+static void ped_advance(const cno_sim* s, env_t* e, int64_t gid, int64_t t0, int64_t t1)
+{
+    const cno_config* c = &s->cfg;
+    const double lo = -c->room_half + c->ped_radius, hi = c->room_half - c->ped_radius;
+    const int64_t T = c->ped_cycle_ms;
+    for (int i = 0; i < c->n_peds; ++i) {
+        double x = e->ped_p[2 * i], y = e->ped_p[2 * i + 1];
+        double vx = e->ped_v[2 * i], vy = e->ped_v[2 * i + 1];
+        int64_t offs = (int64_t)i * c->ped_stagger_ms;
+        int64_t m = (t0 <= offs) ? 0 : (t0 - offs + T - 1) / T;
+        int64_t a = offs + m * T; /* first assignment instant >= t0 */
+        int64_t tc = t0;
+        while (a < t1) {
+            if (a > tc) {
+                double ds = (double)(a - tc) / 1000.0;
+                x = clampd(fma(vx, ds, x), lo, hi);
+                y = clampd(fma(vy, ds, y), lo, hi);
+                tc = a;
+            }
+            if (c->ped_mode == 0) { /* CROWD:101-102 random.uniform(-vmax, vmax) */
+                double u0 = cno_rng_u01(c->seed, gid, 1u, (uint32_t)i, (uint32_t)(2 * m));
+                double u1 = cno_rng_u01(c->seed, gid, 1u, (uint32_t)i, (uint32_t)(2 * m + 1));
+                vx = fma(2.0 * c->ped_vmax, u0, -c->ped_vmax);
+                vy = fma(2.0 * c->ped_vmax, u1, -c->ped_vmax);
+            } else {
+                vx = e->ped_preset[2 * i];
+                vy = e->ped_preset[2 * i + 1];
+            }
+            a += T;
+            m += 1;
+        }
+        if (t1 > tc) {
+            double ds = (double)(t1 - tc) / 1000.0;
+            x = clampd(fma(vx, ds, x), lo, hi);
+            y = clampd(fma(vy, ds, y), lo, hi);
+        }
+        e->ped_p[2 * i] = x; e->ped_p[2 * i + 1] = y;
+        e->ped_v[2 * i] = vx; e->ped_v[2 * i + 1] = vy;
+    }
+}
+
+/* Diff-drive for one interval with (v, w) held: the mid-point rule of turtlebot3_fake.cpp:156-162
+ * (x += ds*cos(th + dth/2), y += ds*sin(th + dth/2), th += dth). */
+static void robot_advance(const cno_sim* s, env_t* e, int64_t ms)
+{
+    const cno_config* c = &s->cfg;
+    double dts = (double)ms / 1000.0;
+    double ds = e->rv * dts, dth = e->rw * dts;
+    double sn, cs;
+    cno_det_sincos(fma(0.5, dth, e->ryaw), &sn, &cs);
+    double lim = c->room_half - c->robot_clearance;
+    e->rx = clampd(fma(ds, cs, e->rx), -lim, lim);
+    e->ry = clampd(fma(ds, sn, e->ry), -lim, lim);
+    double th = e->ryaw + dth;
+    if (th > M_PI) th -= 2.0 * M_PI;
+    else if (th <= -M_PI) th += 2.0 * M_PI;
+    e->ryaw = th;
+}
+
+static void sim_advance(const cno_sim* s, env_t* e, int64_t gid, int64_t ms)
+{
+    if (ms <= 0) return;
+    ped_advance(s, e, gid, e->crowd_ms, e->crowd_ms + ms);
+    e->crowd_ms += ms;
+    robot_advance(s, e, ms);
+}
+
+/* gazebo/reset_simulation (ENV:1228-1231): poses back to their initial values, twists zeroed.
+ * The crowd node is a separate process and keeps its own schedule (crowd_ms is not reset). */
+static void sim_reset(const cno_sim* s, env_t* e)
+{
+    const cno_config* c = &s->cfg;
+    e->rx = c->spawn_x; e->ry = c->spawn_y; e->ryaw = c->spawn_yaw;
+    e->rv = 0.0; e->rw = 0.0;
+    memcpy(e->ped_p, e->ped_init, sizeof(double) * 2 * c->n_peds);
+    memset(e->ped_v, 0, sizeof(double) * 2 * c->n_peds);
+}
+
+static void raycast_impl(const cno_config* c, const double* lc, const double* ls, double rx, double ry,
+                         double ryaw, const double* ped, int P, double* ranges)
+{
+    double sy, cy;
+    cno_det_sincos(ryaw, &sy, &cy);
+    double ox = fma(c->lidar_offset_x, cy, rx), oy = fma(c->lidar_offset_x, sy, ry);
+    const double h = c->room_half, rr = c->ped_radius * c->ped_radius;
+    for (int k = 0; k < c->n_rays; ++k) {
+        double dx = fma(cy, lc[k], -(sy * ls[k]));
+        double dy = fma(sy, lc[k], cy * ls[k]);
+        double t = INFINITY;
+        if (dx > 0.0) t = fmin(t, (h - ox) / dx);
+        else if (dx < 0.0) t = fmin(t, (-h - ox) / dx);
+        if (dy > 0.0) t = fmin(t, (h - oy) / dy);
+        else if (dy < 0.0) t = fmin(t, (-h - oy) / dy);
+        if (t < c->lidar_min) t = c->lidar_min;
+        for (int j = 0; j < P; ++j) {
+            double ocx = ped[2 * j] - ox, ocy = ped[2 * j + 1] - oy;
+            double b = fma(ocx, dx, ocy * dy);
+            double cc = fma(ocx, ocx, fma(ocy, ocy, -rr));
+            double disc = fma(b, b, -cc);
+            if (disc >= 0.0) {
+                double sq = sqrt(disc);
+                double t2 = b + sq;
+                if (t2 >= c->lidar_min) {
+                    double t1 = fmax(b - sq, c->lidar_min);
+                    t = fmin(t, t1);
+                }
+            }
+        }
+        ranges[k] = (t > c->lidar_max) ? INFINITY : t;
+    }
+}
+
+void cno_raycast(const cno_config* cfg, double rx, double ry, double ryaw, const double* ped_xy, int P,
+                 double* ranges)
+{
+    int R = cfg->n_rays;
+    double* lc = (double*)malloc(sizeof(double) * 2 * R);
+    double* ls = lc + R;
+    double step = cfg->lidar_span / (double)(R - 1);
+    for (int k = 0; k < R; ++k) cno_det_sincos((double)k * step, &ls[k], &lc[k]);
+    raycast_impl(cfg, lc, ls, rx, ry, ryaw, ped_xy, P, ranges);
+    free(lc);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * utils.py restatements
+ * ---------------------------------------------------------------------------------------- */
+
+/* UTL:375-392 get_scan_ranges */
+void cno_scan_sanitize(const double* ranges, int R, double max_range, double* scan)
+{
+    /* out[j] = clean(ranges[R-1-j]), j = 0..R-2 (reverse, drop last) */
+    for (int j = 0; j < R - 1; ++j) {
+        double r = ranges[R - 1 - j];
+        double o;
+        if (isinf(r) && r > 0) o = max_range;
+        else if (isnan(r)) o = 0.0;
+        else if (r == 0.0) o = max_range;
+        else if (r > max_range) o = max_range;
+        else o = r;
+        scan[j] = o;
+    }
+}
+
+/* UTL:113 angle_increment = max_angle / (resolution - 1) with Python-2 integer operands.
+ * 360/359 == 1.  For R-1 > 360 Python 2 would give 0 (every ray at angle 0); that case is
+ * outside the reference's operating range and is defined here as true division. */
+static double angle_increment_deg(int R)
+{
+    if (R - 1 <= 360) return (double)(360 / (R - 1));
+    return 360.0 / (double)(R - 1);
+}
+
+/* UTL:110-126 convert_laserscan_to_coordinate */
+void cno_scan_to_points(const double* scan, int R, double px, double py, double yaw, double* pts)
+{
+    const double deg2rad = M_PI / 180.0; /* CPython math.radians: x * (pi/180) */
+    double inc = angle_increment_deg(R);
+    for (int i = 0; i < R - 1; ++i) {
+        double ang = (double)i * inc;
+        double a = ang * deg2rad - yaw;
+        pts[2 * i] = cno_py_round(px + (scan[i] * cos(a)), 3);
+        pts[2 * i + 1] = cno_py_round(py + (scan[i] * sin(a)) * -1.0, 3);
+    }
+}
+
+/* UTL:405-419 */
+double cno_bbox_size(const double* pts, int n)
+{
+    double sum = 0.0; /* Python sum(): left-to-right float adds starting from int 0 */
+    for (int i = 0; i < n; ++i) {
+        int j = (i == n - 1) ? 0 : i + 1;
+        sum += hypot(pts[2 * i] - pts[2 * j], pts[2 * i + 1] - pts[2 * j + 1]);
+    }
+    return sum / (double)n;
+}
+
+/* UTL:395-402 */
+int cno_estimate_num_obs_scans(double d, double max_range, double min_range)
+{
+    return 3 + (int)floor(29 * (max_range - d) / (max_range - min_range));
+}
+
+/* UTL:422-460 is_associated / get_iou: IoU of two axis-aligned squares built from their corner
+ * coordinates, rounded to 3 decimals. */
+double cno_iou(double ax, double ay, double bx, double by, double half)
+{
+    double axp = ax + half, axm = ax - half, ayp = ay + half, aym = ay - half;
+    double bxp = bx + half, bxm = bx - half, byp = by + half, bym = by - half;
+    double ix = fmin(axp, bxp) - fmax(axm, bxm);
+    double iy = fmin(ayp, byp) - fmax(aym, bym);
+    double inter = (ix > 0.0 && iy > 0.0) ? ix * iy : 0.0;
+    double area_a = (axp - axm) * (ayp - aym);
+    double area_b = (bxp - bxm) * (byp - bym);
+    double uni = area_a + area_b - inter;
+    return cno_py_round(inter / uni, 3);
+}
+
+static void poly_tables(double* pc, double* ps)
+{
+    for (int k = 0; k < 64; ++k) {
+        double a = -(double)k * M_PI / 32.0;
+        pc[k] = cos(a);
+        ps[k] = sin(a);
+    }
+}
+
+/* shapely: Point(c).buffer(r).boundary.intersection(LineString([a, b])) -> points.
+ * Edge k runs from vertex k to vertex k+1; a hit belongs to edge k iff its edge parameter u is in
+ * [0, 1) so a vertex is reported once. */
+static int ring_segment(const double* pc, const double* ps, double cx, double cy, double r, double ax,
+                        double ay, double bx, double by, v2* out, int maxout)
+{
+    int cnt = 0;
+    double rx = bx - ax, ry = by - ay;
+    for (int k = 0; k < 64; ++k) {
+        int k2 = (k + 1) & 63;
+        double c0x = cx + r * pc[k], c0y = cy + r * ps[k];
+        double c1x = cx + r * pc[k2], c1y = cy + r * ps[k2];
+        double sx = c1x - c0x, sy = c1y - c0y;
+        double den = rx * sy - ry * sx;
+        if (den == 0.0) continue;
+        double qx = c0x - ax, qy = c0y - ay;
+        double t = (qx * sy - qy * sx) / den;
+        double u = (qx * ry - qy * rx) / den;
+        if (t >= 0.0 && t <= 1.0 && u >= 0.0 && u < 1.0) {
+            if (cnt < maxout) { out[cnt].x = ax + t * rx; out[cnt].y = ay + t * ry; }
+            ++cnt;
+        }
+    }
+    return cnt;
+}
+
+static int waypoint_impl(const double* pc, const double* ps, double ax, double ay, double gx, double gy,
+                         double radius, double* wp)
+{
+    /* UTL:296-314 */
+    v2 hit[4];
+    int cnt = ring_segment(pc, ps, ax, ay, radius, ax, ay, gx, gy, hit, 4);
+    if (cnt == 1) { wp[0] = hit[0].x; wp[1] = hit[0].y; return 1; }
+    wp[0] = -(gx + 0.0); wp[1] = gy + 0.0; /* UTL:310-312: x sign flipped */
+    return 0;
+}
+
+int cno_waypoint(double ax, double ay, double gx, double gy, double radius, double* wp)
+{
+    double pc[64], ps[64];
+    poly_tables(pc, ps);
+    return waypoint_impl(pc, ps, ax, ay, gx, gy, radius, wp);
+}
+
+/* UTL:251-293 get_collision_point.  returns 1 and *dist when a distance exists, else 0 (None) */
+static int collision_point_impl(const double* pc, const double* ps, double a0x, double a0y, double a1x,
+                                double a1y, double ox, double oy, double radius, double* dist)
+{
+    double gradient;
+    if (a1y == 0.0) gradient = 0.0; /* ZeroDivisionError branch, UTL:262-263 */
+    else gradient = (a1x - a0x) / a1y - a0y; /* UTL:261 precedence as written */
+    double b = a0x - (gradient * a0y);
+    int hi = (int)ceil(a0x + 3.5), lo = (int)floor(a0x - 3.5);
+    for (int x2 = hi; x2 > lo; --x2) {
+        double y2 = ((double)x2 * gradient) + b;
+        v2 hit[4];
+        int cnt = ring_segment(pc, ps, ox, oy, radius, a0x, a0y, (double)x2, y2, hit, 4);
+        if (cnt == 0) continue;     /* 'LINESTRING EMPTY' -> keep scanning x2 */
+        if (cnt == 1) return 0;     /* Point has no .geoms -> except -> None, break */
+        double d1 = hypot(a0x - hit[0].x, a0y - hit[0].y);
+        double d2 = hypot(a0x - hit[1].x, a0y - hit[1].y);
+        *dist = fmin(d1, d2);
+        return 1;
+    }
+    return 0;
+}
+
+int cno_collision_point(double a0x, double a0y, double a1x, double a1y, double ox, double oy, double radius,
+                        double* dist)
+{
+    double pc[64], ps[64];
+    poly_tables(pc, ps);
+    return collision_point_impl(pc, ps, a0x, a0y, a1x, a1y, ox, oy, radius, dist);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Env.get_state (ENV:245-1044)
+ * ---------------------------------------------------------------------------------------- */
+
+static double heading_to_goal(const cno_config* c, const env_t* e, double px, double py, double yaw)
+{
+    /* ENV:222-237: adds starting_point to the position (ENV:191-209 does not) */
+    double cx = px + c->start_x, cy = py + c->start_y;
+    double ga = atan2(e->wpy - cy, e->wpx - cx);
+    double h = ga - yaw;
+    if (h > M_PI) h -= 2 * M_PI;
+    else if (h < -M_PI) h += 2 * M_PI;
+    return h;
+}
+
+static double dist3(double ax, double ay, double bx, double by)
+{
+    double dx = ax - bx, dy = ay - by, dz = 0.0;
+    return sqrt(dx * dx + dy * dy + dz * dz); /* np.linalg.norm of a 3-vector, ENV:191-197 */
+}
+
+static void waypoint_refresh(const cno_sim* s, env_t* e, double px, double py)
+{
+    double wp[2];
+    waypoint_impl(s->poly_c, s->poly_s, px, py, s->cfg.goal_x, s->cfg.goal_y, s->cfg.waypoint_radius, wp);
+    e->wpx = wp[0];
+    e->wpy = wp[1];
+}
+
+static int in_box(double x, double y, double gx, double gy, double eps)
+{
+    /* ENV:1285-1319: half-open box, x <= g+eps and x > g-eps */
+    double xp = gx + eps, xm = gx - eps, yp = gy + eps, ym = gy - eps;
+    return (x <= xp) && (x > xm) && (y <= yp) && (y > ym);
+}
+
+typedef struct { int type; v2 pose; double dist; } cobj_t;
+
+static void track_new(env_t* e, const cobj_t* o, double now)
+{
+    if (e->ntracks >= CNO_MAX_TRACKS) { e->status |= ST_TRACK_OVERFLOW; return; }
+    track_t* t = &e->tracks[e->ntracks++];
+    t->pose = o->pose; t->dist = o->dist;
+    t->dq[0] = o->pose; t->dq_len = 1;
+    t->t = now; t->speed = -1.0;
+    t->vel.x = 0.0; t->vel.y = 0.0;
+}
+
+static void env_get_state(const cno_sim* s, env_t* e, const double* ranges, double px, double py, double yaw,
+                          double v, double w, int step_counter, double now, double* state, int* done_out,
+                          int32_t* topk_idx)
+{
+    const cno_config* c = &s->cfg;
+    const int R = c->n_rays, n = R - 1, K = c->k_obstacles;
+    const double MAXR = c->max_scan_range;
+
+    /* ENV:246-253 */
+    if (step_counter == 1) waypoint_refresh(s, e, px, py);
+    /* ENV:255-257: distance is np.float64 -> numpy rounding; heading is a Python float */
+    double distance_to_goal = cno_np_around(dist3(px, py, e->wpx, e->wpy), 2);
+    double heading = cno_py_round(heading_to_goal(c, e, px, py, yaw), 2);
+    /* ENV:259-265 */
+    if (step_counter % 5 == 0 || distance_to_goal < e->prev_dist) waypoint_refresh(s, e, px, py);
+    /* ENV:267-268: the angular velocity is used as the angle */
+    double agent_vel_x = -1.0 * (v * cos(w));
+    double agent_vel_y = v * sin(w);
+
+    double* scan = (double*)malloc(sizeof(double) * (size_t)n * 12 + sizeof(int) * (size_t)n * 8);
+    double* pts = scan + n;          /* 2n */
+    double* d = pts + 2 * n;         /* n  */
+    double* g = d + n;               /* n  */
+    double* cg = g + n;              /* n  */
+    double* ds = cg + n;             /* n  */
+    double* psx = ds + n;            /* n  */
+    double* psy = psx + n;           /* n  */
+    double* gtp = psy + n;           /* 2n */
+    int* gnone = (int*)(gtp + 2 * n + n); /* keep alignment slack */
+    int* cnone = gnone + n;
+    int* Ttype = cnone + n;
+    int* Tsrc = Ttype + n;
+    int* ty = Tsrc + n;
+    int* order = ty + n;
+    int* segend = order + n;         /* segend[k] = 1 if a segment closes after order[k] */
+    int* tmp = segend + n;
+
+    /* ENV:277-283 */
+    cno_scan_sanitize(ranges, R, MAXR, scan);
+    cno_scan_to_points(scan, R, px, py, yaw, pts);
+
+    /* ENV:287-294 */
+    if (step_counter == 0) {
+        for (int i = 0; i < n; ++i) d[i] = MAXR; /* ground_truth_scans, ENV:116 */
+        cno_scan_to_points(d, R, px, py, yaw, gtp);
+        e->bb = cno_bbox_size(gtp, n);
+        v2 p = { cno_py_round(px, 3), cno_py_round(py, 3) };
+        if (e->agent_dq_len < 2) e->agent_dq[e->agent_dq_len++] = p;
+        else { e->agent_dq[0] = e->agent_dq[1]; e->agent_dq[1] = p; } /* unreachable: deque is unbounded but never exceeds 2 */
+    }
+    /* ENV:297-305 is dead code (result unused) -> omitted */
+
+    /* ENV:317-327 */
+    for (int i = 0; i < n; ++i) d[i] = cno_py_round(scan[i], 3);
+
+    /* ENV:329-346 gradients between consecutive end points */
+    for (int i = 0; i < n; ++i) {
+        if (d[i] == 0.6) { gnone[i] = 1; g[i] = 0.0; continue; }
+        int j = (i == n - 1) ? 0 : i + 1;
+        double dy = pts[2 * i + 1] - pts[2 * j + 1];
+        double gr;
+        if (dy == 0) gr = 0.0;
+        else gr = (pts[2 * i] - pts[2 * j]) / dy;
+        gnone[i] = 0;
+        g[i] = cno_py_round(gr, 3);
+    }
+    /* ENV:348-367 change of gradient */
+    {
+        int last_none = 1; double last = 0.0;
+        for (int i = 0; i < n; ++i) {
+            if (gnone[i]) { cnone[i] = 1; cg[i] = 0.0; continue; }
+            if (n == 1 || i == n - 1) { cnone[i] = last_none; cg[i] = last; }
+            else if (!gnone[i + 1]) {
+                double ch = fabs(g[i] - g[i + 1]);
+                last = ch; last_none = 0; cnone[i] = 0; cg[i] = ch;
+            } else { last_none = 1; last = 0.0; cnone[i] = 1; cg[i] = 0.0; }
+        }
+    }
+    /* ENV:372-410 object-type state machine.  T[i] is None or a reference to the list created
+     * at some ray (its range and pose travel with it): (Ttype, Tsrc). */
+    {
+        int last_type = TY_NONE, last_src = -1, du = 0;
+        for (int i = 0; i < n; ++i) { Ttype[i] = TY_NONE; Tsrc[i] = -1; }
+        for (int i = 0; i < n; ++i) {
+            if (cnone[i]) continue;
+            if (i == n - 1) continue;
+            if (cg[i] == 0) {
+                Ttype[i] = TY_W; Tsrc[i] = i; last_type = TY_W; last_src = i;
+            } else {
+                Ttype[i] = TY_O; Tsrc[i] = i;
+                if (du != 1) {
+                    if (!cnone[i + 1] && cg[i + 1] == 0) {
+                        Ttype[i] = TY_W; Tsrc[i] = i; last_type = TY_W; last_src = i; du = 0;
+                    }
+                    if (cnone[i + 1]) {
+                        /* ENV:394-395 pass */
+                    } else if (fabs(cg[i] - cg[i + 1]) == 0) {
+                        Ttype[i] = TY_W; Tsrc[i] = i; last_type = TY_W; last_src = i; du = 0;
+                    } else {
+                        Ttype[i] = last_type; Tsrc[i] = last_src; du += 1;
+                    }
+                } else {
+                    Ttype[i] = TY_O; Tsrc[i] = i; last_type = TY_O; last_src = i;
+                    if (!cnone[i + 1] && cg[i + 1] == 0) du = 0;
+                }
+            }
+        }
+    }
+    /* ENV:433-445 per-ray (type, distance, pose) */
+    for (int i = 0; i < n; ++i) {
+        if (Ttype[i] == TY_NONE) { ty[i] = TY_NONE; ds[i] = d[i]; psx[i] = pts[2 * i]; psy[i] = pts[2 * i + 1]; }
+        else { int q = Tsrc[i]; ty[i] = Ttype[i]; ds[i] = d[q]; psx[i] = pts[2 * q]; psy[i] = pts[2 * q + 1]; }
+    }
+    /* ENV:448-485 segmentation by bounding-box association of consecutive rays */
+    int nseg = 0;
+    {
+        int* brk = tmp; /* brk[i] = 1: a segment closes after ray i */
+        for (int i = 0; i < n; ++i) {
+            if (i == n - 1) brk[i] = 1; /* both branches of ENV:454-470 close the segment */
+            else brk[i] = !(cno_iou(psx[i], psy[i], psx[i + 1], psy[i + 1], e->bb) > 0.0);
+        }
+        int first_end = 0;
+        while (!brk[first_end]) ++first_end;
+        int nsegs0 = 0;
+        for (int i = 0; i < n; ++i) nsegs0 += brk[i];
+        int last_start = n - 1;
+        while (last_start > 0 && !brk[last_start - 1]) --last_start;
+        int merge = 0;
+        /* ENV:490-502 first <-> last with twice the box */
+        if (nsegs0 > 1 &&
+            cno_iou(psx[0], psy[0], psx[n - 1], psy[n - 1], e->bb * 2) > 0.0) merge = 1;
+        int pos = 0;
+        if (merge) {
+            for (int i = 0; i <= first_end; ++i) { order[pos] = i; segend[pos] = 0; ++pos; }
+            for (int i = last_start; i < n; ++i) { order[pos] = i; segend[pos] = 0; ++pos; }
+            segend[pos - 1] = 1;
+            for (int i = first_end + 1; i < last_start; ++i) { order[pos] = i; segend[pos] = brk[i]; ++pos; }
+        } else {
+            for (int i = 0; i < n; ++i) { order[i] = i; segend[i] = brk[i]; }
+            pos = n;
+        }
+        /* ENV:508-566 split each segment where free space (0.6) meets occupied */
+        int k0 = 0;
+        while (k0 < n) {
+            int k1 = k0;
+            while (!segend[k1]) ++k1;
+            int any_occ = 0;
+            for (int k = k0; k <= k1; ++k) if (ds[order[k]] != 0.6) any_occ = 1;
+            if (any_occ) {
+                for (int k = k0; k < k1; ++k) {
+                    int a06 = ds[order[k]] == 0.6, b06 = ds[order[k + 1]] == 0.6;
+                    if (a06 != b06) segend[k] = 1;
+                }
+            }
+            k0 = k1 + 1;
+        }
+        for (int k = 0; k < n; ++k) nseg += segend[k];
+    }
+    /* ENV:568-620 confirmation */
+    int maxc = n / 4 + 2;
+    cobj_t* conf = (cobj_t*)malloc(sizeof(cobj_t) * (size_t)maxc);
+    int nconf = 0;
+    {
+        int k0 = 0;
+        while (k0 < n) {
+            int k1 = k0;
+            while (!segend[k1]) ++k1;
+            int len = k1 - k0 + 1;
+            int any_occ = 0;
+            for (int k = k0; k <= k1; ++k) if (ds[order[k]] != 0.6) any_occ = 1;
+            if (any_occ && len >= 4) {
+                int m = order[k0 + len / 2]; /* ENV:577 Python-2 integer division */
+                int est = cno_estimate_num_obs_scans(ds[m], c->max_scan_range, c->min_scan_range);
+                int no = 0, nw = 0, nn = 0;
+                for (int k = k0; k <= k1; ++k) {
+                    int t = ty[order[k]];
+                    no += (t == TY_O); nw += (t == TY_W); nn += (t == TY_NONE);
+                }
+                int mn = len < est ? len : est;
+                double score = (double)no / (double)mn;
+                int kinds = (no > 0) + (nw > 0) + (nn > 0);
+                int obj = -1;
+                if (kinds > 1) {
+                    if (score >= 0.5) obj = (no > nw) ? TY_O : TY_W;
+                    else if (len <= est) obj = (no > nw) ? TY_O : TY_W;
+                    else obj = TY_W;
+                } else {
+                    int lim = nseg < est ? nseg : est; /* ENV:608,615: compares with the number of segments */
+                    if (len <= lim) obj = -1;
+                    else obj = (nw > 0) ? TY_W : TY_O;
+                }
+                if (obj >= 0 && nconf < maxc) {
+                    conf[nconf].type = obj;
+                    conf[nconf].pose.x = psx[m]; conf[nconf].pose.y = psy[m];
+                    conf[nconf].dist = ds[m];
+                    ++nconf;
+                }
+            }
+            k0 = k1 + 1;
+        }
+    }
+    e->n_confirmed = nconf;
+    /* ENV:637-654 */
+    int n_obst = 0;
+    for (int j = 0; j < nconf; ++j) n_obst += (conf[j].type == TY_O);
+    if (n_obst > 0) e->obst_steps += 1;
+
+    /* ENV:656-743 tracker */
+    if (e->ntracks == 0) {
+        for (int j = 0; j < nconf; ++j) if (conf[j].type == TY_O) track_new(e, &conf[j], now);
+    } else {
+        int nt0 = e->ntracks;
+        for (int i = 0; i < nt0; ++i) if (e->tracks[i].dq_len > 1) { /* ENV:678-680 popleft */
+            e->tracks[i].dq[0] = e->tracks[i].dq[1]; e->tracks[i].dq_len = 1;
+        }
+        if (nconf == 0) {
+            e->ntracks = 0; /* ENV:683-686 nets out to clearing every track */
+        } else {
+            int alive[CNO_MAX_TRACKS];
+            int* checked = tmp;
+            for (int j = 0; j < nconf; ++j) checked[j] = 0;
+            int cur = nt0; /* len(self.tracked_obstacles) */
+            for (int i = 0; i < nt0; ++i) {
+                alive[i] = 1;
+                track_t* t = &e->tracks[i];
+                int bj = 0; double best = -1.0;
+                for (int j = 0; j < nconf; ++j) { /* ENV:688-689, walls included */
+                    double u = cno_iou(t->pose.x, t->pose.y, conf[j].pose.x, conf[j].pose.y, 0.0505);
+                    if (u > best) { best = u; bj = j; } /* list.index(max): first maximum */
+                }
+                if (best > 0.0) { /* ENV:702-712 */
+                    t->pose = conf[bj].pose; t->dist = conf[bj].dist;
+                    t->dq[t->dq_len++] = conf[bj].pose;
+                    t->t = now - t->t;
+                    checked[bj] = 1;
+                } else if (cur > i) { /* ENV:715-717 */
+                    alive[i] = 0; cur -= 1;
+                }
+            }
+            int m = 0;
+            for (int i = 0; i < nt0; ++i) if (alive[i]) { if (m != i) e->tracks[m] = e->tracks[i]; ++m; }
+            e->ntracks = m;
+            for (int j = 0; j < nconf; ++j) /* ENV:723-743 */
+                if (!checked[j] && conf[j].type == TY_O) track_new(e, &conf[j], now);
+        }
+    }
+    /* ENV:745-760 speed of matched tracks */
+    for (int i = 0; i < e->ntracks; ++i) {
+        track_t* t = &e->tracks[i];
+        if (t->dq_len > 1) {
+            double dc = hypot(t->dq[0].y - t->dq[1].y, t->dq[0].x - t->dq[1].x);
+            t->speed = dc / t->t;
+        }
+    }
+
+    /* default K x [px, py, 0, 0] (ENV:273) */
+    double* feat = state + n + 7;
+    for (int k = 0; k < K; ++k) { feat[4 * k] = px; feat[4 * k + 1] = py; feat[4 * k + 2] = 0.0; feat[4 * k + 3] = 0.0; }
+    for (int k = 0; k < K; ++k) topk_idx[k] = -1;
+    e->n_entries = 0;
+
+    /* ENV:769-996 collision cone / collision probability */
+    if (e->agent_dq_len == 2) {
+        double ts = e->agent_vel_timestep;
+        if (ts == 0.0) e->status |= ST_DT_ZERO;
+        /* UTL:227-236 */
+        double vx_ = (e->agent_dq[1].x - e->agent_dq[0].x) / ts;
+        double vy_ = (e->agent_dq[1].y - e->agent_dq[0].y) / ts;
+        double agent_vel = sqrt(pow(vx_, 2) + pow(vy_, 2));
+        double obstacle_vel = (e->ntracks == 0) ? 0.0 : e->tracks[0].speed; /* ENV:787-793 */
+        double vo_x = e->agent_dq[1].x, vo_y = e->agent_dq[1].y;
+        for (int i = 0; i < e->ntracks; ++i) { /* ENV:800-815: the last track's value survives */
+            track_t* t = &e->tracks[i];
+            double chx = 0, chy = 0;
+            if (t->dq_len > 1) {
+                chx = t->dq[0].x - t->dq[1].x; chy = t->dq[0].y - t->dq[1].y;
+                t->vel.x = chx / ts; t->vel.y = chy / ts;
+            }
+            vo_x = e->agent_dq[1].x + chx; vo_y = e->agent_dq[1].y + chy;
+        }
+        double cp[CNO_MAX_TRACKS];
+        double ego_prev = 0.0, ego_max = 0.0;
+        int ne = 0;
+        for (int i = 0; i < e->ntracks; ++i) { /* ENV:818-860 */
+            track_t* t = &e->tracks[i];
+            double dcp;
+            int has = collision_point_impl(s->poly_c, s->poly_s, e->agent_dq[0].x, e->agent_dq[0].y, vo_x, vo_y,
+                                           t->pose.x, t->pose.y, 0.178, &dcp);
+            double rv = agent_vel - obstacle_vel;
+            double gcp = (t->dist > c->max_scan_range) ? 0.0
+                        : (c->max_scan_range - t->dist) / (c->max_scan_range - c->min_scan_range);
+            double ego, cpv;
+            if (has) {
+                if (rv == 0) { cpv = 1.0 * gcp; ego = ego_prev; }
+                else {
+                    double ttc = dcp / rv;
+                    if (ttc == 0.0) { e->status |= ST_TTC_ZERO; ego = 1.0; } /* Python raises; measure-zero */
+                    else ego = fmin(1.0, 0.15 / ttc); /* UTL:319 min(1, 0.15/ttc); may be negative */
+                    cpv = 0.5 * ego + 0.5 * gcp;
+                }
+            } else { ego = 0.0; cpv = 0.5 * 0.0 + 0.5 * gcp; }
+            ego_prev = ego;
+            cp[ne] = cpv;
+            if (ne == 0 || ego > ego_max) ego_max = ego;
+            ++ne;
+        }
+        e->n_entries = ne;
+        if (ne == 0) { /* ENV:862-876 */
+            e->collision_prob = 0.0; e->ego_score_cp = 0.0;
+        } else { /* ENV:878-905 */
+            e->ego_score_cp = ego_max;
+            int idx[CNO_MAX_TRACKS];
+            for (int i = 0; i < ne; ++i) idx[i] = i;
+            for (int i = 1; i < ne; ++i) { /* stable, descending (sorted(..., reverse=True)) */
+                int q = idx[i]; int j = i - 1;
+                while (j >= 0 && cp[idx[j]] < cp[q]) { idx[j + 1] = idx[j]; --j; }
+                idx[j + 1] = q;
+            }
+            int first = ne > K ? ne - K : 0; /* [-K:] keeps the K lowest when ne > K */
+            e->collision_prob = cp[idx[first]];
+            int kk = 0;
+            for (int i = first; i < ne; ++i, ++kk) {
+                track_t* t = &e->tracks[idx[i]];
+                feat[4 * kk] = t->pose.x; feat[4 * kk + 1] = t->pose.y;
+                feat[4 * kk + 2] = t->vel.x; feat[4 * kk + 3] = t->vel.y;
+                topk_idx[kk] = idx[i];
+            }
+        }
+        /* ENV:990-996 */
+        e->agent_dq[0] = e->agent_dq[1]; e->agent_dq_len = 1;
+        for (int i = 0; i < e->ntracks; ++i) e->tracks[i].t = now;
+    }
+    /* ENV:998-1005 safety counters */
+    for (int j = 0; j < nconf; ++j)
+        if (conf[j].type == TY_O && conf[j].dist < 0.140) { e->ego_viol += 1; break; }
+    if (e->ego_score_cp > 0.4) e->social_viol += 1;
+
+    /* ENV:1011-1023 done */
+    if (!e->done) {
+        double mn = scan[0];
+        for (int i = 1; i < n; ++i) if (scan[i] < mn) mn = scan[i];
+        if (mn < c->min_scan_range) e->done = 1;
+        if (in_box(px, py, c->goal_x, c->goal_y, c->goal_eps)) e->done = 1;
+        if (step_counter >= c->max_steps) e->done = 1;
+    }
+    /* ENV:1025-1042 observation */
+    for (int i = 0; i < n; ++i) state[i] = scan[i];
+    state[n] = heading;
+    state[n + 1] = distance_to_goal;
+    state[n + 2] = cno_py_round(px, 3);
+    state[n + 3] = cno_py_round(py, 3);
+    state[n + 4] = cno_py_round(yaw, 3);
+    state[n + 5] = cno_py_round(agent_vel_x, 3);
+    state[n + 6] = cno_py_round(agent_vel_y, 3);
+    for (int i = 0; i < s->D; ++i) state[i] = cno_np_around(state[i], 3);
+    *done_out = e->done;
+    free(conf);
+    free(scan);
+}
+
+/* ENV:1046-1162 */
+static double env_compute_reward(const cno_sim* s, env_t* e, const double* state, double px, double py, int done)
+{
+    const cno_config* c = &s->cfg;
+    const int n = s->n;
+    double cur_head = state[n], cur_dist = state[n + 1];
+    double dd = cur_dist - e->prev_dist, hd = cur_head - e->prev_head;
+    int step_reward = -2, htg = 0, dtg = 0, wp = 0;
+    if (dd > 0) dtg = 0;
+    if (dd < 0) dtg = 1;
+    double ph = e->prev_head;
+    if (hd > 0) {
+        if (cur_head > 0 && ph < 0) htg = 1;
+        if (cur_head < 0 && ph < 0) htg = 1;
+        if (cur_head < 0 && ph > 0) htg = 1;
+        if (cur_head > 0 && ph > 0) htg = 0;
+    }
+    if (hd < 0) {
+        if (cur_head < 0 && ph > 0) htg = 1;
+        if (cur_head > 0 && ph > 0) htg = 1;
+        if (cur_head > 0 && ph < 0) htg = 1;
+        if (cur_head < 0 && ph < 0) htg = 0;
+    }
+    if (in_box(px, py, e->wpx, e->wpy, c->goal_eps)) { /* ENV:1109-1125 */
+        waypoint_refresh(s, e, px, py);
+        wp = 200;
+        if (in_box(e->wpx, e->wpy, c->goal_x, c->goal_y, c->goal_eps)) { e->wpx = c->goal_x; e->wpy = c->goal_y; }
+    }
+    double reward = (double)(step_reward + dtg + htg + wp);
+    e->prev_dist = cur_dist;
+    e->prev_head = cur_head;
+    if (done) {
+        if (in_box(px, py, c->goal_x, c->goal_y, c->goal_eps)) { e->ep_failure = 0; e->ep_success = 1; reward = 200 + reward; }
+        else { e->ep_failure = 1; e->ep_success = 0; reward = -200 + reward; }
+    }
+    return reward;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Env.reset / Env.step flows
+ * ---------------------------------------------------------------------------------------- */
+
+static void env_init(const cno_sim* s, env_t* e)
+{
+    const cno_config* c = &s->cfg;
+    /* Env.__init__ (ENV:43-168) */
+    e->wpx = c->goal_x; e->wpy = c->goal_y;
+    e->prev_dist = 0.0; e->prev_head = 0.0;
+    e->done = 0;
+    e->agent_dq_len = 0; e->agent_vel_timestep = 0.0;
+    e->bb = 0.0;
+    e->ntracks = 0;
+    e->ego_score_cp = 0.0; e->collision_prob = 0.0;
+    e->ego_viol = e->social_viol = e->obst_steps = 0;
+    e->ep_success = e->ep_failure = 0;
+    e->ep_step = 0; e->ep_return = 0.0; e->last_return = 0.0;
+    e->clock = 0.0; e->crowd_ms = 0;
+    e->status = 0;
+}
+
+/* Env.reset (ENV:1227-1263) followed by the trainer's sleep and `env.done = False` (TRAIN:113-116) */
+static void env_reset_flow(const cno_sim* s, env_t* e, int64_t gid, double* obs)
+{
+    const cno_config* c = &s->cfg;
+    int32_t idx[64];
+    int done;
+    sim_reset(s, e);
+    e->clock += (double)c->scan_latency_ms / 1000.0; /* wait_for_message('scan') */
+    sim_advance(s, e, gid, c->scan_latency_ms);
+    raycast_impl(c, s->lidar_c, s->lidar_s, e->rx, e->ry, e->ryaw, e->ped_p, c->n_peds, e->ranges);
+    e->prev_dist = dist3(e->rx, e->ry, e->wpx, e->wpy);           /* ENV:1243 (unrounded) */
+    e->prev_head = heading_to_goal(c, e, e->rx, e->ry, e->ryaw);   /* ENV:1244 */
+    env_get_state(s, e, e->ranges, e->rx, e->ry, e->ryaw, e->rv, e->rw, 0, e->clock, obs, &done, idx);
+    e->social_viol = 0; e->ego_viol = 0; e->obst_steps = 0;       /* ENV:1260-1262 */
+    e->clock += (double)c->settle_ms / 1000.0;                     /* TRAIN:114 time.sleep(0.1) */
+    sim_advance(s, e, gid, c->settle_ms);
+    e->done = 0;                                                   /* TRAIN:116 */
+    e->ep_step = 0; e->ep_return = 0.0;
+}
+
+/* Env.step (ENV:1164-1225), continuous mode */
+static void env_step_flow(const cno_sim* s, env_t* e, int64_t gid, double v, double w, int step_counter,
+                          double* obs, double* reward, int* done, int32_t* topk_idx)
+{
+    const cno_config* c = &s->cfg;
+    double t0 = e->clock;
+    e->rv = v; e->rw = w;                                          /* pub_cmd_vel.publish (ENV:1200) */
+    e->clock += (double)c->dt_ms / 1000.0;                         /* time.sleep(0.15) (ENV:1201) */
+    sim_advance(s, e, gid, c->dt_ms);
+    double end_timestep = e->clock - t0;                           /* ENV:1202 */
+    v2 p = { cno_py_round(e->rx, 3), cno_py_round(e->ry, 3) };   /* ENV:1208 */
+    if (e->agent_dq_len < 2) e->agent_dq[e->agent_dq_len++] = p;
+    else { e->agent_dq[0] = e->agent_dq[1]; e->agent_dq[1] = p; }
+    e->agent_vel_timestep = end_timestep;                          /* ENV:1209 */
+    e->clock += (double)c->scan_latency_ms / 1000.0;               /* wait_for_message('scan') (ENV:1218) */
+    sim_advance(s, e, gid, c->scan_latency_ms);
+    raycast_impl(c, s->lidar_c, s->lidar_s, e->rx, e->ry, e->ryaw, e->ped_p, c->n_peds, e->ranges);
+    env_get_state(s, e, e->ranges, e->rx, e->ry, e->ryaw, e->rv, e->rw, step_counter, e->clock, obs, done, topk_idx);
+    *reward = env_compute_reward(s, e, obs, e->rx, e->ry, *done);
+    if (*done) { e->rv = 0.0; e->rw = 0.0; }                      /* pub_cmd_vel.publish(Twist()) (ENV:1160) */
+}
+
+/* ------------------------------------------------------------------------------------------
+ * public API
+ * ---------------------------------------------------------------------------------------- */
+
+static void default_ped_init(const cno_sim* s, int env, double* xy)
+{
+    const cno_config* c = &s->cfg;
+    int64_t gid = c->env_index_base + env;
+    double lo = -c->room_half + 0.1, span = 2.0 * c->room_half - 0.2;
+    for (int i = 0; i < c->n_peds; ++i) {
+        uint32_t att = 0;
+        for (;;) {
+            double x = fma(span, cno_rng_u01(c->seed, gid, 2u, (uint32_t)i, 2 * att), lo);
+            double y = fma(span, cno_rng_u01(c->seed, gid, 2u, (uint32_t)i, 2 * att + 1), lo);
+            double dx = x - c->spawn_x, dy = y - c->spawn_y;
+            ++att;
+            if (fma(dx, dx, dy * dy) >= 0.16 || att > 1000) { xy[2 * i] = x; xy[2 * i + 1] = y; break; }
+        }
+    }
+}
+
+int cno_create(const cno_config* cfg, cno_sim** out)
+{
+    if (!cfg || !out) return -1;
+    if (cfg->n_envs < 1 || cfg->n_peds < 0 || cfg->n_rays < 8 || cfg->k_obstacles < 1 || cfg->k_obstacles > 16)
+        return -2;
+    if (cfg->ped_cycle_ms < 1 || cfg->dt_ms < 1) return -2;
+    cno_sim* s = (cno_sim*)calloc(1, sizeof(cno_sim));
+    s->cfg = *cfg;
+    s->n = cfg->n_rays - 1;
+    s->D = s->n + 7 + 4 * cfg->k_obstacles;
+    int R = cfg->n_rays, P = cfg->n_peds;
+    s->lidar_c = (double*)malloc(sizeof(double) * 2 * R);
+    s->lidar_s = s->lidar_c + R;
+    double step = cfg->lidar_span / (double)(R - 1);
+    for (int k = 0; k < R; ++k) cno_det_sincos((double)k * step, &s->lidar_s[k], &s->lidar_c[k]);
+    poly_tables(s->poly_c, s->poly_s);
+    s->envs = (env_t*)calloc((size_t)cfg->n_envs, sizeof(env_t));
+    for (int e = 0; e < cfg->n_envs; ++e) {
+        env_t* en = &s->envs[e];
+        en->ped_p = (double*)calloc((size_t)(8 * (P > 0 ? P : 1)) + R, sizeof(double));
+        en->ped_v = en->ped_p + 2 * P;
+        en->ped_init = en->ped_v + 2 * P;
+        en->ped_preset = en->ped_init + 2 * P;
+        en->ranges = en->ped_preset + 2 * P;
+        env_init(s, en);
+        default_ped_init(s, e, en->ped_init);
+        en->rx = cfg->spawn_x; en->ry = cfg->spawn_y; en->ryaw = cfg->spawn_yaw;
+        memcpy(en->ped_p, en->ped_init, sizeof(double) * 2 * P);
+    }
+    *out = s;
+    return 0;
+}
+
+void cno_destroy(cno_sim* s)
+{
+    if (!s) return;
+    for (int e = 0; e < s->cfg.n_envs; ++e) free(s->envs[e].ped_p);
+    free(s->envs);
+    free(s->lidar_c);
+    free(s);
+}
+
+int cno_obs_dim(const cno_sim* s) { return s->D; }
+
+int cno_set_ped_init(cno_sim* s, const double* xy)
+{
+    int P = s->cfg.n_peds;
+    for (int e = 0; e < s->cfg.n_envs; ++e) {
+        memcpy(s->envs[e].ped_init, xy + (size_t)e * 2 * P, sizeof(double) * 2 * P);
+        memcpy(s->envs[e].ped_p, s->envs[e].ped_init, sizeof(double) * 2 * P);
+    }
+    return 0;
+}
+
+int cno_get_ped_init(const cno_sim* s, double* xy)
+{
+    int P = s->cfg.n_peds;
+    for (int e = 0; e < s->cfg.n_envs; ++e) memcpy(xy + (size_t)e * 2 * P, s->envs[e].ped_init, sizeof(double) * 2 * P);
+    return 0;
+}
+
+int cno_set_ped_preset_vel(cno_sim* s, const double* vxy)
+{
+    int P = s->cfg.n_peds;
+    for (int e = 0; e < s->cfg.n_envs; ++e)
+        memcpy(s->envs[e].ped_preset, vxy + (size_t)e * 2 * P, sizeof(double) * 2 * P);
+    return 0;
+}
+
+int cno_set_num_threads(int n)
+{
+    g_threads = n < 1 ? 1 : n;
+    return g_threads;
+}
+
+int cno_reset(cno_sim* s, const uint8_t* mask, double* obs)
+{
+    int N = s->cfg.n_envs;
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+    for (int e = 0; e < N; ++e) {
+        if (mask && !mask[e]) continue;
+        env_reset_flow(s, &s->envs[e], s->cfg.env_index_base + e, obs + (size_t)e * s->D);
+    }
+    return 0;
+}
+
+int cno_step(cno_sim* s, const double* action, const int32_t* step_counter, int auto_reset, double* obs,
+             double* final_obs, double* reward, uint8_t* done, int32_t* topk_idx)
+{
+    int N = s->cfg.n_envs, K = s->cfg.k_obstacles;
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+    for (int e = 0; e < N; ++e) {
+        env_t* en = &s->envs[e];
+        int64_t gid = s->cfg.env_index_base + e;
+        int32_t idx_local[16];
+        int32_t* idx = topk_idx ? topk_idx + (size_t)e * K : idx_local;
+        double* o = obs + (size_t)e * s->D;
+        double r; int d;
+        en->ep_step += 1;
+        int sc = step_counter ? step_counter[e] : en->ep_step;
+        env_step_flow(s, en, gid, action[2 * e], action[2 * e + 1], sc, o, &r, &d, idx);
+        en->ep_return += r;
+        reward[e] = r;
+        done[e] = (uint8_t)d;
+        if (final_obs) memcpy(final_obs + (size_t)e * s->D, o, sizeof(double) * s->D);
+        if (d) {
+            en->last_return = en->ep_return;
+            if (auto_reset) env_reset_flow(s, en, gid, o);
+        }
+    }
+    return 0;
+}
+
+int cno_get_counters(const cno_sim* s, int32_t* out)
+{
+    for (int e = 0; e < s->cfg.n_envs; ++e) {
+        const env_t* en = &s->envs[e];
+        out[6 * e + 0] = en->ego_viol; out[6 * e + 1] = en->social_viol; out[6 * e + 2] = en->obst_steps;
+        out[6 * e + 3] = en->ep_step; out[6 * e + 4] = en->ep_success; out[6 * e + 5] = en->ep_failure;
+    }
+    return 0;
+}
+
+int cno_get_returns(const cno_sim* s, double* out)
+{
+    for (int e = 0; e < s->cfg.n_envs; ++e) out[e] = s->envs[e].last_return;
+    return 0;
+}
+
+int cno_get_sim_state(const cno_sim* s, int env, double* robot5, double* ped_p, double* ped_v, double* ranges)
+{
+    const env_t* e = &s->envs[env];
+    int P = s->cfg.n_peds;
+    if (robot5) { robot5[0] = e->rx; robot5[1] = e->ry; robot5[2] = e->ryaw; robot5[3] = e->rv; robot5[4] = e->rw; }
+    if (ped_p) memcpy(ped_p, e->ped_p, sizeof(double) * 2 * P);
+    if (ped_v) memcpy(ped_v, e->ped_v, sizeof(double) * 2 * P);
+    if (ranges) memcpy(ranges, e->ranges, sizeof(double) * s->cfg.n_rays);
+    return 0;
+}
+
+int cno_get_debug(const cno_sim* s, int env, cno_debug* o)
+{
+    const env_t* e = &s->envs[env];
+    memset(o, 0, sizeof(*o));
+    o->n_confirmed = e->n_confirmed; o->n_tracks = e->ntracks; o->n_entries = e->n_entries; o->status = e->status;
+    o->bb = e->bb; o->collision_prob = e->collision_prob; o->ego_score = e->ego_score_cp;
+    o->wpx = e->wpx; o->wpy = e->wpy;
+    for (int i = 0; i < e->ntracks; ++i) {
+        const track_t* t = &e->tracks[i];
+        o->track_pose[i][0] = t->pose.x; o->track_pose[i][1] = t->pose.y;
+        o->track_dist[i] = t->dist; o->track_speed[i] = t->speed;
+        o->track_vel[i][0] = t->vel.x; o->track_vel[i][1] = t->vel.y;
+        o->track_t[i] = t->t; o->track_dqlen[i] = t->dq_len;
+    }
+    return 0;
+}
+
+/* Golden replay: everything Gazebo/ROS supplied comes from the caller. */
+int cno_ext_call(cno_sim* s, int env, const cno_ext_in* in, const double* ranges, double* obs, double* reward,
+                 uint8_t* done, int32_t* topk_idx)
+{
+    env_t* e = &s->envs[env];
+    const cno_config* c = &s->cfg;
+    int32_t idx_local[16];
+    int32_t* idx = topk_idx ? topk_idx : idx_local;
+    int d = 0;
+    if (in->is_reset) {
+        e->prev_dist = dist3(in->px, in->py, e->wpx, e->wpy);
+        e->prev_head = heading_to_goal(c, e, in->px, in->py, in->yaw);
+        env_get_state(s, e, ranges, in->px, in->py, in->yaw, in->v, in->w, 0, in->now, obs, &d, idx);
+        e->social_viol = 0; e->ego_viol = 0; e->obst_steps = 0;
+        if (reward) *reward = 0.0;
+        if (done) *done = (uint8_t)d;
+        return 0;
+    }
+    v2 p = { cno_py_round(in->deque_x, 3), cno_py_round(in->deque_y, 3) };
+    if (e->agent_dq_len < 2) e->agent_dq[e->agent_dq_len++] = p;
+    else { e->agent_dq[0] = e->agent_dq[1]; e->agent_dq[1] = p; }
+    e->agent_vel_timestep = in->end_timestep;
+    env_get_state(s, e, ranges, in->px, in->py, in->yaw, in->v, in->w, in->step_counter, in->now, obs, &d, idx);
+    double r = env_compute_reward(s, e, obs, in->px, in->py, d);
+    if (reward) *reward = r;
+    if (done) *done = (uint8_t)d;
+    return 0;
+}
+
+void cno_ext_set_done(cno_sim* s, int env, int done) { s->envs[env].done = done; }
+
+/* ------------------------------------------------------------------------------------------
+ * Simulator-only entry points for oracle/harness (which plays Gazebo for the reference's Python)
+ * ---------------------------------------------------------------------------------------- */
+int cno_hsim_reset(cno_sim* s, int env) { sim_reset(s, &s->envs[env]); return 0; }
+
+int cno_hsim_advance(cno_sim* s, int env, int32_t ms, double v, double w)
+{
+    env_t* e = &s->envs[env];
+    e->rv = v; e->rw = w;
+    sim_advance(s, e, s->cfg.env_index_base + env, ms);
+    return 0;
+}
+
+int cno_hsim_scan(cno_sim* s, int env, double* ranges)
+{
+    env_t* e = &s->envs[env];
+    raycast_impl(&s->cfg, s->lidar_c, s->lidar_s, e->rx, e->ry, e->ryaw, e->ped_p, s->cfg.n_peds, ranges);
+    return 0;
+}
+
+int cno_set_robot(cno_sim* s, int env, double x, double y, double yaw)
+{
+    env_t* e = &s->envs[env];
+    e->rx = x; e->ry = y; e->ryaw = yaw;
+    return 0;
+}

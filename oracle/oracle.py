@@ -1,0 +1,240 @@
+"""ctypes binding of oracle/_build/libcn_oracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+The product package never does (tests/test_layout.py greps for that).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "libcn_oracle.so")
+MAX_TRACKS = 64
+
+
+class CnoConfig(C.Structure):
+    _fields_ = [
+        ("n_envs", C.c_int32), ("n_peds", C.c_int32), ("n_rays", C.c_int32), ("k_obstacles", C.c_int32),
+        ("max_steps", C.c_int32), ("ped_mode", C.c_int32), ("dt_ms", C.c_int32), ("scan_latency_ms", C.c_int32),
+        ("settle_ms", C.c_int32), ("ped_cycle_ms", C.c_int32), ("ped_stagger_ms", C.c_int32), ("reserved0", C.c_int32),
+        ("env_index_base", C.c_int64), ("seed", C.c_uint64),
+        ("room_half", C.c_double), ("ped_radius", C.c_double), ("ped_vmax", C.c_double),
+        ("robot_clearance", C.c_double), ("lidar_min", C.c_double), ("lidar_max", C.c_double),
+        ("lidar_span", C.c_double), ("lidar_offset_x", C.c_double), ("max_scan_range", C.c_double),
+        ("min_scan_range", C.c_double), ("goal_x", C.c_double), ("goal_y", C.c_double),
+        ("start_x", C.c_double), ("start_y", C.c_double), ("spawn_x", C.c_double), ("spawn_y", C.c_double),
+        ("spawn_yaw", C.c_double), ("waypoint_radius", C.c_double), ("goal_eps", C.c_double),
+    ]
+
+
+class CnoExtIn(C.Structure):
+    _fields_ = [
+        ("deque_x", C.c_double), ("deque_y", C.c_double), ("end_timestep", C.c_double),
+        ("px", C.c_double), ("py", C.c_double), ("yaw", C.c_double), ("v", C.c_double), ("w", C.c_double),
+        ("now", C.c_double), ("step_counter", C.c_int32), ("is_reset", C.c_int32),
+    ]
+
+
+class CnoDebug(C.Structure):
+    _fields_ = [
+        ("n_confirmed", C.c_int32), ("n_tracks", C.c_int32), ("n_entries", C.c_int32), ("status", C.c_int32),
+        ("bb", C.c_double), ("collision_prob", C.c_double), ("ego_score", C.c_double),
+        ("wpx", C.c_double), ("wpy", C.c_double),
+        ("track_pose", C.c_double * 2 * MAX_TRACKS), ("track_dist", C.c_double * MAX_TRACKS),
+        ("track_speed", C.c_double * MAX_TRACKS), ("track_vel", C.c_double * 2 * MAX_TRACKS),
+        ("track_t", C.c_double * MAX_TRACKS), ("track_dqlen", C.c_int32 * MAX_TRACKS),
+    ]
+
+
+# Reference defaults (SURVEY.md appendix B cites every value).
+DEFAULTS = dict(
+    n_envs=1, n_peds=20, n_rays=360, k_obstacles=8, max_steps=1000, ped_mode=0, dt_ms=150, scan_latency_ms=10,
+    settle_ms=100, ped_cycle_ms=0, ped_stagger_ms=100, reserved0=0, env_index_base=0, seed=1234,
+    room_half=1.40, ped_radius=0.0505, ped_vmax=0.2, robot_clearance=0.09, lidar_min=0.08, lidar_max=0.60,
+    lidar_span=6.28, lidar_offset_x=-0.032, max_scan_range=0.6, min_scan_range=0.12, goal_x=-1.0, goal_y=1.0,
+    start_x=0.75, start_y=-0.75, spawn_x=1.0, spawn_y=-1.0, spawn_yaw=3.14, waypoint_radius=0.3, goal_eps=0.20,
+)
+
+
+def make_config(**kw):
+    d = dict(DEFAULTS)
+    for k, v in kw.items():
+        if k not in d:
+            raise KeyError(k)
+        d[k] = v
+    if not d["ped_cycle_ms"]:
+        d["ped_cycle_ms"] = max(100, 100 * d["n_peds"])  # CROWD:128-144: 0.1 s per obstacle per cycle
+    return CnoConfig(**d)
+
+
+def build(force=False):
+    if force or not os.path.exists(_LIB_PATH) or (
+            os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(os.path.join(_HERE, f))
+                                              for f in ("cn_oracle.c", "cn_oracle.h", "Makefile"))):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = C.CDLL(_LIB_PATH)
+        dp = C.POINTER(C.c_double)
+        L.cno_create.argtypes = [C.POINTER(CnoConfig), C.POINTER(C.c_void_p)]
+        L.cno_destroy.argtypes = [C.c_void_p]
+        L.cno_obs_dim.argtypes = [C.c_void_p]
+        L.cno_set_ped_init.argtypes = [C.c_void_p, dp]
+        L.cno_get_ped_init.argtypes = [C.c_void_p, dp]
+        L.cno_set_ped_preset_vel.argtypes = [C.c_void_p, dp]
+        L.cno_reset.argtypes = [C.c_void_p, C.c_void_p, dp]
+        L.cno_step.argtypes = [C.c_void_p, dp, C.c_void_p, C.c_int, dp, C.c_void_p, dp, C.c_void_p, C.c_void_p]
+        L.cno_get_counters.argtypes = [C.c_void_p, C.c_void_p]
+        L.cno_get_returns.argtypes = [C.c_void_p, dp]
+        L.cno_get_sim_state.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.cno_get_debug.argtypes = [C.c_void_p, C.c_int, C.POINTER(CnoDebug)]
+        L.cno_set_num_threads.argtypes = [C.c_int]
+        L.cno_ext_call.argtypes = [C.c_void_p, C.c_int, C.POINTER(CnoExtIn), dp, dp, dp, C.c_void_p, C.c_void_p]
+        L.cno_ext_set_done.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.cno_py_round.argtypes = [C.c_double, C.c_int]; L.cno_py_round.restype = C.c_double
+        L.cno_np_around.argtypes = [C.c_double, C.c_int]; L.cno_np_around.restype = C.c_double
+        L.cno_det_sincos.argtypes = [C.c_double, dp, dp]
+        L.cno_scan_sanitize.argtypes = [dp, C.c_int, C.c_double, dp]
+        L.cno_scan_to_points.argtypes = [dp, C.c_int, C.c_double, C.c_double, C.c_double, dp]
+        L.cno_waypoint.argtypes = [C.c_double] * 5 + [dp]
+        L.cno_collision_point.argtypes = [C.c_double] * 7 + [dp]
+        L.cno_iou.argtypes = [C.c_double] * 5; L.cno_iou.restype = C.c_double
+        L.cno_bbox_size.argtypes = [dp, C.c_int]; L.cno_bbox_size.restype = C.c_double
+        L.cno_estimate_num_obs_scans.argtypes = [C.c_double] * 3
+        L.cno_raycast.argtypes = [C.POINTER(CnoConfig), C.c_double, C.c_double, C.c_double, dp, C.c_int, dp]
+        L.cno_rng_u01.argtypes = [C.c_uint64, C.c_int64, C.c_uint32, C.c_uint32, C.c_uint32]
+        L.cno_rng_u01.restype = C.c_double
+        L.cno_hsim_reset.argtypes = [C.c_void_p, C.c_int]
+        L.cno_hsim_advance.argtypes = [C.c_void_p, C.c_int, C.c_int32, C.c_double, C.c_double]
+        L.cno_hsim_scan.argtypes = [C.c_void_p, C.c_int, dp]
+        L.cno_set_robot.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double]
+        _lib = L
+    return _lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class Oracle:
+    """Batched CPU oracle: same call shapes as the product's VecEnv, float64 throughout."""
+
+    def __init__(self, cfg=None, **kw):
+        self.cfg = cfg if isinstance(cfg, CnoConfig) else make_config(**(cfg or {}), **kw)
+        self.L = lib()
+        self.h = C.c_void_p()
+        rc = self.L.cno_create(C.byref(self.cfg), C.byref(self.h))
+        if rc != 0:
+            raise RuntimeError("cno_create failed: %d" % rc)
+        self.N, self.P, self.R, self.K = (self.cfg.n_envs, self.cfg.n_peds, self.cfg.n_rays, self.cfg.k_obstacles)
+        self.D = self.L.cno_obs_dim(self.h)
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.L.cno_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def set_ped_init(self, xy):
+        xy = np.ascontiguousarray(xy, dtype=np.float64).reshape(self.N, self.P, 2)
+        self.L.cno_set_ped_init(self.h, _dp(xy))
+
+    def get_ped_init(self):
+        xy = np.zeros((self.N, self.P, 2))
+        self.L.cno_get_ped_init(self.h, _dp(xy))
+        return xy
+
+    def set_ped_preset_vel(self, v):
+        v = np.ascontiguousarray(v, dtype=np.float64).reshape(self.N, self.P, 2)
+        self.L.cno_set_ped_preset_vel(self.h, _dp(v))
+
+    def reset(self, mask=None):
+        obs = np.zeros((self.N, self.D))
+        m = None
+        if mask is not None:
+            m = np.ascontiguousarray(mask, dtype=np.uint8)
+        self.L.cno_reset(self.h, m.ctypes.data if m is not None else None, _dp(obs))
+        return obs
+
+    def step(self, action, step_counter=None, auto_reset=False, want_final=False):
+        a = np.ascontiguousarray(action, dtype=np.float64).reshape(self.N, 2)
+        obs = np.zeros((self.N, self.D))
+        fin = np.zeros((self.N, self.D)) if want_final else None
+        rew = np.zeros(self.N)
+        done = np.zeros(self.N, dtype=np.uint8)
+        idx = np.zeros((self.N, self.K), dtype=np.int32)
+        sc = None
+        if step_counter is not None:
+            sc = np.ascontiguousarray(step_counter, dtype=np.int32).reshape(self.N)
+        self.L.cno_step(self.h, _dp(a), sc.ctypes.data if sc is not None else None, int(auto_reset), _dp(obs),
+                        fin.ctypes.data if fin is not None else None, _dp(rew), done.ctypes.data, idx.ctypes.data)
+        if want_final:
+            return obs, rew, done, idx, fin
+        return obs, rew, done, idx
+
+    def counters(self):
+        out = np.zeros((self.N, 6), dtype=np.int32)
+        self.L.cno_get_counters(self.h, out.ctypes.data)
+        return out
+
+    def returns(self):
+        out = np.zeros(self.N)
+        self.L.cno_get_returns(self.h, _dp(out))
+        return out
+
+    def sim_state(self, env=0):
+        robot = np.zeros(5); pp = np.zeros((self.P, 2)); pv = np.zeros((self.P, 2)); rg = np.zeros(self.R)
+        self.L.cno_get_sim_state(self.h, env, robot.ctypes.data, pp.ctypes.data, pv.ctypes.data, rg.ctypes.data)
+        return robot, pp, pv, rg
+
+    def debug(self, env=0):
+        d = CnoDebug()
+        self.L.cno_get_debug(self.h, env, C.byref(d))
+        n = d.n_tracks
+        return dict(n_confirmed=d.n_confirmed, n_tracks=n, n_entries=d.n_entries, status=d.status, bb=d.bb,
+                    collision_prob=d.collision_prob, ego_score=d.ego_score, wp=(d.wpx, d.wpy),
+                    track_pose=np.array(d.track_pose)[:n].copy(), track_dist=np.array(d.track_dist)[:n].copy(),
+                    track_speed=np.array(d.track_speed)[:n].copy(), track_vel=np.array(d.track_vel)[:n].copy(),
+                    track_t=np.array(d.track_t)[:n].copy(), track_dqlen=np.array(d.track_dqlen)[:n].copy())
+
+    # ---- harness-facing simulator access -------------------------------------------------
+    def hsim_reset(self, env=0):
+        self.L.cno_hsim_reset(self.h, env)
+
+    def hsim_advance(self, ms, v, w, env=0):
+        self.L.cno_hsim_advance(self.h, env, int(ms), float(v), float(w))
+
+    def hsim_scan(self, env=0):
+        rg = np.zeros(self.R)
+        self.L.cno_hsim_scan(self.h, env, _dp(rg))
+        return rg
+
+    # ---- golden replay --------------------------------------------------------------------
+    def ext_call(self, env, ranges, **kw):
+        inp = CnoExtIn(**kw)
+        rg = np.ascontiguousarray(ranges, dtype=np.float64)
+        obs = np.zeros(self.D); rew = C.c_double(0.0); done = C.c_uint8(0)
+        idx = np.zeros(self.K, dtype=np.int32)
+        self.L.cno_ext_call(self.h, env, C.byref(inp), _dp(rg), _dp(obs), C.byref(rew), C.byref(done),
+                            idx.ctypes.data)
+        return obs, rew.value, bool(done.value), idx
+
+    def ext_set_done(self, env, done):
+        self.L.cno_ext_set_done(self.h, env, int(done))
+
+
+def set_num_threads(n):
+    return lib().cno_set_num_threads(int(n))
