@@ -1,0 +1,121 @@
+"""The CPU oracle (oracle/cn_oracle.c) against golden vectors produced by the REFERENCE's own Python
+(oracle/make_goldens.py).  Bit-exact: observations, rewards, done flags, safety counters, the track
+table and the CP scalars.  CPU only."""
+import numpy as np
+import pytest
+
+from conftest import load_seq
+
+SEQS = ["train20", "dense100", "eval60", "k4"]
+IN_KEYS = ("deque_x", "deque_y", "end_timestep", "px", "py", "yaw", "v", "w", "now", "step_counter", "is_reset")
+
+
+@pytest.mark.parametrize("name", SEQS)
+def test_sequence_replay_bit_exact(oracle_mod, name):
+    z, kw = load_seq(name)
+    o = oracle_mod.Oracle(n_envs=1, **kw)
+    ncalls = len(z["now"])
+    over_k = 0
+    for i in range(ncalls):
+        inp = {k: (int(z[k][i]) if k in ("step_counter", "is_reset") else float(z[k][i])) for k in IN_KEYS}
+        obs, r, d, idx = o.ext_call(0, z["ranges"][i], **inp)
+        if inp["is_reset"]:
+            o.ext_set_done(0, False)  # TRAIN:116
+        else:
+            assert r == z["reward"][i], (name, i)
+            assert d == bool(z["done"][i]), (name, i)
+        assert np.array_equal(obs, z["obs"][i]), (name, i, np.nonzero(obs != z["obs"][i])[0][:8])
+        dbg = o.debug(0)
+        n = int(z["n_tracks"][i])
+        assert dbg["n_tracks"] == n, (name, i)
+        assert np.array_equal(dbg["track_pose"], z["track_pose"][i][:n])
+        assert np.array_equal(dbg["track_dist"], z["track_dist"][i][:n])
+        assert np.array_equal(dbg["track_speed"], z["track_speed"][i][:n])
+        assert np.array_equal(dbg["track_vel"], z["track_vel"][i][:n])
+        assert dbg["collision_prob"] == z["collision_prob"][i]
+        assert dbg["ego_score"] == z["ego_score"][i]
+        assert dbg["wp"] == tuple(z["wp"][i])
+        assert dbg["bb"] == z["bb"][i]
+        assert tuple(o.counters()[0][:3]) == tuple(z["counters"][i])
+        over_k += n > o.K
+    if name in ("dense100", "eval60", "k4"):
+        assert over_k > 0  # the "keep the K lowest" branch of ENV:882-883 is exercised
+
+
+@pytest.mark.parametrize("name", SEQS)
+def test_full_simulation_reproduces_reference_run(oracle_mod, name):
+    """The oracle's own simulator + Env logic, driven only by the recorded actions, reproduces the
+    run the reference made on top of the same simulator (it differs from the replay above in that
+    the yaw is not passed through a quaternion)."""
+    z, kw = load_seq(name)
+    o = oracle_mod.Oracle(n_envs=1, **kw)
+    o.set_ped_init(z["ped_init"])
+    for i in range(len(z["now"])):
+        if z["is_reset"][i]:
+            obs = o.reset()[0]
+        else:
+            obs, r, d, _ = o.step(z["action"][i][None, :], step_counter=[int(z["step_counter"][i])])
+            obs = obs[0]
+            assert r[0] == z["reward"][i] and bool(d[0]) == bool(z["done"][i]), (name, i)
+        assert np.array_equal(obs, z["obs"][i]), (name, i)
+
+
+def test_function_level_goldens(oracle_mod):
+    import ctypes as C
+    import os
+    from conftest import GOLDEN
+    L = oracle_mod.lib()
+    g = np.load(os.path.join(GOLDEN, "func.npz"))
+    dp = C.POINTER(C.c_double)
+
+    def p(a):
+        return a.ctypes.data_as(dp)
+
+    # A5
+    for i in range(len(g["scan_in"])):
+        out = np.zeros(359)
+        L.cno_scan_sanitize(p(np.ascontiguousarray(g["scan_in"][i])), 360, 0.6, p(out))
+        assert np.array_equal(out, g["scan_out"][i])
+    # A6 + A10
+    for i in range(len(g["pts_scan"])):
+        out = np.zeros((359, 2))
+        L.cno_scan_to_points(p(np.ascontiguousarray(g["pts_scan"][i])), 360, g["pts_pose"][i, 0], g["pts_pose"][i, 1],
+                             g["pts_yaw"][i], p(out))
+        assert np.array_equal(out, g["pts_out"][i])
+        assert L.cno_bbox_size(p(out), 359) == g["bb_out"][i]
+    # A9
+    for i in range(len(g["wp_agent"])):
+        out = np.zeros(2)
+        L.cno_waypoint(*g["wp_agent"][i], *g["wp_goal"][i], 0.3, p(out))
+        assert np.array_equal(out, g["wp_out"][i]), i
+    # the survey's spot values
+    out = np.zeros(2)
+    L.cno_waypoint(0.75, -0.75, -1.0, 1.0, 0.3, p(out))
+    assert np.allclose(out, [0.53787, -0.53787], atol=2e-4)
+    L.cno_waypoint(0.9, 0.9, 1.0, 1.0, 0.3, p(out))
+    assert tuple(out) == (-1.0, 1.0)  # goal inside -> x sign flipped (UTL:310-312)
+    # A22
+    n_none = 0
+    for i in range(len(g["cp_a0"])):
+        d = C.c_double(0.0)
+        has = L.cno_collision_point(*g["cp_a0"][i], *g["cp_a1"][i], *g["cp_ob"][i], 0.178, C.byref(d))
+        if np.isnan(g["cp_out"][i]):
+            assert has == 0, i
+            n_none += 1
+        else:
+            assert has == 1 and d.value == g["cp_out"][i], i
+    assert 0 < n_none < len(g["cp_a0"])
+    d = C.c_double(0.0)
+    assert L.cno_collision_point(0.0, 0.5, -0.03, 0.5, -0.5, 0.5, 0.178, C.byref(d)) == 1
+    assert d.value == g["cp_spot"][0] and abs(d.value - 0.39767) < 1e-4
+    # A16 / A20
+    for i in range(len(g["iou_p1"])):
+        u = L.cno_iou(*g["iou_p1"][i], *g["iou_p2"][i], g["iou_s"][i])
+        assert u == g["iou_out"][i], i
+        assert (u > 0.0) == bool(g["assoc_out"][i])
+    assert L.cno_iou(0.0, 0.0, 0.05, 0.0, 0.0505) == 0.338
+    # A18
+    for dd, e1, e0 in zip(g["est_d"], g["est_out"], g["est_out0"]):
+        assert L.cno_estimate_num_obs_scans(dd, 0.6, 0.12) == int(e1)
+        assert L.cno_estimate_num_obs_scans(dd, 0.6, 0.0) == int(e0)
+    assert [L.cno_estimate_num_obs_scans(x, 0.6, 0.12) for x in (0.6, 0.36, 0.12)] == [3, 17, 32]
