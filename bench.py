@@ -1,0 +1,146 @@
+#!/usr/bin/env python
+"""bench.py -- env-steps/sec of the fused HIP environment step (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+
+A "step" is one cn_step launch over this rank's shard of environments (4096 envs x 20 pedestrians x
+360 rays, K = 8, BASELINE.json configs[1]); `value` = env-steps/s summed over all ranks, inputs resident
+in HBM, auto-reset included.  Envs shard across ranks with no data-path collective;
+the one collective is the RCCL all-gather of per-env episode returns after the timed region (8e E1).
+
+Adds to the JSON line:
+  roofline      achieved algorithmic HBM bytes/s of cn_env_kernel (HIP events on the launch stream)
+  cpu_baseline  the CPU oracle (plain-C port of the reference path, oracle/cn_oracle.c) timed on this
+                box's host cores on a bounded sample of the same workload (rank 0, N = 1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "drl-based-mapless-crowd-navigation-with-perceived-risk_amd"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def algorithmic_bytes(P, R, K):
+    """Algorithmic HBM bytes per env-step of the float64-state layout:
+    pedestrian pos+vel read+write 2*32P, obs f32 write 4(R-1+7+4K), top-K idx 4K, scalar records
+    (24 f64 + 16 i32) read+write, action 8, reward 4, done 1."""
+    return 64 * P + 4 * (R - 1 + 7 + 4 * K) + 4 * K + 2 * (24 * 8 + 16 * 4) + 8 + 4 + 1
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--envs", type=int, default=4096, help="environments per GPU (weak scaling)")
+    ap.add_argument("--peds", type=int, default=20)
+    ap.add_argument("--rays", type=int, default=360)
+    ap.add_argument("--k", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from crowdnav import Config
+    from crowdnav.env import VecEnv
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    N = a.envs
+    cfg = Config(n_envs=N, n_peds=a.peds, n_rays=a.rays, k_obstacles=a.k, max_steps=1000, seed=1234,
+                 env_index_base=rank * N, ped_cycle_ms=1400,
+                 room_half=2.40 if a.peds > 50 else 1.40)
+    env = VecEnv(cfg, device=local_rank)
+    env.reset()
+    # open-loop actions v ~ U(0, 0.22), w ~ U(-2, 2): counter-based, seed 1234 + global env index
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    n_act = 64
+    acts = torch.stack([torch.rand((n_act, N), generator=g, device=dev) * 0.22,
+                        torch.rand((n_act, N), generator=g, device=dev) * 4.0 - 2.0], 2).contiguous()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for i in range(a.warmup):
+        env.step(acts[i % n_act], auto_reset=True)
+    barrier()
+    stream = torch.cuda.current_stream(dev)
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for i in range(a.steps):
+        env.step(acts[i % n_act], auto_reset=True)
+    ev1.record(stream)
+    barrier()
+    t1 = time.perf_counter()
+    wall = t1 - t0
+    kernel_ms = ev0.elapsed_time(ev1) / a.steps      # cn_env_kernel is the only kernel in the timed region
+    if world > 1:
+        t = torch.tensor([wall], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+        # the path's one exchange: all-gather of per-env episode returns over xGMI
+        ret, _ = env.returns()
+        gathered = torch.empty(world * N, dtype=torch.float32, device=dev)
+        dist.all_gather_into_tensor(gathered, ret)
+        torch.cuda.synchronize(dev)
+
+    value = world * N * a.steps / wall
+    B = algorithmic_bytes(a.peds, a.rays, a.k)
+    achieved = B * N / (kernel_ms * 1e-3) / 1e9
+    out = {
+        "metric": "env-steps/sec @4096 envs x 20 peds x 360 rays; HBM GB/s vs roofline",
+        "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": wall / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "%d envs/GPU x %d pedestrians x %d rays, K=%d, lidar-tracker risk features, "
+                               "auto-reset, open-loop U(0,0.22)xU(-2,2) actions" % (N, a.peds, a.rays, a.k),
+                   "envs_per_gpu": N, "parallelism": "env-sharded x%d" % world},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "cn_env_kernel", "kernel_ms": kernel_ms, "bytes_per_env_step": B},
+    }
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        from oracle import oracle
+        ncpu = os.cpu_count() or 1
+        oracle.set_num_threads(ncpu)
+        n_s = 256
+        c2 = Config(n_envs=n_s, n_peds=a.peds, n_rays=a.rays, k_obstacles=a.k, max_steps=1000, seed=1234,
+                    ped_cycle_ms=1400, room_half=cfg.room_half)
+        orc = oracle.Oracle(c2.as_dict())
+        orc.reset()
+        acts_c = acts[:, :n_s].double().cpu().numpy()
+        orc.step(acts_c[0], auto_reset=True)
+        tc0 = time.perf_counter(); k = 0
+        while time.perf_counter() - tc0 < a.cpu_seconds:
+            orc.step(acts_c[k % n_act], auto_reset=True); k += 1
+        tc = time.perf_counter() - tc0
+        out["cpu_baseline"] = {"value": n_s * k / tc, "unit": "env-steps/s", "cores": ncpu, "kind": "port",
+                               "sample": "%d envs x %d steps of the same workload, oracle/cn_oracle.c with OpenMP "
+                                         "over envs (%d threads), %.1f s" % (n_s, k, ncpu, tc)}
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

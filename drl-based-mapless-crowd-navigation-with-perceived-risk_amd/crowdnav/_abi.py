@@ -1,0 +1,82 @@
+"""ctypes binding of libcrowdnav.so (include/crowdnav.h).  This is the binding INTEGRATION.md shows
+a maintainer of the reference adding; there is no CPU fallback -- importing works anywhere, but
+creating an environment raises unless the HIP library loads and a GPU is present."""
+import ctypes as C
+import os
+import subprocess
+
+from .config import CnConfig
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG, "lib", "libcrowdnav.so")
+BUILD_SH = os.path.join(_PKG, "csrc", "build.sh")
+
+CN_MAX_TRACKS = 64
+CN_SD_COUNT = 24
+CN_SI_COUNT = 16
+CN_TF_COUNT = 12
+SD = dict(RX=0, RY=1, RYAW=2, RV=3, RW=4, CLOCK=5, WPX=6, WPY=7, PREV_DIST=8, PREV_HEAD=9, DQ0X=10, DQ0Y=11,
+          DQ1X=12, DQ1Y=13, TS=14, BB=15, EGO=16, CPROB=17, EP_RETURN=18, LAST_RETURN=19)
+SI = dict(DONE=0, DQ_LEN=1, NTRACKS=2, EGO_VIOL=3, SOCIAL_VIOL=4, OBST_STEPS=5, SUCCESS=6, FAILURE=7, EP_STEP=8,
+          STATUS=9, NCONF=10, NENTRIES=11)
+TF = dict(PX=0, PY=1, DIST=2, D0X=3, D0Y=4, D1X=5, D1Y=6, T=7, SPEED=8, VX=9, VY=10, DQLEN=11)
+
+EXPORTS = ["cn_abi_version", "cn_last_error", "cn_create", "cn_destroy", "cn_obs_dim", "cn_config_of",
+           "cn_set_ped_init", "cn_get_ped_init", "cn_set_ped_preset_vel", "cn_reset", "cn_step", "cn_get_counters",
+           "cn_get_returns", "cn_debug_env", "cn_snapshot_size", "cn_snapshot", "cn_restore"]
+
+
+class CnStepIO(C.Structure):
+    _fields_ = [("action", C.c_void_p), ("step_counter", C.c_void_p), ("obs", C.c_void_p), ("final_obs", C.c_void_p),
+                ("obs_f64", C.c_void_p), ("reward", C.c_void_p), ("done", C.c_void_p), ("topk_idx", C.c_void_p),
+                ("auto_reset", C.c_int32), ("reserved", C.c_int32)]
+
+
+class CrowdNavError(RuntimeError):
+    pass
+
+
+def build(force=False):
+    """Compile libcrowdnav.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(_PKG, "csrc", f) for f in os.listdir(os.path.join(_PKG, "csrc"))]
+    srcs.append(os.path.join(os.path.dirname(_PKG), "include", "crowdnav.h"))
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(s) for s in srcs):
+        subprocess.check_call(["bash", BUILD_SH])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise CrowdNavError("libcrowdnav.so is not built (%s); run __graft_entry__.build() -- there is no CPU "
+                                "fallback" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        vp = C.c_void_p
+        L.cn_abi_version.restype = C.c_int
+        L.cn_last_error.restype = C.c_char_p
+        L.cn_create.argtypes = [C.POINTER(CnConfig), C.c_int, C.POINTER(vp)]
+        L.cn_destroy.argtypes = [vp]; L.cn_destroy.restype = None
+        L.cn_obs_dim.argtypes = [vp]
+        L.cn_config_of.argtypes = [vp, C.POINTER(CnConfig)]
+        L.cn_set_ped_init.argtypes = [vp, vp]
+        L.cn_get_ped_init.argtypes = [vp, vp]
+        L.cn_set_ped_preset_vel.argtypes = [vp, vp]
+        L.cn_reset.argtypes = [vp, vp, vp, vp, vp]
+        L.cn_step.argtypes = [vp, C.POINTER(CnStepIO), vp]
+        L.cn_get_counters.argtypes = [vp, vp, vp]
+        L.cn_get_returns.argtypes = [vp, vp, vp, vp]
+        L.cn_debug_env.argtypes = [vp, C.c_int, vp, vp, vp, vp]
+        L.cn_snapshot_size.argtypes = [vp]; L.cn_snapshot_size.restype = C.c_size_t
+        L.cn_snapshot.argtypes = [vp, vp, C.c_size_t]
+        L.cn_restore.argtypes = [vp, vp, C.c_size_t]
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise CrowdNavError("libcrowdnav error %d: %s" % (rc, lib().cn_last_error().decode()))

@@ -1,0 +1,75 @@
+"""Typed configuration of the batched environment (replaces the rosparam namespace /turtlebot3/*
+read at environment_stage_1_nobonus.py:71-90 and the XACRO / world constants).  SURVEY.md
+appendix B cites every default."""
+import ctypes as C
+from dataclasses import asdict, dataclass
+
+
+class CnConfig(C.Structure):
+    """Mirror of `cn_config` in include/crowdnav.h."""
+    _fields_ = [
+        ("n_envs", C.c_int32), ("n_peds", C.c_int32), ("n_rays", C.c_int32), ("k_obstacles", C.c_int32),
+        ("max_steps", C.c_int32), ("ped_mode", C.c_int32), ("dt_ms", C.c_int32), ("scan_latency_ms", C.c_int32),
+        ("settle_ms", C.c_int32), ("ped_cycle_ms", C.c_int32), ("ped_stagger_ms", C.c_int32), ("reserved0", C.c_int32),
+        ("env_index_base", C.c_int64), ("seed", C.c_uint64),
+        ("room_half", C.c_double), ("ped_radius", C.c_double), ("ped_vmax", C.c_double),
+        ("robot_clearance", C.c_double), ("lidar_min", C.c_double), ("lidar_max", C.c_double),
+        ("lidar_span", C.c_double), ("lidar_offset_x", C.c_double), ("max_scan_range", C.c_double),
+        ("min_scan_range", C.c_double), ("goal_x", C.c_double), ("goal_y", C.c_double),
+        ("start_x", C.c_double), ("start_y", C.c_double), ("spawn_x", C.c_double), ("spawn_y", C.c_double),
+        ("spawn_yaw", C.c_double), ("waypoint_radius", C.c_double), ("goal_eps", C.c_double),
+    ]
+
+
+@dataclass
+class Config:
+    n_envs: int = 1
+    n_peds: int = 20
+    n_rays: int = 360              # XACRO:157
+    k_obstacles: int = 8           # ENV:55 / TRAIN:50
+    max_steps: int = 1000          # configs/td3.yaml nsteps
+    ped_mode: int = 0              # 0 random-velocity walkers (CROWD:98-126), 1 constant preset table
+    dt_ms: int = 150               # ENV:1201
+    scan_latency_ms: int = 10      # virtual /scan wait
+    settle_ms: int = 100           # TRAIN:114
+    ped_cycle_ms: int = 0          # 0 -> 100 ms x n_peds (CROWD:128-144)
+    ped_stagger_ms: int = 100      # CROWD:144
+    env_index_base: int = 0
+    seed: int = 1234
+    room_half: float = 1.40        # WORLD:926-1108
+    ped_radius: float = 0.0505     # WORLD:109
+    ped_vmax: float = 0.2          # CROWD:101-102
+    robot_clearance: float = 0.09
+    lidar_min: float = 0.08        # XACRO:164
+    lidar_max: float = 0.60        # XACRO:165
+    lidar_span: float = 6.28       # XACRO:159-160
+    lidar_offset_x: float = -0.032 # URDF:134-138
+    max_scan_range: float = 0.6    # turtlebot3_world.yaml:7
+    min_scan_range: float = 0.12   # turtlebot3_world.yaml:8
+    goal_x: float = -1.0           # turtlebot3_world.yaml:10-13
+    goal_y: float = 1.0
+    start_x: float = 0.75          # turtlebot3_world.yaml:15-18 (heading offset only, ENV:223-224)
+    start_y: float = -0.75
+    spawn_x: float = 1.0           # put_robot_in_world_training.launch
+    spawn_y: float = -1.0
+    spawn_yaw: float = 3.14
+    waypoint_radius: float = 0.3   # ENV:250
+    goal_eps: float = 0.20         # ENV:1285
+
+    def resolved(self):
+        d = asdict(self)
+        if not d["ped_cycle_ms"]:
+            d["ped_cycle_ms"] = max(100, 100 * d["n_peds"])
+        return d
+
+    def as_dict(self):
+        return self.resolved()
+
+    def to_c(self):
+        d = self.resolved()
+        d["reserved0"] = 0
+        return CnConfig(**d)
+
+    @property
+    def obs_dim(self):
+        return (self.n_rays - 1) + 7 + 4 * self.k_obstacles   # ENV:1038-1039, TRAIN:88

@@ -1,0 +1,185 @@
+"""Host-side mirror of the reference's `Env` (environment_stage_1_nobonus.py:42) over the C-ABI.
+
+`VecEnv`  N environments on one MI355X; tensors stay on the device (zero-copy into the actor).
+`Env`     the reference's single-robot surface -- Env(action_dim, max_step), reset(), step(action,
+          step_counter, mode), get_episode_status(), get_social/ego_safety_violation_status(),
+          shutdown(), writable `done`, readable `k_obstacle_count` -- so the loop of
+          start_td3_training.py:106-166 runs unchanged.
+PyTorch is used only for device memory and streams.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _abi
+from .config import Config
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class VecEnv:
+    def __init__(self, cfg=None, device=0, **kw):
+        self.cfg = cfg if cfg is not None else Config(**kw)
+        if not torch.cuda.is_available():
+            raise _abi.CrowdNavError("VecEnv needs a HIP device: libcrowdnav.so has no CPU fallback")
+        self.L = _abi.lib()
+        self.device = torch.device("cuda", device)
+        self.h = C.c_void_p()
+        ccfg = self.cfg.to_c()
+        _abi.check(self.L.cn_create(C.byref(ccfg), int(device), C.byref(self.h)))
+        self.N, self.P, self.R, self.K = self.cfg.n_envs, self.cfg.n_peds, self.cfg.n_rays, self.cfg.k_obstacles
+        self.D = self.L.cn_obs_dim(self.h)
+        N, D, K, dev = self.N, self.D, self.K, self.device
+        self.obs = torch.zeros((N, D), dtype=torch.float32, device=dev)
+        self.final_obs = torch.zeros((N, D), dtype=torch.float32, device=dev)
+        self.obs_f64 = None
+        self.reward = torch.zeros(N, dtype=torch.float32, device=dev)
+        self.done = torch.zeros(N, dtype=torch.uint8, device=dev)
+        self.topk_idx = torch.full((N, K), -1, dtype=torch.int32, device=dev)
+        self._counters = torch.zeros((N, 8), dtype=torch.int32, device=dev)
+        self._ret = torch.zeros(N, dtype=torch.float32, device=dev)
+        self._run = torch.zeros(N, dtype=torch.float32, device=dev)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.cn_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def enable_f64_obs(self):
+        """Also produce the observation in float64 (the reference's dtype) -- used by parity tests."""
+        if self.obs_f64 is None:
+            self.obs_f64 = torch.zeros((self.N, self.D), dtype=torch.float64, device=self.device)
+        return self.obs_f64
+
+    def set_ped_init(self, xy):
+        xy = np.ascontiguousarray(xy, dtype=np.float64).reshape(self.N, self.P, 2)
+        _abi.check(self.L.cn_set_ped_init(self.h, xy.ctypes.data))
+
+    def get_ped_init(self):
+        xy = np.zeros((self.N, self.P, 2))
+        _abi.check(self.L.cn_get_ped_init(self.h, xy.ctypes.data))
+        return xy
+
+    def set_ped_preset_vel(self, v):
+        v = np.ascontiguousarray(v, dtype=np.float64).reshape(self.N, self.P, 2)
+        _abi.check(self.L.cn_set_ped_preset_vel(self.h, v.ctypes.data))
+
+    def reset(self, mask=None):
+        """Env.reset() for every env (or the masked ones) -> obs [N, D] float32 on the device."""
+        m = None
+        if mask is not None:
+            m = torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
+        _abi.check(self.L.cn_reset(self.h, _ptr(m), _ptr(self.obs), _ptr(self.obs_f64), self._stream()))
+        return self.obs
+
+    def step(self, action, step_counter=None, auto_reset=True, want_final=False):
+        """Env.step for every env.  action: [N,2] float32 device tensor (v, w).
+        Returns (obs, reward, done) device tensors (views of internal buffers)."""
+        a = action
+        if not (isinstance(a, torch.Tensor) and a.device == self.device and a.dtype == torch.float32 and a.is_contiguous()):
+            a = torch.as_tensor(np.asarray(action, dtype=np.float32) if not isinstance(action, torch.Tensor) else action,
+                                dtype=torch.float32, device=self.device).contiguous()
+        sc = None
+        if step_counter is not None:
+            sc = torch.as_tensor(step_counter, dtype=torch.int32, device=self.device).contiguous()
+        io = _abi.CnStepIO(action=a.data_ptr(), step_counter=sc.data_ptr() if sc is not None else None,
+                           obs=self.obs.data_ptr(), final_obs=self.final_obs.data_ptr() if want_final else None,
+                           obs_f64=self.obs_f64.data_ptr() if self.obs_f64 is not None else None,
+                           reward=self.reward.data_ptr(), done=self.done.data_ptr(), topk_idx=self.topk_idx.data_ptr(),
+                           auto_reset=int(bool(auto_reset)), reserved=0)
+        _abi.check(self.L.cn_step(self.h, C.byref(io), self._stream()))
+        return self.obs, self.reward, self.done
+
+    def counters(self):
+        """[N,8] int32: ego_viol, social_viol, obstacle_present_steps, ep_steps, success, failure, status, n_tracks."""
+        _abi.check(self.L.cn_get_counters(self.h, _ptr(self._counters), self._stream()))
+        return self._counters
+
+    def returns(self):
+        """(return of the last finished episode, running return) float32 [N] device tensors."""
+        _abi.check(self.L.cn_get_returns(self.h, _ptr(self._ret), _ptr(self._run), self._stream()))
+        return self._ret, self._run
+
+    def debug_env(self, env=0):
+        sd = np.zeros(_abi.CN_SD_COUNT); rp = np.zeros(5 + 4 * self.P)
+        tr = np.zeros((_abi.CN_TF_COUNT, _abi.CN_MAX_TRACKS)); si = np.zeros(_abi.CN_SI_COUNT, dtype=np.int32)
+        _abi.check(self.L.cn_debug_env(self.h, int(env), sd.ctypes.data, rp.ctypes.data, tr.ctypes.data, si.ctypes.data))
+        n = int(si[_abi.SI["NTRACKS"]])
+        T = _abi.TF
+        return dict(sd=sd, si=si, robot=rp[:5].copy(), ped_p=rp[5:5 + 2 * self.P].reshape(-1, 2).copy(),
+                    ped_v=rp[5 + 2 * self.P:].reshape(-1, 2).copy(), n_tracks=n,
+                    track_pose=np.stack([tr[T["PX"], :n], tr[T["PY"], :n]], 1), track_dist=tr[T["DIST"], :n].copy(),
+                    track_speed=tr[T["SPEED"], :n].copy(), track_vel=np.stack([tr[T["VX"], :n], tr[T["VY"], :n]], 1),
+                    track_t=tr[T["T"], :n].copy(), track_dqlen=tr[T["DQLEN"], :n].astype(np.int32),
+                    bb=sd[_abi.SD["BB"]], collision_prob=sd[_abi.SD["CPROB"]], ego_score=sd[_abi.SD["EGO"]],
+                    wp=(sd[_abi.SD["WPX"]], sd[_abi.SD["WPY"]]), status=int(si[_abi.SI["STATUS"]]),
+                    n_confirmed=int(si[_abi.SI["NCONF"]]), n_entries=int(si[_abi.SI["NENTRIES"]]))
+
+    def snapshot(self):
+        n = self.L.cn_snapshot_size(self.h)
+        buf = np.zeros(n, dtype=np.uint8)
+        _abi.check(self.L.cn_snapshot(self.h, buf.ctypes.data, n))
+        return buf
+
+    def restore(self, buf):
+        buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        _abi.check(self.L.cn_restore(self.h, buf.ctypes.data, buf.size))
+
+
+class Env:
+    """Drop-in for the reference's `Env` (ENV:42): same constructor, methods, return types."""
+
+    def __init__(self, action_dim=2, max_step=200, cfg=None, device=0, **kw):
+        if cfg is None:
+            cfg = Config(n_envs=1, max_steps=max_step, **kw)
+        assert cfg.n_envs == 1
+        self.action_dim = action_dim
+        self.max_steps = cfg.max_steps
+        self.k_obstacle_count = cfg.k_obstacles
+        self._v = VecEnv(cfg, device=device)
+        self._v.enable_f64_obs()
+        self._act = torch.zeros((1, 2), dtype=torch.float32, device=self._v.device)
+        self.done = False
+        self._trainer_done_latch = False
+
+    def reset(self):
+        self._v.reset()
+        torch.cuda.synchronize(self._v.device)
+        self.done = False   # the kernel applies TRAIN:116 (`env.done = False`) as part of reset
+        return self._v.obs_f64[0].cpu().numpy()
+
+    def step(self, action, step_counter, mode="discrete"):
+        if mode != "continuous":
+            raise NotImplementedError("only mode='continuous' (the TD3/DDPG/SAC path, ENV:1178-1188) is implemented")
+        self._act[0, 0] = float(action[0]); self._act[0, 1] = float(action[1])
+        self._v.step(self._act, step_counter=[int(step_counter)], auto_reset=False)
+        torch.cuda.synchronize(self._v.device)
+        self.done = bool(self._v.done[0].item())
+        return self._v.obs_f64[0].cpu().numpy(), float(self._v.reward[0].item()), self.done
+
+    def get_episode_status(self):
+        c = self._v.counters()[0].cpu().numpy()
+        return bool(c[4]), bool(c[5])
+
+    def get_social_safety_violation_status(self, step):
+        c = self._v.counters()[0].cpu().numpy()
+        return 1.0 - ((int(c[1]) * 1.0) / int(c[2]))   # ZeroDivisionError if no obstacle was ever seen (ENV:1272)
+
+    def get_ego_safety_violation_status(self, step):
+        c = self._v.counters()[0].cpu().numpy()
+        return 1.0 - ((int(c[0]) * 1.0) / int(c[2]))
+
+    def shutdown(self):
+        pass

@@ -1,0 +1,12 @@
+#!/bin/bash
+# Builds libcrowdnav.so for gfx950 (MI355X).  hipcc cross-compiles without a GPU.
+#   -ffp-contract=off : no implicit FMA contraction; every fma() in the sources is explicit, which is
+#                       what makes the simulator bit-reproducible against oracle/cn_oracle.c
+set -euo pipefail
+HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+OUT="$HERE/../lib"
+mkdir -p "$OUT"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-builtin-pow -Wall -Wno-unused-function"
+"$HIPCC" $FLAGS ${CN_EXTRA_FLAGS:-} -shared -o "$OUT/libcrowdnav.so" "$HERE/crowdnav_kernel.hip" "$HERE/crowdnav_abi.hip"
+echo "built $OUT/libcrowdnav.so"

@@ -1,0 +1,322 @@
+// crowdnav_abi.hip -- host side of libcrowdnav.so: the C-ABI declared in include/crowdnav.h.
+// Owns the per-env SoA state in HBM, builds the constant tables, and enqueues the fused step
+// kernel on the caller's stream.  No CPU fallback exists: without a HIP device cn_create fails.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "crowdnav_device.h"
+#include "crowdnav_kernel.h"
+
+extern "C" __global__ void cn_env_kernel(CnKParams p);
+extern "C" __global__ void cn_gather_kernel(CnKParams p, float* last_ret, float* run_ret, int32_t* counters);
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) \
+    return fail(CN_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+
+struct cn_env_s {
+    cn_config cfg;
+    int device;
+    int D, max_conf;
+    size_t lds;
+    CnKParams kp;        // template with state/table pointers filled in
+    double *d_lidar, *d_poly, *d_sd, *d_ped_p, *d_ped_v, *d_ped_init, *d_ped_preset, *d_trk;
+    int32_t* d_si;
+    std::vector<double> ped_init;
+};
+
+size_t cn_lds_bytes(int R, int P, int K, int max_conf)
+{
+    size_t n = (size_t)(R - 1);
+    size_t b = 0;
+    b += 8 * n * 5;                               // ptx pty dd g cg
+    b += 8 * (size_t)(2 * P + 2);                 // ped
+    b += 8 * (size_t)(CN_TF_COUNT * CN_MAX_TRACKS);
+    b += 8 * (size_t)max_conf * 3;                // cfx cfy cfd
+    b += 8 * (size_t)CN_MAX_TRACKS;               // cpv
+    b += 8 * (size_t)(7 + 4 * K + 1);             // tail
+    b += 4 * n * 5;                               // flags tmpi tinfo segend brk
+    b += 4 * (size_t)max_conf * 2;                // cft checked
+    b += 4 * (size_t)CN_MAX_K;                    // kidx
+    return (b + 15) & ~(size_t)15;
+}
+
+extern "C" int cn_abi_version(void) { return CN_ABI_VERSION; }
+extern "C" const char* cn_last_error(void) { return g_err.c_str(); }
+
+static void default_ped_init(const cn_config& c, int env, double* xy)
+{
+    // seeded uniform in the room, rejected within 0.4 m of the robot spawn
+    int64_t gid = c.env_index_base + env;
+    double lo = -c.room_half + 0.1, span = 2.0 * c.room_half - 0.2;
+    for (int i = 0; i < c.n_peds; ++i) {
+        uint32_t att = 0;
+        for (;;) {
+            double x = fma(span, cn_rng_u01(c.seed, gid, 2u, (uint32_t)i, 2 * att), lo);
+            double y = fma(span, cn_rng_u01(c.seed, gid, 2u, (uint32_t)i, 2 * att + 1), lo);
+            double dx = x - c.spawn_x, dy = y - c.spawn_y;
+            ++att;
+            if (fma(dx, dx, dy * dy) >= 0.16 || att > 1000) { xy[2 * i] = x; xy[2 * i + 1] = y; break; }
+        }
+    }
+}
+
+static double angle_increment_deg(int R)
+{
+    // UTL:113 `max_angle / (resolution - 1)` with Python-2 integer operands (360/359 == 1).
+    // For R-1 > 360 Python 2 would give 0; defined as true division (outside the reference's range).
+    if (R - 1 <= 360) return (double)(360 / (R - 1));
+    return 360.0 / (double)(R - 1);
+}
+
+static int upload_initial_state(cn_env_s* h)
+{
+    const cn_config& c = h->cfg;
+    const int N = c.n_envs, P = c.n_peds;
+    std::vector<double> sd((size_t)N * CN_SD_COUNT, 0.0);
+    std::vector<int32_t> si((size_t)N * CN_SI_COUNT, 0);
+    for (int e = 0; e < N; ++e) {  // Env.__init__ (ENV:43-168)
+        double* s = &sd[(size_t)e * CN_SD_COUNT];
+        s[CN_SD_RX] = c.spawn_x; s[CN_SD_RY] = c.spawn_y; s[CN_SD_RYAW] = c.spawn_yaw;
+        s[CN_SD_WPX] = c.goal_x; s[CN_SD_WPY] = c.goal_y;
+    }
+    HIPCHK(hipMemcpy(h->d_sd, sd.data(), sd.size() * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_si, si.data(), si.size() * 4, hipMemcpyHostToDevice));
+    if (P > 0) {
+        HIPCHK(hipMemcpy(h->d_ped_init, h->ped_init.data(), (size_t)N * P * 16, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->d_ped_p, h->ped_init.data(), (size_t)N * P * 16, hipMemcpyHostToDevice));
+        HIPCHK(hipMemset(h->d_ped_v, 0, (size_t)N * P * 16));
+        HIPCHK(hipMemset(h->d_ped_preset, 0, (size_t)N * P * 16));
+    }
+    HIPCHK(hipMemset(h->d_trk, 0, (size_t)N * CN_TF_COUNT * CN_MAX_TRACKS * 8));
+    return CN_OK;
+}
+
+extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
+{
+    if (!cfg || !out) return fail(CN_ERR_ARG, "cn_create: null argument");
+    const cn_config& c = *cfg;
+    if (c.n_envs < 1 || c.n_peds < 0 || c.n_peds > 4096 || c.n_rays < 8 || c.n_rays > 1025 || c.k_obstacles < 1 ||
+        c.k_obstacles > CN_MAX_K || c.ped_cycle_ms < 1 || c.dt_ms < 1 || c.scan_latency_ms < 1 || c.settle_ms < 0 ||
+        c.max_steps < 1)
+        return fail(CN_ERR_CONFIG, "cn_create: config out of range");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(CN_ERR_NO_DEVICE, "cn_create: no HIP device (libcrowdnav has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(CN_ERR_ARG, "cn_create: bad device ordinal");
+    HIPCHK(hipSetDevice(device));
+    cn_env_s* h = new cn_env_s();
+    h->cfg = c;
+    h->device = device;
+    const int N = c.n_envs, P = c.n_peds, R = c.n_rays, K = c.k_obstacles;
+    h->D = (R - 1) + 7 + 4 * K;
+    h->max_conf = (R - 1) / 4 + 2;
+    h->lds = cn_lds_bytes(R, P, K, h->max_conf);
+    if (h->lds > 160 * 1024) { delete h; return fail(CN_ERR_CONFIG, "cn_create: per-env working set exceeds 160 KiB of LDS"); }
+    // tables
+    std::vector<double> lidar(2 * (size_t)R), poly(128);
+    double step = c.lidar_span / (double)(R - 1);
+    for (int k = 0; k < R; ++k) cn_det_sincos((double)k * step, &lidar[R + k], &lidar[k]);
+    for (int k = 0; k < 64; ++k) { double a = -(double)k * M_PI / 32.0; poly[k] = cos(a); poly[64 + k] = sin(a); }
+    HIPCHK(hipMalloc(&h->d_lidar, lidar.size() * 8));
+    HIPCHK(hipMalloc(&h->d_poly, poly.size() * 8));
+    HIPCHK(hipMemcpy(h->d_lidar, lidar.data(), lidar.size() * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_poly, poly.data(), poly.size() * 8, hipMemcpyHostToDevice));
+    size_t pb = (size_t)N * (P > 0 ? P : 1) * 16;
+    HIPCHK(hipMalloc(&h->d_sd, (size_t)N * CN_SD_COUNT * 8));
+    HIPCHK(hipMalloc(&h->d_si, (size_t)N * CN_SI_COUNT * 4));
+    HIPCHK(hipMalloc(&h->d_ped_p, pb));
+    HIPCHK(hipMalloc(&h->d_ped_v, pb));
+    HIPCHK(hipMalloc(&h->d_ped_init, pb));
+    HIPCHK(hipMalloc(&h->d_ped_preset, pb));
+    HIPCHK(hipMalloc(&h->d_trk, (size_t)N * CN_TF_COUNT * CN_MAX_TRACKS * 8));
+    h->ped_init.resize((size_t)N * P * 2);
+    for (int e = 0; e < N; ++e) default_ped_init(c, e, &h->ped_init[(size_t)e * P * 2]);
+    int rc = upload_initial_state(h);
+    if (rc != CN_OK) { delete h; return rc; }
+
+    CnKParams& k = h->kp;
+    memset(&k, 0, sizeof(k));
+    k.N = N; k.P = P; k.R = R; k.K = K;
+    k.max_steps = c.max_steps; k.ped_mode = c.ped_mode; k.dt_ms = c.dt_ms; k.scan_latency_ms = c.scan_latency_ms;
+    k.settle_ms = c.settle_ms; k.ped_cycle_ms = c.ped_cycle_ms; k.ped_stagger_ms = c.ped_stagger_ms;
+    k.max_conf = h->max_conf; k.env_index_base = c.env_index_base; k.seed = c.seed;
+    k.room_half = c.room_half; k.ped_radius = c.ped_radius; k.ped_vmax = c.ped_vmax; k.robot_clearance = c.robot_clearance;
+    k.lidar_min = c.lidar_min; k.lidar_max = c.lidar_max; k.lidar_offset_x = c.lidar_offset_x;
+    k.max_scan_range = c.max_scan_range; k.min_scan_range = c.min_scan_range; k.goal_x = c.goal_x; k.goal_y = c.goal_y;
+    k.start_x = c.start_x; k.start_y = c.start_y; k.spawn_x = c.spawn_x; k.spawn_y = c.spawn_y; k.spawn_yaw = c.spawn_yaw;
+    k.waypoint_radius = c.waypoint_radius; k.goal_eps = c.goal_eps; k.angle_inc_deg = angle_increment_deg(R);
+    k.lidar_c = h->d_lidar; k.lidar_s = h->d_lidar + R; k.poly_c = h->d_poly; k.poly_s = h->d_poly + 64;
+    k.sd = h->d_sd; k.si = h->d_si; k.ped_p = h->d_ped_p; k.ped_v = h->d_ped_v; k.ped_init = h->d_ped_init;
+    k.ped_preset = h->d_ped_preset; k.trk = h->d_trk;
+    if (h->lds > 64 * 1024)
+        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
+    *out = h;
+    return CN_OK;
+}
+
+extern "C" void cn_destroy(cn_handle h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    (void)hipFree(h->d_lidar); (void)hipFree(h->d_poly); (void)hipFree(h->d_sd); (void)hipFree(h->d_si);
+    (void)hipFree(h->d_ped_p); (void)hipFree(h->d_ped_v); (void)hipFree(h->d_ped_init); (void)hipFree(h->d_ped_preset);
+    (void)hipFree(h->d_trk);
+    delete h;
+}
+
+extern "C" int cn_obs_dim(cn_handle h) { return h ? h->D : fail(CN_ERR_ARG, "null handle"); }
+
+extern "C" int cn_config_of(cn_handle h, cn_config* out)
+{
+    if (!h || !out) return fail(CN_ERR_ARG, "cn_config_of: null argument");
+    *out = h->cfg;
+    return CN_OK;
+}
+
+extern "C" int cn_set_ped_init(cn_handle h, const double* xy)
+{
+    if (!h || !xy) return fail(CN_ERR_ARG, "cn_set_ped_init: null argument");
+    HIPCHK(hipSetDevice(h->device));
+    size_t cnt = (size_t)h->cfg.n_envs * h->cfg.n_peds * 2;
+    h->ped_init.assign(xy, xy + cnt);
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(h->d_ped_init, xy, cnt * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_ped_p, xy, cnt * 8, hipMemcpyHostToDevice));
+    return CN_OK;
+}
+
+extern "C" int cn_get_ped_init(cn_handle h, double* xy)
+{
+    if (!h || !xy) return fail(CN_ERR_ARG, "cn_get_ped_init: null argument");
+    memcpy(xy, h->ped_init.data(), h->ped_init.size() * 8);
+    return CN_OK;
+}
+
+extern "C" int cn_set_ped_preset_vel(cn_handle h, const double* vxy)
+{
+    if (!h || !vxy) return fail(CN_ERR_ARG, "cn_set_ped_preset_vel: null argument");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(h->d_ped_preset, vxy, (size_t)h->cfg.n_envs * h->cfg.n_peds * 16, hipMemcpyHostToDevice));
+    return CN_OK;
+}
+
+static int launch(cn_handle h, const CnKParams& kp, hipStream_t st)
+{
+    hipLaunchKernelGGL(cn_env_kernel, dim3(kp.N), dim3(64), h->lds, st, kp);
+    HIPCHK(hipGetLastError());
+    return CN_OK;
+}
+
+extern "C" int cn_reset(cn_handle h, const uint8_t* mask, float* obs, double* obs_f64, void* stream)
+{
+    if (!h || !obs) return fail(CN_ERR_ARG, "cn_reset: null argument");
+    CnKParams kp = h->kp;
+    kp.mode = CN_MODE_RESET; kp.mask = mask; kp.obs = obs; kp.obs_f64 = obs_f64;
+    return launch(h, kp, (hipStream_t)stream);
+}
+
+extern "C" int cn_step(cn_handle h, const cn_step_io* io, void* stream)
+{
+    if (!h || !io || !io->action || !io->obs || !io->reward || !io->done) return fail(CN_ERR_ARG, "cn_step: null argument");
+    CnKParams kp = h->kp;
+    kp.mode = CN_MODE_STEP; kp.auto_reset = io->auto_reset;
+    kp.action = io->action; kp.step_counter = io->step_counter; kp.obs = io->obs; kp.final_obs = io->final_obs;
+    kp.obs_f64 = io->obs_f64; kp.reward = io->reward; kp.done = io->done; kp.topk_idx = io->topk_idx;
+    return launch(h, kp, (hipStream_t)stream);
+}
+
+extern "C" int cn_get_counters(cn_handle h, int32_t* out, void* stream)
+{
+    if (!h || !out) return fail(CN_ERR_ARG, "cn_get_counters: null argument");
+    int N = h->cfg.n_envs;
+    hipLaunchKernelGGL(cn_gather_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->kp,
+                       (float*)nullptr, (float*)nullptr, out);
+    HIPCHK(hipGetLastError());
+    return CN_OK;
+}
+
+extern "C" int cn_get_returns(cn_handle h, float* last_return, float* running_return, void* stream)
+{
+    if (!h) return fail(CN_ERR_ARG, "cn_get_returns: null handle");
+    int N = h->cfg.n_envs;
+    hipLaunchKernelGGL(cn_gather_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->kp, last_return,
+                       running_return, (int32_t*)nullptr);
+    HIPCHK(hipGetLastError());
+    return CN_OK;
+}
+
+extern "C" int cn_debug_env(cn_handle h, int env, double* scalars, double* robot_ped, double* tracks, int32_t* ints)
+{
+    if (!h || env < 0 || env >= h->cfg.n_envs) return fail(CN_ERR_ARG, "cn_debug_env: bad argument");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipDeviceSynchronize());
+    const int P = h->cfg.n_peds;
+    std::vector<double> sd(CN_SD_COUNT);
+    HIPCHK(hipMemcpy(sd.data(), h->d_sd + (size_t)env * CN_SD_COUNT, CN_SD_COUNT * 8, hipMemcpyDeviceToHost));
+    if (scalars) memcpy(scalars, sd.data(), CN_SD_COUNT * 8);
+    if (robot_ped) {
+        memcpy(robot_ped, sd.data(), 5 * 8);
+        if (P > 0) {
+            HIPCHK(hipMemcpy(robot_ped + 5, h->d_ped_p + (size_t)env * 2 * P, (size_t)P * 16, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(robot_ped + 5 + 2 * P, h->d_ped_v + (size_t)env * 2 * P, (size_t)P * 16, hipMemcpyDeviceToHost));
+        }
+    }
+    if (tracks)
+        HIPCHK(hipMemcpy(tracks, h->d_trk + (size_t)env * CN_TF_COUNT * CN_MAX_TRACKS, CN_TF_COUNT * CN_MAX_TRACKS * 8,
+                         hipMemcpyDeviceToHost));
+    if (ints) HIPCHK(hipMemcpy(ints, h->d_si + (size_t)env * CN_SI_COUNT, CN_SI_COUNT * 4, hipMemcpyDeviceToHost));
+    return CN_OK;
+}
+
+// snapshot layout: sd | si | ped_p | ped_v | trk
+extern "C" size_t cn_snapshot_size(cn_handle h)
+{
+    if (!h) return 0;
+    size_t N = h->cfg.n_envs, P = h->cfg.n_peds;
+    return N * (CN_SD_COUNT * 8 + CN_SI_COUNT * 4 + 2 * P * 16 + (size_t)CN_TF_COUNT * CN_MAX_TRACKS * 8);
+}
+
+extern "C" int cn_snapshot(cn_handle h, void* buf, size_t size)
+{
+    if (!h || !buf) return fail(CN_ERR_ARG, "cn_snapshot: null argument");
+    if (size < cn_snapshot_size(h)) return fail(CN_ERR_SIZE, "cn_snapshot: buffer too small");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipDeviceSynchronize());
+    size_t N = h->cfg.n_envs, P = h->cfg.n_peds;
+    char* q = (char*)buf;
+    HIPCHK(hipMemcpy(q, h->d_sd, N * CN_SD_COUNT * 8, hipMemcpyDeviceToHost)); q += N * CN_SD_COUNT * 8;
+    HIPCHK(hipMemcpy(q, h->d_si, N * CN_SI_COUNT * 4, hipMemcpyDeviceToHost)); q += N * CN_SI_COUNT * 4;
+    if (P) {
+        HIPCHK(hipMemcpy(q, h->d_ped_p, N * P * 16, hipMemcpyDeviceToHost)); q += N * P * 16;
+        HIPCHK(hipMemcpy(q, h->d_ped_v, N * P * 16, hipMemcpyDeviceToHost)); q += N * P * 16;
+    }
+    HIPCHK(hipMemcpy(q, h->d_trk, N * CN_TF_COUNT * CN_MAX_TRACKS * 8, hipMemcpyDeviceToHost));
+    return CN_OK;
+}
+
+extern "C" int cn_restore(cn_handle h, const void* buf, size_t size)
+{
+    if (!h || !buf) return fail(CN_ERR_ARG, "cn_restore: null argument");
+    if (size < cn_snapshot_size(h)) return fail(CN_ERR_SIZE, "cn_restore: buffer too small");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipDeviceSynchronize());
+    size_t N = h->cfg.n_envs, P = h->cfg.n_peds;
+    const char* q = (const char*)buf;
+    HIPCHK(hipMemcpy(h->d_sd, q, N * CN_SD_COUNT * 8, hipMemcpyHostToDevice)); q += N * CN_SD_COUNT * 8;
+    HIPCHK(hipMemcpy(h->d_si, q, N * CN_SI_COUNT * 4, hipMemcpyHostToDevice)); q += N * CN_SI_COUNT * 4;
+    if (P) {
+        HIPCHK(hipMemcpy(h->d_ped_p, q, N * P * 16, hipMemcpyHostToDevice)); q += N * P * 16;
+        HIPCHK(hipMemcpy(h->d_ped_v, q, N * P * 16, hipMemcpyHostToDevice)); q += N * P * 16;
+    }
+    HIPCHK(hipMemcpy(h->d_trk, q, N * CN_TF_COUNT * CN_MAX_TRACKS * 8, hipMemcpyHostToDevice));
+    return CN_OK;
+}

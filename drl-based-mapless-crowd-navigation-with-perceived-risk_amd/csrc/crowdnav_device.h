@@ -1,0 +1,136 @@
+// crowdnav_device.h -- device-side arithmetic shared by the kernels of libcrowdnav.so (gfx950).
+//
+// Every function states the reference lines it implements (ENV = environment_stage_1_nobonus.py,
+// UTL = utils.py under /root/reference/turtlebot3_rl_sim/src).  All arithmetic that feeds a
+// rounding, a comparison or an index is float64 and written with explicit fma() (the file is
+// compiled with -ffp-contract=off) so that it is reproducible operation-for-operation.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define CN_PI 3.14159265358979323846
+
+// ---- Python / numpy rounding -------------------------------------------------------------
+// Python-3 round(x, nd): correctly rounded decimal (ties-to-even on the exact binary value).
+// x*p = y + err exactly (fma); rint(y) can only be misled when y is exactly a half-integer.
+__device__ __forceinline__ double cn_py_round(double x, double p)
+{
+    double y = x * p;
+    double r = rint(y);
+    double d = y - r;
+    if (fabs(d) == 0.5) {
+        double err = fma(x, p, -y);
+        if (err > 0.0) r = y + 0.5;
+        else if (err < 0.0) r = y - 0.5;
+    }
+    return r / p;
+}
+// numpy around / round(np.float64, nd): multiply, rint, divide (ENV:255, ENV:1042)
+__device__ __forceinline__ double cn_np_around(double x, double p) { return rint(x * p) / p; }
+
+// ---- deterministic sin/cos ----------------------------------------------------------------
+// Cody-Waite reduction by pi/2 + degree-13/14 minimax kernels; only + * fma rint, so host and
+// device produce identical bits (the simulator's contract, DESIGN.md "physics").
+__host__ __device__ inline void cn_det_sincos(double x, double* sn, double* cs)
+{
+    const double two_over_pi = 6.36619772367581382433e-01;
+    const double p1 = 1.57079632673412561417e+00;
+    const double p2 = 6.07710050630396597660e-11;
+    const double p3 = 2.02226624879595063154e-21;
+    double fn = rint(x * two_over_pi);
+    double r = fma(-fn, p1, x);
+    r = fma(-fn, p2, r);
+    r = fma(-fn, p3, r);
+    double z = r * r;
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+                 S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+                 S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    double ps = fma(z, S6, S5);
+    ps = fma(z, ps, S4);
+    ps = fma(z, ps, S3);
+    ps = fma(z, ps, S2);
+    ps = fma(z, ps, S1);
+    double s = fma(r * z, ps, r);
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+                 C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+                 C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    double pc = fma(z, C6, C5);
+    pc = fma(z, pc, C4);
+    pc = fma(z, pc, C3);
+    pc = fma(z, pc, C2);
+    pc = fma(z, pc, C1);
+    double c = fma(z * z, pc, fma(-0.5, z, 1.0));
+    long long q = (long long)fn;
+    switch (q & 3) {
+    case 0: *sn = s;  *cs = c;  break;
+    case 1: *sn = c;  *cs = -s; break;
+    case 2: *sn = -s; *cs = -c; break;
+    default: *sn = -c; *cs = s; break;
+    }
+}
+
+// ---- counter-based RNG (CROWD:101-102 random.uniform) ---------------------------------------
+__host__ __device__ inline uint64_t cn_mix64(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+__host__ __device__ inline double cn_rng_u01(uint64_t seed, int64_t env, uint32_t stream, uint32_t a, uint32_t b)
+{
+    uint64_t h = cn_mix64(seed ^ cn_mix64((uint64_t)env));
+    h = cn_mix64(h ^ (((uint64_t)stream << 32) | (uint64_t)a));
+    h = cn_mix64(h ^ (uint64_t)b);
+    return (double)(h >> 11) * (1.0 / 9007199254740992.0);
+}
+
+__host__ __device__ inline double cn_clamp(double x, double lo, double hi) { return fmin(fmax(x, lo), hi); }
+
+// ---- UTL:422-460 IoU of two axis-aligned squares, rounded to 3 decimals ---------------------
+__device__ __forceinline__ double cn_iou3(double ax, double ay, double bx, double by, double half)
+{
+    double axp = ax + half, axm = ax - half, ayp = ay + half, aym = ay - half;
+    double bxp = bx + half, bxm = bx - half, byp = by + half, bym = by - half;
+    double ix = fmin(axp, bxp) - fmax(axm, bxm);
+    double iy = fmin(ayp, byp) - fmax(aym, bym);
+    if (!(ix > 0.0 && iy > 0.0)) return 0.0;
+    double inter = ix * iy;
+    double area_a = (axp - axm) * (ayp - aym);
+    double area_b = (bxp - bxm) * (byp - bym);
+    double uni = area_a + area_b - inter;
+    return cn_py_round(inter / uni, 1000.0);
+}
+
+// ---- wave64 helpers ---------------------------------------------------------------------------
+__device__ __forceinline__ double cn_shfl_xor_d(double v, int m)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __shfl_xor(lo, m, 64);
+    hi = __shfl_xor(hi, m, 64);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double cn_wave_min_d(double v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmin(v, cn_shfl_xor_d(v, m));
+    return v;
+}
+__device__ __forceinline__ int cn_wave_min_i(int v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = min(v, __shfl_xor(v, m, 64));
+    return v;
+}
+__device__ __forceinline__ int cn_wave_max_i(int v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = max(v, __shfl_xor(v, m, 64));
+    return v;
+}
+__device__ __forceinline__ int cn_wave_sum_i(int v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}

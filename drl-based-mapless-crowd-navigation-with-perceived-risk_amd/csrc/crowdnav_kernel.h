@@ -1,0 +1,50 @@
+// crowdnav_kernel.h -- kernel argument block shared by the device code and the C-ABI host code.
+#pragma once
+#include <stdint.h>
+#include "../../include/crowdnav.h"
+
+enum { CN_MODE_STEP = 0, CN_MODE_RESET = 1 };
+
+struct CnKParams {
+    // sizes
+    int32_t N, P, R, K;
+    int32_t max_steps, ped_mode, dt_ms, scan_latency_ms, settle_ms, ped_cycle_ms, ped_stagger_ms;
+    int32_t mode, auto_reset, max_conf;
+    int64_t env_index_base;
+    uint64_t seed;
+    // constants (cn_config)
+    double room_half, ped_radius, ped_vmax, robot_clearance, lidar_min, lidar_max, lidar_offset_x;
+    double max_scan_range, min_scan_range, goal_x, goal_y, start_x, start_y, spawn_x, spawn_y, spawn_yaw;
+    double waypoint_radius, goal_eps, angle_inc_deg;
+    // tables (device)
+    const double* lidar_c;  // [R] cos(k * span/(R-1)), deterministic sincos
+    const double* lidar_s;  // [R]
+    const double* poly_c;   // [64] cos(-k*pi/32)
+    const double* poly_s;   // [64]
+    // env state (device, library-owned)
+    double* sd;             // [N, CN_SD_COUNT]
+    int32_t* si;            // [N, CN_SI_COUNT]
+    double* ped_p;          // [N, P, 2]
+    double* ped_v;          // [N, P, 2]
+    const double* ped_init; // [N, P, 2]
+    const double* ped_preset; // [N, P, 2]
+    double* trk;            // [N, CN_TF_COUNT, CN_MAX_TRACKS]
+    // caller-owned I/O (device)
+    const float* action;
+    const int32_t* step_counter;
+    const uint8_t* mask;
+    float* obs;
+    float* final_obs;
+    double* obs_f64;
+    float* reward;
+    uint8_t* done;
+    int32_t* topk_idx;
+};
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+size_t cn_lds_bytes(int R, int P, int K, int max_conf);
+#ifdef __cplusplus
+}
+#endif

@@ -1,0 +1,152 @@
+/*
+ * crowdnav.h -- C-ABI of libcrowdnav.so, the MI355X-native batched crowd-navigation environment.
+ *
+ * The reference has no FFI layer: its hot path is the Python object `Env`
+ * (turtlebot3_rl_sim/src/environment_stage_1_nobonus.py:42) driven by
+ * start_td3_training.py:106-166 and backed by Gazebo + a separate crowd node
+ * (crowd_behaviors/simulate_crowd.py).  This header is the boundary a drop-in replacement
+ * exports; each entry point cites the reference interface it replaces.
+ * The Python binding a maintainer would add is shown in INTEGRATION.md and shipped in
+ * drl-based-mapless-crowd-navigation-with-perceived-risk_amd/crowdnav/_abi.py.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every array is caller-owned
+ *   - "dev" pointers are device (HBM) pointers on the handle's GPU, "host" pointers are host memory
+ *   - cn_reset / cn_step only enqueue work on `stream` (a hipStream_t; NULL = default stream)
+ *     and return immediately; no hidden synchronisation
+ *   - return value 0 = OK, negative = error; cn_last_error() gives a thread-local message;
+ *     nothing throws across the boundary
+ *   - there is NO CPU fallback: cn_create fails (CN_ERR_NO_DEVICE) when no HIP device exists
+ */
+#ifndef CROWDNAV_H
+#define CROWDNAV_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CN_ABI_VERSION 1
+#define CN_MAX_TRACKS 64      /* per-env capacity of the obstacle tracker (ENV:656-743) */
+#define CN_MAX_K 16
+
+enum {
+    CN_OK = 0,
+    CN_ERR_ARG = -1,
+    CN_ERR_CONFIG = -2,
+    CN_ERR_NO_DEVICE = -3,
+    CN_ERR_HIP = -4,
+    CN_ERR_SIZE = -5
+};
+
+/* per-env status bits (cn_get_counters column 6) */
+enum { CN_ST_TRACK_OVERFLOW = 1, CN_ST_TTC_ZERO = 2, CN_ST_DT_ZERO = 4, CN_ST_CONF_OVERFLOW = 8 };
+
+/* Every field of Env.__init__'s rosparam reads (ENV:71-91), the robot/lidar constants of the
+ * URDF/XACRO and world files, and the crowd node's constants.  SURVEY.md appendix B cites each. */
+typedef struct cn_config {
+    int32_t n_envs;          /* N environments in this handle (this GPU's shard) */
+    int32_t n_peds;          /* P pedestrians (obstacle cylinders) per env */
+    int32_t n_rays;          /* R lidar samples (XACRO:157 -> 360); the observation uses R-1 */
+    int32_t k_obstacles;     /* K tracked obstacles in the observation (ENV:55 -> 8) */
+    int32_t max_steps;       /* Env(max_step=...) (ENV:43,91) */
+    int32_t ped_mode;        /* 0: U(-vmax,vmax) velocity per cycle (CROWD:98-126); 1: constant preset table */
+    int32_t dt_ms;           /* time.sleep(0.15) in Env.step (ENV:1201) -> 150 */
+    int32_t scan_latency_ms; /* wait_for_message('scan') (ENV:1218,1238) -> 10 */
+    int32_t settle_ms;       /* trainer's time.sleep(0.1) after reset (TRAIN:114) -> 100 */
+    int32_t ped_cycle_ms;    /* crowd node cycle: 0.1 s x number of obstacles (CROWD:128-144) */
+    int32_t ped_stagger_ms;  /* 0.1 s between consecutive obstacles' updates (CROWD:144) -> 100 */
+    int32_t reserved0;
+    int64_t env_index_base;  /* global index of env 0: RNG streams are keyed by global index */
+    uint64_t seed;
+    double room_half;        /* WORLD:926-1108 -> 1.40 */
+    double ped_radius;       /* WORLD:109 -> 0.0505 */
+    double ped_vmax;         /* CROWD:101-102 -> 0.2 */
+    double robot_clearance;  /* robot centre kept this far from the walls -> 0.09 */
+    double lidar_min;        /* XACRO:164 -> 0.08 */
+    double lidar_max;        /* XACRO:165 -> 0.60 */
+    double lidar_span;       /* XACRO:159-160 -> 6.28 rad */
+    double lidar_offset_x;   /* URDF:134-138 -> -0.032 */
+    double max_scan_range;   /* turtlebot3_world.yaml:7 -> 0.6 */
+    double min_scan_range;   /* turtlebot3_world.yaml:8 -> 0.12 (0.0 for evaluation) */
+    double goal_x, goal_y;   /* desired_pose (turtlebot3_world.yaml:10-13) */
+    double start_x, start_y; /* starting_pose: the heading offset of ENV:223-224 only */
+    double spawn_x, spawn_y, spawn_yaw; /* launch-file spawn pose (1.0, -1.0, 3.14) */
+    double waypoint_radius;  /* ENV:250 -> 0.3 */
+    double goal_eps;         /* ENV:1285,1303 -> 0.20 */
+} cn_config;
+
+typedef struct cn_env_s* cn_handle;
+
+/* Replaces Env.step(action, step_counter, mode="continuous") -> (state, reward, done)
+ * (ENV:1164-1225) for N envs at once. */
+typedef struct cn_step_io {
+    const float* action;         /* dev [N,2]  (v, w), already clipped by the caller (TD3:214-215) */
+    const int32_t* step_counter; /* dev [N] 1-based (TRAIN:125) or NULL = per-env internal counter */
+    float* obs;                  /* dev [N, 366+4K]; with auto_reset: first obs of the new episode where done */
+    float* final_obs;            /* dev [N, 366+4K] or NULL: the observation Env.step returned (terminal if done) */
+    double* obs_f64;             /* dev [N, 366+4K] or NULL: `obs` in float64 (the reference's dtype) */
+    float* reward;               /* dev [N] */
+    uint8_t* done;               /* dev [N] */
+    int32_t* topk_idx;           /* dev [N,K] or NULL: tracker slot of each feature row, -1 = padding */
+    int32_t auto_reset;          /* !=0: finished envs run Env.reset() (+TRAIN:114-116) inside the call */
+    int32_t reserved;
+} cn_step_io;
+
+int cn_abi_version(void);
+const char* cn_last_error(void);
+
+/* Env.__init__ (ENV:43-168).  device = HIP device ordinal. */
+int cn_create(const cn_config* cfg, int device, cn_handle* out);
+void cn_destroy(cn_handle h);
+int cn_obs_dim(cn_handle h);                       /* 366 + 4K (ENV:1038-1039) */
+int cn_config_of(cn_handle h, cn_config* out);
+
+/* World description (WORLD initial poses / scripted-crowd velocity tables), host arrays [N,P,2]. */
+int cn_set_ped_init(cn_handle h, const double* xy_host);
+int cn_get_ped_init(cn_handle h, double* xy_host);
+int cn_set_ped_preset_vel(cn_handle h, const double* vxy_host);
+
+/* Env.reset() (ENV:1227-1263) followed by the trainer's sleep(0.1) and `env.done = False`
+ * (TRAIN:114-116).  mask: dev [N] or NULL (= all). obs_f64 may be NULL. */
+int cn_reset(cn_handle h, const uint8_t* mask, float* obs, double* obs_f64, void* stream);
+int cn_step(cn_handle h, const cn_step_io* io, void* stream);
+
+/* get_episode_status / get_*_safety_violation_status inputs (ENV:1265-1283).
+ * out: dev [N,8] = ego_viol, social_viol, obstacle_present_steps, ep_steps, success, failure, status, n_tracks */
+int cn_get_counters(cn_handle h, int32_t* out, void* stream);
+/* return of the last finished episode and running return, dev [N] each (either may be NULL) */
+int cn_get_returns(cn_handle h, float* last_return, float* running_return, void* stream);
+
+/* Parity/debug view of one env (synchronises).  host buffers, any may be NULL:
+ *   scalars[24] (layout: CN_SD_* below), robot_ped (5 + 4P doubles: x,y,yaw,v,w, ped xy, ped vxy),
+ *   tracks [CN_MAX_TRACKS*12] field-major (CN_TF_*), ints[16] (CN_SI_*) */
+int cn_debug_env(cn_handle h, int env, double* scalars, double* robot_ped, double* tracks, int32_t* ints);
+
+/* Whole-state snapshot for deterministic replay. */
+size_t cn_snapshot_size(cn_handle h);
+int cn_snapshot(cn_handle h, void* host_buf, size_t size);
+int cn_restore(cn_handle h, const void* host_buf, size_t size);
+
+/* float64 scalar record per env */
+enum {
+    CN_SD_RX = 0, CN_SD_RY, CN_SD_RYAW, CN_SD_RV, CN_SD_RW, CN_SD_CLOCK, CN_SD_WPX, CN_SD_WPY,
+    CN_SD_PREV_DIST, CN_SD_PREV_HEAD, CN_SD_DQ0X, CN_SD_DQ0Y, CN_SD_DQ1X, CN_SD_DQ1Y, CN_SD_TS,
+    CN_SD_BB, CN_SD_EGO, CN_SD_CPROB, CN_SD_EP_RETURN, CN_SD_LAST_RETURN, CN_SD_COUNT = 24
+};
+/* int32 scalar record per env */
+enum {
+    CN_SI_DONE = 0, CN_SI_DQ_LEN, CN_SI_NTRACKS, CN_SI_EGO_VIOL, CN_SI_SOCIAL_VIOL, CN_SI_OBST_STEPS,
+    CN_SI_SUCCESS, CN_SI_FAILURE, CN_SI_EP_STEP, CN_SI_STATUS, CN_SI_NCONF, CN_SI_NENTRIES,
+    CN_SI_CROWD_LO, CN_SI_CROWD_HI, CN_SI_COUNT = 16
+};
+/* track record fields (ENV:663-670: pose, range, deque(<=2), time stamp, speed, velocity) */
+enum {
+    CN_TF_PX = 0, CN_TF_PY, CN_TF_DIST, CN_TF_D0X, CN_TF_D0Y, CN_TF_D1X, CN_TF_D1Y, CN_TF_T, CN_TF_SPEED,
+    CN_TF_VX, CN_TF_VY, CN_TF_DQLEN, CN_TF_COUNT = 12
+};
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -72,7 +72,8 @@ def gen_seq(name, kw, episodes, arange):
         obs = h.reset()
         push(h.trace[-1], (0.0, 0.0), obs, 0.0, False)
         for st in range(max_steps):
-            a = (float(rng.uniform(arange[0], arange[1])), float(rng.uniform(arange[2], arange[3])))
+            # float32-representable: the product's ABI takes float32 actions (the TD3 actor's dtype)
+            a = (float(np.float32(rng.uniform(arange[0], arange[1]))), float(np.float32(rng.uniform(arange[2], arange[3]))))
             obs, r, d = h.step(a, st + 1)
             push(h.trace[-1], a, obs, r, d)
             if d:

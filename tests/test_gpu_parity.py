@@ -1,0 +1,171 @@
+"""Parity tests proper: the HIP path (libcrowdnav.so through the C-ABI) against the CPU oracle on the
+same seeded inputs, and against the golden runs the REFERENCE's own Python produced.
+
+Bar (BASELINE.json north_star): obstacle indices and done flags bit-exact; float scan / reward within
+1e-5.  The simulator half (pedestrians, diff-drive, lidar) is bit-reproducible by construction
+(explicit fma, deterministic sincos), so in practice every observation value matches exactly."""
+import numpy as np
+import pytest
+
+from conftest import load_seq
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _pair(oracle_mod, **kw):
+    import torch
+    from crowdnav import Config
+    from crowdnav.env import VecEnv
+    cfg = Config(**kw)
+    env = VecEnv(cfg)
+    env.enable_f64_obs()
+    orc = oracle_mod.Oracle(cfg.as_dict())
+    return torch, env, orc
+
+
+def _compare_rollout(oracle_mod, steps, seed, **kw):
+    torch, env, orc = _pair(oracle_mod, seed=seed, **kw)
+    N = env.N
+    env.reset(); torch.cuda.synchronize()
+    oc = orc.reset()
+    og = env.obs_f64.cpu().numpy()
+    assert np.abs(og - oc).max() <= TOL
+    assert np.array_equal(env.obs.cpu().numpy(), oc.astype(np.float32))
+    rng = np.random.default_rng(seed)
+    n_done = 0
+    exact_rows = 0
+    for t in range(steps):
+        act = np.stack([rng.uniform(0, 0.22, N), rng.uniform(-2, 2, N)], 1).astype(np.float32)
+        env.step(torch.from_numpy(act).cuda(), auto_reset=True, want_final=True)
+        torch.cuda.synchronize()
+        oc, rc, dc, ic, fc = orc.step(act.astype(np.float64), auto_reset=True, want_final=True)
+        dg = env.done.cpu().numpy()
+        assert np.array_equal(dg, dc), "done flags differ at step %d" % t                       # bit-exact
+        assert np.array_equal(env.topk_idx.cpu().numpy(), ic), "top-K indices differ at step %d" % t  # bit-exact
+        assert np.abs(env.reward.cpu().numpy() - rc).max() <= TOL, "reward at step %d" % t
+        og = env.obs_f64.cpu().numpy()
+        assert np.abs(og - oc).max() <= TOL, "obs at step %d: %g" % (t, np.abs(og - oc).max())
+        assert np.abs(env.final_obs.cpu().numpy() - fc.astype(np.float32)).max() <= TOL
+        exact_rows += int((og == oc).all(1).sum())
+        n_done += int(dc.sum())
+    assert np.array_equal(env.counters().cpu().numpy()[:, :6], orc.counters())
+    lr, rr = env.returns()
+    assert np.abs(lr.cpu().numpy() - orc.returns()).max() <= 1e-3
+    # tracker tables of a few envs, bit for bit
+    for e in range(0, N, max(1, N // 8)):
+        g = env.debug_env(e); c = orc.debug(e)
+        assert g["n_tracks"] == c["n_tracks"]
+        assert np.array_equal(g["track_pose"], c["track_pose"])
+        assert np.array_equal(g["track_dist"], c["track_dist"])
+        assert np.allclose(g["track_speed"], c["track_speed"], rtol=1e-12, atol=0)
+        assert np.allclose(g["sd"][:5], orc.sim_state(e)[0], rtol=0, atol=0)  # robot state identical
+    return n_done, exact_rows / float(steps * N)
+
+
+def test_rollout_parity_train_config(oracle_mod):
+    n_done, frac = _compare_rollout(oracle_mod, steps=150, seed=3, n_envs=64, n_peds=20, max_steps=60)
+    assert n_done > 20          # auto-reset path exercised
+    assert frac > 0.999
+
+
+def test_rollout_parity_dense_crowd(oracle_mod):
+    # 100 pedestrians in the small room: > K tracks on most steps ("keep the K lowest", ENV:882-883)
+    n_done, frac = _compare_rollout(oracle_mod, steps=60, seed=5, n_envs=32, n_peds=100, max_steps=40)
+    assert frac > 0.999
+
+
+def test_rollout_parity_eval_mode_and_k4(oracle_mod):
+    _compare_rollout(oracle_mod, steps=80, seed=9, n_envs=16, n_peds=60, max_steps=50, min_scan_range=0.0, k_obstacles=4)
+
+
+def test_rollout_parity_720_rays(oracle_mod):
+    # BASELINE config 5 shape (100 pedestrians, 720 rays, 2.4 m room); small N so the oracle finishes in seconds
+    _compare_rollout(oracle_mod, steps=30, seed=11, n_envs=8, n_peds=100, n_rays=720, room_half=2.4, max_steps=25)
+
+
+@pytest.mark.parametrize("name", ["train20", "dense100", "eval60", "k4"])
+def test_reproduces_reference_golden_run(name):
+    """N=1, driven only by the recorded actions: the HIP path reproduces what the REFERENCE's Python
+    returned in the golden run (observations, rewards, done flags)."""
+    import torch
+    from crowdnav import Config
+    from crowdnav.env import VecEnv
+    z, kw = load_seq(name)
+    env = VecEnv(Config(n_envs=1, **kw))
+    env.enable_f64_obs()
+    env.set_ped_init(z["ped_init"])
+    exact = 0
+    for i in range(len(z["now"])):
+        if z["is_reset"][i]:
+            env.reset()
+        else:
+            assert np.all(z["action"][i] == z["action"][i].astype(np.float32))  # goldens use float32 actions
+            a = torch.tensor(z["action"][i][None, :], dtype=torch.float32, device="cuda")
+            env.step(a, step_counter=[int(z["step_counter"][i])], auto_reset=False)
+        torch.cuda.synchronize()
+        og = env.obs_f64[0].cpu().numpy()
+        if not z["is_reset"][i]:
+            assert bool(env.done[0].item()) == bool(z["done"][i]), (name, i)
+            assert float(env.reward[0].item()) == z["reward"][i], (name, i)
+        assert np.abs(og - z["obs"][i]).max() <= TOL, (name, i, np.abs(og - z["obs"][i]).max())
+        exact += int(np.array_equal(og, z["obs"][i]))
+    assert exact >= 0.99 * len(z["now"])
+
+
+def test_snapshot_restore_replays_bit_exact():
+    import torch
+    from crowdnav import Config
+    from crowdnav.env import VecEnv
+    env = VecEnv(Config(n_envs=32, n_peds=20, seed=21, max_steps=50))
+    env.reset()
+    g = torch.Generator(device="cpu").manual_seed(0)
+    acts = [torch.stack([torch.rand(32, generator=g) * 0.22, torch.rand(32, generator=g) * 4 - 2], 1).cuda() for _ in range(40)]
+    for a in acts[:10]:
+        env.step(a)
+    snap = env.snapshot()
+    outs = []
+    for a in acts[10:]:
+        o, r, d = env.step(a)
+        outs.append((o.clone(), r.clone(), d.clone()))
+    env.restore(snap)
+    for a, (o0, r0, d0) in zip(acts[10:], outs):
+        o, r, d = env.step(a)
+        assert torch.equal(o, o0) and torch.equal(r, r0) and torch.equal(d, d0)
+
+
+def test_sharding_is_invariant_to_the_split():
+    """Envs are keyed by global index: 2 shards of 16 == 1 handle of 32 (the multi-GPU layout)."""
+    import torch
+    from crowdnav import Config
+    from crowdnav.env import VecEnv
+    full = VecEnv(Config(n_envs=32, seed=33, max_steps=40))
+    a_ = VecEnv(Config(n_envs=16, seed=33, max_steps=40, env_index_base=0))
+    b_ = VecEnv(Config(n_envs=16, seed=33, max_steps=40, env_index_base=16))
+    full.reset(); a_.reset(); b_.reset()
+    g = torch.Generator(device="cpu").manual_seed(1)
+    for _ in range(60):
+        act = torch.stack([torch.rand(32, generator=g) * 0.22, torch.rand(32, generator=g) * 4 - 2], 1).cuda()
+        o, r, d = full.step(act)
+        oa, ra, da = a_.step(act[:16].contiguous())
+        ob, rb, db = b_.step(act[16:].contiguous())
+        assert torch.equal(o, torch.cat([oa, ob])) and torch.equal(r, torch.cat([ra, rb])) and torch.equal(d, torch.cat([da, db]))
+
+
+def test_env_wrapper_has_reference_surface():
+    """The N=1 `Env` mirror: constructor, reset/step return types, status getters."""
+    from crowdnav.env import Env
+    env = Env(action_dim=2, max_step=30)
+    obs = env.reset()
+    assert isinstance(obs, np.ndarray) and obs.shape == (398,) and obs.dtype == np.float64
+    env.done = False
+    for step in range(30):
+        obs, reward, done = env.step([0.1, 0.3], step + 1, mode="continuous")
+        assert isinstance(reward, float) and isinstance(done, bool) and obs.shape == (398,)
+        if done:
+            break
+    assert done  # max_step reached at the latest
+    s, f = env.get_episode_status()
+    assert s != f
+    assert env.k_obstacle_count == 8
+    env.shutdown()
