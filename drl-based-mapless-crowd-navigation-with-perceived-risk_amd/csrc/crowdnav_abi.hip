@@ -172,6 +172,9 @@ extern "C" void cn_destroy(cn_handle h)
     delete h;
 }
 
+// PROFILING ONLY: stage-skipping mask for time attribution (tools/ablate.py); not part of crowdnav.h
+extern "C" int cn_debug_set_ablate(cn_handle h, int mask) { if (!h) return CN_ERR_ARG; h->kp.ablate = mask; return CN_OK; }
+
 extern "C" int cn_obs_dim(cn_handle h) { return h ? h->D : fail(CN_ERR_ARG, "null handle"); }
 
 extern "C" int cn_config_of(cn_handle h, cn_config* out)

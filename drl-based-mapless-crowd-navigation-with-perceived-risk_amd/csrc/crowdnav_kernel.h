@@ -10,6 +10,7 @@ struct CnKParams {
     int32_t N, P, R, K;
     int32_t max_steps, ped_mode, dt_ms, scan_latency_ms, settle_ms, ped_cycle_ms, ped_stagger_ms;
     int32_t mode, auto_reset, max_conf;
+    int32_t ablate;          // PROFILING ONLY (cn_debug_set_ablate): skips stages, results are then invalid
     int64_t env_index_base;
     uint64_t seed;
     // constants (cn_config)

@@ -220,7 +220,7 @@ __device__ void observe(const CnKParams& p, EnvRegs& e, const Lds& L, int env, i
         if (dy > 0.0) t = fmin(t, (h - oy) / dy);
         else if (dy < 0.0) t = fmin(t, (-h - oy) / dy);
         if (t < p.lidar_min) t = p.lidar_min;
-        for (int j = 0; j < p.P; ++j) {
+        for (int j = 0; j < ((p.ablate & 1) ? 0 : p.P); ++j) {
             double ocx = L.ped[2 * j] - ox, ocy = L.ped[2 * j + 1] - oy;
             double b = fma(ocx, dx, ocy * dy);
             double cc = fma(ocx, ocx, fma(ocy, ocy, -rr));
@@ -323,7 +323,7 @@ __device__ void observe(const CnKParams& p, EnvRegs& e, const Lds& L, int env, i
     {
         int last_t = TY_NONE, last_s = 0, du = 0;
         int fi = L.flags[0];
-        for (int i = 0; i < n - 1; ++i) {
+        for (int i = 0; i < ((p.ablate & 2) ? 0 : n - 1); ++i) {
             int fn = L.flags[i + 1];
             if (!(fi & 1)) {
                 int ty, src = i;
@@ -403,7 +403,7 @@ __device__ void observe(const CnKParams& p, EnvRegs& e, const Lds& L, int env, i
     int nconf = 0;
     {
         int k0 = 0, no = 0, nw = 0, nn = 0, occ = 0;
-        for (int k = 0; k < n; ++k) {
+        for (int k = 0; k < ((p.ablate & 4) ? 0 : n); ++k) {
             int ray = ORDER(k);
             int t = L.tinfo[ray] & 3;
             no += (t == TY_O); nw += (t == TY_W); nn += (t == TY_NONE);
@@ -454,6 +454,7 @@ __device__ void observe(const CnKParams& p, EnvRegs& e, const Lds& L, int env, i
     double* T = L.trk;
 #define TRK(f, i) T[(f) * CN_MAX_TRACKS + (i)]
     bool add_unchecked = false;
+    if (p.ablate & 16) { e.ntracks = 0; nconf = 0; }
     if (e.ntracks == 0) {
         for (int j = lane; j < nconf; j += 64) L.checked[j] = 0;
         add_unchecked = true;  // every 'o' object becomes a track
@@ -556,7 +557,7 @@ __device__ void observe(const CnKParams& p, EnvRegs& e, const Lds& L, int env, i
     __syncthreads();
 
     // ---- ENV:769-996 collision cone / collision probability / top-K -------------------------------
-    if (e.dq_len == 2) {
+    if (e.dq_len == 2 && !(p.ablate & 8)) {
         const double ts = e.ts;
         if (ts == 0.0) e.status |= CN_ST_DT_ZERO;
         const int nt = e.ntracks;
