@@ -42,7 +42,10 @@ size_t cn_lds_bytes(int R, int P, int K, int max_conf)
     b += 8 * (size_t)max_conf * 3;                // cfx cfy cfd
     b += 8 * (size_t)CN_MAX_TRACKS;               // cpv
     b += 8 * (size_t)(7 + 4 * K + 1);             // tail
-    b += 4 * n * 5;                               // flags tmpi tinfo segend brk
+    b += 8 * (size_t)(CN_NMASK * CN_MAXW);        // bit words
+    b += 4 * n;                                   // srcidx
+    b += 4 * (size_t)(3 * CN_MAXW);               // wbase
+    b += 4 * (size_t)(P + 1);                     // nearidx
     b += 4 * (size_t)max_conf * 2;                // cft checked
     b += 4 * (size_t)CN_MAX_K;                    // kidx
     return (b + 15) & ~(size_t)15;

@@ -4,6 +4,8 @@
 #include "../../include/crowdnav.h"
 
 enum { CN_MODE_STEP = 0, CN_MODE_RESET = 1 };
+#define CN_MAXW 17         /* 64-ray bit words per env: ceil(1024/64) + 1 */
+#define CN_NMASK 13        /* number of bit-word masks kept in LDS (M_COUNT in the kernel) */
 
 struct CnKParams {
     // sizes

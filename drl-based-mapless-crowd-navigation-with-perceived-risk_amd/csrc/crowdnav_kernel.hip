@@ -18,6 +18,9 @@
 #define TY_NONE 0
 #define TY_W 1
 #define TY_O 2
+#define CN_NAN __longlong_as_double(0x7ff8000000000000LL)
+typedef unsigned long long u64;
+enum { M_NONE = 0, M_ZERO, M_EQ, M_NNONE, M_NZERO, M_ISW, M_ISO, M_ALIAS, M_BRK, M_SEG, M_KW, M_KO, M_OCC, M_COUNT };
 
 namespace {
 
@@ -30,7 +33,10 @@ struct EnvRegs {  // per-env scalars, uniform across the wave
 
 struct Lds {
     double* ptx; double* pty; double* dd; double* g; double* cg;
-    int* flags; int* tmpi; int* tinfo; int* segend; int* brk;   // flags+tmpi adjacent (reused as n doubles)
+    u64* w64;         // [M_COUNT][CN_MAXW] 64-ray bit words
+    int* srcidx;      // [n] source ray of an aliased type entry
+    int* wbase;       // [3][CN_MAXW]
+    int* nearidx;     // [P] pedestrians within lidar reach
     double* ped;      // [2P] positions
     double* trk;      // [CN_TF_COUNT][CN_MAX_TRACKS]
     double* cfx; double* cfy; double* cfd; int* cft; int* checked;   // confirmed objects
@@ -98,6 +104,14 @@ __device__ __forceinline__ double bcast_d(double v, int src)
 {
     int lo = __shfl(__double2loint(v), src, 64), hi = __shfl(__double2hiint(v), src, 64);
     return __hiloint2double(hi, lo);
+}
+
+// a wave-uniform 64-bit value, forced into scalar registers
+__device__ __forceinline__ u64 uni64(u64 v)
+{
+    unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+    unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return ((u64)hi << 32) | lo;
 }
 
 // UTL:296-314 get_local_goal_waypoints
@@ -206,6 +220,25 @@ __device__ void observe(const CnKParams& p, EnvRegs& e, const Lds& L, int env, i
     const double ox = fma(p.lidar_offset_x, cy, px), oy = fma(p.lidar_offset_x, sy, py);
     const double h = p.room_half, rr = p.ped_radius * p.ped_radius;
     const double deg2rad = CN_PI / 180.0;
+    // Pedestrians that can return a range <= lidar_max: |centre - origin| <= lidar_max + radius (+ slack).
+    // A culled pedestrian could only produce t > lidar_max, which reads as "no return" anyway, so the
+    // result is identical to testing all P (the oracle does).
+    int nnear = 0;
+    {
+        const double lim = p.lidar_max + p.ped_radius + 1e-6, lim2 = lim * lim;
+        for (int j0 = 0; j0 < p.P; j0 += 64) {
+            int j = j0 + lane;
+            bool nr = false;
+            if (j < p.P && !(p.ablate & 1)) {
+                double ocx = L.ped[2 * j] - ox, ocy = L.ped[2 * j + 1] - oy;
+                nr = fma(ocx, ocx, ocy * ocy) <= lim2;
+            }
+            u64 m = __ballot(nr);
+            if (nr) L.nearidx[nnear + __popcll(m & ((1ull << lane) - 1ull))] = j;
+            nnear += __popcll(m);
+        }
+    }
+    __syncthreads();
     double smin = 1e300;
     float* o32 = obs32 + (size_t)env * D;
     float* f32 = fin32 ? fin32 + (size_t)env * D : nullptr;
@@ -220,7 +253,8 @@ __device__ void observe(const CnKParams& p, EnvRegs& e, const Lds& L, int env, i
         if (dy > 0.0) t = fmin(t, (h - oy) / dy);
         else if (dy < 0.0) t = fmin(t, (-h - oy) / dy);
         if (t < p.lidar_min) t = p.lidar_min;
-        for (int j = 0; j < ((p.ablate & 1) ? 0 : p.P); ++j) {
+        for (int c = 0; c < nnear; ++c) {
+            int j = L.nearidx[c];
             double ocx = L.ped[2 * j] - ox, ocy = L.ped[2 * j + 1] - oy;
             double b = fma(ocx, dx, ocy * dy);
             double cc = fma(ocx, ocx, fma(ocy, ocy, -rr));
@@ -263,181 +297,224 @@ __device__ void observe(const CnKParams& p, EnvRegs& e, const Lds& L, int env, i
     smin = cn_wave_min_d(smin);
     __syncthreads();
 
-    if (step_counter == 0) {  // UTL:405-419 + ENV:294
-        double* hs = (double*)L.flags;  // flags+tmpi = 2n ints = n doubles
-        for (int i = lane; i < n; i += 64) {
-            int j = (i == n - 1) ? 0 : i + 1;
-            hs[i] = hypot(L.g[i] - L.g[j], L.cg[i] - L.cg[j]);
+    if (step_counter == 0) {  // UTL:405-419 + ENV:294: mean spacing of consecutive ground-truth end points
+        double sum = 0.0;     // Python sum(): strictly left to right
+        for (int i0 = 0; i0 < n; i0 += 64) {
+            int i = i0 + lane;
+            if (i < n) {
+                int j = (i == n - 1) ? 0 : i + 1;
+                L.cpv[lane] = hypot(L.g[i] - L.g[j], L.cg[i] - L.cg[j]);
+            }
+            __syncthreads();
+            int cnt = min(64, n - i0);
+            for (int c = 0; c < cnt; ++c) sum += L.cpv[c];
+            __syncthreads();
         }
-        __syncthreads();
-        double sum = 0.0;
-        for (int i = 0; i < n; ++i) sum += hs[i];  // Python sum(): left to right
         e.bb = sum / (double)n;
         double qx = cn_py_round(px, 1000.0), qy = cn_py_round(py, 1000.0);
         if (e.dq_len < 2) { if (e.dq_len == 0) { e.dq0x = qx; e.dq0y = qy; } else { e.dq1x = qx; e.dq1y = qy; } e.dq_len += 1; }
         else { e.dq0x = e.dq1x; e.dq0y = e.dq1y; e.dq1x = qx; e.dq1y = qy; }
-        __syncthreads();
     }
 
-    // ENV:329-346 gradients
+    const int W = (n + 63) >> 6;  // 64-ray words; ray i = bit (i & 63) of word (i >> 6)
+#define WORD(id, q) L.w64[(id) * CN_MAXW + (q)]
+#define BIT(id, i) ((WORD(id, (i) >> 6) >> ((i) & 63)) & 1ull)
+    // ENV:329-346 gradients between consecutive end points; None is carried as NaN
     for (int i = lane; i < n; i += 64) {
-        double gr = 0.0; int none = 1;
+        double gr = CN_NAN;
         if (L.dd[i] != 0.6) {
             int j = (i == n - 1) ? 0 : i + 1;
             double dy = L.pty[i] - L.pty[j];
             double q = (dy == 0) ? 0.0 : (L.ptx[i] - L.ptx[j]) / dy;
             gr = cn_py_round(q, 1000.0);
-            none = 0;
         }
         L.g[i] = gr;
-        L.flags[i] = none;
     }
     __syncthreads();
-    // ENV:348-367 change of gradient (i < n-1), then the `last_grad` value for i == n-1
+    // ENV:348-367 change of gradient: |g[i]-g[i+1]| (NaN if either is None); ray n-1 takes `last_grad`
     int lastnn = -1;
     for (int i = lane; i < n - 1; i += 64) {
-        int none = L.flags[i] | L.flags[i + 1];
-        L.cg[i] = none ? 0.0 : fabs(L.g[i] - L.g[i + 1]);
-        L.tmpi[i] = none;
-        if (!L.flags[i]) lastnn = i;
+        double gi = L.g[i];
+        L.cg[i] = fabs(gi - L.g[i + 1]);
+        if (gi == gi) lastnn = i;
     }
     lastnn = cn_wave_max_i(lastnn);
     __syncthreads();
     if (lane == 0) {
-        int none = 1; double val = 0.0;
-        if (!L.flags[n - 1] && lastnn >= 0) { none = L.tmpi[lastnn]; val = L.cg[lastnn]; }
-        L.cg[n - 1] = none ? 0.0 : val;
-        L.tmpi[n - 1] = none;
+        double gl = L.g[n - 1];
+        L.cg[n - 1] = (gl == gl && lastnn >= 0) ? L.cg[lastnn] : CN_NAN;
     }
     __syncthreads();
-    // per-ray flag word for the type machine: bit0 change is None, bit1 change == 0, bit2 |c[i]-c[i+1]| == 0
-    for (int i = lane; i < n; i += 64) {
-        int cn0 = L.tmpi[i];
-        int f = cn0 | ((!cn0 && L.cg[i] == 0) ? 2 : 0);
-        if (i < n - 1 && !cn0 && !L.tmpi[i + 1] && fabs(L.cg[i] - L.cg[i + 1]) == 0) f |= 4;
-        L.flags[i] = f;
-        L.tinfo[i] = TY_NONE;
+    // flag words for the type machine
+    for (int q = 0; q < W; ++q) {
+        int i = lane + 64 * q;
+        bool none = true, zero = false, eq = false, nnone = true, nzero = false;
+        if (i < n - 1) {  // the machine never visits ray n-1 (ENV:380-381)
+            double c0 = L.cg[i], c1 = L.cg[i + 1];
+            none = !(c0 == c0);
+            zero = (c0 == 0);
+            nnone = !(c1 == c1);
+            nzero = (c1 == 0);
+            eq = !none && !nnone && (fabs(c0 - c1) == 0);
+        }
+        u64 b0 = __ballot(none), b1 = __ballot(zero), b2 = __ballot(eq), b3 = __ballot(nnone), b4 = __ballot(nzero);
+        if (lane == 0) { WORD(M_NONE, q) = b0; WORD(M_ZERO, q) = b1; WORD(M_EQ, q) = b2; WORD(M_NNONE, q) = b3; WORD(M_NZERO, q) = b4; }
     }
     __syncthreads();
-    // ENV:372-410 object-type state machine (loop-carried: last_type, du_count); uniform serial
+    // ENV:372-410 object-type state machine.  Loop-carried state (last_type, du_count) lives in scalar
+    // registers; only occupied rays are visited (bit scan over the flag words), no memory in the loop
+    // except the rare aliasing store.
     {
         int last_t = TY_NONE, last_s = 0, du = 0;
-        int fi = L.flags[0];
-        for (int i = 0; i < ((p.ablate & 2) ? 0 : n - 1); ++i) {
-            int fn = L.flags[i + 1];
-            if (!(fi & 1)) {
+        for (int q = 0; q < W; ++q) {
+            u64 occ = ~uni64(WORD(M_NONE, q));
+            const u64 wz = uni64(WORD(M_ZERO, q)), we = uni64(WORD(M_EQ, q)), wnn = uni64(WORD(M_NNONE, q)),
+                      wnz = uni64(WORD(M_NZERO, q));
+            u64 isw = 0, iso = 0, al = 0;
+            if (p.ablate & 2) occ = 0;
+            while (occ) {
+                const int b = __builtin_ctzll(occ);
+                const u64 bit = 1ull << b;
+                occ &= occ - 1;
+                const int i = 64 * q + b;
                 int ty, src = i;
-                if (fi & 2) { ty = TY_W; last_t = TY_W; last_s = i; }
+                if (wz & bit) { ty = TY_W; last_t = TY_W; last_s = i; }
                 else {
                     ty = TY_O;
                     if (du != 1) {
-                        bool nnone = fn & 1, nzero = fn & 2;
-                        if (nzero) { ty = TY_W; last_t = TY_W; last_s = i; du = 0; }
-                        if (nnone) { /* ENV:394-395 pass */ }
-                        else if (fi & 4) { ty = TY_W; last_t = TY_W; last_s = i; du = 0; }
+                        if (wnz & bit) { ty = TY_W; last_t = TY_W; last_s = i; du = 0; }
+                        if (wnn & bit) { /* ENV:394-395 pass */ }
+                        else if (we & bit) { ty = TY_W; last_t = TY_W; last_s = i; du = 0; }
                         else { ty = last_t; src = last_s; du += 1; }
                     } else {
                         ty = TY_O; last_t = TY_O; last_s = i;
-                        if (fn & 2) du = 0;
+                        if (wnz & bit) du = 0;
                     }
                 }
-                if (lane == 0) L.tinfo[i] = ty | (src << 2);
+                if (ty == TY_W) isw |= bit;
+                else if (ty == TY_O) iso |= bit;
+                if (src != i && ty != TY_NONE) { al |= bit; if (lane == 0) L.srcidx[i] = src; }
             }
-            fi = fn;
+            if (lane == 0) { WORD(M_ISW, q) = isw; WORD(M_ISO, q) = iso; WORD(M_ALIAS, q) = al; }
         }
     }
     __syncthreads();
-    // ENV:433-445: a typed ray carries the range and pose of the ray its list was created at.
-    // Written out of place: Ad/Ax/Ay reuse the gradient arrays and the flag words (all dead now).
-    double* Ad = L.g; double* Ax = L.cg; double* Ay = (double*)L.flags;
-    {
-        int q = 0;
-        (void)q;
-        for (int i = lane; i < n; i += 64) {
-            int t = L.tinfo[i];
-            int s = (t & 3) ? (t >> 2) : i;
-            Ad[i] = L.dd[s]; Ax[i] = L.ptx[s]; Ay[i] = L.pty[s];
-        }
-    }
-    __syncthreads();
-    // ENV:448-485 association of consecutive rays; brk[i] = a segment closes after ray i
-    int fe = n, lb = -1, nsegs0 = 0;
+    // ENV:433-445: a typed ray carries the range and pose of the ray its list was created at.  In place:
+    // only aliased rays change, and the rays they copy from are never aliased themselves.
     for (int i = lane; i < n; i += 64) {
-        int brk = 1;
-        if (i < n - 1) brk = !(cn_iou3(Ax[i], Ay[i], Ax[i + 1], Ay[i + 1], e.bb) > 0.0);
-        L.brk[i] = brk;
-        if (brk) { fe = min(fe, i); nsegs0 += 1; if (i < n - 1) lb = max(lb, i); }
+        if (BIT(M_ALIAS, i)) {
+            int s_ = L.srcidx[i];
+            L.dd[i] = L.dd[s_]; L.ptx[i] = L.ptx[s_]; L.pty[i] = L.pty[s_];
+        }
     }
-    fe = cn_wave_min_i(fe);           // end of the first segment
-    lb = cn_wave_max_i(lb);           // last break before ray n-1
-    nsegs0 = cn_wave_sum_i(nsegs0);
+    __syncthreads();
+    // ENV:448-485 association of consecutive rays; brk bit i = a segment closes after ray i
+    int fe = n, lb = -1, nsegs0 = 0;
+    for (int q = 0; q < W; ++q) {
+        int i = lane + 64 * q;
+        bool brk = false;
+        if (i < n) {
+            brk = true;
+            if (i < n - 1) brk = !(cn_iou3(L.ptx[i], L.pty[i], L.ptx[i + 1], L.pty[i + 1], e.bb) > 0.0);
+        }
+        u64 bw = __ballot(brk);
+        if (lane == 0) WORD(M_BRK, q) = bw;
+        if (bw) {
+            if (fe == n) fe = 64 * q + __builtin_ctzll(bw);
+            u64 bl = (q == W - 1) ? (bw & ~(1ull << ((n - 1) & 63))) : bw;  // breaks before ray n-1
+            if (bl) lb = 64 * q + 63 - __builtin_clzll(bl);
+            nsegs0 += __popcll(bw);
+        }
+    }
     const int ls = lb + 1;            // start of the last segment
     // ENV:490-502 first <-> last with twice the box
-    bool merge = (nsegs0 > 1) && (cn_iou3(Ax[0], Ay[0], Ax[n - 1], Ay[n - 1], e.bb * 2) > 0.0);
+    bool merge = (nsegs0 > 1) && (cn_iou3(L.ptx[0], L.pty[0], L.ptx[n - 1], L.pty[n - 1], e.bb * 2) > 0.0);
     __syncthreads();
     // order-space: position k -> ray.  merged: [0..fe] ++ [ls..n-1] ++ [fe+1..ls-1]
     const int nl = n - ls;  // length of the last segment
 #define ORDER(k) (merge ? ((k) <= fe ? (k) : ((k) <= fe + nl ? ls + ((k) - fe - 1) : (k) - nl)) : (k))
-    for (int k = lane; k < n; k += 64) {
-        int ray = ORDER(k);
-        int se;
-        if (!merge) se = L.brk[ray];
-        else if (k <= fe + nl) se = (k == fe + nl);
-        else se = L.brk[ray];
-        L.segend[k] = se;
-    }
-    __syncthreads();
-    // ENV:508-566 split where free space (0.6) meets occupied; count segments
+    // ENV:508-566 split where free space (0.6) meets occupied; per-position words in order space
     int nseg = 0;
-    for (int k = lane; k < n; k += 64) {   // each position only rewrites its own flag
-        int se = L.segend[k];
-        if (!se && k < n - 1) {
-            int a06 = Ad[ORDER(k)] == 0.6, b06 = Ad[ORDER(k + 1)] == 0.6;
-            if (a06 != b06) { se = 1; L.segend[k] = 1; }
-        }
-        nseg += se;
-    }
-    nseg = cn_wave_sum_i(nseg);
-    __syncthreads();
-    // ENV:568-620 confirmation; uniform serial accumulate over order-space
-    int nconf = 0;
-    {
-        int k0 = 0, no = 0, nw = 0, nn = 0, occ = 0;
-        for (int k = 0; k < ((p.ablate & 4) ? 0 : n); ++k) {
+    for (int q = 0; q < W; ++q) {
+        int k = lane + 64 * q;
+        bool se = false, kw = false, ko = false, oc = false;
+        if (k < n) {
             int ray = ORDER(k);
-            int t = L.tinfo[ray] & 3;
-            no += (t == TY_O); nw += (t == TY_W); nn += (t == TY_NONE);
-            occ |= (Ad[ray] != 0.6);
-            if (L.segend[k]) {
-                int len = k - k0 + 1;
-                if (occ && len >= 4) {
-                    int m = ORDER(k0 + len / 2);  // ENV:577 Python-2 integer division
-                    double dm = Ad[m];
-                    int est = 3 + (int)floor(29 * (p.max_scan_range - dm) / (p.max_scan_range - p.min_scan_range));
-                    int mn = len < est ? len : est;
-                    double score = (double)no / (double)mn;
-                    int kinds = (no > 0) + (nw > 0) + (nn > 0);
-                    int obj = -1;
-                    if (kinds > 1) {
-                        if (score >= 0.5) obj = (no > nw) ? TY_O : TY_W;
-                        else if (len <= est) obj = (no > nw) ? TY_O : TY_W;
-                        else obj = TY_W;
-                    } else {
-                        int lim = nseg < est ? nseg : est;  // ENV:608,615
-                        if (len > lim) obj = (nw > 0) ? TY_W : TY_O;
-                    }
-                    if (obj >= 0) {
-                        if (nconf < p.max_conf) {
-                            if (lane == 0) { L.cft[nconf] = obj; L.cfx[nconf] = Ax[m]; L.cfy[nconf] = Ay[m]; L.cfd[nconf] = dm; }
-                            ++nconf;
-                        } else e.status |= CN_ST_CONF_OVERFLOW;
-                    }
+            if (!merge) se = BIT(M_BRK, ray);
+            else if (k <= fe + nl) se = (k == fe + nl);
+            else se = BIT(M_BRK, ray);
+            oc = (L.dd[ray] != 0.6);
+            if (!se && k < n - 1) {
+                bool oc1 = (L.dd[ORDER(k + 1)] != 0.6);
+                if (oc != oc1) se = true;
+            }
+            kw = BIT(M_ISW, ray); ko = BIT(M_ISO, ray);
+        }
+        u64 b0 = __ballot(se), b1 = __ballot(kw), b2 = __ballot(ko), b3 = __ballot(oc);
+        if (lane == 0) { WORD(M_SEG, q) = b0; WORD(M_KW, q) = b1; WORD(M_KO, q) = b2; WORD(M_OCC, q) = b3; }
+        nseg += __popcll(b0);
+    }
+    __syncthreads();
+    // per-word running totals: types seen before word q, last segment end before word q
+    if (lane == 0) {
+        int bw = 0, bo = 0, le = -1;
+        for (int q = 0; q < W; ++q) {
+            L.wbase[q] = bw; L.wbase[CN_MAXW + q] = bo; L.wbase[2 * CN_MAXW + q] = le;
+            u64 sw = WORD(M_SEG, q);
+            bw += __popcll(WORD(M_KW, q)); bo += __popcll(WORD(M_KO, q));
+            if (sw) le = 64 * q + 63 - __builtin_clzll(sw);
+        }
+    }
+    __syncthreads();
+    // ENV:568-620 confirmation: every lane that owns a segment end evaluates its segment
+    int nconf = 0;
+    for (int q = 0; q < ((p.ablate & 4) ? 0 : W); ++q) {
+        const int k = lane + 64 * q;
+        const u64 sw = uni64(WORD(M_SEG, q));
+        int obj = -1, m = 0; double dm = 0.0;
+        if ((sw >> lane) & 1ull) {
+            const u64 low = sw & ((1ull << lane) - 1ull);
+            const int pe = low ? (64 * q + 63 - __builtin_clzll(low)) : L.wbase[2 * CN_MAXW + q];  // previous segment end
+            const int k0 = pe + 1, len = k - pe;
+            const u64 incl = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+            int cw = L.wbase[q] + __popcll(WORD(M_KW, q) & incl);
+            int co = L.wbase[CN_MAXW + q] + __popcll(WORD(M_KO, q) & incl);
+            if (pe >= 0) {
+                const int qp = pe >> 6, bp = pe & 63;
+                const u64 inclp = (bp == 63) ? ~0ull : ((2ull << bp) - 1ull);
+                cw -= L.wbase[qp] + __popcll(WORD(M_KW, qp) & inclp);
+                co -= L.wbase[CN_MAXW + qp] + __popcll(WORD(M_KO, qp) & inclp);
+            }
+            const int no = co, nw = cw, nn = len - no - nw;
+            const bool occ = (WORD(M_OCC, q) >> lane) & 1ull;  // segments are homogeneous after the split
+            if (occ && len >= 4) {
+                m = ORDER(k0 + len / 2);  // ENV:577 Python-2 integer division
+                dm = L.dd[m];
+                int est = 3 + (int)floor(29 * (p.max_scan_range - dm) / (p.max_scan_range - p.min_scan_range));
+                int mn = len < est ? len : est;
+                double score = (double)no / (double)mn;
+                int kinds = (no > 0) + (nw > 0) + (nn > 0);
+                if (kinds > 1) {
+                    if (score >= 0.5) obj = (no > nw) ? TY_O : TY_W;
+                    else if (len <= est) obj = (no > nw) ? TY_O : TY_W;
+                    else obj = TY_W;
+                } else {
+                    int lim = nseg < est ? nseg : est;  // ENV:608,615: compares with the NUMBER of segments
+                    if (len > lim) obj = (nw > 0) ? TY_W : TY_O;
                 }
-                k0 = k + 1; no = nw = nn = occ = 0;
             }
         }
+        const u64 cwd = __ballot(obj >= 0);
+        if (obj >= 0) {
+            int slot = nconf + __popcll(cwd & ((1ull << lane) - 1ull));
+            if (slot < p.max_conf) { L.cft[slot] = obj; L.cfx[slot] = L.ptx[m]; L.cfy[slot] = L.pty[m]; L.cfd[slot] = dm; }
+        }
+        nconf += __popcll(cwd);
     }
+    if (nconf > p.max_conf) { nconf = p.max_conf; e.status |= CN_ST_CONF_OVERFLOW; }
 #undef ORDER
+#undef BIT
+#undef WORD
     e.nconf = nconf;
     __syncthreads();
 
@@ -734,11 +811,10 @@ extern "C" __global__ void __launch_bounds__(64) cn_env_kernel(CnKParams p)
         L.cfd = (double*)q; q += 8 * (size_t)p.max_conf;
         L.cpv = (double*)q; q += 8 * (size_t)CN_MAX_TRACKS;
         L.tail = (double*)q; q += 8 * (size_t)(7 + 4 * K + 1);
-        L.flags = (int*)q; q += 4 * (size_t)n;   // flags and tmpi must stay adjacent and 8-byte aligned (reused as n doubles)
-        L.tmpi = (int*)q; q += 4 * (size_t)n;
-        L.tinfo = (int*)q; q += 4 * (size_t)n;
-        L.segend = (int*)q; q += 4 * (size_t)n;
-        L.brk = (int*)q; q += 4 * (size_t)n;
+        L.w64 = (u64*)q; q += 8 * (size_t)(M_COUNT * CN_MAXW);
+        L.srcidx = (int*)q; q += 4 * (size_t)n;
+        L.wbase = (int*)q; q += 4 * (size_t)(3 * CN_MAXW);
+        L.nearidx = (int*)q; q += 4 * (size_t)(P + 1);
         L.cft = (int*)q; q += 4 * (size_t)p.max_conf;
         L.checked = (int*)q; q += 4 * (size_t)p.max_conf;
         L.kidx = (int*)q; q += 4 * (size_t)CN_MAX_K;
