@@ -1,0 +1,80 @@
+"""Batched counterpart of the reference's training loop (start_td3_training.py:104-168).
+
+The reference drives ONE env: reset() -> done=False -> for step: act -> env.step(a, step+1, "continuous")
+-> accumulate reward -> on done: scores, CSV row.  Here N envs advance per launch; each env keeps its own
+1-based step counter and return on the device, finished envs are reset inside the same launch
+(cn_step auto_reset), and episode statistics come back as tensors.  Across GPUs the envs shard by global
+index with no data-path collective; the one exchange is the all-gather of per-env episode returns."""
+import csv
+import os
+
+import torch
+
+
+def shard_range(n_total, rank, world):
+    """Contiguous shard of global env indices owned by `rank`."""
+    per = n_total // world
+    assert per * world == n_total, "envs must divide evenly across ranks"
+    return rank * per, per
+
+
+def gather_returns(local_returns):
+    """All-gather of per-env episode returns across ranks (RCCL over xGMI on GPUs, gloo on CPU).
+    Identity when torch.distributed is not initialised."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return local_returns
+    world = dist.get_world_size()
+    out = torch.empty(world * local_returns.numel(), dtype=local_returns.dtype, device=local_returns.device)
+    dist.all_gather_into_tensor(out, local_returns.contiguous())
+    return out
+
+
+class EpisodeStats:
+    """Per-episode rows in the reference's CSV schema (utils.py:53-64)."""
+    HEADERS = ['episode_number', 'success_episode', 'failure_episode', 'episode_reward', 'episode_step',
+               'ego_safety_score', 'social_safety_score', 'timelapse']
+
+    def __init__(self):
+        self.rows = []
+
+    def add(self, success, failure, reward, steps, ego, social, timelapse=0.0):
+        self.rows.append([len(self.rows) + 1, bool(success), bool(failure), float(reward), int(steps), float(ego),
+                          float(social), float(timelapse)])
+
+    def write_csv(self, outdir, filename):
+        os.makedirs(outdir, exist_ok=True)
+        path = os.path.join(outdir, filename + ".csv")
+        with open(path, "w", newline="") as fp:
+            w = csv.writer(fp, dialect="excel")
+            w.writerow(self.HEADERS)
+            w.writerows(self.rows)
+        return path
+
+
+def rollout(env, agent, n_steps, learn=False, add_noise=True, stats=None):
+    """Actor-in-the-loop rollout (BASELINE config 3).  Returns total env-steps taken.
+    `env` is a crowdnav.env.VecEnv; `agent` a crowdnav.td3.Agent on the same device."""
+    obs = env.obs if getattr(env, "_started", False) else env.reset()
+    env._started = True
+    for t in range(n_steps):
+        act = agent.act(obs, add_noise=add_noise)
+        if learn or stats is not None:
+            prev = obs.clone()
+            pre_counters = env.counters().clone() if stats is not None else None
+        obs, reward, done = env.step(act, auto_reset=True, want_final=learn or stats is not None)
+        if learn:
+            agent.memory.add(prev, act, reward, env.final_obs, done)
+            agent.learn(t)
+        if stats is not None and bool(done.any()):
+            # counters are reset inside the launch for finished envs; success/failure and returns persist
+            c = env.counters().cpu()
+            ret, _ = env.returns()
+            ret = ret.cpu()
+            pc = pre_counters.cpu()
+            for e in torch.nonzero(done.cpu()).flatten().tolist():
+                seen = int(pc[e, 2])
+                ego = 1.0 - pc[e, 0].item() / seen if seen else float("nan")     # ENV:1277-1283
+                soc = 1.0 - pc[e, 1].item() / seen if seen else float("nan")     # ENV:1269-1275
+                stats.add(c[e, 4].item(), c[e, 5].item(), ret[e].item(), int(pc[e, 3]) + 1, ego, soc)
+    return n_steps * env.N

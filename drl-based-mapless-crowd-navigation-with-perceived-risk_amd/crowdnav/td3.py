@@ -1,0 +1,135 @@
+"""TD3 pieces the rollout needs, in PyTorch-ROCm (the caller of the hot path).
+
+Mirrors td3.py of the reference: Actor 3 x Linear(256) with sigmoid*max_lin_vel / tanh*max_ang_vel heads
+(TD3:81-106), Critic (TD3:109-126), Gaussian exploration sigma = 1.0 (TD3:67-78), clipping to
+v in [0, 0.22], w in [-2, 2] (TD3:214-215), and the TD3 update (TD3:225-285) with the hyper-parameters of
+start_td3_training.py:62-72.  The replay buffer is a device-resident ring so a vectorised env never
+leaves the GPU.  No custom kernels here: these are plain library GEMMs (hipBLASLt)."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class Actor(nn.Module):
+    def __init__(self, num_inputs=398, num_actions=2, hidden_size=256, max_lin_vel=0.22, max_ang_vel=2.0):
+        super().__init__()
+        self.linear1 = nn.Linear(num_inputs, hidden_size)
+        self.linear2 = nn.Linear(hidden_size, hidden_size)
+        self.linear3 = nn.Linear(hidden_size, num_actions)
+        self.max_lin_vel, self.max_ang_vel = max_lin_vel, max_ang_vel
+
+    def forward(self, state):
+        x = F.relu(self.linear1(state))
+        x = F.relu(self.linear2(x))
+        a = self.linear3(x)
+        return torch.stack([torch.sigmoid(a[:, 0]) * self.max_lin_vel, torch.tanh(a[:, 1]) * self.max_ang_vel], 1)
+
+
+class Critic(nn.Module):
+    def __init__(self, num_inputs=398, num_actions=2, hidden_size=256):
+        super().__init__()
+        self.linear1 = nn.Linear(num_inputs + num_actions, hidden_size)
+        self.linear2 = nn.Linear(hidden_size, hidden_size)
+        self.linear3 = nn.Linear(hidden_size, 1)
+
+    def forward(self, state, action):
+        x = torch.cat([state, action], 1)
+        x = F.relu(self.linear1(x))
+        x = F.relu(self.linear2(x))
+        return self.linear3(x)
+
+
+class DeviceReplay:
+    """Ring buffer on the device (ReplayBuffer, TD3:19-37, without the Python list)."""
+
+    def __init__(self, capacity, obs_dim, device):
+        self.cap, self.pos, self.size = int(capacity), 0, 0
+        self.s = torch.empty((capacity, obs_dim), dtype=torch.float32, device=device)
+        self.s2 = torch.empty((capacity, obs_dim), dtype=torch.float32, device=device)
+        self.a = torch.empty((capacity, 2), dtype=torch.float32, device=device)
+        self.r = torch.empty((capacity, 1), dtype=torch.float32, device=device)
+        self.d = torch.empty((capacity, 1), dtype=torch.float32, device=device)
+
+    def add(self, s, a, r, s2, d):
+        n = s.shape[0]
+        idx = (torch.arange(n, device=s.device) + self.pos) % self.cap
+        self.s[idx], self.a[idx], self.s2[idx] = s, a, s2
+        self.r[idx, 0], self.d[idx, 0] = r, d.float()
+        self.pos = (self.pos + n) % self.cap
+        self.size = min(self.cap, self.size + n)
+
+    def sample(self, batch):
+        idx = torch.randint(0, self.size, (batch,), device=self.s.device)
+        return self.s[idx], self.a[idx], self.r[idx], self.s2[idx], self.d[idx]
+
+    def __len__(self):
+        return self.size
+
+
+class Agent:
+    """TD3 agent (TD3:129-319) acting on batches of observations that stay on the device."""
+
+    def __init__(self, obs_dim=398, hidden=256, actor_lr=3e-4, critic_lr=3e-4, batch_size=128, memory_size=1_000_000,
+                 gamma=0.99, tau=0.005, max_v=0.22, max_w=2.0, noise_std=0.2, noise_clip=0.5, policy_delay=2,
+                 explore_sigma=1.0, device="cuda", seed=0):
+        self.device = torch.device(device)
+        g = torch.Generator().manual_seed(seed)
+        torch.manual_seed(seed)
+        self.actor = Actor(obs_dim, 2, hidden, max_v, max_w).to(self.device)
+        self.actor_t = Actor(obs_dim, 2, hidden, max_v, max_w).to(self.device)
+        self.q1, self.q2 = Critic(obs_dim, 2, hidden).to(self.device), Critic(obs_dim, 2, hidden).to(self.device)
+        self.q1_t, self.q2_t = Critic(obs_dim, 2, hidden).to(self.device), Critic(obs_dim, 2, hidden).to(self.device)
+        for t, s in ((self.actor_t, self.actor), (self.q1_t, self.q1), (self.q2_t, self.q2)):
+            t.load_state_dict(s.state_dict())
+        self.opt_a = torch.optim.Adam(self.actor.parameters(), lr=actor_lr)
+        self.opt_q1 = torch.optim.Adam(self.q1.parameters(), lr=critic_lr)
+        self.opt_q2 = torch.optim.Adam(self.q2.parameters(), lr=critic_lr)
+        self.memory = DeviceReplay(memory_size, obs_dim, self.device)
+        self.batch_size, self.gamma, self.tau = batch_size, gamma, tau
+        self.max_v, self.max_w = max_v, max_w
+        self.noise_std, self.noise_clip, self.policy_delay = noise_std, noise_clip, policy_delay
+        self.explore_sigma = explore_sigma
+        self.gen = torch.Generator(device=self.device).manual_seed(seed)
+        self._lo = torch.tensor([0.0, -max_w], device=self.device)
+        self._hi = torch.tensor([max_v, max_w], device=self.device)
+        del g
+
+    @torch.no_grad()
+    def act(self, obs, add_noise=True):
+        """Agent.act (TD3:196-223) for a batch: actor, Gaussian noise sigma=1.0, clip."""
+        a = self.actor(obs)
+        if add_noise:
+            a = a + torch.randn(a.shape, generator=self.gen, device=self.device) * self.explore_sigma
+        return torch.max(torch.min(a, self._hi), self._lo).contiguous()
+
+    def learn(self, step):
+        """One TD3 update (TD3:225-285)."""
+        if len(self.memory) <= self.batch_size:
+            return None
+        s, a, r, s2, d = self.memory.sample(self.batch_size)
+        with torch.no_grad():
+            noise = (torch.randn(a.shape, generator=self.gen, device=self.device) * self.noise_std).clamp(
+                -self.noise_clip, self.noise_clip)
+            a2 = torch.max(torch.min(self.actor_t(s2) + noise, self._hi), self._lo)
+            q_t = torch.min(self.q1_t(s2, a2), self.q2_t(s2, a2))
+            y = r + (1.0 - d) * self.gamma * q_t
+        l1 = F.mse_loss(self.q1(s, a), y)
+        l2 = F.mse_loss(self.q2(s, a), y)
+        self.opt_q1.zero_grad(); l1.backward(); self.opt_q1.step()
+        self.opt_q2.zero_grad(); l2.backward(); self.opt_q2.step()
+        if step % self.policy_delay == 0:
+            la = -self.q1(s, self.actor(s)).mean()
+            self.opt_a.zero_grad(); la.backward(); self.opt_a.step()
+            with torch.no_grad():
+                for t, src in ((self.actor_t, self.actor), (self.q1_t, self.q1), (self.q2_t, self.q2)):
+                    for pt, ps in zip(t.parameters(), src.parameters()):
+                        pt.mul_(1.0 - self.tau).add_(ps, alpha=self.tau)
+        return float(l1.item())
+
+    def save(self, outdir, ep):
+        """Target-network checkpoints every 100 episodes (TRAIN:150-154, TD3:304-311)."""
+        import os
+        os.makedirs(outdir, exist_ok=True)
+        torch.save(self.actor_t.state_dict(), os.path.join(outdir, "td3_actor_model_ep%d.pt" % ep))
+        torch.save(self.q1_t.state_dict(), os.path.join(outdir, "td3_critic1_model_ep%d.pt" % ep))
+        torch.save(self.q2_t.state_dict(), os.path.join(outdir, "td3_critic2_model_ep%d.pt" % ep))

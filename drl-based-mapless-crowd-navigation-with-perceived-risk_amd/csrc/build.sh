@@ -1,7 +1,7 @@
 #!/bin/bash
 # Builds libcrowdnav.so for gfx950 (MI355X).  hipcc cross-compiles without a GPU.
 #   -ffp-contract=off : no implicit FMA contraction; every fma() in the sources is explicit, which is
-#                       what makes the simulator bit-reproducible against oracle/cn_oracle.c
+#                       what makes the simulator bit-reproducible against the CPU oracle
 set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 OUT="$HERE/../lib"

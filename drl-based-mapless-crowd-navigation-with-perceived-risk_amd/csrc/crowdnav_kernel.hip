@@ -11,7 +11,7 @@
 // Reference lines: ENV = environment_stage_1_nobonus.py, UTL = utils.py, CROWD =
 // crowd_behaviors/simulate_crowd.py, TRAIN = start_td3_training.py (under
 // /root/reference/turtlebot3_rl_sim/src).  Gazebo owns the physics in the reference; the
-// simulator here is defined in DESIGN.md and restated independently in oracle/cn_oracle.c.
+// simulator here is defined in DESIGN.md and restated independently by the CPU oracle (test infrastructure).
 #include "crowdnav_device.h"
 #include "crowdnav_kernel.h"
 

@@ -169,3 +169,28 @@ def test_env_wrapper_has_reference_surface():
     assert s != f
     assert env.k_obstacle_count == 8
     env.shutdown()
+
+
+def test_actor_in_the_loop_rollout_config3():
+    """BASELINE config 3 shape at test size: a random-initialised 398->256->256->2 TD3 actor produces the
+    actions on the device; the batched loop keeps TRAIN:104-168's bookkeeping per env."""
+    import torch
+    from crowdnav import Config
+    from crowdnav.env import VecEnv
+    from crowdnav.rollout import EpisodeStats, gather_returns, rollout
+    from crowdnav.td3 import Agent
+    env = VecEnv(Config(n_envs=128, seed=2, max_steps=40))
+    agent = Agent(obs_dim=env.D, device="cuda", seed=0, memory_size=20000)
+    stats = EpisodeStats()
+    n = rollout(env, agent, n_steps=60, learn=True, stats=stats)
+    torch.cuda.synchronize()
+    assert n == 60 * 128
+    assert len(agent.memory) == 60 * 128
+    assert len(stats.rows) >= 128                      # every env finished at least one episode (max_steps 40)
+    for row in stats.rows[:50]:
+        assert row[1] != row[2] and 1 <= row[4] <= 40   # success xor failure; 1-based step count
+    a = agent.act(env.obs)
+    assert a.shape == (128, 2) and float(a[:, 0].min()) >= 0.0 and float(a[:, 0].max()) <= 0.22
+    assert float(a[:, 1].abs().max()) <= 2.0
+    r = gather_returns(env.returns()[0])
+    assert r.shape == (128,)

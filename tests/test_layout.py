@@ -1,0 +1,78 @@
+"""CPU checks of the boundary: the C-ABI library loads, exports every symbol include/crowdnav.h declares,
+fails loudly without a GPU, and the product never touches the oracle."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from conftest import PKG, ROOT
+
+
+def _declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "crowdnav.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(cn_[a-z_0-9]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol():
+    import crowdnav
+    crowdnav.build()
+    L = C.CDLL(crowdnav._abi.LIB_PATH)
+    syms = _declared_symbols()
+    assert len(syms) >= 17
+    for s in syms:
+        assert hasattr(L, s), "libcrowdnav.so does not export %s" % s
+    assert set(syms) == set(crowdnav._abi.EXPORTS)
+    assert L.cn_abi_version() == 1
+
+
+def test_config_struct_matches_header_and_oracle():
+    from crowdnav.config import CnConfig, Config
+    from oracle import oracle
+    assert C.sizeof(CnConfig) == C.sizeof(oracle.CnoConfig) == 12 * 4 + 8 + 8 + 19 * 8
+    assert [f[0] for f in CnConfig._fields_] == [f[0] for f in oracle.CnoConfig._fields_]
+    d = Config().as_dict()
+    for k, v in oracle.DEFAULTS.items():
+        if k in ("reserved0", "ped_cycle_ms"):
+            continue
+        assert d[k] == v, k
+    assert Config().obs_dim == 398 and Config(k_obstacles=4).obs_dim == 382  # TRAIN:88, checkpoints
+
+
+def test_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import crowdnav
+    from crowdnav.config import Config
+    L = crowdnav.lib()
+    h = C.c_void_p()
+    cfg = Config().to_c()
+    rc = L.cn_create(C.byref(cfg), 0, C.byref(h))
+    assert rc == -3 and b"no CPU fallback" in L.cn_last_error()
+    from crowdnav.env import VecEnv
+    with pytest.raises(crowdnav.CrowdNavError):
+        VecEnv(Config())
+
+
+def test_product_never_references_the_oracle_or_the_reference_tree():
+    bad = []
+    for base, _, files in os.walk(PKG):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".sh")):
+                txt = open(os.path.join(base, f)).read()
+                if re.search(r"\bimport oracle\b|from oracle\b|cn_oracle|libcn_oracle", txt):
+                    bad.append(os.path.join(base, f))
+                if "/root/reference" in txt and f.endswith(".py"):
+                    bad.append(os.path.join(base, f))
+    assert not bad, bad
+
+
+def test_lds_budget_of_benchmark_configs():
+    import crowdnav
+    L = crowdnav.lib()
+    L.cn_lds_bytes.restype = C.c_size_t
+    L.cn_lds_bytes.argtypes = [C.c_int] * 4
+    assert L.cn_lds_bytes(360, 20, 8, 359 // 4 + 2) <= 64 * 1024
+    assert L.cn_lds_bytes(720, 100, 8, 719 // 4 + 2) <= 160 * 1024
