@@ -34,20 +34,20 @@ struct cn_env_s {
 
 size_t cn_lds_bytes(int R, int P, int K, int max_conf)
 {
-    size_t n = (size_t)(R - 1);
-    size_t b = 0;
-    b += 8 * n * 5;                               // ptx pty dd g cg
-    b += 8 * (size_t)(2 * P + 2);                 // ped
-    b += 8 * (size_t)(CN_TF_COUNT * CN_MAX_TRACKS);
-    b += 8 * (size_t)max_conf * 3;                // cfx cfy cfd
-    b += 8 * (size_t)CN_MAX_TRACKS;               // cpv
-    b += 8 * (size_t)(7 + 4 * K + 1);             // tail
-    b += 8 * (size_t)(CN_NMASK * CN_MAXW);        // bit words
-    b += 4 * n;                                   // srcidx
-    b += 4 * (size_t)(3 * CN_MAXW);               // wbase
+    // must mirror the carve in cn_env_kernel
+    size_t n = (size_t)(R - 1), mc = (size_t)max_conf;
+    size_t szA_pts = (10 * n + 7) & ~(size_t)7, szA_trk = 8 * (size_t)(CN_TF_COUNT * CN_MAX_TRACKS);
+    size_t szA = szA_pts > szA_trk ? szA_pts : szA_trk;
+    size_t szB_g = (6 * n + 7) & ~(size_t)7;
+    size_t szB_c = 32 * mc + 8 * 64 + 8 * (size_t)(8 + 4 * K) + 4 * (size_t)CN_MAX_K;
+    size_t szB = szB_g > szB_c ? szB_g : szB_c;
+    if (szB < 8 * 64) szB = 8 * 64;
+    size_t Wn = (n + 63) >> 6;
+    size_t b = szA + szB;
+    b += 8 * (size_t)(CN_NMASK * Wn);             // bit words
+    b += 8 * ((3 * Wn + 1) / 2);                  // wbase
+    b += 8 * (size_t)(2 * P + 2) * 2;             // ped, pedv
     b += 4 * (size_t)(P + 1);                     // nearidx
-    b += 4 * (size_t)max_conf * 2;                // cft checked
-    b += 4 * (size_t)CN_MAX_K;                    // kidx
     return (b + 15) & ~(size_t)15;
 }
 

@@ -28,6 +28,56 @@ __device__ __forceinline__ double cn_py_round(double x, double p)
 // numpy around / round(np.float64, nd): multiply, rint, divide (ENV:255, ENV:1042)
 __device__ __forceinline__ double cn_np_around(double x, double p) { return rint(x * p) / p; }
 
+// ---- exact division by 1000 / 100 without the divide sequence ------------------------------------
+// q = x*inv, rem = fma(-q, P, x), q' = fma(rem, inv, q) with inv = RN(1/P) is the correctly rounded
+// x / P (Markstein); verified exhaustively for every integer |x| < 2^31 for P = 1000 and P = 100
+// (tools/check_const_div.c).  All callers pass integral x (a rint() result) in that range.
+#define CN_INV1000 (1.0 / 1000.0)
+#define CN_INV100 (1.0 / 100.0)
+__device__ __forceinline__ double cn_div1000(double r)
+{
+    double q = r * CN_INV1000;
+    return fma(fma(-q, 1000.0, r), CN_INV1000, q);
+}
+__device__ __forceinline__ double cn_div100(double r)
+{
+    double q = r * CN_INV100;
+    return fma(fma(-q, 100.0, r), CN_INV100, q);
+}
+// the integral part of Python round(x, 3): round(x, 3) == cn_div1000(cn_round3_mil(x)) bit for bit
+__device__ __forceinline__ double cn_round_scaled(double x, double p)
+{
+    double y = x * p;
+    double r = rint(y);
+    double d = y - r;
+    if (fabs(d) == 0.5) {
+        double err = fma(x, p, -y);
+        if (err > 0.0) r = y + 0.5;
+        else if (err < 0.0) r = y - 0.5;
+    }
+    return r;
+}
+__device__ __forceinline__ double cn_py_round3(double x)
+{
+    double r = cn_round_scaled(x, 1000.0);
+    return (fabs(r) < 2147483648.0) ? cn_div1000(r) : r / 1000.0;
+}
+__device__ __forceinline__ double cn_py_round2(double x)
+{
+    double r = cn_round_scaled(x, 100.0);
+    return (fabs(r) < 2147483648.0) ? cn_div100(r) : r / 100.0;
+}
+__device__ __forceinline__ double cn_np_around3(double x)
+{
+    double r = rint(x * 1000.0);
+    return (fabs(r) < 2147483648.0) ? cn_div1000(r) : r / 1000.0;
+}
+__device__ __forceinline__ double cn_np_around2(double x)
+{
+    double r = rint(x * 100.0);
+    return (fabs(r) < 2147483648.0) ? cn_div100(r) : r / 100.0;
+}
+
 // ---- deterministic sin/cos ----------------------------------------------------------------
 // Cody-Waite reduction by pi/2 + degree-13/14 minimax kernels; only + * fma rint, so host and
 // device produce identical bits (the simulator's contract, DESIGN.md "physics").
@@ -99,7 +149,7 @@ __device__ __forceinline__ double cn_iou3(double ax, double ay, double bx, doubl
     double area_a = (axp - axm) * (ayp - aym);
     double area_b = (bxp - bxm) * (byp - bym);
     double uni = area_a + area_b - inter;
-    return cn_py_round(inter / uni, 1000.0);
+    return cn_py_round3(inter / uni);
 }
 
 // ---- wave64 helpers ---------------------------------------------------------------------------

@@ -32,15 +32,20 @@ struct EnvRegs {  // per-env scalars, uniform across the wave
 };
 
 struct Lds {
-    double* ptx; double* pty; double* dd; double* g; double* cg;
+    int* ptx; int* pty; int* gq;          // [n] end points / gradients in integer thousandths
+    unsigned short* dmil;                 // [n] rounded range in thousandths (600 = free space)
     u64* w64;         // [M_COUNT][CN_MAXW] 64-ray bit words
-    int* srcidx;      // [n] source ray of an aliased type entry
+    unsigned short* srcidx;  // [n] source ray of an aliased type entry
     int* wbase;       // [3][CN_MAXW]
     int* nearidx;     // [P] pedestrians within lidar reach
     double* ped;      // [2P] positions
+    double* pedv;     // [2P] velocities
     double* trk;      // [CN_TF_COUNT][CN_MAX_TRACKS]
     double* cfx; double* cfy; double* cfd; int* cft; int* checked;   // confirmed objects
-    double* cpv;      // [CN_MAX_TRACKS]
+    double* cpv;      // [CN_MAX_TRACKS] collision probability per track
+    double* stage;    // [64] staging buffer of the bbox-size sum (reset only)
+    double* gtrk;     // this env's tracker table in HBM
+    int wstride;      // words per mask
     double* tail;     // [7 + 4K]
     int* kidx;        // [K]
 };
@@ -130,7 +135,7 @@ __device__ __forceinline__ void waypoint_refresh(const CnKParams& p, EnvRegs& e,
 }
 
 // ---- simulator -------------------------------------------------------------------------------
-__device__ void ped_advance(const CnKParams& p, int env, int lane, double* ped_p, double* ped_v, long long t0, long long t1)
+__device__ __forceinline__ void ped_advance(const CnKParams& p, int env, int lane, double* ped_p, double* ped_v, long long t0, long long t1)
 {
     const double lo = -p.room_half + p.ped_radius, hi = p.room_half - p.ped_radius;
     const long long T = p.ped_cycle_ms;
@@ -198,7 +203,7 @@ __device__ __forceinline__ void sim_advance(const CnKParams& p, EnvRegs& e, int 
 
 // ---- Env.get_state (ENV:245-1044) ----------------------------------------------------------------
 // ped_p: pedestrian positions in LDS.  Writes the observation (float32 and optionally float64).
-__device__ void observe(const CnKParams& p, EnvRegs& e, const Lds& L, int env, int lane, int step_counter,
+__device__ __forceinline__ void observe(const CnKParams& p, EnvRegs& e, const Lds& L, int env, int lane, int step_counter,
                         float* obs32, float* fin32, double* obs64, int* done_out)
 {
     const int R = p.R, n = R - 1, K = p.K, D = n + 7 + 4 * K;
@@ -207,12 +212,14 @@ __device__ void observe(const CnKParams& p, EnvRegs& e, const Lds& L, int env, i
 
     // ENV:246-265
     if (step_counter == 1) waypoint_refresh(p, e, lane, px, py);
-    double distance_to_goal = cn_np_around(dist3(px, py, e.wpx, e.wpy), 100.0);
-    double heading = cn_py_round(heading_to_goal(p, e, px, py, yaw), 100.0);
+    double distance_to_goal = cn_np_around2(dist3(px, py, e.wpx, e.wpy));
+    double heading = cn_py_round2(heading_to_goal(p, e, px, py, yaw));
     if (step_counter % 5 == 0 || distance_to_goal < e.prev_dist) waypoint_refresh(p, e, lane, px, py);
     // ENV:267-268: the angular velocity is used as the angle
-    double agent_vel_x = -1.0 * (v * cos(w));
-    double agent_vel_y = v * sin(w);
+    double sw_, cw_;
+    cn_det_sincos(w, &sw_, &cw_);
+    double agent_vel_x = -1.0 * (v * cw_);
+    double agent_vel_y = v * sw_;
 
     // ---- lidar raycast (XACRO:150-178) + UTL:375-392 sanitise + UTL:110-126 end points ----------
     double sy, cy;
@@ -239,19 +246,29 @@ __device__ void observe(const CnKParams& p, EnvRegs& e, const Lds& L, int env, i
         }
     }
     __syncthreads();
+    const bool wall_x = !(h - fabs(ox) > p.lidar_max + 1e-6);
+    const bool wall_y = !(h - fabs(oy) > p.lidar_max + 1e-6);
     double smin = 1e300;
     float* o32 = obs32 + (size_t)env * D;
     float* f32 = fin32 ? fin32 + (size_t)env * D : nullptr;
     double* o64 = obs64 ? obs64 + (size_t)env * D : nullptr;
+    // End points, rounded ranges and gradients are 3-decimal values: LDS keeps the integer thousandths
+    // (x == cn_div1000(mil) bit for bit), which halves the working set and doubles the waves per CU.
     for (int k = lane; k < R; k += 64) {
         double lc = p.lidar_c[k], ls = p.lidar_s[k];
         double dx = fma(cy, lc, -(sy * ls));
         double dy = fma(sy, lc, cy * ls);
         double t = INFINITY;
-        if (dx > 0.0) t = fmin(t, (h - ox) / dx);
-        else if (dx < 0.0) t = fmin(t, (-h - ox) / dx);
-        if (dy > 0.0) t = fmin(t, (h - oy) / dy);
-        else if (dy < 0.0) t = fmin(t, (-h - oy) / dy);
+        // A wall farther than lidar_max from the origin can only give t > lidar_max ("no return"), so its
+        // divide is skipped when the whole env is out of its reach (uniform test, result unchanged).
+        if (wall_x) {
+            if (dx > 0.0) t = fmin(t, (h - ox) / dx);
+            else if (dx < 0.0) t = fmin(t, (-h - ox) / dx);
+        }
+        if (wall_y) {
+            if (dy > 0.0) t = fmin(t, (h - oy) / dy);
+            else if (dy < 0.0) t = fmin(t, (-h - oy) / dy);
+        }
         if (t < p.lidar_min) t = p.lidar_min;
         for (int c = 0; c < nnear; ++c) {
             int j = L.nearidx[c];
@@ -281,76 +298,76 @@ __device__ void observe(const CnKParams& p, EnvRegs& e, const Lds& L, int env, i
             double a = ang * deg2rad - yaw;
             double sa, ca;
             cn_det_sincos(a, &sa, &ca);
-            L.ptx[j] = cn_py_round(px + (sc * ca), 1000.0);
-            L.pty[j] = cn_py_round(py + (sc * sa) * -1.0, 1000.0);
-            L.dd[j] = cn_py_round(sc, 1000.0);
-            double so = cn_np_around(sc, 1000.0);  // ENV:1042
+            L.ptx[j] = (int)cn_round_scaled(px + (sc * ca), 1000.0);
+            L.pty[j] = (int)cn_round_scaled(py + (sc * sa) * -1.0, 1000.0);
+            L.dmil[j] = (unsigned short)(int)cn_round_scaled(sc, 1000.0);
+            double so = cn_np_around3(sc);  // ENV:1042
             o32[j] = (float)so;
             if (f32) f32[j] = (float)so;
             if (o64) o64[j] = so;
-            if (step_counter == 0) {  // ENV:287-290 ground-truth end points of an all-max scan
-                L.g[j] = cn_py_round(px + (MAXR * ca), 1000.0);
-                L.cg[j] = cn_py_round(py + (MAXR * sa) * -1.0, 1000.0);
-            }
         }
     }
     smin = cn_wave_min_d(smin);
     __syncthreads();
 
-    if (step_counter == 0) {  // UTL:405-419 + ENV:294: mean spacing of consecutive ground-truth end points
+    if (step_counter == 0) {  // UTL:405-419 + ENV:287-294: mean spacing of the end points of an all-max scan
         double sum = 0.0;     // Python sum(): strictly left to right
         for (int i0 = 0; i0 < n; i0 += 64) {
             int i = i0 + lane;
             if (i < n) {
                 int j = (i == n - 1) ? 0 : i + 1;
-                L.cpv[lane] = hypot(L.g[i] - L.g[j], L.cg[i] - L.cg[j]);
+                double s0, c0, s1, c1;
+                cn_det_sincos(((double)i * p.angle_inc_deg) * deg2rad - yaw, &s0, &c0);
+                cn_det_sincos(((double)j * p.angle_inc_deg) * deg2rad - yaw, &s1, &c1);
+                double x0 = cn_py_round3(px + (MAXR * c0)), y0 = cn_py_round3(py + (MAXR * s0) * -1.0);
+                double x1 = cn_py_round3(px + (MAXR * c1)), y1 = cn_py_round3(py + (MAXR * s1) * -1.0);
+                L.stage[lane] = hypot(x0 - x1, y0 - y1);
             }
             __syncthreads();
             int cnt = min(64, n - i0);
-            for (int c = 0; c < cnt; ++c) sum += L.cpv[c];
+            for (int c = 0; c < cnt; ++c) sum += L.stage[c];
             __syncthreads();
         }
         e.bb = sum / (double)n;
-        double qx = cn_py_round(px, 1000.0), qy = cn_py_round(py, 1000.0);
+        double qx = cn_py_round3(px), qy = cn_py_round3(py);
         if (e.dq_len < 2) { if (e.dq_len == 0) { e.dq0x = qx; e.dq0y = qy; } else { e.dq1x = qx; e.dq1y = qy; } e.dq_len += 1; }
         else { e.dq0x = e.dq1x; e.dq0y = e.dq1y; e.dq1x = qx; e.dq1y = qy; }
     }
 
     const int W = (n + 63) >> 6;  // 64-ray words; ray i = bit (i & 63) of word (i >> 6)
-#define WORD(id, q) L.w64[(id) * CN_MAXW + (q)]
+#define WORD(id, q) L.w64[(id) * L.wstride + (q)]
 #define BIT(id, i) ((WORD(id, (i) >> 6) >> ((i) & 63)) & 1ull)
-    // ENV:329-346 gradients between consecutive end points; None is carried as NaN
-    for (int i = lane; i < n; i += 64) {
-        double gr = CN_NAN;
-        if (L.dd[i] != 0.6) {
-            int j = (i == n - 1) ? 0 : i + 1;
-            double dy = L.pty[i] - L.pty[j];
-            double q = (dy == 0) ? 0.0 : (L.ptx[i] - L.ptx[j]) / dy;
-            gr = cn_py_round(q, 1000.0);
-        }
-        L.g[i] = gr;
-    }
-    __syncthreads();
-    // ENV:348-367 change of gradient: |g[i]-g[i+1]| (NaN if either is None); ray n-1 takes `last_grad`
+#define PX(i) cn_div1000((double)L.ptx[i])
+#define PY(i) cn_div1000((double)L.pty[i])
+#define GNONE 0x7fffffff
+    // ENV:329-346 gradients between consecutive end points, kept as integer thousandths (GNONE = None)
     int lastnn = -1;
-    for (int i = lane; i < n - 1; i += 64) {
-        double gi = L.g[i];
-        L.cg[i] = fabs(gi - L.g[i + 1]);
-        if (gi == gi) lastnn = i;
+    for (int i = lane; i < n; i += 64) {
+        int gm = GNONE;
+        if (L.dmil[i] != 600) {
+            int j = (i == n - 1) ? 0 : i + 1;
+            double dy = PY(i) - PY(j);
+            double q = (dy == 0) ? 0.0 : (PX(i) - PX(j)) / dy;
+            gm = (int)cn_round_scaled(q, 1000.0);
+            if (i < n - 1) lastnn = i;
+        }
+        L.gq[i] = gm;
     }
     lastnn = cn_wave_max_i(lastnn);
     __syncthreads();
-    if (lane == 0) {
-        double gl = L.g[n - 1];
-        L.cg[n - 1] = (gl == gl && lastnn >= 0) ? L.cg[lastnn] : CN_NAN;
-    }
-    __syncthreads();
+    // ENV:348-367 change of gradient c[i] = |g[i]-g[i+1]| (None if either is None), recomputed where needed;
+    // ray n-1 takes `last_grad`, i.e. c[lastnn] of the last valid gradient before it.
+#define CHG(a_, b_) (((a_) == GNONE || (b_) == GNONE) ? CN_NAN : fabs(cn_div1000((double)(a_)) - cn_div1000((double)(b_))))
+    double clast = CN_NAN;
+    if (L.gq[n - 1] != GNONE && lastnn >= 0) clast = CHG(L.gq[lastnn], L.gq[lastnn + 1]);
     // flag words for the type machine
     for (int q = 0; q < W; ++q) {
         int i = lane + 64 * q;
         bool none = true, zero = false, eq = false, nnone = true, nzero = false;
         if (i < n - 1) {  // the machine never visits ray n-1 (ENV:380-381)
-            double c0 = L.cg[i], c1 = L.cg[i + 1];
+            int g0 = L.gq[i], g1 = L.gq[i + 1];
+            double c0 = CHG(g0, g1);
+            double c1 = (i + 1 < n - 1) ? CHG(g1, L.gq[i + 2]) : clast;
             none = !(c0 == c0);
             zero = (c0 == 0);
             nnone = !(c1 == c1);
@@ -360,6 +377,7 @@ __device__ void observe(const CnKParams& p, EnvRegs& e, const Lds& L, int env, i
         u64 b0 = __ballot(none), b1 = __ballot(zero), b2 = __ballot(eq), b3 = __ballot(nnone), b4 = __ballot(nzero);
         if (lane == 0) { WORD(M_NONE, q) = b0; WORD(M_ZERO, q) = b1; WORD(M_EQ, q) = b2; WORD(M_NNONE, q) = b3; WORD(M_NZERO, q) = b4; }
     }
+#undef CHG
     __syncthreads();
     // ENV:372-410 object-type state machine.  Loop-carried state (last_type, du_count) lives in scalar
     // registers; only occupied rays are visited (bit scan over the flag words), no memory in the loop
@@ -393,7 +411,7 @@ __device__ void observe(const CnKParams& p, EnvRegs& e, const Lds& L, int env, i
                 }
                 if (ty == TY_W) isw |= bit;
                 else if (ty == TY_O) iso |= bit;
-                if (src != i && ty != TY_NONE) { al |= bit; if (lane == 0) L.srcidx[i] = src; }
+                if (src != i && ty != TY_NONE) { al |= bit; if (lane == 0) L.srcidx[i] = (unsigned short)src; }
             }
             if (lane == 0) { WORD(M_ISW, q) = isw; WORD(M_ISO, q) = iso; WORD(M_ALIAS, q) = al; }
         }
@@ -404,7 +422,7 @@ __device__ void observe(const CnKParams& p, EnvRegs& e, const Lds& L, int env, i
     for (int i = lane; i < n; i += 64) {
         if (BIT(M_ALIAS, i)) {
             int s_ = L.srcidx[i];
-            L.dd[i] = L.dd[s_]; L.ptx[i] = L.ptx[s_]; L.pty[i] = L.pty[s_];
+            L.dmil[i] = L.dmil[s_]; L.ptx[i] = L.ptx[s_]; L.pty[i] = L.pty[s_];
         }
     }
     __syncthreads();
@@ -415,7 +433,7 @@ __device__ void observe(const CnKParams& p, EnvRegs& e, const Lds& L, int env, i
         bool brk = false;
         if (i < n) {
             brk = true;
-            if (i < n - 1) brk = !(cn_iou3(L.ptx[i], L.pty[i], L.ptx[i + 1], L.pty[i + 1], e.bb) > 0.0);
+            if (i < n - 1) brk = !(cn_iou3(PX(i), PY(i), PX(i + 1), PY(i + 1), e.bb) > 0.0);
         }
         u64 bw = __ballot(brk);
         if (lane == 0) WORD(M_BRK, q) = bw;
@@ -428,7 +446,7 @@ __device__ void observe(const CnKParams& p, EnvRegs& e, const Lds& L, int env, i
     }
     const int ls = lb + 1;            // start of the last segment
     // ENV:490-502 first <-> last with twice the box
-    bool merge = (nsegs0 > 1) && (cn_iou3(L.ptx[0], L.pty[0], L.ptx[n - 1], L.pty[n - 1], e.bb * 2) > 0.0);
+    bool merge = (nsegs0 > 1) && (cn_iou3(PX(0), PY(0), PX(n - 1), PY(n - 1), e.bb * 2) > 0.0);
     __syncthreads();
     // order-space: position k -> ray.  merged: [0..fe] ++ [ls..n-1] ++ [fe+1..ls-1]
     const int nl = n - ls;  // length of the last segment
@@ -443,9 +461,9 @@ __device__ void observe(const CnKParams& p, EnvRegs& e, const Lds& L, int env, i
             if (!merge) se = BIT(M_BRK, ray);
             else if (k <= fe + nl) se = (k == fe + nl);
             else se = BIT(M_BRK, ray);
-            oc = (L.dd[ray] != 0.6);
+            oc = (L.dmil[ray] != 600);
             if (!se && k < n - 1) {
-                bool oc1 = (L.dd[ORDER(k + 1)] != 0.6);
+                bool oc1 = (L.dmil[ORDER(k + 1)] != 600);
                 if (oc != oc1) se = true;
             }
             kw = BIT(M_ISW, ray); ko = BIT(M_ISO, ray);
@@ -459,7 +477,7 @@ __device__ void observe(const CnKParams& p, EnvRegs& e, const Lds& L, int env, i
     if (lane == 0) {
         int bw = 0, bo = 0, le = -1;
         for (int q = 0; q < W; ++q) {
-            L.wbase[q] = bw; L.wbase[CN_MAXW + q] = bo; L.wbase[2 * CN_MAXW + q] = le;
+            L.wbase[q] = bw; L.wbase[L.wstride + q] = bo; L.wbase[2 * L.wstride + q] = le;
             u64 sw = WORD(M_SEG, q);
             bw += __popcll(WORD(M_KW, q)); bo += __popcll(WORD(M_KO, q));
             if (sw) le = 64 * q + 63 - __builtin_clzll(sw);
@@ -474,22 +492,22 @@ __device__ void observe(const CnKParams& p, EnvRegs& e, const Lds& L, int env, i
         int obj = -1, m = 0; double dm = 0.0;
         if ((sw >> lane) & 1ull) {
             const u64 low = sw & ((1ull << lane) - 1ull);
-            const int pe = low ? (64 * q + 63 - __builtin_clzll(low)) : L.wbase[2 * CN_MAXW + q];  // previous segment end
+            const int pe = low ? (64 * q + 63 - __builtin_clzll(low)) : L.wbase[2 * L.wstride + q];  // previous segment end
             const int k0 = pe + 1, len = k - pe;
             const u64 incl = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
             int cw = L.wbase[q] + __popcll(WORD(M_KW, q) & incl);
-            int co = L.wbase[CN_MAXW + q] + __popcll(WORD(M_KO, q) & incl);
+            int co = L.wbase[L.wstride + q] + __popcll(WORD(M_KO, q) & incl);
             if (pe >= 0) {
                 const int qp = pe >> 6, bp = pe & 63;
                 const u64 inclp = (bp == 63) ? ~0ull : ((2ull << bp) - 1ull);
                 cw -= L.wbase[qp] + __popcll(WORD(M_KW, qp) & inclp);
-                co -= L.wbase[CN_MAXW + qp] + __popcll(WORD(M_KO, qp) & inclp);
+                co -= L.wbase[L.wstride + qp] + __popcll(WORD(M_KO, qp) & inclp);
             }
             const int no = co, nw = cw, nn = len - no - nw;
             const bool occ = (WORD(M_OCC, q) >> lane) & 1ull;  // segments are homogeneous after the split
             if (occ && len >= 4) {
                 m = ORDER(k0 + len / 2);  // ENV:577 Python-2 integer division
-                dm = L.dd[m];
+                dm = cn_div1000((double)L.dmil[m]);
                 int est = 3 + (int)floor(29 * (p.max_scan_range - dm) / (p.max_scan_range - p.min_scan_range));
                 int mn = len < est ? len : est;
                 double score = (double)no / (double)mn;
@@ -507,7 +525,7 @@ __device__ void observe(const CnKParams& p, EnvRegs& e, const Lds& L, int env, i
         const u64 cwd = __ballot(obj >= 0);
         if (obj >= 0) {
             int slot = nconf + __popcll(cwd & ((1ull << lane) - 1ull));
-            if (slot < p.max_conf) { L.cft[slot] = obj; L.cfx[slot] = L.ptx[m]; L.cfy[slot] = L.pty[m]; L.cfd[slot] = dm; }
+            if (slot < p.max_conf) { L.cft[slot] = obj; L.cfx[slot] = PX(m); L.cfy[slot] = PY(m); L.cfd[slot] = dm; }
         }
         nconf += __popcll(cwd);
     }
@@ -515,6 +533,9 @@ __device__ void observe(const CnKParams& p, EnvRegs& e, const Lds& L, int env, i
 #undef ORDER
 #undef BIT
 #undef WORD
+#undef PX
+#undef PY
+#undef GNONE
     e.nconf = nconf;
     __syncthreads();
 
@@ -528,7 +549,13 @@ __device__ void observe(const CnKParams& p, EnvRegs& e, const Lds& L, int env, i
     if (n_obst > 0) e.obst_steps += 1;
 
     // ---- ENV:656-743 tracker -----------------------------------------------------------------------
+    // The tracker table shares LDS with the end-point arrays (dead from here on): bring it in now.
     double* T = L.trk;
+    if (lane < e.ntracks) {
+#pragma unroll
+        for (int f = 0; f < CN_TF_COUNT; ++f) T[f * CN_MAX_TRACKS + lane] = L.gtrk[f * CN_MAX_TRACKS + lane];
+    }
+    __syncthreads();
 #define TRK(f, i) T[(f) * CN_MAX_TRACKS + (i)]
     bool add_unchecked = false;
     if (p.ablate & 16) { e.ntracks = 0; nconf = 0; }
@@ -735,24 +762,29 @@ __device__ void observe(const CnKParams& p, EnvRegs& e, const Lds& L, int env, i
     // ENV:1025-1042 observation tail
     if (lane == 0) {
         L.tail[0] = heading; L.tail[1] = distance_to_goal;
-        L.tail[2] = cn_py_round(px, 1000.0); L.tail[3] = cn_py_round(py, 1000.0);
-        L.tail[4] = cn_py_round(yaw, 1000.0);
-        L.tail[5] = cn_py_round(agent_vel_x, 1000.0); L.tail[6] = cn_py_round(agent_vel_y, 1000.0);
+        L.tail[2] = cn_py_round3(px); L.tail[3] = cn_py_round3(py);
+        L.tail[4] = cn_py_round3(yaw);
+        L.tail[5] = cn_py_round3(agent_vel_x); L.tail[6] = cn_py_round3(agent_vel_y);
     }
     __syncthreads();
     for (int i = lane; i < 7 + 4 * K; i += 64) {
-        double so = cn_np_around(L.tail[i], 1000.0);
+        double so = cn_np_around3(L.tail[i]);
         L.tail[i] = so;
         o32[n + i] = (float)so;
         if (f32) f32[n + i] = (float)so;
         if (o64) o64[n + i] = so;
+    }
+    // tracker table back to HBM (its LDS space is reused by the next observation's end points)
+    if (lane < e.ntracks) {
+#pragma unroll
+        for (int f = 0; f < CN_TF_COUNT; ++f) L.gtrk[f * CN_MAX_TRACKS + lane] = L.trk[f * CN_MAX_TRACKS + lane];
     }
     __syncthreads();
     *done_out = e.done;
 }
 
 // ENV:1046-1162 compute_reward; state[n] = heading, state[n+1] = distance are in L.tail[0..1]
-__device__ double compute_reward(const CnKParams& p, EnvRegs& e, const Lds& L, int lane, int done)
+__device__ __forceinline__ double compute_reward(const CnKParams& p, EnvRegs& e, const Lds& L, int lane, int done)
 {
     double cur_head = L.tail[0], cur_dist = L.tail[1];
     double dd = cur_dist - e.prev_dist, hd = cur_head - e.prev_head;
@@ -798,26 +830,36 @@ extern "C" __global__ void __launch_bounds__(64) cn_env_kernel(CnKParams p)
 
     Lds L;
     {
-        char* q = smem;
-        L.ptx = (double*)q; q += 8 * (size_t)n;
-        L.pty = (double*)q; q += 8 * (size_t)n;
-        L.dd = (double*)q; q += 8 * (size_t)n;
-        L.g = (double*)q; q += 8 * (size_t)n;
-        L.cg = (double*)q; q += 8 * (size_t)n;
-        L.ped = (double*)q; q += 8 * (size_t)(2 * P + 2);
-        L.trk = (double*)q; q += 8 * (size_t)(CN_TF_COUNT * CN_MAX_TRACKS);
-        L.cfx = (double*)q; q += 8 * (size_t)p.max_conf;
-        L.cfy = (double*)q; q += 8 * (size_t)p.max_conf;
-        L.cfd = (double*)q; q += 8 * (size_t)p.max_conf;
-        L.cpv = (double*)q; q += 8 * (size_t)CN_MAX_TRACKS;
-        L.tail = (double*)q; q += 8 * (size_t)(7 + 4 * K + 1);
-        L.w64 = (u64*)q; q += 8 * (size_t)(M_COUNT * CN_MAXW);
-        L.srcidx = (int*)q; q += 4 * (size_t)n;
-        L.wbase = (int*)q; q += 4 * (size_t)(3 * CN_MAXW);
-        L.nearidx = (int*)q; q += 4 * (size_t)(P + 1);
-        L.cft = (int*)q; q += 4 * (size_t)p.max_conf;
-        L.checked = (int*)q; q += 4 * (size_t)p.max_conf;
-        L.kidx = (int*)q; q += 4 * (size_t)CN_MAX_K;
+        // LDS map.  Region A: end points (integer thousandths) | tracker table.
+        // Region B: gradients + alias sources | bbox staging | confirmed objects, CP, observation tail.
+        const size_t szA_pts = (size_t)(10 * n + 7) & ~(size_t)7;
+        const size_t szA_trk = 8 * (size_t)(CN_TF_COUNT * CN_MAX_TRACKS);
+        const size_t szA = szA_pts > szA_trk ? szA_pts : szA_trk;
+        const size_t mc = (size_t)p.max_conf;
+        const size_t szB_g = (size_t)(6 * n + 7) & ~(size_t)7;
+        const size_t szB_c = 32 * mc + 8 * 64 + 8 * (size_t)(8 + 4 * K) + 4 * (size_t)CN_MAX_K;
+        size_t szB = szB_g > szB_c ? szB_g : szB_c;
+        if (szB < 8 * 64) szB = 8 * 64;
+        char* A = smem;
+        char* B = A + szA;
+        char* Cw = B + szB;
+        L.ptx = (int*)A; L.pty = (int*)(A + 4 * (size_t)n); L.dmil = (unsigned short*)(A + 8 * (size_t)n);
+        L.trk = (double*)A;
+        L.gq = (int*)B; L.srcidx = (unsigned short*)(B + 4 * (size_t)n);
+        L.stage = (double*)B;
+        L.cfx = (double*)B; L.cfy = (double*)(B + 8 * mc); L.cfd = (double*)(B + 16 * mc);
+        L.cft = (int*)(B + 24 * mc); L.checked = (int*)(B + 28 * mc);
+        L.cpv = (double*)(B + 32 * mc);
+        L.tail = L.cpv + 64;
+        L.kidx = (int*)(L.tail + (8 + 4 * K));
+        const int Wn = (n + 63) >> 6;
+        L.wstride = Wn;
+        L.w64 = (u64*)Cw; Cw += 8 * (size_t)(M_COUNT * Wn);
+        L.wbase = (int*)Cw; Cw += 8 * (size_t)((3 * Wn + 1) / 2);
+        L.ped = (double*)Cw; Cw += 8 * (size_t)(2 * P + 2);
+        L.pedv = (double*)Cw; Cw += 8 * (size_t)(2 * P + 2);
+        L.nearidx = (int*)Cw;
+        L.gtrk = p.trk + (size_t)env * CN_TF_COUNT * CN_MAX_TRACKS;
     }
 
     // ---- load env state -------------------------------------------------------------------------
@@ -839,13 +881,8 @@ extern "C" __global__ void __launch_bounds__(64) cn_env_kernel(CnKParams p)
     double* gped_p = p.ped_p + (size_t)env * 2 * P;
     double* gped_v = p.ped_v + (size_t)env * 2 * P;
     const double* gped_init = p.ped_init + (size_t)env * 2 * P;
-    double* pedv = L.g;  // velocities are only needed while advancing; L.g is free until the gradients
+    double* pedv = L.pedv;  // velocities are only needed while advancing
     for (int i = lane; i < 2 * P; i += 64) { L.ped[i] = gped_p[i]; pedv[i] = gped_v[i]; }
-    double* gtrk = p.trk + (size_t)env * CN_TF_COUNT * CN_MAX_TRACKS;
-    if (lane < e.ntracks) {
-#pragma unroll
-        for (int f = 0; f < CN_TF_COUNT; ++f) L.trk[f * CN_MAX_TRACKS + lane] = gtrk[f * CN_MAX_TRACKS + lane];
-    }
     __syncthreads();
 
     int done = 0;
@@ -861,7 +898,7 @@ extern "C" __global__ void __launch_bounds__(64) cn_env_kernel(CnKParams p)
         sim_advance(p, e, env, lane, L.ped, pedv, p.dt_ms);
         const double end_timestep = e.clock - t0;             // ENV:1202
         {
-            double qx = cn_py_round(e.rx, 1000.0), qy = cn_py_round(e.ry, 1000.0);  // ENV:1208
+            double qx = cn_py_round3(e.rx), qy = cn_py_round3(e.ry);  // ENV:1208
             if (e.dq_len == 0) { e.dq0x = qx; e.dq0y = qy; e.dq_len = 1; }
             else if (e.dq_len == 1) { e.dq1x = qx; e.dq1y = qy; e.dq_len = 2; }
             else { e.dq0x = e.dq1x; e.dq0y = e.dq1y; e.dq1x = qx; e.dq1y = qy; }
@@ -869,8 +906,6 @@ extern "C" __global__ void __launch_bounds__(64) cn_env_kernel(CnKParams p)
         e.ts = end_timestep;                                  // ENV:1209
         e.clock += (double)p.scan_latency_ms / 1000.0;        // wait_for_message('scan') (ENV:1218)
         sim_advance(p, e, env, lane, L.ped, pedv, p.scan_latency_ms);
-        __syncthreads();
-        for (int i = lane; i < 2 * P; i += 64) gped_v[i] = pedv[i];  // L.g is about to be reused
         __syncthreads();
         observe(p, e, L, env, lane, sc, p.obs, p.final_obs, p.obs_f64, &done);
         double r = compute_reward(p, e, L, lane, done);
@@ -896,31 +931,21 @@ extern "C" __global__ void __launch_bounds__(64) cn_env_kernel(CnKParams p)
         e.clock += (double)p.scan_latency_ms / 1000.0;        // wait_for_message('scan') (ENV:1238)
         sim_advance(p, e, env, lane, L.ped, pedv, p.scan_latency_ms);
         __syncthreads();
-        // the settle interval needs the velocities again after observe() has reused L.g: park them in HBM
-        for (int i = lane; i < 2 * P; i += 64) gped_v[i] = pedv[i];
         e.prev_dist = dist3(e.rx, e.ry, e.wpx, e.wpy);        // ENV:1243 (unrounded)
         e.prev_head = heading_to_goal(p, e, e.rx, e.ry, e.ryaw);  // ENV:1244
         __syncthreads();
         int d2 = 0;
         observe(p, e, L, env, lane, 0, p.obs, nullptr, p.obs_f64, &d2);
         e.social_viol = 0; e.ego_viol = 0; e.obst_steps = 0;  // ENV:1260-1262
-        __syncthreads();
-        for (int i = lane; i < 2 * P; i += 64) pedv[i] = gped_v[i];
-        __syncthreads();
         e.clock += (double)p.settle_ms / 1000.0;              // TRAIN:114 time.sleep(0.1)
         sim_advance(p, e, env, lane, L.ped, pedv, p.settle_ms);
         e.done = 0;                                           // TRAIN:116
         e.ep_step = 0; e.ep_ret = 0.0;
         __syncthreads();
-        for (int i = lane; i < 2 * P; i += 64) gped_v[i] = pedv[i];
     }
 
     // ---- write env state back ---------------------------------------------------------------------
-    for (int i = lane; i < 2 * P; i += 64) gped_p[i] = L.ped[i];
-    if (lane < e.ntracks) {
-#pragma unroll
-        for (int f = 0; f < CN_TF_COUNT; ++f) gtrk[f * CN_MAX_TRACKS + lane] = L.trk[f * CN_MAX_TRACKS + lane];
-    }
+    for (int i = lane; i < 2 * P; i += 64) { gped_p[i] = L.ped[i]; gped_v[i] = pedv[i]; }
     if (lane == 0) {
         sd[CN_SD_RX] = e.rx; sd[CN_SD_RY] = e.ry; sd[CN_SD_RYAW] = e.ryaw; sd[CN_SD_RV] = e.rv; sd[CN_SD_RW] = e.rw;
         sd[CN_SD_CLOCK] = e.clock; sd[CN_SD_WPX] = e.wpx; sd[CN_SD_WPY] = e.wpy;

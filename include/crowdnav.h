@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 #define CN_ABI_VERSION 1
-#define CN_MAX_TRACKS 64      /* per-env capacity of the obstacle tracker (ENV:656-743) */
+#define CN_MAX_TRACKS 32      /* per-env capacity of the obstacle tracker (ENV:656-743) */
 #define CN_MAX_K 16
 
 enum {
