@@ -89,42 +89,64 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for i in range(a.warmup):
-        env.step(acts[i % n_act], auto_reset=True)
-    barrier()
-    stream = torch.cuda.current_stream(dev)
-    ev0 = torch.cuda.Event(enable_timing=True)
-    ev1 = torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record(stream)
-    for i in range(a.steps):
-        env.step(acts[i % n_act], auto_reset=True)
-    ev1.record(stream)
-    barrier()
-    t1 = time.perf_counter()
-    wall = t1 - t0
-    kernel_ms = ev0.elapsed_time(ev1) / a.steps      # cn_env_kernel is the only kernel in the timed region
+    def timed(mode):
+        """K launches of cn_step; returns (wall s, kernel ms/launch, env-steps actually taken by this rank)."""
+        for i in range(a.warmup):
+            env.step(acts[i % n_act], auto_reset=mode)
+        ep0 = env.counters()[:, 8].sum().item()
+        barrier()
+        stream = torch.cuda.current_stream(dev)
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev1 = torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        for i in range(a.steps):
+            env.step(acts[i % n_act], auto_reset=mode)
+        ev1.record(stream)
+        barrier()
+        wall_ = time.perf_counter() - t0
+        k_ms = ev0.elapsed_time(ev1) / a.steps       # cn_env_kernel is the only kernel in the timed region
+        ep1 = env.counters()[:, 8].sum().item()
+        torch.cuda.synchronize(dev)
+        taken = N * a.steps
+        if mode == "next":                            # a finished env spends one launch on its reset: not an env-step
+            taken -= int(ep1 - ep0)
+        return wall_, k_ms, taken
+
+    # headline: next-step reset (auto_reset = 2); beside it: reset inside the same call (auto_reset = 1)
+    wall_same, kms_same, taken_same = timed("same")
+    env.reset()
+    wall, kernel_ms, taken = timed("next")
     if world > 1:
-        t = torch.tensor([wall], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t.item())
+        t = torch.tensor([wall, float(taken), wall_same, float(taken_same)], dtype=torch.float64, device=dev)
+        tm = t.clone(); dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        ts = t.clone(); dist.all_reduce(ts, op=dist.ReduceOp.SUM)
+        wall, wall_same = float(tm[0].item()), float(tm[2].item())
+        taken_all, taken_same_all = float(ts[1].item()), float(ts[3].item())
         # the path's one exchange: all-gather of per-env episode returns over xGMI (SURVEY 8e)
         ret, _ = env.returns()
         gathered = torch.empty(world * N, dtype=torch.float32, device=dev)
+        tg0 = time.perf_counter()
         dist.all_gather_into_tensor(gathered, ret)
         torch.cuda.synchronize(dev)
+        gather_ms = (time.perf_counter() - tg0) * 1e3
+    else:
+        taken_all, taken_same_all, gather_ms = float(taken), float(taken_same), None
 
-    value = world * N * a.steps / wall
+    value = taken_all / wall
     B = algorithmic_bytes(a.peds, a.rays, a.k)
-    achieved = B * N / (kernel_ms * 1e-3) / 1e9
+    achieved = B * N / (kernel_ms * 1e-3) / 1e9   # every launch moves all N envs' state, reset or step
     out = {
         "metric": "env-steps/sec @4096 envs x 20 peds x 360 rays; HBM GB/s vs roofline",
         "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": wall / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "%d envs/GPU x %d pedestrians x %d rays, K=%d, lidar-tracker risk features, "
-                               "auto-reset, open-loop U(0,0.22)xU(-2,2) actions" % (N, a.peds, a.rays, a.k),
-                   "envs_per_gpu": N, "parallelism": "env-sharded x%d" % world},
+                               "next-step auto-reset (reset launches not counted as env-steps), open-loop "
+                               "U(0,0.22)xU(-2,2) actions" % (N, a.peds, a.rays, a.k),
+                   "envs_per_gpu": N, "parallelism": "env-sharded x%d" % world,
+                   "same_call_reset_value": taken_same_all / wall_same, "same_call_reset_ms_per_step": wall_same / a.steps * 1e3,
+                   "returns_allgather_ms": gather_ms},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "kernel": "cn_env_kernel", "kernel_ms": kernel_ms, "bytes_per_env_step": B},

@@ -18,7 +18,7 @@ CN_TF_COUNT = 12
 SD = dict(RX=0, RY=1, RYAW=2, RV=3, RW=4, CLOCK=5, WPX=6, WPY=7, PREV_DIST=8, PREV_HEAD=9, DQ0X=10, DQ0Y=11,
           DQ1X=12, DQ1Y=13, TS=14, BB=15, EGO=16, CPROB=17, EP_RETURN=18, LAST_RETURN=19)
 SI = dict(DONE=0, DQ_LEN=1, NTRACKS=2, EGO_VIOL=3, SOCIAL_VIOL=4, OBST_STEPS=5, SUCCESS=6, FAILURE=7, EP_STEP=8,
-          STATUS=9, NCONF=10, NENTRIES=11)
+          STATUS=9, NCONF=10, NENTRIES=11, PENDING_RESET=14, EPISODES=15)
 TF = dict(PX=0, PY=1, DIST=2, D0X=3, D0Y=4, D1X=5, D1Y=6, T=7, SPEED=8, VX=9, VY=10, DQLEN=11)
 
 EXPORTS = ["cn_abi_version", "cn_last_error", "cn_create", "cn_destroy", "cn_obs_dim", "cn_config_of",

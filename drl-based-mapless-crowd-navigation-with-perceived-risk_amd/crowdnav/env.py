@@ -39,7 +39,7 @@ class VecEnv:
         self.reward = torch.zeros(N, dtype=torch.float32, device=dev)
         self.done = torch.zeros(N, dtype=torch.uint8, device=dev)
         self.topk_idx = torch.full((N, K), -1, dtype=torch.int32, device=dev)
-        self._counters = torch.zeros((N, 8), dtype=torch.int32, device=dev)
+        self._counters = torch.zeros((N, 10), dtype=torch.int32, device=dev)
         self._ret = torch.zeros(N, dtype=torch.float32, device=dev)
         self._run = torch.zeros(N, dtype=torch.float32, device=dev)
 
@@ -86,6 +86,8 @@ class VecEnv:
 
     def step(self, action, step_counter=None, auto_reset=True, want_final=False):
         """Env.step for every env.  action: [N,2] float32 device tensor (v, w).
+        auto_reset: False | True/"same" (finished envs reset inside this call) | "next" (a finished env
+        spends the next call on its reset: action ignored, reward 0, done 0 -- shortest launches).
         Returns (obs, reward, done) device tensors (views of internal buffers)."""
         a = action
         if not (isinstance(a, torch.Tensor) and a.device == self.device and a.dtype == torch.float32 and a.is_contiguous()):
@@ -98,12 +100,14 @@ class VecEnv:
                            obs=self.obs.data_ptr(), final_obs=self.final_obs.data_ptr() if want_final else None,
                            obs_f64=self.obs_f64.data_ptr() if self.obs_f64 is not None else None,
                            reward=self.reward.data_ptr(), done=self.done.data_ptr(), topk_idx=self.topk_idx.data_ptr(),
-                           auto_reset=int(bool(auto_reset)), reserved=0)
+                           auto_reset={False: 0, True: 1, None: 0, "same": 1, "next": 2}.get(auto_reset, auto_reset),
+                           reserved=0)
         _abi.check(self.L.cn_step(self.h, C.byref(io), self._stream()))
         return self.obs, self.reward, self.done
 
     def counters(self):
-        """[N,8] int32: ego_viol, social_viol, obstacle_present_steps, ep_steps, success, failure, status, n_tracks."""
+        """[N,10] int32: ego_viol, social_viol, obstacle_present_steps, ep_steps, success, failure, status, n_tracks,
+        episodes finished, reset pending."""
         _abi.check(self.L.cn_get_counters(self.h, _ptr(self._counters), self._stream()))
         return self._counters
 

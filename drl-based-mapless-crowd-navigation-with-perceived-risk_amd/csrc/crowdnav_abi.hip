@@ -155,7 +155,7 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
     k.lidar_min = c.lidar_min; k.lidar_max = c.lidar_max; k.lidar_offset_x = c.lidar_offset_x;
     k.max_scan_range = c.max_scan_range; k.min_scan_range = c.min_scan_range; k.goal_x = c.goal_x; k.goal_y = c.goal_y;
     k.start_x = c.start_x; k.start_y = c.start_y; k.spawn_x = c.spawn_x; k.spawn_y = c.spawn_y; k.spawn_yaw = c.spawn_yaw;
-    k.waypoint_radius = c.waypoint_radius; k.goal_eps = c.goal_eps; k.angle_inc_deg = angle_increment_deg(R);
+    k.waypoint_radius = c.waypoint_radius; k.goal_eps = c.goal_eps; k.angle_inc_deg = angle_increment_deg(R); k.lidar_step = step;
     k.lidar_c = h->d_lidar; k.lidar_s = h->d_lidar + R; k.poly_c = h->d_poly; k.poly_s = h->d_poly + 64;
     k.sd = h->d_sd; k.si = h->d_si; k.ped_p = h->d_ped_p; k.ped_v = h->d_ped_v; k.ped_init = h->d_ped_init;
     k.ped_preset = h->d_ped_preset; k.trk = h->d_trk;

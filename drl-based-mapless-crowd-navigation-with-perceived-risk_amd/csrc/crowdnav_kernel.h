@@ -18,7 +18,7 @@ struct CnKParams {
     // constants (cn_config)
     double room_half, ped_radius, ped_vmax, robot_clearance, lidar_min, lidar_max, lidar_offset_x;
     double max_scan_range, min_scan_range, goal_x, goal_y, start_x, start_y, spawn_x, spawn_y, spawn_yaw;
-    double waypoint_radius, goal_eps, angle_inc_deg;
+    double waypoint_radius, goal_eps, angle_inc_deg, lidar_step;
     // tables (device)
     const double* lidar_c;  // [R] cos(k * span/(R-1)), deterministic sincos
     const double* lidar_s;  // [R]

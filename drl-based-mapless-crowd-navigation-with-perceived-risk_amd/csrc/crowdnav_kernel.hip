@@ -15,6 +15,13 @@
 #include "crowdnav_device.h"
 #include "crowdnav_kernel.h"
 
+// One wavefront per workgroup: the LDS processes a wave's DS instructions in issue order, so a
+// cross-lane hand-off through LDS needs no s_barrier and no vmcnt/lgkmcnt drain -- only the compiler
+// must not reorder the accesses.  (A real __syncthreads() here also waits for every outstanding
+// global store, which put ~30 memory-latency stalls on each env-step's critical path.)
+#define CN_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
+                       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+
 #define TY_NONE 0
 #define TY_W 1
 #define TY_O 2
@@ -28,7 +35,7 @@ struct EnvRegs {  // per-env scalars, uniform across the wave
     double rx, ry, ryaw, rv, rw, clock, wpx, wpy, prev_dist, prev_head;
     double dq0x, dq0y, dq1x, dq1y, ts, bb, ego, cprob, ep_ret, last_ret;
     long long crowd_ms;
-    int done, dq_len, ntracks, ego_viol, social_viol, obst_steps, succ, fail, ep_step, status, nconf, nent;
+    int done, dq_len, ntracks, ego_viol, social_viol, obst_steps, succ, fail, ep_step, status, nconf, nent, pending, episodes;
 };
 
 struct Lds {
@@ -79,13 +86,14 @@ __device__ __forceinline__ bool in_box(double x, double y, double gx, double gy,
 //   0 <= tn/den <= 1  <=>  (den > 0 ? 0 <= tn <= den : den <= tn <= 0)   (also for the rounded quotient)
 //   0 <= un/den <  1  likewise with a strict upper bound.
 // Returns the ballot of hit lanes; hit lanes get their intersection point.
-__device__ __forceinline__ unsigned long long ring_segment(const CnKParams& p, int lane, double cx, double cy, double r,
+struct Poly { double c0, s0, c1, s1; };  // this lane's edge: unit-circle vertices `lane` and `lane + 1`
+
+__device__ __forceinline__ unsigned long long ring_segment(const Poly& pg, int lane, double cx, double cy, double r,
                                                            double ax, double ay, double bx, double by,
                                                            double* hx, double* hy)
 {
-    int k2 = (lane + 1) & 63;
-    double c0x = cx + r * p.poly_c[lane], c0y = cy + r * p.poly_s[lane];
-    double c1x = cx + r * p.poly_c[k2], c1y = cy + r * p.poly_s[k2];
+    double c0x = cx + r * pg.c0, c0y = cy + r * pg.s0;
+    double c1x = cx + r * pg.c1, c1y = cy + r * pg.s1;
     double rx = bx - ax, ry = by - ay;
     double sx = c1x - c0x, sy = c1y - c0y;
     double den = rx * sy - ry * sx;
@@ -120,10 +128,10 @@ __device__ __forceinline__ u64 uni64(u64 v)
 }
 
 // UTL:296-314 get_local_goal_waypoints
-__device__ __forceinline__ void waypoint_refresh(const CnKParams& p, EnvRegs& e, int lane, double px, double py)
+__device__ __forceinline__ void waypoint_refresh(const CnKParams& p, const Poly& pg, EnvRegs& e, int lane, double px, double py)
 {
     double hx = 0.0, hy = 0.0;
-    unsigned long long m = ring_segment(p, lane, px, py, p.waypoint_radius, px, py, p.goal_x, p.goal_y, &hx, &hy);
+    unsigned long long m = ring_segment(pg, lane, px, py, p.waypoint_radius, px, py, p.goal_x, p.goal_y, &hx, &hy);
     if (__popcll(m) == 1) {
         int src = __ffsll((long long)m) - 1;
         e.wpx = bcast_d(hx, src);
@@ -203,7 +211,7 @@ __device__ __forceinline__ void sim_advance(const CnKParams& p, EnvRegs& e, int 
 
 // ---- Env.get_state (ENV:245-1044) ----------------------------------------------------------------
 // ped_p: pedestrian positions in LDS.  Writes the observation (float32 and optionally float64).
-__device__ __forceinline__ void observe(const CnKParams& p, EnvRegs& e, const Lds& L, int env, int lane, int step_counter,
+__device__ __forceinline__ void observe(const CnKParams& p, const Poly& pg, EnvRegs& e, const Lds& L, int env, int lane, int step_counter,
                         float* obs32, float* fin32, double* obs64, int* done_out)
 {
     const int R = p.R, n = R - 1, K = p.K, D = n + 7 + 4 * K;
@@ -211,10 +219,10 @@ __device__ __forceinline__ void observe(const CnKParams& p, EnvRegs& e, const Ld
     const double px = e.rx, py = e.ry, yaw = e.ryaw, v = e.rv, w = e.rw, now = e.clock;
 
     // ENV:246-265
-    if (step_counter == 1) waypoint_refresh(p, e, lane, px, py);
+    if (step_counter == 1) waypoint_refresh(p, pg, e, lane, px, py);
     double distance_to_goal = cn_np_around2(dist3(px, py, e.wpx, e.wpy));
     double heading = cn_py_round2(heading_to_goal(p, e, px, py, yaw));
-    if (step_counter % 5 == 0 || distance_to_goal < e.prev_dist) waypoint_refresh(p, e, lane, px, py);
+    if (step_counter % 5 == 0 || distance_to_goal < e.prev_dist) waypoint_refresh(p, pg, e, lane, px, py);
     // ENV:267-268: the angular velocity is used as the angle
     double sw_, cw_;
     cn_det_sincos(w, &sw_, &cw_);
@@ -245,7 +253,7 @@ __device__ __forceinline__ void observe(const CnKParams& p, EnvRegs& e, const Ld
             nnear += __popcll(m);
         }
     }
-    __syncthreads();
+    CN_SYNC();
     const bool wall_x = !(h - fabs(ox) > p.lidar_max + 1e-6);
     const bool wall_y = !(h - fabs(oy) > p.lidar_max + 1e-6);
     double smin = 1e300;
@@ -255,7 +263,8 @@ __device__ __forceinline__ void observe(const CnKParams& p, EnvRegs& e, const Ld
     // End points, rounded ranges and gradients are 3-decimal values: LDS keeps the integer thousandths
     // (x == cn_div1000(mil) bit for bit), which halves the working set and doubles the waves per CU.
     for (int k = lane; k < R; k += 64) {
-        double lc = p.lidar_c[k], ls = p.lidar_s[k];
+        double lc, ls;  // ray k in the robot frame; same bits as a host table of cn_det_sincos(k * step)
+        cn_det_sincos((double)k * p.lidar_step, &ls, &lc);
         double dx = fma(cy, lc, -(sy * ls));
         double dy = fma(sy, lc, cy * ls);
         double t = INFINITY;
@@ -308,7 +317,7 @@ __device__ __forceinline__ void observe(const CnKParams& p, EnvRegs& e, const Ld
         }
     }
     smin = cn_wave_min_d(smin);
-    __syncthreads();
+    CN_SYNC();
 
     if (step_counter == 0) {  // UTL:405-419 + ENV:287-294: mean spacing of the end points of an all-max scan
         double sum = 0.0;     // Python sum(): strictly left to right
@@ -323,10 +332,10 @@ __device__ __forceinline__ void observe(const CnKParams& p, EnvRegs& e, const Ld
                 double x1 = cn_py_round3(px + (MAXR * c1)), y1 = cn_py_round3(py + (MAXR * s1) * -1.0);
                 L.stage[lane] = hypot(x0 - x1, y0 - y1);
             }
-            __syncthreads();
+            CN_SYNC();
             int cnt = min(64, n - i0);
             for (int c = 0; c < cnt; ++c) sum += L.stage[c];
-            __syncthreads();
+            CN_SYNC();
         }
         e.bb = sum / (double)n;
         double qx = cn_py_round3(px), qy = cn_py_round3(py);
@@ -354,7 +363,7 @@ __device__ __forceinline__ void observe(const CnKParams& p, EnvRegs& e, const Ld
         L.gq[i] = gm;
     }
     lastnn = cn_wave_max_i(lastnn);
-    __syncthreads();
+    CN_SYNC();
     // ENV:348-367 change of gradient c[i] = |g[i]-g[i+1]| (None if either is None), recomputed where needed;
     // ray n-1 takes `last_grad`, i.e. c[lastnn] of the last valid gradient before it.
 #define CHG(a_, b_) (((a_) == GNONE || (b_) == GNONE) ? CN_NAN : fabs(cn_div1000((double)(a_)) - cn_div1000((double)(b_))))
@@ -378,7 +387,7 @@ __device__ __forceinline__ void observe(const CnKParams& p, EnvRegs& e, const Ld
         if (lane == 0) { WORD(M_NONE, q) = b0; WORD(M_ZERO, q) = b1; WORD(M_EQ, q) = b2; WORD(M_NNONE, q) = b3; WORD(M_NZERO, q) = b4; }
     }
 #undef CHG
-    __syncthreads();
+    CN_SYNC();
     // ENV:372-410 object-type state machine.  Loop-carried state (last_type, du_count) lives in scalar
     // registers; only occupied rays are visited (bit scan over the flag words), no memory in the loop
     // except the rare aliasing store.
@@ -416,7 +425,7 @@ __device__ __forceinline__ void observe(const CnKParams& p, EnvRegs& e, const Ld
             if (lane == 0) { WORD(M_ISW, q) = isw; WORD(M_ISO, q) = iso; WORD(M_ALIAS, q) = al; }
         }
     }
-    __syncthreads();
+    CN_SYNC();
     // ENV:433-445: a typed ray carries the range and pose of the ray its list was created at.  In place:
     // only aliased rays change, and the rays they copy from are never aliased themselves.
     for (int i = lane; i < n; i += 64) {
@@ -425,7 +434,7 @@ __device__ __forceinline__ void observe(const CnKParams& p, EnvRegs& e, const Ld
             L.dmil[i] = L.dmil[s_]; L.ptx[i] = L.ptx[s_]; L.pty[i] = L.pty[s_];
         }
     }
-    __syncthreads();
+    CN_SYNC();
     // ENV:448-485 association of consecutive rays; brk bit i = a segment closes after ray i
     int fe = n, lb = -1, nsegs0 = 0;
     for (int q = 0; q < W; ++q) {
@@ -447,7 +456,7 @@ __device__ __forceinline__ void observe(const CnKParams& p, EnvRegs& e, const Ld
     const int ls = lb + 1;            // start of the last segment
     // ENV:490-502 first <-> last with twice the box
     bool merge = (nsegs0 > 1) && (cn_iou3(PX(0), PY(0), PX(n - 1), PY(n - 1), e.bb * 2) > 0.0);
-    __syncthreads();
+    CN_SYNC();
     // order-space: position k -> ray.  merged: [0..fe] ++ [ls..n-1] ++ [fe+1..ls-1]
     const int nl = n - ls;  // length of the last segment
 #define ORDER(k) (merge ? ((k) <= fe ? (k) : ((k) <= fe + nl ? ls + ((k) - fe - 1) : (k) - nl)) : (k))
@@ -472,7 +481,7 @@ __device__ __forceinline__ void observe(const CnKParams& p, EnvRegs& e, const Ld
         if (lane == 0) { WORD(M_SEG, q) = b0; WORD(M_KW, q) = b1; WORD(M_KO, q) = b2; WORD(M_OCC, q) = b3; }
         nseg += __popcll(b0);
     }
-    __syncthreads();
+    CN_SYNC();
     // per-word running totals: types seen before word q, last segment end before word q
     if (lane == 0) {
         int bw = 0, bo = 0, le = -1;
@@ -483,7 +492,7 @@ __device__ __forceinline__ void observe(const CnKParams& p, EnvRegs& e, const Ld
             if (sw) le = 64 * q + 63 - __builtin_clzll(sw);
         }
     }
-    __syncthreads();
+    CN_SYNC();
     // ENV:568-620 confirmation: every lane that owns a segment end evaluates its segment
     int nconf = 0;
     for (int q = 0; q < ((p.ablate & 4) ? 0 : W); ++q) {
@@ -537,7 +546,7 @@ __device__ __forceinline__ void observe(const CnKParams& p, EnvRegs& e, const Ld
 #undef PY
 #undef GNONE
     e.nconf = nconf;
-    __syncthreads();
+    CN_SYNC();
 
     // ENV:637-654
     int n_obst = 0, ego_hit = 0;
@@ -555,7 +564,7 @@ __device__ __forceinline__ void observe(const CnKParams& p, EnvRegs& e, const Ld
 #pragma unroll
         for (int f = 0; f < CN_TF_COUNT; ++f) T[f * CN_MAX_TRACKS + lane] = L.gtrk[f * CN_MAX_TRACKS + lane];
     }
-    __syncthreads();
+    CN_SYNC();
 #define TRK(f, i) T[(f) * CN_MAX_TRACKS + (i)]
     bool add_unchecked = false;
     if (p.ablate & 16) { e.ntracks = 0; nconf = 0; }
@@ -569,7 +578,7 @@ __device__ __forceinline__ void observe(const CnKParams& p, EnvRegs& e, const Ld
             TRK(CN_TF_DQLEN, lane) = 1.0;
         }
         for (int j = lane; j < nconf; j += 64) L.checked[j] = 0;
-        __syncthreads();
+        CN_SYNC();
         if (nconf == 0) {
             e.ntracks = 0;  // ENV:683-686 nets out to clearing every track
         } else {
@@ -604,7 +613,7 @@ __device__ __forceinline__ void observe(const CnKParams& p, EnvRegs& e, const Ld
                     alive |= (1ull << i);
                 }
             }
-            __syncthreads();
+            CN_SYNC();
             // compact the survivors, order preserved
             double rec[CN_TF_COUNT];
             bool mine = (lane < nt0) && ((alive >> lane) & 1ull);
@@ -612,7 +621,7 @@ __device__ __forceinline__ void observe(const CnKParams& p, EnvRegs& e, const Ld
 #pragma unroll
                 for (int f = 0; f < CN_TF_COUNT; ++f) rec[f] = TRK(f, lane);
             }
-            __syncthreads();
+            CN_SYNC();
             if (mine) {
                 int slot = __popcll(alive & ((1ull << lane) - 1ull));
 #pragma unroll
@@ -622,7 +631,7 @@ __device__ __forceinline__ void observe(const CnKParams& p, EnvRegs& e, const Ld
             add_unchecked = true;  // ENV:723-743
         }
     }
-    __syncthreads();
+    CN_SYNC();
     if (add_unchecked) {
         for (int j0 = 0; j0 < nconf; j0 += 64) {
             int j = j0 + lane;
@@ -643,13 +652,13 @@ __device__ __forceinline__ void observe(const CnKParams& p, EnvRegs& e, const Ld
             e.ntracks = total;
         }
     }
-    __syncthreads();
+    CN_SYNC();
     // ENV:745-760 speed of the tracks matched in this call
     if (lane < e.ntracks && TRK(CN_TF_DQLEN, lane) > 1.5) {
         double dc = hypot(TRK(CN_TF_D0Y, lane) - TRK(CN_TF_D1Y, lane), TRK(CN_TF_D0X, lane) - TRK(CN_TF_D1X, lane));
         TRK(CN_TF_SPEED, lane) = dc / TRK(CN_TF_T, lane);
     }
-    __syncthreads();
+    CN_SYNC();
 
     // default K x [px, py, 0, 0] (ENV:273)
     for (int i = lane; i < 4 * K; i += 64) {
@@ -658,7 +667,7 @@ __device__ __forceinline__ void observe(const CnKParams& p, EnvRegs& e, const Ld
     }
     if (lane < K) L.kidx[lane] = -1;
     e.nent = 0;
-    __syncthreads();
+    CN_SYNC();
 
     // ---- ENV:769-996 collision cone / collision probability / top-K -------------------------------
     if (e.dq_len == 2 && !(p.ablate & 8)) {
@@ -680,7 +689,7 @@ __device__ __forceinline__ void observe(const CnKParams& p, EnvRegs& e, const Ld
             if (TRK(CN_TF_DQLEN, l) > 1.5) { chx = TRK(CN_TF_D0X, l) - TRK(CN_TF_D1X, l); chy = TRK(CN_TF_D0Y, l) - TRK(CN_TF_D1Y, l); }
             vo_x = e.dq1x + chx; vo_y = e.dq1y + chy;
         }
-        __syncthreads();
+        CN_SYNC();
         // UTL:251-293 collision point per track; lanes = the 64 ring edges
         const double a0x = e.dq0x, a0y = e.dq0y;
         double gradient = (vo_y == 0.0) ? 0.0 : (vo_x - a0x) / vo_y - a0y;  // UTL:261 precedence as written
@@ -693,7 +702,7 @@ __device__ __forceinline__ void observe(const CnKParams& p, EnvRegs& e, const Ld
             for (int x2 = hi; x2 > lo; --x2) {
                 double y2 = ((double)x2 * gradient) + bb0;
                 double hx = 0.0, hy = 0.0;
-                unsigned long long m = ring_segment(p, lane, tx, ty_, 0.178, a0x, a0y, (double)x2, y2, &hx, &hy);
+                unsigned long long m = ring_segment(pg, lane, tx, ty_, 0.178, a0x, a0y, (double)x2, y2, &hx, &hy);
                 int cnt = __popcll(m);
                 if (cnt == 0) continue;
                 if (cnt == 1) break;  // Point has no .geoms -> None
@@ -722,7 +731,7 @@ __device__ __forceinline__ void observe(const CnKParams& p, EnvRegs& e, const Ld
             if (i == 0 || ego > ego_max) ego_max = ego;
         }
         e.nent = nt;
-        __syncthreads();
+        CN_SYNC();
         if (nt == 0) { e.cprob = 0.0; e.ego = 0.0; }  // ENV:862-876
         else {  // ENV:878-905: stable descending sort, keep the LAST K
             e.ego = ego_max;
@@ -766,7 +775,7 @@ __device__ __forceinline__ void observe(const CnKParams& p, EnvRegs& e, const Ld
         L.tail[4] = cn_py_round3(yaw);
         L.tail[5] = cn_py_round3(agent_vel_x); L.tail[6] = cn_py_round3(agent_vel_y);
     }
-    __syncthreads();
+    CN_SYNC();
     for (int i = lane; i < 7 + 4 * K; i += 64) {
         double so = cn_np_around3(L.tail[i]);
         L.tail[i] = so;
@@ -779,12 +788,12 @@ __device__ __forceinline__ void observe(const CnKParams& p, EnvRegs& e, const Ld
 #pragma unroll
         for (int f = 0; f < CN_TF_COUNT; ++f) L.gtrk[f * CN_MAX_TRACKS + lane] = L.trk[f * CN_MAX_TRACKS + lane];
     }
-    __syncthreads();
+    CN_SYNC();
     *done_out = e.done;
 }
 
 // ENV:1046-1162 compute_reward; state[n] = heading, state[n+1] = distance are in L.tail[0..1]
-__device__ __forceinline__ double compute_reward(const CnKParams& p, EnvRegs& e, const Lds& L, int lane, int done)
+__device__ __forceinline__ double compute_reward(const CnKParams& p, const Poly& pg, EnvRegs& e, const Lds& L, int lane, int done)
 {
     double cur_head = L.tail[0], cur_dist = L.tail[1];
     double dd = cur_dist - e.prev_dist, hd = cur_head - e.prev_head;
@@ -804,7 +813,7 @@ __device__ __forceinline__ double compute_reward(const CnKParams& p, EnvRegs& e,
         if (cur_head < 0 && ph < 0) htg = 0;
     }
     if (in_box(e.rx, e.ry, e.wpx, e.wpy, p.goal_eps)) {  // ENV:1109-1125
-        waypoint_refresh(p, e, lane, e.rx, e.ry);
+        waypoint_refresh(p, pg, e, lane, e.rx, e.ry);
         wp = 200;
         if (in_box(e.wpx, e.wpy, p.goal_x, p.goal_y, p.goal_eps)) { e.wpx = p.goal_x; e.wpy = p.goal_y; }
     }
@@ -862,6 +871,9 @@ extern "C" __global__ void __launch_bounds__(64) cn_env_kernel(CnKParams p)
         L.gtrk = p.trk + (size_t)env * CN_TF_COUNT * CN_MAX_TRACKS;
     }
 
+    Poly pg;
+    pg.c0 = p.poly_c[lane]; pg.s0 = p.poly_s[lane]; pg.c1 = p.poly_c[(lane + 1) & 63]; pg.s1 = p.poly_s[(lane + 1) & 63];
+
     // ---- load env state -------------------------------------------------------------------------
     double* sd = p.sd + (size_t)env * CN_SD_COUNT;
     int* si = p.si + (size_t)env * CN_SI_COUNT;
@@ -875,7 +887,7 @@ extern "C" __global__ void __launch_bounds__(64) cn_env_kernel(CnKParams p)
     e.done = si[CN_SI_DONE]; e.dq_len = si[CN_SI_DQ_LEN]; e.ntracks = si[CN_SI_NTRACKS];
     e.ego_viol = si[CN_SI_EGO_VIOL]; e.social_viol = si[CN_SI_SOCIAL_VIOL]; e.obst_steps = si[CN_SI_OBST_STEPS];
     e.succ = si[CN_SI_SUCCESS]; e.fail = si[CN_SI_FAILURE]; e.ep_step = si[CN_SI_EP_STEP]; e.status = si[CN_SI_STATUS];
-    e.nconf = si[CN_SI_NCONF]; e.nent = si[CN_SI_NENTRIES];
+    e.nconf = si[CN_SI_NCONF]; e.nent = si[CN_SI_NENTRIES]; e.pending = si[CN_SI_PENDING_RESET]; e.episodes = si[CN_SI_EPISODES];
     e.crowd_ms = (long long)(((unsigned long long)(unsigned)si[CN_SI_CROWD_HI] << 32) | (unsigned)si[CN_SI_CROWD_LO]);
 
     double* gped_p = p.ped_p + (size_t)env * 2 * P;
@@ -883,11 +895,19 @@ extern "C" __global__ void __launch_bounds__(64) cn_env_kernel(CnKParams p)
     const double* gped_init = p.ped_init + (size_t)env * 2 * P;
     double* pedv = L.pedv;  // velocities are only needed while advancing
     for (int i = lane; i < 2 * P; i += 64) { L.ped[i] = gped_p[i]; pedv[i] = gped_v[i]; }
-    __syncthreads();
+    CN_SYNC();
 
     int done = 0;
     bool need_reset = (p.mode == CN_MODE_RESET);
-    if (p.mode == CN_MODE_STEP) {
+    // auto_reset == 2 ("next-step" reset, the gymnasium NEXT_STEP convention): an env that finished in
+    // the previous launch spends THIS launch on Env.reset() -- its action is ignored, reward 0, done 0 --
+    // so no wavefront ever runs two observations back to back and the launch's critical path halves.
+    if (p.mode == CN_MODE_STEP && p.auto_reset == 2 && e.pending) {
+        need_reset = true;
+        e.pending = 0;
+        if (lane == 0) { p.reward[env] = 0.0f; p.done[env] = 0; }
+        if (p.topk_idx && lane < K) p.topk_idx[(size_t)env * K + lane] = -1;
+    } else if (p.mode == CN_MODE_STEP) {
         // ---- Env.step (ENV:1164-1225), continuous mode ---------------------------------------------
         e.ep_step += 1;
         const int sc = p.step_counter ? p.step_counter[env] : e.ep_step;
@@ -906,9 +926,9 @@ extern "C" __global__ void __launch_bounds__(64) cn_env_kernel(CnKParams p)
         e.ts = end_timestep;                                  // ENV:1209
         e.clock += (double)p.scan_latency_ms / 1000.0;        // wait_for_message('scan') (ENV:1218)
         sim_advance(p, e, env, lane, L.ped, pedv, p.scan_latency_ms);
-        __syncthreads();
-        observe(p, e, L, env, lane, sc, p.obs, p.final_obs, p.obs_f64, &done);
-        double r = compute_reward(p, e, L, lane, done);
+        CN_SYNC();
+        observe(p, pg, e, L, env, lane, sc, p.obs, p.final_obs, p.obs_f64, &done);
+        double r = compute_reward(p, pg, e, L, lane, done);
         e.ep_ret += r;
         if (lane == 0) {
             p.reward[env] = (float)r;
@@ -918,30 +938,33 @@ extern "C" __global__ void __launch_bounds__(64) cn_env_kernel(CnKParams p)
         if (done) {
             e.rv = 0.0; e.rw = 0.0;                           // pub_cmd_vel.publish(Twist()) (ENV:1160)
             e.last_ret = e.ep_ret;
-            need_reset = (p.auto_reset != 0);
+            e.episodes += 1;
+            need_reset = (p.auto_reset == 1);
+            e.pending = (p.auto_reset == 2);
         }
-        __syncthreads();
+        CN_SYNC();
     }
     if (need_reset) {
+        __syncthreads();  // rare path: drain the tracker-table stores of the step phase before they are re-read
         // ---- Env.reset (ENV:1227-1263) + TRAIN:114-116 -----------------------------------------------
         // gazebo/reset_simulation: poses back to their initial values, twists zeroed (crowd clock keeps running)
         e.rx = p.spawn_x; e.ry = p.spawn_y; e.ryaw = p.spawn_yaw; e.rv = 0.0; e.rw = 0.0;
         for (int i = lane; i < 2 * P; i += 64) { L.ped[i] = gped_init[i]; pedv[i] = 0.0; }
-        __syncthreads();
+        CN_SYNC();
         e.clock += (double)p.scan_latency_ms / 1000.0;        // wait_for_message('scan') (ENV:1238)
         sim_advance(p, e, env, lane, L.ped, pedv, p.scan_latency_ms);
-        __syncthreads();
+        CN_SYNC();
         e.prev_dist = dist3(e.rx, e.ry, e.wpx, e.wpy);        // ENV:1243 (unrounded)
         e.prev_head = heading_to_goal(p, e, e.rx, e.ry, e.ryaw);  // ENV:1244
-        __syncthreads();
+        CN_SYNC();
         int d2 = 0;
-        observe(p, e, L, env, lane, 0, p.obs, nullptr, p.obs_f64, &d2);
+        observe(p, pg, e, L, env, lane, 0, p.obs, nullptr, p.obs_f64, &d2);
         e.social_viol = 0; e.ego_viol = 0; e.obst_steps = 0;  // ENV:1260-1262
         e.clock += (double)p.settle_ms / 1000.0;              // TRAIN:114 time.sleep(0.1)
         sim_advance(p, e, env, lane, L.ped, pedv, p.settle_ms);
         e.done = 0;                                           // TRAIN:116
-        e.ep_step = 0; e.ep_ret = 0.0;
-        __syncthreads();
+        e.ep_step = 0; e.ep_ret = 0.0; e.pending = 0;
+        CN_SYNC();
     }
 
     // ---- write env state back ---------------------------------------------------------------------
@@ -956,7 +979,7 @@ extern "C" __global__ void __launch_bounds__(64) cn_env_kernel(CnKParams p)
         si[CN_SI_DONE] = e.done; si[CN_SI_DQ_LEN] = e.dq_len; si[CN_SI_NTRACKS] = e.ntracks;
         si[CN_SI_EGO_VIOL] = e.ego_viol; si[CN_SI_SOCIAL_VIOL] = e.social_viol; si[CN_SI_OBST_STEPS] = e.obst_steps;
         si[CN_SI_SUCCESS] = e.succ; si[CN_SI_FAILURE] = e.fail; si[CN_SI_EP_STEP] = e.ep_step; si[CN_SI_STATUS] = e.status;
-        si[CN_SI_NCONF] = e.nconf; si[CN_SI_NENTRIES] = e.nent;
+        si[CN_SI_NCONF] = e.nconf; si[CN_SI_NENTRIES] = e.nent; si[CN_SI_PENDING_RESET] = e.pending; si[CN_SI_EPISODES] = e.episodes;
         si[CN_SI_CROWD_LO] = (int)(unsigned)((unsigned long long)e.crowd_ms & 0xffffffffull);
         si[CN_SI_CROWD_HI] = (int)(unsigned)((unsigned long long)e.crowd_ms >> 32);
     }
@@ -972,8 +995,9 @@ extern "C" __global__ void cn_gather_kernel(CnKParams p, float* last_ret, float*
     if (last_ret) last_ret[i] = (float)sd[CN_SD_LAST_RETURN];
     if (run_ret) run_ret[i] = (float)sd[CN_SD_EP_RETURN];
     if (counters) {
-        int32_t* c = counters + (size_t)i * 8;
+        int32_t* c = counters + (size_t)i * 10;
         c[0] = si[CN_SI_EGO_VIOL]; c[1] = si[CN_SI_SOCIAL_VIOL]; c[2] = si[CN_SI_OBST_STEPS]; c[3] = si[CN_SI_EP_STEP];
         c[4] = si[CN_SI_SUCCESS]; c[5] = si[CN_SI_FAILURE]; c[6] = si[CN_SI_STATUS]; c[7] = si[CN_SI_NTRACKS];
+        c[8] = si[CN_SI_EPISODES]; c[9] = si[CN_SI_PENDING_RESET];
     }
 }

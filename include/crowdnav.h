@@ -89,7 +89,9 @@ typedef struct cn_step_io {
     float* reward;               /* dev [N] */
     uint8_t* done;               /* dev [N] */
     int32_t* topk_idx;           /* dev [N,K] or NULL: tracker slot of each feature row, -1 = padding */
-    int32_t auto_reset;          /* !=0: finished envs run Env.reset() (+TRAIN:114-116) inside the call */
+    int32_t auto_reset;          /* 0: none.  1: finished envs run Env.reset() (+TRAIN:114-116) inside the same call.
+                                  * 2: "next-step" reset -- a finished env spends the NEXT call on Env.reset() (its
+                                  *    action is ignored, reward 0, done 0, obs = first observation of the new episode) */
     int32_t reserved;
 } cn_step_io;
 
@@ -113,7 +115,8 @@ int cn_reset(cn_handle h, const uint8_t* mask, float* obs, double* obs_f64, void
 int cn_step(cn_handle h, const cn_step_io* io, void* stream);
 
 /* get_episode_status / get_*_safety_violation_status inputs (ENV:1265-1283).
- * out: dev [N,8] = ego_viol, social_viol, obstacle_present_steps, ep_steps, success, failure, status, n_tracks */
+ * out: dev [N,10] = ego_viol, social_viol, obstacle_present_steps, ep_steps, success, failure, status, n_tracks,
+ *                  episodes finished since cn_create, reset pending (auto_reset == 2) */
 int cn_get_counters(cn_handle h, int32_t* out, void* stream);
 /* return of the last finished episode and running return, dev [N] each (either may be NULL) */
 int cn_get_returns(cn_handle h, float* last_return, float* running_return, void* stream);
@@ -138,7 +141,7 @@ enum {
 enum {
     CN_SI_DONE = 0, CN_SI_DQ_LEN, CN_SI_NTRACKS, CN_SI_EGO_VIOL, CN_SI_SOCIAL_VIOL, CN_SI_OBST_STEPS,
     CN_SI_SUCCESS, CN_SI_FAILURE, CN_SI_EP_STEP, CN_SI_STATUS, CN_SI_NCONF, CN_SI_NENTRIES,
-    CN_SI_CROWD_LO, CN_SI_CROWD_HI, CN_SI_COUNT = 16
+    CN_SI_CROWD_LO, CN_SI_CROWD_HI, CN_SI_PENDING_RESET, CN_SI_EPISODES, CN_SI_COUNT = 16
 };
 /* track record fields (ENV:663-670: pose, range, deque(<=2), time stamp, speed, velocity) */
 enum {

@@ -75,6 +75,7 @@ typedef struct {
     double ep_return, last_return;
     int status;
     int n_confirmed, n_entries;
+    int pending_reset;
 } env_t;
 
 struct cno_sim {
@@ -951,6 +952,7 @@ static void env_reset_flow(const cno_sim* s, env_t* e, int64_t gid, double* obs)
     sim_advance(s, e, gid, c->settle_ms);
     e->done = 0;                                                   /* TRAIN:116 */
     e->ep_step = 0; e->ep_return = 0.0;
+    e->pending_reset = 0;
 }
 
 /* Env.step (ENV:1164-1225), continuous mode */
@@ -1094,6 +1096,14 @@ int cno_step(cno_sim* s, const double* action, const int32_t* step_counter, int 
         int32_t* idx = topk_idx ? topk_idx + (size_t)e * K : idx_local;
         double* o = obs + (size_t)e * s->D;
         double r; int d;
+        if (auto_reset == 2 && en->pending_reset) { /* next-step reset: this call resets, action ignored */
+            en->pending_reset = 0;
+            env_reset_flow(s, en, gid, o);
+            reward[e] = 0.0; done[e] = 0;
+            for (int k = 0; k < K; ++k) idx[k] = -1;
+            if (final_obs) memcpy(final_obs + (size_t)e * s->D, o, sizeof(double) * s->D);
+            continue;
+        }
         en->ep_step += 1;
         int sc = step_counter ? step_counter[e] : en->ep_step;
         env_step_flow(s, en, gid, action[2 * e], action[2 * e + 1], sc, o, &r, &d, idx);
@@ -1103,7 +1113,8 @@ int cno_step(cno_sim* s, const double* action, const int32_t* step_counter, int 
         if (final_obs) memcpy(final_obs + (size_t)e * s->D, o, sizeof(double) * s->D);
         if (d) {
             en->last_return = en->ep_return;
-            if (auto_reset) env_reset_flow(s, en, gid, o);
+            if (auto_reset == 1) env_reset_flow(s, en, gid, o);
+            else if (auto_reset == 2) en->pending_reset = 1;
         }
     }
     return 0;

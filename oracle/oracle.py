@@ -123,6 +123,10 @@ def lib():
     return _lib
 
 
+def _ar(mode):
+    return {False: 0, True: 1, None: 0, "next": 2, "same": 1}.get(mode, mode)
+
+
 def _dp(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 
@@ -179,7 +183,7 @@ class Oracle:
         sc = None
         if step_counter is not None:
             sc = np.ascontiguousarray(step_counter, dtype=np.int32).reshape(self.N)
-        self.L.cno_step(self.h, _dp(a), sc.ctypes.data if sc is not None else None, int(auto_reset), _dp(obs),
+        self.L.cno_step(self.h, _dp(a), sc.ctypes.data if sc is not None else None, _ar(auto_reset), _dp(obs),
                         fin.ctypes.data if fin is not None else None, _dp(rew), done.ctypes.data, idx.ctypes.data)
         if want_final:
             return obs, rew, done, idx, fin

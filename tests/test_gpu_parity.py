@@ -24,7 +24,7 @@ def _pair(oracle_mod, **kw):
     return torch, env, orc
 
 
-def _compare_rollout(oracle_mod, steps, seed, **kw):
+def _compare_rollout(oracle_mod, steps, seed, reset_mode=True, **kw):
     torch, env, orc = _pair(oracle_mod, seed=seed, **kw)
     N = env.N
     env.reset(); torch.cuda.synchronize()
@@ -37,16 +37,17 @@ def _compare_rollout(oracle_mod, steps, seed, **kw):
     exact_rows = 0
     for t in range(steps):
         act = np.stack([rng.uniform(0, 0.22, N), rng.uniform(-2, 2, N)], 1).astype(np.float32)
-        env.step(torch.from_numpy(act).cuda(), auto_reset=True, want_final=True)
+        env.step(torch.from_numpy(act).cuda(), auto_reset=reset_mode, want_final=True)
         torch.cuda.synchronize()
-        oc, rc, dc, ic, fc = orc.step(act.astype(np.float64), auto_reset=True, want_final=True)
+        oc, rc, dc, ic, fc = orc.step(act.astype(np.float64), auto_reset=reset_mode, want_final=True)
         dg = env.done.cpu().numpy()
         assert np.array_equal(dg, dc), "done flags differ at step %d" % t                       # bit-exact
         assert np.array_equal(env.topk_idx.cpu().numpy(), ic), "top-K indices differ at step %d" % t  # bit-exact
         assert np.abs(env.reward.cpu().numpy() - rc).max() <= TOL, "reward at step %d" % t
         og = env.obs_f64.cpu().numpy()
         assert np.abs(og - oc).max() <= TOL, "obs at step %d: %g" % (t, np.abs(og - oc).max())
-        assert np.abs(env.final_obs.cpu().numpy() - fc.astype(np.float32)).max() <= TOL
+        if reset_mode != "next":
+            assert np.abs(env.final_obs.cpu().numpy() - fc.astype(np.float32)).max() <= TOL
         exact_rows += int((og == oc).all(1).sum())
         n_done += int(dc.sum())
     assert np.array_equal(env.counters().cpu().numpy()[:, :6], orc.counters())
@@ -67,6 +68,12 @@ def test_rollout_parity_train_config(oracle_mod):
     n_done, frac = _compare_rollout(oracle_mod, steps=150, seed=3, n_envs=64, n_peds=20, max_steps=60)
     assert n_done > 20          # auto-reset path exercised
     assert frac > 0.999
+
+
+def test_rollout_parity_next_step_reset_mode(oracle_mod):
+    # auto_reset = 2: a finished env spends the next call on its reset (action ignored, reward 0, done 0)
+    n_done, frac = _compare_rollout(oracle_mod, steps=150, seed=4, reset_mode="next", n_envs=64, n_peds=20, max_steps=50)
+    assert n_done > 20 and frac > 0.999
 
 
 def test_rollout_parity_dense_crowd(oracle_mod):

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--max-steps", type=int, default=120)
     ap.add_argument("--min-scan", type=float, default=0.12)
     ap.add_argument("--verbose", type=int, default=5)
+    ap.add_argument("--reset-mode", default="same", choices=["same", "next"])
     a = ap.parse_args()
     import torch
     from crowdnav import Config
@@ -45,9 +46,9 @@ def main():
     shown = 0
     for t in range(a.steps):
         act = np.stack([rng.uniform(0, 0.22, a.envs), rng.uniform(-2, 2, a.envs)], 1).astype(np.float32)
-        env.step(torch.from_numpy(act).cuda(), auto_reset=True, want_final=True)
+        env.step(torch.from_numpy(act).cuda(), auto_reset=a.reset_mode, want_final=True)
         torch.cuda.synchronize()
-        oc, rc, dc, ic, fc = orc.step(act.astype(np.float64), auto_reset=True, want_final=True)
+        oc, rc, dc, ic, fc = orc.step(act.astype(np.float64), auto_reset=a.reset_mode, want_final=True)
         og = env.obs_f64.cpu().numpy(); rg = env.reward.cpu().numpy(); dg = env.done.cpu().numpy(); ig = env.topk_idx.cpu().numpy()
         fg = env.final_obs.cpu().numpy()
         bad_rows = ~(og == oc).all(1)
@@ -59,7 +60,7 @@ def main():
         tot["reward"] += int((rg != rc.astype(np.float32)).sum())
         tot["done"] += int((dg != dc).sum())
         tot["idx"] += int((ig != ic).any(1).sum())
-        fin_bad = int((fg != fc.astype(np.float32)).any(1).sum())
+        fin_bad = int((fg != fc.astype(np.float32)).any(1).sum()) if a.reset_mode == "same" else 0
         if (bad_rows.any() or (dg != dc).any() or fin_bad) and shown < a.verbose:
             shown += 1
             e = int(np.nonzero(bad_rows | (dg != dc))[0][0]) if (bad_rows.any() or (dg != dc).any()) else 0
