@@ -19,6 +19,16 @@ def main(d):
             print("  %-28s calls %6s  total %12s ns  avg %12s ns  %6s%%" % (
                 row.get("Name", "")[:28], row.get("Calls"), row.get("TotalDurationNs"), row.get("AverageNs"),
                 row.get("Percentage")))
+    tr = find(os.path.join(d, "trace"), "*kernel_trace.csv")
+    if tr:
+        durs = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(tr))
+                if "cn_env_kernel" in r["Kernel_Name"]]
+        if len(durs) >= 4:
+            # bench.py times the same-call-reset mode first, then the next-step-reset mode (the headline)
+            h = len(durs) // 2
+            print("== cn_env_kernel average duration by bench leg: same-call reset %.1f us (%d launches), "
+                  "next-step reset %.1f us (%d launches)" % (sum(durs[:h]) / h / 1e3, h, sum(durs[h:]) / (len(durs) - h) / 1e3,
+                                                             len(durs) - h))
     for tag in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
         f = find(os.path.join(d, tag), "*counter_collection.csv")
         if not f:
