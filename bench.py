@@ -66,17 +66,25 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # CN_BENCH_DRYRUN_GLOO=1: exercise the N > 1 code path on a single-GPU box (every rank on cuda:0,
+    # gloo collectives on host copies).  Never set by the driver; numbers from it are meaningless.
+    dry = os.environ.get("CN_BENCH_DRYRUN_GLOO") == "1"
+    dev_index = 0 if dry else local_rank
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        if dry:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    cdev = torch.device("cpu") if dry else dev   # where collective buffers live
 
     N = a.envs
     cfg = Config(n_envs=N, n_peds=a.peds, n_rays=a.rays, k_obstacles=a.k, max_steps=1000, seed=1234,
                  env_index_base=rank * N, ped_cycle_ms=1400,
                  room_half=2.40 if a.peds > 50 else 1.40)
-    env = VecEnv(cfg, device=local_rank)
+    env = VecEnv(cfg, device=dev_index)
     env.reset()
     # open-loop actions v ~ U(0, 0.22), w ~ U(-2, 2): counter-based, seed 1234 + global env index
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -118,14 +126,15 @@ def main():
     env.reset()
     wall, kernel_ms, taken = timed("next")
     if world > 1:
-        t = torch.tensor([wall, float(taken), wall_same, float(taken_same)], dtype=torch.float64, device=dev)
+        t = torch.tensor([wall, float(taken), wall_same, float(taken_same)], dtype=torch.float64, device=cdev)
         tm = t.clone(); dist.all_reduce(tm, op=dist.ReduceOp.MAX)
         ts = t.clone(); dist.all_reduce(ts, op=dist.ReduceOp.SUM)
         wall, wall_same = float(tm[0].item()), float(tm[2].item())
         taken_all, taken_same_all = float(ts[1].item()), float(ts[3].item())
         # the path's one exchange: all-gather of per-env episode returns over xGMI
         ret, _ = env.returns()
-        gathered = torch.empty(world * N, dtype=torch.float32, device=dev)
+        ret = ret.to(cdev)
+        gathered = torch.empty(world * N, dtype=torch.float32, device=cdev)
         tg0 = time.perf_counter()
         dist.all_gather_into_tensor(gathered, ret)
         torch.cuda.synchronize(dev)
