@@ -34,6 +34,20 @@ def algorithmic_bytes(P, R, K):
     return 64 * P + 4 * (R - 1 + 7 + 4 * K) + 4 * K + 2 * (24 * 8 + 16 * 4) + 8 + 4 + 1
 
 
+def profiled_traffic():
+    """HBM bytes per cn_env_kernel launch from the committed rocprofv3 PMC passes of this same command
+    (profiles/rNN/traffic.json: FETCH_SIZE and WRITE_SIZE from separate passes, calibrated on this box's
+    known-byte streams).  None when no profile is committed."""
+    import glob
+    c = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")))
+    if not c:
+        return None
+    try:
+        return float(json.load(open(c[-1]))["bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def usable_cpus():
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:  # cgroup v2 CPU quota
@@ -157,7 +171,10 @@ def main():
                    "same_call_reset_value": taken_same_all / wall_same, "same_call_reset_ms_per_step": wall_same / a.steps * 1e3,
                    "returns_allgather_ms": gather_ms},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": profiled_traffic() if (a.envs, a.peds, a.rays) == (4096, 20, 360) else None,
+                     "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE+WRITE_SIZE, calibrated; profiles/)",
+                     "algorithmic_bytes_per_launch": B * N,
                      "kernel": "cn_env_kernel", "kernel_ms": kernel_ms, "bytes_per_env_step": B},
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

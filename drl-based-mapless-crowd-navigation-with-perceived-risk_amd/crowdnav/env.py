@@ -118,8 +118,9 @@ class VecEnv:
 
     def debug_env(self, env=0):
         sd = np.zeros(_abi.CN_SD_COUNT); rp = np.zeros(5 + 4 * self.P)
-        tr = np.zeros((_abi.CN_TF_COUNT, _abi.CN_MAX_TRACKS)); si = np.zeros(_abi.CN_SI_COUNT, dtype=np.int32)
+        tr = np.zeros((_abi.CN_MAX_TRACKS, _abi.CN_TF_COUNT)); si = np.zeros(_abi.CN_SI_COUNT, dtype=np.int32)
         _abi.check(self.L.cn_debug_env(self.h, int(env), sd.ctypes.data, rp.ctypes.data, tr.ctypes.data, si.ctypes.data))
+        tr = np.ascontiguousarray(tr.T)   # -> [field, slot]
         n = int(si[_abi.SI["NTRACKS"]])
         T = _abi.TF
         return dict(sd=sd, si=si, robot=rp[:5].copy(), ped_p=rp[5:5 + 2 * self.P].reshape(-1, 2).copy(),

@@ -31,7 +31,7 @@ struct CnKParams {
     double* ped_v;          // [N, P, 2]
     const double* ped_init; // [N, P, 2]
     const double* ped_preset; // [N, P, 2]
-    double* trk;            // [N, CN_TF_COUNT, CN_MAX_TRACKS]
+    double* trk;            // [N, CN_MAX_TRACKS, CN_TF_COUNT]: one contiguous 96-byte record per track slot
     // caller-owned I/O (device)
     const float* action;
     const int32_t* step_counter;

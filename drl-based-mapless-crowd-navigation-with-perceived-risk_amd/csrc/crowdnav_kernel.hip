@@ -562,7 +562,7 @@ __device__ __forceinline__ void observe(const CnKParams& p, const Poly& pg, EnvR
     double* T = L.trk;
     if (lane < e.ntracks) {
 #pragma unroll
-        for (int f = 0; f < CN_TF_COUNT; ++f) T[f * CN_MAX_TRACKS + lane] = L.gtrk[f * CN_MAX_TRACKS + lane];
+        for (int f = 0; f < CN_TF_COUNT; ++f) T[f * CN_MAX_TRACKS + lane] = L.gtrk[lane * CN_TF_COUNT + f];  // HBM: one 96-byte record per track
     }
     CN_SYNC();
 #define TRK(f, i) T[(f) * CN_MAX_TRACKS + (i)]
@@ -786,7 +786,7 @@ __device__ __forceinline__ void observe(const CnKParams& p, const Poly& pg, EnvR
     // tracker table back to HBM (its LDS space is reused by the next observation's end points)
     if (lane < e.ntracks) {
 #pragma unroll
-        for (int f = 0; f < CN_TF_COUNT; ++f) L.gtrk[f * CN_MAX_TRACKS + lane] = L.trk[f * CN_MAX_TRACKS + lane];
+        for (int f = 0; f < CN_TF_COUNT; ++f) L.gtrk[lane * CN_TF_COUNT + f] = L.trk[f * CN_MAX_TRACKS + lane];
     }
     CN_SYNC();
     *done_out = e.done;
@@ -999,5 +999,34 @@ extern "C" __global__ void cn_gather_kernel(CnKParams p, float* last_ret, float*
         c[0] = si[CN_SI_EGO_VIOL]; c[1] = si[CN_SI_SOCIAL_VIOL]; c[2] = si[CN_SI_OBST_STEPS]; c[3] = si[CN_SI_EP_STEP];
         c[4] = si[CN_SI_SUCCESS]; c[5] = si[CN_SI_FAILURE]; c[6] = si[CN_SI_STATUS]; c[7] = si[CN_SI_NTRACKS];
         c[8] = si[CN_SI_EPISODES]; c[9] = si[CN_SI_PENDING_RESET];
+    }
+}
+
+// ---- PMC calibration (tools/calib_pmc.py): known-byte streaming reads / writes at the access widths the
+// env kernel uses, so FETCH_SIZE / WRITE_SIZE can be turned into bytes (MI355X_MICROARCH.md, HBM section).
+template <typename T>
+__global__ void cn_calib_read_kernel(const T* __restrict__ src, size_t n, T* __restrict__ out)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    T acc = T(0);
+    for (; i < n; i += stride) acc += src[i];
+    if (acc == T(123456789)) out[0] = acc;  // never true for the zero-filled buffer; keeps the loads alive
+}
+template <typename T>
+__global__ void cn_calib_write_kernel(T* __restrict__ dst, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) dst[i] = T(1);
+}
+extern "C" void cn_calib_launch(void* buf, size_t bytes, int width, int write, void* stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    dim3 g(256 * 16), b(256);
+    if (!write) {
+        if (width == 4) hipLaunchKernelGGL(cn_calib_read_kernel<float>, g, b, 0, st, (const float*)buf, bytes / 4, (float*)buf);
+        else hipLaunchKernelGGL(cn_calib_read_kernel<double>, g, b, 0, st, (const double*)buf, bytes / 8, (double*)buf);
+    } else {
+        if (width == 4) hipLaunchKernelGGL(cn_calib_write_kernel<float>, g, b, 0, st, (float*)buf, bytes / 4);
+        else hipLaunchKernelGGL(cn_calib_write_kernel<double>, g, b, 0, st, (double*)buf, bytes / 8);
     }
 }

@@ -123,7 +123,7 @@ int cn_get_returns(cn_handle h, float* last_return, float* running_return, void*
 
 /* Parity/debug view of one env (synchronises).  host buffers, any may be NULL:
  *   scalars[24] (layout: CN_SD_* below), robot_ped (5 + 4P doubles: x,y,yaw,v,w, ped xy, ped vxy),
- *   tracks [CN_MAX_TRACKS*12] field-major (CN_TF_*), ints[16] (CN_SI_*) */
+ *   tracks [CN_MAX_TRACKS][12] one record per slot (CN_TF_*), ints[16] (CN_SI_*) */
 int cn_debug_env(cn_handle h, int env, double* scalars, double* robot_ped, double* tracks, int32_t* ints);
 
 /* Whole-state snapshot for deterministic replay. */

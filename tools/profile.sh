@@ -17,6 +17,8 @@ rocprofv3 --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU 
     -d "$OUT/pmc_sq" -o pmc -- $BENCH > "$OUT/bench_pmc_sq.log" 2>&1
 rocprofv3 --output-format csv --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE \
     -d "$OUT/pmc_sq2" -o pmc -- $BENCH > "$OUT/bench_pmc_sq2.log" 2>&1
+rocprofv3 --output-format csv --pmc FETCH_SIZE -d "$OUT/calib_fetch" -o pmc -- python $REPO/tools/calib_pmc.py > "$OUT/calib_fetch.log" 2>&1
+rocprofv3 --output-format csv --pmc WRITE_SIZE -d "$OUT/calib_write" -o pmc -- python $REPO/tools/calib_pmc.py > "$OUT/calib_write.log" 2>&1
 cd "$REPO"
 python tools/summarize_prof.py "$OUT" > "$OUT/summary.txt" 2>&1
 cat "$OUT/summary.txt"

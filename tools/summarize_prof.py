@@ -43,6 +43,49 @@ def main(d):
         print("== %s (per cn_env_kernel dispatch, mean of %s)" % (tag, sorted(set(cnt.values()))))
         for k in sorted(acc):
             print("  %-24s %.6g" % (k, acc[k] / cnt[k]))
+    # calibration: known 1 GiB streams at 4 and 8 bytes per lane -> KB reported per byte moved
+    calib = {}
+    for tag, ctr in (("calib_fetch", "FETCH_SIZE"), ("calib_write", "WRITE_SIZE")):
+        f = find(os.path.join(d, tag), "*counter_collection.csv")
+        if not f:
+            continue
+        for row in csv.DictReader(open(f)):
+            kn = row.get("Kernel_Name", "")
+            if "cn_calib" not in kn or row["Counter_Name"] != ctr:
+                continue
+            kind = ("read" if "read" in kn else "write") + ("4" if "float" in kn else "8")
+            calib.setdefault((ctr, kind), []).append(float(row["Counter_Value"]))
+    if calib:
+        print("== PMC calibration (1 GiB streamed per launch; counter unit = KB)")
+        fac = {}
+        for (ctr, kind), v in sorted(calib.items()):
+            mean = sum(v) / len(v)
+            fac[(ctr, kind)] = (1 << 30) / (mean * 1024.0) if mean else float("nan")
+            print("  %-10s %-7s reported %.0f KB for 1048576 KB moved -> multiply by %.3f" % (ctr, kind, mean, fac[(ctr, kind)]))
+        try:
+            import json
+            fe = fac.get(("FETCH_SIZE", "read8")); wr8 = fac.get(("WRITE_SIZE", "write8")); wr4 = fac.get(("WRITE_SIZE", "write4"))
+            fsz = wsz = None
+            for tag, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+                ff = find(os.path.join(d, tag), "*counter_collection.csv")
+                vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(ff))
+                        if "cn_env_kernel" in r.get("Kernel_Name", "") and r["Counter_Name"] == ctr]
+                h = len(vals) // 2
+                m = sum(vals[h:]) / max(1, len(vals) - h)   # second bench leg = next-step reset (the headline)
+                if ctr == "FETCH_SIZE":
+                    fsz = m
+                else:
+                    wsz = m
+            # the env kernel's reads are 8-byte lanes; its writes are ~60 % 4-byte (observation) and ~40 % 8-byte (state)
+            wfac = 0.6 * wr4 + 0.4 * wr8
+            out = {"fetch_kb": fsz, "write_kb": wsz, "fetch_factor_read8": fe, "write_factor_mix": wfac,
+                   "bytes_per_launch": fsz * 1024 * fe + wsz * 1024 * wfac,
+                   "note": "per cn_env_kernel launch (next-step-reset leg), corrected with this box's calibration"}
+            json.dump(out, open(os.path.join(d, "traffic.json"), "w"), indent=1)
+            print("== corrected HBM traffic per launch: %.2f MB (fetch %.2f MB, write %.2f MB)" % (
+                out["bytes_per_launch"] / 1e6, fsz * 1024 * fe / 1e6, wsz * 1024 * wfac / 1e6))
+        except Exception as ex:  # noqa
+            print("traffic.json not written:", ex)
     for f in sorted(glob.glob(os.path.join(d, "bench_*.log"))):
         lines = [l for l in open(f).read().splitlines() if l.startswith("{")]
         if lines:
