@@ -86,6 +86,43 @@ def test_rollout_parity_eval_mode_and_k4(oracle_mod):
     _compare_rollout(oracle_mod, steps=80, seed=9, n_envs=16, n_peds=60, max_steps=50, min_scan_range=0.0, k_obstacles=4)
 
 
+@pytest.mark.parametrize("k", [1, 12, 16])
+def test_rollout_parity_other_k(oracle_mod, k):
+    # the shipped checkpoints exist for K in {1, 4, 8, 12, 16} (370/382/398/414/430 inputs)
+    _compare_rollout(oracle_mod, steps=60, seed=13 + k, n_envs=16, n_peds=60, max_steps=40, k_obstacles=k)
+
+
+def test_rollout_parity_scripted_crowd(oracle_mod):
+    """ped_mode = 1: constant per-pedestrian velocities (the scripted crossing/towards/ahead crowds) in the
+    5 x 5 m evaluation room with the evaluation goal/start (README "Start testing")."""
+    import torch
+    kw = dict(n_envs=16, n_peds=20, max_steps=60, ped_mode=1, room_half=2.40, goal_x=-2.0, goal_y=2.0, start_x=1.0,
+              start_y=0.0, spawn_x=1.0, spawn_y=0.0, min_scan_range=0.0, seed=17)
+    torch_, env, orc = _pair(oracle_mod, **kw)
+    rng = np.random.default_rng(5)
+    vel = rng.choice([-0.2, -0.1, -0.04, 0.04, 0.1, 0.2], size=(16, 20, 2))
+    env.set_ped_preset_vel(vel); orc.set_ped_preset_vel(vel)
+    init = rng.uniform(-2.0, 2.0, (16, 20, 2))
+    env.set_ped_init(init); orc.set_ped_init(init)
+    env.reset(); torch.cuda.synchronize()
+    oc = orc.reset()
+    assert np.array_equal(env.obs_f64.cpu().numpy(), oc)
+    for t in range(80):
+        act = np.stack([rng.uniform(0, 0.22, 16), rng.uniform(-1, 1, 16)], 1).astype(np.float32)
+        env.step(torch.from_numpy(act).cuda(), auto_reset=True)
+        torch.cuda.synchronize()
+        oc, rc, dc, ic = orc.step(act.astype(np.float64), auto_reset=True)
+        assert np.array_equal(env.done.cpu().numpy(), dc) and np.array_equal(env.topk_idx.cpu().numpy(), ic)
+        assert np.abs(env.obs_f64.cpu().numpy() - oc).max() <= TOL
+    g = env.debug_env(3); c = orc.sim_state(3)
+    assert np.array_equal(g["ped_p"], c[1]) and np.array_equal(g["ped_v"], c[2])
+
+
+def test_rollout_parity_181_rays(oracle_mod):
+    # R - 1 = 180: UTL:113's Python-2 integer division gives a 2-degree increment
+    _compare_rollout(oracle_mod, steps=40, seed=19, n_envs=8, n_peds=30, n_rays=181, max_steps=30)
+
+
 def test_rollout_parity_720_rays(oracle_mod):
     # BASELINE config 5 shape (100 pedestrians, 720 rays, 2.4 m room); small N so the oracle finishes in seconds
     _compare_rollout(oracle_mod, steps=30, seed=11, n_envs=8, n_peds=100, n_rays=720, room_half=2.4, max_steps=25)

@@ -1,0 +1,31 @@
+#!/usr/bin/env python
+"""BASELINE.json configs 2, 3 and 5 on one MI355X (config 4 = 8 GPUs is the driver's `bench.py --gpus 8`)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "drl-based-mapless-crowd-navigation-with-perceived-risk_amd"))
+import torch
+from crowdnav import Config
+from crowdnav.env import VecEnv
+from crowdnav.td3 import Agent
+
+def run(name, cfg, actor=False, steps=400, mode="next"):
+    env = VecEnv(cfg); env.reset(); N = env.N
+    g = torch.Generator(device="cuda").manual_seed(1)
+    acts = torch.stack([torch.rand((16, N), generator=g, device="cuda") * 0.22, torch.rand((16, N), generator=g, device="cuda") * 4 - 2], 2).contiguous()
+    agent = Agent(obs_dim=env.D, device="cuda", seed=0, memory_size=16) if actor else None
+    obs = env.obs
+    for i in range(40):
+        obs, _, _ = env.step(agent.act(obs) if actor else acts[i % 16], auto_reset=mode)
+    ep0 = env.counters()[:, 8].sum().item(); torch.cuda.synchronize(); t0 = time.perf_counter()
+    for i in range(steps):
+        obs, _, _ = env.step(agent.act(obs) if actor else acts[i % 16], auto_reset=mode)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    resets = env.counters()[:, 8].sum().item() - ep0 if mode == "next" else 0
+    print("%-52s %8.4f ms/step  %8.2f M env-steps/s" % (name, dt / steps * 1e3, (N * steps - resets) / dt / 1e6))
+    env.close()
+
+run("config 2: 4096 x 20 peds x 360 rays (open loop)", Config(n_envs=4096, ped_cycle_ms=1400))
+run("config 3: 4096 x 20 peds, TD3 actor in the loop", Config(n_envs=4096, ped_cycle_ms=1400), actor=True)
+run("config 4 shard: 2048 x 20 peds x 360 rays (1 of 8 GPUs)", Config(n_envs=2048, ped_cycle_ms=1400))
+run("config 5: 4096 x 100 peds x 720 rays", Config(n_envs=4096, n_peds=100, n_rays=720, room_half=2.4, ped_cycle_ms=1400))
+run("16384 x 20 peds x 360 rays on one GPU", Config(n_envs=16384, ped_cycle_ms=1400))
