@@ -10,3 +10,7 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-builtin-pow -Wall -Wno-unused-function"
 "$HIPCC" $FLAGS ${CN_EXTRA_FLAGS:-} -shared -o "$OUT/libcrowdnav.so" "$HERE/crowdnav_kernel.hip" "$HERE/crowdnav_abi.hip"
 echo "built $OUT/libcrowdnav.so"
+if [ "${1:-}" = "timing" ]; then
+  "$HIPCC" $FLAGS -DCN_TIMING -shared -o "$OUT/libcrowdnav_timing.so" "$HERE/crowdnav_kernel.hip" "$HERE/crowdnav_abi.hip"
+  echo "built $OUT/libcrowdnav_timing.so (stage time stamps; profiling only)"
+fi

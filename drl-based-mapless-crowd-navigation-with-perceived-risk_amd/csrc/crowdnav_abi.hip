@@ -175,6 +175,8 @@ extern "C" void cn_destroy(cn_handle h)
     delete h;
 }
 
+extern "C" int cn_debug_set_timing(cn_handle h, long long* dev_buf) { if (!h) return CN_ERR_ARG; h->kp.timing = dev_buf; return CN_OK; }
+
 // PROFILING ONLY: stage-skipping mask for time attribution (tools/ablate.py); not part of crowdnav.h
 extern "C" int cn_debug_set_ablate(cn_handle h, int mask) { if (!h) return CN_ERR_ARG; h->kp.ablate = mask; return CN_OK; }
 

@@ -42,6 +42,7 @@ struct CnKParams {
     float* reward;
     uint8_t* done;
     int32_t* topk_idx;
+    long long* timing;      // profiling build only: [N, 32] s_memtime stamps
 };
 
 #ifdef __cplusplus

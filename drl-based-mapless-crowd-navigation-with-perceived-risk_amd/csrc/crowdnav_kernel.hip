@@ -22,6 +22,13 @@
 #define CN_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 
+// Stage time stamps (PROFILING BUILD ONLY: build.sh timing -> libcrowdnav_timing.so; tools/stage_timing.py)
+#ifdef CN_TIMING
+#define CN_T(k) do { if (p.timing && lane == 0) p.timing[(size_t)env * 32 + (k)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define CN_T(k) do { } while (0)
+#endif
+
 #define TY_NONE 0
 #define TY_W 1
 #define TY_O 2
@@ -229,6 +236,7 @@ __device__ __forceinline__ void observe(const CnKParams& p, const Poly& pg, EnvR
     double agent_vel_x = -1.0 * (v * cw_);
     double agent_vel_y = v * sw_;
 
+    CN_T(2);
     // ---- lidar raycast (XACRO:150-178) + UTL:375-392 sanitise + UTL:110-126 end points ----------
     double sy, cy;
     cn_det_sincos(yaw, &sy, &cy);
@@ -256,6 +264,7 @@ __device__ __forceinline__ void observe(const CnKParams& p, const Poly& pg, EnvR
     CN_SYNC();
     const bool wall_x = !(h - fabs(ox) > p.lidar_max + 1e-6);
     const bool wall_y = !(h - fabs(oy) > p.lidar_max + 1e-6);
+    CN_T(3);
     double smin = 1e300;
     float* o32 = obs32 + (size_t)env * D;
     float* f32 = fin32 ? fin32 + (size_t)env * D : nullptr;
@@ -316,6 +325,7 @@ __device__ __forceinline__ void observe(const CnKParams& p, const Poly& pg, EnvR
             if (o64) o64[j] = so;
         }
     }
+    CN_T(4);
     smin = cn_wave_min_d(smin);
     CN_SYNC();
 
@@ -343,6 +353,7 @@ __device__ __forceinline__ void observe(const CnKParams& p, const Poly& pg, EnvR
         else { e.dq0x = e.dq1x; e.dq0y = e.dq1y; e.dq1x = qx; e.dq1y = qy; }
     }
 
+    CN_T(5);
     const int W = (n + 63) >> 6;  // 64-ray words; ray i = bit (i & 63) of word (i >> 6)
 #define WORD(id, q) L.w64[(id) * L.wstride + (q)]
 #define BIT(id, i) ((WORD(id, (i) >> 6) >> ((i) & 63)) & 1ull)
@@ -369,6 +380,7 @@ __device__ __forceinline__ void observe(const CnKParams& p, const Poly& pg, EnvR
 #define CHG(a_, b_) (((a_) == GNONE || (b_) == GNONE) ? CN_NAN : fabs(cn_div1000((double)(a_)) - cn_div1000((double)(b_))))
     double clast = CN_NAN;
     if (L.gq[n - 1] != GNONE && lastnn >= 0) clast = CHG(L.gq[lastnn], L.gq[lastnn + 1]);
+    CN_T(6);
     // flag words for the type machine
     for (int q = 0; q < W; ++q) {
         int i = lane + 64 * q;
@@ -388,44 +400,69 @@ __device__ __forceinline__ void observe(const CnKParams& p, const Poly& pg, EnvR
     }
 #undef CHG
     CN_SYNC();
-    // ENV:372-410 object-type state machine.  Loop-carried state (last_type, du_count) lives in scalar
-    // registers; only occupied rays are visited (bit scan over the flag words), no memory in the loop
-    // except the rare aliasing store.
+    // ENV:372-410 object-type state machine, on the scalar unit, processed in RUNS instead of rays.
+    // With z = change == 0, nz = next change == 0, nn = next change is None, eq = |change - next| == 0
+    // the per-ray rules (ENV:383-410) are
+    //   du == 1:  every occupied ray gets a fresh type ('w' if z else 'o') and becomes last_type;
+    //             du returns to 0 after the first non-z ray whose next change is 0
+    //   du == 0:  z -> 'w' fresh (last_type = it);  !z,!nz,nn -> 'o' fresh, state untouched;
+    //             !z,!nz,!nn,eq -> 'w' fresh (last_type = it);
+    //             !z,nz -> 'w' fresh, last_type = it, du = 1;   !z,!nz,!nn,!eq -> ALIAS of last_type, du = 1
+    // so within a 64-ray word the state only changes at the rays that flip du; everything between two
+    // flips is a handful of 64-bit mask operations.
+    CN_T(7);
     {
         int last_t = TY_NONE, last_s = 0, du = 0;
         for (int q = 0; q < W; ++q) {
-            u64 occ = ~uni64(WORD(M_NONE, q));
-            const u64 wz = uni64(WORD(M_ZERO, q)), we = uni64(WORD(M_EQ, q)), wnn = uni64(WORD(M_NNONE, q)),
-                      wnz = uni64(WORD(M_NZERO, q));
+            const u64 occ = (p.ablate & 2) ? 0ull : ~uni64(WORD(M_NONE, q));
+            const u64 Z = uni64(WORD(M_ZERO, q)) & occ, NZ = uni64(WORD(M_NZERO, q)), NN = uni64(WORD(M_NNONE, q)),
+                      E = uni64(WORD(M_EQ, q));
+            const u64 nonz = occ & ~Z;
+            const u64 cA = nonz & NZ;                    // 'w' fresh, du -> 1
+            const u64 cB = nonz & ~NZ & NN;              // 'o' fresh, state untouched
+            const u64 cC = nonz & ~NZ & ~NN & E;         // 'w' fresh
+            const u64 cD = nonz & ~NZ & ~NN & ~E;        // alias, du -> 1
             u64 isw = 0, iso = 0, al = 0;
-            if (p.ablate & 2) occ = 0;
-            while (occ) {
-                const int b = __builtin_ctzll(occ);
-                const u64 bit = 1ull << b;
-                occ &= occ - 1;
-                const int i = 64 * q + b;
-                int ty, src = i;
-                if (wz & bit) { ty = TY_W; last_t = TY_W; last_s = i; }
-                else {
-                    ty = TY_O;
-                    if (du != 1) {
-                        if (wnz & bit) { ty = TY_W; last_t = TY_W; last_s = i; du = 0; }
-                        if (wnn & bit) { /* ENV:394-395 pass */ }
-                        else if (we & bit) { ty = TY_W; last_t = TY_W; last_s = i; du = 0; }
-                        else { ty = last_t; src = last_s; du += 1; }
-                    } else {
-                        ty = TY_O; last_t = TY_O; last_s = i;
-                        if (wnz & bit) du = 0;
+            u64 rem = occ;
+            while (rem) {
+                if (du == 1) {
+                    const u64 T = rem & cA;              // first non-z ray whose next change is 0 ends the du == 1 run
+                    u64 range = rem;
+                    if (T) { const int t = __builtin_ctzll(T); range = rem & ((t == 63) ? ~0ull : ((2ull << t) - 1ull)); du = 0; }
+                    isw |= range & Z;
+                    iso |= range & ~Z;
+                    const int hb = 63 - __builtin_clzll(range);
+                    last_s = 64 * q + hb;
+                    last_t = ((Z >> hb) & 1ull) ? TY_W : TY_O;
+                    rem &= ~range;
+                } else {
+                    const u64 X = rem & (cA | cD);       // rays that switch du to 1
+                    u64 range = rem;
+                    int t = -1;
+                    if (X) { t = __builtin_ctzll(X); range = rem & ((1ull << t) - 1ull); }
+                    const u64 Wm = range & (Z | cC);
+                    isw |= Wm;
+                    iso |= range & cB;
+                    if (Wm) { last_t = TY_W; last_s = 64 * q + 63 - __builtin_clzll(Wm); }
+                    rem &= ~range;
+                    if (t >= 0) {
+                        const u64 bit = 1ull << t;
+                        if (cA & bit) { isw |= bit; last_t = TY_W; last_s = 64 * q + t; }
+                        else {                           // T[i] = last_type: carries that ray's range and pose
+                            if (last_t == TY_W) isw |= bit;
+                            else if (last_t == TY_O) iso |= bit;
+                            if (last_t != TY_NONE) { al |= bit; if (lane == 0) L.srcidx[64 * q + t] = (unsigned short)last_s; }
+                        }
+                        du = 1;
+                        rem &= ~bit;
                     }
                 }
-                if (ty == TY_W) isw |= bit;
-                else if (ty == TY_O) iso |= bit;
-                if (src != i && ty != TY_NONE) { al |= bit; if (lane == 0) L.srcidx[i] = (unsigned short)src; }
             }
             if (lane == 0) { WORD(M_ISW, q) = isw; WORD(M_ISO, q) = iso; WORD(M_ALIAS, q) = al; }
         }
     }
     CN_SYNC();
+    CN_T(8);
     // ENV:433-445: a typed ray carries the range and pose of the ray its list was created at.  In place:
     // only aliased rays change, and the rays they copy from are never aliased themselves.
     for (int i = lane; i < n; i += 64) {
@@ -435,6 +472,7 @@ __device__ __forceinline__ void observe(const CnKParams& p, const Poly& pg, EnvR
         }
     }
     CN_SYNC();
+    CN_T(9);
     // ENV:448-485 association of consecutive rays; brk bit i = a segment closes after ray i
     int fe = n, lb = -1, nsegs0 = 0;
     for (int q = 0; q < W; ++q) {
@@ -457,6 +495,7 @@ __device__ __forceinline__ void observe(const CnKParams& p, const Poly& pg, EnvR
     // ENV:490-502 first <-> last with twice the box
     bool merge = (nsegs0 > 1) && (cn_iou3(PX(0), PY(0), PX(n - 1), PY(n - 1), e.bb * 2) > 0.0);
     CN_SYNC();
+    CN_T(10);
     // order-space: position k -> ray.  merged: [0..fe] ++ [ls..n-1] ++ [fe+1..ls-1]
     const int nl = n - ls;  // length of the last segment
 #define ORDER(k) (merge ? ((k) <= fe ? (k) : ((k) <= fe + nl ? ls + ((k) - fe - 1) : (k) - nl)) : (k))
@@ -482,6 +521,7 @@ __device__ __forceinline__ void observe(const CnKParams& p, const Poly& pg, EnvR
         nseg += __popcll(b0);
     }
     CN_SYNC();
+    CN_T(11);
     // per-word running totals: types seen before word q, last segment end before word q
     if (lane == 0) {
         int bw = 0, bo = 0, le = -1;
@@ -493,6 +533,7 @@ __device__ __forceinline__ void observe(const CnKParams& p, const Poly& pg, EnvR
         }
     }
     CN_SYNC();
+    CN_T(12);
     // ENV:568-620 confirmation: every lane that owns a segment end evaluates its segment
     int nconf = 0;
     for (int q = 0; q < ((p.ablate & 4) ? 0 : W); ++q) {
@@ -557,6 +598,7 @@ __device__ __forceinline__ void observe(const CnKParams& p, const Poly& pg, EnvR
     ego_hit = cn_wave_max_i(ego_hit);
     if (n_obst > 0) e.obst_steps += 1;
 
+    CN_T(13);
     // ---- ENV:656-743 tracker -----------------------------------------------------------------------
     // The tracker table shares LDS with the end-point arrays (dead from here on): bring it in now.
     double* T = L.trk;
@@ -653,6 +695,7 @@ __device__ __forceinline__ void observe(const CnKParams& p, const Poly& pg, EnvR
         }
     }
     CN_SYNC();
+    CN_T(14);
     // ENV:745-760 speed of the tracks matched in this call
     if (lane < e.ntracks && TRK(CN_TF_DQLEN, lane) > 1.5) {
         double dc = hypot(TRK(CN_TF_D0Y, lane) - TRK(CN_TF_D1Y, lane), TRK(CN_TF_D0X, lane) - TRK(CN_TF_D1X, lane));
@@ -669,6 +712,7 @@ __device__ __forceinline__ void observe(const CnKParams& p, const Poly& pg, EnvR
     e.nent = 0;
     CN_SYNC();
 
+    CN_T(15);
     // ---- ENV:769-996 collision cone / collision probability / top-K -------------------------------
     if (e.dq_len == 2 && !(p.ablate & 8)) {
         const double ts = e.ts;
@@ -759,6 +803,7 @@ __device__ __forceinline__ void observe(const CnKParams& p, const Poly& pg, EnvR
         if (lane < nt) TRK(CN_TF_T, lane) = now;
     }
 #undef TRK
+    CN_T(16);
     // ENV:998-1005 safety counters
     if (ego_hit) e.ego_viol += 1;
     if (e.ego > 0.4) e.social_viol += 1;
@@ -783,6 +828,7 @@ __device__ __forceinline__ void observe(const CnKParams& p, const Poly& pg, EnvR
         if (f32) f32[n + i] = (float)so;
         if (o64) o64[n + i] = so;
     }
+    CN_T(17);
     // tracker table back to HBM (its LDS space is reused by the next observation's end points)
     if (lane < e.ntracks) {
 #pragma unroll
@@ -871,6 +917,7 @@ extern "C" __global__ void __launch_bounds__(64) cn_env_kernel(CnKParams p)
         L.gtrk = p.trk + (size_t)env * CN_TF_COUNT * CN_MAX_TRACKS;
     }
 
+    CN_T(0);
     Poly pg;
     pg.c0 = p.poly_c[lane]; pg.s0 = p.poly_s[lane]; pg.c1 = p.poly_c[(lane + 1) & 63]; pg.s1 = p.poly_s[(lane + 1) & 63];
 
@@ -897,6 +944,7 @@ extern "C" __global__ void __launch_bounds__(64) cn_env_kernel(CnKParams p)
     for (int i = lane; i < 2 * P; i += 64) { L.ped[i] = gped_p[i]; pedv[i] = gped_v[i]; }
     CN_SYNC();
 
+    CN_T(1);
     int done = 0;
     bool need_reset = (p.mode == CN_MODE_RESET);
     // auto_reset == 2 ("next-step" reset, the gymnasium NEXT_STEP convention): an env that finished in
@@ -967,6 +1015,7 @@ extern "C" __global__ void __launch_bounds__(64) cn_env_kernel(CnKParams p)
         CN_SYNC();
     }
 
+    CN_T(18);
     // ---- write env state back ---------------------------------------------------------------------
     for (int i = lane; i < 2 * P; i += 64) { gped_p[i] = L.ped[i]; gped_v[i] = pedv[i]; }
     if (lane == 0) {
@@ -983,6 +1032,7 @@ extern "C" __global__ void __launch_bounds__(64) cn_env_kernel(CnKParams p)
         si[CN_SI_CROWD_LO] = (int)(unsigned)((unsigned long long)e.crowd_ms & 0xffffffffull);
         si[CN_SI_CROWD_HI] = (int)(unsigned)((unsigned long long)e.crowd_ms >> 32);
     }
+    CN_T(19);
 }
 
 // float32 views of the per-env returns (for the RCCL all-gather of episode returns) and counters
