@@ -78,3 +78,26 @@ def rollout(env, agent, n_steps, learn=False, add_noise=True, stats=None):
                 soc = 1.0 - pc[e, 1].item() / seen if seen else float("nan")     # ENV:1269-1275
                 stats.add(c[e, 4].item(), c[e, 5].item(), ret[e].item(), int(pc[e, 3]) + 1, ego, soc)
     return n_steps * env.N
+
+
+def evaluate(env, agent, episodes_per_env=1, max_launches=100000):
+    """The reference's evaluation run (README "Start testing"; TRAIN:142-161 with learning = False): greedy
+    actor, one CSV row per finished episode (success, failure, return, steps, ego/social safety scores)."""
+    stats = EpisodeStats()
+    env.reset()
+    target = episodes_per_env * env.N
+    obs = env.obs
+    launches = 0
+    while len(stats.rows) < target and launches < max_launches:
+        act = agent.act(obs, add_noise=False)
+        pre = env.counters().clone()
+        obs, reward, done = env.step(act, auto_reset=True)
+        launches += 1
+        if bool(done.any()):
+            c = env.counters().cpu(); pc = pre.cpu(); ret = env.returns()[0].cpu()
+            for e in torch.nonzero(done.cpu()).flatten().tolist():
+                seen = int(pc[e, 2])
+                ego = 1.0 - pc[e, 0].item() / seen if seen else float("nan")
+                soc = 1.0 - pc[e, 1].item() / seen if seen else float("nan")
+                stats.add(c[e, 4].item(), c[e, 5].item(), ret[e].item(), int(pc[e, 3]) + 1, ego, soc)
+    return stats

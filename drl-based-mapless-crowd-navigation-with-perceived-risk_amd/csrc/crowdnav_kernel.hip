@@ -154,13 +154,24 @@ __device__ __forceinline__ void ped_advance(const CnKParams& p, int env, int lan
 {
     const double lo = -p.room_half + p.ped_radius, hi = p.room_half - p.ped_radius;
     const long long T = p.ped_cycle_ms;
+    const double invT = 1.0 / (double)p.ped_cycle_ms;
     const long long gid = p.env_index_base + env;
     const double* preset = p.ped_preset + (size_t)env * 2 * p.P;
     for (int i = lane; i < p.P; i += 64) {
         double x = ped_p[2 * i], y = ped_p[2 * i + 1];
         double vx = ped_v[2 * i], vy = ped_v[2 * i + 1];
         long long offs = (long long)i * p.ped_stagger_ms;
-        long long m = (t0 <= offs) ? 0 : (t0 - offs + T - 1) / T;
+        // m = ceil((t0 - offs) / T).  Times are < 2^40 ms, so the double quotient is within one of the integer
+        // answer; the remainder test below makes it exact (no 64-bit integer divide sequence).
+        long long m = 0;
+        if (t0 > offs) {
+            const long long num = t0 - offs + T - 1;
+            long long qd = (long long)((double)num * invT);
+            long long r = num - qd * T;
+            if (r < 0) { qd -= 1; r += T; }
+            if (r >= T) { qd += 1; }
+            m = qd;
+        }
         long long a = offs + m * T;
         long long tc = t0;
         while (a < t1) {
@@ -745,6 +756,15 @@ __device__ __forceinline__ void observe(const CnKParams& p, const Poly& pg, EnvR
             int has = 0; double dcp = 0.0;
             for (int x2 = hi; x2 > lo; --x2) {
                 double y2 = ((double)x2 * gradient) + bb0;
+                // The polygon lies inside its circumscribed circle: a segment whose closest point to the
+                // centre is farther than the radius (with slack) cannot touch any edge -> same "empty" result.
+                {
+                    double ex = (double)x2 - a0x, ey = y2 - a0y, fx = tx - a0x, fy = ty_ - a0y;
+                    double ee = ex * ex + ey * ey;
+                    double tt = (ee > 0.0) ? fmin(fmax((fx * ex + fy * ey) / ee, 0.0), 1.0) : 0.0;
+                    double gx = fx - tt * ex, gy = fy - tt * ey;
+                    if (gx * gx + gy * gy > 0.178 * 0.178 * 1.000001) continue;
+                }
                 double hx = 0.0, hy = 0.0;
                 unsigned long long m = ring_segment(pg, lane, tx, ty_, 0.178, a0x, a0y, (double)x2, y2, &hx, &hy);
                 int cnt = __popcll(m);

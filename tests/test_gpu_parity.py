@@ -238,3 +238,35 @@ def test_actor_in_the_loop_rollout_config3():
     assert float(a[:, 1].abs().max()) <= 2.0
     r = gather_returns(env.returns()[0])
     assert r.shape == (128,)
+
+
+def test_reference_scenarios_presets(oracle_mod):
+    """crossing_20 in the 5 x 5 m test world and the 14-obstacle training world, from the extracted presets;
+    GPU vs oracle on both, then the evaluation loop writes the reference's CSV schema."""
+    import torch
+    from crowdnav import presets
+    from crowdnav.env import VecEnv
+    from crowdnav.rollout import evaluate
+    from crowdnav.td3 import Agent
+    assert len(presets.names()) == 31
+    cfg, init, vel = presets.evaluation("crossing", 20, n_envs=8, max_steps=40, seed=3)
+    assert cfg.ped_mode == 1 and init.shape == (8, 20, 2) and abs(abs(vel).max() - 0.04) < 1e-12
+    env = VecEnv(cfg); env.enable_f64_obs(); env.set_ped_init(init); env.set_ped_preset_vel(vel)
+    orc = oracle_mod.Oracle(cfg.as_dict()); orc.set_ped_init(init); orc.set_ped_preset_vel(vel)
+    env.reset(); torch.cuda.synchronize()
+    assert np.array_equal(env.obs_f64.cpu().numpy(), orc.reset())
+    rng = np.random.default_rng(0)
+    for t in range(50):
+        act = np.stack([rng.uniform(0.1, 0.22, 8), rng.uniform(-0.5, 0.5, 8)], 1).astype(np.float32)
+        env.step(torch.from_numpy(act).cuda(), auto_reset=True); torch.cuda.synchronize()
+        oc, rc, dc, ic = orc.step(act.astype(np.float64), auto_reset=True)
+        assert np.array_equal(env.done.cpu().numpy(), dc) and np.abs(env.obs_f64.cpu().numpy() - oc).max() <= TOL
+    cfg, init = presets.training(n_envs=8, max_steps=30, seed=4)
+    assert cfg.n_peds == 14 and cfg.ped_cycle_ms == 1400
+    env2 = VecEnv(cfg); env2.set_ped_init(init)
+    agent = Agent(obs_dim=env2.D, device="cuda", seed=1, memory_size=16)
+    st = evaluate(env2, agent, episodes_per_env=1)
+    assert len(st.rows) >= 8 and st.HEADERS[0] == "episode_number"
+    import tempfile
+    path = st.write_csv(tempfile.mkdtemp(), "td3_training_trajectory_test")
+    assert open(path).readline().strip().split(",") == st.HEADERS

@@ -1,0 +1,141 @@
+"""The simulator half (rows A1-A4) has no reference source (Gazebo owns it), so the oracle's simulator is
+pinned by analytic known answers: ray vs a single disc / the walls in closed form, straight-line /
+pure-rotation / arc robot motion, constant-velocity pedestrians with wall clamping, the crowd schedule, and
+the deterministic sin/cos against libm.  CPU only.  (The GPU simulator is then required to match the oracle's
+bit for bit by tests/test_gpu_parity.py.)"""
+import ctypes as C
+import math
+
+import numpy as np
+
+
+def _raycast(oracle_mod, cfg, rx, ry, yaw, peds):
+    L = oracle_mod.lib()
+    peds = np.ascontiguousarray(peds, dtype=np.float64).reshape(-1, 2)
+    out = np.zeros(cfg.n_rays)
+    L.cno_raycast(C.byref(cfg), rx, ry, yaw, peds.ctypes.data_as(C.POINTER(C.c_double)), len(peds),
+                  out.ctypes.data_as(C.POINTER(C.c_double)))
+    return out
+
+
+def test_det_sincos_matches_libm(oracle_mod):
+    L = oracle_mod.lib()
+    s, c = C.c_double(), C.c_double()
+    worst = 0.0
+    for x in np.concatenate([np.linspace(-12, 12, 20001), np.arange(360) * 6.28 / 359, [0.0, math.pi / 2, math.pi, 3.14]]):
+        L.cno_det_sincos(float(x), C.byref(s), C.byref(c))
+        worst = max(worst, abs(s.value - math.sin(x)), abs(c.value - math.cos(x)))
+    assert worst < 3e-16
+
+
+def test_lidar_single_disc_closed_form(oracle_mod):
+    cfg = oracle_mod.make_config(n_peds=1, room_half=5.0, lidar_offset_x=0.0)
+    d, r = 0.40, cfg.ped_radius
+    rg = _raycast(oracle_mod, cfg, 0.0, 0.0, 0.0, [[d, 0.0]])
+    step = cfg.lidar_span / 359
+    for k in range(360):
+        a = k * step
+        perp = abs(d * math.sin(a))
+        if math.cos(a) > 0 and perp < r:
+            exp = d * math.cos(a) - math.sqrt(r * r - perp * perp)
+            assert abs(rg[k] - exp) < 1e-12, k
+        else:
+            assert math.isinf(rg[k]), k
+    assert abs(rg[0] - (d - r)) < 1e-15            # forward ray: centre distance minus radius
+    # yaw rotates the scan: the disc appears at robot-frame angle -yaw
+    rg2 = _raycast(oracle_mod, cfg, 0.0, 0.0, 10 * step, [[d, 0.0]])
+    assert np.isfinite(rg2[359 - 10 + 1]) or np.isfinite(rg2[350])
+
+
+def test_lidar_walls_closed_form_and_range_limits(oracle_mod):
+    cfg = oracle_mod.make_config(n_peds=0, room_half=1.40, lidar_offset_x=0.0)
+    rg = _raycast(oracle_mod, cfg, 1.0, -1.0, 0.0, np.zeros((0, 2)))     # 0.4 m from the +x and -y walls
+    step = cfg.lidar_span / 359
+    for k in range(360):
+        a = k * step
+        cands = []
+        if math.cos(a) > 1e-12: cands.append(0.4 / math.cos(a))
+        if math.sin(a) < -1e-12: cands.append(0.4 / -math.sin(a))
+        if math.cos(a) < -1e-12: cands.append(2.4 / -math.cos(a))
+        if math.sin(a) > 1e-12: cands.append(2.4 / math.sin(a))
+        t = min(cands)
+        if t > cfg.lidar_max:
+            assert math.isinf(rg[k]), k
+        else:
+            assert abs(rg[k] - max(t, cfg.lidar_min)) < 1e-12, k
+    # closer than range_min reads as range_min; the mount offset shifts the origin backwards along the heading
+    cfg2 = oracle_mod.make_config(n_peds=0, room_half=1.40)
+    rg = _raycast(oracle_mod, cfg2, 1.35, 0.0, 0.0, np.zeros((0, 2)))
+    assert abs(rg[0] - (1.40 - (1.35 - 0.032))) < 1e-12
+
+
+def test_robot_kinematics_known_answers(oracle_mod):
+    o = oracle_mod.Oracle(n_envs=1, n_peds=0, spawn_x=0.0, spawn_y=0.0, spawn_yaw=0.0, room_half=5.0)
+    o.hsim_reset()
+    o.hsim_advance(150, 0.2, 0.0)                   # straight line: x += v * dt
+    r = o.sim_state()[0]
+    assert abs(r[0] - 0.03) < 1e-15 and r[1] == 0.0 and r[2] == 0.0
+    o.hsim_advance(150, 0.0, 2.0)                   # pure rotation: yaw += w * dt
+    r = o.sim_state()[0]
+    assert abs(r[0] - 0.03) < 1e-15 and abs(r[2] - 0.3) < 1e-15
+    # arc: many short intervals of the mid-point rule converge to the exact unicycle arc
+    o.hsim_reset()
+    v, w, n = 0.2, 1.0, 1000
+    for _ in range(n):
+        o.hsim_advance(1, v, w)
+    r = o.sim_state()[0]
+    T = n / 1000.0
+    assert abs(r[0] - v / w * math.sin(w * T)) < 1e-7 and abs(r[1] - v / w * (1 - math.cos(w * T))) < 1e-7
+    # yaw wraps into (-pi, pi]
+    o.hsim_reset()
+    for _ in range(30):
+        o.hsim_advance(150, 0.0, 2.0)
+    assert -math.pi < o.sim_state()[0][2] <= math.pi
+
+
+def test_pedestrian_schedule_integration_and_walls(oracle_mod):
+    P = 4
+    o = oracle_mod.Oracle(n_envs=1, n_peds=P, ped_mode=1, ped_cycle_ms=400, room_half=1.40)
+    init = np.array([[[0.0, 0.0], [0.5, 0.5], [1.30, 0.0], [-1.0, -1.3]]])
+    vel = np.array([[[0.1, -0.05], [0.0, 0.2], [0.2, 0.0], [0.0, -0.2]]])
+    o.set_ped_init(init); o.set_ped_preset_vel(vel)
+    o.hsim_reset()
+    o.hsim_advance(1000, 0.0, 0.0)
+    _, pp, pv, _ = o.sim_state()
+    # pedestrian i starts moving at t = 100*i ms (CROWD:144 stagger) and keeps its constant preset velocity
+    for i in range(2):
+        moved = (1000 - 100 * i) / 1000.0
+        assert np.allclose(pp[i], init[0, i] + vel[0, i] * moved, atol=1e-12)
+    lim = 1.40 - 0.0505
+    assert abs(pp[2][0] - lim) < 1e-15 and pp[2][1] == 0.0          # clamped at the +x wall, slides
+    assert abs(pp[3][1] + lim) < 1e-15
+    assert np.array_equal(pv, vel[0])
+    # a simulator reset zeroes the twists; a pedestrian stands still until its next scheduled update
+    o.hsim_reset()
+    _, pp, pv, _ = o.sim_state()
+    assert np.array_equal(pp, init[0]) and not pv.any()
+    # crowd clock is 1000 ms; update instants are 100*i + 400*m: ped 2 is due exactly at 1000, ped 3 at 1100, ped 0 at 1200
+    o.hsim_advance(50, 0.0, 0.0)                     # [1000, 1050): only pedestrian 2 gets its velocity back
+    _, pp, pv, _ = o.sim_state()
+    assert np.array_equal(pp[[0, 1, 3]], init[0][[0, 1, 3]]) and not pv[[0, 1, 3]].any()
+    assert np.array_equal(pv[2], vel[0, 2]) and abs(pp[2][0] - (1.30 + 0.2 * 0.05)) < 1e-15
+    o.hsim_advance(200, 0.0, 0.0)                    # [1050, 1250): ped 3 at 1100, ped 0 at 1200; ped 1 not before 1300
+    _, pp, pv, _ = o.sim_state()
+    assert np.array_equal(pv[0], vel[0, 0]) and np.array_equal(pv[3], vel[0, 3]) and not pv[1].any()
+    assert np.allclose(pp[0], init[0, 0] + vel[0, 0] * 0.05, atol=1e-15)
+
+
+def test_random_walker_velocity_law(oracle_mod):
+    L = oracle_mod.lib()
+    u = np.array([L.cno_rng_u01(1234, e, 1, p, b) for e in range(20) for p in range(20) for b in range(10)])
+    assert 0.0 <= u.min() and u.max() < 1.0 and abs(u.mean() - 0.5) < 0.02 and abs(u.std() - 12 ** -0.5) < 0.02
+    assert L.cno_rng_u01(1234, 3, 1, 2, 7) == L.cno_rng_u01(1234, 3, 1, 2, 7) != L.cno_rng_u01(1234, 4, 1, 2, 7)
+    o = oracle_mod.Oracle(n_envs=3, n_peds=20, ped_cycle_ms=1400)
+    o.reset()
+    for _ in range(30):
+        o.step(np.zeros((3, 2)))
+    for e in range(3):
+        pv = o.sim_state(e)[2]
+        assert np.abs(pv).max() <= 0.2 and np.abs(pv).max() > 0.05     # CROWD:101-102 U(-0.2, 0.2)
+    xy = o.get_ped_init()
+    assert np.abs(xy).max() <= 1.30 and (np.hypot(xy[..., 0] - 1.0, xy[..., 1] + 1.0) >= 0.4).all()

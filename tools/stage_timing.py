@@ -15,7 +15,7 @@ _abi.LIB_PATH = _abi.LIB_PATH.replace("libcrowdnav.so", "libcrowdnav_timing.so")
 from crowdnav import Config
 from crowdnav.env import VecEnv
 
-NAMES = ["load state", "physics + deque", "waypoint/heading/dist", "near-ped list", "ray loop (cast, end points, obs)",
+NAMES = ["", "load state", "physics, deque, waypoint/heading/dist", "near-ped list", "ray loop (cast, end points, obs)",
          "bbox (reset only)", "gradients", "flag words", "type machine", "aliasing", "association (IoU)", "order/split words",
          "word bases", "confirmation + counters", "tracker", "speeds/defaults", "collision cone + top-K", "counters/done/tail",
          "reward + outputs", "state write-back"]
