@@ -101,3 +101,40 @@ def evaluate(env, agent, episodes_per_env=1, max_launches=100000):
                 soc = 1.0 - pc[e, 1].item() / seen if seen else float("nan")
                 stats.add(c[e, 4].item(), c[e, 5].item(), ret[e].item(), int(pc[e, 3]) + 1, ego, soc)
     return stats
+
+
+class GraphedRollout:
+    """Actor-in-the-loop stepping captured once into a HIP graph (torch.cuda.CUDAGraph): the actor's three
+    GEMMs, the exploration noise, the clip and the fused env-step kernel replay as ONE graph launch per
+    step, which removes the per-kernel launch gaps that dominate BASELINE config 3 at this step time.
+    cn_step only enqueues on the capturing stream, so it is captured like any other kernel."""
+
+    def __init__(self, env, agent, add_noise=True, auto_reset="next"):
+        self.env, self.agent = env, agent
+        if not getattr(env, "_started", False):
+            env.reset()
+            env._started = True
+        self.obs = env.obs
+        self.act = torch.zeros((env.N, 2), dtype=torch.float32, device=env.device)
+        s = torch.cuda.Stream(device=env.device)
+        s.wait_stream(torch.cuda.current_stream(env.device))
+        with torch.cuda.stream(s):           # warm-up outside capture (allocator, lazy init)
+            for _ in range(3):
+                self.act.copy_(self._policy(add_noise))
+                env.step(self.act, auto_reset=auto_reset)
+        torch.cuda.current_stream(env.device).wait_stream(s)
+        torch.cuda.synchronize(env.device)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.act.copy_(self._policy(add_noise))
+            env.step(self.act, auto_reset=auto_reset)
+
+    def _policy(self, add_noise):
+        a = self.agent.actor(self.obs)
+        if add_noise:                         # default generator: graph-safe philox offsets
+            a = a + torch.randn_like(a) * self.agent.explore_sigma
+        return torch.max(torch.min(a, self.agent._hi), self.agent._lo)
+
+    def step(self):
+        self.graph.replay()
+        return self.env.obs, self.env.reward, self.env.done

@@ -26,6 +26,22 @@ def run(name, cfg, actor=False, steps=400, mode="next"):
 
 run("config 2: 4096 x 20 peds x 360 rays (open loop)", Config(n_envs=4096, ped_cycle_ms=1400))
 run("config 3: 4096 x 20 peds, TD3 actor in the loop", Config(n_envs=4096, ped_cycle_ms=1400), actor=True)
+
+def run_graphed(name, cfg, steps=400):
+    from crowdnav.rollout import GraphedRollout
+    env = VecEnv(cfg); N = env.N
+    agent = Agent(obs_dim=env.D, device="cuda", seed=0, memory_size=16)
+    with torch.no_grad():
+        g = GraphedRollout(env, agent)
+        for i in range(40): g.step()
+        ep0 = env.counters()[:, 8].sum().item(); torch.cuda.synchronize(); t0 = time.perf_counter()
+        for i in range(steps): g.step()
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    resets = env.counters()[:, 8].sum().item() - ep0
+    print("%-52s %8.4f ms/step  %8.2f M env-steps/s" % (name, dt / steps * 1e3, (N * steps - resets) / dt / 1e6))
+    env.close()
+
+run_graphed("config 3 as one HIP graph per step", Config(n_envs=4096, ped_cycle_ms=1400))
 run("config 4 shard: 2048 x 20 peds x 360 rays (1 of 8 GPUs)", Config(n_envs=2048, ped_cycle_ms=1400))
 run("config 5: 4096 x 100 peds x 720 rays", Config(n_envs=4096, n_peds=100, n_rays=720, room_half=2.4, ped_cycle_ms=1400))
 run("16384 x 20 peds x 360 rays on one GPU", Config(n_envs=16384, ped_cycle_ms=1400))
