@@ -22,7 +22,8 @@ SI = dict(DONE=0, DQ_LEN=1, NTRACKS=2, EGO_VIOL=3, SOCIAL_VIOL=4, OBST_STEPS=5, 
 TF = dict(PX=0, PY=1, DIST=2, D0X=3, D0Y=4, D1X=5, D1Y=6, T=7, SPEED=8, VX=9, VY=10, DQLEN=11)
 
 EXPORTS = ["cn_abi_version", "cn_last_error", "cn_create", "cn_destroy", "cn_obs_dim", "cn_config_of",
-           "cn_set_ped_init", "cn_get_ped_init", "cn_set_ped_preset_vel", "cn_reset", "cn_step", "cn_get_counters",
+           "cn_set_ped_init", "cn_get_ped_init", "cn_set_ped_preset_vel", "cn_reset", "cn_step", "cn_observe_external",
+           "cn_get_counters",
            "cn_get_returns", "cn_debug_env", "cn_snapshot_size", "cn_snapshot", "cn_restore"]
 
 
@@ -30,6 +31,12 @@ class CnStepIO(C.Structure):
     _fields_ = [("action", C.c_void_p), ("step_counter", C.c_void_p), ("obs", C.c_void_p), ("final_obs", C.c_void_p),
                 ("obs_f64", C.c_void_p), ("reward", C.c_void_p), ("done", C.c_void_p), ("topk_idx", C.c_void_p),
                 ("auto_reset", C.c_int32), ("reserved", C.c_int32)]
+
+
+class CnExternalIO(C.Structure):
+    _fields_ = [("ranges", C.c_void_p), ("odom", C.c_void_p), ("step_counter", C.c_void_p), ("obs", C.c_void_p),
+                ("obs_f64", C.c_void_p), ("reward", C.c_void_p), ("done", C.c_void_p), ("topk_idx", C.c_void_p),
+                ("is_reset", C.c_int32), ("reserved", C.c_int32)]
 
 
 class CrowdNavError(RuntimeError):
@@ -67,6 +74,7 @@ def lib():
         L.cn_set_ped_preset_vel.argtypes = [vp, vp]
         L.cn_reset.argtypes = [vp, vp, vp, vp, vp]
         L.cn_step.argtypes = [vp, C.POINTER(CnStepIO), vp]
+        L.cn_observe_external.argtypes = [vp, C.POINTER(CnExternalIO), vp]
         L.cn_get_counters.argtypes = [vp, vp, vp]
         L.cn_get_returns.argtypes = [vp, vp, vp, vp]
         L.cn_debug_env.argtypes = [vp, C.c_int, vp, vp, vp, vp]

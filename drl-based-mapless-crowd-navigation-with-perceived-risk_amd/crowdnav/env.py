@@ -105,6 +105,23 @@ class VecEnv:
         _abi.check(self.L.cn_step(self.h, C.byref(io), self._stream()))
         return self.obs, self.reward, self.done
 
+    def observe_external(self, ranges, odom, step_counter=None, is_reset=False):
+        """Env.get_state + Env.compute_reward on externally supplied /scan and /odom (Gazebo, a physical robot,
+        or a recorded run): ranges [N,R] float64, odom [N,10] float64 = x, y, yaw, v, w, time.time(),
+        x, y at the end of the sleep, end_timestep, 0.  Returns (obs, reward, done) device tensors."""
+        rg = torch.as_tensor(ranges, dtype=torch.float64, device=self.device).contiguous().reshape(self.N, self.R)
+        od = torch.as_tensor(odom, dtype=torch.float64, device=self.device).contiguous().reshape(self.N, 10)
+        sc = None
+        if step_counter is not None:
+            sc = torch.as_tensor(step_counter, dtype=torch.int32, device=self.device).contiguous()
+        io = _abi.CnExternalIO(ranges=rg.data_ptr(), odom=od.data_ptr(), step_counter=sc.data_ptr() if sc is not None else None,
+                               obs=self.obs.data_ptr(), obs_f64=self.obs_f64.data_ptr() if self.obs_f64 is not None else None,
+                               reward=self.reward.data_ptr(), done=self.done.data_ptr(), topk_idx=self.topk_idx.data_ptr(),
+                               is_reset=int(bool(is_reset)), reserved=0)
+        _abi.check(self.L.cn_observe_external(self.h, C.byref(io), self._stream()))
+        self._keep = (rg, od, sc)
+        return self.obs, self.reward, self.done
+
     def counters(self):
         """[N,10] int32: ego_viol, social_viol, obstacle_present_steps, ep_steps, success, failure, status, n_tracks,
         episodes finished, reset pending."""

@@ -13,6 +13,7 @@
 #include "crowdnav_kernel.h"
 
 extern "C" __global__ void cn_env_kernel(CnKParams p);
+extern "C" __global__ void cn_env_kernel_ext(CnKParams p);
 extern "C" __global__ void cn_gather_kernel(CnKParams p, float* last_ret, float* run_ret, int32_t* counters);
 
 static thread_local std::string g_err;
@@ -160,7 +161,10 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
     k.sd = h->d_sd; k.si = h->d_si; k.ped_p = h->d_ped_p; k.ped_v = h->d_ped_v; k.ped_init = h->d_ped_init;
     k.ped_preset = h->d_ped_preset; k.trk = h->d_trk;
     if (h->lds > 64 * 1024)
+    {
         HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
+        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_ext, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
+    }
     *out = h;
     return CN_OK;
 }
@@ -219,7 +223,10 @@ extern "C" int cn_set_ped_preset_vel(cn_handle h, const double* vxy)
 
 static int launch(cn_handle h, const CnKParams& kp, hipStream_t st)
 {
-    hipLaunchKernelGGL(cn_env_kernel, dim3(kp.N), dim3(64), h->lds, st, kp);
+    if (kp.mode == CN_MODE_EXT_STEP || kp.mode == CN_MODE_EXT_RESET)
+        hipLaunchKernelGGL(cn_env_kernel_ext, dim3(kp.N), dim3(64), h->lds, st, kp);
+    else
+        hipLaunchKernelGGL(cn_env_kernel, dim3(kp.N), dim3(64), h->lds, st, kp);
     HIPCHK(hipGetLastError());
     return CN_OK;
 }
@@ -239,6 +246,17 @@ extern "C" int cn_step(cn_handle h, const cn_step_io* io, void* stream)
     kp.mode = CN_MODE_STEP; kp.auto_reset = io->auto_reset;
     kp.action = io->action; kp.step_counter = io->step_counter; kp.obs = io->obs; kp.final_obs = io->final_obs;
     kp.obs_f64 = io->obs_f64; kp.reward = io->reward; kp.done = io->done; kp.topk_idx = io->topk_idx;
+    return launch(h, kp, (hipStream_t)stream);
+}
+
+extern "C" int cn_observe_external(cn_handle h, const cn_external_io* io, void* stream)
+{
+    if (!h || !io || !io->ranges || !io->odom || !io->obs || !io->reward || !io->done)
+        return fail(CN_ERR_ARG, "cn_observe_external: null argument");
+    CnKParams kp = h->kp;
+    kp.mode = io->is_reset ? CN_MODE_EXT_RESET : CN_MODE_EXT_STEP;
+    kp.ext_ranges = io->ranges; kp.ext_odom = io->odom; kp.step_counter = io->step_counter;
+    kp.obs = io->obs; kp.obs_f64 = io->obs_f64; kp.reward = io->reward; kp.done = io->done; kp.topk_idx = io->topk_idx;
     return launch(h, kp, (hipStream_t)stream);
 }
 

@@ -3,7 +3,7 @@
 #include <stdint.h>
 #include "../../include/crowdnav.h"
 
-enum { CN_MODE_STEP = 0, CN_MODE_RESET = 1 };
+enum { CN_MODE_STEP = 0, CN_MODE_RESET = 1, CN_MODE_EXT_STEP = 2, CN_MODE_EXT_RESET = 3 };
 #define CN_MAXW 17         /* 64-ray bit words per env: ceil(1024/64) + 1 */
 #define CN_NMASK 13        /* number of bit-word masks kept in LDS (M_COUNT in the kernel) */
 
@@ -36,6 +36,8 @@ struct CnKParams {
     const float* action;
     const int32_t* step_counter;
     const uint8_t* mask;
+    const double* ext_ranges;  // [N, R] externally supplied lidar ranges (CN_MODE_EXT_*), else NULL
+    const double* ext_odom;    // [N, 10]
     float* obs;
     float* final_obs;
     double* obs_f64;

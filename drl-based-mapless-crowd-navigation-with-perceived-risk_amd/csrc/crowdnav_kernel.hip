@@ -229,6 +229,7 @@ __device__ __forceinline__ void sim_advance(const CnKParams& p, EnvRegs& e, int 
 
 // ---- Env.get_state (ENV:245-1044) ----------------------------------------------------------------
 // ped_p: pedestrian positions in LDS.  Writes the observation (float32 and optionally float64).
+template <bool EXT>
 __device__ __forceinline__ void observe(const CnKParams& p, const Poly& pg, EnvRegs& e, const Lds& L, int env, int lane, int step_counter,
                         float* obs32, float* fin32, double* obs64, int* done_out)
 {
@@ -283,11 +284,14 @@ __device__ __forceinline__ void observe(const CnKParams& p, const Poly& pg, EnvR
     // End points, rounded ranges and gradients are 3-decimal values: LDS keeps the integer thousandths
     // (x == cn_div1000(mil) bit for bit), which halves the working set and doubles the waves per CU.
     for (int k = lane; k < R; k += 64) {
+        double t = INFINITY;
+        if constexpr (EXT) {
+            t = p.ext_ranges[(size_t)env * R + k];   // the sensor's own reading (Gazebo / a physical lidar)
+        } else {
         double lc, ls;  // ray k in the robot frame; same bits as a host table of cn_det_sincos(k * step)
         cn_det_sincos((double)k * p.lidar_step, &ls, &lc);
         double dx = fma(cy, lc, -(sy * ls));
         double dy = fma(sy, lc, cy * ls);
-        double t = INFINITY;
         // A wall farther than lidar_max from the origin can only give t > lidar_max ("no return"), so its
         // divide is skipped when the whole env is out of its reach (uniform test, result unchanged).
         if (wall_x) {
@@ -314,11 +318,14 @@ __device__ __forceinline__ void observe(const CnKParams& p, const Poly& pg, EnvR
                 }
             }
         }
+        t = (t > p.lidar_max) ? INFINITY : t;       // the simulated sensor reports no return beyond its range
+        }
         if (k >= 1) {
             int j = R - 1 - k;  // UTL:389-390 reverse, drop last
-            double r = (t > p.lidar_max) ? INFINITY : t;
+            double r = t;
             double sc;
-            if (isinf(r)) sc = MAXR;
+            if (isinf(r) && r > 0) sc = MAXR;
+            else if (r != r) sc = 0.0;                // UTL:380-381 NaN -> 0 (external scans only)
             else if (r == 0.0) sc = MAXR;
             else if (r > MAXR) sc = MAXR;
             else sc = r;
@@ -895,7 +902,8 @@ __device__ __forceinline__ double compute_reward(const CnKParams& p, const Poly&
 
 }  // namespace
 
-extern "C" __global__ void __launch_bounds__(64) cn_env_kernel(CnKParams p)
+template <bool EXT>
+__device__ __forceinline__ void env_kernel_body(const CnKParams& p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int env = blockIdx.x, lane = threadIdx.x;
@@ -966,36 +974,49 @@ extern "C" __global__ void __launch_bounds__(64) cn_env_kernel(CnKParams p)
 
     CN_T(1);
     int done = 0;
-    bool need_reset = (p.mode == CN_MODE_RESET);
+    bool need_reset = (p.mode == CN_MODE_RESET || p.mode == CN_MODE_EXT_RESET);
     // auto_reset == 2 ("next-step" reset, the gymnasium NEXT_STEP convention): an env that finished in
     // the previous launch spends THIS launch on Env.reset() -- its action is ignored, reward 0, done 0 --
     // so no wavefront ever runs two observations back to back and the launch's critical path halves.
+    constexpr bool ext = EXT;
+    const double* od = ext ? p.ext_odom + (size_t)env * 10 : nullptr;
+    if (ext) {   // /odom callback (ENV:239-243) and time.time()
+        e.rx = od[0]; e.ry = od[1]; e.ryaw = od[2]; e.rv = od[3]; e.rw = od[4]; e.clock = od[5];
+    }
     if (p.mode == CN_MODE_STEP && p.auto_reset == 2 && e.pending) {
         need_reset = true;
         e.pending = 0;
         if (lane == 0) { p.reward[env] = 0.0f; p.done[env] = 0; }
         if (p.topk_idx && lane < K) p.topk_idx[(size_t)env * K + lane] = -1;
-    } else if (p.mode == CN_MODE_STEP) {
+    } else if (p.mode == CN_MODE_STEP || p.mode == CN_MODE_EXT_STEP) {
         // ---- Env.step (ENV:1164-1225), continuous mode ---------------------------------------------
         e.ep_step += 1;
         const int sc = p.step_counter ? p.step_counter[env] : e.ep_step;
-        const double v = (double)p.action[2 * env], w = (double)p.action[2 * env + 1];
-        const double t0 = e.clock;
-        e.rv = v; e.rw = w;                                   // pub_cmd_vel.publish (ENV:1200)
-        e.clock += (double)p.dt_ms / 1000.0;                  // time.sleep(0.15) (ENV:1201)
-        sim_advance(p, e, env, lane, L.ped, pedv, p.dt_ms);
-        const double end_timestep = e.clock - t0;             // ENV:1202
+        double deq_x, deq_y, end_timestep;
+        if (!ext) {
+            const double v = (double)p.action[2 * env], w = (double)p.action[2 * env + 1];
+            const double t0 = e.clock;
+            e.rv = v; e.rw = w;                               // pub_cmd_vel.publish (ENV:1200)
+            e.clock += (double)p.dt_ms / 1000.0;              // time.sleep(0.15) (ENV:1201)
+            sim_advance(p, e, env, lane, L.ped, pedv, p.dt_ms);
+            end_timestep = e.clock - t0;                      // ENV:1202
+            deq_x = e.rx; deq_y = e.ry;
+        } else {                                              // the caller ran the sleep; /odom said where we are
+            deq_x = od[6]; deq_y = od[7]; end_timestep = od[8];
+        }
         {
-            double qx = cn_py_round3(e.rx), qy = cn_py_round3(e.ry);  // ENV:1208
+            double qx = cn_py_round3(deq_x), qy = cn_py_round3(deq_y);  // ENV:1208
             if (e.dq_len == 0) { e.dq0x = qx; e.dq0y = qy; e.dq_len = 1; }
             else if (e.dq_len == 1) { e.dq1x = qx; e.dq1y = qy; e.dq_len = 2; }
             else { e.dq0x = e.dq1x; e.dq0y = e.dq1y; e.dq1x = qx; e.dq1y = qy; }
         }
         e.ts = end_timestep;                                  // ENV:1209
-        e.clock += (double)p.scan_latency_ms / 1000.0;        // wait_for_message('scan') (ENV:1218)
-        sim_advance(p, e, env, lane, L.ped, pedv, p.scan_latency_ms);
+        if (!ext) {
+            e.clock += (double)p.scan_latency_ms / 1000.0;    // wait_for_message('scan') (ENV:1218)
+            sim_advance(p, e, env, lane, L.ped, pedv, p.scan_latency_ms);
+        }
         CN_SYNC();
-        observe(p, pg, e, L, env, lane, sc, p.obs, p.final_obs, p.obs_f64, &done);
+        observe<EXT>(p, pg, e, L, env, lane, sc, p.obs, ext ? nullptr : p.final_obs, p.obs_f64, &done);
         double r = compute_reward(p, pg, e, L, lane, done);
         e.ep_ret += r;
         if (lane == 0) {
@@ -1004,11 +1025,11 @@ extern "C" __global__ void __launch_bounds__(64) cn_env_kernel(CnKParams p)
         }
         if (p.topk_idx && lane < K) p.topk_idx[(size_t)env * K + lane] = L.kidx[lane];
         if (done) {
-            e.rv = 0.0; e.rw = 0.0;                           // pub_cmd_vel.publish(Twist()) (ENV:1160)
+            if (!ext) { e.rv = 0.0; e.rw = 0.0; }             // pub_cmd_vel.publish(Twist()) (ENV:1160)
             e.last_ret = e.ep_ret;
             e.episodes += 1;
-            need_reset = (p.auto_reset == 1);
-            e.pending = (p.auto_reset == 2);
+            need_reset = !ext && (p.auto_reset == 1);
+            e.pending = !ext && (p.auto_reset == 2);
         }
         CN_SYNC();
     }
@@ -1016,20 +1037,24 @@ extern "C" __global__ void __launch_bounds__(64) cn_env_kernel(CnKParams p)
         __syncthreads();  // rare path: drain the tracker-table stores of the step phase before they are re-read
         // ---- Env.reset (ENV:1227-1263) + TRAIN:114-116 -----------------------------------------------
         // gazebo/reset_simulation: poses back to their initial values, twists zeroed (crowd clock keeps running)
+        if (!ext) {
         e.rx = p.spawn_x; e.ry = p.spawn_y; e.ryaw = p.spawn_yaw; e.rv = 0.0; e.rw = 0.0;
         for (int i = lane; i < 2 * P; i += 64) { L.ped[i] = gped_init[i]; pedv[i] = 0.0; }
         CN_SYNC();
         e.clock += (double)p.scan_latency_ms / 1000.0;        // wait_for_message('scan') (ENV:1238)
         sim_advance(p, e, env, lane, L.ped, pedv, p.scan_latency_ms);
+        }
         CN_SYNC();
         e.prev_dist = dist3(e.rx, e.ry, e.wpx, e.wpy);        // ENV:1243 (unrounded)
         e.prev_head = heading_to_goal(p, e, e.rx, e.ry, e.ryaw);  // ENV:1244
         CN_SYNC();
         int d2 = 0;
-        observe(p, pg, e, L, env, lane, 0, p.obs, nullptr, p.obs_f64, &d2);
+        observe<EXT>(p, pg, e, L, env, lane, 0, p.obs, nullptr, p.obs_f64, &d2);
         e.social_viol = 0; e.ego_viol = 0; e.obst_steps = 0;  // ENV:1260-1262
+        if (!ext) {
         e.clock += (double)p.settle_ms / 1000.0;              // TRAIN:114 time.sleep(0.1)
         sim_advance(p, e, env, lane, L.ped, pedv, p.settle_ms);
+        }
         e.done = 0;                                           // TRAIN:116
         e.ep_step = 0; e.ep_ret = 0.0; e.pending = 0;
         CN_SYNC();
@@ -1054,6 +1079,11 @@ extern "C" __global__ void __launch_bounds__(64) cn_env_kernel(CnKParams p)
     }
     CN_T(19);
 }
+
+// The product kernel (simulated sensors) and its sibling for externally supplied /scan + /odom.  Two
+// instantiations keep the external-data branch out of the hot kernel's registers.
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel(CnKParams p) { env_kernel_body<false>(p); }
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_ext(CnKParams p) { env_kernel_body<true>(p); }
 
 // float32 views of the per-env returns (for the RCCL all-gather of episode returns) and counters
 extern "C" __global__ void cn_gather_kernel(CnKParams p, float* last_ret, float* run_ret, int32_t* counters)

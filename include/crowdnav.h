@@ -95,6 +95,25 @@ typedef struct cn_step_io {
     int32_t reserved;
 } cn_step_io;
 
+/* Env.get_state + Env.compute_reward on EXTERNALLY supplied sensor data (ENV:245-1162): what the reference's
+ * `Env` does when Gazebo -- or the physical robot of environment_stage_1_nobonus_realworld.py -- delivers the
+ * /scan and /odom messages.  The library's own simulator is bypassed; tracker / waypoint / deque state is the
+ * handle's.  This is also how the golden runs recorded from the reference are replayed through the kernel. */
+typedef struct cn_external_io {
+    const double* ranges;        /* dev [N,R] LaserScan.ranges as delivered (+inf = no return; ENV:1218,1238) */
+    const double* odom;          /* dev [N,10]: position x, y, yaw, linear_twist.x, angular_twist.z (ENV:239-243),
+                                  *   time.time() inside get_state, position x, y at the end of time.sleep (ENV:1208),
+                                  *   end_timestep (ENV:1202), reserved */
+    const int32_t* step_counter; /* dev [N] (ignored for the reset flow) */
+    float* obs;                  /* dev [N, 366+4K] */
+    double* obs_f64;             /* dev [N, 366+4K] or NULL */
+    float* reward;               /* dev [N] */
+    uint8_t* done;               /* dev [N] */
+    int32_t* topk_idx;           /* dev [N,K] or NULL */
+    int32_t is_reset;            /* 1: Env.reset() flow (ENV:1243-1262 + TRAIN:116), 0: Env.step() flow (ENV:1208-1223) */
+    int32_t reserved;
+} cn_external_io;
+
 int cn_abi_version(void);
 const char* cn_last_error(void);
 
@@ -113,6 +132,7 @@ int cn_set_ped_preset_vel(cn_handle h, const double* vxy_host);
  * (TRAIN:114-116).  mask: dev [N] or NULL (= all). obs_f64 may be NULL. */
 int cn_reset(cn_handle h, const uint8_t* mask, float* obs, double* obs_f64, void* stream);
 int cn_step(cn_handle h, const cn_step_io* io, void* stream);
+int cn_observe_external(cn_handle h, const cn_external_io* io, void* stream);
 
 /* get_episode_status / get_*_safety_violation_status inputs (ENV:1265-1283).
  * out: dev [N,10] = ego_viol, social_viol, obstacle_present_steps, ep_steps, success, failure, status, n_tracks,

@@ -270,3 +270,39 @@ def test_reference_scenarios_presets(oracle_mod):
     import tempfile
     path = st.write_csv(tempfile.mkdtemp(), "td3_training_trajectory_test")
     assert open(path).readline().strip().split(",") == st.HEADERS
+
+
+@pytest.mark.parametrize("name", ["train20", "dense100", "eval60", "k4"])
+def test_golden_replay_through_the_kernel(name):
+    """The kernel fed with EXACTLY what Gazebo/ROS handed the reference in the golden runs (lidar ranges, odom,
+    clock, step counter; cn_observe_external) returns what the REFERENCE's own Python returned: observations,
+    rewards, done flags, safety counters, the track table, CP scalars, waypoint, bbox size.  No simulator of
+    ours is involved."""
+    import torch
+    from crowdnav import Config
+    from crowdnav.env import VecEnv
+    z, kw = load_seq(name)
+    env = VecEnv(Config(n_envs=1, **kw))
+    env.enable_f64_obs()
+    n_exact = 0
+    for i in range(len(z["now"])):
+        odom = [z["px"][i], z["py"][i], z["yaw"][i], z["v"][i], z["w"][i], z["now"][i], z["deque_x"][i], z["deque_y"][i],
+                z["end_timestep"][i], 0.0]
+        is_reset = bool(z["is_reset"][i])
+        env.observe_external(z["ranges"][i][None, :], [odom], step_counter=[int(z["step_counter"][i])], is_reset=is_reset)
+        torch.cuda.synchronize()
+        og = env.obs_f64[0].cpu().numpy()
+        assert np.abs(og - z["obs"][i]).max() <= TOL, (name, i)
+        n_exact += int(np.array_equal(og, z["obs"][i]))
+        if not is_reset:
+            assert float(env.reward[0].item()) == z["reward"][i] and bool(env.done[0].item()) == bool(z["done"][i]), (name, i)
+        d = env.debug_env(0)
+        n = int(z["n_tracks"][i])
+        assert d["n_tracks"] == n, (name, i)
+        assert np.array_equal(d["track_pose"], z["track_pose"][i][:n]) and np.array_equal(d["track_dist"], z["track_dist"][i][:n])
+        assert np.allclose(d["track_speed"], z["track_speed"][i][:n], rtol=1e-12, atol=0)
+        assert np.allclose(d["track_vel"], z["track_vel"][i][:n], rtol=1e-12, atol=0)
+        assert abs(d["collision_prob"] - z["collision_prob"][i]) <= 1e-12 and abs(d["ego_score"] - z["ego_score"][i]) <= 1e-12
+        assert np.allclose(d["wp"], z["wp"][i], rtol=0, atol=1e-15) and abs(d["bb"] - z["bb"][i]) <= 1e-15
+        assert tuple(env.counters()[0, :3].cpu().tolist()) == tuple(int(c) for c in z["counters"][i])
+    assert n_exact >= 0.995 * len(z["now"])
