@@ -58,9 +58,12 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise CrowdNavError("libcrowdnav.so is not built (%s); run __graft_entry__.build() -- there is no CPU "
-                                "fallback" % LIB_PATH)
+        try:
+            build()          # no-op when lib/libcrowdnav.so is newer than every source
+        except Exception as ex:  # hipcc missing: use what is there, or fail loudly below
+            if not os.path.exists(LIB_PATH):
+                raise CrowdNavError("libcrowdnav.so is not built (%s) and cannot be built here (%s); there is no CPU "
+                                    "fallback" % (LIB_PATH, ex))
         L = C.CDLL(LIB_PATH)
         vp = C.c_void_p
         L.cn_abi_version.restype = C.c_int
