@@ -306,3 +306,25 @@ def test_golden_replay_through_the_kernel(name):
         assert np.allclose(d["wp"], z["wp"][i], rtol=0, atol=1e-15) and abs(d["bb"] - z["bb"][i]) <= 1e-15
         assert tuple(env.counters()[0, :3].cpu().tolist()) == tuple(int(c) for c in z["counters"][i])
     assert n_exact >= 0.995 * len(z["now"])
+
+
+def test_empty_room_and_masked_reset(oracle_mod):
+    """P = 0 (empty room: the division hazard of ENV:1272 is reported, not raised) and cn_reset with a mask."""
+    import torch
+    torch_, env, orc = _pair(oracle_mod, n_envs=8, n_peds=0, max_steps=25, seed=6)
+    env.reset(); torch.cuda.synchronize()
+    assert np.array_equal(env.obs_f64.cpu().numpy(), orc.reset())
+    rng = np.random.default_rng(1)
+    for t in range(30):
+        act = np.stack([rng.uniform(0, 0.22, 8), rng.uniform(-2, 2, 8)], 1).astype(np.float32)
+        env.step(torch.from_numpy(act).cuda(), auto_reset=False); torch.cuda.synchronize()
+        oc, rc, dc, ic = orc.step(act.astype(np.float64), auto_reset=False)
+        assert np.array_equal(env.done.cpu().numpy(), dc) and np.array_equal(env.obs_f64.cpu().numpy(), oc)
+        if dc.any():
+            mask = dc.astype(np.uint8)
+            env.reset(mask=mask); torch.cuda.synchronize()
+            o2 = orc.reset(mask=mask)
+            sel = mask.astype(bool)
+            assert np.array_equal(env.obs_f64.cpu().numpy()[sel], o2[sel])
+    c = env.counters().cpu().numpy()
+    assert (c[:, 2] == 0).all()          # no obstacle was ever seen: the safety scores are undefined
