@@ -14,6 +14,7 @@
 
 extern "C" __global__ void cn_env_kernel(CnKParams p);
 extern "C" __global__ void cn_env_kernel_ext(CnKParams p);
+extern "C" __global__ void cn_env_kernel_same(CnKParams p);
 extern "C" __global__ void cn_gather_kernel(CnKParams p, float* last_ret, float* run_ret, int32_t* counters);
 
 static thread_local std::string g_err;
@@ -164,6 +165,7 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
     {
         HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
         HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_ext, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
+        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_same, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
     }
     *out = h;
     return CN_OK;
@@ -225,6 +227,8 @@ static int launch(cn_handle h, const CnKParams& kp, hipStream_t st)
 {
     if (kp.mode == CN_MODE_EXT_STEP || kp.mode == CN_MODE_EXT_RESET)
         hipLaunchKernelGGL(cn_env_kernel_ext, dim3(kp.N), dim3(64), h->lds, st, kp);
+    else if (kp.mode == CN_MODE_STEP && kp.auto_reset == 1)   // step + reset of finished envs in the same launch
+        hipLaunchKernelGGL(cn_env_kernel_same, dim3(kp.N), dim3(64), h->lds, st, kp);
     else
         hipLaunchKernelGGL(cn_env_kernel, dim3(kp.N), dim3(64), h->lds, st, kp);
     HIPCHK(hipGetLastError());

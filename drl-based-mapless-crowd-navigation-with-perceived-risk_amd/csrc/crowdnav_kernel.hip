@@ -902,7 +902,7 @@ __device__ __forceinline__ double compute_reward(const CnKParams& p, const Poly&
 
 }  // namespace
 
-template <bool EXT>
+template <bool EXT, bool TWO>
 __device__ __forceinline__ void env_kernel_body(const CnKParams& p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -974,15 +974,95 @@ __device__ __forceinline__ void env_kernel_body(const CnKParams& p)
 
     CN_T(1);
     int done = 0;
-    bool need_reset = (p.mode == CN_MODE_RESET || p.mode == CN_MODE_EXT_RESET);
-    // auto_reset == 2 ("next-step" reset, the gymnasium NEXT_STEP convention): an env that finished in
-    // the previous launch spends THIS launch on Env.reset() -- its action is ignored, reward 0, done 0 --
-    // so no wavefront ever runs two observations back to back and the launch's critical path halves.
     constexpr bool ext = EXT;
     const double* od = ext ? p.ext_odom + (size_t)env * 10 : nullptr;
     if (ext) {   // /odom callback (ENV:239-243) and time.time()
         e.rx = od[0]; e.ry = od[1]; e.ryaw = od[2]; e.rv = od[3]; e.rw = od[4]; e.clock = od[5];
     }
+    if constexpr (!TWO) {
+        // ---- ONE observation per wavefront: Env.step, or Env.reset (explicit cn_reset, or the deferred reset
+        // of auto_reset == 2, the gymnasium NEXT_STEP convention: an env that finished in the previous launch
+        // spends THIS launch on its reset -- action ignored, reward 0, done 0).  Keeping a single inlined copy of
+        // observe() also halves the kernel's code size (the instruction cache is 64 KB per two CUs).
+        bool do_reset = !(p.mode == CN_MODE_STEP || p.mode == CN_MODE_EXT_STEP);
+        if (p.mode == CN_MODE_STEP && p.auto_reset == 2 && e.pending) {
+            do_reset = true;
+            e.pending = 0;
+            if (lane == 0) { p.reward[env] = 0.0f; p.done[env] = 0; }
+            if (p.topk_idx && lane < K) p.topk_idx[(size_t)env * K + lane] = -1;
+        }
+        int sc = 0;
+        float* fin = nullptr;
+        if (!do_reset) {
+            // Env.step (ENV:1164-1225), continuous mode
+            e.ep_step += 1;
+            sc = p.step_counter ? p.step_counter[env] : e.ep_step;
+            double deq_x, deq_y, end_timestep;
+            if (!ext) {
+                const double v = (double)p.action[2 * env], w = (double)p.action[2 * env + 1];
+                const double t0 = e.clock;
+                e.rv = v; e.rw = w;                               // pub_cmd_vel.publish (ENV:1200)
+                e.clock += (double)p.dt_ms / 1000.0;              // time.sleep(0.15) (ENV:1201)
+                sim_advance(p, e, env, lane, L.ped, pedv, p.dt_ms);
+                end_timestep = e.clock - t0;                      // ENV:1202
+                deq_x = e.rx; deq_y = e.ry;
+                fin = p.final_obs;
+            } else {                                              // the caller ran the sleep; /odom said where we are
+                deq_x = od[6]; deq_y = od[7]; end_timestep = od[8];
+            }
+            double qx = cn_py_round3(deq_x), qy = cn_py_round3(deq_y);  // ENV:1208
+            if (e.dq_len == 0) { e.dq0x = qx; e.dq0y = qy; e.dq_len = 1; }
+            else if (e.dq_len == 1) { e.dq1x = qx; e.dq1y = qy; e.dq_len = 2; }
+            else { e.dq0x = e.dq1x; e.dq0y = e.dq1y; e.dq1x = qx; e.dq1y = qy; }
+            e.ts = end_timestep;                                  // ENV:1209
+            if (!ext) {
+                e.clock += (double)p.scan_latency_ms / 1000.0;    // wait_for_message('scan') (ENV:1218)
+                sim_advance(p, e, env, lane, L.ped, pedv, p.scan_latency_ms);
+            }
+        } else {
+            // Env.reset (ENV:1227-1263): gazebo/reset_simulation puts poses back and zeroes twists (the crowd clock keeps running)
+            if (!ext) {
+                e.rx = p.spawn_x; e.ry = p.spawn_y; e.ryaw = p.spawn_yaw; e.rv = 0.0; e.rw = 0.0;
+                for (int i = lane; i < 2 * P; i += 64) { L.ped[i] = gped_init[i]; pedv[i] = 0.0; }
+                CN_SYNC();
+                e.clock += (double)p.scan_latency_ms / 1000.0;    // wait_for_message('scan') (ENV:1238)
+                sim_advance(p, e, env, lane, L.ped, pedv, p.scan_latency_ms);
+            }
+            e.prev_dist = dist3(e.rx, e.ry, e.wpx, e.wpy);        // ENV:1243 (unrounded)
+            e.prev_head = heading_to_goal(p, e, e.rx, e.ry, e.ryaw);  // ENV:1244
+        }
+        CN_SYNC();
+        observe<EXT>(p, pg, e, L, env, lane, sc, p.obs, fin, p.obs_f64, &done);
+        if (!do_reset) {
+            double r = compute_reward(p, pg, e, L, lane, done);
+            e.ep_ret += r;
+            if (lane == 0) {
+                p.reward[env] = (float)r;
+                p.done[env] = (uint8_t)done;
+            }
+            if (p.topk_idx && lane < K) p.topk_idx[(size_t)env * K + lane] = L.kidx[lane];
+            if (done) {
+                if (!ext) { e.rv = 0.0; e.rw = 0.0; }             // pub_cmd_vel.publish(Twist()) (ENV:1160)
+                e.last_ret = e.ep_ret;
+                e.episodes += 1;
+                e.pending = !ext && (p.auto_reset == 2);
+            }
+        } else {
+            e.social_viol = 0; e.ego_viol = 0; e.obst_steps = 0;  // ENV:1260-1262
+            if (!ext) {
+                e.clock += (double)p.settle_ms / 1000.0;          // TRAIN:114 time.sleep(0.1)
+                sim_advance(p, e, env, lane, L.ped, pedv, p.settle_ms);
+            }
+            e.done = 0;                                           // TRAIN:116
+            e.ep_step = 0; e.ep_ret = 0.0; e.pending = 0;
+        }
+        CN_SYNC();
+    } else {
+    // ---- same-call reset (auto_reset == 1): Env.step, then Env.reset for an env that just finished ----
+    bool need_reset = (p.mode == CN_MODE_RESET || p.mode == CN_MODE_EXT_RESET);
+    // auto_reset == 2 ("next-step" reset, the gymnasium NEXT_STEP convention): an env that finished in
+    // the previous launch spends THIS launch on Env.reset() -- its action is ignored, reward 0, done 0 --
+    // so no wavefront ever runs two observations back to back and the launch's critical path halves.
     if (p.mode == CN_MODE_STEP && p.auto_reset == 2 && e.pending) {
         need_reset = true;
         e.pending = 0;
@@ -1060,6 +1140,7 @@ __device__ __forceinline__ void env_kernel_body(const CnKParams& p)
         CN_SYNC();
     }
 
+    }
     CN_T(18);
     // ---- write env state back ---------------------------------------------------------------------
     for (int i = lane; i < 2 * P; i += 64) { gped_p[i] = L.ped[i]; gped_v[i] = pedv[i]; }
@@ -1082,8 +1163,9 @@ __device__ __forceinline__ void env_kernel_body(const CnKParams& p)
 
 // The product kernel (simulated sensors) and its sibling for externally supplied /scan + /odom.  Two
 // instantiations keep the external-data branch out of the hot kernel's registers.
-extern "C" __global__ void __launch_bounds__(64) cn_env_kernel(CnKParams p) { env_kernel_body<false>(p); }
-extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_ext(CnKParams p) { env_kernel_body<true>(p); }
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel(CnKParams p) { env_kernel_body<false, false>(p); }
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_same(CnKParams p) { env_kernel_body<false, true>(p); }
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_ext(CnKParams p) { env_kernel_body<true, false>(p); }
 
 // float32 views of the per-env returns (for the RCCL all-gather of episode returns) and counters
 extern "C" __global__ void cn_gather_kernel(CnKParams p, float* last_ret, float* run_ret, int32_t* counters)
