@@ -126,9 +126,13 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
     h->lds = cn_lds_bytes(R, P, K, h->max_conf);
     if (h->lds > 160 * 1024) { delete h; return fail(CN_ERR_CONFIG, "cn_create: per-env working set exceeds 160 KiB of LDS"); }
     // tables
-    std::vector<double> lidar(2 * (size_t)R), poly(128);
+    std::vector<double> lidar(4 * (size_t)R), poly(128);
     double step = c.lidar_span / (double)(R - 1);
     for (int k = 0; k < R; ++k) cn_det_sincos((double)k * step, &lidar[R + k], &lidar[k]);
+    for (int j = 0; j < R - 1; ++j) {  // UTL:121-123 math.radians(i * angle_increment)
+        double a = ((double)j * angle_increment_deg(R)) * (M_PI / 180.0);
+        lidar[2 * R + j] = sin(a); lidar[3 * R + j] = cos(a);
+    }
     for (int k = 0; k < 64; ++k) { double a = -(double)k * M_PI / 32.0; poly[k] = cos(a); poly[64 + k] = sin(a); }
     HIPCHK(hipMalloc(&h->d_lidar, lidar.size() * 8));
     HIPCHK(hipMalloc(&h->d_poly, poly.size() * 8));
@@ -158,7 +162,7 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
     k.max_scan_range = c.max_scan_range; k.min_scan_range = c.min_scan_range; k.goal_x = c.goal_x; k.goal_y = c.goal_y;
     k.start_x = c.start_x; k.start_y = c.start_y; k.spawn_x = c.spawn_x; k.spawn_y = c.spawn_y; k.spawn_yaw = c.spawn_yaw;
     k.waypoint_radius = c.waypoint_radius; k.goal_eps = c.goal_eps; k.angle_inc_deg = angle_increment_deg(R); k.lidar_step = step;
-    k.lidar_c = h->d_lidar; k.lidar_s = h->d_lidar + R; k.poly_c = h->d_poly; k.poly_s = h->d_poly + 64;
+    k.lidar_c = h->d_lidar; k.lidar_s = h->d_lidar + R; k.ang_s = h->d_lidar + 2 * R; k.ang_c = h->d_lidar + 3 * R; k.poly_c = h->d_poly; k.poly_s = h->d_poly + 64;
     k.sd = h->d_sd; k.si = h->d_si; k.ped_p = h->d_ped_p; k.ped_v = h->d_ped_v; k.ped_init = h->d_ped_init;
     k.ped_preset = h->d_ped_preset; k.trk = h->d_trk;
     if (h->lds > 64 * 1024)

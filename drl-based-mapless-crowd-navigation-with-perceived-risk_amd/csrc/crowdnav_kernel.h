@@ -22,6 +22,8 @@ struct CnKParams {
     // tables (device)
     const double* lidar_c;  // [R] cos(k * span/(R-1)), deterministic sincos
     const double* lidar_s;  // [R]
+    const double* ang_s;    // [R-1] sin(radians(j * angle_inc_deg))
+    const double* ang_c;    // [R-1]
     const double* poly_c;   // [64] cos(-k*pi/32)
     const double* poly_s;   // [64]
     // env state (device, library-owned)

@@ -288,8 +288,7 @@ __device__ __forceinline__ void observe(const CnKParams& p, const Poly& pg, EnvR
         if constexpr (EXT) {
             t = p.ext_ranges[(size_t)env * R + k];   // the sensor's own reading (Gazebo / a physical lidar)
         } else {
-        double lc, ls;  // ray k in the robot frame; same bits as a host table of cn_det_sincos(k * step)
-        cn_det_sincos((double)k * p.lidar_step, &ls, &lc);
+        const double lc = p.lidar_c[k], ls = p.lidar_s[k];  // ray k in the robot frame: host table of cn_det_sincos(k * step)
         double dx = fma(cy, lc, -(sy * ls));
         double dy = fma(sy, lc, cy * ls);
         // A wall farther than lidar_max from the origin can only give t > lidar_max ("no return"), so its
@@ -330,10 +329,9 @@ __device__ __forceinline__ void observe(const CnKParams& p, const Poly& pg, EnvR
             else if (r > MAXR) sc = MAXR;
             else sc = r;
             smin = fmin(smin, sc);
-            double ang = (double)j * p.angle_inc_deg;
-            double a = ang * deg2rad - yaw;
-            double sa, ca;
-            cn_det_sincos(a, &sa, &ca);
+            // sin/cos(radians(j * inc) - yaw) by angle addition from a host table of sin/cos(radians(j * inc))
+            const double tS = p.ang_s[j], tC = p.ang_c[j];
+            const double sa = fma(tS, cy, -(tC * sy)), ca = fma(tC, cy, tS * sy);
             L.ptx[j] = (int)cn_round_scaled(px + (sc * ca), 1000.0);
             L.pty[j] = (int)cn_round_scaled(py + (sc * sa) * -1.0, 1000.0);
             L.dmil[j] = (unsigned short)(int)cn_round_scaled(sc, 1000.0);
