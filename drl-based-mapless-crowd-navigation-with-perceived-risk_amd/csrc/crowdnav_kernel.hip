@@ -153,37 +153,48 @@ __device__ __forceinline__ void waypoint_refresh(const CnKParams& p, const Poly&
 __device__ __forceinline__ void ped_advance(const CnKParams& p, int env, int lane, double* ped_p, double* ped_v, long long t0, long long t1)
 {
     const double lo = -p.room_half + p.ped_radius, hi = p.room_half - p.ped_radius;
-    const long long T = p.ped_cycle_ms;
+    const int T = p.ped_cycle_ms;
     const double invT = 1.0 / (double)p.ped_cycle_ms;
     const long long gid = p.env_index_base + env;
     const double* preset = p.ped_preset + (size_t)env * 2 * p.P;
+    // Per-env part of the schedule, once: t0 = cyc * T + ph.  Everything per pedestrian is then 32-bit
+    // arithmetic on times RELATIVE to t0 (the 64-bit emulated integer ops were most of this stage).
+    long long cyc = (long long)((double)t0 * invT);
+    long long ph64 = t0 - cyc * (long long)T;
+    if (ph64 < 0) { cyc -= 1; ph64 += T; }
+    if (ph64 >= T) { cyc += 1; ph64 -= T; }
+    const int ph = (int)ph64;
+    const int dt = (int)(t1 - t0);
+    const uint64_t hbase = cn_mix64(p.seed ^ cn_mix64((uint64_t)gid));   // env part of the RNG key
     for (int i = lane; i < p.P; i += 64) {
         double x = ped_p[2 * i], y = ped_p[2 * i + 1];
         double vx = ped_v[2 * i], vy = ped_v[2 * i + 1];
-        long long offs = (long long)i * p.ped_stagger_ms;
-        // m = ceil((t0 - offs) / T).  Times are < 2^40 ms, so the double quotient is within one of the integer
-        // answer; the remainder test below makes it exact (no 64-bit integer divide sequence).
-        long long m = 0;
-        if (t0 > offs) {
-            const long long num = t0 - offs + T - 1;
-            long long qd = (long long)((double)num * invT);
-            long long r = num - qd * T;
-            if (r < 0) { qd -= 1; r += T; }
-            if (r >= T) { qd += 1; }
-            m = qd;
+        const int offs = i * p.ped_stagger_ms;
+        // first update instant >= t0 is offs + m*T with m = max(0, ceil((t0 - offs) / T)); a = that instant - t0
+        const long long tt = cyc * (long long)T + (long long)(ph - offs);      // t0 - offs
+        unsigned m; int a;
+        if (tt <= 0) { m = 0u; a = (int)(-tt); }
+        else {
+            const int num = (ph - offs) + T - 1;                               // ceil((ph - offs) / T), may be negative
+            int q = (int)floor((double)num * invT);
+            int r = num - q * T;
+            if (r < 0) { q -= 1; r += T; }
+            if (r >= T) { q += 1; }
+            m = (unsigned)cyc + (unsigned)q;
+            a = q * T - (ph - offs);
         }
-        long long a = offs + m * T;
-        long long tc = t0;
-        while (a < t1) {
+        int tc = 0;
+        while (a < dt) {
             if (a > tc) {
-                double ds = (double)(a - tc) / 1000.0;
+                double ds = cn_div1000((double)(a - tc));    // == (a - tc) / 1000.0 exactly
                 x = cn_clamp(fma(vx, ds, x), lo, hi);
                 y = cn_clamp(fma(vy, ds, y), lo, hi);
                 tc = a;
             }
-            if (p.ped_mode == 0) {  // CROWD:101-102
-                double u0 = cn_rng_u01(p.seed, gid, 1u, (uint32_t)i, (uint32_t)(2 * m));
-                double u1 = cn_rng_u01(p.seed, gid, 1u, (uint32_t)i, (uint32_t)(2 * m + 1));
+            if (p.ped_mode == 0) {  // CROWD:101-102: cn_rng_u01(seed, gid, 1, i, 2m | 2m+1) with the shared prefix hoisted
+                const uint64_t h1 = cn_mix64(hbase ^ ((1ull << 32) | (uint64_t)(uint32_t)i));
+                const double u0 = (double)(cn_mix64(h1 ^ (uint64_t)(uint32_t)(2u * m)) >> 11) * (1.0 / 9007199254740992.0);
+                const double u1 = (double)(cn_mix64(h1 ^ (uint64_t)(uint32_t)(2u * m + 1u)) >> 11) * (1.0 / 9007199254740992.0);
                 vx = fma(2.0 * p.ped_vmax, u0, -p.ped_vmax);
                 vy = fma(2.0 * p.ped_vmax, u1, -p.ped_vmax);
             } else {
@@ -191,10 +202,10 @@ __device__ __forceinline__ void ped_advance(const CnKParams& p, int env, int lan
                 vy = preset[2 * i + 1];
             }
             a += T;
-            m += 1;
+            m += 1u;
         }
-        if (t1 > tc) {
-            double ds = (double)(t1 - tc) / 1000.0;
+        if (dt > tc) {
+            double ds = cn_div1000((double)(dt - tc));
             x = cn_clamp(fma(vx, ds, x), lo, hi);
             y = cn_clamp(fma(vy, ds, y), lo, hi);
         }
@@ -206,7 +217,7 @@ __device__ __forceinline__ void ped_advance(const CnKParams& p, int env, int lan
 // mid-point diff-drive step (turtlebot3_fake.cpp:156-162)
 __device__ __forceinline__ void robot_advance(const CnKParams& p, EnvRegs& e, int ms)
 {
-    double dts = (double)ms / 1000.0;
+    double dts = cn_div1000((double)ms);
     double ds = e.rv * dts, dth = e.rw * dts;
     double sn, cs;
     cn_det_sincos(fma(0.5, dth, e.ryaw), &sn, &cs);
@@ -238,10 +249,13 @@ __device__ __forceinline__ void observe(const CnKParams& p, const Poly& pg, EnvR
     const double px = e.rx, py = e.ry, yaw = e.ryaw, v = e.rv, w = e.rw, now = e.clock;
 
     // ENV:246-265
+    CN_T(22);
     if (step_counter == 1) waypoint_refresh(p, pg, e, lane, px, py);
     double distance_to_goal = cn_np_around2(dist3(px, py, e.wpx, e.wpy));
     double heading = cn_py_round2(heading_to_goal(p, e, px, py, yaw));
+    CN_T(23);
     if (step_counter % 5 == 0 || distance_to_goal < e.prev_dist) waypoint_refresh(p, pg, e, lane, px, py);
+    CN_T(24);
     // ENV:267-268: the angular velocity is used as the angle
     double sw_, cw_;
     cn_det_sincos(w, &sw_, &cw_);
@@ -1000,8 +1014,9 @@ __device__ __forceinline__ void env_kernel_body(const CnKParams& p)
                 const double v = (double)p.action[2 * env], w = (double)p.action[2 * env + 1];
                 const double t0 = e.clock;
                 e.rv = v; e.rw = w;                               // pub_cmd_vel.publish (ENV:1200)
-                e.clock += (double)p.dt_ms / 1000.0;              // time.sleep(0.15) (ENV:1201)
+                e.clock += cn_div1000((double)p.dt_ms);              // time.sleep(0.15) (ENV:1201)
                 sim_advance(p, e, env, lane, L.ped, pedv, p.dt_ms);
+                CN_T(20);
                 end_timestep = e.clock - t0;                      // ENV:1202
                 deq_x = e.rx; deq_y = e.ry;
                 fin = p.final_obs;
@@ -1014,8 +1029,9 @@ __device__ __forceinline__ void env_kernel_body(const CnKParams& p)
             else { e.dq0x = e.dq1x; e.dq0y = e.dq1y; e.dq1x = qx; e.dq1y = qy; }
             e.ts = end_timestep;                                  // ENV:1209
             if (!ext) {
-                e.clock += (double)p.scan_latency_ms / 1000.0;    // wait_for_message('scan') (ENV:1218)
+                e.clock += cn_div1000((double)p.scan_latency_ms);    // wait_for_message('scan') (ENV:1218)
                 sim_advance(p, e, env, lane, L.ped, pedv, p.scan_latency_ms);
+                CN_T(21);
             }
         } else {
             // Env.reset (ENV:1227-1263): gazebo/reset_simulation puts poses back and zeroes twists (the crowd clock keeps running)
@@ -1023,7 +1039,7 @@ __device__ __forceinline__ void env_kernel_body(const CnKParams& p)
                 e.rx = p.spawn_x; e.ry = p.spawn_y; e.ryaw = p.spawn_yaw; e.rv = 0.0; e.rw = 0.0;
                 for (int i = lane; i < 2 * P; i += 64) { L.ped[i] = gped_init[i]; pedv[i] = 0.0; }
                 CN_SYNC();
-                e.clock += (double)p.scan_latency_ms / 1000.0;    // wait_for_message('scan') (ENV:1238)
+                e.clock += cn_div1000((double)p.scan_latency_ms);    // wait_for_message('scan') (ENV:1238)
                 sim_advance(p, e, env, lane, L.ped, pedv, p.scan_latency_ms);
             }
             e.prev_dist = dist3(e.rx, e.ry, e.wpx, e.wpy);        // ENV:1243 (unrounded)
@@ -1048,7 +1064,7 @@ __device__ __forceinline__ void env_kernel_body(const CnKParams& p)
         } else {
             e.social_viol = 0; e.ego_viol = 0; e.obst_steps = 0;  // ENV:1260-1262
             if (!ext) {
-                e.clock += (double)p.settle_ms / 1000.0;          // TRAIN:114 time.sleep(0.1)
+                e.clock += cn_div1000((double)p.settle_ms);          // TRAIN:114 time.sleep(0.1)
                 sim_advance(p, e, env, lane, L.ped, pedv, p.settle_ms);
             }
             e.done = 0;                                           // TRAIN:116
@@ -1075,7 +1091,7 @@ __device__ __forceinline__ void env_kernel_body(const CnKParams& p)
             const double v = (double)p.action[2 * env], w = (double)p.action[2 * env + 1];
             const double t0 = e.clock;
             e.rv = v; e.rw = w;                               // pub_cmd_vel.publish (ENV:1200)
-            e.clock += (double)p.dt_ms / 1000.0;              // time.sleep(0.15) (ENV:1201)
+            e.clock += cn_div1000((double)p.dt_ms);              // time.sleep(0.15) (ENV:1201)
             sim_advance(p, e, env, lane, L.ped, pedv, p.dt_ms);
             end_timestep = e.clock - t0;                      // ENV:1202
             deq_x = e.rx; deq_y = e.ry;
@@ -1090,7 +1106,7 @@ __device__ __forceinline__ void env_kernel_body(const CnKParams& p)
         }
         e.ts = end_timestep;                                  // ENV:1209
         if (!ext) {
-            e.clock += (double)p.scan_latency_ms / 1000.0;    // wait_for_message('scan') (ENV:1218)
+            e.clock += cn_div1000((double)p.scan_latency_ms);    // wait_for_message('scan') (ENV:1218)
             sim_advance(p, e, env, lane, L.ped, pedv, p.scan_latency_ms);
         }
         CN_SYNC();
@@ -1119,7 +1135,7 @@ __device__ __forceinline__ void env_kernel_body(const CnKParams& p)
         e.rx = p.spawn_x; e.ry = p.spawn_y; e.ryaw = p.spawn_yaw; e.rv = 0.0; e.rw = 0.0;
         for (int i = lane; i < 2 * P; i += 64) { L.ped[i] = gped_init[i]; pedv[i] = 0.0; }
         CN_SYNC();
-        e.clock += (double)p.scan_latency_ms / 1000.0;        // wait_for_message('scan') (ENV:1238)
+        e.clock += cn_div1000((double)p.scan_latency_ms);        // wait_for_message('scan') (ENV:1238)
         sim_advance(p, e, env, lane, L.ped, pedv, p.scan_latency_ms);
         }
         CN_SYNC();
@@ -1130,7 +1146,7 @@ __device__ __forceinline__ void env_kernel_body(const CnKParams& p)
         observe<EXT>(p, pg, e, L, env, lane, 0, p.obs, nullptr, p.obs_f64, &d2);
         e.social_viol = 0; e.ego_viol = 0; e.obst_steps = 0;  // ENV:1260-1262
         if (!ext) {
-        e.clock += (double)p.settle_ms / 1000.0;              // TRAIN:114 time.sleep(0.1)
+        e.clock += cn_div1000((double)p.settle_ms);              // TRAIN:114 time.sleep(0.1)
         sim_advance(p, e, env, lane, L.ped, pedv, p.settle_ms);
         }
         e.done = 0;                                           // TRAIN:116
