@@ -24,8 +24,10 @@
 
 // Stage time stamps (PROFILING BUILD ONLY: build.sh timing -> libcrowdnav_timing.so; tools/stage_timing.py)
 #ifdef CN_TIMING
+#define CN_ABLATE(bit) (p.ablate & (bit))   /* stage-skipping mask of tools/ablate.py: timing build only */
 #define CN_T(k) do { if (p.timing && lane == 0) p.timing[(size_t)env * 32 + (k)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 #else
+#define CN_ABLATE(bit) 0
 #define CN_T(k) do { } while (0)
 #endif
 
@@ -278,7 +280,7 @@ __device__ __forceinline__ void observe(const CnKParams& p, const Poly& pg, EnvR
         for (int j0 = 0; j0 < p.P; j0 += 64) {
             int j = j0 + lane;
             bool nr = false;
-            if (j < p.P && !(p.ablate & 1)) {
+            if (j < p.P && !(CN_ABLATE(1))) {
                 double ocx = L.ped[2 * j] - ox, ocy = L.ped[2 * j + 1] - oy;
                 nr = fma(ocx, ocx, ocy * ocy) <= lim2;
             }
@@ -444,7 +446,7 @@ __device__ __forceinline__ void observe(const CnKParams& p, const Poly& pg, EnvR
     {
         int last_t = TY_NONE, last_s = 0, du = 0;
         for (int q = 0; q < W; ++q) {
-            const u64 occ = (p.ablate & 2) ? 0ull : ~uni64(WORD(M_NONE, q));
+            const u64 occ = (CN_ABLATE(2)) ? 0ull : ~uni64(WORD(M_NONE, q));
             const u64 Z = uni64(WORD(M_ZERO, q)) & occ, NZ = uni64(WORD(M_NZERO, q)), NN = uni64(WORD(M_NNONE, q)),
                       E = uni64(WORD(M_EQ, q));
             const u64 nonz = occ & ~Z;
@@ -566,7 +568,7 @@ __device__ __forceinline__ void observe(const CnKParams& p, const Poly& pg, EnvR
     CN_T(12);
     // ENV:568-620 confirmation: every lane that owns a segment end evaluates its segment
     int nconf = 0;
-    for (int q = 0; q < ((p.ablate & 4) ? 0 : W); ++q) {
+    for (int q = 0; q < ((CN_ABLATE(4)) ? 0 : W); ++q) {
         const int k = lane + 64 * q;
         const u64 sw = uni64(WORD(M_SEG, q));
         int obj = -1, m = 0; double dm = 0.0;
@@ -639,7 +641,7 @@ __device__ __forceinline__ void observe(const CnKParams& p, const Poly& pg, EnvR
     CN_SYNC();
 #define TRK(f, i) T[(f) * CN_MAX_TRACKS + (i)]
     bool add_unchecked = false;
-    if (p.ablate & 16) { e.ntracks = 0; nconf = 0; }
+    if (CN_ABLATE(16)) { e.ntracks = 0; nconf = 0; }
     if (e.ntracks == 0) {
         for (int j = lane; j < nconf; j += 64) L.checked[j] = 0;
         add_unchecked = true;  // every 'o' object becomes a track
@@ -744,7 +746,7 @@ __device__ __forceinline__ void observe(const CnKParams& p, const Poly& pg, EnvR
 
     CN_T(15);
     // ---- ENV:769-996 collision cone / collision probability / top-K -------------------------------
-    if (e.dq_len == 2 && !(p.ablate & 8)) {
+    if (e.dq_len == 2 && !(CN_ABLATE(8))) {
         const double ts = e.ts;
         if (ts == 0.0) e.status |= CN_ST_DT_ZERO;
         const int nt = e.ntracks;

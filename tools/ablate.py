@@ -7,6 +7,9 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "drl-based-mapless-crowd-navigation-with-perceived-risk_amd"))
 import torch  # noqa: E402
+from crowdnav import _abi  # noqa: E402
+_abi.LIB_PATH = _abi.LIB_PATH.replace("libcrowdnav.so", "libcrowdnav_timing.so")   # the mask only exists in the profiling build
+_abi.build = lambda force=False: _abi.LIB_PATH
 from crowdnav import Config  # noqa: E402
 from crowdnav.env import VecEnv  # noqa: E402
 

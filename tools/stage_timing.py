@@ -12,6 +12,7 @@ import torch
 import crowdnav
 from crowdnav import _abi
 _abi.LIB_PATH = _abi.LIB_PATH.replace("libcrowdnav.so", "libcrowdnav_timing.so")
+_abi.build = lambda force=False: _abi.LIB_PATH
 from crowdnav import Config
 from crowdnav.env import VecEnv
 
