@@ -11,7 +11,7 @@ _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG, "lib", "libcrowdnav.so")
 BUILD_SH = os.path.join(_PKG, "csrc", "build.sh")
 
-CN_MAX_TRACKS = 32
+CN_MAX_TRACKS = 64
 CN_SD_COUNT = 24
 CN_SI_COUNT = 16
 CN_TF_COUNT = 12

@@ -10,7 +10,7 @@ class CnConfig(C.Structure):
     _fields_ = [
         ("n_envs", C.c_int32), ("n_peds", C.c_int32), ("n_rays", C.c_int32), ("k_obstacles", C.c_int32),
         ("max_steps", C.c_int32), ("ped_mode", C.c_int32), ("dt_ms", C.c_int32), ("scan_latency_ms", C.c_int32),
-        ("settle_ms", C.c_int32), ("ped_cycle_ms", C.c_int32), ("ped_stagger_ms", C.c_int32), ("reserved0", C.c_int32),
+        ("settle_ms", C.c_int32), ("ped_cycle_ms", C.c_int32), ("ped_stagger_ms", C.c_int32), ("track_capacity", C.c_int32),
         ("env_index_base", C.c_int64), ("seed", C.c_uint64),
         ("room_half", C.c_double), ("ped_radius", C.c_double), ("ped_vmax", C.c_double),
         ("robot_clearance", C.c_double), ("lidar_min", C.c_double), ("lidar_max", C.c_double),
@@ -34,6 +34,7 @@ class Config:
     settle_ms: int = 100           # TRAIN:114
     ped_cycle_ms: int = 0          # 0 -> 100 ms x n_peds (CROWD:128-144)
     ped_stagger_ms: int = 100      # CROWD:144
+    track_capacity: int = 0        # tracker slots per env: 0 = auto (32 up to 40 pedestrians, else 64)
     env_index_base: int = 0
     seed: int = 1234
     room_half: float = 1.40        # WORLD:926-1108
@@ -67,7 +68,6 @@ class Config:
 
     def to_c(self):
         d = self.resolved()
-        d["reserved0"] = 0
         return CnConfig(**d)
 
     @property

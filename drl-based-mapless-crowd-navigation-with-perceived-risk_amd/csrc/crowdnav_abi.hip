@@ -26,7 +26,7 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 struct cn_env_s {
     cn_config cfg;
     int device;
-    int D, max_conf;
+    int D, max_conf, trk_cap;
     size_t lds;
     CnKParams kp;        // template with state/table pointers filled in
     double *d_lidar, *d_poly, *d_sd, *d_ped_p, *d_ped_v, *d_ped_init, *d_ped_preset, *d_trk;
@@ -34,11 +34,11 @@ struct cn_env_s {
     std::vector<double> ped_init;
 };
 
-size_t cn_lds_bytes(int R, int P, int K, int max_conf)
+size_t cn_lds_bytes(int R, int P, int K, int max_conf, int trk_cap)
 {
     // must mirror the carve in cn_env_kernel
     size_t n = (size_t)(R - 1), mc = (size_t)max_conf;
-    size_t szA_pts = (10 * n + 7) & ~(size_t)7, szA_trk = 8 * (size_t)(CN_TF_COUNT * CN_MAX_TRACKS);
+    size_t szA_pts = (10 * n + 7) & ~(size_t)7, szA_trk = 8 * (size_t)(CN_TF_COUNT * trk_cap);
     size_t szA = szA_pts > szA_trk ? szA_pts : szA_trk;
     size_t szB_g = (6 * n + 7) & ~(size_t)7;
     size_t szB_c = 32 * mc + 8 * 64 + 8 * (size_t)(8 + 4 * K) + 4 * (size_t)CN_MAX_K;
@@ -100,7 +100,7 @@ static int upload_initial_state(cn_env_s* h)
         HIPCHK(hipMemset(h->d_ped_v, 0, (size_t)N * P * 16));
         HIPCHK(hipMemset(h->d_ped_preset, 0, (size_t)N * P * 16));
     }
-    HIPCHK(hipMemset(h->d_trk, 0, (size_t)N * CN_TF_COUNT * CN_MAX_TRACKS * 8));
+    HIPCHK(hipMemset(h->d_trk, 0, (size_t)N * CN_TF_COUNT * h->trk_cap * 8));
     return CN_OK;
 }
 
@@ -110,7 +110,7 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
     const cn_config& c = *cfg;
     if (c.n_envs < 1 || c.n_peds < 0 || c.n_peds > 4096 || c.n_rays < 8 || c.n_rays > 1025 || c.k_obstacles < 1 ||
         c.k_obstacles > CN_MAX_K || c.ped_cycle_ms < 1 || c.dt_ms < 1 || c.scan_latency_ms < 1 || c.settle_ms < 0 ||
-        c.max_steps < 1)
+        c.max_steps < 1 || !(c.track_capacity == 0 || c.track_capacity == 32 || c.track_capacity == 64))
         return fail(CN_ERR_CONFIG, "cn_create: config out of range");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
@@ -123,7 +123,8 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
     const int N = c.n_envs, P = c.n_peds, R = c.n_rays, K = c.k_obstacles;
     h->D = (R - 1) + 7 + 4 * K;
     h->max_conf = (R - 1) / 4 + 2;
-    h->lds = cn_lds_bytes(R, P, K, h->max_conf);
+    h->trk_cap = c.track_capacity ? c.track_capacity : (P <= 40 ? 32 : 64);
+    h->lds = cn_lds_bytes(R, P, K, h->max_conf, h->trk_cap);
     if (h->lds > 160 * 1024) { delete h; return fail(CN_ERR_CONFIG, "cn_create: per-env working set exceeds 160 KiB of LDS"); }
     // tables
     std::vector<double> lidar(4 * (size_t)R), poly(128);
@@ -145,7 +146,7 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
     HIPCHK(hipMalloc(&h->d_ped_v, pb));
     HIPCHK(hipMalloc(&h->d_ped_init, pb));
     HIPCHK(hipMalloc(&h->d_ped_preset, pb));
-    HIPCHK(hipMalloc(&h->d_trk, (size_t)N * CN_TF_COUNT * CN_MAX_TRACKS * 8));
+    HIPCHK(hipMalloc(&h->d_trk, (size_t)N * CN_TF_COUNT * h->trk_cap * 8));
     h->ped_init.resize((size_t)N * P * 2);
     for (int e = 0; e < N; ++e) default_ped_init(c, e, &h->ped_init[(size_t)e * P * 2]);
     int rc = upload_initial_state(h);
@@ -156,7 +157,7 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
     k.N = N; k.P = P; k.R = R; k.K = K;
     k.max_steps = c.max_steps; k.ped_mode = c.ped_mode; k.dt_ms = c.dt_ms; k.scan_latency_ms = c.scan_latency_ms;
     k.settle_ms = c.settle_ms; k.ped_cycle_ms = c.ped_cycle_ms; k.ped_stagger_ms = c.ped_stagger_ms;
-    k.max_conf = h->max_conf; k.env_index_base = c.env_index_base; k.seed = c.seed;
+    k.max_conf = h->max_conf; k.trk_cap = h->trk_cap; k.env_index_base = c.env_index_base; k.seed = c.seed;
     k.room_half = c.room_half; k.ped_radius = c.ped_radius; k.ped_vmax = c.ped_vmax; k.robot_clearance = c.robot_clearance;
     k.lidar_min = c.lidar_min; k.lidar_max = c.lidar_max; k.lidar_offset_x = c.lidar_offset_x;
     k.max_scan_range = c.max_scan_range; k.min_scan_range = c.min_scan_range; k.goal_x = c.goal_x; k.goal_y = c.goal_y;
@@ -305,7 +306,7 @@ extern "C" int cn_debug_env(cn_handle h, int env, double* scalars, double* robot
         }
     }
     if (tracks)
-        HIPCHK(hipMemcpy(tracks, h->d_trk + (size_t)env * CN_TF_COUNT * CN_MAX_TRACKS, CN_TF_COUNT * CN_MAX_TRACKS * 8,
+        HIPCHK(hipMemcpy(tracks, h->d_trk + (size_t)env * CN_TF_COUNT * h->trk_cap, CN_TF_COUNT * h->trk_cap * 8,
                          hipMemcpyDeviceToHost));
     if (ints) HIPCHK(hipMemcpy(ints, h->d_si + (size_t)env * CN_SI_COUNT, CN_SI_COUNT * 4, hipMemcpyDeviceToHost));
     return CN_OK;
@@ -316,7 +317,7 @@ extern "C" size_t cn_snapshot_size(cn_handle h)
 {
     if (!h) return 0;
     size_t N = h->cfg.n_envs, P = h->cfg.n_peds;
-    return N * (CN_SD_COUNT * 8 + CN_SI_COUNT * 4 + 2 * P * 16 + (size_t)CN_TF_COUNT * CN_MAX_TRACKS * 8);
+    return N * (CN_SD_COUNT * 8 + CN_SI_COUNT * 4 + 2 * P * 16 + (size_t)CN_TF_COUNT * h->trk_cap * 8);
 }
 
 extern "C" int cn_snapshot(cn_handle h, void* buf, size_t size)
@@ -333,7 +334,7 @@ extern "C" int cn_snapshot(cn_handle h, void* buf, size_t size)
         HIPCHK(hipMemcpy(q, h->d_ped_p, N * P * 16, hipMemcpyDeviceToHost)); q += N * P * 16;
         HIPCHK(hipMemcpy(q, h->d_ped_v, N * P * 16, hipMemcpyDeviceToHost)); q += N * P * 16;
     }
-    HIPCHK(hipMemcpy(q, h->d_trk, N * CN_TF_COUNT * CN_MAX_TRACKS * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(q, h->d_trk, N * CN_TF_COUNT * h->trk_cap * 8, hipMemcpyDeviceToHost));
     return CN_OK;
 }
 
@@ -351,6 +352,6 @@ extern "C" int cn_restore(cn_handle h, const void* buf, size_t size)
         HIPCHK(hipMemcpy(h->d_ped_p, q, N * P * 16, hipMemcpyHostToDevice)); q += N * P * 16;
         HIPCHK(hipMemcpy(h->d_ped_v, q, N * P * 16, hipMemcpyHostToDevice)); q += N * P * 16;
     }
-    HIPCHK(hipMemcpy(h->d_trk, q, N * CN_TF_COUNT * CN_MAX_TRACKS * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_trk, q, N * CN_TF_COUNT * h->trk_cap * 8, hipMemcpyHostToDevice));
     return CN_OK;
 }

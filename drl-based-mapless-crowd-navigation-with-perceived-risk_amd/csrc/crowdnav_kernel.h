@@ -11,7 +11,7 @@ struct CnKParams {
     // sizes
     int32_t N, P, R, K;
     int32_t max_steps, ped_mode, dt_ms, scan_latency_ms, settle_ms, ped_cycle_ms, ped_stagger_ms;
-    int32_t mode, auto_reset, max_conf;
+    int32_t mode, auto_reset, max_conf, trk_cap;
     int32_t ablate;          // PROFILING ONLY (cn_debug_set_ablate): skips stages, results are then invalid
     int64_t env_index_base;
     uint64_t seed;
@@ -33,7 +33,7 @@ struct CnKParams {
     double* ped_v;          // [N, P, 2]
     const double* ped_init; // [N, P, 2]
     const double* ped_preset; // [N, P, 2]
-    double* trk;            // [N, CN_MAX_TRACKS, CN_TF_COUNT]: one contiguous 96-byte record per track slot
+    double* trk;            // [N, trk_cap, CN_TF_COUNT]: one contiguous 96-byte record per track slot
     // caller-owned I/O (device)
     const float* action;
     const int32_t* step_counter;
@@ -52,7 +52,7 @@ struct CnKParams {
 #ifdef __cplusplus
 extern "C" {
 #endif
-size_t cn_lds_bytes(int R, int P, int K, int max_conf);
+size_t cn_lds_bytes(int R, int P, int K, int max_conf, int trk_cap);
 #ifdef __cplusplus
 }
 #endif

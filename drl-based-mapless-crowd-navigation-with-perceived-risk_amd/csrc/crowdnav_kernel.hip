@@ -56,7 +56,8 @@ struct Lds {
     int* nearidx;     // [P] pedestrians within lidar reach
     double* ped;      // [2P] positions
     double* pedv;     // [2P] velocities
-    double* trk;      // [CN_TF_COUNT][CN_MAX_TRACKS]
+    double* trk;      // [CN_TF_COUNT][tcap]
+    int tcap;         // tracker slots (32 or 64)
     double* cfx; double* cfy; double* cfd; int* cft; int* checked;   // confirmed objects
     double* cpv;      // [CN_MAX_TRACKS] collision probability per track
     double* stage;    // [64] staging buffer of the bbox-size sum (reset only)
@@ -636,10 +637,10 @@ __device__ __forceinline__ void observe(const CnKParams& p, const Poly& pg, EnvR
     double* T = L.trk;
     if (lane < e.ntracks) {
 #pragma unroll
-        for (int f = 0; f < CN_TF_COUNT; ++f) T[f * CN_MAX_TRACKS + lane] = L.gtrk[lane * CN_TF_COUNT + f];  // HBM: one 96-byte record per track
+        for (int f = 0; f < CN_TF_COUNT; ++f) T[f * L.tcap + lane] = L.gtrk[lane * CN_TF_COUNT + f];  // HBM: one 96-byte record per track
     }
     CN_SYNC();
-#define TRK(f, i) T[(f) * CN_MAX_TRACKS + (i)]
+#define TRK(f, i) T[(f) * L.tcap + (i)]
     bool add_unchecked = false;
     if (CN_ABLATE(16)) { e.ntracks = 0; nconf = 0; }
     if (e.ntracks == 0) {
@@ -713,7 +714,7 @@ __device__ __forceinline__ void observe(const CnKParams& p, const Poly& pg, EnvR
             unsigned long long m = __ballot(want);
             int slot = e.ntracks + __popcll(m & ((1ull << lane) - 1ull));
             if (want) {
-                if (slot < CN_MAX_TRACKS) {
+                if (slot < L.tcap) {
                     double cxj = L.cfx[j], cyj = L.cfy[j];
                     TRK(CN_TF_PX, slot) = cxj; TRK(CN_TF_PY, slot) = cyj; TRK(CN_TF_DIST, slot) = L.cfd[j];
                     TRK(CN_TF_D0X, slot) = cxj; TRK(CN_TF_D0Y, slot) = cyj; TRK(CN_TF_D1X, slot) = 0.0; TRK(CN_TF_D1Y, slot) = 0.0;
@@ -722,7 +723,7 @@ __device__ __forceinline__ void observe(const CnKParams& p, const Poly& pg, EnvR
                 }
             }
             int total = e.ntracks + __popcll(m);
-            if (total > CN_MAX_TRACKS) { e.status |= CN_ST_TRACK_OVERFLOW; total = CN_MAX_TRACKS; }
+            if (total > L.tcap) { e.status |= CN_ST_TRACK_OVERFLOW; total = L.tcap; }
             e.ntracks = total;
         }
     }
@@ -873,7 +874,7 @@ __device__ __forceinline__ void observe(const CnKParams& p, const Poly& pg, EnvR
     // tracker table back to HBM (its LDS space is reused by the next observation's end points)
     if (lane < e.ntracks) {
 #pragma unroll
-        for (int f = 0; f < CN_TF_COUNT; ++f) L.gtrk[lane * CN_TF_COUNT + f] = L.trk[f * CN_MAX_TRACKS + lane];
+        for (int f = 0; f < CN_TF_COUNT; ++f) L.gtrk[lane * CN_TF_COUNT + f] = L.trk[f * L.tcap + lane];
     }
     CN_SYNC();
     *done_out = e.done;
@@ -930,7 +931,8 @@ __device__ __forceinline__ void env_kernel_body(const CnKParams& p)
         // LDS map.  Region A: end points (integer thousandths) | tracker table.
         // Region B: gradients + alias sources | bbox staging | confirmed objects, CP, observation tail.
         const size_t szA_pts = (size_t)(10 * n + 7) & ~(size_t)7;
-        const size_t szA_trk = 8 * (size_t)(CN_TF_COUNT * CN_MAX_TRACKS);
+        const size_t szA_trk = 8 * (size_t)(CN_TF_COUNT * p.trk_cap);
+        L.tcap = p.trk_cap;
         const size_t szA = szA_pts > szA_trk ? szA_pts : szA_trk;
         const size_t mc = (size_t)p.max_conf;
         const size_t szB_g = (size_t)(6 * n + 7) & ~(size_t)7;
@@ -956,7 +958,7 @@ __device__ __forceinline__ void env_kernel_body(const CnKParams& p)
         L.ped = (double*)Cw; Cw += 8 * (size_t)(2 * P + 2);
         L.pedv = (double*)Cw; Cw += 8 * (size_t)(2 * P + 2);
         L.nearidx = (int*)Cw;
-        L.gtrk = p.trk + (size_t)env * CN_TF_COUNT * CN_MAX_TRACKS;
+        L.gtrk = p.trk + (size_t)env * CN_TF_COUNT * p.trk_cap;
     }
 
     CN_T(0);

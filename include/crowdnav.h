@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 #define CN_ABI_VERSION 1
-#define CN_MAX_TRACKS 32      /* per-env capacity of the obstacle tracker (ENV:656-743) */
+#define CN_MAX_TRACKS 64      /* largest per-env capacity of the obstacle tracker (ENV:656-743): one lane per track */
 #define CN_MAX_K 16
 
 enum {
@@ -56,7 +56,7 @@ typedef struct cn_config {
     int32_t settle_ms;       /* trainer's time.sleep(0.1) after reset (TRAIN:114) -> 100 */
     int32_t ped_cycle_ms;    /* crowd node cycle: 0.1 s x number of obstacles (CROWD:128-144) */
     int32_t ped_stagger_ms;  /* 0.1 s between consecutive obstacles' updates (CROWD:144) -> 100 */
-    int32_t reserved0;
+    int32_t track_capacity;  /* tracker slots per env: 0 = auto (32 for <= 40 pedestrians, else 64), or 32 / 64 */
     int64_t env_index_base;  /* global index of env 0: RNG streams are keyed by global index */
     uint64_t seed;
     double room_half;        /* WORLD:926-1108 -> 1.40 */
@@ -143,7 +143,7 @@ int cn_get_returns(cn_handle h, float* last_return, float* running_return, void*
 
 /* Parity/debug view of one env (synchronises).  host buffers, any may be NULL:
  *   scalars[24] (layout: CN_SD_* below), robot_ped (5 + 4P doubles: x,y,yaw,v,w, ped xy, ped vxy),
- *   tracks [CN_MAX_TRACKS][12] one record per slot (CN_TF_*), ints[16] (CN_SI_*) */
+ *   tracks [CN_MAX_TRACKS][12] one record per slot (CN_TF_*; the first track_capacity slots are used), ints[16] */
 int cn_debug_env(cn_handle h, int env, double* scalars, double* robot_ped, double* tracks, int32_t* ints);
 
 /* Whole-state snapshot for deterministic replay. */

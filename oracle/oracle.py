@@ -60,6 +60,8 @@ DEFAULTS = dict(
 
 def make_config(**kw):
     d = dict(DEFAULTS)
+    kw = dict(kw)
+    kw.pop("track_capacity", None)   # product-only field (the oracle always has 64 slots)
     for k, v in kw.items():
         if k not in d:
             raise KeyError(k)

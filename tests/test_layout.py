@@ -31,7 +31,7 @@ def test_config_struct_matches_header_and_oracle():
     from crowdnav.config import CnConfig, Config
     from oracle import oracle
     assert C.sizeof(CnConfig) == C.sizeof(oracle.CnoConfig) == 12 * 4 + 8 + 8 + 19 * 8
-    assert [f[0] for f in CnConfig._fields_] == [f[0] for f in oracle.CnoConfig._fields_]
+    assert [f[0].replace("track_capacity", "reserved0") for f in CnConfig._fields_] == [f[0] for f in oracle.CnoConfig._fields_]
     d = Config().as_dict()
     for k, v in oracle.DEFAULTS.items():
         if k in ("reserved0", "ped_cycle_ms"):
@@ -73,6 +73,6 @@ def test_lds_budget_of_benchmark_configs():
     import crowdnav
     L = crowdnav.lib()
     L.cn_lds_bytes.restype = C.c_size_t
-    L.cn_lds_bytes.argtypes = [C.c_int] * 4
-    assert L.cn_lds_bytes(360, 20, 8, 359 // 4 + 2) <= 64 * 1024
-    assert L.cn_lds_bytes(720, 100, 8, 719 // 4 + 2) <= 160 * 1024
+    L.cn_lds_bytes.argtypes = [C.c_int] * 5
+    assert L.cn_lds_bytes(360, 20, 8, 359 // 4 + 2, 32) <= 10 * 1024      # 16 wavefronts per CU
+    assert L.cn_lds_bytes(720, 100, 8, 719 // 4 + 2, 64) <= 160 * 1024
