@@ -52,13 +52,14 @@ class EpisodeStats:
         return path
 
 
-def rollout(env, agent, n_steps, learn=False, add_noise=True, stats=None):
+def rollout(env, agent, n_steps, learn=False, add_noise=True, stats=None, fused_tail=True):
     """Actor-in-the-loop rollout (BASELINE config 3).  Returns total env-steps taken.
-    `env` is a crowdnav.env.VecEnv; `agent` a crowdnav.td3.Agent on the same device."""
+    `env` is a crowdnav.env.VecEnv; `agent` a crowdnav.td3.Agent on the same device.  fused_tail: the actor's
+    heads + exploration noise + clip run as one libcrowdnav kernel (cn_policy_tail)."""
     obs = env.obs if getattr(env, "_started", False) else env.reset()
     env._started = True
     for t in range(n_steps):
-        act = agent.act(obs, add_noise=add_noise)
+        act = agent.act_fused(obs, add_noise=add_noise) if fused_tail else agent.act(obs, add_noise=add_noise)
         if learn or stats is not None:
             prev = obs.clone()
             pre_counters = env.counters().clone() if stats is not None else None
@@ -130,8 +131,12 @@ class GraphedRollout:
             env.step(self.act, auto_reset=auto_reset)
 
     def _policy(self, add_noise):
+        # three library GEMMs + the fused output stage (cn_policy_tail).  The noise counter is frozen into the
+        # captured launch, so a replayed graph would repeat its noise: the counter is folded with the per-env
+        # step count that the env kernel keeps in the observation-independent state... simpler and graph-safe:
+        # draw the Gaussian with torch's default generator (philox offsets advance under replay).
         a = self.agent.actor(self.obs)
-        if add_noise:                         # default generator: graph-safe philox offsets
+        if add_noise:
             a = a + torch.randn_like(a) * self.agent.explore_sigma
         return torch.max(torch.min(a, self.agent._hi), self.agent._lo)
 

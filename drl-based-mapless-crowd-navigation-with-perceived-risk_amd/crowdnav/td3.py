@@ -18,10 +18,13 @@ class Actor(nn.Module):
         self.linear3 = nn.Linear(hidden_size, num_actions)
         self.max_lin_vel, self.max_ang_vel = max_lin_vel, max_ang_vel
 
-    def forward(self, state):
+    def logits(self, state):
         x = F.relu(self.linear1(state))
         x = F.relu(self.linear2(x))
-        a = self.linear3(x)
+        return self.linear3(x)
+
+    def forward(self, state):
+        a = self.logits(state)
         return torch.stack([torch.sigmoid(a[:, 0]) * self.max_lin_vel, torch.tanh(a[:, 1]) * self.max_ang_vel], 1)
 
 
@@ -101,6 +104,23 @@ class Agent:
         if add_noise:
             a = a + torch.randn(a.shape, generator=self.gen, device=self.device) * self.explore_sigma
         return torch.max(torch.min(a, self._hi), self._lo).contiguous()
+
+    @torch.no_grad()
+    def act_fused(self, obs, out=None, add_noise=True):
+        """Agent.act with the output stage (heads + exploration noise + clip) as ONE kernel of libcrowdnav
+        (cn_policy_tail) instead of ~10 elementwise launches.  Same distribution as act(); the noise comes from
+        a counter-based generator keyed by (seed, call counter, row)."""
+        import ctypes as C
+        from . import _abi
+        lg = self.actor.logits(obs).contiguous()
+        if out is None:
+            out = torch.empty_like(lg)
+        self._fused_calls = getattr(self, "_fused_calls", 0) + 1
+        st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        _abi.check(_abi.lib().cn_policy_tail(C.c_void_p(lg.data_ptr()), C.c_void_p(out.data_ptr()), lg.shape[0],
+                                             self.max_v, self.max_w, self.explore_sigma if add_noise else 0.0,
+                                             12345, self._fused_calls, st))
+        return out
 
     def learn(self, step):
         """One TD3 update (TD3:225-285)."""

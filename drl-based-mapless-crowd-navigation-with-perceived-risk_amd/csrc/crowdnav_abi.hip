@@ -269,6 +269,20 @@ extern "C" int cn_observe_external(cn_handle h, const cn_external_io* io, void* 
     return launch(h, kp, (hipStream_t)stream);
 }
 
+extern "C" __global__ void cn_policy_tail_kernel(const float* logits, float* action, int n, float max_v, float max_w,
+                                                 float sigma, uint64_t seed, uint64_t counter);
+
+extern "C" int cn_policy_tail(const float* logits, float* action, int n, float max_v, float max_w, float sigma,
+                              uint64_t seed, uint64_t counter, void* stream)
+{
+    if (!logits || !action || n < 0) return fail(CN_ERR_ARG, "cn_policy_tail: bad argument");
+    if (n == 0) return CN_OK;
+    hipLaunchKernelGGL(cn_policy_tail_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, logits, action, n,
+                       max_v, max_w, sigma, seed, counter);
+    HIPCHK(hipGetLastError());
+    return CN_OK;
+}
+
 extern "C" int cn_get_counters(cn_handle h, int32_t* out, void* stream)
 {
     if (!h || !out) return fail(CN_ERR_ARG, "cn_get_counters: null argument");

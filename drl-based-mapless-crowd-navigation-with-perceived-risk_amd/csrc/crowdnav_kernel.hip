@@ -1202,6 +1202,32 @@ extern "C" __global__ void cn_gather_kernel(CnKParams p, float* last_ret, float*
     }
 }
 
+// ---- policy tail of the TD3 actor (the caller of the hot path) ---------------------------
+// One launch instead of ~10 elementwise ones: action heads sigmoid(l0)*max_v / tanh(l1)*max_w (TD3:103-104),
+// Gaussian exploration noise N(0, sigma) (TD3:67-78, 209-211) from a counter-based RNG, clip to
+// v in [0, max_v], w in [-max_w, max_w] (TD3:214-215).
+extern "C" __global__ void cn_policy_tail_kernel(const float* __restrict__ logits, float* __restrict__ action, int n,
+                                                 float max_v, float max_w, float sigma, uint64_t seed, uint64_t counter)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float l0 = logits[2 * i], l1 = logits[2 * i + 1];
+    float v = max_v / (1.0f + __expf(-l0));
+    float w = max_w * tanhf(l1);
+    if (sigma > 0.0f) {
+        uint64_t h = cn_mix64(seed ^ cn_mix64(counter));
+        h = cn_mix64(h ^ (uint64_t)(uint32_t)i);
+        float u1 = ((float)(uint32_t)(h >> 40) + 1.0f) * (1.0f / 16777217.0f);   // (0, 1]
+        float u2 = (float)(uint32_t)((h >> 8) & 0xffffffu) * (1.0f / 16777216.0f);
+        float r = sqrtf(-2.0f * __logf(u1)), s_, c_;
+        __sincosf(6.28318530718f * u2, &s_, &c_);
+        v += sigma * r * c_;
+        w += sigma * r * s_;
+    }
+    action[2 * i] = fminf(fmaxf(v, 0.0f), max_v);
+    action[2 * i + 1] = fminf(fmaxf(w, -max_w), max_w);
+}
+
 // ---- PMC calibration (tools/calib_pmc.py): known-byte streaming reads / writes at the access widths the
 // env kernel uses, so FETCH_SIZE / WRITE_SIZE can be turned into bytes (MI355X_MICROARCH.md, HBM section).
 template <typename T>

@@ -134,6 +134,12 @@ int cn_reset(cn_handle h, const uint8_t* mask, float* obs, double* obs_f64, void
 int cn_step(cn_handle h, const cn_step_io* io, void* stream);
 int cn_observe_external(cn_handle h, const cn_external_io* io, void* stream);
 
+/* The actor's output stage as one launch (no handle needed): action = clip(heads(logits) + N(0, sigma)).
+ * Replaces td3.py:103-104 (sigmoid*max_v, tanh*max_w), td3.py:67-78,209-211 (Gaussian exploration) and
+ * td3.py:214-215 (clip).  logits, action: dev [n,2] float32; noise is keyed by (seed, counter, row). */
+int cn_policy_tail(const float* logits, float* action, int n, float max_v, float max_w, float sigma,
+                   uint64_t seed, uint64_t counter, void* stream);
+
 /* get_episode_status / get_*_safety_violation_status inputs (ENV:1265-1283).
  * out: dev [N,10] = ego_viol, social_viol, obstacle_present_steps, ep_steps, success, failure, status, n_tracks,
  *                  episodes finished since cn_create, reset pending (auto_reset == 2) */

@@ -328,3 +328,26 @@ def test_empty_room_and_masked_reset(oracle_mod):
             assert np.array_equal(env.obs_f64.cpu().numpy()[sel], o2[sel])
     c = env.counters().cpu().numpy()
     assert (c[:, 2] == 0).all()          # no obstacle was ever seen: the safety scores are undefined
+
+
+def test_fused_policy_tail_matches_the_torch_heads():
+    """cn_policy_tail = td3.py:103-104 heads + clip (noise off: exact up to float32 rounding; noise on: N(0, sigma)
+    statistics and the clip bounds)."""
+    import torch
+    from crowdnav.td3 import Agent
+    agent = Agent(obs_dim=398, device="cuda", seed=3, memory_size=16)
+    obs = torch.randn((4096, 398), device="cuda")
+    ref = agent.act(obs, add_noise=False)
+    got = agent.act_fused(obs, add_noise=False)
+    assert torch.allclose(got, ref, atol=2e-6, rtol=1e-5)
+    noisy = agent.act_fused(obs, add_noise=True)
+    assert float(noisy[:, 0].min()) >= 0.0 and float(noisy[:, 0].max()) <= 0.22 and float(noisy[:, 1].abs().max()) <= 2.0
+    # with sigma = 1 most of the mass is clipped: check the unclipped interior of w instead
+    raw = torch.empty((200000, 2), device="cuda"); z = torch.zeros((200000, 2), device="cuda")
+    import ctypes as C
+    from crowdnav import _abi
+    _abi.check(_abi.lib().cn_policy_tail(C.c_void_p(z.data_ptr()), C.c_void_p(raw.data_ptr()), 200000, 1e9, 1e9, 1.0, 7, 1,
+                                         C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    w = raw[:, 1]                     # tanh(0) * max_w + N(0, 1), never clipped with max_w = 1e9
+    assert abs(float(w.mean())) < 0.02 and abs(float(w.std()) - 1.0) < 0.02

@@ -8,17 +8,18 @@ from crowdnav import Config
 from crowdnav.env import VecEnv
 from crowdnav.td3 import Agent
 
-def run(name, cfg, actor=False, steps=400, mode="next"):
+def run(name, cfg, actor=False, steps=400, mode="next", fused=False):
     env = VecEnv(cfg); env.reset(); N = env.N
     g = torch.Generator(device="cuda").manual_seed(1)
     acts = torch.stack([torch.rand((16, N), generator=g, device="cuda") * 0.22, torch.rand((16, N), generator=g, device="cuda") * 4 - 2], 2).contiguous()
     agent = Agent(obs_dim=env.D, device="cuda", seed=0, memory_size=16) if actor else None
     obs = env.obs
+    pol = (lambda o: agent.act_fused(o)) if fused else (lambda o: agent.act(o))
     for i in range(40):
-        obs, _, _ = env.step(agent.act(obs) if actor else acts[i % 16], auto_reset=mode)
+        obs, _, _ = env.step(pol(obs) if actor else acts[i % 16], auto_reset=mode)
     ep0 = env.counters()[:, 8].sum().item(); torch.cuda.synchronize(); t0 = time.perf_counter()
     for i in range(steps):
-        obs, _, _ = env.step(agent.act(obs) if actor else acts[i % 16], auto_reset=mode)
+        obs, _, _ = env.step(pol(obs) if actor else acts[i % 16], auto_reset=mode)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     resets = env.counters()[:, 8].sum().item() - ep0 if mode == "next" else 0
     print("%-52s %8.4f ms/step  %8.2f M env-steps/s" % (name, dt / steps * 1e3, (N * steps - resets) / dt / 1e6))
@@ -26,6 +27,7 @@ def run(name, cfg, actor=False, steps=400, mode="next"):
 
 run("config 2: 4096 x 20 peds x 360 rays (open loop)", Config(n_envs=4096, ped_cycle_ms=1400))
 run("config 3: 4096 x 20 peds, TD3 actor in the loop", Config(n_envs=4096, ped_cycle_ms=1400), actor=True)
+run("config 3 with the fused policy tail (cn_policy_tail)", Config(n_envs=4096, ped_cycle_ms=1400), actor=True, fused=True)
 
 def run_graphed(name, cfg, steps=400):
     from crowdnav.rollout import GraphedRollout
