@@ -351,3 +351,55 @@ def test_fused_policy_tail_matches_the_torch_heads():
     torch.cuda.synchronize()
     w = raw[:, 1]                     # tanh(0) * max_w + N(0, 1), never clipped with max_w = 1e9
     assert abs(float(w.mean())) < 0.02 and abs(float(w.std()) - 1.0) < 0.02
+
+
+def test_randomised_configurations(oracle_mod):
+    """A dozen random worlds (pedestrian count, rays, K, room size, goal, spawn, clock constants, crowd speed):
+    the HIP path and the oracle agree on every one (guards the parts of the kernel that depend on R, P, K)."""
+    import torch
+    rng = np.random.default_rng(2025)
+    for trial in range(12):
+        R = int(rng.choice([90, 181, 200, 360, 361, 500, 720]))
+        kw = dict(n_envs=4, n_peds=int(rng.integers(0, 90)), n_rays=R, k_obstacles=int(rng.integers(1, 17)),
+                  max_steps=int(rng.integers(8, 30)), room_half=float(rng.uniform(1.0, 3.0)),
+                  goal_x=float(rng.uniform(-0.9, 0.9)), goal_y=float(rng.uniform(-0.9, 0.9)),
+                  spawn_x=float(rng.uniform(-0.6, 0.6)), spawn_y=float(rng.uniform(-0.6, 0.6)),
+                  spawn_yaw=float(rng.uniform(-3.1, 3.1)), dt_ms=int(rng.choice([100, 150, 200])),
+                  scan_latency_ms=int(rng.choice([5, 10, 20])), settle_ms=int(rng.choice([0, 50, 100])),
+                  ped_cycle_ms=int(rng.choice([300, 700, 1400, 2000])), ped_vmax=float(rng.uniform(0.05, 0.5)),
+                  min_scan_range=float(rng.choice([0.0, 0.12])), seed=int(rng.integers(1, 1 << 30)),
+                  env_index_base=int(rng.integers(0, 1 << 20)))
+        torch_, env, orc = _pair(oracle_mod, **kw)
+        env.reset(); torch.cuda.synchronize()
+        assert np.array_equal(env.obs_f64.cpu().numpy(), orc.reset()), kw
+        for t in range(40):
+            act = np.stack([rng.uniform(0, 0.22, 4), rng.uniform(-2, 2, 4)], 1).astype(np.float32)
+            mode = ("next", True)[trial % 2]
+            env.step(torch.from_numpy(act).cuda(), auto_reset=mode); torch.cuda.synchronize()
+            oc, rc, dc, ic = orc.step(act.astype(np.float64), auto_reset=mode)
+            assert np.array_equal(env.done.cpu().numpy(), dc), (kw, t)
+            assert np.array_equal(env.topk_idx.cpu().numpy(), ic), (kw, t)
+            assert np.abs(env.obs_f64.cpu().numpy() - oc).max() <= TOL, (kw, t)
+            assert np.array_equal(env.reward.cpu().numpy(), rc.astype(np.float32)), (kw, t)
+        env.close()
+
+
+def test_graphed_rollout_replays():
+    """The actor + env step captured in one HIP graph (rollout.GraphedRollout) advances the envs on replay."""
+    import torch
+    from crowdnav import Config
+    from crowdnav.env import VecEnv
+    from crowdnav.rollout import GraphedRollout
+    from crowdnav.td3 import Agent
+    env = VecEnv(Config(n_envs=64, seed=8, max_steps=30))
+    agent = Agent(obs_dim=env.D, device="cuda", seed=2, memory_size=16)
+    with torch.no_grad():
+        g = GraphedRollout(env, agent)
+        ep0 = int(env.counters()[:, 8].sum().item())
+        seen = set()
+        for _ in range(80):
+            obs, reward, done = g.step()
+            seen.add(float(obs[0, 361].item()))
+        torch.cuda.synchronize()
+    assert int(env.counters()[:, 8].sum().item()) - ep0 >= 64      # every env finished at least once (max_steps 30)
+    assert len(seen) > 5                                            # the robot moved: observations change across replays
