@@ -780,12 +780,15 @@ __device__ __forceinline__ void observe(const CnKParams& p, const Poly& pg, EnvR
                 double y2 = ((double)x2 * gradient) + bb0;
                 // The polygon lies inside its circumscribed circle: a segment whose closest point to the
                 // centre is farther than the radius (with slack) cannot touch any edge -> same "empty" result.
-                {
-                    double ex = (double)x2 - a0x, ey = y2 - a0y, fx = tx - a0x, fy = ty_ - a0y;
-                    double ee = ex * ex + ey * ey;
-                    double tt = (ee > 0.0) ? fmin(fmax((fx * ex + fy * ey) / ee, 0.0), 1.0) : 0.0;
-                    double gx = fx - tt * ex, gy = fy - tt * ey;
-                    if (gx * gx + gy * gy > 0.178 * 0.178 * 1.000001) continue;
+                {   // squared distance from the centre to the segment, compared with r^2 without a divide
+                    const double ex = (double)x2 - a0x, ey = y2 - a0y, fx = tx - a0x, fy = ty_ - a0y;
+                    const double ee = ex * ex + ey * ey, ff = fx * fx + fy * fy, num = fx * ex + fy * ey;
+                    const double rr2 = 0.178 * 0.178 * 1.000001;
+                    bool far_;
+                    if (num <= 0.0) far_ = ff > rr2;                                   // closest point is the agent
+                    else if (num >= ee) far_ = (fx - ex) * (fx - ex) + (fy - ey) * (fy - ey) > rr2;  // ... the far end
+                    else far_ = (ff - rr2) * ee > num * num * 1.000001;                // ... the foot of the perpendicular
+                    if (far_) continue;
                 }
                 double hx = 0.0, hy = 0.0;
                 unsigned long long m = ring_segment(pg, lane, tx, ty_, 0.178, a0x, a0y, (double)x2, y2, &hx, &hy);
