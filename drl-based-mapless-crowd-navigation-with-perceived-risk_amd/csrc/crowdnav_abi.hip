@@ -228,8 +228,16 @@ extern "C" int cn_set_ped_preset_vel(cn_handle h, const double* vxy)
     return CN_OK;
 }
 
+// RAII: run on the handle's device even if the calling thread's current device is another one
+struct DeviceScope {
+    int prev = -1, want;
+    explicit DeviceScope(int dev) : want(dev) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; if (prev != want) (void)hipSetDevice(want); }
+    ~DeviceScope() { if (prev >= 0 && prev != want) (void)hipSetDevice(prev); }
+};
+
 static int launch(cn_handle h, const CnKParams& kp, hipStream_t st)
 {
+    DeviceScope scope(h->device);
     if (kp.mode == CN_MODE_EXT_STEP || kp.mode == CN_MODE_EXT_RESET)
         hipLaunchKernelGGL(cn_env_kernel_ext, dim3(kp.N), dim3(64), h->lds, st, kp);
     else if (kp.mode == CN_MODE_STEP && kp.auto_reset == 1)   // step + reset of finished envs in the same launch
@@ -287,6 +295,7 @@ extern "C" int cn_get_counters(cn_handle h, int32_t* out, void* stream)
 {
     if (!h || !out) return fail(CN_ERR_ARG, "cn_get_counters: null argument");
     int N = h->cfg.n_envs;
+    DeviceScope scope(h->device);
     hipLaunchKernelGGL(cn_gather_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->kp,
                        (float*)nullptr, (float*)nullptr, out);
     HIPCHK(hipGetLastError());
@@ -297,6 +306,7 @@ extern "C" int cn_get_returns(cn_handle h, float* last_return, float* running_re
 {
     if (!h) return fail(CN_ERR_ARG, "cn_get_returns: null handle");
     int N = h->cfg.n_envs;
+    DeviceScope scope(h->device);
     hipLaunchKernelGGL(cn_gather_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->kp, last_return,
                        running_return, (int32_t*)nullptr);
     HIPCHK(hipGetLastError());
