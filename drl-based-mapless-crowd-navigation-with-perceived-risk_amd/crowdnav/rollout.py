@@ -52,14 +52,21 @@ class EpisodeStats:
         return path
 
 
-def rollout(env, agent, n_steps, learn=False, add_noise=True, stats=None, fused_tail=True):
+def rollout(env, agent, n_steps, learn=False, add_noise=True, stats=None, policy=None):
     """Actor-in-the-loop rollout (BASELINE config 3).  Returns total env-steps taken.
-    `env` is a crowdnav.env.VecEnv; `agent` a crowdnav.td3.Agent on the same device.  fused_tail: the actor's
-    heads + exploration noise + clip run as one libcrowdnav kernel (cn_policy_tail)."""
+    `env` is a crowdnav.env.VecEnv; `agent` a crowdnav.td3.Agent on the same device.
+    policy: "mfma" = the whole actor as one libcrowdnav kernel (cn_actor_forward; default when the weights are
+    static), "tail" = PyTorch GEMMs + fused output stage (cn_policy_tail; default while learning, since the
+    weights change every update), "torch" = plain PyTorch."""
+    if policy is None:
+        policy = "tail" if learn else "mfma"
+    act_fn = {"mfma": agent.act_mfma, "tail": agent.act_fused, "torch": agent.act}[policy]
+    if policy == "mfma":
+        agent.sync_fused_weights()
     obs = env.obs if getattr(env, "_started", False) else env.reset()
     env._started = True
     for t in range(n_steps):
-        act = agent.act_fused(obs, add_noise=add_noise) if fused_tail else agent.act(obs, add_noise=add_noise)
+        act = act_fn(obs, add_noise=add_noise)
         if learn or stats is not None:
             prev = obs.clone()
             pre_counters = env.counters().clone() if stats is not None else None

@@ -122,6 +122,42 @@ class Agent:
                                              12345, self._fused_calls, st))
         return out
 
+    def sync_fused_weights(self):
+        """(Re)build the K-major float32 copies cn_actor_forward reads; call after the actor's weights change."""
+        import ctypes as C
+        from . import _abi
+        a = self.actor
+        D = a.linear1.in_features
+        Dp = (D + 3) // 4 * 4
+        with torch.no_grad():
+            w1t = torch.zeros((Dp, 256), dtype=torch.float32, device=self.device)
+            w1t[:D] = a.linear1.weight.detach().t()
+            self._fw = dict(w1t=w1t.contiguous(), b1=a.linear1.bias.detach().float().contiguous(),
+                            w2t=a.linear2.weight.detach().t().contiguous().float(), b2=a.linear2.bias.detach().float().contiguous(),
+                            w3=a.linear3.weight.detach().float().contiguous(), b3=a.linear3.bias.detach().float().contiguous())
+        f = self._fw
+        self._fw_struct = _abi.CnActorWeights(w1t=f["w1t"].data_ptr(), b1=f["b1"].data_ptr(), w2t=f["w2t"].data_ptr(),
+                                              b2=f["b2"].data_ptr(), w3=f["w3"].data_ptr(), b3=f["b3"].data_ptr(),
+                                              obs_dim=D, obs_dim_padded=Dp, hidden=256, reserved=0)
+
+    @torch.no_grad()
+    def act_mfma(self, obs, out=None, add_noise=True):
+        """Agent.act as ONE kernel (cn_actor_forward): the three Linear layers on the f32 matrix cores with the
+        activations in LDS, plus heads, exploration noise and clip.  float32 throughout, like the reference."""
+        import ctypes as C
+        from . import _abi
+        if not hasattr(self, "_fw_struct"):
+            self.sync_fused_weights()
+        obs = obs.contiguous()
+        if out is None:
+            out = torch.empty((obs.shape[0], 2), dtype=torch.float32, device=self.device)
+        self._fused_calls = getattr(self, "_fused_calls", 0) + 1
+        st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        _abi.check(_abi.lib().cn_actor_forward(C.byref(self._fw_struct), C.c_void_p(obs.data_ptr()), C.c_void_p(out.data_ptr()),
+                                               obs.shape[0], self.max_v, self.max_w,
+                                               self.explore_sigma if add_noise else 0.0, 12345, self._fused_calls, st))
+        return out
+
     def learn(self, step):
         """One TD3 update (TD3:225-285)."""
         if len(self.memory) <= self.batch_size:

@@ -291,6 +291,32 @@ extern "C" int cn_policy_tail(const float* logits, float* action, int n, float m
     return CN_OK;
 }
 
+extern "C" __global__ void cn_actor_kernel(const float* obs, int n, int D, int Dp, const float* W1T, const float* b1,
+                                           const float* W2T, const float* b2, const float* W3, const float* b3, float* action,
+                                           float max_v, float max_w, float sigma, uint64_t seed, uint64_t counter);
+
+extern "C" int cn_actor_forward(const cn_actor_weights* w, const float* obs, float* action, int n, float max_v, float max_w,
+                                float sigma, uint64_t seed, uint64_t counter, void* stream)
+{
+    if (!w || !obs || !action || n < 0 || !w->w1t || !w->b1 || !w->w2t || !w->b2 || !w->w3 || !w->b3)
+        return fail(CN_ERR_ARG, "cn_actor_forward: null argument");
+    if (w->hidden != 256 || w->obs_dim < 1 || w->obs_dim_padded < w->obs_dim || (w->obs_dim_padded & 3))
+        return fail(CN_ERR_CONFIG, "cn_actor_forward: hidden must be 256 and obs_dim_padded a multiple of 4");
+    if (n == 0) return CN_OK;
+    const int Dp = w->obs_dim_padded;
+    const size_t lds = sizeof(float) * (16 * (size_t)(Dp + 1) + 2 * 16 * 257);
+    if (lds > 160 * 1024) return fail(CN_ERR_CONFIG, "cn_actor_forward: observation too wide for one LDS tile");
+    static bool attr_set = false;
+    if (lds > 64 * 1024 && !attr_set) {
+        HIPCHK(hipFuncSetAttribute((const void*)cn_actor_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(cn_actor_kernel, dim3((n + 15) / 16), dim3(256), lds, (hipStream_t)stream, obs, n, w->obs_dim, Dp,
+                       w->w1t, w->b1, w->w2t, w->b2, w->w3, w->b3, action, max_v, max_w, sigma, seed, counter);
+    HIPCHK(hipGetLastError());
+    return CN_OK;
+}
+
 extern "C" int cn_get_counters(cn_handle h, int32_t* out, void* stream)
 {
     if (!h || !out) return fail(CN_ERR_ARG, "cn_get_counters: null argument");

@@ -1231,6 +1231,118 @@ extern "C" __global__ void cn_policy_tail_kernel(const float* __restrict__ logit
     action[2 * i + 1] = fminf(fmaxf(w, -max_w), max_w);
 }
 
+// ---- fused TD3 actor: 3 x Linear(256) + ReLU + output stage in ONE launch (the caller of the hot path, A33) -------
+// Actor.forward (TD3:96-106) + Agent.act's noise and clip (TD3:209-215) for a tile of 16 environments per workgroup,
+// on the f32-input matrix cores: v_mfma_f32_16x16x4_f32 (exact f32: a k-ordered fmaf chain, same precision as the
+// reference's fp32 PyTorch actor).  Lane l feeds A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15]; the four
+// column tiles of a wave interleave their columns (col = 64*wave + 4*j + t) so one 16-byte load of the K-major
+// weights feeds all four MFMAs.  Activations never leave LDS; weights stream from L2 (670 KB, shared by all tiles).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define ACT_H 256
+#define ACT_M 16
+
+template <bool RELU>
+__device__ __forceinline__ void actor_layer(const float* __restrict__ A, int lda, int Kp, const float* __restrict__ WT,
+                                            const float* __restrict__ bias, float* __restrict__ out, int ldo, int wave, int lane)
+{
+    const int ai = lane & 15, ak = lane >> 4;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+    const float* ap = A + ai * lda + ak;
+    const float* bp = WT + (size_t)ak * ACT_H + 64 * wave + 4 * ai;
+    // Software pipeline: the 16-byte weight loads of the NEXT block of 8 k-steps are in flight while the 32 MFMAs
+    // of the current block issue (one wave per SIMD here, so nothing else hides the L2 latency).
+    constexpr int U = 8;
+    float4 bcur[U], bnxt[U];
+    const int nblk = Kp / (4 * U), tail0 = nblk * 4 * U;
+    if (nblk > 0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) bcur[u] = *reinterpret_cast<const float4*>(bp + (size_t)(4 * u) * ACT_H);
+    }
+    for (int blk = 0; blk < nblk; ++blk) {
+        const int k0 = blk * 4 * U;
+        if (blk + 1 < nblk) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) bnxt[u] = *reinterpret_cast<const float4*>(bp + (size_t)(k0 + 4 * U + 4 * u) * ACT_H);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float a = ap[k0 + 4 * u];
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bcur[u].x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bcur[u].y, acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bcur[u].z, acc2, 0, 0, 0);
+            acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bcur[u].w, acc3, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) bcur[u] = bnxt[u];
+    }
+    for (int k0 = tail0; k0 < Kp; k0 += 4) {   // remainder (Kp is a multiple of 4, not necessarily of 32)
+        const float a = ap[k0];
+        const float4 b = *reinterpret_cast<const float4*>(bp + (size_t)k0 * ACT_H);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.y, acc1, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.z, acc2, 0, 0, 0);
+        acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.w, acc3, 0, 0, 0);
+    }
+    const int colb = 64 * wave + 4 * ai, rowb = ak * 4;   // C/D: col = lane & 15, row = (lane >> 4) * 4 + reg
+    const float4 bb = *reinterpret_cast<const float4*>(bias + colb);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float v0 = acc0[r] + bb.x, v1 = acc1[r] + bb.y, v2 = acc2[r] + bb.z, v3 = acc3[r] + bb.w;
+        if (RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+        float* o = out + (rowb + r) * ldo + colb;
+        o[0] = v0; o[1] = v1; o[2] = v2; o[3] = v3;
+    }
+}
+
+extern "C" __global__ void __launch_bounds__(256) cn_actor_kernel(const float* __restrict__ obs, int n, int D, int Dp,
+        const float* __restrict__ W1T, const float* __restrict__ b1, const float* __restrict__ W2T,
+        const float* __restrict__ b2, const float* __restrict__ W3, const float* __restrict__ b3,
+        float* __restrict__ action, float max_v, float max_w, float sigma, uint64_t seed, uint64_t counter)
+{
+    extern __shared__ __attribute__((aligned(16))) float act_sm[];
+    const int ldx = Dp + 1, ldh = ACT_H + 1;
+    float* X = act_sm;                 // [16][Dp + 1]
+    float* H1 = X + ACT_M * ldx;       // [16][257]
+    float* H2 = H1 + ACT_M * ldh;      // [16][257]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int row0 = blockIdx.x * ACT_M;
+    for (int r = wave; r < ACT_M; r += 4) {   // one row per wave at a time: coalesced, no integer divide
+        const bool live = (row0 + r < n);
+        const float* src = obs + (size_t)(row0 + r) * D;
+        for (int c = lane; c < Dp; c += 64) X[r * ldx + c] = (live && c < D) ? src[c] : 0.f;
+    }
+    __syncthreads();
+    actor_layer<true>(X, ldx, Dp, W1T, b1, H1, ldh, wave, lane);
+    __syncthreads();
+    actor_layer<true>(H1, ldh, ACT_H, W2T, b2, H2, ldh, wave, lane);
+    __syncthreads();
+    {   // linear3 (TD3:101) + heads, exploration noise, clip: thread = (env i, output o, eighth of K), 32-term partial dots
+        const int i = tid >> 4, o = (tid >> 3) & 1, part = tid & 7;
+        const float* h = H2 + i * ldh + part * 32;
+        const float* w = W3 + o * ACT_H + part * 32;
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) acc = fmaf(h[k], w[k], acc);
+        acc += __shfl_xor(acc, 1, 64);
+        acc += __shfl_xor(acc, 2, 64);
+        acc += __shfl_xor(acc, 4, 64);
+        const float logit = acc + b3[o];
+        const int e = row0 + i;
+        float val = (o == 0) ? max_v / (1.0f + __expf(-logit)) : max_w * tanhf(logit);
+        if (sigma > 0.0f) {   // same generator as cn_policy_tail_kernel: keyed by (seed, counter, env row)
+            uint64_t hh = cn_mix64(seed ^ cn_mix64(counter));
+            hh = cn_mix64(hh ^ (uint64_t)(uint32_t)e);
+            float u1 = ((float)(uint32_t)(hh >> 40) + 1.0f) * (1.0f / 16777217.0f);
+            float u2 = (float)(uint32_t)((hh >> 8) & 0xffffffu) * (1.0f / 16777216.0f);
+            float rr_ = sqrtf(-2.0f * __logf(u1)), s_, c_;
+            __sincosf(6.28318530718f * u2, &s_, &c_);
+            val += sigma * rr_ * ((o == 0) ? c_ : s_);
+        }
+        val = (o == 0) ? fminf(fmaxf(val, 0.0f), max_v) : fminf(fmaxf(val, -max_w), max_w);
+        if (part == 0 && e < n) action[2 * (size_t)e + o] = val;
+    }
+}
+
 // ---- PMC calibration (tools/calib_pmc.py): known-byte streaming reads / writes at the access widths the
 // env kernel uses, so FETCH_SIZE / WRITE_SIZE can be turned into bytes (MI355X_MICROARCH.md, HBM section).
 template <typename T>

@@ -140,6 +140,18 @@ int cn_observe_external(cn_handle h, const cn_external_io* io, void* stream);
 int cn_policy_tail(const float* logits, float* action, int n, float max_v, float max_w, float sigma,
                    uint64_t seed, uint64_t counter, void* stream);
 
+/* The whole TD3 actor as one launch: Actor.forward (td3.py:96-106: Linear(obs_dim,256)-ReLU-Linear(256,256)-ReLU-
+ * Linear(256,2), sigmoid*max_v / tanh*max_w heads) + Agent.act's exploration noise and clip (td3.py:209-215), in
+ * float32 on the f32 matrix cores.  Weights are caller-owned device arrays in K-major layout:
+ *   w1t [obs_dim_padded][256] = linear1.weight^T with zero rows up to a multiple of 4, w2t [256][256] = linear2.weight^T,
+ *   w3 [2][256] = linear3.weight, biases as in PyTorch.  obs: dev [n, obs_dim] float32; action: dev [n,2]. */
+typedef struct cn_actor_weights {
+    const float* w1t; const float* b1; const float* w2t; const float* b2; const float* w3; const float* b3;
+    int32_t obs_dim, obs_dim_padded, hidden, reserved;
+} cn_actor_weights;
+int cn_actor_forward(const cn_actor_weights* w, const float* obs, float* action, int n, float max_v, float max_w,
+                     float sigma, uint64_t seed, uint64_t counter, void* stream);
+
 /* get_episode_status / get_*_safety_violation_status inputs (ENV:1265-1283).
  * out: dev [N,10] = ego_viol, social_viol, obstacle_present_steps, ep_steps, success, failure, status, n_tracks,
  *                  episodes finished since cn_create, reset pending (auto_reset == 2) */

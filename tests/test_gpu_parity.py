@@ -403,3 +403,24 @@ def test_graphed_rollout_replays():
         torch.cuda.synchronize()
     assert int(env.counters()[:, 8].sum().item()) - ep0 >= 64      # every env finished at least once (max_steps 30)
     assert len(seen) > 5                                            # the robot moved: observations change across replays
+
+
+def test_mfma_actor_matches_the_torch_actor():
+    """cn_actor_forward (one kernel, f32 matrix cores) vs the PyTorch fp32 actor of td3.py:81-106: same actions
+    up to float32 summation order; ragged batch sizes; K = 4 layout (382 inputs, not a multiple of 4 -> padded)."""
+    import torch
+    from crowdnav.td3 import Agent
+    for obs_dim, n in ((398, 4096), (398, 37), (382, 1000), (370, 16)):
+        agent = Agent(obs_dim=obs_dim, device="cuda", seed=obs_dim, memory_size=16)
+        with torch.no_grad():   # asymmetric, non-trivial weights so a transposed tile would show
+            for p_ in agent.actor.parameters():
+                p_.mul_(3.0)
+        obs = torch.randn((n, obs_dim), device="cuda") * 0.7
+        ref = agent.act(obs, add_noise=False)
+        got = agent.act_mfma(obs, add_noise=False)
+        torch.cuda.synchronize()
+        assert got.shape == ref.shape
+        assert torch.allclose(got, ref, atol=3e-5, rtol=1e-4), float((got - ref).abs().max())
+        noisy = agent.act_mfma(obs, add_noise=True)
+        assert float(noisy[:, 0].min()) >= 0.0 and float(noisy[:, 0].max()) <= 0.22 and float(noisy[:, 1].abs().max()) <= 2.0
+        assert not torch.equal(noisy, got)

@@ -8,13 +8,13 @@ from crowdnav import Config
 from crowdnav.env import VecEnv
 from crowdnav.td3 import Agent
 
-def run(name, cfg, actor=False, steps=400, mode="next", fused=False):
+def run(name, cfg, actor=False, steps=400, mode="next", fused=False, mfma=False):
     env = VecEnv(cfg); env.reset(); N = env.N
     g = torch.Generator(device="cuda").manual_seed(1)
     acts = torch.stack([torch.rand((16, N), generator=g, device="cuda") * 0.22, torch.rand((16, N), generator=g, device="cuda") * 4 - 2], 2).contiguous()
     agent = Agent(obs_dim=env.D, device="cuda", seed=0, memory_size=16) if actor else None
     obs = env.obs
-    pol = (lambda o: agent.act_fused(o)) if fused else (lambda o: agent.act(o))
+    pol = (lambda o: agent.act_mfma(o)) if mfma else ((lambda o: agent.act_fused(o)) if fused else (lambda o: agent.act(o)))
     for i in range(40):
         obs, _, _ = env.step(pol(obs) if actor else acts[i % 16], auto_reset=mode)
     ep0 = env.counters()[:, 8].sum().item(); torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -28,6 +28,7 @@ def run(name, cfg, actor=False, steps=400, mode="next", fused=False):
 run("config 2: 4096 x 20 peds x 360 rays (open loop)", Config(n_envs=4096, ped_cycle_ms=1400))
 run("config 3: 4096 x 20 peds, TD3 actor in the loop", Config(n_envs=4096, ped_cycle_ms=1400), actor=True)
 run("config 3 with the fused policy tail (cn_policy_tail)", Config(n_envs=4096, ped_cycle_ms=1400), actor=True, fused=True)
+run("config 3 with the one-kernel f32-MFMA actor (cn_actor_forward)", Config(n_envs=4096, ped_cycle_ms=1400), actor=True, mfma=True)
 
 def run_graphed(name, cfg, steps=400):
     from crowdnav.rollout import GraphedRollout
