@@ -424,3 +424,32 @@ def test_mfma_actor_matches_the_torch_actor():
         noisy = agent.act_mfma(obs, add_noise=True)
         assert float(noisy[:, 0].min()) >= 0.0 and float(noisy[:, 0].max()) <= 0.22 and float(noisy[:, 1].abs().max()) <= 2.0
         assert not torch.equal(noisy, got)
+
+
+def test_error_codes_and_limits():
+    """The boundary never throws: bad configurations come back as negative codes with a message."""
+    import ctypes as C
+    import crowdnav
+    from crowdnav.config import Config
+    L = crowdnav.lib()
+    h = C.c_void_p()
+    for kw, code in ((dict(n_envs=0), -2), (dict(k_obstacles=17), -2), (dict(n_rays=4), -2), (dict(track_capacity=48), -2),
+                     (dict(n_peds=5000), -2)):
+        cfg = Config(**kw).to_c()
+        rc = L.cn_create(C.byref(cfg), 0, C.byref(h))
+        assert rc == code, (kw, rc, L.cn_last_error())
+        assert len(L.cn_last_error()) > 0
+    cfg = Config(n_envs=4).to_c()
+    assert L.cn_create(C.byref(cfg), 99, C.byref(h)) == -1       # no such device
+    assert L.cn_create(C.byref(cfg), 0, C.byref(h)) == 0
+    assert L.cn_step(h, None, None) == -1 and b"null" in L.cn_last_error()
+    assert L.cn_reset(h, None, None, None, None) == -1
+    assert L.cn_snapshot(h, C.c_void_p(1), 8) == -5              # buffer too small
+    L.cn_destroy(h)
+    # 1024 rays x 128 pedestrians still fits (LDS sized per configuration)
+    from crowdnav.env import VecEnv
+    env = VecEnv(Config(n_envs=2, n_rays=1024, n_peds=128, room_half=3.0))
+    env.reset(); env.step([[0.1, 0.2], [0.1, -0.2]])
+    import torch
+    torch.cuda.synchronize()
+    assert env.obs.shape == (2, 1023 + 7 + 32) and bool(torch.isfinite(env.obs).all())
