@@ -68,6 +68,8 @@ def main():
     ap.add_argument("--peds", type=int, default=20)
     ap.add_argument("--rays", type=int, default=360)
     ap.add_argument("--k", type=int, default=8)
+    ap.add_argument("--groups", type=int, default=4,
+                    help="headline leg: the rank's envs as this many independent stream groups (1 = one launch per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     a = ap.parse_args()
@@ -75,7 +77,7 @@ def main():
     import torch
     import torch.distributed as dist
     from crowdnav import Config
-    from crowdnav.env import VecEnv
+    from crowdnav.env import VecEnv, VecEnvGroups
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -135,16 +137,57 @@ def main():
             taken -= int(ep1 - ep0)
         return wall_, k_ms, taken
 
-    # headline: next-step reset (auto_reset = 2); beside it: reset inside the same call (auto_reset = 1)
+    conc = 1
+
+    def timed_groups(G, mode="next"):
+        """The same N envs as G independent groups (crowdnav.env.VecEnvGroups): one step = every group stepped
+        once, each on its own HIP stream, no join between groups inside the timed region.  Returns (wall s,
+        mean per-stream ms/launch from HIP events on each group's stream, env-steps taken)."""
+        grp = VecEnvGroups(cfg, groups=G, device=dev_index)
+        nonlocal conc
+        conc = grp.concurrent
+        grp.reset()
+        rows = [grp.rows(g) for g in range(G)]
+        for i in range(a.warmup):
+            for g in range(G):
+                grp.step_group(g, acts[i % n_act][rows[g]], auto_reset=mode)
+        ep0 = grp.episodes()
+        barrier()
+        ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(G)]
+        ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(G)]
+        t0 = time.perf_counter()
+        for g in range(G):
+            ev0[g].record(grp.streams[g])
+        for i in range(a.steps):
+            ai = acts[i % n_act]
+            for g in range(G):
+                grp.step_group(g, ai[rows[g]], auto_reset=mode)
+        for g in range(G):
+            ev1[g].record(grp.streams[g])
+        barrier()
+        wall_ = time.perf_counter() - t0
+        k_ms = sum(ev0[g].elapsed_time(ev1[g]) for g in range(G)) / G / a.steps
+        taken = N * a.steps - (grp.episodes() - ep0 if mode == "next" else 0)
+        grp.close()
+        return wall_, k_ms, taken
+
+    # legs: reset inside the same call (auto_reset = 1); next-step reset (auto_reset = 2) as one launch per step;
+    # next-step reset with the envs as `--groups` independent stream groups (the headline when groups > 1)
     wall_same, kms_same, taken_same = timed("same")
     env.reset()
-    wall, kernel_ms, taken = timed("next")
+    wall_1, kernel_ms_1, taken_1 = timed("next")
+    G = max(1, a.groups)
+    if G > 1:
+        wall, kernel_ms, taken = timed_groups(G)
+    else:
+        wall, kernel_ms, taken = wall_1, kernel_ms_1, taken_1
     if world > 1:
-        t = torch.tensor([wall, float(taken), wall_same, float(taken_same)], dtype=torch.float64, device=cdev)
+        t = torch.tensor([wall, float(taken), wall_same, float(taken_same), wall_1, float(taken_1)],
+                         dtype=torch.float64, device=cdev)
         tm = t.clone(); dist.all_reduce(tm, op=dist.ReduceOp.MAX)
         ts = t.clone(); dist.all_reduce(ts, op=dist.ReduceOp.SUM)
-        wall, wall_same = float(tm[0].item()), float(tm[2].item())
-        taken_all, taken_same_all = float(ts[1].item()), float(ts[3].item())
+        wall, wall_same, wall_1 = float(tm[0].item()), float(tm[2].item()), float(tm[4].item())
+        taken_all, taken_same_all, taken_1_all = float(ts[1].item()), float(ts[3].item()), float(ts[5].item())
         # the path's one exchange: all-gather of per-env episode returns over xGMI (SURVEY 8e)
         ret, _ = env.returns()
         ret = ret.to(cdev)
@@ -154,11 +197,15 @@ def main():
         torch.cuda.synchronize(dev)
         gather_ms = (time.perf_counter() - tg0) * 1e3
     else:
-        taken_all, taken_same_all, gather_ms = float(taken), float(taken_same), None
+        taken_all, taken_same_all, taken_1_all, gather_ms = float(taken), float(taken_same), float(taken_1), None
 
     value = taken_all / wall
     B = algorithmic_bytes(a.peds, a.rays, a.k)
-    achieved = B * N / (kernel_ms * 1e-3) / 1e9   # every launch moves all N envs' state, reset or step
+    n_launch = N // G                                  # envs per cn_env_kernel launch in the headline leg
+    # every launch moves its envs' state, reset or step; G launches are in flight at once, one per stream
+    achieved = G * B * n_launch / (kernel_ms * 1e-3) / 1e9
+    achieved_1 = B * N / (kernel_ms_1 * 1e-3) / 1e9
+    traffic = profiled_traffic() if (a.envs, a.peds, a.rays) == (4096, 20, 360) else None
     out = {
         "metric": "env-steps/sec @4096 envs x 20 peds x 360 rays; HBM GB/s vs roofline",
         "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -166,16 +213,23 @@ def main():
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "%d envs/GPU x %d pedestrians x %d rays, K=%d, lidar-tracker risk features, "
                                "next-step auto-reset (reset launches not counted as env-steps), open-loop "
-                               "U(0,0.22)xU(-2,2) actions" % (N, a.peds, a.rays, a.k),
-                   "envs_per_gpu": N, "parallelism": "env-sharded x%d" % world,
+                               "U(0,0.22)xU(-2,2) actions; one step = every env stepped once, the envs running as "
+                               "%d independent stream group(s) of %d" % (N, a.peds, a.rays, a.k, G, n_launch),
+                   "envs_per_gpu": N, "stream_groups": G, "concurrent_hw_queues_found": conc, "parallelism": "env-sharded x%d" % world,
+                   "one_launch_per_step_value": taken_1_all / wall_1, "one_launch_per_step_ms": wall_1 / a.steps * 1e3,
                    "same_call_reset_value": taken_same_all / wall_same, "same_call_reset_ms_per_step": wall_same / a.steps * 1e3,
                    "returns_allgather_ms": gather_ms},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": profiled_traffic() if (a.envs, a.peds, a.rays) == (4096, 20, 360) else None,
+                     "traffic": traffic * n_launch / 4096.0 if traffic is not None else None,
                      "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE+WRITE_SIZE, calibrated; profiles/)",
-                     "algorithmic_bytes_per_launch": B * N,
-                     "kernel": "cn_env_kernel", "kernel_ms": kernel_ms, "bytes_per_env_step": B},
+                     "algorithmic_bytes_per_launch": B * n_launch, "envs_per_launch": n_launch,
+                     "concurrent_launches": G,
+                     "kernel": "cn_env_kernel", "kernel_ms": kernel_ms, "bytes_per_env_step": B,
+                     "note": "achieved = concurrent_launches x algorithmic bytes per launch / mean launch duration on "
+                             "its own stream (HIP events per group stream)",
+                     "one_launch_per_step": {"envs_per_launch": N, "kernel_ms": kernel_ms_1, "achieved": achieved_1,
+                                             "frac": achieved_1 / HBM_PEAK_GBS}},
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         from oracle import oracle

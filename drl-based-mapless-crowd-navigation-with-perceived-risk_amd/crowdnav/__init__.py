@@ -7,7 +7,7 @@ from ._abi import CrowdNavError, build, lib  # noqa: F401
 
 
 def __getattr__(name):
-    if name in ("VecEnv", "Env"):
+    if name in ("VecEnv", "VecEnvGroups", "Env"):
         from . import env
         return getattr(env, name)
     raise AttributeError(name)

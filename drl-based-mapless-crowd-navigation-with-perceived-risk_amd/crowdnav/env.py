@@ -21,8 +21,12 @@ def _ptr(t):
 
 
 class VecEnv:
-    def __init__(self, cfg=None, device=0, **kw):
+    def __init__(self, cfg=None, device=0, stream=None, out=None, **kw):
+        """stream: a torch.cuda.Stream every launch of this handle goes to (default: the current stream at
+        call time).  out: dict of preallocated output tensors (obs, final_obs, reward, done, topk_idx) --
+        VecEnvGroups passes row slices of one [N_total, ...] allocation."""
         self.cfg = cfg if cfg is not None else Config(**kw)
+        self.stream = stream
         if not torch.cuda.is_available():
             raise _abi.CrowdNavError("VecEnv needs a HIP device: libcrowdnav.so has no CPU fallback")
         self.L = _abi.lib()
@@ -33,12 +37,20 @@ class VecEnv:
         self.N, self.P, self.R, self.K = self.cfg.n_envs, self.cfg.n_peds, self.cfg.n_rays, self.cfg.k_obstacles
         self.D = self.L.cn_obs_dim(self.h)
         N, D, K, dev = self.N, self.D, self.K, self.device
-        self.obs = torch.zeros((N, D), dtype=torch.float32, device=dev)
-        self.final_obs = torch.zeros((N, D), dtype=torch.float32, device=dev)
+        out = out or {}
+
+        def buf(name, shape, dtype, fill=0):
+            t = out.get(name)
+            if t is None:
+                return torch.full(shape, fill, dtype=dtype, device=dev)
+            assert tuple(t.shape) == tuple(shape) and t.dtype == dtype and t.is_contiguous() and t.device == dev, name
+            return t
+        self.obs = buf("obs", (N, D), torch.float32)
+        self.final_obs = buf("final_obs", (N, D), torch.float32)
         self.obs_f64 = None
-        self.reward = torch.zeros(N, dtype=torch.float32, device=dev)
-        self.done = torch.zeros(N, dtype=torch.uint8, device=dev)
-        self.topk_idx = torch.full((N, K), -1, dtype=torch.int32, device=dev)
+        self.reward = buf("reward", (N,), torch.float32)
+        self.done = buf("done", (N,), torch.uint8)
+        self.topk_idx = buf("topk_idx", (N, K), torch.int32, -1)
         self._counters = torch.zeros((N, 10), dtype=torch.int32, device=dev)
         self._ret = torch.zeros(N, dtype=torch.float32, device=dev)
         self._run = torch.zeros(N, dtype=torch.float32, device=dev)
@@ -55,7 +67,8 @@ class VecEnv:
             pass
 
     def _stream(self):
-        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        s = self.stream if self.stream is not None else torch.cuda.current_stream(self.device)
+        return C.c_void_p(s.cuda_stream)
 
     def enable_f64_obs(self):
         """Also produce the observation in float64 (the reference's dtype) -- used by parity tests."""
@@ -158,6 +171,153 @@ class VecEnv:
     def restore(self, buf):
         buf = np.ascontiguousarray(buf, dtype=np.uint8)
         _abi.check(self.L.cn_restore(self.h, buf.ctypes.data, buf.size))
+
+
+def concurrent_streams(want, device=0, candidates=None):
+    """`want` torch streams that really run concurrently with each other on `device`.
+
+    HIP multiplexes streams onto a few hardware queues (4 by default, GPU_MAX_HW_QUEUES) and two streams that
+    share a queue serialise; which pool stream lands on which queue is an implementation detail of the runtime
+    (tools/queue_probe.py prints the matrix).  So: measure.  Two 64-env probe handles step on candidate pairs;
+    a pair is concurrent when both chains together take < 1.5x one chain.  Greedy clique, a few ms.
+    Returns a list of `want` streams; if fewer than `want` mutually concurrent ones exist the list is padded by
+    cycling through the ones found (groups that share a queue still run correctly, just back to back)."""
+    import time
+    dev = torch.device("cuda", device)
+    if want <= 1:
+        return [torch.cuda.Stream(device=dev) for _ in range(max(1, want))], 1
+    cands = [torch.cuda.Stream(device=dev) for _ in range(candidates or (3 * want + 4))]
+    pa = VecEnv(Config(n_envs=64, ped_cycle_ms=1400), device=device)
+    pb = VecEnv(Config(n_envs=64, ped_cycle_ms=1400, env_index_base=64), device=device)
+    act = torch.zeros((64, 2), dtype=torch.float32, device=dev)
+    pa.stream = pb.stream = cands[0]
+    pa.reset(); pb.reset()
+    torch.cuda.synchronize(dev)
+
+    def t_chain(sa, sb, k=8):
+        pa.stream, pb.stream = sa, sb
+        best = float("inf")
+        for _ in range(2):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(k):
+                pa.step(act, auto_reset="next")
+                if sb is not None:
+                    pb.step(act, auto_reset="next")
+            torch.cuda.synchronize(dev)
+            best = min(best, time.perf_counter() - t0)
+        return best
+
+    t_chain(cands[0], None)
+    one = t_chain(cands[0], None)
+    chosen = [cands[0]]
+    for c in cands[1:]:
+        if len(chosen) >= want:
+            break
+        if all(t_chain(ch, c) < 1.5 * one for ch in chosen):
+            chosen.append(c)
+    pa.close(); pb.close()
+    found = len(chosen)
+    out = [chosen[i % found] for i in range(want)]
+    return out, found
+
+
+class VecEnvGroups:
+    """N environments as G independent groups, each a VecEnv handle with its own HIP stream.
+
+    Every wavefront of one launch walks the same phases (ray cast -> type machine -> tracker -> cone) in step,
+    so a single launch alternates between VALU-bound and scalar-bound stretches; launches of different groups
+    drift apart and fill each other's idle units (4096 envs: 2 groups step ~20 % faster than one launch,
+    DESIGN.md section 6).  Groups are contiguous slices of the global env index, so every env sees exactly
+    the trajectory it would see in one VecEnv of N envs.  Outputs are row slices of one [N, ...] allocation.
+
+    There is NO join between groups: `step_group(g, ...)` only enqueues on group g's stream.  A consumer
+    either works per group on `streams[g]` (double-buffered sampler: actor of group A overlaps the env step
+    of group B) or calls `join()` to make the current stream wait for every group."""
+
+    def __init__(self, cfg=None, groups=2, device=0, streams=None, **kw):
+        cfg = cfg if cfg is not None else Config(**kw)
+        assert cfg.n_envs % groups == 0, "n_envs must divide evenly into groups"
+        self.cfg, self.G, self.N = cfg, groups, cfg.n_envs
+        self.device = torch.device("cuda", device)
+        n = self.N // groups
+        self.n = n
+        if streams is None:
+            streams, self.concurrent = concurrent_streams(groups, device)   # streams on distinct hardware queues
+        else:
+            self.concurrent = None
+        assert len(streams) == groups
+        D, K, dev = cfg.obs_dim, cfg.k_obstacles, self.device
+        self.D, self.K = D, K
+        self.obs = torch.zeros((self.N, D), dtype=torch.float32, device=dev)
+        self.final_obs = torch.zeros((self.N, D), dtype=torch.float32, device=dev)
+        self.reward = torch.zeros(self.N, dtype=torch.float32, device=dev)
+        self.done = torch.zeros(self.N, dtype=torch.uint8, device=dev)
+        self.topk_idx = torch.full((self.N, K), -1, dtype=torch.int32, device=dev)
+        self.envs = []
+        for g in range(groups):
+            sl = slice(g * n, (g + 1) * n)
+            out = dict(obs=self.obs[sl], final_obs=self.final_obs[sl], reward=self.reward[sl], done=self.done[sl],
+                       topk_idx=self.topk_idx[sl])
+            self.envs.append(VecEnv(self._group_cfg(g), device=device, stream=streams[g], out=out))
+        self.streams = [e.stream for e in self.envs]
+
+    def _group_cfg(self, g):
+        import dataclasses
+        n = self.N // self.G
+        return dataclasses.replace(self.cfg, n_envs=n, env_index_base=self.cfg.env_index_base + g * n)
+
+    def close(self):
+        for e in self.envs:
+            e.close()
+
+    def rows(self, g):
+        return slice(g * self.n, (g + 1) * self.n)
+
+    def fork(self):
+        """Every group stream waits for work already queued on the current stream (e.g. the actions)."""
+        cur = torch.cuda.current_stream(self.device)
+        for s in self.streams:
+            s.wait_stream(cur)
+
+    def join(self):
+        """The current stream waits for everything queued on the group streams."""
+        cur = torch.cuda.current_stream(self.device)
+        for s in self.streams:
+            cur.wait_stream(s)
+
+    def reset(self):
+        self.fork()
+        for e in self.envs:
+            e.reset()
+        self.join()
+        return self.obs
+
+    def step_group(self, g, action, **kw):
+        """Env.step for group g on its own stream; `action` is that group's [n, 2] slice."""
+        return self.envs[g].step(action, **kw)
+
+    def step(self, action, **kw):
+        """Step every group once (action: [N, 2]); fork/join against the current stream, so this is a drop-in
+        for VecEnv.step -- the groups still overlap each other inside the call."""
+        self.fork()
+        for g, e in enumerate(self.envs):
+            e.step(action[self.rows(g)], **kw)
+        self.join()
+        return self.obs, self.reward, self.done
+
+    def counters(self):
+        cs = [e.counters() for e in self.envs]
+        self.join()
+        return torch.cat(cs, 0)
+
+    def episodes(self):
+        """Total finished episodes over all groups (host int; synchronises)."""
+        tot = 0
+        for e in self.envs:
+            with torch.cuda.stream(e.stream):
+                tot += int(e.counters()[:, 8].sum().item())
+        return tot
 
 
 class Env:

@@ -88,6 +88,30 @@ def rollout(env, agent, n_steps, learn=False, add_noise=True, stats=None, policy
     return n_steps * env.N
 
 
+def rollout_groups(envs, agent, n_steps, add_noise=True, auto_reset="next"):
+    """Actor-in-the-loop rollout over a crowdnav.env.VecEnvGroups: each group runs its own act -> step chain
+    (cn_actor_forward, then cn_step) on its own HIP stream, so the actor of one group overlaps the env step of
+    another and the env launches of different groups fill each other's idle phases.
+    No join between groups until the end.  Static weights (evaluation / data collection between updates);
+    call agent.sync_fused_weights() after an update.  Returns env-steps issued (N per step)."""
+    agent.sync_fused_weights()
+    if not getattr(envs, "_started", False):
+        envs.reset()
+        envs._started = True
+    if getattr(envs, "_act", None) is None:
+        envs._act = torch.zeros((envs.N, 2), dtype=torch.float32, device=envs.device)
+    envs.fork()
+    rows = [envs.rows(g) for g in range(envs.G)]
+    obs = [envs.obs[r] for r in rows]
+    act = [envs._act[r] for r in rows]
+    for _ in range(n_steps):
+        for g in range(envs.G):
+            agent.act_mfma(obs[g], out=act[g], add_noise=add_noise, stream=envs.streams[g], noise_seed=12345 + g)
+            envs.step_group(g, act[g], auto_reset=auto_reset)
+    envs.join()
+    return n_steps * envs.N
+
+
 def evaluate(env, agent, episodes_per_env=1, max_launches=100000):
     """The reference's evaluation run (README "Start testing"; TRAIN:142-161 with learning = False): greedy
     actor, one CSV row per finished episode (success, failure, return, steps, ego/social safety scores)."""

@@ -141,9 +141,11 @@ class Agent:
                                               obs_dim=D, obs_dim_padded=Dp, hidden=256, reserved=0)
 
     @torch.no_grad()
-    def act_mfma(self, obs, out=None, add_noise=True):
+    def act_mfma(self, obs, out=None, add_noise=True, stream=None, noise_seed=12345):
         """Agent.act as ONE kernel (cn_actor_forward): the three Linear layers on the f32 matrix cores with the
-        activations in LDS, plus heads, exploration noise and clip.  float32 throughout, like the reference."""
+        activations in LDS, plus heads, exploration noise and clip.  float32 throughout, like the reference.
+        stream: torch stream to enqueue on (default: current).  The exploration noise is keyed by
+        (noise_seed, call counter, row): callers that split a batch over several calls give each its own seed."""
         import ctypes as C
         from . import _abi
         if not hasattr(self, "_fw_struct"):
@@ -152,10 +154,10 @@ class Agent:
         if out is None:
             out = torch.empty((obs.shape[0], 2), dtype=torch.float32, device=self.device)
         self._fused_calls = getattr(self, "_fused_calls", 0) + 1
-        st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        st = C.c_void_p((stream if stream is not None else torch.cuda.current_stream(self.device)).cuda_stream)
         _abi.check(_abi.lib().cn_actor_forward(C.byref(self._fw_struct), C.c_void_p(obs.data_ptr()), C.c_void_p(out.data_ptr()),
                                                obs.shape[0], self.max_v, self.max_w,
-                                               self.explore_sigma if add_noise else 0.0, 12345, self._fused_calls, st))
+                                               self.explore_sigma if add_noise else 0.0, int(noise_seed), self._fused_calls, st))
         return out
 
     def learn(self, step):

@@ -196,6 +196,44 @@ def test_sharding_is_invariant_to_the_split():
         assert torch.equal(o, torch.cat([oa, ob])) and torch.equal(r, torch.cat([ra, rb])) and torch.equal(d, torch.cat([da, db]))
 
 
+@pytest.mark.parametrize("mode", ["same", "next"])
+def test_stream_groups_equal_one_handle(mode):
+    """VecEnvGroups (G handles on G HIP streams, no join between groups) == one VecEnv of N envs, bit for bit:
+    both through the fork/join `step()` and through free-running per-group chains."""
+    import torch
+    from crowdnav import Config
+    from crowdnav.env import VecEnv, VecEnvGroups
+    cfg = Config(n_envs=96, seed=5, max_steps=30, ped_cycle_ms=1400)
+    full = VecEnv(cfg)
+    grp = VecEnvGroups(cfg, groups=3)
+    free = VecEnvGroups(cfg, groups=2)
+    assert torch.equal(full.reset(), grp.reset())
+    free.reset()
+    g = torch.Generator(device="cpu").manual_seed(2)
+    acts = torch.stack([torch.rand((50, 96), generator=g) * 0.22, torch.rand((50, 96), generator=g) * 4 - 2], 2).cuda()
+    torch.cuda.synchronize()
+    hist = []
+    for t in range(50):
+        o, r, d = full.step(acts[t], auto_reset=mode)
+        o2, r2, d2 = grp.step(acts[t], auto_reset=mode)
+        assert torch.equal(o, o2) and torch.equal(r, r2) and torch.equal(d, d2), t
+        assert torch.equal(full.topk_idx, grp.topk_idx)
+        hist.append((o.clone(), r.clone(), d.clone()))
+    assert torch.equal(full.counters(), grp.counters())
+    # free-running chains: group 0 runs all 50 steps before group 1 is even queued
+    for gi in (0, 1):
+        rows = free.rows(gi)
+        for t in range(50):
+            free.step_group(gi, acts[t, rows], auto_reset=mode)
+            if t in (0, 17, 49):
+                free.streams[gi].synchronize()
+                assert torch.equal(free.obs[rows], hist[t][0][rows]) and torch.equal(free.done[rows], hist[t][2][rows])
+    free.join()
+    torch.cuda.synchronize()
+    assert torch.equal(free.obs, hist[-1][0]) and torch.equal(free.reward, hist[-1][1])
+    assert free.episodes() == int(full.counters()[:, 8].sum().item())
+
+
 def test_env_wrapper_has_reference_surface():
     """The N=1 `Env` mirror: constructor, reset/step return types, status getters."""
     from crowdnav.env import Env

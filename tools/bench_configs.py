@@ -44,7 +44,38 @@ def run_graphed(name, cfg, steps=400):
     print("%-52s %8.4f ms/step  %8.2f M env-steps/s" % (name, dt / steps * 1e3, (N * steps - resets) / dt / 1e6))
     env.close()
 
+def run_groups(name, cfg, G, actor=False, steps=400):
+    from crowdnav.env import VecEnvGroups
+    from crowdnav.rollout import rollout_groups
+    envs = VecEnvGroups(cfg, groups=G); envs.reset(); N = envs.N
+    if actor:
+        agent = Agent(obs_dim=envs.D, device="cuda", seed=0, memory_size=16)
+        rollout_groups(envs, agent, 40)
+        ep0 = envs.episodes(); torch.cuda.synchronize(); t0 = time.perf_counter()
+        rollout_groups(envs, agent, steps)
+    else:
+        g = torch.Generator(device="cuda").manual_seed(1)
+        acts = torch.stack([torch.rand((16, N), generator=g, device="cuda") * 0.22, torch.rand((16, N), generator=g, device="cuda") * 4 - 2], 2).contiguous()
+        def loop(k):
+            for i in range(k):
+                for gi in range(G):
+                    envs.step_group(gi, acts[i % 16][envs.rows(gi)], auto_reset="next")
+        loop(40)
+        ep0 = envs.episodes(); torch.cuda.synchronize(); t0 = time.perf_counter()
+        loop(steps)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    resets = envs.episodes() - ep0
+    print("%-52s %8.4f ms/step  %8.2f M env-steps/s" % (name, dt / steps * 1e3, (N * steps - resets) / dt / 1e6))
+    envs.close()
+
+run_groups("config 2 as 4 stream groups (VecEnvGroups)", Config(n_envs=4096, ped_cycle_ms=1400), 4)
+run_groups("config 3, MFMA actor, 2 stream groups (rollout_groups)", Config(n_envs=4096, ped_cycle_ms=1400), 2, actor=True)
+run_groups("config 3, MFMA actor, 4 stream groups (rollout_groups)", Config(n_envs=4096, ped_cycle_ms=1400), 4, actor=True)
 run_graphed("config 3 as one HIP graph per step", Config(n_envs=4096, ped_cycle_ms=1400))
 run("config 4 shard: 2048 x 20 peds x 360 rays (1 of 8 GPUs)", Config(n_envs=2048, ped_cycle_ms=1400))
 run("config 5: 4096 x 100 peds x 720 rays", Config(n_envs=4096, n_peds=100, n_rays=720, room_half=2.4, ped_cycle_ms=1400))
+run_groups("config 4 shard as 2 stream groups", Config(n_envs=2048, ped_cycle_ms=1400), 2)
+run_groups("config 5 as 4 stream groups", Config(n_envs=4096, n_peds=100, n_rays=720, room_half=2.4, ped_cycle_ms=1400), 4)
 run("16384 x 20 peds x 360 rays on one GPU", Config(n_envs=16384, ped_cycle_ms=1400))
+run_groups("16384 x 20 peds x 360 rays as 4 stream groups", Config(n_envs=16384, ped_cycle_ms=1400), 4)
+run_groups("16384 envs, MFMA actor in the loop, 4 stream groups", Config(n_envs=16384, ped_cycle_ms=1400), 4, actor=True)

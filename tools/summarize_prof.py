@@ -21,26 +21,33 @@ def main(d):
                 row.get("Percentage")))
     tr = find(os.path.join(d, "trace"), "*kernel_trace.csv")
     if tr:
-        durs = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(tr))
-                if "cn_env_kernel" in r["Kernel_Name"]]
-        if len(durs) >= 4:
-            # bench.py times the same-call-reset mode first, then the next-step-reset mode (the headline)
-            h = len(durs) // 2
-            print("== cn_env_kernel average duration by bench leg: same-call reset %.1f us (%d launches), "
-                  "next-step reset %.1f us (%d launches)" % (sum(durs[:h]) / h / 1e3, h, sum(durs[h:]) / (len(durs) - h) / 1e3,
-                                                             len(durs) - h))
+        legs = {}
+        for r in csv.DictReader(open(tr)):
+            kn = r["Kernel_Name"].split("(")[0].strip()
+            if not kn.startswith("cn_env_kernel"):
+                continue
+            g = int(r.get("Grid_Size_X", r.get("Grid_Size", 0)) or 0)
+            legs.setdefault((kn, g), []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        # bench.py legs: cn_env_kernel_same (same-call reset), cn_env_kernel at the full grid (one launch per step),
+        # cn_env_kernel at grid / G (the stream-group leg: G launches in flight, so durations overlap)
+        print("== env kernel average duration by (kernel, grid = 64 x envs per launch):")
+        for (kn, g), dd in sorted(legs.items()):
+            print("  %-22s grid %7d (%5d envs)  launches %5d  avg %.1f us  min %.1f  max %.1f" % (
+                kn, g, g // 64, len(dd), sum(dd) / len(dd) / 1e3, min(dd) / 1e3, max(dd) / 1e3))
     for tag in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
         f = find(os.path.join(d, tag), "*counter_collection.csv")
         if not f:
             print("== %s: no counter csv" % tag)
             continue
         acc, cnt = {}, {}
-        for row in csv.DictReader(open(f)):
-            if "cn_env_kernel" not in row.get("Kernel_Name", ""):
+        rows = [r for r in csv.DictReader(open(f)) if r.get("Kernel_Name", "").split("(")[0].strip() == "cn_env_kernel"]
+        gmax = max([int(r.get("Grid_Size", 0) or 0) for r in rows] or [0])
+        for row in rows:
+            if int(row.get("Grid_Size", 0) or 0) != gmax:      # the one-launch-per-step leg only (full grid)
                 continue
             k = row["Counter_Name"]; v = float(row["Counter_Value"])
             acc[k] = acc.get(k, 0.0) + v; cnt[k] = cnt.get(k, 0) + 1
-        print("== %s (per cn_env_kernel dispatch, mean of %s)" % (tag, sorted(set(cnt.values()))))
+        print("== %s (per cn_env_kernel dispatch of %d envs, mean of %s)" % (tag, gmax // 64, sorted(set(cnt.values()))))
         for k in sorted(acc):
             print("  %-24s %.6g" % (k, acc[k] / cnt[k]))
     # calibration: known 1 GiB streams at 4 and 8 bytes per lane -> KB reported per byte moved
@@ -68,10 +75,11 @@ def main(d):
             fsz = wsz = None
             for tag, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
                 ff = find(os.path.join(d, tag), "*counter_collection.csv")
-                vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(ff))
-                        if "cn_env_kernel" in r.get("Kernel_Name", "") and r["Counter_Name"] == ctr]
-                h = len(vals) // 2
-                m = sum(vals[h:]) / max(1, len(vals) - h)   # second bench leg = next-step reset (the headline)
+                rows = [r for r in csv.DictReader(open(ff))
+                        if r.get("Kernel_Name", "").split("(")[0].strip() == "cn_env_kernel" and r["Counter_Name"] == ctr]
+                gmax = max(int(r.get("Grid_Size", 0) or 0) for r in rows)
+                vals = [float(r["Counter_Value"]) for r in rows if int(r.get("Grid_Size", 0) or 0) == gmax]
+                m = sum(vals) / max(1, len(vals))   # the one-launch-per-step leg (4096 envs per launch)
                 if ctr == "FETCH_SIZE":
                     fsz = m
                 else:
@@ -80,7 +88,8 @@ def main(d):
             wfac = 0.6 * wr4 + 0.4 * wr8
             out = {"fetch_kb": fsz, "write_kb": wsz, "fetch_factor_read8": fe, "write_factor_mix": wfac,
                    "bytes_per_launch": fsz * 1024 * fe + wsz * 1024 * wfac,
-                   "note": "per cn_env_kernel launch (next-step-reset leg), corrected with this box's calibration"}
+                   "note": "per cn_env_kernel launch of the full 4096-env grid (next-step-reset, one launch per step), "
+                           "corrected with this box's calibration; a stream-group launch of n envs moves n/4096 of it"}
             json.dump(out, open(os.path.join(d, "traffic.json"), "w"), indent=1)
             print("== corrected HBM traffic per launch: %.2f MB (fetch %.2f MB, write %.2f MB)" % (
                 out["bytes_per_launch"] / 1e6, fsz * 1024 * fe / 1e6, wsz * 1024 * wfac / 1e6))
