@@ -118,6 +118,27 @@ class VecEnv:
         _abi.check(self.L.cn_step(self.h, C.byref(io), self._stream()))
         return self.obs, self.reward, self.done
 
+    def bind_step(self, action, auto_reset="next", want_final=False):
+        """Pre-marshalled cn_step for a fixed action buffer: returns a zero-argument callable that only enqueues
+        (a fraction of the host time of step(), tools/host_overhead.py).  For rollouts that call several handles per step
+        (VecEnvGroups): the action tensor is written in place by the policy, outputs land in self.obs/reward/done.
+        Needs a bound stream (VecEnv(stream=...)) or uses the stream current at bind time."""
+        assert action.device == self.device and action.dtype == torch.float32 and action.is_contiguous()
+        io = _abi.CnStepIO(action=action.data_ptr(), step_counter=None, obs=self.obs.data_ptr(),
+                           final_obs=self.final_obs.data_ptr() if want_final else None,
+                           obs_f64=self.obs_f64.data_ptr() if self.obs_f64 is not None else None,
+                           reward=self.reward.data_ptr(), done=self.done.data_ptr(), topk_idx=self.topk_idx.data_ptr(),
+                           auto_reset={False: 0, True: 1, None: 0, "same": 1, "next": 2}.get(auto_reset, auto_reset),
+                           reserved=0)
+        ref, st, h, fn, check = C.byref(io), self._stream(), self.h, self.L.cn_step, _abi.check
+        keep = (io, action)
+
+        def call(_keep=keep):
+            rc = fn(h, ref, st)
+            if rc:
+                check(rc)
+        return call
+
     def observe_external(self, ranges, odom, step_counter=None, is_reset=False):
         """Env.get_state + Env.compute_reward on externally supplied /scan and /odom (Gazebo, a physical robot,
         or a recorded run): ranges [N,R] float64, odom [N,10] float64 = x, y, yaw, v, w, time.time(),

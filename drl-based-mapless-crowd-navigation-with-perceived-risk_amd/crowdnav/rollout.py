@@ -102,12 +102,15 @@ def rollout_groups(envs, agent, n_steps, add_noise=True, auto_reset="next"):
         envs._act = torch.zeros((envs.N, 2), dtype=torch.float32, device=envs.device)
     envs.fork()
     rows = [envs.rows(g) for g in range(envs.G)]
-    obs = [envs.obs[r] for r in rows]
-    act = [envs._act[r] for r in rows]
+    # pre-marshalled launches: the loop is host-bound otherwise (2 G ctypes calls per step)
+    calls = []
+    for g in range(envs.G):
+        calls.append(agent.bind_act_mfma(envs.obs[rows[g]], envs._act[rows[g]], add_noise=add_noise,
+                                         stream=envs.streams[g], noise_seed=12345 + g))
+        calls.append(envs.envs[g].bind_step(envs._act[rows[g]], auto_reset=auto_reset))
     for _ in range(n_steps):
-        for g in range(envs.G):
-            agent.act_mfma(obs[g], out=act[g], add_noise=add_noise, stream=envs.streams[g], noise_seed=12345 + g)
-            envs.step_group(g, act[g], auto_reset=auto_reset)
+        for c in calls:
+            c()
     envs.join()
     return n_steps * envs.N
 

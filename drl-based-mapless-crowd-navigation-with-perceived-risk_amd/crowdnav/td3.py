@@ -160,6 +160,28 @@ class Agent:
                                                self.explore_sigma if add_noise else 0.0, int(noise_seed), self._fused_calls, st))
         return out
 
+    def bind_act_mfma(self, obs, out, add_noise=True, stream=None, noise_seed=12345):
+        """Pre-marshalled act_mfma for fixed obs/out buffers: a zero-argument callable that only enqueues."""
+        import ctypes as C
+        from . import _abi
+        if not hasattr(self, "_fw_struct"):
+            self.sync_fused_weights()
+        assert obs.is_contiguous() and out.is_contiguous()
+        fn, check = _abi.lib().cn_actor_forward, _abi.check
+        w = C.byref(self._fw_struct)
+        po, pa, n = C.c_void_p(obs.data_ptr()), C.c_void_p(out.data_ptr()), obs.shape[0]
+        st = C.c_void_p((stream if stream is not None else torch.cuda.current_stream(self.device)).cuda_stream)
+        sigma = self.explore_sigma if add_noise else 0.0
+        mv, mw, seed = self.max_v, self.max_w, int(noise_seed)
+        keep = (obs, out, self._fw_struct, self._fw)
+
+        def call(_keep=keep):
+            self._fused_calls = c = getattr(self, "_fused_calls", 0) + 1
+            rc = fn(w, po, pa, n, mv, mw, sigma, seed, c, st)
+            if rc:
+                check(rc)
+        return call
+
     def learn(self, step):
         """One TD3 update (TD3:225-285)."""
         if len(self.memory) <= self.batch_size:

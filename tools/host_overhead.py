@@ -16,3 +16,11 @@ for _ in range(n): env.step(a, auto_reset="next")
 t1 = time.perf_counter()
 torch.cuda.synchronize()
 print("VecEnv.step host enqueue time: %.1f us per call" % ((t1 - t0) / n * 1e6))
+f = env.bind_step(a, auto_reset="next")
+for _ in range(50): f()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(n): f()
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+print("VecEnv.bind_step callable:     %.1f us per call" % ((t1 - t0) / n * 1e6))
