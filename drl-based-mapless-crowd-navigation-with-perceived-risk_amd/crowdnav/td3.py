@@ -182,15 +182,22 @@ class Agent:
                 check(rc)
         return call
 
-    def learn(self, step):
-        """One TD3 update (TD3:225-285)."""
-        if len(self.memory) <= self.batch_size:
-            return None
-        s, a, r, s2, d = self.memory.sample(self.batch_size)
+    def learn(self, step, batch=None, target_noise=None):
+        """One TD3 update (TD3:225-285): clipped target-policy noise added to the target actor's action (the
+        reference does not re-clip the noisy action to the action bounds, TD3:244-247), min of the two target
+        critics, MSE critic losses with one Adam step each, and every `policy_delay` steps the actor step plus
+        the three soft updates.  `batch` = (s, a, r[B,1], s2, d[B,1]) and `target_noise` [B,2] (before the clip)
+        override the replay sample / the generator -- used by the parity test against the reference's update."""
+        if batch is None:
+            if len(self.memory) <= self.batch_size:
+                return None
+            batch = self.memory.sample(self.batch_size)
+        s, a, r, s2, d = batch
         with torch.no_grad():
-            noise = (torch.randn(a.shape, generator=self.gen, device=self.device) * self.noise_std).clamp(
-                -self.noise_clip, self.noise_clip)
-            a2 = torch.max(torch.min(self.actor_t(s2) + noise, self._hi), self._lo)
+            if target_noise is None:
+                target_noise = torch.randn(a.shape, generator=self.gen, device=self.device)
+            noise = (target_noise * self.noise_std).clamp(-self.noise_clip, self.noise_clip)
+            a2 = self.actor_t(s2) + noise
             q_t = torch.min(self.q1_t(s2, a2), self.q2_t(s2, a2))
             y = r + (1.0 - d) * self.gamma * q_t
         l1 = F.mse_loss(self.q1(s, a), y)
@@ -201,10 +208,21 @@ class Agent:
             la = -self.q1(s, self.actor(s)).mean()
             self.opt_a.zero_grad(); la.backward(); self.opt_a.step()
             with torch.no_grad():
-                for t, src in ((self.actor_t, self.actor), (self.q1_t, self.q1), (self.q2_t, self.q2)):
+                for t, src in ((self.q1_t, self.q1), (self.q2_t, self.q2), (self.actor_t, self.actor)):
                     for pt, ps in zip(t.parameters(), src.parameters()):
-                        pt.mul_(1.0 - self.tau).add_(ps, alpha=self.tau)
+                        pt.copy_(pt * (1.0 - self.tau) + ps * self.tau)          # TD3:287-299
         return float(l1.item())
+
+    def load_models(self, actor_path, critic1_path, critic2_path):
+        """Agent.load_models (TD3:313-319): the reference's checkpoints are plain state_dicts with the same
+        parameter names (linear1/2/3), so its published .pt files load unchanged; targets are hard-copied."""
+        self.actor.load_state_dict(torch.load(actor_path, map_location=self.device))
+        self.q1.load_state_dict(torch.load(critic1_path, map_location=self.device))
+        self.q2.load_state_dict(torch.load(critic2_path, map_location=self.device))
+        for t, src in ((self.actor_t, self.actor), (self.q1_t, self.q1), (self.q2_t, self.q2)):
+            t.load_state_dict(src.state_dict())
+        if hasattr(self, "_fw_struct"):
+            self.sync_fused_weights()
 
     def save(self, outdir, ep):
         """Target-network checkpoints every 100 episodes (TRAIN:150-154, TD3:304-311)."""
