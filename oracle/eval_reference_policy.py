@@ -1,0 +1,114 @@
+#!/usr/bin/env python
+"""TEST INFRASTRUCTURE, container-only (reads /root/reference at run time; nothing on the GPU box imports it).
+
+End-to-end sanity check of the observation / action conventions: the reference's own TRAINED TD3 actors
+(models/td3/**/td3_actor_model_ep*.pt, trained in Gazebo) drive the build's simulator through the CPU oracle,
+greedy (no exploration noise), in the training world and in the README's scripted evaluation scenarios.  A policy
+that was trained against the reference Env only reaches goals here if heading/distance signs, scan ordering, top-K
+feature layout and the (v, w) action semantics all agree with what it was trained on.
+
+The published training logs (results/td3/**/td3_training.csv) hold training-time episodes, i.e. with the exploration
+noise sigma = 1.0 of TD3:67-78, so the comparable rows here are the sigma = 1 ones.
+
+  python oracle/eval_reference_policy.py [--envs 128] [--episodes 1]      -> table on stdout
+"""
+import argparse
+import glob
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "drl-based-mapless-crowd-navigation-with-perceived-risk_amd"))
+from crowdnav import presets            # noqa: E402  (data + Config only; no GPU needed)
+from crowdnav.td3 import Actor          # noqa: E402
+from oracle import oracle               # noqa: E402
+
+MODELS = "/root/reference/turtlebot3_rl_sim/src/models/td3"
+
+
+def run(actor, cfg, init, vel, episodes, policy="actor", sigma=0.0):
+    """Greedy (sigma = 0) or training-time (sigma = 1.0, TD3:67-78 + clip TD3:214-215) roll-outs; returns rates."""
+    o = oracle.Oracle(cfg.as_dict() if hasattr(cfg, "as_dict") else cfg)
+    if init is not None:
+        o.set_ped_init(init)
+    if vel is not None:
+        o.set_ped_preset_vel(vel)
+    obs = o.reset()
+    N = o.N
+    succ = fail = 0; steps = []; ego = []; soc = []
+    ep_done = np.zeros(N, dtype=np.int64)
+    rng = np.random.RandomState(0)
+    while ep_done.min() < episodes:
+        if policy == "actor":
+            with torch.no_grad():
+                a = actor(torch.from_numpy(obs.astype(np.float32))).numpy().astype(np.float64)
+            if sigma:
+                a = a + rng.normal(0.0, sigma, a.shape)
+            a[:, 0] = np.clip(a[:, 0], 0.0, 0.22); a[:, 1] = np.clip(a[:, 1], -2.0, 2.0)
+        else:
+            a = np.stack([rng.uniform(0, 0.22, N), rng.uniform(-2, 2, N)], 1)
+        pre = o.counters().copy()
+        obs, rew, done, _ = o.step(a, auto_reset=True)
+        if done.any():
+            c = o.counters()
+            for e in np.nonzero(done)[0]:
+                if ep_done[e] >= episodes:
+                    continue
+                ep_done[e] += 1
+                succ += int(c[e, 4]); fail += int(c[e, 5])
+                steps.append(int(pre[e, 3]) + 1)
+                if pre[e, 2] > 0:
+                    ego.append(1.0 - pre[e, 0] / pre[e, 2]); soc.append(1.0 - pre[e, 1] / pre[e, 2])
+    n = int(ep_done.sum())
+    return dict(n=n, success=succ / n, failure=fail / n, steps=float(np.mean(steps)),
+                ego=float(np.mean(ego)) if ego else float("nan"), social=float(np.mean(soc)) if soc else float("nan"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--envs", type=int, default=128)
+    ap.add_argument("--episodes", type=int, default=1)
+    ap.add_argument("--max-steps", type=int, default=1000)
+    a = ap.parse_args()
+    oracle.set_num_threads(min(16, os.cpu_count() or 1))
+    actors = {}
+    for k in (1, 4, 8, 12, 16):        # the K-ablation checkpoints of the 366 + 4K layout
+        f = os.path.join(MODELS, "turtlebot3_top_%d_obstacle" % k, "td3_actor_model_ep2500.pt")
+        sd = torch.load(f, map_location="cpu")
+        assert sd["linear1.weight"].shape[1] == 366 + 4 * k
+        m = Actor(366 + 4 * k, 2, 256); m.load_state_dict(sd); m.eval()
+        actors[k] = m
+    print("failure = collision or step limit (the reference counts both as failure_episode, ENV:1131-1158)")
+    print("%-86s %5s | %7s %7s %6s %6s %6s" % ("policy / world", "eps", "success", "failure", "steps", "ego", "social"))
+
+    def show(name, r):
+        print("%-86s %5d | %7.3f %7.3f %6.1f %6.3f %6.3f" % (name, r["n"], r["success"], r["failure"], r["steps"], r["ego"], r["social"]), flush=True)
+
+    def world(k, vmax=None):
+        cfg, init = presets.training(n_envs=a.envs, max_steps=a.max_steps, seed=77, k_obstacles=k)
+        if vmax is not None:
+            cfg.ped_vmax = vmax
+        return cfg, init
+
+    cfg, init = world(8)
+    show("uniform-random actions / training world, 14 walkers U(-0.2, 0.2) m/s", run(None, cfg, init, None, a.episodes, policy="random"))
+    for k, m in actors.items():
+        for sigma in (1.0, 0.0):
+            cfg, init = world(k)
+            show("top_%d_obstacle ep2500, sigma %.0f / training world, walkers U(-0.2, 0.2) m/s" % (k, sigma), run(m, cfg, init, None, a.episodes, sigma=sigma))
+    for vmax in (0.1, 0.03, 0.0):
+        for k in (1, 8):
+            cfg, init = world(k, vmax)
+            show("top_%d_obstacle ep2500, sigma 1 / training world, walkers U(-%.2f, %.2f) m/s" % (k, vmax, vmax), run(actors[k], cfg, init, None, a.episodes, sigma=1.0))
+    for kind in ("crossing", "towards", "ahead", "random"):
+        for n in (4, 8, 12, 20):
+            cfg, init, vel = presets.evaluation(kind, n, n_envs=a.envs, max_steps=a.max_steps, seed=77, k_obstacles=8)
+            show("top_8_obstacle ep2500, sigma 1 / test room, %s x %d" % (kind, n), run(actors[8], cfg, init, vel, a.episodes, sigma=1.0))
+
+
+if __name__ == "__main__":
+    main()
