@@ -11,6 +11,7 @@ class CnConfig(C.Structure):
         ("n_envs", C.c_int32), ("n_peds", C.c_int32), ("n_rays", C.c_int32), ("k_obstacles", C.c_int32),
         ("max_steps", C.c_int32), ("ped_mode", C.c_int32), ("dt_ms", C.c_int32), ("scan_latency_ms", C.c_int32),
         ("settle_ms", C.c_int32), ("ped_cycle_ms", C.c_int32), ("ped_stagger_ms", C.c_int32), ("track_capacity", C.c_int32),
+        ("obs_layout", C.c_int32), ("reserved1", C.c_int32),
         ("env_index_base", C.c_int64), ("seed", C.c_uint64),
         ("room_half", C.c_double), ("ped_radius", C.c_double), ("ped_vmax", C.c_double),
         ("robot_clearance", C.c_double), ("lidar_min", C.c_double), ("lidar_max", C.c_double),
@@ -35,6 +36,8 @@ class Config:
     ped_cycle_ms: int = 0          # 0 -> 100 ms x n_peds (CROWD:128-144)
     ped_stagger_ms: int = 100      # CROWD:144
     track_capacity: int = 0        # tracker slots per env: 0 = auto (32 up to 40 pedestrians, else 64)
+    obs_layout: int = 0            # 0: environment_stage_1_nobonus (366 + 4K); 1: environment_stage_1_original (R-1 + 4)
+    reserved1: int = 0
     env_index_base: int = 0
     seed: int = 1234
     room_half: float = 1.40        # WORLD:926-1108
@@ -72,4 +75,6 @@ class Config:
 
     @property
     def obs_dim(self):
+        if self.obs_layout == 1:
+            return (self.n_rays - 1) + 4                        # ORIG:315-320 (363 at 360 rays)
         return (self.n_rays - 1) + 7 + 4 * self.k_obstacles   # ENV:1038-1039, TRAIN:88

@@ -15,6 +15,9 @@
 extern "C" __global__ void cn_env_kernel(CnKParams p);
 extern "C" __global__ void cn_env_kernel_ext(CnKParams p);
 extern "C" __global__ void cn_env_kernel_same(CnKParams p);
+extern "C" __global__ void cn_env_kernel_orig(CnKParams p);
+extern "C" __global__ void cn_env_kernel_orig_ext(CnKParams p);
+extern "C" __global__ void cn_env_kernel_orig_same(CnKParams p);
 extern "C" __global__ void cn_gather_kernel(CnKParams p, float* last_ret, float* run_ret, int32_t* counters);
 
 static thread_local std::string g_err;
@@ -110,7 +113,8 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
     const cn_config& c = *cfg;
     if (c.n_envs < 1 || c.n_peds < 0 || c.n_peds > 4096 || c.n_rays < 8 || c.n_rays > 1025 || c.k_obstacles < 1 ||
         c.k_obstacles > CN_MAX_K || c.ped_cycle_ms < 1 || c.dt_ms < 1 || c.scan_latency_ms < 1 || c.settle_ms < 0 ||
-        c.max_steps < 1 || !(c.track_capacity == 0 || c.track_capacity == 32 || c.track_capacity == 64))
+        c.max_steps < 1 || !(c.track_capacity == 0 || c.track_capacity == 32 || c.track_capacity == 64) ||
+        !(c.obs_layout == CN_LAYOUT_RISK || c.obs_layout == CN_LAYOUT_ORIGINAL))
         return fail(CN_ERR_CONFIG, "cn_create: config out of range");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
@@ -121,7 +125,7 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
     h->cfg = c;
     h->device = device;
     const int N = c.n_envs, P = c.n_peds, R = c.n_rays, K = c.k_obstacles;
-    h->D = (R - 1) + 7 + 4 * K;
+    h->D = c.obs_layout == CN_LAYOUT_ORIGINAL ? (R - 1) + 4 : (R - 1) + 7 + 4 * K;
     h->max_conf = (R - 1) / 4 + 2;
     h->trk_cap = c.track_capacity ? c.track_capacity : (P <= 40 ? 32 : 64);
     h->lds = cn_lds_bytes(R, P, K, h->max_conf, h->trk_cap);
@@ -171,6 +175,9 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
         HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
         HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_ext, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
         HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_same, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
+        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_orig, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
+        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_orig_ext, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
+        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_orig_same, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
     }
     *out = h;
     return CN_OK;
@@ -238,7 +245,14 @@ struct DeviceScope {
 static int launch(cn_handle h, const CnKParams& kp, hipStream_t st)
 {
     DeviceScope scope(h->device);
-    if (kp.mode == CN_MODE_EXT_STEP || kp.mode == CN_MODE_EXT_RESET)
+    if (h->cfg.obs_layout == CN_LAYOUT_ORIGINAL) {
+        if (kp.mode == CN_MODE_EXT_STEP || kp.mode == CN_MODE_EXT_RESET)
+            hipLaunchKernelGGL(cn_env_kernel_orig_ext, dim3(kp.N), dim3(64), h->lds, st, kp);
+        else if (kp.mode == CN_MODE_STEP && kp.auto_reset == 1)
+            hipLaunchKernelGGL(cn_env_kernel_orig_same, dim3(kp.N), dim3(64), h->lds, st, kp);
+        else
+            hipLaunchKernelGGL(cn_env_kernel_orig, dim3(kp.N), dim3(64), h->lds, st, kp);
+    } else if (kp.mode == CN_MODE_EXT_STEP || kp.mode == CN_MODE_EXT_RESET)
         hipLaunchKernelGGL(cn_env_kernel_ext, dim3(kp.N), dim3(64), h->lds, st, kp);
     else if (kp.mode == CN_MODE_STEP && kp.auto_reset == 1)   // step + reset of finished envs in the same launch
         hipLaunchKernelGGL(cn_env_kernel_same, dim3(kp.N), dim3(64), h->lds, st, kp);

@@ -243,68 +243,39 @@ __device__ __forceinline__ void sim_advance(const CnKParams& p, EnvRegs& e, int 
 
 // ---- Env.get_state (ENV:245-1044) ----------------------------------------------------------------
 // ped_p: pedestrian positions in LDS.  Writes the observation (float32 and optionally float64).
-template <bool EXT>
-__device__ __forceinline__ void observe(const CnKParams& p, const Poly& pg, EnvRegs& e, const Lds& L, int env, int lane, int step_counter,
-                        float* obs32, float* fin32, double* obs64, int* done_out)
+// ---- lidar (XACRO:150-178), shared by both observation layouts ------------------------------------------
+// Pedestrians that can return a range <= lidar_max: |centre - origin| <= lidar_max + radius (+ slack).
+// A culled pedestrian could only produce t > lidar_max, which reads as "no return" anyway, so the
+// result is identical to testing all P (the oracle does).
+__device__ __forceinline__ int near_peds(const CnKParams& p, const Lds& L, int lane, double ox, double oy)
 {
-    const int R = p.R, n = R - 1, K = p.K, D = n + 7 + 4 * K;
-    const double MAXR = p.max_scan_range;
-    const double px = e.rx, py = e.ry, yaw = e.ryaw, v = e.rv, w = e.rw, now = e.clock;
-
-    // ENV:246-265
-    CN_T(22);
-    if (step_counter == 1) waypoint_refresh(p, pg, e, lane, px, py);
-    double distance_to_goal = cn_np_around2(dist3(px, py, e.wpx, e.wpy));
-    double heading = cn_py_round2(heading_to_goal(p, e, px, py, yaw));
-    CN_T(23);
-    if (step_counter % 5 == 0 || distance_to_goal < e.prev_dist) waypoint_refresh(p, pg, e, lane, px, py);
-    CN_T(24);
-    // ENV:267-268: the angular velocity is used as the angle
-    double sw_, cw_;
-    cn_det_sincos(w, &sw_, &cw_);
-    double agent_vel_x = -1.0 * (v * cw_);
-    double agent_vel_y = v * sw_;
-
-    CN_T(2);
-    // ---- lidar raycast (XACRO:150-178) + UTL:375-392 sanitise + UTL:110-126 end points ----------
-    double sy, cy;
-    cn_det_sincos(yaw, &sy, &cy);
-    const double ox = fma(p.lidar_offset_x, cy, px), oy = fma(p.lidar_offset_x, sy, py);
-    const double h = p.room_half, rr = p.ped_radius * p.ped_radius;
-    const double deg2rad = CN_PI / 180.0;
-    // Pedestrians that can return a range <= lidar_max: |centre - origin| <= lidar_max + radius (+ slack).
-    // A culled pedestrian could only produce t > lidar_max, which reads as "no return" anyway, so the
-    // result is identical to testing all P (the oracle does).
     int nnear = 0;
-    {
-        const double lim = p.lidar_max + p.ped_radius + 1e-6, lim2 = lim * lim;
-        for (int j0 = 0; j0 < p.P; j0 += 64) {
-            int j = j0 + lane;
-            bool nr = false;
-            if (j < p.P && !(CN_ABLATE(1))) {
-                double ocx = L.ped[2 * j] - ox, ocy = L.ped[2 * j + 1] - oy;
-                nr = fma(ocx, ocx, ocy * ocy) <= lim2;
-            }
-            u64 m = __ballot(nr);
-            if (nr) L.nearidx[nnear + __popcll(m & ((1ull << lane) - 1ull))] = j;
-            nnear += __popcll(m);
+    const double lim = p.lidar_max + p.ped_radius + 1e-6, lim2 = lim * lim;
+    for (int j0 = 0; j0 < p.P; j0 += 64) {
+        int j = j0 + lane;
+        bool nr = false;
+        if (j < p.P && !(CN_ABLATE(1))) {
+            double ocx = L.ped[2 * j] - ox, ocy = L.ped[2 * j + 1] - oy;
+            nr = fma(ocx, ocx, ocy * ocy) <= lim2;
         }
+        u64 m = __ballot(nr);
+        if (nr) L.nearidx[nnear + __popcll(m & ((1ull << lane) - 1ull))] = j;
+        nnear += __popcll(m);
     }
     CN_SYNC();
-    const bool wall_x = !(h - fabs(ox) > p.lidar_max + 1e-6);
-    const bool wall_y = !(h - fabs(oy) > p.lidar_max + 1e-6);
-    CN_T(3);
-    double smin = 1e300;
-    float* o32 = obs32 + (size_t)env * D;
-    float* f32 = fin32 ? fin32 + (size_t)env * D : nullptr;
-    double* o64 = obs64 ? obs64 + (size_t)env * D : nullptr;
-    // End points, rounded ranges and gradients are 3-decimal values: LDS keeps the integer thousandths
-    // (x == cn_div1000(mil) bit for bit), which halves the working set and doubles the waves per CU.
-    for (int k = lane; k < R; k += 64) {
+    return nnear;
+}
+
+// Range of ray k: the sensor's own reading (EXT), or the nearest hit among the room walls and the near pedestrians.
+template <bool EXT>
+__device__ __forceinline__ double cast_ray(const CnKParams& p, const Lds& L, int env, int k, double ox, double oy, double sy,
+                                           double cy, int nnear, bool wall_x, bool wall_y)
+{
+    if constexpr (EXT) {
+        return p.ext_ranges[(size_t)env * p.R + k];   // Gazebo / a physical lidar
+    } else {
+        const double h = p.room_half, rr = p.ped_radius * p.ped_radius;
         double t = INFINITY;
-        if constexpr (EXT) {
-            t = p.ext_ranges[(size_t)env * R + k];   // the sensor's own reading (Gazebo / a physical lidar)
-        } else {
         const double lc = p.lidar_c[k], ls = p.lidar_s[k];  // ray k in the robot frame: host table of cn_det_sincos(k * step)
         double dx = fma(cy, lc, -(sy * ls));
         double dy = fma(sy, lc, cy * ls);
@@ -334,8 +305,146 @@ __device__ __forceinline__ void observe(const CnKParams& p, const Poly& pg, EnvR
                 }
             }
         }
-        t = (t > p.lidar_max) ? INFINITY : t;       // the simulated sensor reports no return beyond its range
+        return (t > p.lidar_max) ? INFINITY : t;       // the simulated sensor reports no return beyond its range
+    }
+}
+
+// ---- obs_layout 1: environment_stage_1_original.py ("ORIG"), SURVEY 8f N3 --------------------------------
+// ORIG:244-260: heading straight to desired_point, no starting_pose offset
+__device__ __forceinline__ double orig_heading(const CnKParams& p, double px, double py, double yaw)
+{
+    double ga = atan2(p.goal_y - py, p.goal_x - px);
+    double h = ga - yaw;
+    if (h > CN_PI) h -= 2 * CN_PI;
+    else if (h < -CN_PI) h += 2 * CN_PI;
+    return h;
+}
+
+// ORIG:278-322: state = [round(range, 3)] * (R-1) + [heading, distance] + [round(x, 3), round(y, 3)]; tail -> L.tail[0..3]
+template <bool EXT>
+__device__ __forceinline__ void observe_original(const CnKParams& p, EnvRegs& e, const Lds& L, int env, int lane, int step_counter,
+                                                 float* obs32, float* fin32, double* obs64, int* done_out)
+{
+    const int R = p.R, n = R - 1, D = n + 4;
+    const double px = e.rx, py = e.ry, yaw = e.ryaw;
+    double dist = cn_np_around2(dist3(px, py, p.goal_x, p.goal_y));   // round(np.float64, 2), ORIG:280
+    double head = cn_py_round2(orig_heading(p, px, py, yaw));        // ORIG:281
+    double sy, cy;
+    cn_det_sincos(yaw, &sy, &cy);
+    const double ox = fma(p.lidar_offset_x, cy, px), oy = fma(p.lidar_offset_x, sy, py);
+    const double h = p.room_half;
+    const int nnear = near_peds(p, L, lane, ox, oy);
+    const bool wall_x = !(h - fabs(ox) > p.lidar_max + 1e-6);
+    const bool wall_y = !(h - fabs(oy) > p.lidar_max + 1e-6);
+    float* o32 = obs32 + (size_t)env * D;
+    float* f32 = fin32 ? fin32 + (size_t)env * D : nullptr;
+    double* o64 = obs64 ? obs64 + (size_t)env * D : nullptr;
+    double smin = 1e300;
+    for (int k = lane; k < R; k += 64) {
+        const double r = cast_ray<EXT>(p, L, env, k, ox, oy, sy, cy, nnear, wall_x, wall_y);
+        if (k >= 1) {
+            int j = R - 1 - k;                                        // ORIG:298-300 reverse, drop the last
+            double v;
+            if (isinf(r)) v = 0.6;                                    // ORIG:290-291: the literal, not max_scan_range
+            else if (r != r) v = 0.0;
+            else v = r;
+            smin = fmin(smin, v);
+            double so = cn_py_round3(v);                              // ORIG:317
+            o32[j] = (float)so;
+            if (f32) f32[j] = (float)so;
+            if (o64) o64[j] = so;
         }
+    }
+    smin = cn_wave_min_d(smin);
+    if (!e.done) {
+        if (0.105 > smin && smin > 0.0) e.done = 1;                   // ORIG:282,303-305
+        if (in_box(px, py, p.goal_x, p.goal_y, 0.20)) e.done = 1;     // ORIG:307-309 (epsilon default, ORIG:500)
+        if (step_counter >= p.max_steps) e.done = 1;                  // ORIG:311-313
+    }
+    const double x3 = cn_py_round3(px), y3 = cn_py_round3(py);        // ORIG:315
+    if (lane < 4) {
+        double tv = lane == 0 ? head : lane == 1 ? dist : lane == 2 ? x3 : y3;
+        L.tail[lane] = tv;
+        o32[n + lane] = (float)tv;
+        if (f32) f32[n + lane] = (float)tv;
+        if (o64) o64[n + lane] = tv;
+    }
+    CN_SYNC();
+    *done_out = e.done;
+}
+
+// ORIG:324-402.  The quirk is the reference's: state[-1] (the rounded y) is its "current_distance" and state[-2]
+// (the rounded x) its "current_heading".
+__device__ __forceinline__ double compute_reward_original(const CnKParams& p, EnvRegs& e, const Lds& L, int done)
+{
+    double cur_dist = L.tail[3], cur_head = L.tail[2];
+    double dd = cur_dist - e.prev_dist, hd = cur_head - e.prev_head;
+    int htg = 0, dtg = 0;
+    if (dd < 0) dtg = 1;
+    double ph = e.prev_head;
+    if (hd > 0) {
+        if (cur_head > 0 && ph < 0) htg = 1;
+        if (cur_head < 0 && ph < 0) htg = 1;
+        if (cur_head < 0 && ph > 0) htg = 1;
+        if (cur_head > 0 && ph > 0) htg = 0;
+    }
+    if (hd < 0) {
+        if (cur_head < 0 && ph > 0) htg = 1;
+        if (cur_head > 0 && ph > 0) htg = 1;
+        if (cur_head > 0 && ph < 0) htg = 1;
+        if (cur_head < 0 && ph < 0) htg = 0;
+    }
+    double reward = (double)(dtg + htg);                              // step_reward 0, action_reward unused (ORIG:333-374)
+    e.prev_dist = cur_dist;
+    e.prev_head = cur_head;
+    if (done) {
+        if (in_box(e.rx, e.ry, p.goal_x, p.goal_y, 0.20)) { e.fail = 0; e.succ = 1; reward = 200 + reward; }
+        else { e.fail = 1; e.succ = 0; reward = -200 + reward; }
+    }
+    return reward;
+}
+
+template <bool EXT>
+__device__ __forceinline__ void observe(const CnKParams& p, const Poly& pg, EnvRegs& e, const Lds& L, int env, int lane, int step_counter,
+                        float* obs32, float* fin32, double* obs64, int* done_out)
+{
+    const int R = p.R, n = R - 1, K = p.K, D = n + 7 + 4 * K;
+    const double MAXR = p.max_scan_range;
+    const double px = e.rx, py = e.ry, yaw = e.ryaw, v = e.rv, w = e.rw, now = e.clock;
+
+    // ENV:246-265
+    CN_T(22);
+    if (step_counter == 1) waypoint_refresh(p, pg, e, lane, px, py);
+    double distance_to_goal = cn_np_around2(dist3(px, py, e.wpx, e.wpy));
+    double heading = cn_py_round2(heading_to_goal(p, e, px, py, yaw));
+    CN_T(23);
+    if (step_counter % 5 == 0 || distance_to_goal < e.prev_dist) waypoint_refresh(p, pg, e, lane, px, py);
+    CN_T(24);
+    // ENV:267-268: the angular velocity is used as the angle
+    double sw_, cw_;
+    cn_det_sincos(w, &sw_, &cw_);
+    double agent_vel_x = -1.0 * (v * cw_);
+    double agent_vel_y = v * sw_;
+
+    CN_T(2);
+    // ---- lidar raycast (XACRO:150-178) + UTL:375-392 sanitise + UTL:110-126 end points ----------
+    double sy, cy;
+    cn_det_sincos(yaw, &sy, &cy);
+    const double ox = fma(p.lidar_offset_x, cy, px), oy = fma(p.lidar_offset_x, sy, py);
+    const double h = p.room_half;
+    const double deg2rad = CN_PI / 180.0;
+    const int nnear = near_peds(p, L, lane, ox, oy);
+    const bool wall_x = !(h - fabs(ox) > p.lidar_max + 1e-6);
+    const bool wall_y = !(h - fabs(oy) > p.lidar_max + 1e-6);
+    CN_T(3);
+    double smin = 1e300;
+    float* o32 = obs32 + (size_t)env * D;
+    float* f32 = fin32 ? fin32 + (size_t)env * D : nullptr;
+    double* o64 = obs64 ? obs64 + (size_t)env * D : nullptr;
+    // End points, rounded ranges and gradients are 3-decimal values: LDS keeps the integer thousandths
+    // (x == cn_div1000(mil) bit for bit), which halves the working set and doubles the waves per CU.
+    for (int k = lane; k < R; k += 64) {
+        const double t = cast_ray<EXT>(p, L, env, k, ox, oy, sy, cy, nnear, wall_x, wall_y);
         if (k >= 1) {
             int j = R - 1 - k;  // UTL:389-390 reverse, drop last
             double r = t;
@@ -920,7 +1029,7 @@ __device__ __forceinline__ double compute_reward(const CnKParams& p, const Poly&
 
 }  // namespace
 
-template <bool EXT, bool TWO>
+template <bool EXT, bool TWO, int LAYOUT>
 __device__ __forceinline__ void env_kernel_body(const CnKParams& p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1049,19 +1158,27 @@ __device__ __forceinline__ void env_kernel_body(const CnKParams& p)
                 e.clock += cn_div1000((double)p.scan_latency_ms);    // wait_for_message('scan') (ENV:1238)
                 sim_advance(p, e, env, lane, L.ped, pedv, p.scan_latency_ms);
             }
+            if constexpr (LAYOUT == 1) {
+                e.prev_dist = dist3(e.rx, e.ry, p.goal_x, p.goal_y);   // ORIG:472 (unrounded)
+                e.prev_head = orig_heading(p, e.rx, e.ry, e.ryaw);     // ORIG:473
+            } else {
             e.prev_dist = dist3(e.rx, e.ry, e.wpx, e.wpy);        // ENV:1243 (unrounded)
             e.prev_head = heading_to_goal(p, e, e.rx, e.ry, e.ryaw);  // ENV:1244
+            }
         }
         CN_SYNC();
-        observe<EXT>(p, pg, e, L, env, lane, sc, p.obs, fin, p.obs_f64, &done);
+        if constexpr (LAYOUT == 1) observe_original<EXT>(p, e, L, env, lane, sc, p.obs, fin, p.obs_f64, &done);
+        else observe<EXT>(p, pg, e, L, env, lane, sc, p.obs, fin, p.obs_f64, &done);
         if (!do_reset) {
-            double r = compute_reward(p, pg, e, L, lane, done);
+            double r;
+            if constexpr (LAYOUT == 1) r = compute_reward_original(p, e, L, done);
+            else r = compute_reward(p, pg, e, L, lane, done);
             e.ep_ret += r;
             if (lane == 0) {
                 p.reward[env] = (float)r;
                 p.done[env] = (uint8_t)done;
             }
-            if (p.topk_idx && lane < K) p.topk_idx[(size_t)env * K + lane] = L.kidx[lane];
+            if (p.topk_idx && lane < K) p.topk_idx[(size_t)env * K + lane] = LAYOUT == 1 ? -1 : L.kidx[lane];
             if (done) {
                 if (!ext) { e.rv = 0.0; e.rw = 0.0; }             // pub_cmd_vel.publish(Twist()) (ENV:1160)
                 e.last_ret = e.ep_ret;
@@ -1117,14 +1234,20 @@ __device__ __forceinline__ void env_kernel_body(const CnKParams& p)
             sim_advance(p, e, env, lane, L.ped, pedv, p.scan_latency_ms);
         }
         CN_SYNC();
-        observe<EXT>(p, pg, e, L, env, lane, sc, p.obs, ext ? nullptr : p.final_obs, p.obs_f64, &done);
-        double r = compute_reward(p, pg, e, L, lane, done);
+        double r;
+        if constexpr (LAYOUT == 1) {
+            observe_original<EXT>(p, e, L, env, lane, sc, p.obs, ext ? nullptr : p.final_obs, p.obs_f64, &done);
+            r = compute_reward_original(p, e, L, done);
+        } else {
+            observe<EXT>(p, pg, e, L, env, lane, sc, p.obs, ext ? nullptr : p.final_obs, p.obs_f64, &done);
+            r = compute_reward(p, pg, e, L, lane, done);
+        }
         e.ep_ret += r;
         if (lane == 0) {
             p.reward[env] = (float)r;
             p.done[env] = (uint8_t)done;
         }
-        if (p.topk_idx && lane < K) p.topk_idx[(size_t)env * K + lane] = L.kidx[lane];
+        if (p.topk_idx && lane < K) p.topk_idx[(size_t)env * K + lane] = LAYOUT == 1 ? -1 : L.kidx[lane];
         if (done) {
             if (!ext) { e.rv = 0.0; e.rw = 0.0; }             // pub_cmd_vel.publish(Twist()) (ENV:1160)
             e.last_ret = e.ep_ret;
@@ -1146,11 +1269,18 @@ __device__ __forceinline__ void env_kernel_body(const CnKParams& p)
         sim_advance(p, e, env, lane, L.ped, pedv, p.scan_latency_ms);
         }
         CN_SYNC();
+        int d2 = 0;
+        if constexpr (LAYOUT == 1) {
+            e.prev_dist = dist3(e.rx, e.ry, p.goal_x, p.goal_y);   // ORIG:472 (unrounded)
+            e.prev_head = orig_heading(p, e.rx, e.ry, e.ryaw);     // ORIG:473
+            CN_SYNC();
+            observe_original<EXT>(p, e, L, env, lane, 0, p.obs, nullptr, p.obs_f64, &d2);
+        } else {
         e.prev_dist = dist3(e.rx, e.ry, e.wpx, e.wpy);        // ENV:1243 (unrounded)
         e.prev_head = heading_to_goal(p, e, e.rx, e.ry, e.ryaw);  // ENV:1244
         CN_SYNC();
-        int d2 = 0;
         observe<EXT>(p, pg, e, L, env, lane, 0, p.obs, nullptr, p.obs_f64, &d2);
+        }
         e.social_viol = 0; e.ego_viol = 0; e.obst_steps = 0;  // ENV:1260-1262
         if (!ext) {
         e.clock += cn_div1000((double)p.settle_ms);              // TRAIN:114 time.sleep(0.1)
@@ -1184,9 +1314,13 @@ __device__ __forceinline__ void env_kernel_body(const CnKParams& p)
 
 // The product kernel (simulated sensors) and its sibling for externally supplied /scan + /odom.  Two
 // instantiations keep the external-data branch out of the hot kernel's registers.
-extern "C" __global__ void __launch_bounds__(64) cn_env_kernel(CnKParams p) { env_kernel_body<false, false>(p); }
-extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_same(CnKParams p) { env_kernel_body<false, true>(p); }
-extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_ext(CnKParams p) { env_kernel_body<true, false>(p); }
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel(CnKParams p) { env_kernel_body<false, false, 0>(p); }
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_same(CnKParams p) { env_kernel_body<false, true, 0>(p); }
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_ext(CnKParams p) { env_kernel_body<true, false, 0>(p); }
+// obs_layout 1 (environment_stage_1_original.py): same physics and lidar, no tracker
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_orig(CnKParams p) { env_kernel_body<false, false, 1>(p); }
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_orig_same(CnKParams p) { env_kernel_body<false, true, 1>(p); }
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_orig_ext(CnKParams p) { env_kernel_body<true, false, 1>(p); }
 
 // float32 views of the per-env returns (for the RCCL all-gather of episode returns) and counters
 extern "C" __global__ void cn_gather_kernel(CnKParams p, float* last_ret, float* run_ret, int32_t* counters)

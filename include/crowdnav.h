@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CN_ABI_VERSION 1
+#define CN_ABI_VERSION 2
 #define CN_MAX_TRACKS 64      /* largest per-env capacity of the obstacle tracker (ENV:656-743): one lane per track */
 #define CN_MAX_K 16
 
@@ -44,6 +44,8 @@ enum { CN_ST_TRACK_OVERFLOW = 1, CN_ST_TTC_ZERO = 2, CN_ST_DT_ZERO = 4, CN_ST_CO
 
 /* Every field of Env.__init__'s rosparam reads (ENV:71-91), the robot/lidar constants of the
  * URDF/XACRO and world files, and the crowd node's constants.  SURVEY.md appendix B cites each. */
+enum { CN_LAYOUT_RISK = 0, CN_LAYOUT_ORIGINAL = 1 };
+
 typedef struct cn_config {
     int32_t n_envs;          /* N environments in this handle (this GPU's shard) */
     int32_t n_peds;          /* P pedestrians (obstacle cylinders) per env */
@@ -57,6 +59,10 @@ typedef struct cn_config {
     int32_t ped_cycle_ms;    /* crowd node cycle: 0.1 s x number of obstacles (CROWD:128-144) */
     int32_t ped_stagger_ms;  /* 0.1 s between consecutive obstacles' updates (CROWD:144) -> 100 */
     int32_t track_capacity;  /* tracker slots per env: 0 = auto (32 for <= 40 pedestrians, else 64), or 32 / 64 */
+    int32_t obs_layout;      /* CN_LAYOUT_RISK (0): environment_stage_1_nobonus.py, obs = R-1 + 7 + 4K (TD3 / DDPG trainers);
+                              * CN_LAYOUT_ORIGINAL (1): environment_stage_1_original.py:278-402, obs = R-1 + 4 =
+                              * rounded ranges + heading + distance + rounded (x, y) (SAC / DQN / Q-learning trainers) */
+    int32_t reserved1;
     int64_t env_index_base;  /* global index of env 0: RNG streams are keyed by global index */
     uint64_t seed;
     double room_half;        /* WORLD:926-1108 -> 1.40 */
@@ -83,7 +89,8 @@ typedef struct cn_env_s* cn_handle;
 typedef struct cn_step_io {
     const float* action;         /* dev [N,2]  (v, w), already clipped by the caller (TD3:214-215) */
     const int32_t* step_counter; /* dev [N] 1-based (TRAIN:125) or NULL = per-env internal counter */
-    float* obs;                  /* dev [N, 366+4K]; with auto_reset: first obs of the new episode where done */
+    float* obs;                  /* dev [N, D], D = cn_obs_dim(): 366+4K (obs_layout 0) or R-1+4 (obs_layout 1);
+                                  * with auto_reset: first obs of the new episode where done */
     float* final_obs;            /* dev [N, 366+4K] or NULL: the observation Env.step returned (terminal if done) */
     double* obs_f64;             /* dev [N, 366+4K] or NULL: `obs` in float64 (the reference's dtype) */
     float* reward;               /* dev [N] */

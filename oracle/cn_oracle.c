@@ -913,6 +913,82 @@ static double env_compute_reward(const cno_sim* s, env_t* e, const double* state
 }
 
 /* ------------------------------------------------------------------------------------------
+ * obs_layout 1: environment_stage_1_original.py ("ORIG"), the 363-input environment of the SAC / DQN /
+ * Q-learning / SARSA trainers (start_sac_training.py:13,105-116): no waypoints, no tracker.
+ * ---------------------------------------------------------------------------------------- */
+
+static double orig_heading(const cno_config* c, double px, double py, double yaw)
+{
+    /* ORIG:244-260: no starting_pose offset, straight to desired_point */
+    double ga = atan2(c->goal_y - py, c->goal_x - px);
+    double h = ga - yaw;
+    if (h > M_PI) h -= 2 * M_PI;
+    else if (h < -M_PI) h += 2 * M_PI;
+    return h;
+}
+
+/* ORIG:278-322.  state = [round(range, 3)] * (R-1) + [heading, distance] + [round(x, 3), round(y, 3)] */
+static void orig_get_state(const cno_sim* s, env_t* e, const double* ranges, double px, double py, double yaw,
+                           int step_counter, double* state, int* done_out)
+{
+    const cno_config* c = &s->cfg;
+    const int R = c->n_rays, n = R - 1;
+    double dist = cno_np_around(dist3(px, py, c->goal_x, c->goal_y), 2); /* round(np.float64, 2), ORIG:280 */
+    double head = cno_py_round(orig_heading(c, px, py, yaw), 2);          /* ORIG:281 */
+    const double min_range = 0.105;                                       /* ORIG:282 */
+    double mn = INFINITY;
+    for (int j = 0; j < n; ++j) {
+        double r = ranges[R - 1 - j], v;                                  /* ORIG:289-300: reverse, drop the last */
+        if (isinf(r)) v = 0.6;                                            /* ORIG:290-291 (the literal, not max_scan_range) */
+        else if (isnan(r)) v = 0.0;
+        else v = r;
+        if (v < mn) mn = v;                                               /* Python min(): first smallest, NaN-free here */
+        state[j] = cno_py_round(v, 3);                                    /* ORIG:317 */
+    }
+    if (!e->done) {
+        if (min_range > mn && mn > 0) e->done = 1;                        /* ORIG:303-305 */
+        if (in_box(px, py, c->goal_x, c->goal_y, 0.20)) e->done = 1;     /* ORIG:307-309, epsilon default 0.20 (ORIG:500) */
+        if (step_counter >= c->max_steps) e->done = 1;                    /* ORIG:311-313 */
+    }
+    state[n] = head; state[n + 1] = dist;
+    state[n + 2] = cno_py_round(px, 3); state[n + 3] = cno_py_round(py, 3); /* ORIG:315 */
+    *done_out = e->done;
+}
+
+/* ORIG:324-402.  The layout quirk is the reference's: state[-1] is the rounded y and state[-2] the rounded x, and those
+ * are what it calls current_distance / current_heading. */
+static double orig_compute_reward(const cno_sim* s, env_t* e, const double* state, double px, double py, int done)
+{
+    const cno_config* c = &s->cfg;
+    const int n = s->n;
+    double cur_dist = state[n + 3], cur_head = state[n + 2];
+    double dd = cur_dist - e->prev_dist, hd = cur_head - e->prev_head;
+    int htg = 0, dtg = 0;
+    if (dd < 0) dtg = 1;
+    double ph = e->prev_head;
+    if (hd > 0) {
+        if (cur_head > 0 && ph < 0) htg = 1;
+        if (cur_head < 0 && ph < 0) htg = 1;
+        if (cur_head < 0 && ph > 0) htg = 1;
+        if (cur_head > 0 && ph > 0) htg = 0;
+    }
+    if (hd < 0) {
+        if (cur_head < 0 && ph > 0) htg = 1;
+        if (cur_head > 0 && ph > 0) htg = 1;
+        if (cur_head > 0 && ph < 0) htg = 1;
+        if (cur_head < 0 && ph < 0) htg = 0;
+    }
+    double reward = (double)(dtg + htg);                                  /* step_reward = 0, action_reward unused (ORIG:333-374) */
+    e->prev_dist = cur_dist;
+    e->prev_head = cur_head;
+    if (done) {
+        if (in_box(px, py, c->goal_x, c->goal_y, 0.20)) { e->ep_failure = 0; e->ep_success = 1; reward = 200 + reward; }
+        else { e->ep_failure = 1; e->ep_success = 0; reward = -200 + reward; }
+    }
+    return reward;
+}
+
+/* ------------------------------------------------------------------------------------------
  * Env.reset / Env.step flows
  * ---------------------------------------------------------------------------------------- */
 
@@ -944,9 +1020,15 @@ static void env_reset_flow(const cno_sim* s, env_t* e, int64_t gid, double* obs)
     e->clock += (double)c->scan_latency_ms / 1000.0; /* wait_for_message('scan') */
     sim_advance(s, e, gid, c->scan_latency_ms);
     raycast_impl(c, s->lidar_c, s->lidar_s, e->rx, e->ry, e->ryaw, e->ped_p, c->n_peds, e->ranges);
+    if (c->obs_layout == 1) {                                      /* ORIG:456-486, then SAC:106-107 */
+        e->prev_dist = dist3(e->rx, e->ry, c->goal_x, c->goal_y);  /* ORIG:472 (unrounded) */
+        e->prev_head = orig_heading(c, e->rx, e->ry, e->ryaw);     /* ORIG:473 */
+        orig_get_state(s, e, e->ranges, e->rx, e->ry, e->ryaw, 0, obs, &done);
+    } else {
     e->prev_dist = dist3(e->rx, e->ry, e->wpx, e->wpy);           /* ENV:1243 (unrounded) */
     e->prev_head = heading_to_goal(c, e, e->rx, e->ry, e->ryaw);   /* ENV:1244 */
     env_get_state(s, e, e->ranges, e->rx, e->ry, e->ryaw, e->rv, e->rw, 0, e->clock, obs, &done, idx);
+    }
     e->social_viol = 0; e->ego_viol = 0; e->obst_steps = 0;       /* ENV:1260-1262 */
     e->clock += (double)c->settle_ms / 1000.0;                     /* TRAIN:114 time.sleep(0.1) */
     sim_advance(s, e, gid, c->settle_ms);
@@ -972,8 +1054,14 @@ static void env_step_flow(const cno_sim* s, env_t* e, int64_t gid, double v, dou
     e->clock += (double)c->scan_latency_ms / 1000.0;               /* wait_for_message('scan') (ENV:1218) */
     sim_advance(s, e, gid, c->scan_latency_ms);
     raycast_impl(c, s->lidar_c, s->lidar_s, e->rx, e->ry, e->ryaw, e->ped_p, c->n_peds, e->ranges);
+    if (c->obs_layout == 1) {                                      /* ORIG:404-454 */
+        orig_get_state(s, e, e->ranges, e->rx, e->ry, e->ryaw, step_counter, obs, done);
+        *reward = orig_compute_reward(s, e, obs, e->rx, e->ry, *done);
+        for (int k = 0; k < c->k_obstacles; ++k) topk_idx[k] = -1;
+    } else {
     env_get_state(s, e, e->ranges, e->rx, e->ry, e->ryaw, e->rv, e->rw, step_counter, e->clock, obs, done, topk_idx);
     *reward = env_compute_reward(s, e, obs, e->rx, e->ry, *done);
+    }
     if (*done) { e->rv = 0.0; e->rw = 0.0; }                      /* pub_cmd_vel.publish(Twist()) (ENV:1160) */
 }
 
@@ -1007,7 +1095,8 @@ int cno_create(const cno_config* cfg, cno_sim** out)
     cno_sim* s = (cno_sim*)calloc(1, sizeof(cno_sim));
     s->cfg = *cfg;
     s->n = cfg->n_rays - 1;
-    s->D = s->n + 7 + 4 * cfg->k_obstacles;
+    if (cfg->obs_layout != 0 && cfg->obs_layout != 1) return -2;
+    s->D = cfg->obs_layout == 1 ? s->n + 4 : s->n + 7 + 4 * cfg->k_obstacles;
     int R = cfg->n_rays, P = cfg->n_peds;
     s->lidar_c = (double*)malloc(sizeof(double) * 2 * R);
     s->lidar_s = s->lidar_c + R;
@@ -1173,6 +1262,21 @@ int cno_ext_call(cno_sim* s, int env, const cno_ext_in* in, const double* ranges
     int32_t idx_local[16];
     int32_t* idx = topk_idx ? topk_idx : idx_local;
     int d = 0;
+    if (c->obs_layout == 1) {
+        if (in->is_reset) {
+            e->prev_dist = dist3(in->px, in->py, c->goal_x, c->goal_y);
+            e->prev_head = orig_heading(c, in->px, in->py, in->yaw);
+            orig_get_state(s, e, ranges, in->px, in->py, in->yaw, 0, obs, &d);
+            if (reward) *reward = 0.0;
+        } else {
+            orig_get_state(s, e, ranges, in->px, in->py, in->yaw, in->step_counter, obs, &d);
+            double r = orig_compute_reward(s, e, obs, in->px, in->py, d);
+            if (reward) *reward = r;
+        }
+        if (done) *done = (uint8_t)d;
+        for (int k = 0; k < c->k_obstacles; ++k) idx[k] = -1;
+        return 0;
+    }
     if (in->is_reset) {
         e->prev_dist = dist3(in->px, in->py, e->wpx, e->wpy);
         e->prev_head = heading_to_goal(c, e, in->px, in->py, in->yaw);

@@ -8,6 +8,8 @@
  *                              environment_stage_1_nobonus.py:245-1263
  *   geometry / scan / CP helpers  utils.py:110-126, 227-345, 375-460
  *   pedestrian velocity process   crowd_behaviors/simulate_crowd.py:98-144
+ *   obs_layout 1: Env.reset / step / get_state / compute_reward of
+ *                              environment_stage_1_original.py:278-486 ("ORIG")
  * What has NO reference source (Gazebo/ODE + gazebo_ros plugins own it) and is
  * therefore DEFINED here and in DESIGN.md ("parity unpinned" for these rows):
  *   pedestrian position integration, diff-drive kinematics, lidar raycast.
@@ -36,6 +38,8 @@ typedef struct cno_config {
     int32_t ped_cycle_ms;    /* velocity resample period (CROWD: 0.1 s * n_obs) */
     int32_t ped_stagger_ms;  /* per-pedestrian offset (CROWD:144 sleep 0.1) -> 100 */
     int32_t reserved0;
+    int32_t obs_layout;      /* 0: environment_stage_1_nobonus.py (366+4K); 1: environment_stage_1_original.py (R-1+4) */
+    int32_t reserved1;
     int64_t env_index_base;  /* global index of env 0 (multi-GPU sharding) */
     uint64_t seed;
     double room_half;        /* inner half extent of the square room (WORLD:926-1108 -> 1.40) */

@@ -163,6 +163,8 @@ class Harness(object):
     """Plays ROS + Gazebo for one reference `Env`.  `sim` is an oracle.Oracle with n_envs == 1
     whose simulator half (cno_hsim_*) stands in for Gazebo."""
 
+    ENV_MODULE = "environment_stage_1_nobonus"
+
     def __init__(self, sim, params=None, quiet=True):
         self.sim = sim
         c = sim.cfg
@@ -187,16 +189,22 @@ class Harness(object):
             self.params.update(params)
         self._install()
         self.utils = _load_py2("utils", os.path.join(REF_SRC, "utils.py"), {})
-        self.envmod = _load_py2("environment_stage_1_nobonus",
-                                os.path.join(REF_SRC, "environment_stage_1_nobonus.py"), {})
+        self.envmod = _load_py2(self.ENV_MODULE, os.path.join(REF_SRC, self.ENV_MODULE + ".py"), {})
         for m in (self.utils, self.envmod):
             m.time = self.time_mod
             m.math = self.math_mod
+        self._before_env()
         with self._silence():
             self.env = self.envmod.Env(action_dim=2, max_step=c.max_steps)
+        self._after_env(c)
+        self._push_odom()
+
+    def _before_env(self):
+        pass
+
+    def _after_env(self, c):
         self.env.k_obstacle_count = c.k_obstacles  # ENV:55 is a source-edit switch
         self._wrap_get_state()
-        self._push_odom()
 
     # -- stubs ---------------------------------------------------------------------------
     def _install(self):
@@ -258,6 +266,7 @@ class Harness(object):
         mod("std_srvs"); mod("std_srvs.srv", Empty=Empty)
         mod("visualization_msgs"); mod("visualization_msgs.msg", Marker=Marker)
         mod("tf"); mod("tf.transformations", euler_from_quaternion=euler_from_quaternion)
+        mod("rospkg", RosPack=lambda: _Obj(get_path=lambda name: "/tmp"))   # environment_stage_1_original.py:35,127
         from . import shapely_shim
         mod("shapely")
         mod("shapely.geometry", Point=shapely_shim.Point, LineString=shapely_shim.LineString,
@@ -347,3 +356,49 @@ class Harness(object):
             bb=float(e.bounding_box_size) if e.bounding_box_size is not None else 0.0,
             status=(bool(e.episode_success), bool(e.episode_failure)),
         )
+
+
+class HarnessOriginal(Harness):
+    """The same harness around environment_stage_1_original.py (the 363-input layout of the SAC / DQN / Q-learning
+    trainers: 359 rounded ranges + heading + distance + rounded position).  Differences handled here:
+    the module imports rospkg (stubbed in _install), and get_state appends a trajectory row to a results CSV on every call
+    (ORIG:286 utils.record_data) -- file output only, replaced by a no-op."""
+    ENV_MODULE = "environment_stage_1_original"
+
+    def _before_env(self):
+        self.utils.record_data = lambda *a, **k: None
+
+    def _after_env(self, c):
+        h = self
+        orig = self.env.get_state
+
+        def get_state(scan, step_counter=0, action=[0, 0]):
+            e = h.env
+            rec = dict(ranges=np.array(scan.ranges, dtype=np.float64), px=e.position.x, py=e.position.y,
+                       v=h.cmd[0], w=h.cmd[1], now=h.clock, step_counter=int(step_counter))
+            out = orig(scan, step_counter, action)
+            rec["yaw"] = float(e.robot_odometry[2])
+            h.trace.append(rec)
+            return out
+
+        self.env.get_state = get_state
+
+    def step(self, action, step_counter):
+        with self._silence():
+            obs, reward, done = self.env.step([float(action[0]), float(action[1])], int(step_counter),
+                                              mode="continuous")  # SAC:116
+        self.trace[-1].update(is_reset=0)
+        return np.asarray(obs, dtype=np.float64), float(reward), bool(done)
+
+    def reset(self):
+        with self._silence():
+            obs = self.env.reset()                    # SAC:105
+            self.trace[-1].update(is_reset=1)
+            self.time_mod.sleep(0.1)                  # SAC:106
+            self.env.done = False                     # SAC:107
+        return np.asarray(obs, dtype=np.float64)
+
+    def snapshot(self):
+        e = self.env
+        return dict(status=(bool(e.episode_success), bool(e.episode_failure)),
+                    prev=(float(e.previous_distance), float(e.previous_heading)))

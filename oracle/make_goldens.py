@@ -18,7 +18,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import oracle  # noqa: E402
-from oracle.harness.refenv import Harness  # noqa: E402
+from oracle.harness.refenv import Harness, HarnessOriginal  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
 MAXT = 24
@@ -88,6 +88,49 @@ def gen_seq(name, kw, episodes, arange):
     print("%-10s calls=%4d  tracks mean %.2f max %d  (>K on %d calls)  done=%d  %.0f KB" % (
         name, len(nt), nt.mean(), nt.max(), int((nt > kw.get("k_obstacles", 8)).sum()), int(arrs["done"].sum()),
         os.path.getsize(path) / 1024))
+
+
+ORIG_CONFIGS = {
+    # environment_stage_1_original.py (obs_layout 1, 363 inputs): name -> (config overrides, episodes, action ranges)
+    "orig20": (dict(n_peds=20, max_steps=150, seed=21, obs_layout=1), 6, (0.0, 0.22, -2.0, 2.0)),
+    "orig60": (dict(n_peds=60, max_steps=80, seed=22, obs_layout=1, room_half=1.8), 4, (0.05, 0.22, -1.0, 1.0)),
+}
+
+
+def gen_seq_original(name, kw, episodes, arange):
+    """Sequence goldens of the 363-input environment: inputs (ranges, pose, yaw, step counter) and what the reference
+    returned (obs[363], reward, done, success/failure flags, previous_distance / previous_heading)."""
+    sim = oracle.Oracle(n_envs=1, **kw)
+    h = HarnessOriginal(sim)
+    rng = np.random.default_rng(kw["seed"])
+    cols = {k: [] for k in ("ranges", "px", "py", "yaw", "v", "w", "now", "step_counter", "is_reset", "action", "obs",
+                            "reward", "done", "status", "prev")}
+
+    def push(rec, action, obs, reward, done):
+        snap = h.snapshot()
+        for k in ("ranges", "px", "py", "yaw", "v", "w", "now", "step_counter", "is_reset"):
+            cols[k].append(rec[k])
+        cols["action"].append(action); cols["obs"].append(obs); cols["reward"].append(reward); cols["done"].append(done)
+        cols["status"].append(snap["status"]); cols["prev"].append(snap["prev"])
+
+    for ep in range(episodes):
+        obs = h.reset()
+        push(h.trace[-1], (0.0, 0.0), obs, 0.0, False)
+        for st in range(kw["max_steps"]):
+            a = (float(np.float32(rng.uniform(arange[0], arange[1]))), float(np.float32(rng.uniform(arange[2], arange[3]))))
+            obs, r, d = h.step(a, st + 1)
+            push(h.trace[-1], a, obs, r, d)
+            if d:
+                break
+    arrs = {k: np.asarray(v) for k, v in cols.items()}
+    arrs["ped_init"] = sim.get_ped_init()
+    arrs["config_keys"] = np.array(sorted(kw.keys()))
+    arrs["config_vals"] = np.array([float(kw[k]) for k in sorted(kw.keys())])
+    path = os.path.join(OUT, "seq_%s.npz" % name)
+    np.savez_compressed(path, **arrs)
+    print("%-10s calls=%4d  done=%d (success %d)  %.0f KB" % (name, len(arrs["done"]), int(arrs["done"].sum()),
+                                                              int(sum(1 for i in range(len(arrs["done"])) if arrs["done"][i] and arrs["status"][i][0])),
+                                                              os.path.getsize(path) / 1024))
 
 
 def gen_func():
@@ -205,6 +248,12 @@ def gen_func():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    only = sys.argv[1:]            # e.g. `python oracle/make_goldens.py orig20 orig60` regenerates just those
     for name, (kw, eps, ar) in SEQ_CONFIGS.items():
-        gen_seq(name, kw, eps, ar)
-    gen_func()
+        if not only or name in only:
+            gen_seq(name, kw, eps, ar)
+    for name, (kw, eps, ar) in ORIG_CONFIGS.items():
+        if not only or name in only:
+            gen_seq_original(name, kw, eps, ar)
+    if not only or "func" in only:
+        gen_func()

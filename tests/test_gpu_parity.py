@@ -346,6 +346,58 @@ def test_golden_replay_through_the_kernel(name):
     assert n_exact >= 0.995 * len(z["now"])
 
 
+# ---- obs_layout 1: environment_stage_1_original.py (363 inputs), SURVEY 8f N3 -----------------------------
+@pytest.mark.parametrize("mode", [True, "next", False])
+def test_original_layout_rollout_parity(oracle_mod, mode):
+    """cn_env_kernel_orig / _orig_same against the oracle's restatement of environment_stage_1_original.py."""
+    n_done, exact = _compare_rollout(oracle_mod, steps=120, seed=41, reset_mode=mode, n_envs=96, n_peds=20, max_steps=60,
+                                     obs_layout=1)
+    assert n_done > 50 and exact == 1.0
+
+
+def test_original_layout_other_shapes(oracle_mod):
+    n_done, exact = _compare_rollout(oracle_mod, steps=60, seed=42, n_envs=32, n_peds=100, n_rays=720, max_steps=40,
+                                     room_half=2.4, obs_layout=1)
+    assert exact == 1.0
+    n_done, exact = _compare_rollout(oracle_mod, steps=60, seed=43, n_envs=32, n_peds=0, n_rays=181, max_steps=25, obs_layout=1)
+    assert n_done >= 32 and exact == 1.0
+
+
+@pytest.mark.parametrize("name", ["orig20", "orig60"])
+def test_original_layout_golden_replay_and_run(name):
+    """Layout 1 against the REFERENCE's own Python: (a) the kernel fed with the recorded /scan + /odom
+    (cn_observe_external), (b) the full simulated path driven by the recorded actions."""
+    import torch
+    from crowdnav import Config
+    from crowdnav.env import VecEnv
+    z, kw = load_seq(name)
+    env = VecEnv(Config(n_envs=1, **kw))
+    assert env.D == 363
+    env.enable_f64_obs()
+    for i in range(len(z["now"])):
+        odom = [z["px"][i], z["py"][i], z["yaw"][i], z["v"][i], z["w"][i], z["now"][i], 0.0, 0.0, 0.0, 0.0]
+        is_reset = bool(z["is_reset"][i])
+        env.observe_external(z["ranges"][i][None, :], [odom], step_counter=[int(z["step_counter"][i])], is_reset=is_reset)
+        torch.cuda.synchronize()
+        assert np.array_equal(env.obs_f64[0].cpu().numpy(), z["obs"][i]), (name, i)
+        if not is_reset:
+            assert float(env.reward[0].item()) == z["reward"][i] and bool(env.done[0].item()) == bool(z["done"][i]), (name, i)
+        c = env.counters()[0].cpu().tolist()
+        assert (bool(c[4]), bool(c[5])) == tuple(bool(x) for x in z["status"][i])
+    env2 = VecEnv(Config(n_envs=1, **kw))
+    env2.enable_f64_obs()
+    env2.set_ped_init(z["ped_init"])
+    for i in range(len(z["now"])):
+        if z["is_reset"][i]:
+            env2.reset()
+        else:
+            env2.step(torch.tensor(z["action"][i][None, :], dtype=torch.float32).cuda(), step_counter=[int(z["step_counter"][i])],
+                      auto_reset=False)
+            assert float(env2.reward[0].item()) == z["reward"][i] and bool(env2.done[0].item()) == bool(z["done"][i]), (name, i)
+        torch.cuda.synchronize()
+        assert np.abs(env2.obs_f64[0].cpu().numpy() - z["obs"][i]).max() <= TOL, (name, i)
+
+
 def test_empty_room_and_masked_reset(oracle_mod):
     """P = 0 (empty room: the division hazard of ENV:1272 is reported, not raised) and cn_reset with a mask."""
     import torch

@@ -119,3 +119,43 @@ def test_function_level_goldens(oracle_mod):
         assert L.cno_estimate_num_obs_scans(dd, 0.6, 0.12) == int(e1)
         assert L.cno_estimate_num_obs_scans(dd, 0.6, 0.0) == int(e0)
     assert [L.cno_estimate_num_obs_scans(x, 0.6, 0.12) for x in (0.6, 0.36, 0.12)] == [3, 17, 32]
+
+
+# ---- obs_layout 1: environment_stage_1_original.py (363 inputs), SURVEY 8f N3 -----------------------------
+ORIG_SEQS = ["orig20", "orig60"]
+
+
+@pytest.mark.parametrize("name", ORIG_SEQS)
+def test_original_layout_replay_bit_exact(oracle_mod, name):
+    """get_state / compute_reward of environment_stage_1_original.py on the recorded /scan + /odom (ORIG:278-402):
+    observation, reward, done, success / failure flags and the (mislabelled) previous_distance / previous_heading."""
+    z, kw = load_seq(name)
+    o = oracle_mod.Oracle(n_envs=1, **kw)
+    assert o.D == 363
+    for i in range(len(z["now"])):
+        inp = {k: (int(z[k][i]) if k in ("step_counter", "is_reset") else float(z[k][i]))
+               for k in ("px", "py", "yaw", "v", "w", "now", "step_counter", "is_reset")}
+        obs, r, d, idx = o.ext_call(0, z["ranges"][i], deque_x=0.0, deque_y=0.0, end_timestep=0.0, **inp)
+        if inp["is_reset"]:
+            o.ext_set_done(0, False)  # SAC:107
+        else:
+            assert r == z["reward"][i] and d == bool(z["done"][i]), (name, i)
+        assert np.array_equal(obs, z["obs"][i]), (name, i, np.nonzero(obs != z["obs"][i])[0][:8])
+        c = o.counters()[0]
+        assert (bool(c[4]), bool(c[5])) == tuple(bool(x) for x in z["status"][i]), (name, i)
+    assert z["done"].sum() >= 4
+
+
+@pytest.mark.parametrize("name", ORIG_SEQS)
+def test_original_layout_full_simulation_reproduces_reference_run(oracle_mod, name):
+    z, kw = load_seq(name)
+    o = oracle_mod.Oracle(n_envs=1, **kw)
+    o.set_ped_init(z["ped_init"])
+    for i in range(len(z["now"])):
+        if z["is_reset"][i]:
+            obs = o.reset()[0]
+        else:
+            obs, r, d, _ = o.step(z["action"][i][None, :], step_counter=[int(z["step_counter"][i])])
+            obs = obs[0]
+            assert r[0] == z["reward"][i] and bool(d[0]) == bool(z["done"][i]), (name, i)
+        assert np.array_equal(obs, z["obs"][i]), (name, i)

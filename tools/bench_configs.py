@@ -79,3 +79,6 @@ run_groups("config 5 as 4 stream groups", Config(n_envs=4096, n_peds=100, n_rays
 run("16384 x 20 peds x 360 rays on one GPU", Config(n_envs=16384, ped_cycle_ms=1400))
 run_groups("16384 x 20 peds x 360 rays as 4 stream groups", Config(n_envs=16384, ped_cycle_ms=1400), 4)
 run_groups("16384 envs, MFMA actor in the loop, 4 stream groups", Config(n_envs=16384, ped_cycle_ms=1400), 4, actor=True)
+run("obs_layout 1 (environment_stage_1_original, 363 inputs): 4096 x 20 peds x 360 rays", Config(n_envs=4096, ped_cycle_ms=1400, obs_layout=1))
+run_groups("obs_layout 1 as 4 stream groups", Config(n_envs=4096, ped_cycle_ms=1400, obs_layout=1), 4)
+run("obs_layout 1: 16384 envs", Config(n_envs=16384, ped_cycle_ms=1400, obs_layout=1))
