@@ -215,10 +215,10 @@ def concurrent_streams(want, device=0, candidates=None):
     pa.reset(); pb.reset()
     torch.cuda.synchronize(dev)
 
-    def t_chain(sa, sb, k=8):
+    def t_chain(sa, sb, k=16):
         pa.stream, pb.stream = sa, sb
         best = float("inf")
-        for _ in range(2):
+        for _ in range(3):            # best of three: host jitter only ever makes a pair look serialised
             torch.cuda.synchronize(dev)
             t0 = time.perf_counter()
             for _ in range(k):
@@ -331,6 +331,29 @@ class VecEnvGroups:
         cs = [e.counters() for e in self.envs]
         self.join()
         return torch.cat(cs, 0)
+
+    def returns(self):
+        """(return of the last finished episode, running return) float32 [N], gathered over the groups."""
+        rs = [e.returns() for e in self.envs]
+        self.join()
+        return torch.cat([r[0] for r in rs]), torch.cat([r[1] for r in rs])
+
+    def set_ped_init(self, xy):
+        xy = np.ascontiguousarray(xy, dtype=np.float64).reshape(self.N, self.cfg.n_peds, 2)
+        for g, e in enumerate(self.envs):
+            e.set_ped_init(xy[self.rows(g)])
+
+    def set_ped_preset_vel(self, v):
+        v = np.ascontiguousarray(v, dtype=np.float64).reshape(self.N, self.cfg.n_peds, 2)
+        for g, e in enumerate(self.envs):
+            e.set_ped_preset_vel(v[self.rows(g)])
+
+    def snapshot(self):
+        return [e.snapshot() for e in self.envs]
+
+    def restore(self, bufs):
+        for e, b in zip(self.envs, bufs):
+            e.restore(b)
 
     def episodes(self):
         """Total finished episodes over all groups (host int; synchronises)."""

@@ -22,9 +22,11 @@ from .rollout import EpisodeStats, evaluate
 from .td3 import Agent
 
 
-def make_env(scenario, n_envs, max_steps, seed, device):
+def make_env(scenario, n_envs, max_steps, seed, device, ped_vmax=None):
     if scenario == "training":
         cfg, init = presets.training(n_envs=n_envs, max_steps=max_steps, seed=seed)
+        if ped_vmax is not None:
+            cfg.ped_vmax = ped_vmax
         vel = None
     elif scenario == "bench":
         cfg, init, vel = Config(n_envs=n_envs, max_steps=max_steps, seed=seed, ped_cycle_ms=1400), None, None
@@ -41,7 +43,7 @@ def make_env(scenario, n_envs, max_steps, seed, device):
 
 def train(a):
     dev = a.device
-    env = make_env(a.scenario, a.envs, a.max_steps, a.seed, dev)
+    env = make_env(a.scenario, a.envs, a.max_steps, a.seed, dev, a.ped_vmax)
     agent = Agent(obs_dim=env.D, device="cuda:%d" % dev, seed=a.seed, batch_size=a.batch, memory_size=a.memory)
     if a.load:
         agent.load_models(*[os.path.join(a.load, "td3_%s_model_ep%d.pt" % (n, a.load_episode)) for n in ("actor", "critic1", "critic2")])
@@ -90,7 +92,7 @@ def train(a):
 
 
 def run_evaluation(a):
-    env = make_env(a.scenario, a.envs, a.max_steps, a.seed, a.device)
+    env = make_env(a.scenario, a.envs, a.max_steps, a.seed, a.device, a.ped_vmax)
     agent = Agent(obs_dim=env.D, device="cuda:%d" % a.device, seed=a.seed, memory_size=16)
     agent.load_models(*[os.path.join(a.load, "td3_%s_model_ep%d.pt" % (n, a.load_episode)) for n in ("actor", "critic1", "critic2")])
     st = evaluate(env, agent, episodes_per_env=a.episodes_per_env)
@@ -115,6 +117,7 @@ def main(argv=None):
     ap.add_argument("--memory", type=int, default=1_000_000, help="TRAIN:63")
     ap.add_argument("--checkpoint-every", type=int, default=100000, help="episodes between checkpoints (TRAIN:150: 100)")
     ap.add_argument("--log-every", type=int, default=100)
+    ap.add_argument("--ped-vmax", type=float, default=None, help="training world only: walker speed bound (CROWD:101 -> 0.2)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--out", default="runs/td3")

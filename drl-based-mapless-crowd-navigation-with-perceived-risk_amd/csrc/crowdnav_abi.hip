@@ -32,8 +32,9 @@ struct cn_env_s {
     int D, max_conf, trk_cap;
     size_t lds;
     CnKParams kp;        // template with state/table pointers filled in
-    double *d_lidar, *d_poly, *d_sd, *d_ped_p, *d_ped_v, *d_ped_init, *d_ped_preset, *d_trk;
-    int32_t* d_si;
+    double *d_lidar, *d_poly, *d_ped_init, *d_ped_preset, *d_trk;
+    char* d_state;          // N per-env records (crowdnav_kernel.h: sd | si | ped_p | ped_v | pad), `stride` bytes apart
+    size_t stride;
     std::vector<double> ped_init;
 };
 
@@ -84,6 +85,21 @@ static double angle_increment_deg(int R)
     return 360.0 / (double)(R - 1);
 }
 
+// One field of every env's record <-> a dense host array [N, width bytes]
+static int field_to_device(cn_env_s* h, size_t off, const void* host, size_t width)
+{
+    if (!width) return CN_OK;
+    HIPCHK(hipMemcpy2D(h->d_state + off, h->stride, host, width, width, (size_t)h->cfg.n_envs, hipMemcpyHostToDevice));
+    return CN_OK;
+}
+static int field_to_host(cn_env_s* h, size_t off, void* host, size_t width)
+{
+    if (!width) return CN_OK;
+    HIPCHK(hipMemcpy2D(host, width, h->d_state + off, h->stride, width, (size_t)h->cfg.n_envs, hipMemcpyDeviceToHost));
+    return CN_OK;
+}
+#define FIELD(call) do { int rc_ = (call); if (rc_ != CN_OK) return rc_; } while (0)
+
 static int upload_initial_state(cn_env_s* h)
 {
     const cn_config& c = h->cfg;
@@ -95,12 +111,12 @@ static int upload_initial_state(cn_env_s* h)
         s[CN_SD_RX] = c.spawn_x; s[CN_SD_RY] = c.spawn_y; s[CN_SD_RYAW] = c.spawn_yaw;
         s[CN_SD_WPX] = c.goal_x; s[CN_SD_WPY] = c.goal_y;
     }
-    HIPCHK(hipMemcpy(h->d_sd, sd.data(), sd.size() * 8, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(h->d_si, si.data(), si.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(h->d_state, 0, (size_t)N * h->stride));
+    FIELD(field_to_device(h, CN_ST_OFF_SD, sd.data(), CN_SD_COUNT * 8));
+    FIELD(field_to_device(h, CN_ST_OFF_SI, si.data(), CN_SI_COUNT * 4));
     if (P > 0) {
         HIPCHK(hipMemcpy(h->d_ped_init, h->ped_init.data(), (size_t)N * P * 16, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(h->d_ped_p, h->ped_init.data(), (size_t)N * P * 16, hipMemcpyHostToDevice));
-        HIPCHK(hipMemset(h->d_ped_v, 0, (size_t)N * P * 16));
+        FIELD(field_to_device(h, CN_ST_OFF_PED_P, h->ped_init.data(), (size_t)P * 16));
         HIPCHK(hipMemset(h->d_ped_preset, 0, (size_t)N * P * 16));
     }
     HIPCHK(hipMemset(h->d_trk, 0, (size_t)N * CN_TF_COUNT * h->trk_cap * 8));
@@ -144,10 +160,8 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
     HIPCHK(hipMemcpy(h->d_lidar, lidar.data(), lidar.size() * 8, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->d_poly, poly.data(), poly.size() * 8, hipMemcpyHostToDevice));
     size_t pb = (size_t)N * (P > 0 ? P : 1) * 16;
-    HIPCHK(hipMalloc(&h->d_sd, (size_t)N * CN_SD_COUNT * 8));
-    HIPCHK(hipMalloc(&h->d_si, (size_t)N * CN_SI_COUNT * 4));
-    HIPCHK(hipMalloc(&h->d_ped_p, pb));
-    HIPCHK(hipMalloc(&h->d_ped_v, pb));
+    h->stride = CN_ST_STRIDE(P);
+    HIPCHK(hipMalloc(&h->d_state, (size_t)N * h->stride));
     HIPCHK(hipMalloc(&h->d_ped_init, pb));
     HIPCHK(hipMalloc(&h->d_ped_preset, pb));
     HIPCHK(hipMalloc(&h->d_trk, (size_t)N * CN_TF_COUNT * h->trk_cap * 8));
@@ -168,7 +182,7 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
     k.start_x = c.start_x; k.start_y = c.start_y; k.spawn_x = c.spawn_x; k.spawn_y = c.spawn_y; k.spawn_yaw = c.spawn_yaw;
     k.waypoint_radius = c.waypoint_radius; k.goal_eps = c.goal_eps; k.angle_inc_deg = angle_increment_deg(R); k.lidar_step = step;
     k.lidar_c = h->d_lidar; k.lidar_s = h->d_lidar + R; k.ang_s = h->d_lidar + 2 * R; k.ang_c = h->d_lidar + 3 * R; k.poly_c = h->d_poly; k.poly_s = h->d_poly + 64;
-    k.sd = h->d_sd; k.si = h->d_si; k.ped_p = h->d_ped_p; k.ped_v = h->d_ped_v; k.ped_init = h->d_ped_init;
+    k.state = h->d_state; k.state_stride = (int64_t)h->stride; k.ped_init = h->d_ped_init;
     k.ped_preset = h->d_ped_preset; k.trk = h->d_trk;
     if (h->lds > 64 * 1024)
     {
@@ -187,8 +201,8 @@ extern "C" void cn_destroy(cn_handle h)
 {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    (void)hipFree(h->d_lidar); (void)hipFree(h->d_poly); (void)hipFree(h->d_sd); (void)hipFree(h->d_si);
-    (void)hipFree(h->d_ped_p); (void)hipFree(h->d_ped_v); (void)hipFree(h->d_ped_init); (void)hipFree(h->d_ped_preset);
+    (void)hipFree(h->d_lidar); (void)hipFree(h->d_poly); (void)hipFree(h->d_state);
+    (void)hipFree(h->d_ped_init); (void)hipFree(h->d_ped_preset);
     (void)hipFree(h->d_trk);
     delete h;
 }
@@ -215,7 +229,7 @@ extern "C" int cn_set_ped_init(cn_handle h, const double* xy)
     h->ped_init.assign(xy, xy + cnt);
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(h->d_ped_init, xy, cnt * 8, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(h->d_ped_p, xy, cnt * 8, hipMemcpyHostToDevice));
+    FIELD(field_to_device(h, CN_ST_OFF_PED_P, xy, (size_t)h->cfg.n_peds * 16));
     return CN_OK;
 }
 
@@ -360,19 +374,19 @@ extern "C" int cn_debug_env(cn_handle h, int env, double* scalars, double* robot
     HIPCHK(hipDeviceSynchronize());
     const int P = h->cfg.n_peds;
     std::vector<double> sd(CN_SD_COUNT);
-    HIPCHK(hipMemcpy(sd.data(), h->d_sd + (size_t)env * CN_SD_COUNT, CN_SD_COUNT * 8, hipMemcpyDeviceToHost));
+    const char* rec = h->d_state + (size_t)env * h->stride;
+    HIPCHK(hipMemcpy(sd.data(), rec + CN_ST_OFF_SD, CN_SD_COUNT * 8, hipMemcpyDeviceToHost));
     if (scalars) memcpy(scalars, sd.data(), CN_SD_COUNT * 8);
     if (robot_ped) {
         memcpy(robot_ped, sd.data(), 5 * 8);
         if (P > 0) {
-            HIPCHK(hipMemcpy(robot_ped + 5, h->d_ped_p + (size_t)env * 2 * P, (size_t)P * 16, hipMemcpyDeviceToHost));
-            HIPCHK(hipMemcpy(robot_ped + 5 + 2 * P, h->d_ped_v + (size_t)env * 2 * P, (size_t)P * 16, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(robot_ped + 5, rec + CN_ST_OFF_PED_P, (size_t)P * 32, hipMemcpyDeviceToHost));   // ped_p | ped_v
         }
     }
     if (tracks)
         HIPCHK(hipMemcpy(tracks, h->d_trk + (size_t)env * CN_TF_COUNT * h->trk_cap, CN_TF_COUNT * h->trk_cap * 8,
                          hipMemcpyDeviceToHost));
-    if (ints) HIPCHK(hipMemcpy(ints, h->d_si + (size_t)env * CN_SI_COUNT, CN_SI_COUNT * 4, hipMemcpyDeviceToHost));
+    if (ints) HIPCHK(hipMemcpy(ints, rec + CN_ST_OFF_SI, CN_SI_COUNT * 4, hipMemcpyDeviceToHost));
     return CN_OK;
 }
 
@@ -392,11 +406,11 @@ extern "C" int cn_snapshot(cn_handle h, void* buf, size_t size)
     HIPCHK(hipDeviceSynchronize());
     size_t N = h->cfg.n_envs, P = h->cfg.n_peds;
     char* q = (char*)buf;
-    HIPCHK(hipMemcpy(q, h->d_sd, N * CN_SD_COUNT * 8, hipMemcpyDeviceToHost)); q += N * CN_SD_COUNT * 8;
-    HIPCHK(hipMemcpy(q, h->d_si, N * CN_SI_COUNT * 4, hipMemcpyDeviceToHost)); q += N * CN_SI_COUNT * 4;
+    FIELD(field_to_host(h, CN_ST_OFF_SD, q, CN_SD_COUNT * 8)); q += N * CN_SD_COUNT * 8;
+    FIELD(field_to_host(h, CN_ST_OFF_SI, q, CN_SI_COUNT * 4)); q += N * CN_SI_COUNT * 4;
     if (P) {
-        HIPCHK(hipMemcpy(q, h->d_ped_p, N * P * 16, hipMemcpyDeviceToHost)); q += N * P * 16;
-        HIPCHK(hipMemcpy(q, h->d_ped_v, N * P * 16, hipMemcpyDeviceToHost)); q += N * P * 16;
+        FIELD(field_to_host(h, CN_ST_OFF_PED_P, q, P * 16)); q += N * P * 16;
+        FIELD(field_to_host(h, CN_ST_OFF_PED_V(P), q, P * 16)); q += N * P * 16;
     }
     HIPCHK(hipMemcpy(q, h->d_trk, N * CN_TF_COUNT * h->trk_cap * 8, hipMemcpyDeviceToHost));
     return CN_OK;
@@ -410,11 +424,11 @@ extern "C" int cn_restore(cn_handle h, const void* buf, size_t size)
     HIPCHK(hipDeviceSynchronize());
     size_t N = h->cfg.n_envs, P = h->cfg.n_peds;
     const char* q = (const char*)buf;
-    HIPCHK(hipMemcpy(h->d_sd, q, N * CN_SD_COUNT * 8, hipMemcpyHostToDevice)); q += N * CN_SD_COUNT * 8;
-    HIPCHK(hipMemcpy(h->d_si, q, N * CN_SI_COUNT * 4, hipMemcpyHostToDevice)); q += N * CN_SI_COUNT * 4;
+    FIELD(field_to_device(h, CN_ST_OFF_SD, q, CN_SD_COUNT * 8)); q += N * CN_SD_COUNT * 8;
+    FIELD(field_to_device(h, CN_ST_OFF_SI, q, CN_SI_COUNT * 4)); q += N * CN_SI_COUNT * 4;
     if (P) {
-        HIPCHK(hipMemcpy(h->d_ped_p, q, N * P * 16, hipMemcpyHostToDevice)); q += N * P * 16;
-        HIPCHK(hipMemcpy(h->d_ped_v, q, N * P * 16, hipMemcpyHostToDevice)); q += N * P * 16;
+        FIELD(field_to_device(h, CN_ST_OFF_PED_P, q, P * 16)); q += N * P * 16;
+        FIELD(field_to_device(h, CN_ST_OFF_PED_V(P), q, P * 16)); q += N * P * 16;
     }
     HIPCHK(hipMemcpy(h->d_trk, q, N * CN_TF_COUNT * h->trk_cap * 8, hipMemcpyHostToDevice));
     return CN_OK;

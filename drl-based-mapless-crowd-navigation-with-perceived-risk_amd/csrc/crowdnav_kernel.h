@@ -26,11 +26,11 @@ struct CnKParams {
     const double* ang_c;    // [R-1]
     const double* poly_c;   // [64] cos(-k*pi/32)
     const double* poly_s;   // [64]
-    // env state (device, library-owned)
-    double* sd;             // [N, CN_SD_COUNT]
-    int32_t* si;            // [N, CN_SI_COUNT]
-    double* ped_p;          // [N, P, 2]
-    double* ped_v;          // [N, P, 2]
+    // env state (device, library-owned).  One record per env, `state_stride` bytes (a multiple of 128) apart:
+    //   [ sd: CN_SD_COUNT f64 | si: CN_SI_COUNT i32 | ped_p: 2P f64 | ped_v: 2P f64 | pad ]
+    // so a wavefront's load/store of its env touches whole 128-byte lines only.
+    char* state;
+    int64_t state_stride;
     const double* ped_init; // [N, P, 2]
     const double* ped_preset; // [N, P, 2]
     double* trk;            // [N, trk_cap, CN_TF_COUNT]: one contiguous 96-byte record per track slot
@@ -48,6 +48,12 @@ struct CnKParams {
     int32_t* topk_idx;
     long long* timing;      // profiling build only: [N, 32] s_memtime stamps
 };
+
+#define CN_ST_OFF_SD 0
+#define CN_ST_OFF_SI (CN_SD_COUNT * 8)
+#define CN_ST_OFF_PED_P (CN_SD_COUNT * 8 + CN_SI_COUNT * 4)
+#define CN_ST_OFF_PED_V(P) (CN_ST_OFF_PED_P + 16 * (size_t)(P))
+#define CN_ST_STRIDE(P) ((CN_ST_OFF_PED_P + 32 * (size_t)(P) + 127) & ~(size_t)127)
 
 #ifdef __cplusplus
 extern "C" {

@@ -1078,8 +1078,9 @@ __device__ __forceinline__ void env_kernel_body(const CnKParams& p)
     pg.c0 = p.poly_c[lane]; pg.s0 = p.poly_s[lane]; pg.c1 = p.poly_c[(lane + 1) & 63]; pg.s1 = p.poly_s[(lane + 1) & 63];
 
     // ---- load env state -------------------------------------------------------------------------
-    double* sd = p.sd + (size_t)env * CN_SD_COUNT;
-    int* si = p.si + (size_t)env * CN_SI_COUNT;
+    char* rec = p.state + (size_t)env * (size_t)p.state_stride;
+    double* sd = (double*)(rec + CN_ST_OFF_SD);
+    int* si = (int*)(rec + CN_ST_OFF_SI);
     EnvRegs e;
     e.rx = sd[CN_SD_RX]; e.ry = sd[CN_SD_RY]; e.ryaw = sd[CN_SD_RYAW]; e.rv = sd[CN_SD_RV]; e.rw = sd[CN_SD_RW];
     e.clock = sd[CN_SD_CLOCK]; e.wpx = sd[CN_SD_WPX]; e.wpy = sd[CN_SD_WPY];
@@ -1093,8 +1094,8 @@ __device__ __forceinline__ void env_kernel_body(const CnKParams& p)
     e.nconf = si[CN_SI_NCONF]; e.nent = si[CN_SI_NENTRIES]; e.pending = si[CN_SI_PENDING_RESET]; e.episodes = si[CN_SI_EPISODES];
     e.crowd_ms = (long long)(((unsigned long long)(unsigned)si[CN_SI_CROWD_HI] << 32) | (unsigned)si[CN_SI_CROWD_LO]);
 
-    double* gped_p = p.ped_p + (size_t)env * 2 * P;
-    double* gped_v = p.ped_v + (size_t)env * 2 * P;
+    double* gped_p = (double*)(rec + CN_ST_OFF_PED_P);
+    double* gped_v = (double*)(rec + CN_ST_OFF_PED_V(P));
     const double* gped_init = p.ped_init + (size_t)env * 2 * P;
     double* pedv = L.pedv;  // velocities are only needed while advancing
     for (int i = lane; i < 2 * P; i += 64) { L.ped[i] = gped_p[i]; pedv[i] = gped_v[i]; }
@@ -1327,8 +1328,9 @@ extern "C" __global__ void cn_gather_kernel(CnKParams p, float* last_ret, float*
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= p.N) return;
-    const double* sd = p.sd + (size_t)i * CN_SD_COUNT;
-    const int* si = p.si + (size_t)i * CN_SI_COUNT;
+    const char* rec = p.state + (size_t)i * (size_t)p.state_stride;
+    const double* sd = (const double*)(rec + CN_ST_OFF_SD);
+    const int* si = (const int*)(rec + CN_ST_OFF_SI);
     if (last_ret) last_ret[i] = (float)sd[CN_SD_LAST_RETURN];
     if (run_ret) run_ret[i] = (float)sd[CN_SD_EP_RETURN];
     if (counters) {

@@ -232,6 +232,16 @@ def test_stream_groups_equal_one_handle(mode):
     torch.cuda.synchronize()
     assert torch.equal(free.obs, hist[-1][0]) and torch.equal(free.reward, hist[-1][1])
     assert free.episodes() == int(full.counters()[:, 8].sum().item())
+    assert torch.equal(free.returns()[0], full.returns()[0])
+    # snapshot / restore and pedestrian tables go through the groups too
+    snap = grp.snapshot()
+    o_a = grp.step(acts[0], auto_reset=mode)[0].clone()
+    grp.restore(snap)
+    assert torch.equal(grp.step(acts[0], auto_reset=mode)[0], o_a)
+    assert torch.equal(full.step(acts[0], auto_reset=mode)[0], o_a)
+    init = full.get_ped_init() + 0.01
+    full.set_ped_init(init); grp.set_ped_init(init)
+    assert torch.equal(full.reset(), grp.reset())
 
 
 def test_env_wrapper_has_reference_surface():
