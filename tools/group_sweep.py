@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 from crowdnav import Config
 from crowdnav.env import VecEnv, concurrent_streams
 
-def run(N, G, steps=300, mode="next"):
+def run(N, G, steps=300, mode=os.environ.get("CN_MODE", "next")):
     n = N // G
     envs = [VecEnv(Config(n_envs=n, env_index_base=i * n, ped_cycle_ms=1400)) for i in range(G)]
     acts = [torch.rand((n, 2), device="cuda") * 0.2 for _ in range(G)]
