@@ -70,6 +70,10 @@ def lib():
             if not os.path.exists(LIB_PATH):
                 raise CrowdNavError("libcrowdnav.so is not built (%s) and cannot be built here (%s); there is no CPU "
                                     "fallback" % (LIB_PATH, ex))
+        # PyTorch-ROCm ships its own HIP / ROCr runtime libraries; the caller's tensors live in THAT runtime.  Importing
+        # torch first makes libcrowdnav.so's libamdhip64 dependency resolve to the copy that is already loaded.  Loaded
+        # the other way round the process ends up with two runtimes and cn_create sees no device (CN_ERR_NO_DEVICE).
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         vp = C.c_void_p
         L.cn_abi_version.restype = C.c_int

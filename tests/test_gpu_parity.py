@@ -4,6 +4,8 @@ same seeded inputs, and against the golden runs the REFERENCE's own Python produ
 Bar (BASELINE.json north_star): obstacle indices and done flags bit-exact; float scan / reward within
 1e-5.  The simulator half (pedestrians, diff-drive, lidar) is bit-reproducible by construction
 (explicit fma, deterministic sincos), so in practice every observation value matches exactly."""
+import os
+
 import numpy as np
 import pytest
 
@@ -553,3 +555,15 @@ def test_error_codes_and_limits():
     import torch
     torch.cuda.synchronize()
     assert env.obs.shape == (2, 1023 + 7 + 32) and bool(torch.isfinite(env.obs).all())
+
+
+def test_build_then_smoke_in_one_process():
+    """The driver's order: build() (which loads libcrowdnav.so) and then smoke() in the same interpreter.  Regression
+    for a load-order trap: libcrowdnav.so loaded before torch used to bring up a second HIP runtime with no device."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build(); g.smoke()"], cwd=root,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "smoke OK" in r.stdout
