@@ -50,11 +50,25 @@ class CrowdNavError(RuntimeError):
 
 
 def build(force=False):
-    """Compile libcrowdnav.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    """Compile libcrowdnav.so for gfx950 (hipcc cross-compiles without a GPU).  Safe to call from several ranks
+    at once: the staleness check and the build run under a file lock and build.sh renames the finished library into
+    place, so no process ever maps a half-written file."""
+    import fcntl
     srcs = [os.path.join(_PKG, "csrc", f) for f in os.listdir(os.path.join(_PKG, "csrc"))]
     srcs.append(os.path.join(os.path.dirname(_PKG), "include", "crowdnav.h"))
-    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(s) for s in srcs):
-        subprocess.check_call(["bash", BUILD_SH])
+
+    def stale():
+        return force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(s) for s in srcs)
+
+    if stale():
+        os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
+        with open(os.path.join(os.path.dirname(LIB_PATH), ".build.lock"), "w") as lk:
+            fcntl.flock(lk, fcntl.LOCK_EX)
+            try:
+                if stale():          # another rank may have built it while we waited
+                    subprocess.check_call(["bash", BUILD_SH])
+            finally:
+                fcntl.flock(lk, fcntl.LOCK_UN)
     return LIB_PATH
 
 

@@ -8,7 +8,9 @@ OUT="$HERE/../lib"
 mkdir -p "$OUT"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-builtin-pow -Wall -Wno-unused-function"
-"$HIPCC" $FLAGS ${CN_EXTRA_FLAGS:-} -shared -o "$OUT/libcrowdnav.so" "$HERE/crowdnav_kernel.hip" "$HERE/crowdnav_abi.hip"
+# build next to the target and rename: a process that already mapped the old file keeps it, nobody maps a partial one
+"$HIPCC" $FLAGS ${CN_EXTRA_FLAGS:-} -shared -o "$OUT/.libcrowdnav.so.$$" "$HERE/crowdnav_kernel.hip" "$HERE/crowdnav_abi.hip"
+mv -f "$OUT/.libcrowdnav.so.$$" "$OUT/libcrowdnav.so"
 echo "built $OUT/libcrowdnav.so"
 if [ "${1:-}" = "timing" ]; then
   "$HIPCC" $FLAGS -DCN_TIMING -shared -o "$OUT/libcrowdnav_timing.so" "$HERE/crowdnav_kernel.hip" "$HERE/crowdnav_abi.hip"
