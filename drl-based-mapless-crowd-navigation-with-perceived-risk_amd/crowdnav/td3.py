@@ -84,10 +84,11 @@ class Agent:
         self.q1_t, self.q2_t = Critic(obs_dim, 2, hidden).to(self.device), Critic(obs_dim, 2, hidden).to(self.device)
         for t, s in ((self.actor_t, self.actor), (self.q1_t, self.q1), (self.q2_t, self.q2)):
             t.load_state_dict(s.state_dict())
-        fused = self.device.type == "cuda"        # one kernel per optimizer step instead of ~10 per parameter tensor
-        self.opt_a = torch.optim.Adam(self.actor.parameters(), lr=actor_lr, fused=fused)
-        self.opt_q1 = torch.optim.Adam(self.q1.parameters(), lr=critic_lr, fused=fused)
-        self.opt_q2 = torch.optim.Adam(self.q2.parameters(), lr=critic_lr, fused=fused)
+        fused = self.device.type == "cuda"        # one kernel per optimizer step instead of ~10 per parameter tensor;
+        kw = dict(fused=True) if fused else {}
+        self.opt_a = torch.optim.Adam(self.actor.parameters(), lr=actor_lr, **kw)
+        self.opt_q1 = torch.optim.Adam(self.q1.parameters(), lr=critic_lr, **kw)
+        self.opt_q2 = torch.optim.Adam(self.q2.parameters(), lr=critic_lr, **kw)
         self.memory = DeviceReplay(memory_size, obs_dim, self.device)
         self.batch_size, self.gamma, self.tau = batch_size, gamma, tau
         self.max_v, self.max_w = max_v, max_w
@@ -183,37 +184,42 @@ class Agent:
                 check(rc)
         return call
 
-    def learn(self, step, batch=None, target_noise=None):
-        """One TD3 update (TD3:225-285): clipped target-policy noise added to the target actor's action (the
-        reference does not re-clip the noisy action to the action bounds, TD3:244-247), min of the two target
-        critics, MSE critic losses with one Adam step each, and every `policy_delay` steps the actor step plus
-        the three soft updates.  `batch` = (s, a, r[B,1], s2, d[B,1]) and `target_noise` [B,2] (before the clip)
-        override the replay sample / the generator -- used by the parity test against the reference's update."""
-        if batch is None:
-            if len(self.memory) <= self.batch_size:
-                return None
-            batch = self.memory.sample(self.batch_size)
-        s, a, r, s2, d = batch
+    def _update(self, s, a, r, s2, d, target_noise, do_actor):
+        """The arithmetic of one TD3 update (TD3:225-285) on a given batch."""
         with torch.no_grad():
-            if target_noise is None:
-                target_noise = torch.randn(a.shape, generator=self.gen, device=self.device)
             noise = (target_noise * self.noise_std).clamp(-self.noise_clip, self.noise_clip)
-            a2 = self.actor_t(s2) + noise
+            a2 = self.actor_t(s2) + noise                       # not re-clipped to the action bounds (TD3:244-247)
             q_t = torch.min(self.q1_t(s2, a2), self.q2_t(s2, a2))
             y = r + (1.0 - d) * self.gamma * q_t
         l1 = F.mse_loss(self.q1(s, a), y)
         l2 = F.mse_loss(self.q2(s, a), y)
-        self.opt_q1.zero_grad(); l1.backward(); self.opt_q1.step()
-        self.opt_q2.zero_grad(); l2.backward(); self.opt_q2.step()
-        if step % self.policy_delay == 0:
+        self.opt_q1.zero_grad(set_to_none=True); l1.backward(); self.opt_q1.step()
+        self.opt_q2.zero_grad(set_to_none=True); l2.backward(); self.opt_q2.step()
+        if do_actor:
             la = -self.q1(s, self.actor(s)).mean()
-            self.opt_a.zero_grad(); la.backward(); self.opt_a.step()
+            self.opt_a.zero_grad(set_to_none=True); la.backward(); self.opt_a.step()
             with torch.no_grad():
                 for t, src in ((self.q1_t, self.q1), (self.q2_t, self.q2), (self.actor_t, self.actor)):
                     pt, ps = list(t.parameters()), list(src.parameters())
                     torch._foreach_mul_(pt, 1.0 - self.tau)                      # TD3:287-299: target*(1-tau) + local*tau
                     torch._foreach_add_(pt, torch._foreach_mul(ps, self.tau))
-        return float(l1.item())
+        return l1.detach()
+
+    def learn(self, step, batch=None, target_noise=None):
+        """One TD3 update (TD3:225-285): clipped target-policy noise added to the target actor's action (the
+        reference does not re-clip the noisy action to the action bounds, TD3:244-247), min of the two target
+        critics, MSE critic losses with one Adam step each, and every `policy_delay` steps the actor step plus
+        the three soft updates.  `batch` = (s, a, r[B,1], s2, d[B,1]) and `target_noise` [B,2] (before the clip)
+        override the replay sample / the generator -- used by the parity test against the reference's update.
+        Returns the first critic's loss as a 0-d tensor (no host synchronisation)."""
+        if batch is None:
+            if len(self.memory) <= self.batch_size:
+                return None
+            batch = self.memory.sample(self.batch_size)
+        s, a, r, s2, d = batch
+        if target_noise is None:
+            target_noise = torch.randn(a.shape, generator=self.gen, device=self.device)
+        return self._update(s, a, r, s2, d, target_noise, step % self.policy_delay == 0)
 
     def load_models(self, actor_path, critic1_path, critic2_path):
         """Agent.load_models (TD3:313-319): the reference's checkpoints are plain state_dicts with the same

@@ -567,3 +567,4 @@ def test_build_then_smoke_in_one_process():
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "smoke OK" in r.stdout
+
