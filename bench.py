@@ -48,6 +48,14 @@ def profiled_traffic():
         return None
 
 
+def baseline_metric():
+    """The metric string exactly as BASELINE.json spells it."""
+    try:
+        return json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+    except Exception:
+        return "env-steps/sec @4096 envs\u00d720 peds\u00d7360 rays; HBM GB/s vs roofline"
+
+
 def usable_cpus():
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:  # cgroup v2 CPU quota
@@ -207,7 +215,7 @@ def main():
     achieved_1 = B * N / (kernel_ms_1 * 1e-3) / 1e9
     traffic = profiled_traffic() if (a.envs, a.peds, a.rays) == (4096, 20, 360) else None
     out = {
-        "metric": "env-steps/sec @4096 envs x 20 peds x 360 rays; HBM GB/s vs roofline",
+        "metric": baseline_metric(),
         "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": wall / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
