@@ -139,3 +139,22 @@ def test_random_walker_velocity_law(oracle_mod):
         assert np.abs(pv).max() <= 0.2 and np.abs(pv).max() > 0.05     # CROWD:101-102 U(-0.2, 0.2)
     xy = o.get_ped_init()
     assert np.abs(xy).max() <= 1.30 and (np.hypot(xy[..., 0] - 1.0, xy[..., 1] + 1.0) >= 0.4).all()
+
+
+def test_rounding_restatements_match_python_and_numpy(oracle_mod):
+    """A29: round(float, nd) (correctly rounded decimal, what the harness runs the reference under) and
+    round(np.float64, nd) / np.around (multiply, rint, divide) -- on random values, on exact binary ties
+    (k/16 + 1/32 style dyadics such as 0.0625 -> 0.062) and on decimal near-ties (x.xxx5 literals)."""
+    L = oracle_mod.lib()
+    rng = np.random.default_rng(9)
+    xs = np.concatenate([rng.uniform(-3.5, 3.5, 20000), rng.uniform(-1e-3, 1e-3, 2000),
+                         np.arange(-2000, 2000) / 16.0 + 1.0 / 32.0,            # exact ties at 3 decimals? (0.03125 ...)
+                         np.arange(-4000, 4000) / 2000.0 + 0.0005,              # decimal half-way literals at 3 digits
+                         np.arange(-400, 400) / 200.0 + 0.005,                  # ... and at 2 digits
+                         np.array([0.0625, 0.1875, 2.5e-4, -0.0625, 0.5, 1.5, 2.5, 0.6, 0.105, 0.12, 1e-9, -1e-9])])
+    for nd in (2, 3):
+        for x in xs:
+            x = float(x)
+            assert L.cno_py_round(x, nd) == round(x, nd), (x, nd)
+            assert L.cno_np_around(x, nd) == float(np.around(np.float64(x), nd)), (x, nd)
+            assert L.cno_np_around(x, nd) == float(round(np.float64(x), nd)), (x, nd)
