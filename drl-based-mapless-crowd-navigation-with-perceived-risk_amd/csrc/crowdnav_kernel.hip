@@ -882,23 +882,39 @@ __device__ __forceinline__ void observe(const CnKParams& p, const Poly& pg, EnvR
         double bb0 = a0x - (gradient * a0y);
         int hi = (int)ceil(a0x + 3.5), lo = (int)floor(a0x - 3.5);
         double ego_prev = 0.0, ego_max = 0.0;
+        // The candidate segments agent -> (x2, y2), x2 = hi, hi-1, ... > lo (at most 8 of them, UTL:264-291), are the
+        // same for every track.  The polygon lies inside its circumscribed circle, so a segment whose closest
+        // point to the track's centre is farther than the radius (with slack) cannot touch any edge -> same
+        // "empty" result as running the ring test.  That pre-rejection is evaluated for 8 tracks x 8 candidates
+        // at once (lane = track * 8 + candidate); the serial part only visits the survivors, in x2 order.
+        u64 nearm = 0;
         for (int i = 0; i < nt; ++i) {  // ENV:818-860
-            double tx = TRK(CN_TF_PX, i), ty_ = TRK(CN_TF_PY, i), td = TRK(CN_TF_DIST, i);
-            int has = 0; double dcp = 0.0;
-            for (int x2 = hi; x2 > lo; --x2) {
-                double y2 = ((double)x2 * gradient) + bb0;
-                // The polygon lies inside its circumscribed circle: a segment whose closest point to the
-                // centre is farther than the radius (with slack) cannot touch any edge -> same "empty" result.
-                {   // squared distance from the centre to the segment, compared with r^2 without a divide
-                    const double ex = (double)x2 - a0x, ey = y2 - a0y, fx = tx - a0x, fy = ty_ - a0y;
+            if ((i & 7) == 0) {
+                const int ti = i + (lane >> 3), x2l = hi - (lane & 7);
+                bool nearc = false;
+                if (ti < nt && x2l > lo) {
+                    const double ctx = TRK(CN_TF_PX, ti), cty = TRK(CN_TF_PY, ti);
+                    const double y2l = ((double)x2l * gradient) + bb0;
+                    // squared distance from the centre to the segment, compared with r^2 without a divide
+                    const double ex = (double)x2l - a0x, ey = y2l - a0y, fx = ctx - a0x, fy = cty - a0y;
                     const double ee = ex * ex + ey * ey, ff = fx * fx + fy * fy, num = fx * ex + fy * ey;
                     const double rr2 = 0.178 * 0.178 * 1.000001;
                     bool far_;
                     if (num <= 0.0) far_ = ff > rr2;                                   // closest point is the agent
                     else if (num >= ee) far_ = (fx - ex) * (fx - ex) + (fy - ey) * (fy - ey) > rr2;  // ... the far end
                     else far_ = (ff - rr2) * ee > num * num * 1.000001;                // ... the foot of the perpendicular
-                    if (far_) continue;
+                    nearc = !far_;
                 }
+                nearm = __ballot(nearc);
+            }
+            double tx = TRK(CN_TF_PX, i), ty_ = TRK(CN_TF_PY, i), td = TRK(CN_TF_DIST, i);
+            int has = 0; double dcp = 0.0;
+            unsigned cand = (unsigned)((nearm >> (8 * (i & 7))) & 0xffull);   // bit c <-> x2 = hi - c
+            while (cand) {
+                const int c = __builtin_ctz(cand);
+                cand &= cand - 1u;
+                const int x2 = hi - c;
+                double y2 = ((double)x2 * gradient) + bb0;
                 double hx = 0.0, hy = 0.0;
                 unsigned long long m = ring_segment(pg, lane, tx, ty_, 0.178, a0x, a0y, (double)x2, y2, &hx, &hy);
                 int cnt = __popcll(m);
