@@ -768,6 +768,38 @@ __device__ __forceinline__ void observe(const CnKParams& p, const Poly& pg, EnvR
         } else {
             unsigned long long alive = 0ull;
             int cur = nt0;
+            if (nt0 <= 8 && nconf <= 8) {
+                // The usual case (a handful of tracks and confirmed objects): the whole IoU matrix in one pass,
+                // lane = track * 8 + object, arg-max inside each 8-lane group (first maximum wins, ENV:688-700),
+                // then lane = track applies its match.  Same arithmetic per pair as the general loop below.
+                const int ti = lane >> 3, oj = lane & 7;
+                double best = -1.0; int bj = 0x7fffffff;
+                if (ti < nt0 && oj < nconf) {
+                    best = cn_iou3(TRK(CN_TF_PX, ti), TRK(CN_TF_PY, ti), L.cfx[oj], L.cfy[oj], 0.0505);
+                    bj = oj;
+                }
+#pragma unroll
+                for (int m = 4; m >= 1; m >>= 1) {
+                    double ob = cn_shfl_xor_d(best, m);
+                    int ojx = __shfl_xor(bj, m, 64);
+                    if (ob > best || (ob == best && ojx < bj)) { best = ob; bj = ojx; }
+                }
+                const u64 posm = __ballot(best > 0.0);             // bit 8*i (any lane of group i): track i matched
+                const int mybj = __shfl(bj, (lane & 7) * 8, 64);   // lane i < 8 <- group i's winner
+                for (int i = 0; i < nt0; ++i) {                     // ENV:702-717, the order-dependent part (scalar)
+                    if ((posm >> (8 * i)) & 1ull) alive |= (1ull << i);
+                    else if (cur > i) cur -= 1;
+                    else alive |= (1ull << i);
+                }
+                if (lane < nt0 && ((posm >> (8 * lane)) & 1ull)) {  // ENV:702-712
+                    const int i = lane;
+                    double cxj = L.cfx[mybj], cyj = L.cfy[mybj];
+                    TRK(CN_TF_PX, i) = cxj; TRK(CN_TF_PY, i) = cyj; TRK(CN_TF_DIST, i) = L.cfd[mybj];
+                    if (TRK(CN_TF_DQLEN, i) < 1.5) { TRK(CN_TF_D1X, i) = cxj; TRK(CN_TF_D1Y, i) = cyj; TRK(CN_TF_DQLEN, i) = 2.0; }
+                    TRK(CN_TF_T, i) = now - TRK(CN_TF_T, i);
+                    L.checked[mybj] = 1;
+                }
+            } else
             for (int i = 0; i < nt0; ++i) {
                 double tx = TRK(CN_TF_PX, i), ty_ = TRK(CN_TF_PY, i);
                 double best = -1.0; int bj = 0x7fffffff;
