@@ -665,13 +665,22 @@ __device__ __forceinline__ void observe(const CnKParams& p, const Poly& pg, EnvR
     CN_SYNC();
     CN_T(11);
     // per-word running totals: types seen before word q, last segment end before word q
-    if (lane == 0) {
-        int bw = 0, bo = 0, le = -1;
-        for (int q = 0; q < W; ++q) {
-            L.wbase[q] = bw; L.wbase[L.wstride + q] = bo; L.wbase[2 * L.wstride + q] = le;
-            u64 sw = WORD(M_SEG, q);
-            bw += __popcll(WORD(M_KW, q)); bo += __popcll(WORD(M_KO, q));
-            if (sw) le = 64 * q + 63 - __builtin_clzll(sw);
+    {   // lane = word: exclusive prefix sums / prefix max across the (at most 17) words by shuffles
+        int pw = 0, po = 0, le = -1;
+        if (lane < W) {
+            const u64 sw = WORD(M_SEG, lane);
+            pw = __popcll(WORD(M_KW, lane)); po = __popcll(WORD(M_KO, lane));
+            if (sw) le = 64 * lane + 63 - __builtin_clzll(sw);
+        }
+        int sw_ = pw, so_ = po, sl_ = le;              // inclusive scans
+#pragma unroll
+        for (int d = 1; d < 32; d <<= 1) {              // CN_MAXW = 17 words <= 32 lanes
+            const int aw = __shfl_up(sw_, d, 64), ao = __shfl_up(so_, d, 64), al_ = __shfl_up(sl_, d, 64);
+            if (lane >= d) { sw_ += aw; so_ += ao; sl_ = max(sl_, al_); }
+        }
+        const int pl = __shfl_up(sl_, 1, 64);           // last segment end before this word
+        if (lane < W) {
+            L.wbase[lane] = sw_ - pw; L.wbase[L.wstride + lane] = so_ - po; L.wbase[2 * L.wstride + lane] = lane ? pl : -1;
         }
     }
     CN_SYNC();
@@ -1016,11 +1025,10 @@ __device__ __forceinline__ void observe(const CnKParams& p, const Poly& pg, EnvR
         if (step_counter >= p.max_steps) e.done = 1;
     }
     // ENV:1025-1042 observation tail
-    if (lane == 0) {
-        L.tail[0] = heading; L.tail[1] = distance_to_goal;
-        L.tail[2] = cn_py_round3(px); L.tail[3] = cn_py_round3(py);
-        L.tail[4] = cn_py_round3(yaw);
-        L.tail[5] = cn_py_round3(agent_vel_x); L.tail[6] = cn_py_round3(agent_vel_y);
+    if (lane < 7) {   // one rounding pass, lane = tail slot (heading and distance are already rounded)
+        const double v = lane == 2 ? px : lane == 3 ? py : lane == 4 ? yaw : lane == 5 ? agent_vel_x : agent_vel_y;
+        const double r = cn_py_round3(v);
+        L.tail[lane] = lane == 0 ? heading : lane == 1 ? distance_to_goal : r;
     }
     CN_SYNC();
     for (int i = lane; i < 7 + 4 * K; i += 64) {
