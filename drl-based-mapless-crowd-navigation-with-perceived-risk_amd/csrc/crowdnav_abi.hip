@@ -53,7 +53,7 @@ size_t cn_lds_bytes(int R, int P, int K, int max_conf, int trk_cap)
     b += 8 * (size_t)(CN_NMASK * Wn);             // bit words
     b += 8 * ((3 * Wn + 1) / 2);                  // wbase
     b += 8 * (size_t)(2 * P + 2) * 2;             // ped, pedv
-    b += 4 * (size_t)(P + 1);                     // nearidx
+    b += 24 * (size_t)(P + 1);                    // nearp
     return (b + 15) & ~(size_t)15;
 }
 

@@ -53,7 +53,7 @@ struct Lds {
     u64* w64;         // [M_COUNT][CN_MAXW] 64-ray bit words
     unsigned short* srcidx;  // [n] source ray of an aliased type entry
     int* wbase;       // [3][CN_MAXW]
-    int* nearidx;     // [P] pedestrians within lidar reach
+    double* nearp;    // [3 (P+1)] pedestrians within lidar reach: centre relative to the lidar origin (x, y) and |c|^2 - r^2
     double* ped;      // [2P] positions
     double* pedv;     // [2P] velocities
     double* trk;      // [CN_TF_COUNT][tcap]
@@ -249,17 +249,25 @@ __device__ __forceinline__ void sim_advance(const CnKParams& p, EnvRegs& e, int 
 // result is identical to testing all P (the oracle does).
 __device__ __forceinline__ int near_peds(const CnKParams& p, const Lds& L, int lane, double ox, double oy)
 {
+    // The list holds what the ray test needs (not indices): the inner loop then reads three independent values per
+    // pedestrian instead of chasing index -> position through two dependent LDS reads for every ray block.
     int nnear = 0;
     const double lim = p.lidar_max + p.ped_radius + 1e-6, lim2 = lim * lim;
+    const double rr = p.ped_radius * p.ped_radius;
     for (int j0 = 0; j0 < p.P; j0 += 64) {
         int j = j0 + lane;
         bool nr = false;
+        double ocx = 0.0, ocy = 0.0;
         if (j < p.P && !(CN_ABLATE(1))) {
-            double ocx = L.ped[2 * j] - ox, ocy = L.ped[2 * j + 1] - oy;
+            ocx = L.ped[2 * j] - ox; ocy = L.ped[2 * j + 1] - oy;
             nr = fma(ocx, ocx, ocy * ocy) <= lim2;
         }
         u64 m = __ballot(nr);
-        if (nr) L.nearidx[nnear + __popcll(m & ((1ull << lane) - 1ull))] = j;
+        if (nr) {
+            const int slot = nnear + __popcll(m & ((1ull << lane) - 1ull));
+            L.nearp[3 * slot] = ocx; L.nearp[3 * slot + 1] = ocy;
+            L.nearp[3 * slot + 2] = fma(ocx, ocx, fma(ocy, ocy, -rr));
+        }
         nnear += __popcll(m);
     }
     CN_SYNC();
@@ -274,7 +282,7 @@ __device__ __forceinline__ double cast_ray(const CnKParams& p, const Lds& L, int
     if constexpr (EXT) {
         return p.ext_ranges[(size_t)env * p.R + k];   // Gazebo / a physical lidar
     } else {
-        const double h = p.room_half, rr = p.ped_radius * p.ped_radius;
+        const double h = p.room_half;
         double t = INFINITY;
         const double lc = p.lidar_c[k], ls = p.lidar_s[k];  // ray k in the robot frame: host table of cn_det_sincos(k * step)
         double dx = fma(cy, lc, -(sy * ls));
@@ -291,10 +299,8 @@ __device__ __forceinline__ double cast_ray(const CnKParams& p, const Lds& L, int
         }
         if (t < p.lidar_min) t = p.lidar_min;
         for (int c = 0; c < nnear; ++c) {
-            int j = L.nearidx[c];
-            double ocx = L.ped[2 * j] - ox, ocy = L.ped[2 * j + 1] - oy;
+            const double ocx = L.nearp[3 * c], ocy = L.nearp[3 * c + 1], cc = L.nearp[3 * c + 2];
             double b = fma(ocx, dx, ocy * dy);
-            double cc = fma(ocx, ocx, fma(ocy, ocy, -rr));
             double disc = fma(b, b, -cc);
             if (disc >= 0.0) {
                 double sq = sqrt(disc);
@@ -1125,7 +1131,7 @@ __device__ __forceinline__ void env_kernel_body(const CnKParams& p)
         L.wbase = (int*)Cw; Cw += 8 * (size_t)((3 * Wn + 1) / 2);
         L.ped = (double*)Cw; Cw += 8 * (size_t)(2 * P + 2);
         L.pedv = (double*)Cw; Cw += 8 * (size_t)(2 * P + 2);
-        L.nearidx = (int*)Cw;
+        L.nearp = (double*)Cw;
         L.gtrk = p.trk + (size_t)env * CN_TF_COUNT * p.trk_cap;
     }
 

@@ -24,6 +24,8 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 env = VecEnv(Config(n_envs=N, ped_cycle_ms=1400, max_steps=100000)); env.reset()
 tb = torch.zeros((N, 32), dtype=torch.int64, device="cuda")
 env.L.cn_debug_set_timing(env.h, C.c_void_p(tb.data_ptr()))
+if os.environ.get("CN_ABLATE"):      # e.g. CN_ABLATE=1: no pedestrians in the ray cast (results invalid, timing only)
+    env.L.cn_debug_set_ablate(env.h, int(os.environ["CN_ABLATE"]))
 g = torch.Generator(device="cuda").manual_seed(1)
 acts = torch.stack([torch.rand((16, N), generator=g, device="cuda") * 0.22, torch.rand((16, N), generator=g, device="cuda") * 4 - 2], 2).contiguous()
 acc = np.zeros(20); cnt = 0; tot = []
