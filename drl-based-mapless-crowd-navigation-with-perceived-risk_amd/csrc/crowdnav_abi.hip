@@ -38,7 +38,7 @@ struct cn_env_s {
     std::vector<double> ped_init;
 };
 
-size_t cn_lds_bytes(int R, int P, int K, int max_conf, int trk_cap)
+static size_t lds_bytes_impl(int R, int P, int K, int max_conf, int trk_cap, bool near_separate)
 {
     // must mirror the carve in cn_env_kernel
     size_t n = (size_t)(R - 1), mc = (size_t)max_conf;
@@ -48,13 +48,28 @@ size_t cn_lds_bytes(int R, int P, int K, int max_conf, int trk_cap)
     size_t szB_c = 32 * mc + 8 * 64 + 8 * (size_t)(8 + 4 * K) + 4 * (size_t)CN_MAX_K;
     size_t szB = szB_g > szB_c ? szB_g : szB_c;
     if (szB < 8 * 64) szB = 8 * 64;
+    if (!near_separate && szB < 24 * (size_t)(P + 1)) szB = 24 * (size_t)(P + 1);   // near-pedestrian list overlaid on region B
     size_t Wn = (n + 63) >> 6;
     size_t b = szA + szB;
     b += 8 * (size_t)(CN_NMASK * Wn);             // bit words
     b += 8 * ((3 * Wn + 1) / 2);                  // wbase
     b += 8 * (size_t)(2 * P + 2) * 2;             // ped, pedv
-    b += 24 * (size_t)(P + 1);                    // nearp
+    if (near_separate) b += 24 * (size_t)(P + 1); // near-pedestrian list in its own region
     return (b + 15) & ~(size_t)15;
+}
+
+// The near-pedestrian list (ray loop only) gets its own LDS region when that costs no resident wavefront -- measured
+// 1.5 % faster than sharing region B with the gradients -- and is overlaid on region B otherwise (100 pedestrians x 720
+// rays: 8 instead of 7 wavefronts per CU).
+static int waves_per_cu(size_t lds) { size_t w = (160 * 1024) / (lds ? lds : 1); return (int)(w > 16 ? 16 : w); }
+int cn_near_separate(int R, int P, int K, int max_conf, int trk_cap)
+{
+    return waves_per_cu(lds_bytes_impl(R, P, K, max_conf, trk_cap, true)) ==
+           waves_per_cu(lds_bytes_impl(R, P, K, max_conf, trk_cap, false));
+}
+size_t cn_lds_bytes(int R, int P, int K, int max_conf, int trk_cap)
+{
+    return lds_bytes_impl(R, P, K, max_conf, trk_cap, cn_near_separate(R, P, K, max_conf, trk_cap) != 0);
 }
 
 extern "C" int cn_abi_version(void) { return CN_ABI_VERSION; }
@@ -175,6 +190,7 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
     k.N = N; k.P = P; k.R = R; k.K = K;
     k.max_steps = c.max_steps; k.ped_mode = c.ped_mode; k.dt_ms = c.dt_ms; k.scan_latency_ms = c.scan_latency_ms;
     k.settle_ms = c.settle_ms; k.ped_cycle_ms = c.ped_cycle_ms; k.ped_stagger_ms = c.ped_stagger_ms;
+    k.near_sep = cn_near_separate(R, P, K, h->max_conf, h->trk_cap);
     k.max_conf = h->max_conf; k.trk_cap = h->trk_cap; k.env_index_base = c.env_index_base; k.seed = c.seed;
     k.room_half = c.room_half; k.ped_radius = c.ped_radius; k.ped_vmax = c.ped_vmax; k.robot_clearance = c.robot_clearance;
     k.lidar_min = c.lidar_min; k.lidar_max = c.lidar_max; k.lidar_offset_x = c.lidar_offset_x;

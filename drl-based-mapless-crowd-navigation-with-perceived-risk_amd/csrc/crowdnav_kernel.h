@@ -12,6 +12,7 @@ struct CnKParams {
     int32_t N, P, R, K;
     int32_t max_steps, ped_mode, dt_ms, scan_latency_ms, settle_ms, ped_cycle_ms, ped_stagger_ms;
     int32_t mode, auto_reset, max_conf, trk_cap;
+    int32_t near_sep;        // near-pedestrian list: 1 = own LDS region, 0 = overlaid on region B (cn_near_separate)
     int32_t ablate;          // PROFILING ONLY (cn_debug_set_ablate): skips stages, results are then invalid
     int64_t env_index_base;
     uint64_t seed;
@@ -59,6 +60,7 @@ struct CnKParams {
 extern "C" {
 #endif
 size_t cn_lds_bytes(int R, int P, int K, int max_conf, int trk_cap);
+int cn_near_separate(int R, int P, int K, int max_conf, int trk_cap);
 #ifdef __cplusplus
 }
 #endif

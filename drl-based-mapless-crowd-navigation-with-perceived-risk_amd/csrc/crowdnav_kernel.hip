@@ -1113,6 +1113,7 @@ __device__ __forceinline__ void env_kernel_body(const CnKParams& p)
         const size_t szB_c = 32 * mc + 8 * 64 + 8 * (size_t)(8 + 4 * K) + 4 * (size_t)CN_MAX_K;
         size_t szB = szB_g > szB_c ? szB_g : szB_c;
         if (szB < 8 * 64) szB = 8 * 64;
+        if (!p.near_sep && szB < 24 * (size_t)(P + 1)) szB = 24 * (size_t)(P + 1);   // near-pedestrian list overlaid on B
         char* A = smem;
         char* B = A + szA;
         char* Cw = B + szB;
@@ -1131,7 +1132,7 @@ __device__ __forceinline__ void env_kernel_body(const CnKParams& p)
         L.wbase = (int*)Cw; Cw += 8 * (size_t)((3 * Wn + 1) / 2);
         L.ped = (double*)Cw; Cw += 8 * (size_t)(2 * P + 2);
         L.pedv = (double*)Cw; Cw += 8 * (size_t)(2 * P + 2);
-        L.nearp = (double*)Cw;
+        L.nearp = p.near_sep ? (double*)Cw : (double*)B;   // ray loop only: region B is dead until the gradients are written
         L.gtrk = p.trk + (size_t)env * CN_TF_COUNT * p.trk_cap;
     }
 
