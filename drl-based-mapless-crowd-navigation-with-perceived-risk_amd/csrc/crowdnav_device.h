@@ -152,6 +152,24 @@ __device__ __forceinline__ double cn_iou3(double ax, double ay, double bx, doubl
     return cn_py_round3(inter / uni);
 }
 
+// round(IoU, 3) > 0 without the divide in the common cases.  The boxes either do not overlap (IoU = 0) or overlap
+// well: inter > 0.00075 * union means the quotient exceeds 0.00075 (1 - 2^-52), which rounds to >= 0.001.  Only the
+// sliver in between takes the exact path, so the result equals cn_iou3(...) > 0.0 always.
+__device__ __forceinline__ bool cn_iou3_positive(double ax, double ay, double bx, double by, double half)
+{
+    double axp = ax + half, axm = ax - half, ayp = ay + half, aym = ay - half;
+    double bxp = bx + half, bxm = bx - half, byp = by + half, bym = by - half;
+    double ix = fmin(axp, bxp) - fmax(axm, bxm);
+    double iy = fmin(ayp, byp) - fmax(aym, bym);
+    if (!(ix > 0.0 && iy > 0.0)) return false;
+    double inter = ix * iy;
+    double area_a = (axp - axm) * (ayp - aym);
+    double area_b = (bxp - bxm) * (byp - bym);
+    double uni = area_a + area_b - inter;
+    if (inter > 0.00075 * uni) return true;
+    return cn_py_round3(inter / uni) > 0.0;
+}
+
 // ---- wave64 helpers ---------------------------------------------------------------------------
 __device__ __forceinline__ double cn_shfl_xor_d(double v, int m)
 {

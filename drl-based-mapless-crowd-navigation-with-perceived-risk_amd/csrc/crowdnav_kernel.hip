@@ -628,7 +628,7 @@ __device__ __forceinline__ void observe(const CnKParams& p, const Poly& pg, EnvR
         bool brk = false;
         if (i < n) {
             brk = true;
-            if (i < n - 1) brk = !(cn_iou3(PX(i), PY(i), PX(i + 1), PY(i + 1), e.bb) > 0.0);
+            if (i < n - 1) brk = !cn_iou3_positive(PX(i), PY(i), PX(i + 1), PY(i + 1), e.bb);
         }
         u64 bw = __ballot(brk);
         if (lane == 0) WORD(M_BRK, q) = bw;
@@ -641,7 +641,7 @@ __device__ __forceinline__ void observe(const CnKParams& p, const Poly& pg, EnvR
     }
     const int ls = lb + 1;            // start of the last segment
     // ENV:490-502 first <-> last with twice the box
-    bool merge = (nsegs0 > 1) && (cn_iou3(PX(0), PY(0), PX(n - 1), PY(n - 1), e.bb * 2) > 0.0);
+    bool merge = (nsegs0 > 1) && cn_iou3_positive(PX(0), PY(0), PX(n - 1), PY(n - 1), e.bb * 2);
     CN_SYNC();
     CN_T(10);
     // order-space: position k -> ray.  merged: [0..fe] ++ [ls..n-1] ++ [fe+1..ls-1]
