@@ -671,19 +671,21 @@ __device__ __forceinline__ void observe(const CnKParams& p, const Poly& pg, EnvR
     CN_SYNC();
     CN_T(11);
     // per-word running totals: types seen before word q, last segment end before word q
+    int segbase = 0;
     {   // lane = word: exclusive prefix sums / prefix max across the (at most 17) words by shuffles
-        int pw = 0, po = 0, le = -1;
+        int pw = 0, po = 0, le = -1, ps = 0;
         if (lane < W) {
             const u64 sw = WORD(M_SEG, lane);
-            pw = __popcll(WORD(M_KW, lane)); po = __popcll(WORD(M_KO, lane));
+            pw = __popcll(WORD(M_KW, lane)); po = __popcll(WORD(M_KO, lane)); ps = __popcll(sw);
             if (sw) le = 64 * lane + 63 - __builtin_clzll(sw);
         }
-        int sw_ = pw, so_ = po, sl_ = le;              // inclusive scans
+        int sw_ = pw, so_ = po, sl_ = le, ss_ = ps;    // inclusive scans
 #pragma unroll
         for (int d = 1; d < 32; d <<= 1) {              // CN_MAXW = 17 words <= 32 lanes
-            const int aw = __shfl_up(sw_, d, 64), ao = __shfl_up(so_, d, 64), al_ = __shfl_up(sl_, d, 64);
-            if (lane >= d) { sw_ += aw; so_ += ao; sl_ = max(sl_, al_); }
+            const int aw = __shfl_up(sw_, d, 64), ao = __shfl_up(so_, d, 64), al_ = __shfl_up(sl_, d, 64), as_ = __shfl_up(ss_, d, 64);
+            if (lane >= d) { sw_ += aw; so_ += ao; sl_ = max(sl_, al_); ss_ += as_; }
         }
+        segbase = ss_ - ps;                             // lane q: segment ends before word q
         const int pl = __shfl_up(sl_, 1, 64);           // last segment end before this word
         if (lane < W) {
             L.wbase[lane] = sw_ - pw; L.wbase[L.wstride + lane] = so_ - po; L.wbase[2 * L.wstride + lane] = lane ? pl : -1;
@@ -691,17 +693,27 @@ __device__ __forceinline__ void observe(const CnKParams& p, const Poly& pg, EnvR
     }
     CN_SYNC();
     CN_T(12);
-    // ENV:568-620 confirmation: every lane that owns a segment end evaluates its segment
+    // ENV:568-620 confirmation.  The segment ends (a few dozen at most) are first compacted into one list, in order,
+    // so that ONE pass with lane = segment evaluates them all (instead of one pass per 64-ray word, each executing the
+    // whole body for its handful of segment-end lanes).  The list lives in the flag words, dead since the type machine.
     int nconf = 0;
-    for (int q = 0; q < ((CN_ABLATE(4)) ? 0 : W); ++q) {
-        const int k = lane + 64 * q;
-        const u64 sw = uni64(WORD(M_SEG, q));
+    unsigned short* seglist = (unsigned short*)&WORD(M_NONE, 0);
+    const int segcap = min(64, 20 * W);
+    for (int c0 = 0; c0 < ((CN_ABLATE(4)) ? 0 : nseg); c0 += segcap) {
+        for (int q = 0; q < W; ++q) {
+            const u64 sw = uni64(WORD(M_SEG, q));
+            const int r = __shfl(segbase, q, 64) + __popcll(sw & ((1ull << lane) - 1ull)) - c0;
+            if (((sw >> lane) & 1ull) && r >= 0 && r < segcap) seglist[r] = (unsigned short)(lane + 64 * q);
+        }
+        CN_SYNC();
         int obj = -1, m = 0; double dm = 0.0;
-        if ((sw >> lane) & 1ull) {
-            const u64 low = sw & ((1ull << lane) - 1ull);
+        if (lane < min(segcap, nseg - c0)) {
+            const int k = seglist[lane], q = k >> 6, bl = k & 63;
+            const u64 sw = WORD(M_SEG, q);
+            const u64 low = sw & ((1ull << bl) - 1ull);
             const int pe = low ? (64 * q + 63 - __builtin_clzll(low)) : L.wbase[2 * L.wstride + q];  // previous segment end
             const int k0 = pe + 1, len = k - pe;
-            const u64 incl = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+            const u64 incl = (bl == 63) ? ~0ull : ((2ull << bl) - 1ull);
             int cw = L.wbase[q] + __popcll(WORD(M_KW, q) & incl);
             int co = L.wbase[L.wstride + q] + __popcll(WORD(M_KO, q) & incl);
             if (pe >= 0) {
@@ -711,7 +723,7 @@ __device__ __forceinline__ void observe(const CnKParams& p, const Poly& pg, EnvR
                 co -= L.wbase[L.wstride + qp] + __popcll(WORD(M_KO, qp) & inclp);
             }
             const int no = co, nw = cw, nn = len - no - nw;
-            const bool occ = (WORD(M_OCC, q) >> lane) & 1ull;  // segments are homogeneous after the split
+            const bool occ = (WORD(M_OCC, q) >> bl) & 1ull;  // segments are homogeneous after the split
             if (occ && len >= 4) {
                 m = ORDER(k0 + len / 2);  // ENV:577 Python-2 integer division
                 dm = cn_div1000((double)L.dmil[m]);
@@ -735,6 +747,7 @@ __device__ __forceinline__ void observe(const CnKParams& p, const Poly& pg, EnvR
             if (slot < p.max_conf) { L.cft[slot] = obj; L.cfx[slot] = PX(m); L.cfy[slot] = PY(m); L.cfd[slot] = dm; }
         }
         nconf += __popcll(cwd);
+        CN_SYNC();
     }
     if (nconf > p.max_conf) { nconf = p.max_conf; e.status |= CN_ST_CONF_OVERFLOW; }
 #undef ORDER
