@@ -168,7 +168,6 @@ __device__ __forceinline__ void ped_advance(const CnKParams& p, int env, int lan
     if (ph64 >= T) { cyc += 1; ph64 -= T; }
     const int ph = (int)ph64;
     const int dt = (int)(t1 - t0);
-    const uint64_t hbase = cn_mix64(p.seed ^ cn_mix64((uint64_t)gid));   // env part of the RNG key
     for (int i = lane; i < p.P; i += 64) {
         double x = ped_p[2 * i], y = ped_p[2 * i + 1];
         double vx = ped_v[2 * i], vy = ped_v[2 * i + 1];
@@ -194,7 +193,9 @@ __device__ __forceinline__ void ped_advance(const CnKParams& p, int env, int lan
                 y = cn_clamp(fma(vy, ds, y), lo, hi);
                 tc = a;
             }
-            if (p.ped_mode == 0) {  // CROWD:101-102: cn_rng_u01(seed, gid, 1, i, 2m | 2m+1) with the shared prefix hoisted
+            if (p.ped_mode == 0) {  // CROWD:101-102: cn_rng_u01(seed, gid, 1, i, 2m | 2m+1); the env part of the key is
+                // only computed when some pedestrian of the wave really draws (most 10 ms advances have none)
+                const uint64_t hbase = cn_mix64(p.seed ^ cn_mix64((uint64_t)gid));
                 const uint64_t h1 = cn_mix64(hbase ^ ((1ull << 32) | (uint64_t)(uint32_t)i));
                 const double u0 = (double)(cn_mix64(h1 ^ (uint64_t)(uint32_t)(2u * m)) >> 11) * (1.0 / 9007199254740992.0);
                 const double u1 = (double)(cn_mix64(h1 ^ (uint64_t)(uint32_t)(2u * m + 1u)) >> 11) * (1.0 / 9007199254740992.0);
