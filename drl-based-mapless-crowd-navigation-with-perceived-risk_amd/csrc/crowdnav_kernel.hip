@@ -509,43 +509,62 @@ __device__ __forceinline__ void observe(const CnKParams& p, const Poly& pg, EnvR
 #define PX(i) cn_div1000((double)L.ptx[i])
 #define PY(i) cn_div1000((double)L.pty[i])
 #define GNONE 0x7fffffff
-    // ENV:329-346 gradients between consecutive end points, kept as integer thousandths (GNONE = None)
-    int lastnn = -1;
-    for (int i = lane; i < n; i += 64) {
-        int gm = GNONE;
-        if (L.dmil[i] != 600) {
-            int j = (i == n - 1) ? 0 : i + 1;
-            double dy = PY(i) - PY(j);
-            double q = (dy == 0) ? 0.0 : (PX(i) - PX(j)) / dy;
-            gm = (int)cn_round_scaled(q, 1000.0);
-            if (i < n - 1) lastnn = i;
-        }
-        L.gq[i] = gm;
+    // ENV:329-346 gradients between consecutive end points, kept as integer thousandths (GNONE = None), and
+    // ENV:348-367 the flag words of the type machine.  Only OCCUPIED rays (range != 0.6, typically a third of the scan)
+    // have a gradient, and the machine only looks at rays whose own and next gradient exist -- so the occupied rays are
+    // compacted into one list first and both computations run over that list (2 dense passes instead of 6 sparse ones).
+    // Flag bits of list entries are merged into the ray-space words with LDS atomics; rays outside the list keep
+    // none = 1 (their other flags are never read: the machine masks everything with ~none).
+    unsigned short* occlist = L.srcidx;            // free until the type machine records alias sources
+    int nocc = 0;
+    for (int q = 0; q < W; ++q) {
+        const int i = lane + 64 * q;
+        const bool oc = (i < n) && (L.dmil[i] != 600);
+        if (i < n) L.gq[i] = GNONE;
+        const u64 bo = __ballot(oc);
+        if (oc) occlist[nocc + __popcll(bo & ((1ull << lane) - 1ull))] = (unsigned short)i;
+        nocc += __popcll(bo);
     }
-    lastnn = cn_wave_max_i(lastnn);
+    if (lane < W) { WORD(M_NONE, lane) = ~0ull; WORD(M_ZERO, lane) = 0ull; WORD(M_EQ, lane) = 0ull; WORD(M_NNONE, lane) = 0ull; WORD(M_NZERO, lane) = 0ull; }
     CN_SYNC();
-    // ENV:348-367 change of gradient c[i] = |g[i]-g[i+1]| (None if either is None), recomputed where needed;
+    for (int c = lane; c < nocc; c += 64) {
+        const int i = occlist[c];
+        const int j = (i == n - 1) ? 0 : i + 1;
+        double dy = PY(i) - PY(j);
+        double q = (dy == 0) ? 0.0 : (PX(i) - PX(j)) / dy;
+        L.gq[i] = (int)cn_round_scaled(q, 1000.0);
+    }
+    // last occupied ray before n-1 (ENV:356-366 `last_grad`)
+    int lastnn = -1;
+    if (nocc > 0) {
+        lastnn = occlist[nocc - 1];
+        if (lastnn == n - 1) lastnn = (nocc > 1) ? (int)occlist[nocc - 2] : -1;
+    }
+    CN_SYNC();
+    // change of gradient c[i] = |g[i]-g[i+1]| (None if either is None), recomputed where needed;
     // ray n-1 takes `last_grad`, i.e. c[lastnn] of the last valid gradient before it.
 #define CHG(a_, b_) (((a_) == GNONE || (b_) == GNONE) ? CN_NAN : fabs(cn_div1000((double)(a_)) - cn_div1000((double)(b_))))
     double clast = CN_NAN;
     if (L.gq[n - 1] != GNONE && lastnn >= 0) clast = CHG(L.gq[lastnn], L.gq[lastnn + 1]);
     CN_T(6);
-    // flag words for the type machine
-    for (int q = 0; q < W; ++q) {
-        int i = lane + 64 * q;
-        bool none = true, zero = false, eq = false, nnone = true, nzero = false;
+    for (int c = lane; c < nocc; c += 64) {
+        const int i = occlist[c];
         if (i < n - 1) {  // the machine never visits ray n-1 (ENV:380-381)
             int g0 = L.gq[i], g1 = L.gq[i + 1];
             double c0 = CHG(g0, g1);
-            double c1 = (i + 1 < n - 1) ? CHG(g1, L.gq[i + 2]) : clast;
-            none = !(c0 == c0);
-            zero = (c0 == 0);
-            nnone = !(c1 == c1);
-            nzero = (c1 == 0);
-            eq = !none && !nnone && (fabs(c0 - c1) == 0);
+            if (c0 == c0) {                               // none = 0: the only rays the machine reads flags of
+                double c1 = (i + 1 < n - 1) ? CHG(g1, L.gq[i + 2]) : clast;
+                const bool zero = (c0 == 0), nnone = !(c1 == c1), nzero = (c1 == 0);
+                const bool eq = !nnone && (fabs(c0 - c1) == 0);
+                const u64 bit = 1ull << (i & 63);
+                const int qw = i >> 6;
+                atomicAnd((unsigned long long*)&WORD(M_NONE, qw), ~bit);
+                if (zero) atomicOr((unsigned long long*)&WORD(M_ZERO, qw), bit);
+                if (eq) atomicOr((unsigned long long*)&WORD(M_EQ, qw), bit);
+                if (nnone) atomicOr((unsigned long long*)&WORD(M_NNONE, qw), bit);
+                if (nzero) atomicOr((unsigned long long*)&WORD(M_NZERO, qw), bit);
+            }
         }
-        u64 b0 = __ballot(none), b1 = __ballot(zero), b2 = __ballot(eq), b3 = __ballot(nnone), b4 = __ballot(nzero);
-        if (lane == 0) { WORD(M_NONE, q) = b0; WORD(M_ZERO, q) = b1; WORD(M_EQ, q) = b2; WORD(M_NNONE, q) = b3; WORD(M_NZERO, q) = b4; }
     }
 #undef CHG
     CN_SYNC();
