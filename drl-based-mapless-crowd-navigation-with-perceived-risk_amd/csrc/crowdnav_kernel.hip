@@ -633,11 +633,20 @@ __device__ __forceinline__ void observe(const CnKParams& p, const Poly& pg, EnvR
     CN_T(8);
     // ENV:433-445: a typed ray carries the range and pose of the ray its list was created at.  In place:
     // only aliased rays change, and the rays they copy from are never aliased themselves.
-    for (int i = lane; i < n; i += 64) {
-        if (BIT(M_ALIAS, i)) {
-            int s_ = L.srcidx[i];
-            L.dmil[i] = L.dmil[s_]; L.ptx[i] = L.ptx[s_]; L.pty[i] = L.pty[s_];
+    for (int q = 0; q < W; ++q) {
+        const int i = lane + 64 * q;
+        unsigned short dm = 600;
+        if (i < n) {
+            dm = L.dmil[i];
+            if (BIT(M_ALIAS, i)) {
+                int s_ = L.srcidx[i];
+                dm = L.dmil[s_];
+                L.dmil[i] = dm; L.ptx[i] = L.ptx[s_]; L.pty[i] = L.pty[s_];
+            }
         }
+        // ray-space occupancy (range != 0.6) for the order/split words, in a flag-word slot that is dead by now
+        const u64 bo = __ballot((i < n) && (dm != 600));
+        if (lane == 0) WORD(M_NNONE, q) = bo;
     }
     CN_SYNC();
     CN_T(9);
@@ -667,26 +676,56 @@ __device__ __forceinline__ void observe(const CnKParams& p, const Poly& pg, EnvR
     // order-space: position k -> ray.  merged: [0..fe] ++ [ls..n-1] ++ [fe+1..ls-1]
     const int nl = n - ls;  // length of the last segment
 #define ORDER(k) (merge ? ((k) <= fe ? (k) : ((k) <= fe + nl ? ls + ((k) - fe - 1) : (k) - nl)) : (k))
-    // ENV:508-566 split where free space (0.6) meets occupied; per-position words in order space
+    // ENV:508-566 split where free space (0.6) meets occupied; per-position words in order space.
+    // Order space is the ray sequence with three ranges moved ([0..fe] ++ [ls..n-1] ++ [fe+1..ls-1]), so the words are
+    // built by lane = word with 64-bit field moves (two source words + a funnel shift per range) instead of one
+    // pass per word with five LDS reads per ray.
     int nseg = 0;
-    for (int q = 0; q < W; ++q) {
-        int k = lane + 64 * q;
-        bool se = false, kw = false, ko = false, oc = false;
-        if (k < n) {
-            int ray = ORDER(k);
-            if (!merge) se = BIT(M_BRK, ray);
-            else if (k <= fe + nl) se = (k == fe + nl);
-            else se = BIT(M_BRK, ray);
-            oc = (L.dmil[ray] != 600);
-            if (!se && k < n - 1) {
-                bool oc1 = (L.dmil[ORDER(k + 1)] != 600);
-                if (oc != oc1) se = true;
-            }
-            kw = BIT(M_ISW, ray); ko = BIT(M_ISO, ray);
+    {
+        // 64 bits of mask `id` starting at ray `pos` (bits past the last word read as 0)
+        auto extract = [&](int id, int pos) -> u64 {
+            const int w = pos >> 6, bsh = pos & 63;
+            u64 v = WORD(id, w) >> bsh;
+            if (bsh && w + 1 < W) v |= WORD(id, w + 1) << (64 - bsh);
+            return v;
+        };
+        // order positions [o0, o1] <- rays s0.., restricted to word q
+        auto piece = [&](int id, int q, int o0, int o1, int s0) -> u64 {
+            const int lo = max(o0, 64 * q), hi = min(o1, 64 * q + 63);
+            if (lo > hi) return 0ull;
+            const int len = hi - lo + 1;
+            u64 bits = extract(id, s0 + (lo - o0));
+            if (len < 64) bits &= (1ull << len) - 1ull;
+            return bits << (lo - 64 * q);
+        };
+        auto gather = [&](int id, int q) -> u64 {
+            if (!merge) return WORD(id, q);
+            return piece(id, q, 0, fe, 0) | piece(id, q, fe + 1, fe + nl, ls) | piece(id, q, fe + nl + 1, n - 1, fe + 1);
+        };
+        // W <= 16 words (R <= 1025): lane group g = lane / 16 gathers one mask (occupancy, wall type, obstacle type,
+        // breaks), word q = lane % 16
+        const int g = lane >> 4, q = lane & 15;
+        const int gid = g == 0 ? M_NNONE : (g == 1 ? M_ISW : (g == 2 ? M_ISO : M_BRK));
+        const u64 mine = (q < W) ? gather(gid, q) : 0ull;
+        // the break lanes (group 3) need their word's occupancy and the first occupancy bit of the next word
+        const u64 occw = ((u64)(unsigned)__shfl((int)(unsigned)(mine >> 32), q, 64) << 32) | (u64)(unsigned)__shfl((int)(unsigned)mine, q, 64);
+        const int next0 = __shfl((int)(mine & 1ull), (q + 1) & 15, 64);
+        u64 segw = 0;
+        if (q < W) {
+            if (g == 3) {
+                if (merge) {   // inside the merged first segment only its last position is a segment end
+                    const int j = fe + nl;
+                    const u64 after = (64 * q > j) ? ~0ull : ((64 * q + 63 <= j) ? 0ull : (~0ull << ((j - 64 * q) + 1)));
+                    segw = (mine & after) | (((j >> 6) == q) ? (1ull << (j & 63)) : 0ull);
+                } else segw = mine;
+                const u64 occ_next = (occw >> 1) | ((u64)(unsigned)((q + 1 < W) ? next0 : 0) << 63);
+                const int lastk = n - 2;                                // transitions are tested for k < n-1
+                const u64 vm = (64 * q > lastk) ? 0ull : ((64 * q + 63 <= lastk) ? ~0ull : ((1ull << (lastk - 64 * q + 1)) - 1ull));
+                segw |= (occw ^ occ_next) & vm;
+                WORD(M_SEG, q) = segw;
+            } else WORD(g == 0 ? M_OCC : (g == 1 ? M_KW : M_KO), q) = mine;
         }
-        u64 b0 = __ballot(se), b1 = __ballot(kw), b2 = __ballot(ko), b3 = __ballot(oc);
-        if (lane == 0) { WORD(M_SEG, q) = b0; WORD(M_KW, q) = b1; WORD(M_KO, q) = b2; WORD(M_OCC, q) = b3; }
-        nseg += __popcll(b0);
+        nseg = cn_wave_sum_i(__popcll(segw));
     }
     CN_SYNC();
     CN_T(11);
