@@ -583,6 +583,10 @@ __device__ __forceinline__ void observe(const CnKParams& p, const Poly& pg, EnvR
         int last_t = TY_NONE, last_s = 0, du = 0;
         for (int q = 0; q < W; ++q) {
             const u64 occ = (CN_ABLATE(2)) ? 0ull : ~uni64(WORD(M_NONE, q));
+            if (!occ) {      // a word without typed rays (free space): nothing happens to the state
+                if (lane == 0) { WORD(M_ISW, q) = 0ull; WORD(M_ISO, q) = 0ull; WORD(M_ALIAS, q) = 0ull; }
+                continue;
+            }
             const u64 Z = uni64(WORD(M_ZERO, q)) & occ, NZ = uni64(WORD(M_NZERO, q)), NN = uni64(WORD(M_NNONE, q)),
                       E = uni64(WORD(M_EQ, q));
             const u64 nonz = occ & ~Z;
@@ -590,42 +594,43 @@ __device__ __forceinline__ void observe(const CnKParams& p, const Poly& pg, EnvR
             const u64 cB = nonz & ~NZ & NN;              // 'o' fresh, state untouched
             const u64 cC = nonz & ~NZ & ~NN & E;         // 'w' fresh
             const u64 cD = nonz & ~NZ & ~NN & ~E;        // alias, du -> 1
-            u64 isw = 0, iso = 0, al = 0;
-            u64 rem = occ;
-            while (rem) {
-                if (du == 1) {
-                    const u64 T = rem & cA;              // first non-z ray whose next change is 0 ends the du == 1 run
-                    u64 range = rem;
-                    if (T) { const int t = __builtin_ctzll(T); range = rem & ((t == 63) ? ~0ull : ((2ull << t) - 1ull)); du = 0; }
-                    isw |= range & Z;
-                    iso |= range & ~Z;
-                    const int hb = 63 - __builtin_clzll(range);
-                    last_s = 64 * q + hb;
-                    last_t = ((Z >> hb) & 1ull) ? TY_W : TY_O;
-                    rem &= ~range;
-                } else {
-                    const u64 X = rem & (cA | cD);       // rays that switch du to 1
-                    u64 range = rem;
-                    int t = -1;
-                    if (X) { t = __builtin_ctzll(X); range = rem & ((1ull << t) - 1ull); }
-                    const u64 Wm = range & (Z | cC);
-                    isw |= Wm;
-                    iso |= range & cB;
-                    if (Wm) { last_t = TY_W; last_s = 64 * q + 63 - __builtin_clzll(Wm); }
-                    rem &= ~range;
-                    if (t >= 0) {
-                        const u64 bit = 1ull << t;
-                        if (cA & bit) { isw |= bit; last_t = TY_W; last_s = 64 * q + t; }
-                        else {                           // T[i] = last_type: carries that ray's range and pose
-                            if (last_t == TY_W) isw |= bit;
-                            else if (last_t == TY_O) iso |= bit;
-                            if (last_t != TY_NONE) { al |= bit; if (lane == 0) L.srcidx[64 * q + t] = (unsigned short)last_s; }
-                        }
-                        du = 1;
-                        rem &= ~bit;
-                    }
-                }
+            // The only state that steers the machine is du, and every occupied ray acts on it as one of three maps:
+            // class A swaps it (0 -> 1 by the rule above, 1 -> 0 as the ray that ends a du == 1 run), class D sets it to 1,
+            // everything else leaves it alone.  So du BEFORE each ray is: "1 if a D ray precedes, else du_in", XOR the
+            // parity of the A rays since then -- a prefix parity and a fill-forward, both log-step 64-bit mask operations.
+            u64 PI = cA;                                  // inclusive prefix parity of the A rays
+            PI ^= PI << 1; PI ^= PI << 2; PI ^= PI << 4; PI ^= PI << 8; PI ^= PI << 16; PI ^= PI << 32;
+            const u64 PE = PI << 1;                       // exclusive
+            u64 have = cD, F = PI & cD;                   // F: PI at the last D ray at or below each position
+            F |= (F << 1) & ~have;  have |= have << 1;
+            F |= (F << 2) & ~have;  have |= have << 2;
+            F |= (F << 4) & ~have;  have |= have << 4;
+            F |= (F << 8) & ~have;  have |= have << 8;
+            F |= (F << 16) & ~have; have |= have << 16;
+            F |= (F << 32) & ~have; have |= have << 32;
+            const u64 haveE = have << 1, FE = F << 1;     // ... strictly below
+            const u64 DU = (haveE & ~(PE ^ FE)) | (~haveE & (du ? ~PE : PE));   // du before each ray
+            const u64 du1 = DU & occ, du0 = ~DU & occ;
+            const u64 setW = (du1 & Z) | (du0 & (Z | cA | cC));   // fresh 'w'; these rays also become last_type
+            const u64 setO = du1 & ~Z;                             // fresh 'o' that becomes last_type (du == 1 only)
+            u64 isw = setW, iso = setO | (du0 & cB), al = 0;
+            const u64 S = setW | setO;
+            u64 alias = du0 & cD;                          // T[i] = last_type: carries that ray's range and pose
+            while (alias) {
+                const int t = __builtin_ctzll(alias);
+                const u64 bit = 1ull << t;
+                alias &= ~bit;
+                const u64 prev = S & (bit - 1ull);
+                int ty = last_t, src = last_s;
+                if (prev) { const int hb = 63 - __builtin_clzll(prev); ty = ((setW >> hb) & 1ull) ? TY_W : TY_O; src = 64 * q + hb; }
+                if (ty == TY_W) isw |= bit;
+                else if (ty == TY_O) iso |= bit;
+                if (ty != TY_NONE) { al |= bit; if (lane == 0) L.srcidx[64 * q + t] = (unsigned short)src; }
             }
+            if (S) { const int hb = 63 - __builtin_clzll(S); last_t = ((setW >> hb) & 1ull) ? TY_W : TY_O; last_s = 64 * q + hb; }
+            // du after the word
+            if (cD) { const int jd = 63 - __builtin_clzll(cD); du = 1 ^ (int)((PI >> 63) & 1ull) ^ (int)((PI >> jd) & 1ull); }
+            else du ^= (int)((PI >> 63) & 1ull);
             if (lane == 0) { WORD(M_ISW, q) = isw; WORD(M_ISO, q) = iso; WORD(M_ALIAS, q) = al; }
         }
     }
