@@ -580,59 +580,74 @@ __device__ __forceinline__ void observe(const CnKParams& p, const Poly& pg, EnvR
     // flips is a handful of 64-bit mask operations.
     CN_T(7);
     {
-        int last_t = TY_NONE, last_s = 0, du = 0;
-        for (int q = 0; q < W; ++q) {
-            const u64 occ = (CN_ABLATE(2)) ? 0ull : ~uni64(WORD(M_NONE, q));
-            if (!occ) {      // a word without typed rays (free space): nothing happens to the state
-                if (lane == 0) { WORD(M_ISW, q) = 0ull; WORD(M_ISO, q) = 0ull; WORD(M_ALIAS, q) = 0ull; }
-                continue;
-            }
-            const u64 Z = uni64(WORD(M_ZERO, q)) & occ, NZ = uni64(WORD(M_NZERO, q)), NN = uni64(WORD(M_NNONE, q)),
-                      E = uni64(WORD(M_EQ, q));
+        // lane = word (W <= 16).  Inside a word, du before each ray is a prefix parity of the class-A rays (they swap du)
+        // combined with a fill-forward from the class-D rays (they set it to 1); ACROSS words the same two maps
+        // compose (a word with a D ray outputs a constant, one without XORs its parity in), so the words' incoming du
+        // -- and the last ray that set last_type below each word -- come from two 4-step shuffle scans.
+        const int q = lane;
+        u64 occ = 0, Z = 0, cA = 0, cB = 0, cC = 0, cD = 0;
+        if (q < W && !(CN_ABLATE(2))) {
+            occ = ~WORD(M_NONE, q);
+            Z = WORD(M_ZERO, q) & occ;
+            const u64 NZ = WORD(M_NZERO, q), NN = WORD(M_NNONE, q), E = WORD(M_EQ, q);
             const u64 nonz = occ & ~Z;
-            const u64 cA = nonz & NZ;                    // 'w' fresh, du -> 1
-            const u64 cB = nonz & ~NZ & NN;              // 'o' fresh, state untouched
-            const u64 cC = nonz & ~NZ & ~NN & E;         // 'w' fresh
-            const u64 cD = nonz & ~NZ & ~NN & ~E;        // alias, du -> 1
-            // The only state that steers the machine is du, and every occupied ray acts on it as one of three maps:
-            // class A swaps it (0 -> 1 by the rule above, 1 -> 0 as the ray that ends a du == 1 run), class D sets it to 1,
-            // everything else leaves it alone.  So du BEFORE each ray is: "1 if a D ray precedes, else du_in", XOR the
-            // parity of the A rays since then -- a prefix parity and a fill-forward, both log-step 64-bit mask operations.
-            u64 PI = cA;                                  // inclusive prefix parity of the A rays
-            PI ^= PI << 1; PI ^= PI << 2; PI ^= PI << 4; PI ^= PI << 8; PI ^= PI << 16; PI ^= PI << 32;
-            const u64 PE = PI << 1;                       // exclusive
-            u64 have = cD, F = PI & cD;                   // F: PI at the last D ray at or below each position
-            F |= (F << 1) & ~have;  have |= have << 1;
-            F |= (F << 2) & ~have;  have |= have << 2;
-            F |= (F << 4) & ~have;  have |= have << 4;
-            F |= (F << 8) & ~have;  have |= have << 8;
-            F |= (F << 16) & ~have; have |= have << 16;
-            F |= (F << 32) & ~have; have |= have << 32;
-            const u64 haveE = have << 1, FE = F << 1;     // ... strictly below
-            const u64 DU = (haveE & ~(PE ^ FE)) | (~haveE & (du ? ~PE : PE));   // du before each ray
-            const u64 du1 = DU & occ, du0 = ~DU & occ;
-            const u64 setW = (du1 & Z) | (du0 & (Z | cA | cC));   // fresh 'w'; these rays also become last_type
-            const u64 setO = du1 & ~Z;                             // fresh 'o' that becomes last_type (du == 1 only)
-            u64 isw = setW, iso = setO | (du0 & cB), al = 0;
-            const u64 S = setW | setO;
-            u64 alias = du0 & cD;                          // T[i] = last_type: carries that ray's range and pose
-            while (alias) {
-                const int t = __builtin_ctzll(alias);
-                const u64 bit = 1ull << t;
-                alias &= ~bit;
-                const u64 prev = S & (bit - 1ull);
-                int ty = last_t, src = last_s;
-                if (prev) { const int hb = 63 - __builtin_clzll(prev); ty = ((setW >> hb) & 1ull) ? TY_W : TY_O; src = 64 * q + hb; }
-                if (ty == TY_W) isw |= bit;
-                else if (ty == TY_O) iso |= bit;
-                if (ty != TY_NONE) { al |= bit; if (lane == 0) L.srcidx[64 * q + t] = (unsigned short)src; }
-            }
-            if (S) { const int hb = 63 - __builtin_clzll(S); last_t = ((setW >> hb) & 1ull) ? TY_W : TY_O; last_s = 64 * q + hb; }
-            // du after the word
-            if (cD) { const int jd = 63 - __builtin_clzll(cD); du = 1 ^ (int)((PI >> 63) & 1ull) ^ (int)((PI >> jd) & 1ull); }
-            else du ^= (int)((PI >> 63) & 1ull);
-            if (lane == 0) { WORD(M_ISW, q) = isw; WORD(M_ISO, q) = iso; WORD(M_ALIAS, q) = al; }
+            cA = nonz & NZ;                    // 'w' fresh, du -> 1
+            cB = nonz & ~NZ & NN;              // 'o' fresh, state untouched
+            cC = nonz & ~NZ & ~NN & E;         // 'w' fresh
+            cD = nonz & ~NZ & ~NN & ~E;        // alias, du -> 1
         }
+        u64 PI = cA;                                  // inclusive prefix parity of the A rays
+        PI ^= PI << 1; PI ^= PI << 2; PI ^= PI << 4; PI ^= PI << 8; PI ^= PI << 16; PI ^= PI << 32;
+        const u64 PE = PI << 1;                       // exclusive
+        u64 have = cD, F = PI & cD;                   // F: PI at the last D ray at or below each position
+        F |= (F << 1) & ~have;  have |= have << 1;
+        F |= (F << 2) & ~have;  have |= have << 2;
+        F |= (F << 4) & ~have;  have |= have << 4;
+        F |= (F << 8) & ~have;  have |= have << 8;
+        F |= (F << 16) & ~have; have |= have << 16;
+        F |= (F << 32) & ~have; have |= have << 32;
+        // this word as a map of du: constant (fc = 1, fv) if it has a D ray, else du ^ fv
+        int fc = cD != 0ull;
+        int fv = (int)((PI >> 63) & 1ull);
+        if (fc) fv = 1 ^ fv ^ (int)((PI >> (63 - __builtin_clzll(cD))) & 1ull);
+        int sc_ = fc, sv_ = fv;                       // inclusive scan of the composition over the words below
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) {
+            const int lc = __shfl_up(sc_, d, 64), lv = __shfl_up(sv_, d, 64);
+            if (lane >= d && !sc_) { sc_ = lc; sv_ ^= lv; }   // (this o lower): a constant map absorbs what is below it
+        }
+        int du = __shfl_up(sv_, 1, 64);               // du entering this word: the maps below applied to du = 0
+        if (lane == 0) du = 0;
+        const u64 haveE = have << 1, FE = F << 1;     // ... strictly below
+        const u64 DU = (haveE & ~(PE ^ FE)) | (~haveE & (du ? ~PE : PE));   // du before each ray
+        const u64 du1 = DU & occ, du0 = ~DU & occ;
+        const u64 setW = (du1 & Z) | (du0 & (Z | cA | cC));   // fresh 'w'; these rays also become last_type
+        const u64 setO = du1 & ~Z;                             // fresh 'o' that becomes last_type (du == 1 only)
+        u64 isw = setW, iso = setO | (du0 & cB), al = 0;
+        const u64 S = setW | setO;
+        // last ray that set last_type at or below each word: packed (valid, type, index), fill-forward over the lanes
+        int pk = 0;
+        if (S) { const int hb = 63 - __builtin_clzll(S); pk = (1 << 30) | ((((setW >> hb) & 1ull) ? TY_W : TY_O) << 16) | (64 * q + hb); }
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) {
+            const int lo_ = __shfl_up(pk, d, 64);
+            if (lane >= d && !pk) pk = lo_;
+        }
+        int below = __shfl_up(pk, 1, 64);             // ... strictly below this word
+        if (lane == 0) below = 0;
+        u64 alias = du0 & cD;                          // T[i] = last_type: carries that ray's range and pose
+        while (alias) {
+            const int t = __builtin_ctzll(alias);
+            const u64 bit = 1ull << t;
+            alias &= ~bit;
+            const u64 prev = S & (bit - 1ull);
+            int ty = below ? ((below >> 16) & 3) : TY_NONE, src = below & 0xffff;
+            if (prev) { const int hb = 63 - __builtin_clzll(prev); ty = ((setW >> hb) & 1ull) ? TY_W : TY_O; src = 64 * q + hb; }
+            if (ty == TY_W) isw |= bit;
+            else if (ty == TY_O) iso |= bit;
+            if (ty != TY_NONE) { al |= bit; L.srcidx[64 * q + t] = (unsigned short)src; }
+        }
+        if (q < W) { WORD(M_ISW, q) = isw; WORD(M_ISO, q) = iso; WORD(M_ALIAS, q) = al; }
     }
     CN_SYNC();
     CN_T(8);
