@@ -2,7 +2,11 @@
 """bench.py -- env-steps/sec of the fused HIP environment step (BASELINE.json metric).
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+  N > 1: either launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (the driver's
+  way: RANK / LOCAL_RANK / WORLD_SIZE come from the environment), or run bare -- `python bench.py --gpus N` then re-executes
+  itself under torch.distributed.run with N ranks on 127.0.0.1, one rank per GPU over RCCL.
+  --envs-total T: strong scaling, T environments split over the ranks (BASELINE config 4: 16384 over 8 GPUs = 2048 per
+  GPU); default is weak scaling, --envs (4096) per GPU.
 
 A "step" is one cn_step launch over this rank's shard of environments (4096 envs x 20 pedestrians x
 360 rays, K = 8, BASELINE.json configs[1]); `value` = env-steps/s summed over all ranks, inputs resident
@@ -32,6 +36,37 @@ def algorithmic_bytes(P, R, K):
     pedestrian pos+vel read+write 2*32P, obs f32 write 4(R-1+7+4K), top-K idx 4K, scalar records
     (24 f64 + 16 i32) read+write, action 8, reward 4, done 1."""
     return 64 * P + 4 * (R - 1 + 7 + 4 * K) + 4 * K + 2 * (24 * 8 + 16 * 4) + 8 + 4 + 1
+
+
+D4_BYTES_PER_ENV_STEP = 2400.0   # SURVEY 8(d) D4's own per-env-step figure (float32 state), for round-to-round comparison
+
+
+def profiled_counters():
+    """Issue-side figures of cn_env_kernel from the committed rocprofv3 PMC passes of this same command
+    (profiles/rNN/counters.json, written by tools/summarize_prof.py): VALU busy fraction and wave instructions per
+    env-step.  None when no profile is committed."""
+    import glob
+    c = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "counters.json")))
+    if not c:
+        return None
+    try:
+        return json.load(open(c[-1]))
+    except Exception:
+        return None
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: become the launcher (one rank per GPU)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def profiled_traffic():
@@ -73,6 +108,11 @@ def main():
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--envs", type=int, default=4096, help="environments per GPU (weak scaling)")
+    ap.add_argument("--envs-total", type=int, default=0,
+                    help="strong scaling: this many environments split evenly over the ranks (overrides --envs)")
+    ap.add_argument("--preroll", type=int, default=200,
+                    help="untimed steps after every reset so that the timed sample sees de-phased envs and real resets")
+    ap.add_argument("--no-plateau", action="store_true", help="skip the 16384-env issue-bound measurement")
     ap.add_argument("--peds", type=int, default=20)
     ap.add_argument("--rays", type=int, default=360)
     ap.add_argument("--k", type=int, default=8)
@@ -81,6 +121,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     a = ap.parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a))
 
     import torch
     import torch.distributed as dist
@@ -93,6 +135,11 @@ def main():
     # CN_BENCH_DRYRUN_GLOO=1: exercise the N > 1 code path on a single-GPU box (every rank on cuda:0,
     # gloo collectives on host copies).  Never set by the driver; numbers from it are meaningless.
     dry = os.environ.get("CN_BENCH_DRYRUN_GLOO") == "1"
+    if a.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    if not dry and torch.cuda.device_count() < (local_rank + 1):
+        raise SystemExit("bench.py: rank %d has no GPU (%d visible); CN_BENCH_DRYRUN_GLOO=1 shares cuda:0 for a dry run"
+                         % (rank, torch.cuda.device_count()))
     dev_index = 0 if dry else local_rank
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -104,7 +151,12 @@ def main():
     dev = torch.device("cuda", dev_index)
     cdev = torch.device("cpu") if dry else dev   # where collective buffers live
 
-    N = a.envs
+    if a.envs_total:
+        if a.envs_total % world:
+            raise SystemExit("bench.py: --envs-total must divide evenly over the ranks")
+        N = a.envs_total // world
+    else:
+        N = a.envs
     cfg = Config(n_envs=N, n_peds=a.peds, n_rays=a.rays, k_obstacles=a.k, max_steps=1000, seed=1234,
                  env_index_base=rank * N, ped_cycle_ms=1400,
                  room_half=2.40 if a.peds > 50 else 1.40)
@@ -123,7 +175,7 @@ def main():
 
     def timed(mode):
         """K launches of cn_step; returns (wall s, kernel ms/launch, env-steps actually taken by this rank)."""
-        for i in range(a.warmup):
+        for i in range(a.preroll + a.warmup):
             env.step(acts[i % n_act], auto_reset=mode)
         ep0 = env.counters()[:, 8].sum().item()
         barrier()
@@ -147,18 +199,21 @@ def main():
 
     conc = 1
 
-    def timed_groups(G, mode="next"):
+    def timed_groups(G, mode="next", gcfg=None, gacts=None, steps=None):
         """The same N envs as G independent groups (crowdnav.env.VecEnvGroups): one step = every group stepped
         once, each on its own HIP stream, no join between groups inside the timed region.  Returns (wall s,
         mean per-stream ms/launch from HIP events on each group's stream, env-steps taken)."""
-        grp = VecEnvGroups(cfg, groups=G, device=dev_index)
+        gcfg = gcfg or cfg
+        acts_ = gacts if gacts is not None else acts
+        steps_ = steps or a.steps
+        grp = VecEnvGroups(gcfg, groups=G, device=dev_index)
         nonlocal conc
         conc = grp.concurrent
         grp.reset()
         rows = [grp.rows(g) for g in range(G)]
-        for i in range(a.warmup):
+        for i in range(a.preroll + a.warmup):
             for g in range(G):
-                grp.step_group(g, acts[i % n_act][rows[g]], auto_reset=mode)
+                grp.step_group(g, acts_[i % n_act][rows[g]], auto_reset=mode)
         ep0 = grp.episodes()
         barrier()
         ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(G)]
@@ -166,16 +221,16 @@ def main():
         t0 = time.perf_counter()
         for g in range(G):
             ev0[g].record(grp.streams[g])
-        for i in range(a.steps):
-            ai = acts[i % n_act]
+        for i in range(steps_):
+            ai = acts_[i % n_act]
             for g in range(G):
                 grp.step_group(g, ai[rows[g]], auto_reset=mode)
         for g in range(G):
             ev1[g].record(grp.streams[g])
         barrier()
         wall_ = time.perf_counter() - t0
-        k_ms = sum(ev0[g].elapsed_time(ev1[g]) for g in range(G)) / G / a.steps
-        taken = N * a.steps - (grp.episodes() - ep0 if mode == "next" else 0)
+        k_ms = sum(ev0[g].elapsed_time(ev1[g]) for g in range(G)) / G / steps_
+        taken = gcfg.n_envs * steps_ - (grp.episodes() - ep0 if mode == "next" else 0)
         grp.close()
         return wall_, k_ms, taken
 
@@ -189,6 +244,18 @@ def main():
         wall, kernel_ms, taken = timed_groups(G)
     else:
         wall, kernel_ms, taken = wall_1, kernel_ms_1, taken_1
+    # Issue-bound ceiling of this kernel on this GPU, measured in the same run: 16384 resident envs in 4 stream groups
+    # (every SIMD has work in every phase).  Rank 0 of a single-GPU run only.
+    plateau = None
+    if world == 1 and not a.no_plateau and (a.peds, a.rays) == (20, 360):
+        import dataclasses
+        pcfg = dataclasses.replace(cfg, n_envs=16384)
+        gp = torch.Generator(device=dev).manual_seed(99)
+        pacts = torch.stack([torch.rand((n_act, 16384), generator=gp, device=dev) * 0.22,
+                             torch.rand((n_act, 16384), generator=gp, device=dev) * 4.0 - 2.0], 2).contiguous()
+        pw, pk, pt = timed_groups(max(1, a.groups), gcfg=pcfg, gacts=pacts, steps=max(50, min(a.steps, 300)))
+        plateau = pt / pw
+        del pacts
     if world > 1:
         t = torch.tensor([wall, float(taken), wall_same, float(taken_same), wall_1, float(taken_1)],
                          dtype=torch.float64, device=cdev)
@@ -200,10 +267,16 @@ def main():
         ret, _ = env.returns()
         ret = ret.to(cdev)
         gathered = torch.empty(world * N, dtype=torch.float32, device=cdev)
-        tg0 = time.perf_counter()
-        dist.all_gather_into_tensor(gathered, ret)
+        dist.all_gather_into_tensor(gathered, ret)     # first call builds the communicator rings: not timed
         torch.cuda.synchronize(dev)
-        gather_ms = (time.perf_counter() - tg0) * 1e3
+        dist.barrier()
+        tg0 = time.perf_counter()
+        for _ in range(10):
+            dist.all_gather_into_tensor(gathered, ret)
+        torch.cuda.synchronize(dev)
+        gather_ms = (time.perf_counter() - tg0) * 1e3 / 10
+        # every rank holds every env's return; rank r's slice must be what rank r computed
+        assert torch.equal(gathered[rank * N:(rank + 1) * N], ret)
     else:
         taken_all, taken_same_all, taken_1_all, gather_ms = float(taken), float(taken_same), float(taken_1), None
 
@@ -219,17 +292,22 @@ def main():
     # every launch moves its envs' state, reset or step; G launches are in flight at once, one per stream
     achieved = G * B * n_launch / (kernel_ms * 1e-3) / 1e9
     achieved_1 = B * N / (kernel_ms_1 * 1e-3) / 1e9
+    counters = profiled_counters() if (a.peds, a.rays) == (20, 360) else None
     traffic = profiled_traffic() if (a.envs, a.peds, a.rays) == (4096, 20, 360) else None
     out = {
         "metric": baseline_metric(),
         "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": wall / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": wall / a.steps * 1e3, "higher_is_better": True, "scaling": "strong" if a.envs_total else "weak",
+        "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "%d envs/GPU x %d pedestrians x %d rays, K=%d, lidar-tracker risk features, "
+        "config": {"workload": "%s: %d envs/GPU x %d pedestrians x %d rays, K=%d, lidar-tracker risk features, "
                                "next-step auto-reset (reset launches not counted as env-steps), open-loop "
-                               "U(0,0.22)xU(-2,2) actions; one step = every env stepped once, the envs running as "
-                               "%d independent stream group(s) of %d" % (N, a.peds, a.rays, a.k, G, n_launch),
-                   "envs_per_gpu": N, "stream_groups": G, "stream_groups_requested": groups_requested,
+                               "U(0,0.22)xU(-2,2) actions, %d untimed pre-roll steps; one step = every env stepped once, "
+                               "the envs running as %d independent stream group(s) of %d" % (
+                                   ("BASELINE configs[3] shape, %d envs total over %d GPU(s) (strong scaling)" % (a.envs_total, world))
+                                   if a.envs_total else ("BASELINE configs[1] per GPU (weak scaling over %d GPU(s))" % world),
+                                   N, a.peds, a.rays, a.k, a.preroll, G, n_launch),
+                   "envs_per_gpu": N, "envs_total": N * world, "stream_groups": G, "stream_groups_requested": groups_requested,
                    "concurrent_hw_queues_found": conc, "parallelism": "env-sharded x%d" % world,
                    "one_launch_per_step_value": taken_1_all / wall_1, "one_launch_per_step_ms": wall_1 / a.steps * 1e3,
                    "same_call_reset_value": taken_same_all / wall_same, "same_call_reset_ms_per_step": wall_same / a.steps * 1e3,
@@ -241,6 +319,16 @@ def main():
                      "algorithmic_bytes_per_launch": B * n_launch, "envs_per_launch": n_launch,
                      "concurrent_launches": G,
                      "kernel": "cn_env_kernel", "kernel_ms": kernel_ms, "bytes_per_env_step": B,
+                     # the same speed priced with SURVEY 8(d) D4's 2400 B per env-step (float32 state), so that the HBM
+                     # fraction stays comparable across rounds whatever the state dtype is
+                     "frac_d4": G * D4_BYTES_PER_ENV_STEP * n_launch / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     # what actually binds: instruction issue (float64 VALU) and one wavefront's critical path, not HBM
+                     "binding": "instruction issue (f64 VALU) above ~8k resident envs; one wavefront's critical path at 4096",
+                     "issue_bound_env_steps_s": plateau,
+                     "frac_of_issue_bound": (value / world / plateau) if plateau else None,
+                     "valu_busy": (counters or {}).get("valu_busy"),
+                     "wave_instr_per_env_step": (counters or {}).get("wave_instr_per_env_step"),
+                     "counters_source": (counters or {}).get("source"),
                      "note": "achieved = concurrent_launches x algorithmic bytes per launch / mean launch duration on "
                              "its own stream (HIP events per group stream)",
                      "one_launch_per_step": {"envs_per_launch": N, "kernel_ms": kernel_ms_1, "achieved": achieved_1,

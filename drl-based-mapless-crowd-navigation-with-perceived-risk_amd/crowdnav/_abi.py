@@ -12,9 +12,12 @@ LIB_PATH = os.path.join(_PKG, "lib", "libcrowdnav.so")
 BUILD_SH = os.path.join(_PKG, "csrc", "build.sh")
 
 CN_MAX_TRACKS = 64
+EXPECTED_ABI = 3       # the version the ctypes structs below were written against (include/crowdnav.h CN_ABI_VERSION)
+CN_PHASE_ALL, CN_PHASE_PRE, CN_PHASE_GET_STATE, CN_PHASE_REWARD = 0, 1, 2, 4
 CN_SD_COUNT = 24
 CN_SI_COUNT = 16
 CN_TF_COUNT = 12
+CN_COUNTER_COLS = 14
 SD = dict(RX=0, RY=1, RYAW=2, RV=3, RW=4, CLOCK=5, WPX=6, WPY=7, PREV_DIST=8, PREV_HEAD=9, DQ0X=10, DQ0Y=11,
           DQ1X=12, DQ1Y=13, TS=14, BB=15, EGO=16, CPROB=17, EP_RETURN=18, LAST_RETURN=19)
 SI = dict(DONE=0, DQ_LEN=1, NTRACKS=2, EGO_VIOL=3, SOCIAL_VIOL=4, OBST_STEPS=5, SUCCESS=6, FAILURE=7, EP_STEP=8,
@@ -36,7 +39,7 @@ class CnStepIO(C.Structure):
 class CnExternalIO(C.Structure):
     _fields_ = [("ranges", C.c_void_p), ("odom", C.c_void_p), ("step_counter", C.c_void_p), ("obs", C.c_void_p),
                 ("obs_f64", C.c_void_p), ("reward", C.c_void_p), ("done", C.c_void_p), ("topk_idx", C.c_void_p),
-                ("is_reset", C.c_int32), ("reserved", C.c_int32)]
+                ("is_reset", C.c_int32), ("phase", C.c_int32)]
 
 
 class CnActorWeights(C.Structure):
@@ -72,6 +75,16 @@ def build(force=False):
     return LIB_PATH
 
 
+def build_timing(force=False):
+    """Compile the PROFILING build lib/libcrowdnav_timing.so (stage time stamps, ablation mask, PMC calibration kernels:
+    tools/stage_timing.py, tools/ablate.py, tools/calib_pmc.py).  Never loaded by the product."""
+    tpath = LIB_PATH.replace("libcrowdnav.so", "libcrowdnav_timing.so")
+    srcs = [os.path.join(_PKG, "csrc", f) for f in os.listdir(os.path.join(_PKG, "csrc"))]
+    if force or not os.path.exists(tpath) or os.path.getmtime(tpath) < max(os.path.getmtime(s) for s in srcs):
+        subprocess.check_call(["bash", BUILD_SH, "timing"])
+    return tpath
+
+
 _lib = None
 
 
@@ -84,6 +97,9 @@ def lib():
             if not os.path.exists(LIB_PATH):
                 raise CrowdNavError("libcrowdnav.so is not built (%s) and cannot be built here (%s); there is no CPU "
                                     "fallback" % (LIB_PATH, ex))
+            import warnings
+            warnings.warn("libcrowdnav.so could not be rebuilt (%s); loading the existing %s -- its ABI version is "
+                          "checked below" % (ex, LIB_PATH))
         # PyTorch-ROCm ships its own HIP / ROCr runtime libraries; the caller's tensors live in THAT runtime.  Importing
         # torch first makes libcrowdnav.so's libamdhip64 dependency resolve to the copy that is already loaded.  Loaded
         # the other way round the process ends up with two runtimes and cn_create sees no device (CN_ERR_NO_DEVICE).
@@ -91,6 +107,9 @@ def lib():
         L = C.CDLL(LIB_PATH)
         vp = C.c_void_p
         L.cn_abi_version.restype = C.c_int
+        if L.cn_abi_version() != EXPECTED_ABI:   # a stale library with other struct layouts would corrupt kernel arguments
+            raise CrowdNavError("%s reports ABI %d but this binding is written against ABI %d: rebuild it "
+                                "(csrc/build.sh)" % (LIB_PATH, L.cn_abi_version(), EXPECTED_ABI))
         L.cn_last_error.restype = C.c_char_p
         L.cn_create.argtypes = [C.POINTER(CnConfig), C.c_int, C.POINTER(vp)]
         L.cn_destroy.argtypes = [vp]; L.cn_destroy.restype = None
@@ -102,9 +121,9 @@ def lib():
         L.cn_reset.argtypes = [vp, vp, vp, vp, vp]
         L.cn_step.argtypes = [vp, C.POINTER(CnStepIO), vp]
         L.cn_observe_external.argtypes = [vp, C.POINTER(CnExternalIO), vp]
-        L.cn_policy_tail.argtypes = [vp, vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_uint64, C.c_uint64, vp]
+        L.cn_policy_tail.argtypes = [vp, vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_uint64, C.c_uint64, C.c_int, vp]
         L.cn_actor_forward.argtypes = [C.POINTER(CnActorWeights), vp, vp, C.c_int, C.c_float, C.c_float, C.c_float,
-                                       C.c_uint64, C.c_uint64, vp]
+                                       C.c_uint64, C.c_uint64, C.c_int, vp]
         L.cn_get_counters.argtypes = [vp, vp, vp]
         L.cn_get_returns.argtypes = [vp, vp, vp, vp]
         L.cn_debug_env.argtypes = [vp, C.c_int, vp, vp, vp, vp]

@@ -11,7 +11,7 @@ class CnConfig(C.Structure):
         ("n_envs", C.c_int32), ("n_peds", C.c_int32), ("n_rays", C.c_int32), ("k_obstacles", C.c_int32),
         ("max_steps", C.c_int32), ("ped_mode", C.c_int32), ("dt_ms", C.c_int32), ("scan_latency_ms", C.c_int32),
         ("settle_ms", C.c_int32), ("ped_cycle_ms", C.c_int32), ("ped_stagger_ms", C.c_int32), ("track_capacity", C.c_int32),
-        ("obs_layout", C.c_int32), ("reserved1", C.c_int32),
+        ("obs_layout", C.c_int32), ("geos_untyped_empty", C.c_int32), ("ped_contact", C.c_int32), ("risk_mode", C.c_int32),
         ("env_index_base", C.c_int64), ("seed", C.c_uint64),
         ("room_half", C.c_double), ("ped_radius", C.c_double), ("ped_vmax", C.c_double),
         ("robot_clearance", C.c_double), ("lidar_min", C.c_double), ("lidar_max", C.c_double),
@@ -37,7 +37,9 @@ class Config:
     ped_stagger_ms: int = 100      # CROWD:144
     track_capacity: int = 0        # tracker slots per env: 0 = auto (32 up to 40 pedestrians, else 64)
     obs_layout: int = 0            # 0: environment_stage_1_nobonus (366 + 4K); 1: environment_stage_1_original (R-1 + 4)
-    reserved1: int = 0
+    geos_untyped_empty: int = 0    # 1: shapely <= 1.7 / GEOS <= 3.8 empty-result semantics at UTL:279,306 (the reference's platform)
+    ped_contact: int = 0           # 1: frictionless rigid contact between pedestrians and with the robot (WORLD:86-145)
+    risk_mode: int = 0             # 0: lidar segmentation + tracker (the reference); 1: "gt" -- simulator pedestrians
     env_index_base: int = 0
     seed: int = 1234
     room_half: float = 1.40        # WORLD:926-1108

@@ -7,6 +7,7 @@
           start_td3_training.py:106-166 runs unchanged.
 PyTorch is used only for device memory and streams.
 """
+import contextlib
 import ctypes as C
 
 import numpy as np
@@ -51,7 +52,7 @@ class VecEnv:
         self.reward = buf("reward", (N,), torch.float32)
         self.done = buf("done", (N,), torch.uint8)
         self.topk_idx = buf("topk_idx", (N, K), torch.int32, -1)
-        self._counters = torch.zeros((N, 10), dtype=torch.int32, device=dev)
+        self._counters = torch.zeros((N, _abi.CN_COUNTER_COLS), dtype=torch.int32, device=dev)
         self._ret = torch.zeros(N, dtype=torch.float32, device=dev)
         self._run = torch.zeros(N, dtype=torch.float32, device=dev)
 
@@ -69,6 +70,25 @@ class VecEnv:
     def _stream(self):
         s = self.stream if self.stream is not None else torch.cuda.current_stream(self.device)
         return C.c_void_p(s.cuda_stream)
+
+    def _on_stream(self):
+        """Context in which host->device temporaries of a call are allocated and copied: the stream the kernel is
+        launched on, so the copy is ordered before the launch and the caching allocator ties the block to that stream."""
+        return torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
+
+    def _dev(self, x, dtype, shape=None):
+        """x as a contiguous device tensor of `dtype`; a tensor produced on another stream is ordered before our launch."""
+        if isinstance(x, torch.Tensor) and x.device == self.device and x.dtype == dtype and x.is_contiguous():
+            if self.stream is not None:
+                self.stream.wait_stream(torch.cuda.current_stream(self.device))
+                x.record_stream(self.stream)
+            return x if shape is None else x.reshape(shape)
+        with self._on_stream():
+            if not isinstance(x, torch.Tensor):
+                x = np.asarray(x, dtype={torch.float32: np.float32, torch.float64: np.float64, torch.int32: np.int32,
+                                         torch.uint8: np.uint8}[dtype])
+            t = torch.as_tensor(x, dtype=dtype, device=self.device).contiguous()
+        return t if shape is None else t.reshape(shape)
 
     def enable_f64_obs(self):
         """Also produce the observation in float64 (the reference's dtype) -- used by parity tests."""
@@ -93,8 +113,9 @@ class VecEnv:
         """Env.reset() for every env (or the masked ones) -> obs [N, D] float32 on the device."""
         m = None
         if mask is not None:
-            m = torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
+            m = self._dev(mask.to(torch.uint8) if isinstance(mask, torch.Tensor) else np.asarray(mask).astype(np.uint8), torch.uint8)
         _abi.check(self.L.cn_reset(self.h, _ptr(m), _ptr(self.obs), _ptr(self.obs_f64), self._stream()))
+        self._keep_reset = m      # alive until the next call: the launch is asynchronous
         return self.obs
 
     def step(self, action, step_counter=None, auto_reset=True, want_final=False):
@@ -104,11 +125,11 @@ class VecEnv:
         Returns (obs, reward, done) device tensors (views of internal buffers)."""
         a = action
         if not (isinstance(a, torch.Tensor) and a.device == self.device and a.dtype == torch.float32 and a.is_contiguous()):
-            a = torch.as_tensor(np.asarray(action, dtype=np.float32) if not isinstance(action, torch.Tensor) else action,
-                                dtype=torch.float32, device=self.device).contiguous()
+            a = self._dev(action, torch.float32)
         sc = None
         if step_counter is not None:
-            sc = torch.as_tensor(step_counter, dtype=torch.int32, device=self.device).contiguous()
+            sc = self._dev(step_counter, torch.int32)
+        self._keep_step = (a, sc)     # alive until the next call: the launch is asynchronous
         io = _abi.CnStepIO(action=a.data_ptr(), step_counter=sc.data_ptr() if sc is not None else None,
                            obs=self.obs.data_ptr(), final_obs=self.final_obs.data_ptr() if want_final else None,
                            obs_f64=self.obs_f64.data_ptr() if self.obs_f64 is not None else None,
@@ -139,26 +160,30 @@ class VecEnv:
                 check(rc)
         return call
 
-    def observe_external(self, ranges, odom, step_counter=None, is_reset=False):
+    def observe_external(self, ranges, odom, step_counter=None, is_reset=False, phase=0):
         """Env.get_state + Env.compute_reward on externally supplied /scan and /odom (Gazebo, a physical robot,
         or a recorded run): ranges [N,R] float64, odom [N,10] float64 = x, y, yaw, v, w, time.time(),
-        x, y at the end of the sleep, end_timestep, 0.  Returns (obs, reward, done) device tensors."""
-        rg = torch.as_tensor(ranges, dtype=torch.float64, device=self.device).contiguous().reshape(self.N, self.R)
-        od = torch.as_tensor(odom, dtype=torch.float64, device=self.device).contiguous().reshape(self.N, 10)
+        x, y at the end of the sleep, end_timestep, 0.  Returns (obs, reward, done) device tensors.
+        phase: 0 = the whole step / reset flow, or a mask of _abi.CN_PHASE_PRE | CN_PHASE_GET_STATE | CN_PHASE_REWARD
+        to run the pieces of Env.step separately (ENV:1208-1209, get_state, compute_reward).  CN_PHASE_REWARD
+        without CN_PHASE_GET_STATE reads state[R-1], state[R] from self.obs_f64 and `done` from self.done."""
+        rg = self._dev(ranges, torch.float64, (self.N, self.R))
+        od = self._dev(odom, torch.float64, (self.N, 10))
         sc = None
         if step_counter is not None:
-            sc = torch.as_tensor(step_counter, dtype=torch.int32, device=self.device).contiguous()
+            sc = self._dev(step_counter, torch.int32)
         io = _abi.CnExternalIO(ranges=rg.data_ptr(), odom=od.data_ptr(), step_counter=sc.data_ptr() if sc is not None else None,
                                obs=self.obs.data_ptr(), obs_f64=self.obs_f64.data_ptr() if self.obs_f64 is not None else None,
                                reward=self.reward.data_ptr(), done=self.done.data_ptr(), topk_idx=self.topk_idx.data_ptr(),
-                               is_reset=int(bool(is_reset)), reserved=0)
+                               is_reset=int(bool(is_reset)), phase=int(phase))
         _abi.check(self.L.cn_observe_external(self.h, C.byref(io), self._stream()))
         self._keep = (rg, od, sc)
         return self.obs, self.reward, self.done
 
     def counters(self):
-        """[N,10] int32: ego_viol, social_viol, obstacle_present_steps, ep_steps, success, failure, status, n_tracks,
-        episodes finished, reset pending."""
+        """[N,14] int32: ego_viol, social_viol, obstacle_present_steps, ep_steps, success, failure, status, n_tracks,
+        episodes finished, reset pending, and the last finished episode's ego_viol, social_viol,
+        obstacle_present_steps, ep_steps at the moment Env.step returned done."""
         _abi.check(self.L.cn_get_counters(self.h, _ptr(self._counters), self._stream()))
         return self._counters
 
@@ -384,16 +409,63 @@ class Env:
         self._v.reset()
         torch.cuda.synchronize(self._v.device)
         self.done = False   # the kernel applies TRAIN:116 (`env.done = False`) as part of reset
+        self._ext_odom = None
         return self._v.obs_f64[0].cpu().numpy()
 
-    def step(self, action, step_counter, mode="discrete"):
+    def step(self, action, step_counter, mode="continuous"):
+        """Env.step (ENV:1164-1225).  The reference's default is mode="discrete" (the DQN / Q-learning trainers, out of
+        scope); every trainer on this path passes "continuous" (TRAIN:125), which is the default here."""
         if mode != "continuous":
             raise NotImplementedError("only mode='continuous' (the TD3/DDPG/SAC path, ENV:1178-1188) is implemented")
         self._act[0, 0] = float(action[0]); self._act[0, 1] = float(action[1])
         self._v.step(self._act, step_counter=[int(step_counter)], auto_reset=False)
         torch.cuda.synchronize(self._v.device)
         self.done = bool(self._v.done[0].item())
+        self._ext_odom = None
         return self._v.obs_f64[0].cpu().numpy(), float(self._v.reward[0].item()), self.done
+
+    # ---- the two halves of Env.step, callable on their own like the reference's (ENV:1222-1223) -------------
+    def odom_callback(self, x, y, yaw, linear_x, angular_z, now=None):
+        """What the /odom subscriber stores (ENV:239-243) plus the wall clock get_state will read (time.time()).
+        Until the next step()/reset(), get_state / compute_reward use THIS pose instead of the library simulator's."""
+        self._ext_odom = [float(x), float(y), float(yaw), float(linear_x), float(angular_z),
+                          float(now) if now is not None else None]
+
+    def append_agent_pose(self, x, y, end_timestep):
+        """ENV:1208-1209 inside Env.step: agent_pose_deque.append([round(x, 3), round(y, 3)]); agent_vel_timestep."""
+        od = self._odom(); od[6], od[7], od[8] = float(x), float(y), float(end_timestep)
+        self._v.observe_external(np.zeros((1, self._v.R)), [od], step_counter=[0], phase=_abi.CN_PHASE_PRE)
+        torch.cuda.synchronize(self._v.device)
+
+    def _odom(self):
+        d = self._v.debug_env(0)["sd"]
+        od = [d[_abi.SD["RX"]], d[_abi.SD["RY"]], d[_abi.SD["RYAW"]], d[_abi.SD["RV"]], d[_abi.SD["RW"]],
+              d[_abi.SD["CLOCK"]], 0.0, 0.0, 0.0, 0.0]
+        ext = getattr(self, "_ext_odom", None)
+        if ext is not None:
+            od[:5] = ext[:5]
+            if ext[5] is not None:
+                od[5] = ext[5]
+        return od
+
+    def get_state(self, scan, step_counter=0, action=(0, 0)):
+        """Env.get_state(scan, step_counter=0, action=[0, 0]) -> (state list, done) (ENV:245-1044): `scan` is a
+        LaserScan-like object with `.ranges` (or a sequence of R ranges); the robot pose is the last /odom (the
+        library simulator's, or odom_callback's)."""
+        rg = np.asarray(getattr(scan, "ranges", scan), dtype=np.float64).reshape(1, self._v.R)
+        self._v.observe_external(rg, [self._odom()], step_counter=[int(step_counter)], phase=_abi.CN_PHASE_GET_STATE)
+        torch.cuda.synchronize(self._v.device)
+        self.done = bool(self._v.done[0].item())
+        return list(self._v.obs_f64[0].cpu().numpy()), self.done
+
+    def compute_reward(self, state, step_counter, done):
+        """Env.compute_reward(state, step_counter, done) -> (reward, done) (ENV:1046-1162)."""
+        self._v.obs_f64[0].copy_(torch.as_tensor(np.asarray(state, dtype=np.float64)))
+        self._v.done[0] = int(bool(done))
+        self._v.observe_external(np.zeros((1, self._v.R)), [self._odom()], step_counter=[int(step_counter)],
+                                 phase=_abi.CN_PHASE_REWARD)
+        torch.cuda.synchronize(self._v.device)
+        return float(self._v.reward[0].item()), bool(self._v.done[0].item())
 
     def get_episode_status(self):
         c = self._v.counters()[0].cpu().numpy()

@@ -42,6 +42,13 @@ class EpisodeStats:
         self.rows.append([len(self.rows) + 1, bool(success), bool(failure), float(reward), int(steps), float(ego),
                           float(social), float(timelapse)])
 
+    def add_from_counters(self, c, episode_return, timelapse=0.0):
+        """One row from an env's cn_get_counters record taken after the launch in which it finished."""
+        seen = int(c[12])
+        ego = 1.0 - int(c[10]) * 1.0 / seen if seen else float("nan")      # ENV:1277-1283 (ZeroDivisionError there)
+        soc = 1.0 - int(c[11]) * 1.0 / seen if seen else float("nan")      # ENV:1269-1275
+        self.add(int(c[4]), int(c[5]), episode_return, int(c[13]), ego, soc, timelapse)
+
     def write_csv(self, outdir, filename):
         os.makedirs(outdir, exist_ok=True)
         path = os.path.join(outdir, filename + ".csv")
@@ -57,34 +64,34 @@ def rollout(env, agent, n_steps, learn=False, add_noise=True, stats=None, policy
     `env` is a crowdnav.env.VecEnv; `agent` a crowdnav.td3.Agent on the same device.
     policy: "mfma" = the whole actor as one libcrowdnav kernel (cn_actor_forward; default when the weights are
     static), "tail" = PyTorch GEMMs + fused output stage (cn_policy_tail; default while learning, since the
-    weights change every update), "torch" = plain PyTorch."""
+    weights change every update), "torch" = plain PyTorch; or a callable `policy(obs, t) -> [N, 2] float32 device
+    tensor` (scripted / replayed actions; `agent` may then be None)."""
     if policy is None:
         policy = "tail" if learn else "mfma"
-    act_fn = {"mfma": agent.act_mfma, "tail": agent.act_fused, "torch": agent.act}[policy]
+    if callable(policy):
+        act_fn = None
+    else:
+        act_fn = {"mfma": agent.act_mfma, "tail": agent.act_fused, "torch": agent.act}[policy]
     if policy == "mfma":
         agent.sync_fused_weights()
     obs = env.obs if getattr(env, "_started", False) else env.reset()
     env._started = True
     for t in range(n_steps):
-        act = act_fn(obs, add_noise=add_noise)
-        if learn or stats is not None:
+        act = policy(obs, t) if act_fn is None else act_fn(obs, add_noise=add_noise)
+        if learn:
             prev = obs.clone()
-            pre_counters = env.counters().clone() if stats is not None else None
         obs, reward, done = env.step(act, auto_reset=True, want_final=learn or stats is not None)
         if learn:
             agent.memory.add(prev, act, reward, env.final_obs, done)
             agent.learn(t)
         if stats is not None and bool(done.any()):
-            # counters are reset inside the launch for finished envs; success/failure and returns persist
+            # the live counters are zeroed by the reset inside the launch; columns 10..13 keep the finished episode's
+            # values as they stood when Env.step returned done (what TRAIN:142-147 reads), terminal step included
             c = env.counters().cpu()
             ret, _ = env.returns()
             ret = ret.cpu()
-            pc = pre_counters.cpu()
             for e in torch.nonzero(done.cpu()).flatten().tolist():
-                seen = int(pc[e, 2])
-                ego = 1.0 - pc[e, 0].item() / seen if seen else float("nan")     # ENV:1277-1283
-                soc = 1.0 - pc[e, 1].item() / seen if seen else float("nan")     # ENV:1269-1275
-                stats.add(c[e, 4].item(), c[e, 5].item(), ret[e].item(), int(pc[e, 3]) + 1, ego, soc)
+                stats.add_from_counters(c[e], ret[e].item())
     return n_steps * env.N
 
 
@@ -106,7 +113,7 @@ def rollout_groups(envs, agent, n_steps, add_noise=True, auto_reset="next"):
     calls = []
     for g in range(envs.G):
         calls.append(agent.bind_act_mfma(envs.obs[rows[g]], envs._act[rows[g]], add_noise=add_noise,
-                                         stream=envs.streams[g], noise_seed=12345 + g))
+                                         stream=envs.streams[g], noise_seed=agent.group_noise_seed(g)))
         calls.append(envs.envs[g].bind_step(envs._act[rows[g]], auto_reset=auto_reset))
     for _ in range(n_steps):
         for c in calls:
@@ -117,24 +124,25 @@ def rollout_groups(envs, agent, n_steps, add_noise=True, auto_reset="next"):
 
 def evaluate(env, agent, episodes_per_env=1, max_launches=100000):
     """The reference's evaluation run (README "Start testing"; TRAIN:142-161 with learning = False): greedy
-    actor, one CSV row per finished episode (success, failure, return, steps, ego/social safety scores)."""
+    actor, one CSV row per finished episode (success, failure, return, steps, ego/social safety scores).
+    Every env contributes exactly its FIRST `episodes_per_env` episodes and the loop runs until every env has
+    reached that quota: with auto-reset, short episodes would otherwise be over-represented (an env that fails early
+    starts a second episode while long ones are still running)."""
     stats = EpisodeStats()
     env.reset()
-    target = episodes_per_env * env.N
     obs = env.obs
+    finished = torch.zeros(env.N, dtype=torch.int64, device=obs.device)   # per-env count of recorded episodes
     launches = 0
-    while len(stats.rows) < target and launches < max_launches:
+    while int(finished.min().item()) < episodes_per_env and launches < max_launches:
         act = agent.act(obs, add_noise=False)
-        pre = env.counters().clone()
         obs, reward, done = env.step(act, auto_reset=True)
         launches += 1
-        if bool(done.any()):
-            c = env.counters().cpu(); pc = pre.cpu(); ret = env.returns()[0].cpu()
-            for e in torch.nonzero(done.cpu()).flatten().tolist():
-                seen = int(pc[e, 2])
-                ego = 1.0 - pc[e, 0].item() / seen if seen else float("nan")
-                soc = 1.0 - pc[e, 1].item() / seen if seen else float("nan")
-                stats.add(c[e, 4].item(), c[e, 5].item(), ret[e].item(), int(pc[e, 3]) + 1, ego, soc)
+        take = done.bool() & (finished < episodes_per_env)
+        if bool(take.any()):
+            c = env.counters().cpu(); ret = env.returns()[0].cpu()
+            for e in torch.nonzero(take.cpu()).flatten().tolist():
+                stats.add_from_counters(c[e], ret[e].item())
+            finished += take.to(finished.dtype)
     return stats
 
 

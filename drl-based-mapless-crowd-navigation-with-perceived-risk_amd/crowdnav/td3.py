@@ -95,6 +95,13 @@ class Agent:
         self.noise_std, self.noise_clip, self.policy_delay = noise_std, noise_clip, policy_delay
         self.explore_sigma = explore_sigma
         self.gen = torch.Generator(device=self.device).manual_seed(seed)
+        # exploration-noise key of the fused actor paths (cn_policy_tail / cn_actor_forward): derived from the Agent seed so that
+        # --seed changes the noise; the call counter is part of checkpoints' bookkeeping (noise_state) so a resumed run
+        # does not replay the stream
+        self._noise_seed = (0x9E3779B97F4A7C15 * (int(seed) + 1) ^ 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+        self._fused_calls = 0
+        self._dev_index = self.device.index if self.device.type == "cuda" and self.device.index is not None else (
+            torch.cuda.current_device() if self.device.type == "cuda" else -1)
         self._lo = torch.tensor([0.0, -max_w], device=self.device)
         self._hi = torch.tensor([max_v, max_w], device=self.device)
         del g
@@ -117,12 +124,20 @@ class Agent:
         lg = self.actor.logits(obs).contiguous()
         if out is None:
             out = torch.empty_like(lg)
-        self._fused_calls = getattr(self, "_fused_calls", 0) + 1
+        self._fused_calls += 1
         st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         _abi.check(_abi.lib().cn_policy_tail(C.c_void_p(lg.data_ptr()), C.c_void_p(out.data_ptr()), lg.shape[0],
                                              self.max_v, self.max_w, self.explore_sigma if add_noise else 0.0,
-                                             12345, self._fused_calls, st))
+                                             self._noise_seed, self._fused_calls, self._dev_index, st))
         return out
+
+    def noise_state(self):
+        """(seed, call counter) of the fused exploration noise -- persist it with a checkpoint and hand it back to
+        set_noise_state() on resume so the noise stream continues instead of restarting."""
+        return self._noise_seed, self._fused_calls
+
+    def set_noise_state(self, seed, calls):
+        self._noise_seed, self._fused_calls = int(seed), int(calls)
 
     def sync_fused_weights(self):
         """(Re)build the K-major float32 copies cn_actor_forward reads; call after the actor's weights change."""
@@ -143,11 +158,12 @@ class Agent:
                                               obs_dim=D, obs_dim_padded=Dp, hidden=256, reserved=0)
 
     @torch.no_grad()
-    def act_mfma(self, obs, out=None, add_noise=True, stream=None, noise_seed=12345):
+    def act_mfma(self, obs, out=None, add_noise=True, stream=None, noise_seed=None):
         """Agent.act as ONE kernel (cn_actor_forward): the three Linear layers on the f32 matrix cores with the
         activations in LDS, plus heads, exploration noise and clip.  float32 throughout, like the reference.
         stream: torch stream to enqueue on (default: current).  The exploration noise is keyed by
-        (noise_seed, call counter, row): callers that split a batch over several calls give each its own seed."""
+        (noise_seed, call counter, row); noise_seed defaults to the Agent's own key, callers that split a batch over
+        several calls pass `agent.group_noise_seed(g)` so that the groups draw different noise."""
         import ctypes as C
         from . import _abi
         if not hasattr(self, "_fw_struct"):
@@ -155,14 +171,20 @@ class Agent:
         obs = obs.contiguous()
         if out is None:
             out = torch.empty((obs.shape[0], 2), dtype=torch.float32, device=self.device)
-        self._fused_calls = getattr(self, "_fused_calls", 0) + 1
+        self._fused_calls += 1
         st = C.c_void_p((stream if stream is not None else torch.cuda.current_stream(self.device)).cuda_stream)
+        seed = self._noise_seed if noise_seed is None else int(noise_seed)
         _abi.check(_abi.lib().cn_actor_forward(C.byref(self._fw_struct), C.c_void_p(obs.data_ptr()), C.c_void_p(out.data_ptr()),
                                                obs.shape[0], self.max_v, self.max_w,
-                                               self.explore_sigma if add_noise else 0.0, int(noise_seed), self._fused_calls, st))
+                                               self.explore_sigma if add_noise else 0.0, seed, self._fused_calls,
+                                               self._dev_index, st))
         return out
 
-    def bind_act_mfma(self, obs, out, add_noise=True, stream=None, noise_seed=12345):
+    def group_noise_seed(self, g):
+        """Noise key of stream group / rank `g` (distinct per group, derived from the Agent seed)."""
+        return (self._noise_seed ^ (0xA0761D6478BD642F * (int(g) + 1))) & 0xFFFFFFFFFFFFFFFF
+
+    def bind_act_mfma(self, obs, out, add_noise=True, stream=None, noise_seed=None):
         """Pre-marshalled act_mfma for fixed obs/out buffers: a zero-argument callable that only enqueues."""
         import ctypes as C
         from . import _abi
@@ -174,12 +196,13 @@ class Agent:
         po, pa, n = C.c_void_p(obs.data_ptr()), C.c_void_p(out.data_ptr()), obs.shape[0]
         st = C.c_void_p((stream if stream is not None else torch.cuda.current_stream(self.device)).cuda_stream)
         sigma = self.explore_sigma if add_noise else 0.0
-        mv, mw, seed = self.max_v, self.max_w, int(noise_seed)
+        mv, mw, seed = self.max_v, self.max_w, self._noise_seed if noise_seed is None else int(noise_seed)
         keep = (obs, out, self._fw_struct, self._fw)
+        dv = self._dev_index
 
         def call(_keep=keep):
-            self._fused_calls = c = getattr(self, "_fused_calls", 0) + 1
-            rc = fn(w, po, pa, n, mv, mw, sigma, seed, c, st)
+            self._fused_calls = c = self._fused_calls + 1
+            rc = fn(w, po, pa, n, mv, mw, sigma, seed, c, dv, st)
             if rc:
                 check(rc)
         return call

@@ -43,10 +43,14 @@ def make_env(scenario, n_envs, max_steps, seed, device, ped_vmax=None):
 
 def train(a):
     dev = a.device
+    torch.cuda.set_device(dev)        # policy kernels and torch ops of this process all target the env's GPU
     env = make_env(a.scenario, a.envs, a.max_steps, a.seed, dev, a.ped_vmax)
     agent = Agent(obs_dim=env.D, device="cuda:%d" % dev, seed=a.seed, batch_size=a.batch, memory_size=a.memory)
     if a.load:
         agent.load_models(*[os.path.join(a.load, "td3_%s_model_ep%d.pt" % (n, a.load_episode)) for n in ("actor", "critic1", "critic2")])
+        ns = os.path.join(a.load, "noise_state_ep%d.txt" % a.load_episode)
+        if os.path.exists(ns):           # continue the exploration-noise stream instead of replaying it
+            agent.set_noise_state(*[int(x) for x in open(ns).read().split()])
     stats = EpisodeStats()
     os.makedirs(a.out, exist_ok=True)
     obs = env.reset()
@@ -58,7 +62,6 @@ def train(a):
     for it in range(1, a.launches + 1):
         act = agent.act_fused(obs, add_noise=True)                     # TD3:196-223, sigma = 1.0, clipped
         prev = obs.clone()
-        pre = env.counters().clone()
         obs, reward, done = env.step(act, auto_reset="same", want_final=True)
         agent.memory.add(prev, act, reward, env.final_obs, done)        # TRAIN:129-131
         if len(agent.memory) > a.batch:
@@ -71,14 +74,12 @@ def train(a):
             s = c[idx, 4].sum().item()
             episodes += nd; done_w += nd; succ_w += s; ret_w += ret[idx].sum().item()
             if a.csv:
-                cc, pc, rr = c.cpu(), pre.cpu(), ret.cpu()
+                cc, rr = c.cpu(), ret.cpu()
                 for e in idx.cpu().tolist():
-                    seen = int(pc[e, 2])
-                    stats.add(cc[e, 4].item(), cc[e, 5].item(), rr[e].item(), int(pc[e, 3]) + 1,
-                              1.0 - pc[e, 0].item() / seen if seen else float("nan"),
-                              1.0 - pc[e, 1].item() / seen if seen else float("nan"), time.time() - t0)
+                    stats.add_from_counters(cc[e], rr[e].item(), time.time() - t0)
             if episodes >= next_ckpt:                                    # TRAIN:150-154 (every 100 episodes there)
                 agent.save(a.out, next_ckpt)
+                open(os.path.join(a.out, "noise_state_ep%d.txt" % next_ckpt), "w").write("%d %d\n" % agent.noise_state())
                 next_ckpt += a.checkpoint_every
         if it % a.log_every == 0 and done_w:
             line = "launch %6d  env-steps %10d  episodes %8d  success %.3f  mean return %8.1f  replay %8d  %.0f s" % (
@@ -86,12 +87,14 @@ def train(a):
             print(line, flush=True); log.write(line + "\n"); log.flush()
             succ_w = done_w = 0; ret_w = 0.0
     agent.save(a.out, episodes)
+    open(os.path.join(a.out, "noise_state_ep%d.txt" % episodes), "w").write("%d %d\n" % agent.noise_state())
     if a.csv:
         stats.write_csv(a.out, "td3_training")
     return agent, episodes
 
 
 def run_evaluation(a):
+    torch.cuda.set_device(a.device)
     env = make_env(a.scenario, a.envs, a.max_steps, a.seed, a.device, a.ped_vmax)
     agent = Agent(obs_dim=env.D, device="cuda:%d" % a.device, seed=a.seed, memory_size=16)
     agent.load_models(*[os.path.join(a.load, "td3_%s_model_ep%d.pt" % (n, a.load_episode)) for n in ("actor", "critic1", "critic2")])

@@ -13,6 +13,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-builtin
 mv -f "$OUT/.libcrowdnav.so.$$" "$OUT/libcrowdnav.so"
 echo "built $OUT/libcrowdnav.so"
 if [ "${1:-}" = "timing" ]; then
-  "$HIPCC" $FLAGS -DCN_TIMING -shared -o "$OUT/libcrowdnav_timing.so" "$HERE/crowdnav_kernel.hip" "$HERE/crowdnav_abi.hip"
+  "$HIPCC" $FLAGS -DCN_TIMING -shared -o "$OUT/.libcrowdnav_timing.so.$$" "$HERE/crowdnav_kernel.hip" "$HERE/crowdnav_abi.hip"
+  mv -f "$OUT/.libcrowdnav_timing.so.$$" "$OUT/libcrowdnav_timing.so"
   echo "built $OUT/libcrowdnav_timing.so (stage time stamps; profiling only)"
 fi

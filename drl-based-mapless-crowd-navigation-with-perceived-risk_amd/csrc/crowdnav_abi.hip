@@ -6,6 +6,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -32,11 +34,29 @@ struct cn_env_s {
     int D, max_conf, trk_cap;
     size_t lds;
     CnKParams kp;        // template with state/table pointers filled in
-    double *d_lidar, *d_poly, *d_ped_init, *d_ped_preset, *d_trk;
-    char* d_state;          // N per-env records (crowdnav_kernel.h: sd | si | ped_p | ped_v | pad), `stride` bytes apart
+    double *d_lidar = nullptr, *d_poly = nullptr, *d_ped_init = nullptr, *d_ped_preset = nullptr, *d_trk = nullptr;
+    char* d_state = nullptr;          // N per-env records (crowdnav_kernel.h: sd | si | ped_p | ped_v | pad), `stride` bytes apart
     size_t stride;
     std::vector<double> ped_init;
 };
+
+// RAII: run on the handle's device even if the calling thread's current device is another one
+struct DeviceScope {
+    int prev = -1, want;
+    explicit DeviceScope(int dev) : want(dev) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; if (prev != want) (void)hipSetDevice(want); }
+    ~DeviceScope() { if (prev >= 0 && prev != want) (void)hipSetDevice(prev); }
+};
+
+static void destroy_handle(cn_env_s* h)
+{
+    if (!h) return;
+    DeviceScope scope(h->device);
+    (void)hipFree(h->d_lidar); (void)hipFree(h->d_poly); (void)hipFree(h->d_state);
+    (void)hipFree(h->d_ped_init); (void)hipFree(h->d_ped_preset);
+    (void)hipFree(h->d_trk);
+    delete h;
+}
+struct HandleDeleter { void operator()(cn_env_s* h) const { destroy_handle(h); } };
 
 static size_t lds_bytes_impl(int R, int P, int K, int max_conf, int trk_cap, bool near_separate)
 {
@@ -145,14 +165,21 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
     if (c.n_envs < 1 || c.n_peds < 0 || c.n_peds > 4096 || c.n_rays < 8 || c.n_rays > 1025 || c.k_obstacles < 1 ||
         c.k_obstacles > CN_MAX_K || c.ped_cycle_ms < 1 || c.dt_ms < 1 || c.scan_latency_ms < 1 || c.settle_ms < 0 ||
         c.max_steps < 1 || !(c.track_capacity == 0 || c.track_capacity == 32 || c.track_capacity == 64) ||
-        !(c.obs_layout == CN_LAYOUT_RISK || c.obs_layout == CN_LAYOUT_ORIGINAL))
+        !(c.obs_layout == CN_LAYOUT_RISK || c.obs_layout == CN_LAYOUT_ORIGINAL) ||
+        !(c.geos_untyped_empty == 0 || c.geos_untyped_empty == 1) || !(c.ped_contact == 0 || c.ped_contact == 1) ||
+        !(c.risk_mode == CN_RISK_LIDAR_TRACKER || c.risk_mode == CN_RISK_GT))
         return fail(CN_ERR_CONFIG, "cn_create: config out of range");
+    if (c.ped_contact) return fail(CN_ERR_CONFIG, "cn_create: ped_contact is not built yet");
+    if (c.risk_mode != CN_RISK_LIDAR_TRACKER) return fail(CN_ERR_CONFIG, "cn_create: risk_mode gt is not built yet");
+    if (c.geos_untyped_empty) return fail(CN_ERR_CONFIG, "cn_create: geos_untyped_empty is not built yet");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         return fail(CN_ERR_NO_DEVICE, "cn_create: no HIP device (libcrowdnav has no CPU fallback)");
     if (device < 0 || device >= ndev) return fail(CN_ERR_ARG, "cn_create: bad device ordinal");
-    HIPCHK(hipSetDevice(device));
-    cn_env_s* h = new cn_env_s();
+    DeviceScope scope(device);
+    // every failure path below (HIPCHK returns) releases what was allocated so far
+    std::unique_ptr<cn_env_s, HandleDeleter> guard(new cn_env_s());
+    cn_env_s* h = guard.get();
     h->cfg = c;
     h->device = device;
     const int N = c.n_envs, P = c.n_peds, R = c.n_rays, K = c.k_obstacles;
@@ -160,7 +187,7 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
     h->max_conf = (R - 1) / 4 + 2;
     h->trk_cap = c.track_capacity ? c.track_capacity : (P <= 40 ? 32 : 64);
     h->lds = cn_lds_bytes(R, P, K, h->max_conf, h->trk_cap);
-    if (h->lds > 160 * 1024) { delete h; return fail(CN_ERR_CONFIG, "cn_create: per-env working set exceeds 160 KiB of LDS"); }
+    if (h->lds > 160 * 1024) { return fail(CN_ERR_CONFIG, "cn_create: per-env working set exceeds 160 KiB of LDS"); }
     // tables
     std::vector<double> lidar(4 * (size_t)R), poly(128);
     double step = c.lidar_span / (double)(R - 1);
@@ -183,13 +210,14 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
     h->ped_init.resize((size_t)N * P * 2);
     for (int e = 0; e < N; ++e) default_ped_init(c, e, &h->ped_init[(size_t)e * P * 2]);
     int rc = upload_initial_state(h);
-    if (rc != CN_OK) { delete h; return rc; }
+    if (rc != CN_OK) return rc;
 
     CnKParams& k = h->kp;
     memset(&k, 0, sizeof(k));
     k.N = N; k.P = P; k.R = R; k.K = K;
     k.max_steps = c.max_steps; k.ped_mode = c.ped_mode; k.dt_ms = c.dt_ms; k.scan_latency_ms = c.scan_latency_ms;
     k.settle_ms = c.settle_ms; k.ped_cycle_ms = c.ped_cycle_ms; k.ped_stagger_ms = c.ped_stagger_ms;
+    k.geos_untyped_empty = c.geos_untyped_empty; k.ped_contact = c.ped_contact; k.risk_mode = c.risk_mode;
     k.near_sep = cn_near_separate(R, P, K, h->max_conf, h->trk_cap);
     k.max_conf = h->max_conf; k.trk_cap = h->trk_cap; k.env_index_base = c.env_index_base; k.seed = c.seed;
     k.room_half = c.room_half; k.ped_radius = c.ped_radius; k.ped_vmax = c.ped_vmax; k.robot_clearance = c.robot_clearance;
@@ -209,24 +237,18 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
         HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_orig_ext, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
         HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_orig_same, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
     }
-    *out = h;
+    *out = guard.release();
     return CN_OK;
 }
 
-extern "C" void cn_destroy(cn_handle h)
-{
-    if (!h) return;
-    (void)hipSetDevice(h->device);
-    (void)hipFree(h->d_lidar); (void)hipFree(h->d_poly); (void)hipFree(h->d_state);
-    (void)hipFree(h->d_ped_init); (void)hipFree(h->d_ped_preset);
-    (void)hipFree(h->d_trk);
-    delete h;
-}
+extern "C" void cn_destroy(cn_handle h) { destroy_handle(h); }
 
+#ifdef CN_TIMING
+// PROFILING BUILD ONLY (libcrowdnav_timing.so; not in crowdnav.h, not in the product library): stage time stamps
+// (tools/stage_timing.py) and the stage-skipping mask for time attribution (tools/ablate.py)
 extern "C" int cn_debug_set_timing(cn_handle h, long long* dev_buf) { if (!h) return CN_ERR_ARG; h->kp.timing = dev_buf; return CN_OK; }
-
-// PROFILING ONLY: stage-skipping mask for time attribution (tools/ablate.py); not part of crowdnav.h
 extern "C" int cn_debug_set_ablate(cn_handle h, int mask) { if (!h) return CN_ERR_ARG; h->kp.ablate = mask; return CN_OK; }
+#endif
 
 extern "C" int cn_obs_dim(cn_handle h) { return h ? h->D : fail(CN_ERR_ARG, "null handle"); }
 
@@ -240,7 +262,7 @@ extern "C" int cn_config_of(cn_handle h, cn_config* out)
 extern "C" int cn_set_ped_init(cn_handle h, const double* xy)
 {
     if (!h || !xy) return fail(CN_ERR_ARG, "cn_set_ped_init: null argument");
-    HIPCHK(hipSetDevice(h->device));
+    DeviceScope scope(h->device);
     size_t cnt = (size_t)h->cfg.n_envs * h->cfg.n_peds * 2;
     h->ped_init.assign(xy, xy + cnt);
     HIPCHK(hipDeviceSynchronize());
@@ -259,18 +281,11 @@ extern "C" int cn_get_ped_init(cn_handle h, double* xy)
 extern "C" int cn_set_ped_preset_vel(cn_handle h, const double* vxy)
 {
     if (!h || !vxy) return fail(CN_ERR_ARG, "cn_set_ped_preset_vel: null argument");
-    HIPCHK(hipSetDevice(h->device));
+    DeviceScope scope(h->device);
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(h->d_ped_preset, vxy, (size_t)h->cfg.n_envs * h->cfg.n_peds * 16, hipMemcpyHostToDevice));
     return CN_OK;
 }
-
-// RAII: run on the handle's device even if the calling thread's current device is another one
-struct DeviceScope {
-    int prev = -1, want;
-    explicit DeviceScope(int dev) : want(dev) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; if (prev != want) (void)hipSetDevice(want); }
-    ~DeviceScope() { if (prev >= 0 && prev != want) (void)hipSetDevice(prev); }
-};
 
 static int launch(cn_handle h, const CnKParams& kp, hipStream_t st)
 {
@@ -315,7 +330,12 @@ extern "C" int cn_observe_external(cn_handle h, const cn_external_io* io, void* 
     if (!h || !io || !io->ranges || !io->odom || !io->obs || !io->reward || !io->done)
         return fail(CN_ERR_ARG, "cn_observe_external: null argument");
     CnKParams kp = h->kp;
+    if (io->phase < 0 || io->phase > 7 || (io->phase && io->is_reset))
+        return fail(CN_ERR_ARG, "cn_observe_external: phase is a mask of CN_PHASE_* and only applies to the step flow");
+    if ((io->phase & CN_PHASE_REWARD) && !(io->phase & CN_PHASE_GET_STATE) && !io->obs_f64)
+        return fail(CN_ERR_ARG, "cn_observe_external: CN_PHASE_REWARD alone reads the float64 state (obs_f64)");
     kp.mode = io->is_reset ? CN_MODE_EXT_RESET : CN_MODE_EXT_STEP;
+    kp.ext_phase = io->phase;
     kp.ext_ranges = io->ranges; kp.ext_odom = io->odom; kp.step_counter = io->step_counter;
     kp.obs = io->obs; kp.obs_f64 = io->obs_f64; kp.reward = io->reward; kp.done = io->done; kp.topk_idx = io->topk_idx;
     return launch(h, kp, (hipStream_t)stream);
@@ -325,10 +345,13 @@ extern "C" __global__ void cn_policy_tail_kernel(const float* logits, float* act
                                                  float sigma, uint64_t seed, uint64_t counter);
 
 extern "C" int cn_policy_tail(const float* logits, float* action, int n, float max_v, float max_w, float sigma,
-                              uint64_t seed, uint64_t counter, void* stream)
+                              uint64_t seed, uint64_t counter, int device, void* stream)
 {
     if (!logits || !action || n < 0) return fail(CN_ERR_ARG, "cn_policy_tail: bad argument");
     if (n == 0) return CN_OK;
+    int dev = device;
+    if (dev < 0) HIPCHK(hipGetDevice(&dev));
+    DeviceScope scope(dev);
     hipLaunchKernelGGL(cn_policy_tail_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, logits, action, n,
                        max_v, max_w, sigma, seed, counter);
     HIPCHK(hipGetLastError());
@@ -340,7 +363,7 @@ extern "C" __global__ void cn_actor_kernel(const float* obs, int n, int D, int D
                                            float max_v, float max_w, float sigma, uint64_t seed, uint64_t counter);
 
 extern "C" int cn_actor_forward(const cn_actor_weights* w, const float* obs, float* action, int n, float max_v, float max_w,
-                                float sigma, uint64_t seed, uint64_t counter, void* stream)
+                                float sigma, uint64_t seed, uint64_t counter, int device, void* stream)
 {
     if (!w || !obs || !action || n < 0 || !w->w1t || !w->b1 || !w->w2t || !w->b2 || !w->w3 || !w->b3)
         return fail(CN_ERR_ARG, "cn_actor_forward: null argument");
@@ -350,10 +373,17 @@ extern "C" int cn_actor_forward(const cn_actor_weights* w, const float* obs, flo
     const int Dp = w->obs_dim_padded;
     const size_t lds = sizeof(float) * (16 * (size_t)(Dp + 1) + 2 * 16 * 257);
     if (lds > 160 * 1024) return fail(CN_ERR_CONFIG, "cn_actor_forward: observation too wide for one LDS tile");
-    static bool attr_set = false;
-    if (lds > 64 * 1024 && !attr_set) {
-        HIPCHK(hipFuncSetAttribute((const void*)cn_actor_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+    int dev = device;
+    if (dev < 0) HIPCHK(hipGetDevice(&dev));
+    DeviceScope scope(dev);
+    if (lds > 64 * 1024) {   // hipFuncSetAttribute is per device: once per ordinal, under a lock
+        static std::mutex mu;
+        static bool attr_set[64] = {false};
+        std::lock_guard<std::mutex> lk(mu);
+        if (dev >= 64 || !attr_set[dev]) {
+            HIPCHK(hipFuncSetAttribute((const void*)cn_actor_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            if (dev < 64) attr_set[dev] = true;
+        }
     }
     hipLaunchKernelGGL(cn_actor_kernel, dim3((n + 15) / 16), dim3(256), lds, (hipStream_t)stream, obs, n, w->obs_dim, Dp,
                        w->w1t, w->b1, w->w2t, w->b2, w->w3, w->b3, action, max_v, max_w, sigma, seed, counter);
@@ -386,7 +416,7 @@ extern "C" int cn_get_returns(cn_handle h, float* last_return, float* running_re
 extern "C" int cn_debug_env(cn_handle h, int env, double* scalars, double* robot_ped, double* tracks, int32_t* ints)
 {
     if (!h || env < 0 || env >= h->cfg.n_envs) return fail(CN_ERR_ARG, "cn_debug_env: bad argument");
-    HIPCHK(hipSetDevice(h->device));
+    DeviceScope scope(h->device);
     HIPCHK(hipDeviceSynchronize());
     const int P = h->cfg.n_peds;
     std::vector<double> sd(CN_SD_COUNT);
@@ -418,7 +448,7 @@ extern "C" int cn_snapshot(cn_handle h, void* buf, size_t size)
 {
     if (!h || !buf) return fail(CN_ERR_ARG, "cn_snapshot: null argument");
     if (size < cn_snapshot_size(h)) return fail(CN_ERR_SIZE, "cn_snapshot: buffer too small");
-    HIPCHK(hipSetDevice(h->device));
+    DeviceScope scope(h->device);
     HIPCHK(hipDeviceSynchronize());
     size_t N = h->cfg.n_envs, P = h->cfg.n_peds;
     char* q = (char*)buf;
@@ -436,7 +466,7 @@ extern "C" int cn_restore(cn_handle h, const void* buf, size_t size)
 {
     if (!h || !buf) return fail(CN_ERR_ARG, "cn_restore: null argument");
     if (size < cn_snapshot_size(h)) return fail(CN_ERR_SIZE, "cn_restore: buffer too small");
-    HIPCHK(hipSetDevice(h->device));
+    DeviceScope scope(h->device);
     HIPCHK(hipDeviceSynchronize());
     size_t N = h->cfg.n_envs, P = h->cfg.n_peds;
     const char* q = (const char*)buf;

@@ -13,7 +13,9 @@ struct CnKParams {
     int32_t max_steps, ped_mode, dt_ms, scan_latency_ms, settle_ms, ped_cycle_ms, ped_stagger_ms;
     int32_t mode, auto_reset, max_conf, trk_cap;
     int32_t near_sep;        // near-pedestrian list: 1 = own LDS region, 0 = overlaid on region B (cn_near_separate)
-    int32_t ablate;          // PROFILING ONLY (cn_debug_set_ablate): skips stages, results are then invalid
+    int32_t ablate;          // PROFILING BUILD ONLY (cn_debug_set_ablate): skips stages, results are then invalid
+    int32_t ext_phase;       // cn_external_io.phase (CN_PHASE_* mask, 0 = whole flow); CN_MODE_EXT_STEP only
+    int32_t geos_untyped_empty, ped_contact, risk_mode;   // cn_config switches
     int64_t env_index_base;
     uint64_t seed;
     // constants (cn_config)

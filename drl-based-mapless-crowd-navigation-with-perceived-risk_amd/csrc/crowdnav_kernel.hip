@@ -1277,9 +1277,14 @@ __device__ __forceinline__ void env_kernel_body(const CnKParams& p)
         }
         int sc = 0;
         float* fin = nullptr;
+        // cn_external_io.phase: which pieces of Env.step this launch runs (external data only; 0 = all of them)
+        bool ph_pre = true, ph_obs = true, ph_rew = true;
+        if constexpr (EXT) {
+            if (p.ext_phase) { ph_pre = p.ext_phase & CN_PHASE_PRE; ph_obs = p.ext_phase & CN_PHASE_GET_STATE; ph_rew = p.ext_phase & CN_PHASE_REWARD; }
+        }
         if (!do_reset) {
             // Env.step (ENV:1164-1225), continuous mode
-            e.ep_step += 1;
+            if (ph_pre) e.ep_step += 1;
             sc = p.step_counter ? p.step_counter[env] : e.ep_step;
             double deq_x, deq_y, end_timestep;
             if (!ext) {
@@ -1295,11 +1300,13 @@ __device__ __forceinline__ void env_kernel_body(const CnKParams& p)
             } else {                                              // the caller ran the sleep; /odom said where we are
                 deq_x = od[6]; deq_y = od[7]; end_timestep = od[8];
             }
+            if (ph_pre) {
             double qx = cn_py_round3(deq_x), qy = cn_py_round3(deq_y);  // ENV:1208
             if (e.dq_len == 0) { e.dq0x = qx; e.dq0y = qy; e.dq_len = 1; }
             else if (e.dq_len == 1) { e.dq1x = qx; e.dq1y = qy; e.dq_len = 2; }
             else { e.dq0x = e.dq1x; e.dq0y = e.dq1y; e.dq1x = qx; e.dq1y = qy; }
             e.ts = end_timestep;                                  // ENV:1209
+            }
             if (!ext) {
                 e.clock += cn_div1000((double)p.scan_latency_ms);    // wait_for_message('scan') (ENV:1218)
                 sim_advance(p, e, env, lane, L.ped, pedv, p.scan_latency_ms);
@@ -1323,8 +1330,24 @@ __device__ __forceinline__ void env_kernel_body(const CnKParams& p)
             }
         }
         CN_SYNC();
-        if constexpr (LAYOUT == 1) observe_original<EXT>(p, e, L, env, lane, sc, p.obs, fin, p.obs_f64, &done);
-        else observe<EXT>(p, pg, e, L, env, lane, sc, p.obs, fin, p.obs_f64, &done);
+        if (ph_obs) {
+            if constexpr (LAYOUT == 1) observe_original<EXT>(p, e, L, env, lane, sc, p.obs, fin, p.obs_f64, &done);
+            else observe<EXT>(p, pg, e, L, env, lane, sc, p.obs, fin, p.obs_f64, &done);
+        } else if constexpr (EXT) {
+            // Env.compute_reward(state, step_counter, done) on its own (ENV:1046): heading and distance are state[n], state[n+1]
+            // (LAYOUT 1: state[-2], state[-1] are what ORIG:324-330 reads), `done` is the caller's
+            const int D_ = (LAYOUT == 1) ? n + 4 : n + 7 + 4 * K;
+            if (lane < 4) {
+                const int src = (LAYOUT == 1) ? n + lane : n + (lane & 1);
+                L.tail[lane] = p.obs_f64 ? p.obs_f64[(size_t)env * D_ + src] : (double)p.obs[(size_t)env * D_ + src];
+            }
+            done = p.done[env] ? 1 : 0;
+            CN_SYNC();
+        }
+        if (!do_reset && !ph_rew) {
+            if (lane == 0) p.done[env] = (uint8_t)done;           // get_state returns (state, self.done) (ENV:1044)
+            if (p.topk_idx && lane < K) p.topk_idx[(size_t)env * K + lane] = LAYOUT == 1 ? -1 : L.kidx[lane];
+        } else
         if (!do_reset) {
             double r;
             if constexpr (LAYOUT == 1) r = compute_reward_original(p, e, L, done);
@@ -1334,12 +1357,16 @@ __device__ __forceinline__ void env_kernel_body(const CnKParams& p)
                 p.reward[env] = (float)r;
                 p.done[env] = (uint8_t)done;
             }
-            if (p.topk_idx && lane < K) p.topk_idx[(size_t)env * K + lane] = LAYOUT == 1 ? -1 : L.kidx[lane];
+            if (ph_obs && p.topk_idx && lane < K) p.topk_idx[(size_t)env * K + lane] = LAYOUT == 1 ? -1 : L.kidx[lane];
             if (done) {
                 if (!ext) { e.rv = 0.0; e.rw = 0.0; }             // pub_cmd_vel.publish(Twist()) (ENV:1160)
                 e.last_ret = e.ep_ret;
                 e.episodes += 1;
                 e.pending = !ext && (p.auto_reset == 2);
+                if (lane == 0) {   // the finished episode's counters as TRAIN:142-147 reads them (the reset zeroes the live ones)
+                    sd[CN_SD_LAST_EGO_VIOL] = (double)e.ego_viol; sd[CN_SD_LAST_SOCIAL_VIOL] = (double)e.social_viol;
+                    sd[CN_SD_LAST_OBST_STEPS] = (double)e.obst_steps; sd[CN_SD_LAST_EP_STEPS] = (double)e.ep_step;
+                }
             }
         } else {
             e.social_viol = 0; e.ego_viol = 0; e.obst_steps = 0;  // ENV:1260-1262
@@ -1410,6 +1437,10 @@ __device__ __forceinline__ void env_kernel_body(const CnKParams& p)
             e.episodes += 1;
             need_reset = !ext && (p.auto_reset == 1);
             e.pending = !ext && (p.auto_reset == 2);
+            if (lane == 0) {   // the finished episode's counters as TRAIN:142-147 reads them (the reset zeroes the live ones)
+                sd[CN_SD_LAST_EGO_VIOL] = (double)e.ego_viol; sd[CN_SD_LAST_SOCIAL_VIOL] = (double)e.social_viol;
+                sd[CN_SD_LAST_OBST_STEPS] = (double)e.obst_steps; sd[CN_SD_LAST_EP_STEPS] = (double)e.ep_step;
+            }
         }
         CN_SYNC();
     }
@@ -1489,10 +1520,12 @@ extern "C" __global__ void cn_gather_kernel(CnKParams p, float* last_ret, float*
     if (last_ret) last_ret[i] = (float)sd[CN_SD_LAST_RETURN];
     if (run_ret) run_ret[i] = (float)sd[CN_SD_EP_RETURN];
     if (counters) {
-        int32_t* c = counters + (size_t)i * 10;
+        int32_t* c = counters + (size_t)i * CN_COUNTER_COLS;
         c[0] = si[CN_SI_EGO_VIOL]; c[1] = si[CN_SI_SOCIAL_VIOL]; c[2] = si[CN_SI_OBST_STEPS]; c[3] = si[CN_SI_EP_STEP];
         c[4] = si[CN_SI_SUCCESS]; c[5] = si[CN_SI_FAILURE]; c[6] = si[CN_SI_STATUS]; c[7] = si[CN_SI_NTRACKS];
         c[8] = si[CN_SI_EPISODES]; c[9] = si[CN_SI_PENDING_RESET];
+        c[10] = (int32_t)sd[CN_SD_LAST_EGO_VIOL]; c[11] = (int32_t)sd[CN_SD_LAST_SOCIAL_VIOL];
+        c[12] = (int32_t)sd[CN_SD_LAST_OBST_STEPS]; c[13] = (int32_t)sd[CN_SD_LAST_EP_STEPS];
     }
 }
 
@@ -1634,7 +1667,8 @@ extern "C" __global__ void __launch_bounds__(256) cn_actor_kernel(const float* _
     }
 }
 
-// ---- PMC calibration (tools/calib_pmc.py): known-byte streaming reads / writes at the access widths the
+#ifdef CN_TIMING
+// ---- PMC calibration (PROFILING BUILD ONLY, libcrowdnav_timing.so; tools/calib_pmc.py): known-byte streaming reads / writes at the access widths the
 // env kernel uses, so FETCH_SIZE / WRITE_SIZE can be turned into bytes (MI355X_MICROARCH.md, HBM section).
 template <typename T>
 __global__ void cn_calib_read_kernel(const T* __restrict__ src, size_t n, T* __restrict__ out)
@@ -1662,3 +1696,4 @@ extern "C" void cn_calib_launch(void* buf, size_t bytes, int width, int write, v
         else hipLaunchKernelGGL(cn_calib_write_kernel<double>, g, b, 0, st, (double*)buf, bytes / 8);
     }
 }
+#endif

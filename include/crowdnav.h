@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CN_ABI_VERSION 2
+#define CN_ABI_VERSION 3
 #define CN_MAX_TRACKS 64      /* largest per-env capacity of the obstacle tracker (ENV:656-743): one lane per track */
 #define CN_MAX_K 16
 
@@ -45,6 +45,8 @@ enum { CN_ST_TRACK_OVERFLOW = 1, CN_ST_TTC_ZERO = 2, CN_ST_DT_ZERO = 4, CN_ST_CO
 /* Every field of Env.__init__'s rosparam reads (ENV:71-91), the robot/lidar constants of the
  * URDF/XACRO and world files, and the crowd node's constants.  SURVEY.md appendix B cites each. */
 enum { CN_LAYOUT_RISK = 0, CN_LAYOUT_ORIGINAL = 1 };
+/* where the perceived-risk features (rows A21-A24) take their obstacles from */
+enum { CN_RISK_LIDAR_TRACKER = 0, CN_RISK_GT = 1 };
 
 typedef struct cn_config {
     int32_t n_envs;          /* N environments in this handle (this GPU's shard) */
@@ -62,7 +64,17 @@ typedef struct cn_config {
     int32_t obs_layout;      /* CN_LAYOUT_RISK (0): environment_stage_1_nobonus.py, obs = R-1 + 7 + 4K (TD3 / DDPG trainers);
                               * CN_LAYOUT_ORIGINAL (1): environment_stage_1_original.py:278-402, obs = R-1 + 4 =
                               * rounded ranges + heading + distance + rounded (x, y) (SAC / DQN / Q-learning trainers) */
-    int32_t reserved1;
+    int32_t geos_untyped_empty; /* shapely/GEOS version switch for UTL:279,306 `str(i) != 'LINESTRING EMPTY'`:
+                              * 0: GEOS >= 3.9 typed empties (a miss prints 'LINESTRING EMPTY' and is skipped);
+                              * 1: GEOS <= 3.8 (the reference's Python-2.7 / shapely <= 1.7 platform): a miss prints
+                              *    'GEOMETRYCOLLECTION EMPTY', the comparison is true, `.geoms` of the empty result is
+                              *    empty and the [0] raises -> get_collision_point returns None on the FIRST candidate
+                              *    that misses, and get_local_goal_waypoints takes its except branch */
+    int32_t ped_contact;     /* 0: pedestrians pass through each other and the robot (round-1 simulator);
+                              * 1: frictionless rigid contact, disc-disc and disc-robot (WORLD:86-145 mu = 0 cylinders) */
+    int32_t risk_mode;       /* CN_RISK_LIDAR_TRACKER (0): the reference's lidar segmentation + tracker (ENV:329-760);
+                              * CN_RISK_GT (1): A21-A24 fed with the simulator's own pedestrians (nearest surface point,
+                              *    true velocity) within lidar range and line of sight; indices = pedestrian ids */
     int64_t env_index_base;  /* global index of env 0: RNG streams are keyed by global index */
     uint64_t seed;
     double room_half;        /* WORLD:926-1108 -> 1.40 */
@@ -118,8 +130,15 @@ typedef struct cn_external_io {
     uint8_t* done;               /* dev [N] */
     int32_t* topk_idx;           /* dev [N,K] or NULL */
     int32_t is_reset;            /* 1: Env.reset() flow (ENV:1243-1262 + TRAIN:116), 0: Env.step() flow (ENV:1208-1223) */
-    int32_t reserved;
+    int32_t phase;               /* 0: the whole flow selected by is_reset.  Otherwise a mask of the pieces of Env.step, so that
+                                  * get_state and compute_reward can be called separately as ENV:1222-1223 does:
+                                  *   CN_PHASE_PRE          ENV:1208-1209 agent_pose_deque.append + agent_vel_timestep (odom[6..8])
+                                  *   CN_PHASE_GET_STATE    Env.get_state(scan, step_counter, action) -> obs, done (ENV:245-1044)
+                                  *   CN_PHASE_REWARD       Env.compute_reward(state, step_counter, done) -> reward, done
+                                  *                         (ENV:1046-1162): reads state[R-1], state[R] from obs_f64 (or obs)
+                                  *                         and `done` as INPUTS, position from odom[0..1] */
 } cn_external_io;
+enum { CN_PHASE_ALL = 0, CN_PHASE_PRE = 1, CN_PHASE_GET_STATE = 2, CN_PHASE_REWARD = 4 };
 
 int cn_abi_version(void);
 const char* cn_last_error(void);
@@ -145,7 +164,7 @@ int cn_observe_external(cn_handle h, const cn_external_io* io, void* stream);
  * Replaces td3.py:103-104 (sigmoid*max_v, tanh*max_w), td3.py:67-78,209-211 (Gaussian exploration) and
  * td3.py:214-215 (clip).  logits, action: dev [n,2] float32; noise is keyed by (seed, counter, row). */
 int cn_policy_tail(const float* logits, float* action, int n, float max_v, float max_w, float sigma,
-                   uint64_t seed, uint64_t counter, void* stream);
+                   uint64_t seed, uint64_t counter, int device, void* stream);   /* device: HIP ordinal, -1 = current */
 
 /* The whole TD3 actor as one launch: Actor.forward (td3.py:96-106: Linear(obs_dim,256)-ReLU-Linear(256,256)-ReLU-
  * Linear(256,2), sigmoid*max_v / tanh*max_w heads) + Agent.act's exploration noise and clip (td3.py:209-215), in
@@ -157,11 +176,14 @@ typedef struct cn_actor_weights {
     int32_t obs_dim, obs_dim_padded, hidden, reserved;
 } cn_actor_weights;
 int cn_actor_forward(const cn_actor_weights* w, const float* obs, float* action, int n, float max_v, float max_w,
-                     float sigma, uint64_t seed, uint64_t counter, void* stream);
+                     float sigma, uint64_t seed, uint64_t counter, int device, void* stream);
 
 /* get_episode_status / get_*_safety_violation_status inputs (ENV:1265-1283).
- * out: dev [N,10] = ego_viol, social_viol, obstacle_present_steps, ep_steps, success, failure, status, n_tracks,
- *                  episodes finished since cn_create, reset pending (auto_reset == 2) */
+ * out: dev [N,14] = ego_viol, social_viol, obstacle_present_steps, ep_steps, success, failure, status, n_tracks,
+ *                  episodes finished since cn_create, reset pending (auto_reset == 2),
+ *                  and the LAST FINISHED episode's ego_viol, social_viol, obstacle_present_steps, ep_steps as they stood
+ *                  when Env.step returned done (what TRAIN:142-147 reads before the next reset zeroes them) */
+#define CN_COUNTER_COLS 14
 int cn_get_counters(cn_handle h, int32_t* out, void* stream);
 /* return of the last finished episode and running return, dev [N] each (either may be NULL) */
 int cn_get_returns(cn_handle h, float* last_return, float* running_return, void* stream);
@@ -180,7 +202,8 @@ int cn_restore(cn_handle h, const void* host_buf, size_t size);
 enum {
     CN_SD_RX = 0, CN_SD_RY, CN_SD_RYAW, CN_SD_RV, CN_SD_RW, CN_SD_CLOCK, CN_SD_WPX, CN_SD_WPY,
     CN_SD_PREV_DIST, CN_SD_PREV_HEAD, CN_SD_DQ0X, CN_SD_DQ0Y, CN_SD_DQ1X, CN_SD_DQ1Y, CN_SD_TS,
-    CN_SD_BB, CN_SD_EGO, CN_SD_CPROB, CN_SD_EP_RETURN, CN_SD_LAST_RETURN, CN_SD_COUNT = 24
+    CN_SD_BB, CN_SD_EGO, CN_SD_CPROB, CN_SD_EP_RETURN, CN_SD_LAST_RETURN,
+    CN_SD_LAST_EGO_VIOL, CN_SD_LAST_SOCIAL_VIOL, CN_SD_LAST_OBST_STEPS, CN_SD_LAST_EP_STEPS, CN_SD_COUNT = 24
 };
 /* int32 scalar record per env */
 enum {

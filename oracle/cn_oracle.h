@@ -39,7 +39,9 @@ typedef struct cno_config {
     int32_t ped_stagger_ms;  /* per-pedestrian offset (CROWD:144 sleep 0.1) -> 100 */
     int32_t reserved0;
     int32_t obs_layout;      /* 0: environment_stage_1_nobonus.py (366+4K); 1: environment_stage_1_original.py (R-1+4) */
-    int32_t reserved1;
+    int32_t geos_untyped_empty; /* 1: GEOS <= 3.8 / shapely <= 1.7 untyped empties at UTL:279,306 (see include/crowdnav.h) */
+    int32_t ped_contact;     /* 1: frictionless rigid contact pedestrian-pedestrian and pedestrian-robot */
+    int32_t risk_mode;       /* 0: lidar tracker (reference); 1: gt (simulator pedestrians feed A21-A24) */
     int64_t env_index_base;  /* global index of env 0 (multi-GPU sharding) */
     uint64_t seed;
     double room_half;        /* inner half extent of the square room (WORLD:926-1108 -> 1.40) */

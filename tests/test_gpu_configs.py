@@ -1,0 +1,207 @@
+"""BASELINE.json configs 2, 3 and 4 at their FULL sizes against the CPU oracle, through the C-ABI (`-m gpu`).
+
+  config 2   4096 envs x 20 pedestrians x 360 rays, K = 8, one MI355X
+  config 3   4096 envs, the TD3 actor in the loop (cn_actor_forward -> cn_step chains on 4 stream groups)
+  config 4   envs sharded over ranks by global index, all-gather of episode returns: two ranks with the REAL kernel
+             (two processes sharing cuda:0, gloo) against one handle
+
+Envs are independent, so the oracle needs < 1 s per config here (OpenMP over envs).  Bar: done flags and top-K
+indices bit-exact, observation / reward within 1e-5 (north_star); in practice everything is equal."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import PKG, ROOT, load_seq
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def test_config2_full_size_4096_envs(oracle_mod):
+    import torch
+    from crowdnav import Config
+    from crowdnav.env import VecEnv
+    N, STEPS = 4096, 40
+    cfg = Config(n_envs=N, n_peds=20, n_rays=360, k_obstacles=8, max_steps=30, seed=1234, ped_cycle_ms=1400)
+    env = VecEnv(cfg); env.enable_f64_obs()
+    orc = oracle_mod.Oracle(cfg.as_dict())
+    oracle_mod.set_num_threads(os.cpu_count() or 1)
+    env.reset(); torch.cuda.synchronize()
+    assert np.array_equal(env.obs_f64.cpu().numpy(), orc.reset())
+    g = torch.Generator(device="cpu").manual_seed(7)
+    n_done = exact = 0
+    for t in range(STEPS):
+        act = torch.stack([torch.rand(N, generator=g) * 0.22, torch.rand(N, generator=g) * 4 - 2], 1)
+        mode = "next" if t >= STEPS // 2 else "same"       # both reset conventions at full size
+        env.step(act.cuda(), auto_reset=mode, want_final=True); torch.cuda.synchronize()
+        oc, rc, dc, ic, fc = orc.step(act.numpy().astype(np.float64), auto_reset=mode, want_final=True)
+        assert np.array_equal(env.done.cpu().numpy(), dc), t                      # bit-exact
+        assert np.array_equal(env.topk_idx.cpu().numpy(), ic), t                  # bit-exact
+        assert np.abs(env.reward.cpu().numpy() - rc).max() <= TOL, t
+        og = env.obs_f64.cpu().numpy()
+        assert np.abs(og - oc).max() <= TOL, t
+        assert np.array_equal(env.obs.cpu().numpy(), oc.astype(np.float32)), t
+        exact += int((og == oc).all(1).sum()); n_done += int(dc.sum())
+    assert np.array_equal(env.counters().cpu().numpy()[:, :6], orc.counters())
+    assert n_done > N // 2 and exact == STEPS * N
+
+
+@pytest.mark.parametrize("sigma", [0.0, 1.0])
+def test_config3_actor_in_the_loop_4096_envs(oracle_mod, sigma):
+    """The act -> step chain of rollout_groups at full size: 4 stream groups, each running cn_actor_forward then cn_step
+    on its own stream.  Every step the GPU's actions are copied to the host and drive the oracle; the trajectory the
+    policy sees (observations -> actions -> observations ...) must then be the oracle's, for 50 steps."""
+    import torch
+    from crowdnav import Config
+    from crowdnav.env import VecEnvGroups
+    from crowdnav.rollout import rollout_groups
+    from crowdnav.td3 import Agent
+    N, STEPS = 4096, 50
+    cfg = Config(n_envs=N, n_peds=20, max_steps=25, seed=77, ped_cycle_ms=1400)
+    envs = VecEnvGroups(cfg, groups=4)
+    agent = Agent(obs_dim=envs.D, device="cuda", seed=5, memory_size=16, explore_sigma=sigma)
+    with torch.no_grad():                 # spread the random-init actor's outputs so that the robots really move
+        agent.actor.linear3.weight.mul_(25.0)
+    orc = oracle_mod.Oracle(cfg.as_dict())
+    oracle_mod.set_num_threads(os.cpu_count() or 1)
+    o0 = envs.reset(); torch.cuda.synchronize()
+    oc = orc.reset()
+    assert np.array_equal(o0.cpu().numpy(), oc.astype(np.float32))
+    envs._started = True
+    n_done = 0
+    acts_seen = []
+    for t in range(STEPS):
+        rollout_groups(envs, agent, 1, add_noise=sigma > 0, auto_reset="next")
+        torch.cuda.synchronize()
+        act = envs._act.cpu().numpy()
+        assert act[:, 0].min() >= 0.0 and act[:, 0].max() <= 0.22 and np.abs(act[:, 1]).max() <= 2.0
+        oc, rc, dc, ic = orc.step(act.astype(np.float64), auto_reset="next")
+        assert np.array_equal(envs.done.cpu().numpy(), dc), t
+        assert np.array_equal(envs.topk_idx.cpu().numpy(), ic), t
+        assert np.abs(envs.reward.cpu().numpy() - rc).max() <= TOL, t
+        assert np.abs(envs.obs.cpu().numpy().astype(np.float64) - oc).max() <= TOL, t
+        n_done += int(dc.sum()); acts_seen.append(act[:64].copy())
+    assert n_done > N
+    a = np.stack(acts_seen)
+    assert a[:, :, 1].std() > 0.05            # the policy's output varies across envs and steps
+    if sigma > 0:                              # groups draw different noise; steps draw different noise
+        assert not np.array_equal(acts_seen[0], acts_seen[1])
+    envs.close()
+
+
+def test_episode_stats_rows_match_the_reference_run():
+    """SURVEY 8a A33 "pinned by": the batched loop's per-episode rows (EpisodeStats: success, failure, return, steps,
+    ego / social safety scores) equal the tuples of the golden run the REFERENCE's Python produced (`train20`: five
+    episodes), the recorded actions replayed through crowdnav.rollout.rollout with same-call auto-reset."""
+    import torch
+    from crowdnav import Config
+    from crowdnav.env import VecEnv
+    from crowdnav.rollout import EpisodeStats, rollout
+    z, kw = load_seq("train20")
+    steps = [i for i in range(len(z["now"])) if not z["is_reset"][i]]
+    acts = torch.tensor(np.stack([z["action"][i] for i in steps]), dtype=torch.float32, device="cuda")
+    env = VecEnv(Config(n_envs=1, **kw))
+    env.set_ped_init(z["ped_init"])
+    stats = EpisodeStats()
+    rollout(env, None, len(steps), stats=stats, policy=lambda obs, t: acts[t:t + 1].contiguous())
+    # the reference's tuples, episode by episode (TRAIN:142-161)
+    want, ret, n = [], 0.0, 0
+    for i in steps:
+        ret += float(z["reward"][i]); n += 1
+        if z["done"][i]:
+            ego_v, soc_v, seen = (int(c) for c in z["counters"][i])
+            want.append((bool(z["status"][i][0]), bool(z["status"][i][1]), ret, n,
+                         1.0 - ego_v * 1.0 / seen if seen else float("nan"), 1.0 - soc_v * 1.0 / seen if seen else float("nan")))
+            ret, n = 0.0, 0
+    assert len(want) == 5 and len(stats.rows) == len(want)
+    for row, w in zip(stats.rows, want):
+        assert (row[1], row[2]) == (w[0], w[1])
+        assert row[3] == pytest.approx(w[2], abs=1e-3) and row[4] == w[3]        # return (float32 on the device), steps
+        for got, exp in ((row[5], w[4]), (row[6], w[5])):
+            assert (got != got and exp != exp) or got == pytest.approx(exp, abs=1e-12)
+
+
+def _rank_worker(rank, world, port, n_total, steps, q):
+    for p_ in (ROOT, PKG):
+        sys.path.insert(0, p_)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from crowdnav import Config
+    from crowdnav.env import VecEnv
+    from crowdnav.rollout import gather_returns, shard_range
+    base, n = shard_range(n_total, rank, world)
+    env = VecEnv(Config(n_envs=n, env_index_base=base, max_steps=15, seed=77))     # both ranks share cuda:0
+    env.reset()
+    g = torch.Generator(device="cpu").manual_seed(123)
+    done_count = 0
+    for t in range(steps):
+        act = torch.stack([torch.rand(n_total, generator=g) * 0.22, torch.rand(n_total, generator=g) * 4 - 2], 1)
+        _, _, d = env.step(act[base:base + n].contiguous().cuda(), auto_reset=True)
+        done_count += int(d.sum().item())
+    allr = gather_returns(env.returns()[0].cpu())            # gloo: host tensors
+    obs = [torch.empty_like(env.obs.cpu()) for _ in range(world)]
+    dist.all_gather(obs, env.obs.cpu())
+    total = torch.tensor([done_count]); dist.all_reduce(total)
+    if rank == 0:
+        q.put((allr.numpy(), torch.cat(obs).numpy(), int(total.item())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_config4_two_ranks_with_the_real_kernel():
+    """World size 2 with the HIP kernel (not the oracle) as the environment: rank r owns global envs [r N/2, (r+1) N/2)
+    with env_index_base = r N/2; the gathered returns and observations equal a single handle of N envs."""
+    import torch
+    import torch.multiprocessing as mp
+    from crowdnav import Config
+    from crowdnav.env import VecEnv
+    N_TOTAL, STEPS = 256, 40
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_rank_worker, args=(r, 2, port, N_TOTAL, STEPS, q)) for r in range(2)]
+    for p_ in procs:
+        p_.start()
+    allr, allobs, total = q.get(timeout=300)
+    for p_ in procs:
+        p_.join(timeout=120)
+        assert p_.exitcode == 0
+    env = VecEnv(Config(n_envs=N_TOTAL, max_steps=15, seed=77))
+    env.reset()
+    g = torch.Generator(device="cpu").manual_seed(123)
+    dc = 0
+    for t in range(STEPS):
+        act = torch.stack([torch.rand(N_TOTAL, generator=g) * 0.22, torch.rand(N_TOTAL, generator=g) * 4 - 2], 1)
+        _, _, d = env.step(act.cuda(), auto_reset=True)
+        dc += int(d.sum().item())
+    assert total == dc and dc >= N_TOTAL
+    assert np.array_equal(allr, env.returns()[0].cpu().numpy())
+    assert np.array_equal(allobs, env.obs.cpu().numpy())
+
+
+def test_bench_self_launches_two_ranks():
+    """`python bench.py --gpus 2` with no launcher environment re-executes itself under torch.distributed.run and prints
+    ONE JSON line with n_gpus = 2 and a measured all-gather (dry run: both ranks share cuda:0 over gloo, so the numbers
+    mean nothing -- the launch path, the sharding arguments and the JSON contract are what is checked), in both the
+    weak-scaling and the --envs-total (BASELINE config 4) forms."""
+    import json
+    import subprocess
+    env = dict(os.environ, CN_BENCH_DRYRUN_GLOO="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    for extra, per_gpu, scaling in ((["--envs", "256"], 256, "weak"), (["--envs-total", "512"], 256, "strong")):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
+                            "--preroll", "5", "--groups", "2", "--no-cpu-baseline"] + extra,
+                           capture_output=True, text=True, timeout=900, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]
+        out = json.loads(lines[0])
+        assert out["n_gpus"] == 2 and out["scaling"] == scaling
+        assert out["config"]["envs_per_gpu"] == per_gpu and out["config"]["envs_total"] == 2 * per_gpu
+        assert out["config"]["returns_allgather_ms"] is not None and out["value"] > 0

@@ -448,7 +448,7 @@ def test_fused_policy_tail_matches_the_torch_heads():
     raw = torch.empty((200000, 2), device="cuda"); z = torch.zeros((200000, 2), device="cuda")
     import ctypes as C
     from crowdnav import _abi
-    _abi.check(_abi.lib().cn_policy_tail(C.c_void_p(z.data_ptr()), C.c_void_p(raw.data_ptr()), 200000, 1e9, 1e9, 1.0, 7, 1,
+    _abi.check(_abi.lib().cn_policy_tail(C.c_void_p(z.data_ptr()), C.c_void_p(raw.data_ptr()), 200000, 1e9, 1e9, 1.0, 7, 1, -1,
                                          C.c_void_p(torch.cuda.current_stream().cuda_stream)))
     torch.cuda.synchronize()
     w = raw[:, 1]                     # tanh(0) * max_w + N(0, 1), never clipped with max_w = 1e9

@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.join(ROOT, "drl-based-mapless-crowd-navigation-with-p
 import torch  # noqa: E402
 import crowdnav  # noqa: E402
 
-L = crowdnav.lib()
+L = C.CDLL(crowdnav._abi.build_timing())   # the calibration kernels live in the profiling build only
 L.cn_calib_launch.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
 L.cn_calib_launch.restype = None
 BYTES = 1 << 30   # 1 GiB: well past the 256 MiB Infinity Cache
