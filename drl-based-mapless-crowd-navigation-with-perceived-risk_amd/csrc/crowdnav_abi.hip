@@ -20,6 +20,7 @@ extern "C" __global__ void cn_env_kernel_same(CnKParams p);
 extern "C" __global__ void cn_env_kernel_orig(CnKParams p);
 extern "C" __global__ void cn_env_kernel_orig_ext(CnKParams p);
 extern "C" __global__ void cn_env_kernel_orig_same(CnKParams p);
+extern "C" __global__ void cn_bbox_kernel(CnKParams p, double* out);
 extern "C" __global__ void cn_gather_kernel(CnKParams p, float* last_ret, float* run_ret, int32_t* counters);
 
 static thread_local std::string g_err;
@@ -228,6 +229,15 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
     k.lidar_c = h->d_lidar; k.lidar_s = h->d_lidar + R; k.ang_s = h->d_lidar + 2 * R; k.ang_c = h->d_lidar + 3 * R; k.poly_c = h->d_poly; k.poly_s = h->d_poly + 64;
     k.state = h->d_state; k.state_stride = (int64_t)h->stride; k.ped_init = h->d_ped_init;
     k.ped_preset = h->d_ped_preset; k.trk = h->d_trk;
+    {   // the reset path's bounding-box size at the spawn pose (a constant of the configuration), from the device's own arithmetic
+        double* d_out = nullptr;
+        HIPCHK(hipMalloc(&d_out, sizeof(double)));
+        hipLaunchKernelGGL(cn_bbox_kernel, dim3(1), dim3(64), 0, (hipStream_t)0, k, d_out);
+        hipError_t e1 = hipGetLastError(), e2 = hipMemcpy(&k.bb_spawn, d_out, sizeof(double), hipMemcpyDeviceToHost);
+        (void)hipFree(d_out);
+        HIPCHK(e1); HIPCHK(e2);
+        k.bb_spawn_valid = 1;
+    }
     if (h->lds > 64 * 1024)
     {
         HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));

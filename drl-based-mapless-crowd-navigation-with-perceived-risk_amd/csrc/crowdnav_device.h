@@ -184,6 +184,12 @@ __device__ __forceinline__ double cn_wave_min_d(double v)
     for (int m = 32; m >= 1; m >>= 1) v = fmin(v, cn_shfl_xor_d(v, m));
     return v;
 }
+__device__ __forceinline__ double cn_wave_max_d(double v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmax(v, cn_shfl_xor_d(v, m));
+    return v;
+}
 __device__ __forceinline__ int cn_wave_min_i(int v)
 {
 #pragma unroll

@@ -22,6 +22,8 @@ struct CnKParams {
     double room_half, ped_radius, ped_vmax, robot_clearance, lidar_min, lidar_max, lidar_offset_x;
     double max_scan_range, min_scan_range, goal_x, goal_y, start_x, start_y, spawn_x, spawn_y, spawn_yaw;
     double waypoint_radius, goal_eps, angle_inc_deg, lidar_step;
+    double bb_spawn;         // bounding-box size (UTL:405-419) at the spawn pose, evaluated on the device by cn_create
+    int64_t bb_spawn_valid;
     // tables (device)
     const double* lidar_c;  // [R] cos(k * span/(R-1)), deterministic sincos
     const double* lidar_s;  // [R]

@@ -24,8 +24,8 @@
 
 // Stage time stamps (PROFILING BUILD ONLY: build.sh timing -> libcrowdnav_timing.so; tools/stage_timing.py)
 #ifdef CN_TIMING
-#define CN_ABLATE(bit) (p.ablate & (bit))   /* stage-skipping mask of tools/ablate.py: timing build only */
-#define CN_T(k) do { if (p.timing && lane == 0) p.timing[(size_t)env * 32 + (k)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#define CN_ABLATE(bit) (p->ablate & (bit))   /* stage-skipping mask of tools/ablate.py: timing build only */
+#define CN_T(k) do { if (p->timing && lane == 0) p->timing[(size_t)env * 32 + (k)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define CN_ABLATE(bit) 0
 #define CN_T(k) do { } while (0)
@@ -39,6 +39,11 @@ typedef unsigned long long u64;
 enum { M_NONE = 0, M_ZERO, M_EQ, M_NNONE, M_NZERO, M_ISW, M_ISO, M_ALIAS, M_BRK, M_SEG, M_KW, M_KO, M_OCC, M_COUNT };
 
 namespace {
+// The kernel parameters (~110 dwords) are read from the KERNARG SEGMENT where they are needed, through a constant-address-
+// space pointer, instead of through the by-value kernel argument: the compiler preloads a by-value argument into SGPRs at
+// entry and, with 106 SGPRs per wave, spills most of it into VGPR lanes -- 1037 v_readlane reloads, a sixth of the kernel's
+// VALU instructions and a third of the ray loop.  Read in place they are scalar loads next to their uses.
+typedef const __attribute__((address_space(4))) CnKParams* KP;
 
 struct EnvRegs {  // per-env scalars, uniform across the wave
     double rx, ry, ryaw, rv, rw, clock, wpx, wpy, prev_dist, prev_head;
@@ -67,10 +72,10 @@ struct Lds {
     int* kidx;        // [K]
 };
 
-__device__ __forceinline__ double heading_to_goal(const CnKParams& p, const EnvRegs& e, double px, double py, double yaw)
+__device__ __forceinline__ double heading_to_goal(KP p, const EnvRegs& e, double px, double py, double yaw)
 {
     // ENV:222-237 (adds starting_point to the position; ENV:191-209 does not)
-    double cx = px + p.start_x, cy = py + p.start_y;
+    double cx = px + p->start_x, cy = py + p->start_y;
     double ga = atan2(e.wpy - cy, e.wpx - cx);
     double h = ga - yaw;
     if (h > CN_PI) h -= 2 * CN_PI;
@@ -138,28 +143,32 @@ __device__ __forceinline__ u64 uni64(u64 v)
 }
 
 // UTL:296-314 get_local_goal_waypoints
-__device__ __forceinline__ void waypoint_refresh(const CnKParams& p, const Poly& pg, EnvRegs& e, int lane, double px, double py)
+__device__ __forceinline__ void waypoint_refresh(KP p, const Poly& pg, EnvRegs& e, int lane, double px, double py)
 {
     double hx = 0.0, hy = 0.0;
-    unsigned long long m = ring_segment(pg, lane, px, py, p.waypoint_radius, px, py, p.goal_x, p.goal_y, &hx, &hy);
+    unsigned long long m = ring_segment(pg, lane, px, py, p->waypoint_radius, px, py, p->goal_x, p->goal_y, &hx, &hy);
     if (__popcll(m) == 1) {
         int src = __ffsll((long long)m) - 1;
         e.wpx = bcast_d(hx, src);
         e.wpy = bcast_d(hy, src);
     } else {
-        e.wpx = -(p.goal_x + 0.0);  // UTL:310-312: x sign flipped
-        e.wpy = p.goal_y + 0.0;
+        e.wpx = -(p->goal_x + 0.0);  // UTL:310-312: x sign flipped
+        e.wpy = p->goal_y + 0.0;
     }
 }
 
 // ---- simulator -------------------------------------------------------------------------------
-__device__ __forceinline__ void ped_advance(const CnKParams& p, int env, int lane, double* ped_p, double* ped_v, long long t0, long long t1)
+// Advances every pedestrian from crowd time t0 to t1.  `split` (0 < split < t1 - t0, or 0 for none) is an instant at which
+// the integration is cut in two -- x <- clamp(fma(v, split - tc, x)), then on from there -- exactly as two back-to-back calls
+// [t0, t0 + split], [t0 + split, t1] would: Env.step samples the world at +150 ms (deque) and +160 ms (scan), and the same
+// fma chain cut at the same instants gives the same bits while the schedule prologue runs once.
+__device__ __forceinline__ void ped_advance(KP p, int env, int lane, double* ped_p, double* ped_v, long long t0, long long t1, int split = 0)
 {
-    const double lo = -p.room_half + p.ped_radius, hi = p.room_half - p.ped_radius;
-    const int T = p.ped_cycle_ms;
-    const double invT = 1.0 / (double)p.ped_cycle_ms;
-    const long long gid = p.env_index_base + env;
-    const double* preset = p.ped_preset + (size_t)env * 2 * p.P;
+    const double lo = -p->room_half + p->ped_radius, hi = p->room_half - p->ped_radius;
+    const int T = p->ped_cycle_ms;
+    const double invT = 1.0 / (double)p->ped_cycle_ms;
+    const long long gid = p->env_index_base + env;
+    const double* preset = p->ped_preset + (size_t)env * 2 * p->P;
     // Per-env part of the schedule, once: t0 = cyc * T + ph.  Everything per pedestrian is then 32-bit
     // arithmetic on times RELATIVE to t0 (the 64-bit emulated integer ops were most of this stage).
     long long cyc = (long long)((double)t0 * invT);
@@ -168,10 +177,10 @@ __device__ __forceinline__ void ped_advance(const CnKParams& p, int env, int lan
     if (ph64 >= T) { cyc += 1; ph64 -= T; }
     const int ph = (int)ph64;
     const int dt = (int)(t1 - t0);
-    for (int i = lane; i < p.P; i += 64) {
+    for (int i = lane; i < p->P; i += 64) {
         double x = ped_p[2 * i], y = ped_p[2 * i + 1];
         double vx = ped_v[2 * i], vy = ped_v[2 * i + 1];
-        const int offs = i * p.ped_stagger_ms;
+        const int offs = i * p->ped_stagger_ms;
         // first update instant >= t0 is offs + m*T with m = max(0, ceil((t0 - offs) / T)); a = that instant - t0
         const long long tt = cyc * (long long)T + (long long)(ph - offs);      // t0 - offs
         unsigned m; int a;
@@ -187,26 +196,38 @@ __device__ __forceinline__ void ped_advance(const CnKParams& p, int env, int lan
         }
         int tc = 0;
         while (a < dt) {
+            if (split > tc && a >= split) {                  // the cut comes first (an update AT the cut belongs to the second half)
+                double ds = cn_div1000((double)(split - tc));
+                x = cn_clamp(fma(vx, ds, x), lo, hi);
+                y = cn_clamp(fma(vy, ds, y), lo, hi);
+                tc = split;
+            }
             if (a > tc) {
                 double ds = cn_div1000((double)(a - tc));    // == (a - tc) / 1000.0 exactly
                 x = cn_clamp(fma(vx, ds, x), lo, hi);
                 y = cn_clamp(fma(vy, ds, y), lo, hi);
                 tc = a;
             }
-            if (p.ped_mode == 0) {  // CROWD:101-102: cn_rng_u01(seed, gid, 1, i, 2m | 2m+1); the env part of the key is
+            if (p->ped_mode == 0) {  // CROWD:101-102: cn_rng_u01(seed, gid, 1, i, 2m | 2m+1); the env part of the key is
                 // only computed when some pedestrian of the wave really draws (most 10 ms advances have none)
-                const uint64_t hbase = cn_mix64(p.seed ^ cn_mix64((uint64_t)gid));
+                const uint64_t hbase = cn_mix64(p->seed ^ cn_mix64((uint64_t)gid));
                 const uint64_t h1 = cn_mix64(hbase ^ ((1ull << 32) | (uint64_t)(uint32_t)i));
                 const double u0 = (double)(cn_mix64(h1 ^ (uint64_t)(uint32_t)(2u * m)) >> 11) * (1.0 / 9007199254740992.0);
                 const double u1 = (double)(cn_mix64(h1 ^ (uint64_t)(uint32_t)(2u * m + 1u)) >> 11) * (1.0 / 9007199254740992.0);
-                vx = fma(2.0 * p.ped_vmax, u0, -p.ped_vmax);
-                vy = fma(2.0 * p.ped_vmax, u1, -p.ped_vmax);
+                vx = fma(2.0 * p->ped_vmax, u0, -p->ped_vmax);
+                vy = fma(2.0 * p->ped_vmax, u1, -p->ped_vmax);
             } else {
                 vx = preset[2 * i];
                 vy = preset[2 * i + 1];
             }
             a += T;
             m += 1u;
+        }
+        if (split > tc) {
+            double ds = cn_div1000((double)(split - tc));
+            x = cn_clamp(fma(vx, ds, x), lo, hi);
+            y = cn_clamp(fma(vy, ds, y), lo, hi);
+            tc = split;
         }
         if (dt > tc) {
             double ds = cn_div1000((double)(dt - tc));
@@ -218,14 +239,54 @@ __device__ __forceinline__ void ped_advance(const CnKParams& p, int env, int lan
     }
 }
 
-// mid-point diff-drive step (turtlebot3_fake.cpp:156-162)
-__device__ __forceinline__ void robot_advance(const CnKParams& p, EnvRegs& e, int ms)
+__device__ __forceinline__ double lane_d(double v, int src)   // lane `src` (a constant) of v as a wave-uniform value
+{
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wrap_yaw(double th)
+{
+    if (th > CN_PI) th -= 2.0 * CN_PI;
+    else if (th <= -CN_PI) th += 2.0 * CN_PI;
+    return th;
+}
+// sin/cos an observation needs besides the simulator's own: the lidar frame (yaw) and ENV:267-268's cos(w), sin(w)
+struct Trig { double sy, cy, sw, cw; };
+
+// mid-point diff-drive step (turtlebot3_fake.cpp:156-162); sn, cs = sin/cos of the mid-point heading fma(0.5, w dt, yaw)
+__device__ __forceinline__ void robot_advance_sc(KP p, EnvRegs& e, int ms, double sn, double cs)
+{
+    double dts = cn_div1000((double)ms);
+    double ds = e.rv * dts, dth = e.rw * dts;
+    double lim = p->room_half - p->robot_clearance;
+    e.rx = cn_clamp(fma(ds, cs, e.rx), -lim, lim);
+    e.ry = cn_clamp(fma(ds, sn, e.ry), -lim, lim);
+    e.ryaw = wrap_yaw(e.ryaw + dth);
+}
+// Env.step's two robot advances (dt, then the scan latency) with every sine and cosine the step needs evaluated in ONE pass:
+// the mid-point headings of both advances, the final yaw and w itself are all known once the action is, so lanes 0..3 take
+// one argument each through the same polynomial (the four evaluations were ~45 wave-uniform float64 instructions apiece,
+// each a serial dependency chain on the critical path).  Same arithmetic per value as robot_advance + observe.
+__device__ __forceinline__ void step_trig(KP p, const EnvRegs& e, int lane, double& s1, double& c1, double& s2, double& c2, Trig& tg)
+{
+    const double dth1 = e.rw * cn_div1000((double)p->dt_ms), dth2 = e.rw * cn_div1000((double)p->scan_latency_ms);
+    const double a1 = fma(0.5, dth1, e.ryaw);
+    const double y1 = wrap_yaw(e.ryaw + dth1);
+    const double a2 = fma(0.5, dth2, y1);
+    const double y2 = wrap_yaw(y1 + dth2);
+    const double x = lane == 0 ? a1 : (lane == 1 ? a2 : (lane == 2 ? y2 : e.rw));
+    double s_, c_;
+    cn_det_sincos(x, &s_, &c_);
+    s1 = lane_d(s_, 0); c1 = lane_d(c_, 0); s2 = lane_d(s_, 1); c2 = lane_d(c_, 1);
+    tg.sy = lane_d(s_, 2); tg.cy = lane_d(c_, 2); tg.sw = lane_d(s_, 3); tg.cw = lane_d(c_, 3);
+}
+__device__ __forceinline__ void robot_advance(KP p, EnvRegs& e, int ms)
 {
     double dts = cn_div1000((double)ms);
     double ds = e.rv * dts, dth = e.rw * dts;
     double sn, cs;
     cn_det_sincos(fma(0.5, dth, e.ryaw), &sn, &cs);
-    double lim = p.room_half - p.robot_clearance;
+    double lim = p->room_half - p->robot_clearance;
     e.rx = cn_clamp(fma(ds, cs, e.rx), -lim, lim);
     e.ry = cn_clamp(fma(ds, sn, e.ry), -lim, lim);
     double th = e.ryaw + dth;
@@ -234,7 +295,7 @@ __device__ __forceinline__ void robot_advance(const CnKParams& p, EnvRegs& e, in
     e.ryaw = th;
 }
 
-__device__ __forceinline__ void sim_advance(const CnKParams& p, EnvRegs& e, int env, int lane, double* ped_p, double* ped_v, int ms)
+__device__ __forceinline__ void sim_advance(KP p, EnvRegs& e, int env, int lane, double* ped_p, double* ped_v, int ms)
 {
     if (ms <= 0) return;
     ped_advance(p, env, lane, ped_p, ped_v, e.crowd_ms, e.crowd_ms + ms);
@@ -248,18 +309,18 @@ __device__ __forceinline__ void sim_advance(const CnKParams& p, EnvRegs& e, int 
 // Pedestrians that can return a range <= lidar_max: |centre - origin| <= lidar_max + radius (+ slack).
 // A culled pedestrian could only produce t > lidar_max, which reads as "no return" anyway, so the
 // result is identical to testing all P (the oracle does).
-__device__ __forceinline__ int near_peds(const CnKParams& p, const Lds& L, int lane, double ox, double oy)
+__device__ __forceinline__ int near_peds(KP p, const Lds& L, int lane, double ox, double oy)
 {
     // The list holds what the ray test needs (not indices): the inner loop then reads three independent values per
     // pedestrian instead of chasing index -> position through two dependent LDS reads for every ray block.
     int nnear = 0;
-    const double lim = p.lidar_max + p.ped_radius + 1e-6, lim2 = lim * lim;
-    const double rr = p.ped_radius * p.ped_radius;
-    for (int j0 = 0; j0 < p.P; j0 += 64) {
+    const double lim = p->lidar_max + p->ped_radius + 1e-6, lim2 = lim * lim;
+    const double rr = p->ped_radius * p->ped_radius;
+    for (int j0 = 0; j0 < p->P; j0 += 64) {
         int j = j0 + lane;
         bool nr = false;
         double ocx = 0.0, ocy = 0.0;
-        if (j < p.P && !(CN_ABLATE(1))) {
+        if (j < p->P && !(CN_ABLATE(1))) {
             ocx = L.ped[2 * j] - ox; ocy = L.ped[2 * j + 1] - oy;
             nr = fma(ocx, ocx, ocy * ocy) <= lim2;
         }
@@ -276,29 +337,24 @@ __device__ __forceinline__ int near_peds(const CnKParams& p, const Lds& L, int l
 }
 
 // Range of ray k: the sensor's own reading (EXT), or the nearest hit among the room walls and the near pedestrians.
+// lc, ls: ray k in the robot frame = the host table of cn_det_sincos(k * step), loaded by the caller one block ahead.
 template <bool EXT>
-__device__ __forceinline__ double cast_ray(const CnKParams& p, const Lds& L, int env, int k, double ox, double oy, double sy,
-                                           double cy, int nnear, bool wall_x, bool wall_y)
+__device__ __forceinline__ double cast_ray(KP p, const Lds& L, int env, int k, double ox, double oy, double sy,
+                                           double cy, int nnear, bool wall_x, bool wall_y, double lc, double ls)
 {
     if constexpr (EXT) {
-        return p.ext_ranges[(size_t)env * p.R + k];   // Gazebo / a physical lidar
+        return p->ext_ranges[(size_t)env * p->R + k];   // Gazebo / a physical lidar
     } else {
-        const double h = p.room_half;
+        const double h = p->room_half;
         double t = INFINITY;
-        const double lc = p.lidar_c[k], ls = p.lidar_s[k];  // ray k in the robot frame: host table of cn_det_sincos(k * step)
         double dx = fma(cy, lc, -(sy * ls));
         double dy = fma(sy, lc, cy * ls);
         // A wall farther than lidar_max from the origin can only give t > lidar_max ("no return"), so its
         // divide is skipped when the whole env is out of its reach (uniform test, result unchanged).
-        if (wall_x) {
-            if (dx > 0.0) t = fmin(t, (h - ox) / dx);
-            else if (dx < 0.0) t = fmin(t, (-h - ox) / dx);
-        }
-        if (wall_y) {
-            if (dy > 0.0) t = fmin(t, (h - oy) / dy);
-            else if (dy < 0.0) t = fmin(t, (-h - oy) / dy);
-        }
-        if (t < p.lidar_min) t = p.lidar_min;
+        // (one divide per axis: the facing wall is selected first -- a wave has rays of both signs)
+        if (wall_x && dx != 0.0) t = fmin(t, ((dx > 0.0 ? h : -h) - ox) / dx);
+        if (wall_y && dy != 0.0) t = fmin(t, ((dy > 0.0 ? h : -h) - oy) / dy);
+        if (t < p->lidar_min) t = p->lidar_min;
         for (int c = 0; c < nnear; ++c) {
             const double ocx = L.nearp[3 * c], ocy = L.nearp[3 * c + 1], cc = L.nearp[3 * c + 2];
             double b = fma(ocx, dx, ocy * dy);
@@ -306,21 +362,21 @@ __device__ __forceinline__ double cast_ray(const CnKParams& p, const Lds& L, int
             if (disc >= 0.0) {
                 double sq = sqrt(disc);
                 double t2 = b + sq;
-                if (t2 >= p.lidar_min) {
-                    double t1 = fmax(b - sq, p.lidar_min);
+                if (t2 >= p->lidar_min) {
+                    double t1 = fmax(b - sq, p->lidar_min);
                     t = fmin(t, t1);
                 }
             }
         }
-        return (t > p.lidar_max) ? INFINITY : t;       // the simulated sensor reports no return beyond its range
+        return (t > p->lidar_max) ? INFINITY : t;       // the simulated sensor reports no return beyond its range
     }
 }
 
 // ---- obs_layout 1: environment_stage_1_original.py ("ORIG"), SURVEY 8f N3 --------------------------------
 // ORIG:244-260: heading straight to desired_point, no starting_pose offset
-__device__ __forceinline__ double orig_heading(const CnKParams& p, double px, double py, double yaw)
+__device__ __forceinline__ double orig_heading(KP p, double px, double py, double yaw)
 {
-    double ga = atan2(p.goal_y - py, p.goal_x - px);
+    double ga = atan2(p->goal_y - py, p->goal_x - px);
     double h = ga - yaw;
     if (h > CN_PI) h -= 2 * CN_PI;
     else if (h < -CN_PI) h += 2 * CN_PI;
@@ -329,26 +385,31 @@ __device__ __forceinline__ double orig_heading(const CnKParams& p, double px, do
 
 // ORIG:278-322: state = [round(range, 3)] * (R-1) + [heading, distance] + [round(x, 3), round(y, 3)]; tail -> L.tail[0..3]
 template <bool EXT>
-__device__ __forceinline__ void observe_original(const CnKParams& p, EnvRegs& e, const Lds& L, int env, int lane, int step_counter,
+__device__ __forceinline__ void observe_original(KP p, EnvRegs& e, const Lds& L, int env, int lane, int step_counter,
                                                  float* obs32, float* fin32, double* obs64, int* done_out)
 {
-    const int R = p.R, n = R - 1, D = n + 4;
+    const int R = p->R, n = R - 1, D = n + 4;
     const double px = e.rx, py = e.ry, yaw = e.ryaw;
-    double dist = cn_np_around2(dist3(px, py, p.goal_x, p.goal_y));   // round(np.float64, 2), ORIG:280
+    double dist = cn_np_around2(dist3(px, py, p->goal_x, p->goal_y));   // round(np.float64, 2), ORIG:280
     double head = cn_py_round2(orig_heading(p, px, py, yaw));        // ORIG:281
     double sy, cy;
     cn_det_sincos(yaw, &sy, &cy);
-    const double ox = fma(p.lidar_offset_x, cy, px), oy = fma(p.lidar_offset_x, sy, py);
-    const double h = p.room_half;
+    const double ox = fma(p->lidar_offset_x, cy, px), oy = fma(p->lidar_offset_x, sy, py);
+    const double h = p->room_half;
     const int nnear = near_peds(p, L, lane, ox, oy);
-    const bool wall_x = !(h - fabs(ox) > p.lidar_max + 1e-6);
-    const bool wall_y = !(h - fabs(oy) > p.lidar_max + 1e-6);
+    const bool wall_x = !(h - fabs(ox) > p->lidar_max + 1e-6);
+    const bool wall_y = !(h - fabs(oy) > p->lidar_max + 1e-6);
     float* o32 = obs32 + (size_t)env * D;
     float* f32 = fin32 ? fin32 + (size_t)env * D : nullptr;
     double* o64 = obs64 ? obs64 + (size_t)env * D : nullptr;
     double smin = 1e300;
+    const double* const lidc = p->lidar_c; const double* const lids = p->lidar_s;
+    double lc_n = 0.0, ls_n = 0.0;
+    if (!EXT && lane < R) { lc_n = lidc[lane]; ls_n = lids[lane]; }
     for (int k = lane; k < R; k += 64) {
-        const double r = cast_ray<EXT>(p, L, env, k, ox, oy, sy, cy, nnear, wall_x, wall_y);
+        const double lc = lc_n, ls = ls_n;
+        if (!EXT && k + 64 < R) { lc_n = lidc[k + 64]; ls_n = lids[k + 64]; }      // next block's directions: in flight during this one
+        const double r = cast_ray<EXT>(p, L, env, k, ox, oy, sy, cy, nnear, wall_x, wall_y, lc, ls);
         if (k >= 1) {
             int j = R - 1 - k;                                        // ORIG:298-300 reverse, drop the last
             double v;
@@ -365,8 +426,8 @@ __device__ __forceinline__ void observe_original(const CnKParams& p, EnvRegs& e,
     smin = cn_wave_min_d(smin);
     if (!e.done) {
         if (0.105 > smin && smin > 0.0) e.done = 1;                   // ORIG:282,303-305
-        if (in_box(px, py, p.goal_x, p.goal_y, 0.20)) e.done = 1;     // ORIG:307-309 (epsilon default, ORIG:500)
-        if (step_counter >= p.max_steps) e.done = 1;                  // ORIG:311-313
+        if (in_box(px, py, p->goal_x, p->goal_y, 0.20)) e.done = 1;     // ORIG:307-309 (epsilon default, ORIG:500)
+        if (step_counter >= p->max_steps) e.done = 1;                  // ORIG:311-313
     }
     const double x3 = cn_py_round3(px), y3 = cn_py_round3(py);        // ORIG:315
     if (lane < 4) {
@@ -382,7 +443,7 @@ __device__ __forceinline__ void observe_original(const CnKParams& p, EnvRegs& e,
 
 // ORIG:324-402.  The quirk is the reference's: state[-1] (the rounded y) is its "current_distance" and state[-2]
 // (the rounded x) its "current_heading".
-__device__ __forceinline__ double compute_reward_original(const CnKParams& p, EnvRegs& e, const Lds& L, int done)
+__device__ __forceinline__ double compute_reward_original(KP p, EnvRegs& e, const Lds& L, int done)
 {
     double cur_dist = L.tail[3], cur_head = L.tail[2];
     double dd = cur_dist - e.prev_dist, hd = cur_head - e.prev_head;
@@ -405,18 +466,43 @@ __device__ __forceinline__ double compute_reward_original(const CnKParams& p, En
     e.prev_dist = cur_dist;
     e.prev_head = cur_head;
     if (done) {
-        if (in_box(e.rx, e.ry, p.goal_x, p.goal_y, 0.20)) { e.fail = 0; e.succ = 1; reward = 200 + reward; }
+        if (in_box(e.rx, e.ry, p->goal_x, p->goal_y, 0.20)) { e.fail = 0; e.succ = 1; reward = 200 + reward; }
         else { e.fail = 1; e.succ = 0; reward = -200 + reward; }
     }
     return reward;
 }
 
-template <bool EXT>
-__device__ __forceinline__ void observe(const CnKParams& p, const Poly& pg, EnvRegs& e, const Lds& L, int env, int lane, int step_counter,
-                        float* obs32, float* fin32, double* obs64, int* done_out)
+// UTL:405-419 compute_average_bounding_box_size on the end points of an all-max scan at pose (px, py, yaw) (ENV:287-294).
+// stage: 64 doubles of LDS.  Python sum(): strictly left to right.
+__device__ __forceinline__ double bbox_size(KP p, double* stage, int lane, int n, double px, double py, double yaw)
 {
-    const int R = p.R, n = R - 1, K = p.K, D = n + 7 + 4 * K;
-    const double MAXR = p.max_scan_range;
+    const double MAXR = p->max_scan_range, deg2rad = CN_PI / 180.0;
+    double sum = 0.0;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        int i = i0 + lane;
+        if (i < n) {
+            int j = (i == n - 1) ? 0 : i + 1;
+            double s0, c0, s1, c1;
+            cn_det_sincos(((double)i * p->angle_inc_deg) * deg2rad - yaw, &s0, &c0);
+            cn_det_sincos(((double)j * p->angle_inc_deg) * deg2rad - yaw, &s1, &c1);
+            double x0 = cn_py_round3(px + (MAXR * c0)), y0 = cn_py_round3(py + (MAXR * s0) * -1.0);
+            double x1 = cn_py_round3(px + (MAXR * c1)), y1 = cn_py_round3(py + (MAXR * s1) * -1.0);
+            stage[lane] = hypot(x0 - x1, y0 - y1);
+        }
+        CN_SYNC();
+        int cnt = min(64, n - i0);
+        for (int c = 0; c < cnt; ++c) sum += stage[c];
+        CN_SYNC();
+    }
+    return sum / (double)n;
+}
+
+template <bool EXT>
+__device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const Lds& L, int env, int lane, int step_counter,
+                        float* obs32, float* fin32, double* obs64, int* done_out, bool have_tg = false, Trig tg = Trig{0.0, 0.0, 0.0, 0.0})
+{
+    const int R = p->R, n = R - 1, K = p->K, D = n + 7 + 4 * K;
+    const double MAXR = p->max_scan_range;
     const double px = e.rx, py = e.ry, yaw = e.ryaw, v = e.rv, w = e.rw, now = e.clock;
 
     // ENV:246-265
@@ -429,20 +515,20 @@ __device__ __forceinline__ void observe(const CnKParams& p, const Poly& pg, EnvR
     CN_T(24);
     // ENV:267-268: the angular velocity is used as the angle
     double sw_, cw_;
-    cn_det_sincos(w, &sw_, &cw_);
+    if (have_tg) { sw_ = tg.sw; cw_ = tg.cw; } else cn_det_sincos(w, &sw_, &cw_);
     double agent_vel_x = -1.0 * (v * cw_);
     double agent_vel_y = v * sw_;
 
     CN_T(2);
     // ---- lidar raycast (XACRO:150-178) + UTL:375-392 sanitise + UTL:110-126 end points ----------
     double sy, cy;
-    cn_det_sincos(yaw, &sy, &cy);
-    const double ox = fma(p.lidar_offset_x, cy, px), oy = fma(p.lidar_offset_x, sy, py);
-    const double h = p.room_half;
+    if (have_tg) { sy = tg.sy; cy = tg.cy; } else cn_det_sincos(yaw, &sy, &cy);
+    const double ox = fma(p->lidar_offset_x, cy, px), oy = fma(p->lidar_offset_x, sy, py);
+    const double h = p->room_half;
     const double deg2rad = CN_PI / 180.0;
     const int nnear = near_peds(p, L, lane, ox, oy);
-    const bool wall_x = !(h - fabs(ox) > p.lidar_max + 1e-6);
-    const bool wall_y = !(h - fabs(oy) > p.lidar_max + 1e-6);
+    const bool wall_x = !(h - fabs(ox) > p->lidar_max + 1e-6);
+    const bool wall_y = !(h - fabs(oy) > p->lidar_max + 1e-6);
     CN_T(3);
     double smin = 1e300;
     float* o32 = obs32 + (size_t)env * D;
@@ -450,8 +536,22 @@ __device__ __forceinline__ void observe(const CnKParams& p, const Poly& pg, EnvR
     double* o64 = obs64 ? obs64 + (size_t)env * D : nullptr;
     // End points, rounded ranges and gradients are 3-decimal values: LDS keeps the integer thousandths
     // (x == cn_div1000(mil) bit for bit), which halves the working set and doubles the waves per CU.
+    // The four table values a ray needs (its direction, and sin/cos of its end-point angle) are loaded ONE BLOCK AHEAD, so
+    // that their L2 latency overlaps the previous block's arithmetic instead of heading every block's dependency chain.
+    const double* const lidc = p->lidar_c; const double* const lids = p->lidar_s;
+    const double* const angs = p->ang_s; const double* const angc = p->ang_c;
+    double lc_n = 0.0, ls_n = 0.0, tS_n = 0.0, tC_n = 0.0;
+    if (lane < R) {
+        if (!EXT) { lc_n = lidc[lane]; ls_n = lids[lane]; }
+        if (lane >= 1) { tS_n = angs[R - 1 - lane]; tC_n = angc[R - 1 - lane]; }
+    }
     for (int k = lane; k < R; k += 64) {
-        const double t = cast_ray<EXT>(p, L, env, k, ox, oy, sy, cy, nnear, wall_x, wall_y);
+        const double lc = lc_n, ls = ls_n, tS = tS_n, tC = tC_n;
+        if (k + 64 < R) {
+            if (!EXT) { lc_n = lidc[k + 64]; ls_n = lids[k + 64]; }
+            tS_n = angs[R - 1 - (k + 64)]; tC_n = angc[R - 1 - (k + 64)];
+        }
+        const double t = cast_ray<EXT>(p, L, env, k, ox, oy, sy, cy, nnear, wall_x, wall_y, lc, ls);
         if (k >= 1) {
             int j = R - 1 - k;  // UTL:389-390 reverse, drop last
             double r = t;
@@ -463,7 +563,6 @@ __device__ __forceinline__ void observe(const CnKParams& p, const Poly& pg, EnvR
             else sc = r;
             smin = fmin(smin, sc);
             // sin/cos(radians(j * inc) - yaw) by angle addition from a host table of sin/cos(radians(j * inc))
-            const double tS = p.ang_s[j], tC = p.ang_c[j];
             const double sa = fma(tS, cy, -(tC * sy)), ca = fma(tC, cy, tS * sy);
             L.ptx[j] = (int)cn_round_scaled(px + (sc * ca), 1000.0);
             L.pty[j] = (int)cn_round_scaled(py + (sc * sa) * -1.0, 1000.0);
@@ -479,24 +578,12 @@ __device__ __forceinline__ void observe(const CnKParams& p, const Poly& pg, EnvR
     CN_SYNC();
 
     if (step_counter == 0) {  // UTL:405-419 + ENV:287-294: mean spacing of the end points of an all-max scan
-        double sum = 0.0;     // Python sum(): strictly left to right
-        for (int i0 = 0; i0 < n; i0 += 64) {
-            int i = i0 + lane;
-            if (i < n) {
-                int j = (i == n - 1) ? 0 : i + 1;
-                double s0, c0, s1, c1;
-                cn_det_sincos(((double)i * p.angle_inc_deg) * deg2rad - yaw, &s0, &c0);
-                cn_det_sincos(((double)j * p.angle_inc_deg) * deg2rad - yaw, &s1, &c1);
-                double x0 = cn_py_round3(px + (MAXR * c0)), y0 = cn_py_round3(py + (MAXR * s0) * -1.0);
-                double x1 = cn_py_round3(px + (MAXR * c1)), y1 = cn_py_round3(py + (MAXR * s1) * -1.0);
-                L.stage[lane] = hypot(x0 - x1, y0 - y1);
-            }
-            CN_SYNC();
-            int cnt = min(64, n - i0);
-            for (int c = 0; c < cnt; ++c) sum += L.stage[c];
-            CN_SYNC();
-        }
-        e.bb = sum / (double)n;
+        // After a simulated reset the robot stands exactly at the spawn pose (reset_simulation, then 10 ms at zero twist),
+        // so the value is a constant of the configuration: cn_create evaluates bbox_size() once on the device and the
+        // 359 sincos pairs + the strictly serial Python sum() leave the reset path (they made a resetting wavefront 30 %
+        // longer than a stepping one, and a launch lasts as long as its slowest wavefront).
+        if (!EXT && p->bb_spawn_valid && px == p->spawn_x && py == p->spawn_y && yaw == p->spawn_yaw) e.bb = p->bb_spawn;
+        else e.bb = bbox_size(p, L.stage, lane, n, px, py, yaw);
         double qx = cn_py_round3(px), qy = cn_py_round3(py);
         if (e.dq_len < 2) { if (e.dq_len == 0) { e.dq0x = qx; e.dq0y = qy; } else { e.dq1x = qx; e.dq1y = qy; } e.dq_len += 1; }
         else { e.dq0x = e.dq1x; e.dq0y = e.dq1y; e.dq1x = qx; e.dq1y = qy; }
@@ -670,14 +757,55 @@ __device__ __forceinline__ void observe(const CnKParams& p, const Poly& pg, EnvR
     }
     CN_SYNC();
     CN_T(9);
-    // ENV:448-485 association of consecutive rays; brk bit i = a segment closes after ray i
+    // ENV:448-485 association of consecutive rays; brk bit i = a segment closes after ray i.
+    // is_associated = round(IoU, 3) > 0 of two squares of half-size bb about consecutive end points.  The end points are
+    // integer thousandths, so the decision is a function of (|dx|, |dy|) in thousandths alone as long as no pair sits within
+    // floating-point noise (~1e-14) of one of the two cuts: the squares overlap iff |dx|, |dy| < T = 2000 bb, and the rounded
+    // IoU is positive iff (T - |dx|)(T - |dy|) > T^2 2c / (1 + c), c = 0.0005.  Both cuts are tabulated once per
+    // observation WITH A GUARD BAND of 1e-7 thousandths / 1e-6 relative -- lane d holds the largest |dy| that still
+    // associates with |dx| = d -- and the per-ray test becomes integer: two differences, a table look-up, a compare
+    // (about 12 instructions instead of about 200 float64 ones per 64 rays x 6 blocks).  If the guard band is touched
+    // (T within 1e-7 of an integer, a table cut within 1e-6 of the threshold) or T > 254 the float test runs instead.
     int fe = n, lb = -1, nsegs0 = 0;
+    bool fast_assoc;
+    int K1;
+    short* const amax = (short*)L.gq;                  // region B is free between the type machine and the confirmation
+    {
+        const double Tm = 2000.0 * e.bb;
+        K1 = (int)floor(Tm - 1e-7);
+        const int K2 = (int)ceil(Tm + 1e-7);
+        fast_assoc = (K2 == K1 + 1) && K1 >= 0 && K1 <= 254 && !(CN_ABLATE(32));
+        if (fast_assoc) {
+            const double c_hi = 0.0005 * (1.0 + 1e-6), c_lo = 0.0005 * (1.0 - 1e-6);
+            const double T2 = Tm * Tm;
+            const double Phi = T2 * (2.0 * c_hi) / (1.0 + c_hi), Plo = T2 * (2.0 * c_lo) / (1.0 + c_lo);
+            int amb = 0;
+            for (int d = lane; d <= K1 + 1; d += 64) {
+                int m = -1;
+                if (d <= K1) {
+                    const double fx = Tm - (double)d;                     // > 0
+                    double mm = fmin(ceil(Tm - Phi / fx) - 1.0, (double)K1);
+                    m = mm < 0.0 ? -1 : (int)mm;
+                    if (m >= 0 && !(fx * (Tm - (double)m) > Phi)) amb = 1;               // m associates, with margin
+                    if (m + 1 <= K1 && !(fx * (Tm - (double)(m + 1)) < Plo)) amb = 1;     // m + 1 does not, with margin
+                }
+                amax[d] = (short)m;
+            }
+            if (__ballot(amb != 0) != 0ull) fast_assoc = false;
+        }
+        CN_SYNC();
+    }
     for (int q = 0; q < W; ++q) {
         int i = lane + 64 * q;
         bool brk = false;
         if (i < n) {
             brk = true;
-            if (i < n - 1) brk = !cn_iou3_positive(PX(i), PY(i), PX(i + 1), PY(i + 1), e.bb);
+            if (i < n - 1) {
+                if (fast_assoc) {
+                    const int dxm = abs(L.ptx[i] - L.ptx[i + 1]), dym = abs(L.pty[i] - L.pty[i + 1]);
+                    brk = dym > (int)amax[min(dxm, K1 + 1)];
+                } else brk = !cn_iou3_positive(PX(i), PY(i), PX(i + 1), PY(i + 1), e.bb);
+            }
         }
         u64 bw = __ballot(brk);
         if (lane == 0) WORD(M_BRK, q) = bw;
@@ -806,7 +934,7 @@ __device__ __forceinline__ void observe(const CnKParams& p, const Poly& pg, EnvR
             if (occ && len >= 4) {
                 m = ORDER(k0 + len / 2);  // ENV:577 Python-2 integer division
                 dm = cn_div1000((double)L.dmil[m]);
-                int est = 3 + (int)floor(29 * (p.max_scan_range - dm) / (p.max_scan_range - p.min_scan_range));
+                int est = 3 + (int)floor(29 * (p->max_scan_range - dm) / (p->max_scan_range - p->min_scan_range));
                 int mn = len < est ? len : est;
                 double score = (double)no / (double)mn;
                 int kinds = (no > 0) + (nw > 0) + (nn > 0);
@@ -823,12 +951,12 @@ __device__ __forceinline__ void observe(const CnKParams& p, const Poly& pg, EnvR
         const u64 cwd = __ballot(obj >= 0);
         if (obj >= 0) {
             int slot = nconf + __popcll(cwd & ((1ull << lane) - 1ull));
-            if (slot < p.max_conf) { L.cft[slot] = obj; L.cfx[slot] = PX(m); L.cfy[slot] = PY(m); L.cfd[slot] = dm; }
+            if (slot < p->max_conf) { L.cft[slot] = obj; L.cfx[slot] = PX(m); L.cfy[slot] = PY(m); L.cfd[slot] = dm; }
         }
         nconf += __popcll(cwd);
         CN_SYNC();
     }
-    if (nconf > p.max_conf) { nconf = p.max_conf; e.status |= CN_ST_CONF_OVERFLOW; }
+    if (nconf > p->max_conf) { nconf = p->max_conf; e.status |= CN_ST_CONF_OVERFLOW; }
 #undef ORDER
 #undef BIT
 #undef WORD
@@ -1020,68 +1148,98 @@ __device__ __forceinline__ void observe(const CnKParams& p, const Poly& pg, EnvR
         double gradient = (vo_y == 0.0) ? 0.0 : (vo_x - a0x) / vo_y - a0y;  // UTL:261 precedence as written
         double bb0 = a0x - (gradient * a0y);
         int hi = (int)ceil(a0x + 3.5), lo = (int)floor(a0x - 3.5);
-        double ego_prev = 0.0, ego_max = 0.0;
+        double ego_max = 0.0;
         // The candidate segments agent -> (x2, y2), x2 = hi, hi-1, ... > lo (at most 8 of them, UTL:264-291), are the
         // same for every track.  The polygon lies inside its circumscribed circle, so a segment whose closest
         // point to the track's centre is farther than the radius (with slack) cannot touch any edge -> same
         // "empty" result as running the ring test.  That pre-rejection is evaluated for 8 tracks x 8 candidates
-        // at once (lane = track * 8 + candidate); the serial part only visits the survivors, in x2 order.
-        u64 nearm = 0;
-        for (int i = 0; i < nt; ++i) {  // ENV:818-860
-            if ((i & 7) == 0) {
-                const int ti = i + (lane >> 3), x2l = hi - (lane & 7);
-                bool nearc = false;
-                if (ti < nt && x2l > lo) {
-                    const double ctx = TRK(CN_TF_PX, ti), cty = TRK(CN_TF_PY, ti);
-                    const double y2l = ((double)x2l * gradient) + bb0;
-                    // squared distance from the centre to the segment, compared with r^2 without a divide
-                    const double ex = (double)x2l - a0x, ey = y2l - a0y, fx = ctx - a0x, fy = cty - a0y;
-                    const double ee = ex * ex + ey * ey, ff = fx * fx + fy * fy, num = fx * ex + fy * ey;
-                    const double rr2 = 0.178 * 0.178 * 1.000001;
-                    bool far_;
-                    if (num <= 0.0) far_ = ff > rr2;                                   // closest point is the agent
-                    else if (num >= ee) far_ = (fx - ex) * (fx - ex) + (fy - ey) * (fy - ey) > rr2;  // ... the far end
-                    else far_ = (ff - rr2) * ee > num * num * 1.000001;                // ... the foot of the perpendicular
-                    nearc = !far_;
+        // at once (lane = track * 8 + candidate).
+        // Two phases per chunk of tracks (a launch lasts as long as its slowest wavefront, and crowded envs used to
+        // spend ~2 k ticks PER TRACK here in one serial chain):
+        //   1. per track, only what needs lane = polygon edge: the ring test of the surviving candidates, in x2 order;
+        //      the two hit lanes drop their intersection points into LDS (the confirmed-object arrays are dead by now);
+        //   2. lane = track: distances to the hit points, ttc, ego score, CP -- the hypots and divides of ALL tracks at once.
+        // ENV:818-860 carries `ego` from one track to the next only when the relative speed is exactly 0, and then every
+        // track's value is 0 by induction (it starts at 0 and a track without a collision point resets it to 0).
+        const double rv = agent_vel - obstacle_vel;
+        const int hcap = min(p->max_conf, 64);         // tracks per chunk: one lane each, 4 doubles of LDS each
+        double* const hitp = L.cfx;                     // [4][hcap]: first hit x, y, second hit x, y
+        for (int c0 = 0; c0 < nt; c0 += hcap) {
+            const int c1 = min(nt, c0 + hcap);
+            u64 nearm = 0, hasm = 0;
+            for (int i = c0; i < c1; ++i) {  // ENV:818-860, UTL:251-293
+                const int r_ = i - c0;
+                if ((r_ & 7) == 0) {
+                    const int ti = i + (lane >> 3), x2l = hi - (lane & 7);
+                    bool nearc = false;
+                    if (ti < c1 && x2l > lo) {
+                        const double ctx = TRK(CN_TF_PX, ti), cty = TRK(CN_TF_PY, ti);
+                        const double y2l = ((double)x2l * gradient) + bb0;
+                        // squared distance from the centre to the segment, compared with r^2 without a divide
+                        const double ex = (double)x2l - a0x, ey = y2l - a0y, fx = ctx - a0x, fy = cty - a0y;
+                        const double ee = ex * ex + ey * ey, ff = fx * fx + fy * fy, num = fx * ex + fy * ey;
+                        const double rr2 = 0.178 * 0.178 * 1.000001;
+                        bool far_;
+                        if (num <= 0.0) far_ = ff > rr2;                                   // closest point is the agent
+                        else if (num >= ee) far_ = (fx - ex) * (fx - ex) + (fy - ey) * (fy - ey) > rr2;  // ... the far end
+                        else far_ = (ff - rr2) * ee > num * num * 1.000001;                // ... the foot of the perpendicular
+                        nearc = !far_;
+                    }
+                    nearm = __ballot(nearc);
                 }
-                nearm = __ballot(nearc);
-            }
-            double tx = TRK(CN_TF_PX, i), ty_ = TRK(CN_TF_PY, i), td = TRK(CN_TF_DIST, i);
-            int has = 0; double dcp = 0.0;
-            unsigned cand = (unsigned)((nearm >> (8 * (i & 7))) & 0xffull);   // bit c <-> x2 = hi - c
-            while (cand) {
-                const int c = __builtin_ctz(cand);
-                cand &= cand - 1u;
-                const int x2 = hi - c;
-                double y2 = ((double)x2 * gradient) + bb0;
-                double hx = 0.0, hy = 0.0;
-                unsigned long long m = ring_segment(pg, lane, tx, ty_, 0.178, a0x, a0y, (double)x2, y2, &hx, &hy);
-                int cnt = __popcll(m);
-                if (cnt == 0) continue;
-                if (cnt == 1) break;  // Point has no .geoms -> None
-                int l1 = __ffsll((long long)m) - 1;
-                unsigned long long m2 = m & (m - 1ull);
-                int l2 = __ffsll((long long)m2) - 1;
-                double d1 = hypot(a0x - bcast_d(hx, l1), a0y - bcast_d(hy, l1));
-                double d2 = hypot(a0x - bcast_d(hx, l2), a0y - bcast_d(hy, l2));
-                dcp = fmin(d1, d2); has = 1;
-                break;
-            }
-            double rv = agent_vel - obstacle_vel;
-            double gcp = (td > p.max_scan_range) ? 0.0 : (p.max_scan_range - td) / (p.max_scan_range - p.min_scan_range);
-            double ego, cpv;
-            if (has) {
-                if (rv == 0) { cpv = 1.0 * gcp; ego = ego_prev; }
-                else {
-                    double ttc = dcp / rv;
-                    if (ttc == 0.0) { e.status |= CN_ST_TTC_ZERO; ego = 1.0; }
-                    else ego = fmin(1.0, 0.15 / ttc);  // UTL:319
-                    cpv = 0.5 * ego + 0.5 * gcp;
+                unsigned cand = (unsigned)((nearm >> (8 * (r_ & 7))) & 0xffull);   // bit c <-> x2 = hi - c
+                if (!cand) continue;
+                const double tx = TRK(CN_TF_PX, i), ty_ = TRK(CN_TF_PY, i);
+                while (cand) {
+                    const int c = __builtin_ctz(cand);
+                    cand &= cand - 1u;
+                    const int x2 = hi - c;
+                    double y2 = ((double)x2 * gradient) + bb0;
+                    double hx = 0.0, hy = 0.0;
+                    unsigned long long m = ring_segment(pg, lane, tx, ty_, 0.178, a0x, a0y, (double)x2, y2, &hx, &hy);
+                    int cnt = __popcll(m);
+                    if (cnt == 0) continue;
+                    if (cnt == 1) break;  // Point has no .geoms -> None
+                    const int l1 = __ffsll((long long)m) - 1;
+                    const int l2 = __ffsll((long long)(m & (m - 1ull))) - 1;
+                    if (lane == l1) { hitp[r_] = hx; hitp[hcap + r_] = hy; }
+                    if (lane == l2) { hitp[2 * hcap + r_] = hx; hitp[3 * hcap + r_] = hy; }
+                    hasm |= 1ull << r_;
+                    break;
                 }
-            } else { ego = 0.0; cpv = 0.5 * 0.0 + 0.5 * gcp; }
-            ego_prev = ego;
-            if (lane == 0) L.cpv[i] = cpv;
-            if (i == 0 || ego > ego_max) ego_max = ego;
+            }
+            CN_SYNC();
+            {
+                const int i = c0 + lane;
+                double ego = 0.0;
+                bool ttc0 = false;
+                if (i < c1) {
+                    const double td = TRK(CN_TF_DIST, i);
+                    const double gcp = (td > p->max_scan_range) ? 0.0 : (p->max_scan_range - td) / (p->max_scan_range - p->min_scan_range);
+                    double cpv;
+                    if ((hasm >> lane) & 1ull) {
+                        const double d1 = hypot(a0x - hitp[lane], a0y - hitp[hcap + lane]);
+                        const double d2 = hypot(a0x - hitp[2 * hcap + lane], a0y - hitp[3 * hcap + lane]);
+                        const double dcp = fmin(d1, d2);
+                        if (rv == 0) { cpv = 1.0 * gcp; ego = 0.0; }
+                        else {
+                            double ttc = dcp / rv;
+                            if (ttc == 0.0) { ttc0 = true; ego = 1.0; }
+                            else ego = fmin(1.0, 0.15 / ttc);  // UTL:319
+                            cpv = 0.5 * ego + 0.5 * gcp;
+                        }
+                    } else { ego = 0.0; cpv = 0.5 * 0.0 + 0.5 * gcp; }
+                    L.cpv[i] = cpv;
+                }
+                if (__ballot(ttc0) != 0ull) e.status |= CN_ST_TTC_ZERO;
+                // ENV: `if i == 0 or ego > ego_max: ego_max = ego`, folded left to right (a NaN is only ever kept as the first value)
+                const double first = lane_d(ego, 0);
+                const bool rest = (i < c1) && !(c0 == 0 && lane == 0) && (ego == ego);
+                const double mrest = cn_wave_max_d(rest ? ego : -INFINITY);
+                if (c0 == 0) ego_max = first;
+                if (mrest > ego_max) ego_max = mrest;
+            }
+            CN_SYNC();
         }
         e.nent = nt;
         CN_SYNC();
@@ -1118,9 +1276,9 @@ __device__ __forceinline__ void observe(const CnKParams& p, const Poly& pg, EnvR
     if (e.ego > 0.4) e.social_viol += 1;
     // ENV:1011-1023 done
     if (!e.done) {
-        if (smin < p.min_scan_range) e.done = 1;
-        if (in_box(px, py, p.goal_x, p.goal_y, p.goal_eps)) e.done = 1;
-        if (step_counter >= p.max_steps) e.done = 1;
+        if (smin < p->min_scan_range) e.done = 1;
+        if (in_box(px, py, p->goal_x, p->goal_y, p->goal_eps)) e.done = 1;
+        if (step_counter >= p->max_steps) e.done = 1;
     }
     // ENV:1025-1042 observation tail
     if (lane < 7) {   // one rounding pass, lane = tail slot (heading and distance are already rounded)
@@ -1147,7 +1305,7 @@ __device__ __forceinline__ void observe(const CnKParams& p, const Poly& pg, EnvR
 }
 
 // ENV:1046-1162 compute_reward; state[n] = heading, state[n+1] = distance are in L.tail[0..1]
-__device__ __forceinline__ double compute_reward(const CnKParams& p, const Poly& pg, EnvRegs& e, const Lds& L, int lane, int done)
+__device__ __forceinline__ double compute_reward(KP p, const Poly& pg, EnvRegs& e, const Lds& L, int lane, int done)
 {
     double cur_head = L.tail[0], cur_dist = L.tail[1];
     double dd = cur_dist - e.prev_dist, hd = cur_head - e.prev_head;
@@ -1166,16 +1324,16 @@ __device__ __forceinline__ double compute_reward(const CnKParams& p, const Poly&
         if (cur_head > 0 && ph < 0) htg = 1;
         if (cur_head < 0 && ph < 0) htg = 0;
     }
-    if (in_box(e.rx, e.ry, e.wpx, e.wpy, p.goal_eps)) {  // ENV:1109-1125
+    if (in_box(e.rx, e.ry, e.wpx, e.wpy, p->goal_eps)) {  // ENV:1109-1125
         waypoint_refresh(p, pg, e, lane, e.rx, e.ry);
         wp = 200;
-        if (in_box(e.wpx, e.wpy, p.goal_x, p.goal_y, p.goal_eps)) { e.wpx = p.goal_x; e.wpy = p.goal_y; }
+        if (in_box(e.wpx, e.wpy, p->goal_x, p->goal_y, p->goal_eps)) { e.wpx = p->goal_x; e.wpy = p->goal_y; }
     }
     double reward = (double)(-2 + dtg + htg + wp);
     e.prev_dist = cur_dist;
     e.prev_head = cur_head;
     if (done) {
-        if (in_box(e.rx, e.ry, p.goal_x, p.goal_y, p.goal_eps)) { e.fail = 0; e.succ = 1; reward = 200 + reward; }
+        if (in_box(e.rx, e.ry, p->goal_x, p->goal_y, p->goal_eps)) { e.fail = 0; e.succ = 1; reward = 200 + reward; }
         else { e.fail = 1; e.succ = 0; reward = -200 + reward; }
     }
     return reward;
@@ -1184,28 +1342,29 @@ __device__ __forceinline__ double compute_reward(const CnKParams& p, const Poly&
 }  // namespace
 
 template <bool EXT, bool TWO, int LAYOUT>
-__device__ __forceinline__ void env_kernel_body(const CnKParams& p)
+__device__ __forceinline__ void env_kernel_body()
 {
+    KP p = (KP)__builtin_amdgcn_kernarg_segment_ptr();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int env = blockIdx.x, lane = threadIdx.x;
-    if (env >= p.N) return;
-    if (p.mode == CN_MODE_RESET && p.mask && !p.mask[env]) return;
-    const int R = p.R, n = R - 1, P = p.P, K = p.K;
+    if (env >= p->N) return;
+    if (p->mode == CN_MODE_RESET && p->mask && !p->mask[env]) return;
+    const int R = p->R, n = R - 1, P = p->P, K = p->K;
 
     Lds L;
     {
         // LDS map.  Region A: end points (integer thousandths) | tracker table.
         // Region B: gradients + alias sources | bbox staging | confirmed objects, CP, observation tail.
         const size_t szA_pts = (size_t)(10 * n + 7) & ~(size_t)7;
-        const size_t szA_trk = 8 * (size_t)(CN_TF_COUNT * p.trk_cap);
-        L.tcap = p.trk_cap;
+        const size_t szA_trk = 8 * (size_t)(CN_TF_COUNT * p->trk_cap);
+        L.tcap = p->trk_cap;
         const size_t szA = szA_pts > szA_trk ? szA_pts : szA_trk;
-        const size_t mc = (size_t)p.max_conf;
+        const size_t mc = (size_t)p->max_conf;
         const size_t szB_g = (size_t)(6 * n + 7) & ~(size_t)7;
         const size_t szB_c = 32 * mc + 8 * 64 + 8 * (size_t)(8 + 4 * K) + 4 * (size_t)CN_MAX_K;
         size_t szB = szB_g > szB_c ? szB_g : szB_c;
         if (szB < 8 * 64) szB = 8 * 64;
-        if (!p.near_sep && szB < 24 * (size_t)(P + 1)) szB = 24 * (size_t)(P + 1);   // near-pedestrian list overlaid on B
+        if (!p->near_sep && szB < 24 * (size_t)(P + 1)) szB = 24 * (size_t)(P + 1);   // near-pedestrian list overlaid on B
         char* A = smem;
         char* B = A + szA;
         char* Cw = B + szB;
@@ -1224,16 +1383,16 @@ __device__ __forceinline__ void env_kernel_body(const CnKParams& p)
         L.wbase = (int*)Cw; Cw += 8 * (size_t)((3 * Wn + 1) / 2);
         L.ped = (double*)Cw; Cw += 8 * (size_t)(2 * P + 2);
         L.pedv = (double*)Cw; Cw += 8 * (size_t)(2 * P + 2);
-        L.nearp = p.near_sep ? (double*)Cw : (double*)B;   // ray loop only: region B is dead until the gradients are written
-        L.gtrk = p.trk + (size_t)env * CN_TF_COUNT * p.trk_cap;
+        L.nearp = p->near_sep ? (double*)Cw : (double*)B;   // ray loop only: region B is dead until the gradients are written
+        L.gtrk = p->trk + (size_t)env * CN_TF_COUNT * p->trk_cap;
     }
 
     CN_T(0);
     Poly pg;
-    pg.c0 = p.poly_c[lane]; pg.s0 = p.poly_s[lane]; pg.c1 = p.poly_c[(lane + 1) & 63]; pg.s1 = p.poly_s[(lane + 1) & 63];
+    pg.c0 = p->poly_c[lane]; pg.s0 = p->poly_s[lane]; pg.c1 = p->poly_c[(lane + 1) & 63]; pg.s1 = p->poly_s[(lane + 1) & 63];
 
     // ---- load env state -------------------------------------------------------------------------
-    char* rec = p.state + (size_t)env * (size_t)p.state_stride;
+    char* rec = p->state + (size_t)env * (size_t)p->state_stride;
     double* sd = (double*)(rec + CN_ST_OFF_SD);
     int* si = (int*)(rec + CN_ST_OFF_SI);
     EnvRegs e;
@@ -1249,9 +1408,14 @@ __device__ __forceinline__ void env_kernel_body(const CnKParams& p)
     e.nconf = si[CN_SI_NCONF]; e.nent = si[CN_SI_NENTRIES]; e.pending = si[CN_SI_PENDING_RESET]; e.episodes = si[CN_SI_EPISODES];
     e.crowd_ms = (long long)(((unsigned long long)(unsigned)si[CN_SI_CROWD_HI] << 32) | (unsigned)si[CN_SI_CROWD_LO]);
 
+    // The tracker table is read from HBM in the middle of the observation (its LDS space holds the end points until then),
+    // which would put a full memory round trip on the wavefront's critical path.  Touch its lines now -- one dword per
+    // 128-byte line of the live records -- so that the real load, ~20 us later, hits the L2.
+    int trk_warm = 0;
+    if (LAYOUT == 0 && lane * 128 < e.ntracks * (CN_TF_COUNT * 8)) trk_warm = ((const volatile int*)L.gtrk)[lane * 32];
     double* gped_p = (double*)(rec + CN_ST_OFF_PED_P);
     double* gped_v = (double*)(rec + CN_ST_OFF_PED_V(P));
-    const double* gped_init = p.ped_init + (size_t)env * 2 * P;
+    const double* gped_init = p->ped_init + (size_t)env * 2 * P;
     double* pedv = L.pedv;  // velocities are only needed while advancing
     for (int i = lane; i < 2 * P; i += 64) { L.ped[i] = gped_p[i]; pedv[i] = gped_v[i]; }
     CN_SYNC();
@@ -1259,7 +1423,7 @@ __device__ __forceinline__ void env_kernel_body(const CnKParams& p)
     CN_T(1);
     int done = 0;
     constexpr bool ext = EXT;
-    const double* od = ext ? p.ext_odom + (size_t)env * 10 : nullptr;
+    const double* od = ext ? p->ext_odom + (size_t)env * 10 : nullptr;
     if (ext) {   // /odom callback (ENV:239-243) and time.time()
         e.rx = od[0]; e.ry = od[1]; e.ryaw = od[2]; e.rv = od[3]; e.rw = od[4]; e.clock = od[5];
     }
@@ -1268,35 +1432,41 @@ __device__ __forceinline__ void env_kernel_body(const CnKParams& p)
         // of auto_reset == 2, the gymnasium NEXT_STEP convention: an env that finished in the previous launch
         // spends THIS launch on its reset -- action ignored, reward 0, done 0).  Keeping a single inlined copy of
         // observe() also halves the kernel's code size (the instruction cache is 64 KB per two CUs).
-        bool do_reset = !(p.mode == CN_MODE_STEP || p.mode == CN_MODE_EXT_STEP);
-        if (p.mode == CN_MODE_STEP && p.auto_reset == 2 && e.pending) {
+        bool do_reset = !(p->mode == CN_MODE_STEP || p->mode == CN_MODE_EXT_STEP);
+        if (p->mode == CN_MODE_STEP && p->auto_reset == 2 && e.pending) {
             do_reset = true;
             e.pending = 0;
-            if (lane == 0) { p.reward[env] = 0.0f; p.done[env] = 0; }
-            if (p.topk_idx && lane < K) p.topk_idx[(size_t)env * K + lane] = -1;
+            if (lane == 0) { p->reward[env] = 0.0f; p->done[env] = 0; }
+            if (p->topk_idx && lane < K) p->topk_idx[(size_t)env * K + lane] = -1;
         }
         int sc = 0;
         float* fin = nullptr;
+        Trig trig = Trig{0.0, 0.0, 0.0, 0.0}; bool have_trig = false;
+        double rs1 = 0.0, rc1 = 0.0, rs2 = 0.0, rc2 = 0.0;
         // cn_external_io.phase: which pieces of Env.step this launch runs (external data only; 0 = all of them)
         bool ph_pre = true, ph_obs = true, ph_rew = true;
         if constexpr (EXT) {
-            if (p.ext_phase) { ph_pre = p.ext_phase & CN_PHASE_PRE; ph_obs = p.ext_phase & CN_PHASE_GET_STATE; ph_rew = p.ext_phase & CN_PHASE_REWARD; }
+            if (p->ext_phase) { ph_pre = p->ext_phase & CN_PHASE_PRE; ph_obs = p->ext_phase & CN_PHASE_GET_STATE; ph_rew = p->ext_phase & CN_PHASE_REWARD; }
         }
         if (!do_reset) {
             // Env.step (ENV:1164-1225), continuous mode
             if (ph_pre) e.ep_step += 1;
-            sc = p.step_counter ? p.step_counter[env] : e.ep_step;
+            sc = p->step_counter ? p->step_counter[env] : e.ep_step;
             double deq_x, deq_y, end_timestep;
             if (!ext) {
-                const double v = (double)p.action[2 * env], w = (double)p.action[2 * env + 1];
+                const double v = (double)p->action[2 * env], w = (double)p->action[2 * env + 1];
                 const double t0 = e.clock;
                 e.rv = v; e.rw = w;                               // pub_cmd_vel.publish (ENV:1200)
-                e.clock += cn_div1000((double)p.dt_ms);              // time.sleep(0.15) (ENV:1201)
-                sim_advance(p, e, env, lane, L.ped, pedv, p.dt_ms);
+                e.clock += cn_div1000((double)p->dt_ms);              // time.sleep(0.15) (ENV:1201)
+                if constexpr (LAYOUT == 0) { step_trig(p, e, lane, rs1, rc1, rs2, rc2, trig); have_trig = true; }
+                // pedestrians: ONE pass over [0, dt + scan latency], cut at dt (they are only looked at by the scan)
+                ped_advance(p, env, lane, L.ped, pedv, e.crowd_ms, e.crowd_ms + p->dt_ms + p->scan_latency_ms, p->dt_ms);
+                e.crowd_ms += p->dt_ms + p->scan_latency_ms;
+                if (have_trig) robot_advance_sc(p, e, p->dt_ms, rs1, rc1); else robot_advance(p, e, p->dt_ms);
                 CN_T(20);
                 end_timestep = e.clock - t0;                      // ENV:1202
                 deq_x = e.rx; deq_y = e.ry;
-                fin = p.final_obs;
+                fin = p->final_obs;
             } else {                                              // the caller ran the sleep; /odom said where we are
                 deq_x = od[6]; deq_y = od[7]; end_timestep = od[8];
             }
@@ -1308,21 +1478,21 @@ __device__ __forceinline__ void env_kernel_body(const CnKParams& p)
             e.ts = end_timestep;                                  // ENV:1209
             }
             if (!ext) {
-                e.clock += cn_div1000((double)p.scan_latency_ms);    // wait_for_message('scan') (ENV:1218)
-                sim_advance(p, e, env, lane, L.ped, pedv, p.scan_latency_ms);
+                e.clock += cn_div1000((double)p->scan_latency_ms);    // wait_for_message('scan') (ENV:1218)
+                if (have_trig) robot_advance_sc(p, e, p->scan_latency_ms, rs2, rc2); else robot_advance(p, e, p->scan_latency_ms);
                 CN_T(21);
             }
         } else {
             // Env.reset (ENV:1227-1263): gazebo/reset_simulation puts poses back and zeroes twists (the crowd clock keeps running)
             if (!ext) {
-                e.rx = p.spawn_x; e.ry = p.spawn_y; e.ryaw = p.spawn_yaw; e.rv = 0.0; e.rw = 0.0;
+                e.rx = p->spawn_x; e.ry = p->spawn_y; e.ryaw = p->spawn_yaw; e.rv = 0.0; e.rw = 0.0;
                 for (int i = lane; i < 2 * P; i += 64) { L.ped[i] = gped_init[i]; pedv[i] = 0.0; }
                 CN_SYNC();
-                e.clock += cn_div1000((double)p.scan_latency_ms);    // wait_for_message('scan') (ENV:1238)
-                sim_advance(p, e, env, lane, L.ped, pedv, p.scan_latency_ms);
+                e.clock += cn_div1000((double)p->scan_latency_ms);    // wait_for_message('scan') (ENV:1238)
+                sim_advance(p, e, env, lane, L.ped, pedv, p->scan_latency_ms);
             }
             if constexpr (LAYOUT == 1) {
-                e.prev_dist = dist3(e.rx, e.ry, p.goal_x, p.goal_y);   // ORIG:472 (unrounded)
+                e.prev_dist = dist3(e.rx, e.ry, p->goal_x, p->goal_y);   // ORIG:472 (unrounded)
                 e.prev_head = orig_heading(p, e.rx, e.ry, e.ryaw);     // ORIG:473
             } else {
             e.prev_dist = dist3(e.rx, e.ry, e.wpx, e.wpy);        // ENV:1243 (unrounded)
@@ -1331,22 +1501,22 @@ __device__ __forceinline__ void env_kernel_body(const CnKParams& p)
         }
         CN_SYNC();
         if (ph_obs) {
-            if constexpr (LAYOUT == 1) observe_original<EXT>(p, e, L, env, lane, sc, p.obs, fin, p.obs_f64, &done);
-            else observe<EXT>(p, pg, e, L, env, lane, sc, p.obs, fin, p.obs_f64, &done);
+            if constexpr (LAYOUT == 1) observe_original<EXT>(p, e, L, env, lane, sc, p->obs, fin, p->obs_f64, &done);
+            else observe<EXT>(p, pg, e, L, env, lane, sc, p->obs, fin, p->obs_f64, &done, have_trig, trig);
         } else if constexpr (EXT) {
             // Env.compute_reward(state, step_counter, done) on its own (ENV:1046): heading and distance are state[n], state[n+1]
             // (LAYOUT 1: state[-2], state[-1] are what ORIG:324-330 reads), `done` is the caller's
             const int D_ = (LAYOUT == 1) ? n + 4 : n + 7 + 4 * K;
             if (lane < 4) {
                 const int src = (LAYOUT == 1) ? n + lane : n + (lane & 1);
-                L.tail[lane] = p.obs_f64 ? p.obs_f64[(size_t)env * D_ + src] : (double)p.obs[(size_t)env * D_ + src];
+                L.tail[lane] = p->obs_f64 ? p->obs_f64[(size_t)env * D_ + src] : (double)p->obs[(size_t)env * D_ + src];
             }
-            done = p.done[env] ? 1 : 0;
+            done = p->done[env] ? 1 : 0;
             CN_SYNC();
         }
         if (!do_reset && !ph_rew) {
-            if (lane == 0) p.done[env] = (uint8_t)done;           // get_state returns (state, self.done) (ENV:1044)
-            if (p.topk_idx && lane < K) p.topk_idx[(size_t)env * K + lane] = LAYOUT == 1 ? -1 : L.kidx[lane];
+            if (lane == 0) p->done[env] = (uint8_t)done;           // get_state returns (state, self.done) (ENV:1044)
+            if (ph_obs && p->topk_idx && lane < K) p->topk_idx[(size_t)env * K + lane] = LAYOUT == 1 ? -1 : L.kidx[lane];
         } else
         if (!do_reset) {
             double r;
@@ -1354,15 +1524,15 @@ __device__ __forceinline__ void env_kernel_body(const CnKParams& p)
             else r = compute_reward(p, pg, e, L, lane, done);
             e.ep_ret += r;
             if (lane == 0) {
-                p.reward[env] = (float)r;
-                p.done[env] = (uint8_t)done;
+                p->reward[env] = (float)r;
+                p->done[env] = (uint8_t)done;
             }
-            if (ph_obs && p.topk_idx && lane < K) p.topk_idx[(size_t)env * K + lane] = LAYOUT == 1 ? -1 : L.kidx[lane];
+            if (ph_obs && p->topk_idx && lane < K) p->topk_idx[(size_t)env * K + lane] = LAYOUT == 1 ? -1 : L.kidx[lane];
             if (done) {
                 if (!ext) { e.rv = 0.0; e.rw = 0.0; }             // pub_cmd_vel.publish(Twist()) (ENV:1160)
                 e.last_ret = e.ep_ret;
                 e.episodes += 1;
-                e.pending = !ext && (p.auto_reset == 2);
+                e.pending = !ext && (p->auto_reset == 2);
                 if (lane == 0) {   // the finished episode's counters as TRAIN:142-147 reads them (the reset zeroes the live ones)
                     sd[CN_SD_LAST_EGO_VIOL] = (double)e.ego_viol; sd[CN_SD_LAST_SOCIAL_VIOL] = (double)e.social_viol;
                     sd[CN_SD_LAST_OBST_STEPS] = (double)e.obst_steps; sd[CN_SD_LAST_EP_STEPS] = (double)e.ep_step;
@@ -1371,8 +1541,8 @@ __device__ __forceinline__ void env_kernel_body(const CnKParams& p)
         } else {
             e.social_viol = 0; e.ego_viol = 0; e.obst_steps = 0;  // ENV:1260-1262
             if (!ext) {
-                e.clock += cn_div1000((double)p.settle_ms);          // TRAIN:114 time.sleep(0.1)
-                sim_advance(p, e, env, lane, L.ped, pedv, p.settle_ms);
+                e.clock += cn_div1000((double)p->settle_ms);          // TRAIN:114 time.sleep(0.1)
+                sim_advance(p, e, env, lane, L.ped, pedv, p->settle_ms);
             }
             e.done = 0;                                           // TRAIN:116
             e.ep_step = 0; e.ep_ret = 0.0; e.pending = 0;
@@ -1380,26 +1550,28 @@ __device__ __forceinline__ void env_kernel_body(const CnKParams& p)
         CN_SYNC();
     } else {
     // ---- same-call reset (auto_reset == 1): Env.step, then Env.reset for an env that just finished ----
-    bool need_reset = (p.mode == CN_MODE_RESET || p.mode == CN_MODE_EXT_RESET);
+    bool need_reset = (p->mode == CN_MODE_RESET || p->mode == CN_MODE_EXT_RESET);
     // auto_reset == 2 ("next-step" reset, the gymnasium NEXT_STEP convention): an env that finished in
     // the previous launch spends THIS launch on Env.reset() -- its action is ignored, reward 0, done 0 --
     // so no wavefront ever runs two observations back to back and the launch's critical path halves.
-    if (p.mode == CN_MODE_STEP && p.auto_reset == 2 && e.pending) {
+    if (p->mode == CN_MODE_STEP && p->auto_reset == 2 && e.pending) {
         need_reset = true;
         e.pending = 0;
-        if (lane == 0) { p.reward[env] = 0.0f; p.done[env] = 0; }
-        if (p.topk_idx && lane < K) p.topk_idx[(size_t)env * K + lane] = -1;
-    } else if (p.mode == CN_MODE_STEP || p.mode == CN_MODE_EXT_STEP) {
+        if (lane == 0) { p->reward[env] = 0.0f; p->done[env] = 0; }
+        if (p->topk_idx && lane < K) p->topk_idx[(size_t)env * K + lane] = -1;
+    } else if (p->mode == CN_MODE_STEP || p->mode == CN_MODE_EXT_STEP) {
         // ---- Env.step (ENV:1164-1225), continuous mode ---------------------------------------------
         e.ep_step += 1;
-        const int sc = p.step_counter ? p.step_counter[env] : e.ep_step;
+        const int sc = p->step_counter ? p->step_counter[env] : e.ep_step;
         double deq_x, deq_y, end_timestep;
         if (!ext) {
-            const double v = (double)p.action[2 * env], w = (double)p.action[2 * env + 1];
+            const double v = (double)p->action[2 * env], w = (double)p->action[2 * env + 1];
             const double t0 = e.clock;
             e.rv = v; e.rw = w;                               // pub_cmd_vel.publish (ENV:1200)
-            e.clock += cn_div1000((double)p.dt_ms);              // time.sleep(0.15) (ENV:1201)
-            sim_advance(p, e, env, lane, L.ped, pedv, p.dt_ms);
+            e.clock += cn_div1000((double)p->dt_ms);              // time.sleep(0.15) (ENV:1201)
+            ped_advance(p, env, lane, L.ped, pedv, e.crowd_ms, e.crowd_ms + p->dt_ms + p->scan_latency_ms, p->dt_ms);
+            e.crowd_ms += p->dt_ms + p->scan_latency_ms;
+            robot_advance(p, e, p->dt_ms);
             end_timestep = e.clock - t0;                      // ENV:1202
             deq_x = e.rx; deq_y = e.ry;
         } else {                                              // the caller ran the sleep; /odom said where we are
@@ -1413,30 +1585,30 @@ __device__ __forceinline__ void env_kernel_body(const CnKParams& p)
         }
         e.ts = end_timestep;                                  // ENV:1209
         if (!ext) {
-            e.clock += cn_div1000((double)p.scan_latency_ms);    // wait_for_message('scan') (ENV:1218)
-            sim_advance(p, e, env, lane, L.ped, pedv, p.scan_latency_ms);
+            e.clock += cn_div1000((double)p->scan_latency_ms);    // wait_for_message('scan') (ENV:1218)
+            robot_advance(p, e, p->scan_latency_ms);
         }
         CN_SYNC();
         double r;
         if constexpr (LAYOUT == 1) {
-            observe_original<EXT>(p, e, L, env, lane, sc, p.obs, ext ? nullptr : p.final_obs, p.obs_f64, &done);
+            observe_original<EXT>(p, e, L, env, lane, sc, p->obs, ext ? nullptr : p->final_obs, p->obs_f64, &done);
             r = compute_reward_original(p, e, L, done);
         } else {
-            observe<EXT>(p, pg, e, L, env, lane, sc, p.obs, ext ? nullptr : p.final_obs, p.obs_f64, &done);
+            observe<EXT>(p, pg, e, L, env, lane, sc, p->obs, ext ? nullptr : p->final_obs, p->obs_f64, &done);
             r = compute_reward(p, pg, e, L, lane, done);
         }
         e.ep_ret += r;
         if (lane == 0) {
-            p.reward[env] = (float)r;
-            p.done[env] = (uint8_t)done;
+            p->reward[env] = (float)r;
+            p->done[env] = (uint8_t)done;
         }
-        if (p.topk_idx && lane < K) p.topk_idx[(size_t)env * K + lane] = LAYOUT == 1 ? -1 : L.kidx[lane];
+        if (p->topk_idx && lane < K) p->topk_idx[(size_t)env * K + lane] = LAYOUT == 1 ? -1 : L.kidx[lane];
         if (done) {
             if (!ext) { e.rv = 0.0; e.rw = 0.0; }             // pub_cmd_vel.publish(Twist()) (ENV:1160)
             e.last_ret = e.ep_ret;
             e.episodes += 1;
-            need_reset = !ext && (p.auto_reset == 1);
-            e.pending = !ext && (p.auto_reset == 2);
+            need_reset = !ext && (p->auto_reset == 1);
+            e.pending = !ext && (p->auto_reset == 2);
             if (lane == 0) {   // the finished episode's counters as TRAIN:142-147 reads them (the reset zeroes the live ones)
                 sd[CN_SD_LAST_EGO_VIOL] = (double)e.ego_viol; sd[CN_SD_LAST_SOCIAL_VIOL] = (double)e.social_viol;
                 sd[CN_SD_LAST_OBST_STEPS] = (double)e.obst_steps; sd[CN_SD_LAST_EP_STEPS] = (double)e.ep_step;
@@ -1449,29 +1621,29 @@ __device__ __forceinline__ void env_kernel_body(const CnKParams& p)
         // ---- Env.reset (ENV:1227-1263) + TRAIN:114-116 -----------------------------------------------
         // gazebo/reset_simulation: poses back to their initial values, twists zeroed (crowd clock keeps running)
         if (!ext) {
-        e.rx = p.spawn_x; e.ry = p.spawn_y; e.ryaw = p.spawn_yaw; e.rv = 0.0; e.rw = 0.0;
+        e.rx = p->spawn_x; e.ry = p->spawn_y; e.ryaw = p->spawn_yaw; e.rv = 0.0; e.rw = 0.0;
         for (int i = lane; i < 2 * P; i += 64) { L.ped[i] = gped_init[i]; pedv[i] = 0.0; }
         CN_SYNC();
-        e.clock += cn_div1000((double)p.scan_latency_ms);        // wait_for_message('scan') (ENV:1238)
-        sim_advance(p, e, env, lane, L.ped, pedv, p.scan_latency_ms);
+        e.clock += cn_div1000((double)p->scan_latency_ms);        // wait_for_message('scan') (ENV:1238)
+        sim_advance(p, e, env, lane, L.ped, pedv, p->scan_latency_ms);
         }
         CN_SYNC();
         int d2 = 0;
         if constexpr (LAYOUT == 1) {
-            e.prev_dist = dist3(e.rx, e.ry, p.goal_x, p.goal_y);   // ORIG:472 (unrounded)
+            e.prev_dist = dist3(e.rx, e.ry, p->goal_x, p->goal_y);   // ORIG:472 (unrounded)
             e.prev_head = orig_heading(p, e.rx, e.ry, e.ryaw);     // ORIG:473
             CN_SYNC();
-            observe_original<EXT>(p, e, L, env, lane, 0, p.obs, nullptr, p.obs_f64, &d2);
+            observe_original<EXT>(p, e, L, env, lane, 0, p->obs, nullptr, p->obs_f64, &d2);
         } else {
         e.prev_dist = dist3(e.rx, e.ry, e.wpx, e.wpy);        // ENV:1243 (unrounded)
         e.prev_head = heading_to_goal(p, e, e.rx, e.ry, e.ryaw);  // ENV:1244
         CN_SYNC();
-        observe<EXT>(p, pg, e, L, env, lane, 0, p.obs, nullptr, p.obs_f64, &d2);
+        observe<EXT>(p, pg, e, L, env, lane, 0, p->obs, nullptr, p->obs_f64, &d2);
         }
         e.social_viol = 0; e.ego_viol = 0; e.obst_steps = 0;  // ENV:1260-1262
         if (!ext) {
-        e.clock += cn_div1000((double)p.settle_ms);              // TRAIN:114 time.sleep(0.1)
-        sim_advance(p, e, env, lane, L.ped, pedv, p.settle_ms);
+        e.clock += cn_div1000((double)p->settle_ms);              // TRAIN:114 time.sleep(0.1)
+        sim_advance(p, e, env, lane, L.ped, pedv, p->settle_ms);
         }
         e.done = 0;                                           // TRAIN:116
         e.ep_step = 0; e.ep_ret = 0.0; e.pending = 0;
@@ -1479,6 +1651,7 @@ __device__ __forceinline__ void env_kernel_body(const CnKParams& p)
     }
 
     }
+    asm volatile("" :: "v"(trk_warm));   // keeps the warming load (its value is irrelevant)
     CN_T(18);
     // ---- write env state back ---------------------------------------------------------------------
     for (int i = lane; i < 2 * P; i += 64) { gped_p[i] = L.ped[i]; gped_v[i] = pedv[i]; }
@@ -1501,13 +1674,22 @@ __device__ __forceinline__ void env_kernel_body(const CnKParams& p)
 
 // The product kernel (simulated sensors) and its sibling for externally supplied /scan + /odom.  Two
 // instantiations keep the external-data branch out of the hot kernel's registers.
-extern "C" __global__ void __launch_bounds__(64) cn_env_kernel(CnKParams p) { env_kernel_body<false, false, 0>(p); }
-extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_same(CnKParams p) { env_kernel_body<false, true, 0>(p); }
-extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_ext(CnKParams p) { env_kernel_body<true, false, 0>(p); }
+extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) cn_env_kernel(CnKParams p) { env_kernel_body<false, false, 0>(); }
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_same(CnKParams p) { env_kernel_body<false, true, 0>(); }
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_ext(CnKParams p) { env_kernel_body<true, false, 0>(); }
 // obs_layout 1 (environment_stage_1_original.py): same physics and lidar, no tracker
-extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_orig(CnKParams p) { env_kernel_body<false, false, 1>(p); }
-extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_orig_same(CnKParams p) { env_kernel_body<false, true, 1>(p); }
-extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_orig_ext(CnKParams p) { env_kernel_body<true, false, 1>(p); }
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_orig(CnKParams p) { env_kernel_body<false, false, 1>(); }
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_orig_same(CnKParams p) { env_kernel_body<false, true, 1>(); }
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_orig_ext(CnKParams p) { env_kernel_body<true, false, 1>(); }
+
+// cn_create: bbox_size() at the spawn pose, evaluated once by the same device code the step kernel would run
+extern "C" __global__ void __launch_bounds__(64) cn_bbox_kernel(CnKParams pv, double* out)
+{
+    __shared__ double stage[64];
+    KP p = (KP)__builtin_amdgcn_kernarg_segment_ptr();
+    const double v = bbox_size(p, stage, threadIdx.x, p->R - 1, p->spawn_x, p->spawn_y, p->spawn_yaw);
+    if (threadIdx.x == 0) out[0] = v;
+}
 
 // float32 views of the per-env returns (for the RCCL all-gather of episode returns) and counters
 extern "C" __global__ void cn_gather_kernel(CnKParams p, float* last_ret, float* run_ret, int32_t* counters)
