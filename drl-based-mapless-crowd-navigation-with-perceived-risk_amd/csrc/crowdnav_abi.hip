@@ -69,13 +69,13 @@ static size_t lds_bytes_impl(int R, int P, int K, int max_conf, int trk_cap, boo
     size_t szB_c = 32 * mc + 8 * 64 + 8 * (size_t)(8 + 4 * K) + 4 * (size_t)CN_MAX_K;
     size_t szB = szB_g > szB_c ? szB_g : szB_c;
     if (szB < 8 * 64) szB = 8 * 64;
-    if (!near_separate && szB < 24 * (size_t)(P + 1)) szB = 24 * (size_t)(P + 1);   // near-pedestrian list overlaid on region B
+    if (!near_separate && szB < 32 * (size_t)(P + 1)) szB = 32 * (size_t)(P + 1);   // near-pedestrian list overlaid on region B
     size_t Wn = (n + 63) >> 6;
     size_t b = szA + szB;
     b += 8 * (size_t)(CN_NMASK * Wn);             // bit words
     b += 8 * ((3 * Wn + 1) / 2);                  // wbase
     b += 8 * (size_t)(2 * P + 2) * 2;             // ped, pedv
-    if (near_separate) b += 24 * (size_t)(P + 1); // near-pedestrian list in its own region
+    if (near_separate) b += 32 * (size_t)(P + 1); // near-pedestrian list in its own region
     return (b + 15) & ~(size_t)15;
 }
 
@@ -190,12 +190,17 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
     h->lds = cn_lds_bytes(R, P, K, h->max_conf, h->trk_cap);
     if (h->lds > 160 * 1024) { return fail(CN_ERR_CONFIG, "cn_create: per-env working set exceeds 160 KiB of LDS"); }
     // tables
-    std::vector<double> lidar(4 * (size_t)R), poly(128);
+    const int Wb = (R + 63) / 64;
+    std::vector<double> lidar(4 * (size_t)R + 2 * (size_t)Wb), poly(128);
     double step = c.lidar_span / (double)(R - 1);
     for (int k = 0; k < R; ++k) cn_det_sincos((double)k * step, &lidar[R + k], &lidar[k]);
     for (int j = 0; j < R - 1; ++j) {  // UTL:121-123 math.radians(i * angle_increment)
         double a = ((double)j * angle_increment_deg(R)) * (M_PI / 180.0);
         lidar[2 * R + j] = sin(a); lidar[3 * R + j] = cos(a);
+    }
+    for (int q = 0; q < Wb; ++q) {   // axis of 64-ray block q: ray 64 q + 32 (robot frame)
+        int kq = 64 * q + 32 < R ? 64 * q + 32 : R - 1;
+        lidar[4 * (size_t)R + 2 * q] = lidar[kq]; lidar[4 * (size_t)R + 2 * q + 1] = lidar[R + kq];
     }
     for (int k = 0; k < 64; ++k) { double a = -(double)k * M_PI / 32.0; poly[k] = cos(a); poly[64 + k] = sin(a); }
     HIPCHK(hipMalloc(&h->d_lidar, lidar.size() * 8));
@@ -226,6 +231,7 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
     k.max_scan_range = c.max_scan_range; k.min_scan_range = c.min_scan_range; k.goal_x = c.goal_x; k.goal_y = c.goal_y;
     k.start_x = c.start_x; k.start_y = c.start_y; k.spawn_x = c.spawn_x; k.spawn_y = c.spawn_y; k.spawn_yaw = c.spawn_yaw;
     k.waypoint_radius = c.waypoint_radius; k.goal_eps = c.goal_eps; k.angle_inc_deg = angle_increment_deg(R); k.lidar_step = step;
+    k.blk_dir = h->d_lidar + 4 * (size_t)R; k.blk_cb = cos(32.5 * step); k.blk_sb = sin(32.5 * step);
     k.lidar_c = h->d_lidar; k.lidar_s = h->d_lidar + R; k.ang_s = h->d_lidar + 2 * R; k.ang_c = h->d_lidar + 3 * R; k.poly_c = h->d_poly; k.poly_s = h->d_poly + 64;
     k.state = h->d_state; k.state_stride = (int64_t)h->stride; k.ped_init = h->d_ped_init;
     k.ped_preset = h->d_ped_preset; k.trk = h->d_trk;

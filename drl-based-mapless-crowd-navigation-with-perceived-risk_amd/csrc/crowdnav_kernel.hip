@@ -58,7 +58,7 @@ struct Lds {
     u64* w64;         // [M_COUNT][CN_MAXW] 64-ray bit words
     unsigned short* srcidx;  // [n] source ray of an aliased type entry
     int* wbase;       // [3][CN_MAXW]
-    double* nearp;    // [3 (P+1)] pedestrians within lidar reach: centre relative to the lidar origin (x, y) and |c|^2 - r^2
+    double* nearp;    // [4 (P+1)] pedestrians within lidar reach: centre relative to the lidar origin (x, y), |c|^2 - r^2, block bits
     double* ped;      // [2P] positions
     double* pedv;     // [2P] velocities
     double* trk;      // [CN_TF_COUNT][tcap]
@@ -309,13 +309,22 @@ __device__ __forceinline__ void sim_advance(KP p, EnvRegs& e, int env, int lane,
 // Pedestrians that can return a range <= lidar_max: |centre - origin| <= lidar_max + radius (+ slack).
 // A culled pedestrian could only produce t > lidar_max, which reads as "no return" anyway, so the
 // result is identical to testing all P (the oracle does).
-__device__ __forceinline__ int near_peds(KP p, const Lds& L, int lane, double ox, double oy)
+// Each listed pedestrian also carries a bit per 64-ray block: can ANY ray of that block reach its disc?  Block q spans
+// the rays within beta = 32.5 steps of ray 64q + 32; a disc at distance d subtends asin(r / d); the two cones meet iff
+// the angle between them is <= asin(r / d) + beta, i.e. (times d, cos decreasing on [0, pi])
+//     oc . u_q  >=  cos(beta) sqrt(d^2 - r^2) - sin(beta) r
+// with u_q the block's axis (robot frame: a host table) and oc rotated into the robot frame.  Evaluated with slack, so a
+// cleared bit only ever skips a test that could not hit (ranges unchanged); a crowded env otherwise pays every near
+// pedestrian in every block, and the launch waits for its most crowded env.
+__device__ __forceinline__ int near_peds(KP p, const Lds& L, int lane, double ox, double oy, double sy, double cy)
 {
     // The list holds what the ray test needs (not indices): the inner loop then reads three independent values per
     // pedestrian instead of chasing index -> position through two dependent LDS reads for every ray block.
     int nnear = 0;
     const double lim = p->lidar_max + p->ped_radius + 1e-6, lim2 = lim * lim;
     const double rr = p->ped_radius * p->ped_radius;
+    const int Wb = (p->R + 63) >> 6;
+    const double* const bd = p->blk_dir;
     for (int j0 = 0; j0 < p->P; j0 += 64) {
         int j = j0 + lane;
         bool nr = false;
@@ -327,10 +336,29 @@ __device__ __forceinline__ int near_peds(KP p, const Lds& L, int lane, double ox
         u64 m = __ballot(nr);
         if (nr) {
             const int slot = nnear + __popcll(m & ((1ull << lane) - 1ull));
-            L.nearp[3 * slot] = ocx; L.nearp[3 * slot + 1] = ocy;
-            L.nearp[3 * slot + 2] = fma(ocx, ocx, fma(ocy, ocy, -rr));
+            const double cc = fma(ocx, ocx, fma(ocy, ocy, -rr));
+            u64 tag = ~0ull;
+            if (cc > 0.0) {
+                const double rx_ = fma(cy, ocx, sy * ocy), ry_ = fma(cy, ocy, -(sy * ocx));     // oc in the robot frame
+                const double thr = fma(p->blk_cb, sqrt(cc), -(p->blk_sb * p->ped_radius)) - 1e-9;
+                tag = 0ull;
+                for (int q = 0; q < Wb; ++q)
+                    if (fma(rx_, bd[2 * q], ry_ * bd[2 * q + 1]) >= thr) tag |= 1ull << q;
+            }
+            L.nearp[4 * slot] = ocx; L.nearp[4 * slot + 1] = ocy; L.nearp[4 * slot + 2] = cc;
+            ((u64*)L.nearp)[4 * slot + 3] = tag;
         }
         nnear += __popcll(m);
+    }
+    CN_SYNC();
+    // Transposed for the ray loop: one 64-bit word per block = the list slots (first 64) worth testing in that block, so the
+    // loop walks set bits held in scalar registers instead of paying an LDS round trip per pedestrian per block to find out.
+    // (The flag-word area is free until the ray loop is over.)
+    u64 mytag = 0ull;
+    if (lane < nnear) mytag = ((const u64*)L.nearp)[4 * lane + 3];
+    for (int q = 0; q < Wb; ++q) {
+        const u64 bm = __ballot(((mytag >> q) & 1ull) != 0ull);
+        if (lane == 0) L.w64[q] = bm;
     }
     CN_SYNC();
     return nnear;
@@ -355,8 +383,9 @@ __device__ __forceinline__ double cast_ray(KP p, const Lds& L, int env, int k, d
         if (wall_x && dx != 0.0) t = fmin(t, ((dx > 0.0 ? h : -h) - ox) / dx);
         if (wall_y && dy != 0.0) t = fmin(t, ((dy > 0.0 ? h : -h) - oy) / dy);
         if (t < p->lidar_min) t = p->lidar_min;
-        for (int c = 0; c < nnear; ++c) {
-            const double ocx = L.nearp[3 * c], ocy = L.nearp[3 * c + 1], cc = L.nearp[3 * c + 2];
+        const int q = k >> 6;                                  // this block of 64 rays (wave-uniform)
+        auto test = [&](int c) {
+            const double ocx = L.nearp[4 * c], ocy = L.nearp[4 * c + 1], cc = L.nearp[4 * c + 2];
             double b = fma(ocx, dx, ocy * dy);
             double disc = fma(b, b, -cc);
             if (disc >= 0.0) {
@@ -367,7 +396,15 @@ __device__ __forceinline__ double cast_ray(KP p, const Lds& L, int env, int k, d
                     t = fmin(t, t1);
                 }
             }
+        };
+        u64 bm = uni64(L.w64[q]);                              // list slots some ray of this block can reach
+        while (bm) {
+            const int c = __builtin_ctzll(bm);
+            bm &= bm - 1ull;
+            test(c);
         }
+        for (int c = 64; c < nnear; ++c)                       // beyond 64 near pedestrians: per-slot bits
+            if ((((const u64*)L.nearp)[4 * c + 3] >> q) & 1ull) test(c);
         return (t > p->lidar_max) ? INFINITY : t;       // the simulated sensor reports no return beyond its range
     }
 }
@@ -396,7 +433,7 @@ __device__ __forceinline__ void observe_original(KP p, EnvRegs& e, const Lds& L,
     cn_det_sincos(yaw, &sy, &cy);
     const double ox = fma(p->lidar_offset_x, cy, px), oy = fma(p->lidar_offset_x, sy, py);
     const double h = p->room_half;
-    const int nnear = near_peds(p, L, lane, ox, oy);
+    const int nnear = near_peds(p, L, lane, ox, oy, sy, cy);
     const bool wall_x = !(h - fabs(ox) > p->lidar_max + 1e-6);
     const bool wall_y = !(h - fabs(oy) > p->lidar_max + 1e-6);
     float* o32 = obs32 + (size_t)env * D;
@@ -526,7 +563,7 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
     const double ox = fma(p->lidar_offset_x, cy, px), oy = fma(p->lidar_offset_x, sy, py);
     const double h = p->room_half;
     const double deg2rad = CN_PI / 180.0;
-    const int nnear = near_peds(p, L, lane, ox, oy);
+    const int nnear = near_peds(p, L, lane, ox, oy, sy, cy);
     const bool wall_x = !(h - fabs(ox) > p->lidar_max + 1e-6);
     const bool wall_y = !(h - fabs(oy) > p->lidar_max + 1e-6);
     CN_T(3);
@@ -1003,15 +1040,22 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
         } else {
             unsigned long long alive = 0ull;
             int cur = nt0;
-            if (nt0 <= 8 && nconf <= 8) {
-                // The usual case (a handful of tracks and confirmed objects): the whole IoU matrix in one pass,
-                // lane = track * 8 + object, arg-max inside each 8-lane group (first maximum wins, ENV:688-700),
-                // then lane = track applies its match.  Same arithmetic per pair as the general loop below.
-                const int ti = lane >> 3, oj = lane & 7;
+            // ENV:688-700: every track against every confirmed object (walls included), arg-max with the first maximum
+            // winning (list.index(max)).  Tiled 8 tracks x 8 objects per pass, lane = track * 8 + object: a lane keeps the
+            // best of ITS objects across the object tiles (ascending index, strict >), the 8 lanes of a track then reduce
+            // with the lower index winning ties.  One pass in the usual case; a crowded env (> 8 tracks or objects) pays
+            // ceil(nt / 8) * ceil(nconf / 8) passes instead of one serial wave-wide arg-max per track -- and a launch
+            // lasts as long as its most crowded env.
+            int mybj = 0; bool mymatch = false;                      // lane = track
+            for (int t0 = 0; t0 < nt0; t0 += 8) {
+                const int ti = t0 + (lane >> 3);
                 double best = -1.0; int bj = 0x7fffffff;
-                if (ti < nt0 && oj < nconf) {
-                    best = cn_iou3(TRK(CN_TF_PX, ti), TRK(CN_TF_PY, ti), L.cfx[oj], L.cfy[oj], 0.0505);
-                    bj = oj;
+                if (ti < nt0) {
+                    const double tx = TRK(CN_TF_PX, ti), ty_ = TRK(CN_TF_PY, ti);
+                    for (int oj = lane & 7; oj < nconf; oj += 8) {
+                        const double u = cn_iou3(tx, ty_, L.cfx[oj], L.cfy[oj], 0.0505);
+                        if (u > best) { best = u; bj = oj; }
+                    }
                 }
 #pragma unroll
                 for (int m = 4; m >= 1; m >>= 1) {
@@ -1019,50 +1063,23 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
                     int ojx = __shfl_xor(bj, m, 64);
                     if (ob > best || (ob == best && ojx < bj)) { best = ob; bj = ojx; }
                 }
-                const u64 posm = __ballot(best > 0.0);             // bit 8*i (any lane of group i): track i matched
-                const int mybj = __shfl(bj, (lane & 7) * 8, 64);   // lane i < 8 <- group i's winner
-                for (int i = 0; i < nt0; ++i) {                     // ENV:702-717, the order-dependent part (scalar)
-                    if ((posm >> (8 * i)) & 1ull) alive |= (1ull << i);
-                    else if (cur > i) cur -= 1;
-                    else alive |= (1ull << i);
-                }
-                if (lane < nt0 && ((posm >> (8 * lane)) & 1ull)) {  // ENV:702-712
-                    const int i = lane;
-                    double cxj = L.cfx[mybj], cyj = L.cfy[mybj];
-                    TRK(CN_TF_PX, i) = cxj; TRK(CN_TF_PY, i) = cyj; TRK(CN_TF_DIST, i) = L.cfd[mybj];
-                    if (TRK(CN_TF_DQLEN, i) < 1.5) { TRK(CN_TF_D1X, i) = cxj; TRK(CN_TF_D1Y, i) = cyj; TRK(CN_TF_DQLEN, i) = 2.0; }
-                    TRK(CN_TF_T, i) = now - TRK(CN_TF_T, i);
-                    L.checked[mybj] = 1;
-                }
-            } else
-            for (int i = 0; i < nt0; ++i) {
-                double tx = TRK(CN_TF_PX, i), ty_ = TRK(CN_TF_PY, i);
-                double best = -1.0; int bj = 0x7fffffff;
-                for (int j = lane; j < nconf; j += 64) {  // ENV:688-689 (walls included)
-                    double u = cn_iou3(tx, ty_, L.cfx[j], L.cfy[j], 0.0505);
-                    if (u > best) { best = u; bj = j; }
-                }
-                // wave arg-max, first maximum wins (list.index(max))
-#pragma unroll
-                for (int m = 32; m >= 1; m >>= 1) {
-                    double ob = cn_shfl_xor_d(best, m);
-                    int oj = __shfl_xor(bj, m, 64);
-                    if (ob > best || (ob == best && oj < bj)) { best = ob; bj = oj; }
-                }
-                if (best > 0.0) {  // ENV:702-712
-                    alive |= (1ull << i);
-                    if (lane == 0) {
-                        double cxj = L.cfx[bj], cyj = L.cfy[bj];
-                        TRK(CN_TF_PX, i) = cxj; TRK(CN_TF_PY, i) = cyj; TRK(CN_TF_DIST, i) = L.cfd[bj];
-                        if (TRK(CN_TF_DQLEN, i) < 1.5) { TRK(CN_TF_D1X, i) = cxj; TRK(CN_TF_D1Y, i) = cyj; TRK(CN_TF_DQLEN, i) = 2.0; }
-                        TRK(CN_TF_T, i) = now - TRK(CN_TF_T, i);
-                        L.checked[bj] = 1;
-                    }
-                } else if (cur > i) {  // ENV:715-717
-                    cur -= 1;
-                } else {
-                    alive |= (1ull << i);
-                }
+                const u64 posm = __ballot(best > 0.0);             // bit 8 g (any lane of group g): track t0 + g matched
+                const int wb = __shfl(bj, (lane & 7) * 8, 64);     // lane t0 + g <- group g's winner
+                if ((lane >> 3) == (t0 >> 3)) { mybj = wb; mymatch = ((posm >> (8 * (lane & 7))) & 1ull) != 0ull; }
+            }
+            const u64 matchm = __ballot(mymatch && lane < nt0);
+            for (int i = 0; i < nt0; ++i) {                         // ENV:702-717, the order-dependent part (scalar)
+                if ((matchm >> i) & 1ull) alive |= (1ull << i);
+                else if (cur > i) cur -= 1;
+                else alive |= (1ull << i);
+            }
+            if (lane < nt0 && ((matchm >> lane) & 1ull)) {          // ENV:702-712
+                const int i = lane;
+                double cxj = L.cfx[mybj], cyj = L.cfy[mybj];
+                TRK(CN_TF_PX, i) = cxj; TRK(CN_TF_PY, i) = cyj; TRK(CN_TF_DIST, i) = L.cfd[mybj];
+                if (TRK(CN_TF_DQLEN, i) < 1.5) { TRK(CN_TF_D1X, i) = cxj; TRK(CN_TF_D1Y, i) = cyj; TRK(CN_TF_DQLEN, i) = 2.0; }
+                TRK(CN_TF_T, i) = now - TRK(CN_TF_T, i);
+                L.checked[mybj] = 1;
             }
             CN_SYNC();
             // compact the survivors, order preserved
@@ -1364,7 +1381,7 @@ __device__ __forceinline__ void env_kernel_body()
         const size_t szB_c = 32 * mc + 8 * 64 + 8 * (size_t)(8 + 4 * K) + 4 * (size_t)CN_MAX_K;
         size_t szB = szB_g > szB_c ? szB_g : szB_c;
         if (szB < 8 * 64) szB = 8 * 64;
-        if (!p->near_sep && szB < 24 * (size_t)(P + 1)) szB = 24 * (size_t)(P + 1);   // near-pedestrian list overlaid on B
+        if (!p->near_sep && szB < 32 * (size_t)(P + 1)) szB = 32 * (size_t)(P + 1);   // near-pedestrian list overlaid on B
         char* A = smem;
         char* B = A + szA;
         char* Cw = B + szB;
@@ -1674,7 +1691,14 @@ __device__ __forceinline__ void env_kernel_body()
 
 // The product kernel (simulated sensors) and its sibling for externally supplied /scan + /odom.  Two
 // instantiations keep the external-data branch out of the hot kernel's registers.
-extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) cn_env_kernel(CnKParams p) { env_kernel_body<false, false, 0>(); }
+// 4 waves per SIMD = 128 VGPRs: the allocator lands on 131 without the bound (3 waves per SIMD) and on 128 with it, no spills.
+// (Not in the profiling build: there the bound trips an LLVM "even aligned vector registers" assertion.)
+#ifdef CN_TIMING
+#define CN_HOT_BOUNDS __launch_bounds__(64)
+#else
+#define CN_HOT_BOUNDS __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
+#endif
+extern "C" __global__ void CN_HOT_BOUNDS cn_env_kernel(CnKParams p) { env_kernel_body<false, false, 0>(); }
 extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_same(CnKParams p) { env_kernel_body<false, true, 0>(); }
 extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_ext(CnKParams p) { env_kernel_body<true, false, 0>(); }
 // obs_layout 1 (environment_stage_1_original.py): same physics and lidar, no tracker
