@@ -178,33 +178,61 @@ __device__ __forceinline__ double cn_shfl_xor_d(double v, int m)
     hi = __shfl_xor(hi, m, 64);
     return __hiloint2double(hi, lo);
 }
+// Wave-wide reductions on the DPP path (row_shr 1/2/4/8 inside each row of 16 lanes, then row_bcast:15 / row_bcast:31
+// across the rows; the total lands in lane 63 and is read back as a scalar).  A step is two or three VALU instructions;
+// the __shfl_xor butterfly is two ds_bpermute LDS round trips per step, ~1 k cycles of pure latency per reduction on a
+// wavefront's critical path, six times per observation.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int cn_dpp_i(int ident, int v) { return __builtin_amdgcn_update_dpp(ident, v, CTRL, ROW_MASK, 0xf, false); }
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double cn_dpp_d(double ident, double v)
+{
+    int lo = __builtin_amdgcn_update_dpp(__double2loint(ident), __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    int hi = __builtin_amdgcn_update_dpp(__double2hiint(ident), __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+#define CN_DPP_REDUCE(T, DPP, v, ident, OP)                         \
+    do {                                                            \
+        v = OP(v, DPP<0x111, 0xf>(ident, v)); /* row_shr:1 */       \
+        v = OP(v, DPP<0x112, 0xf>(ident, v)); /* row_shr:2 */       \
+        v = OP(v, DPP<0x114, 0xf>(ident, v)); /* row_shr:4 */       \
+        v = OP(v, DPP<0x118, 0xf>(ident, v)); /* row_shr:8 */       \
+        v = OP(v, DPP<0x142, 0xa>(ident, v)); /* row_bcast:15 */    \
+        v = OP(v, DPP<0x143, 0xc>(ident, v)); /* row_bcast:31 */    \
+    } while (0)
+__device__ __forceinline__ double cn_lane63_d(double v)
+{
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double cn_wave_min_d(double v)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = fmin(v, cn_shfl_xor_d(v, m));
-    return v;
+    const double id = INFINITY;
+    CN_DPP_REDUCE(double, cn_dpp_d, v, id, fmin);
+    return cn_lane63_d(v);
 }
 __device__ __forceinline__ double cn_wave_max_d(double v)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = fmax(v, cn_shfl_xor_d(v, m));
-    return v;
+    const double id = -INFINITY;
+    CN_DPP_REDUCE(double, cn_dpp_d, v, id, fmax);
+    return cn_lane63_d(v);
 }
+__device__ __forceinline__ int cn_add_i(int a, int b) { return a + b; }
 __device__ __forceinline__ int cn_wave_min_i(int v)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = min(v, __shfl_xor(v, m, 64));
-    return v;
+    const int id = 0x7fffffff;
+    CN_DPP_REDUCE(int, cn_dpp_i, v, id, min);
+    return __builtin_amdgcn_readlane(v, 63);
 }
 __device__ __forceinline__ int cn_wave_max_i(int v)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = max(v, __shfl_xor(v, m, 64));
-    return v;
+    const int id = (int)0x80000000;
+    CN_DPP_REDUCE(int, cn_dpp_i, v, id, max);
+    return __builtin_amdgcn_readlane(v, 63);
 }
 __device__ __forceinline__ int cn_wave_sum_i(int v)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
+    const int id = 0;
+    CN_DPP_REDUCE(int, cn_dpp_i, v, id, cn_add_i);
+    return __builtin_amdgcn_readlane(v, 63);
 }
