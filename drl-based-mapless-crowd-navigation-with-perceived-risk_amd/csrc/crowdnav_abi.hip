@@ -172,7 +172,6 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
         return fail(CN_ERR_CONFIG, "cn_create: config out of range");
     if (c.ped_contact) return fail(CN_ERR_CONFIG, "cn_create: ped_contact is not built yet");
     if (c.risk_mode != CN_RISK_LIDAR_TRACKER) return fail(CN_ERR_CONFIG, "cn_create: risk_mode gt is not built yet");
-    if (c.geos_untyped_empty) return fail(CN_ERR_CONFIG, "cn_create: geos_untyped_empty is not built yet");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         return fail(CN_ERR_NO_DEVICE, "cn_create: no HIP device (libcrowdnav has no CPU fallback)");

@@ -85,8 +85,9 @@ __device__ __forceinline__ double heading_to_goal(KP p, const EnvRegs& e, double
 
 __device__ __forceinline__ double dist3(double ax, double ay, double bx, double by)
 {
+    // np.linalg.norm of the 3-vector (ENV:191-197) = sqrt(ddot(d, d)): BLAS accumulates with fma (pinned by the goldens)
     double dx = ax - bx, dy = ay - by;
-    return sqrt(dx * dx + dy * dy + 0.0);  // np.linalg.norm of the 3-vector, ENV:191-197
+    return sqrt(fma(dy, dy, dx * dx));
 }
 
 __device__ __forceinline__ bool in_box(double x, double y, double gx, double gy, double eps)
@@ -1205,6 +1206,9 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
                     nearm = __ballot(nearc);
                 }
                 unsigned cand = (unsigned)((nearm >> (8 * (r_ & 7))) & 0xffull);   // bit c <-> x2 = hi - c
+                // cn_config.geos_untyped_empty (GEOS <= 3.8): a candidate that misses prints 'GEOMETRYCOLLECTION EMPTY',
+                // UTL:279's comparison is true, `.geoms[0]` raises and the search ends with None -- only x2 = hi counts
+                if (p->geos_untyped_empty) cand &= 1u;
                 if (!cand) continue;
                 const double tx = TRK(CN_TF_PX, i), ty_ = TRK(CN_TF_PY, i);
                 while (cand) {

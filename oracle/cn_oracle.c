@@ -69,6 +69,8 @@ typedef struct {
     int ntracks;
     double ego_score_cp;
     double collision_prob;
+    double entry_cp[CNO_MAX_TRACKS];   /* debug: CP of every entry before the top-K cut (ENV:818-860) */
+    double entry_ego[CNO_MAX_TRACKS];
     int ego_viol, social_viol, obst_steps;
     int ep_success, ep_failure;
     int ep_step;
@@ -437,7 +439,7 @@ int cno_waypoint(double ax, double ay, double gx, double gy, double radius, doub
 
 /* UTL:251-293 get_collision_point.  returns 1 and *dist when a distance exists, else 0 (None) */
 static int collision_point_impl(const double* pc, const double* ps, double a0x, double a0y, double a1x,
-                                double a1y, double ox, double oy, double radius, double* dist)
+                                double a1y, double ox, double oy, double radius, double* dist, int untyped_empty)
 {
     double gradient;
     if (a1y == 0.0) gradient = 0.0; /* ZeroDivisionError branch, UTL:262-263 */
@@ -448,7 +450,13 @@ static int collision_point_impl(const double* pc, const double* ps, double a0x, 
         double y2 = ((double)x2 * gradient) + b;
         v2 hit[4];
         int cnt = ring_segment(pc, ps, ox, oy, radius, a0x, a0y, (double)x2, y2, hit, 4);
-        if (cnt == 0) continue;     /* 'LINESTRING EMPTY' -> keep scanning x2 */
+        if (cnt == 0) {
+            /* GEOS >= 3.9: str(i) == 'LINESTRING EMPTY' -> else branch, keep scanning x2 (UTL:290-291).
+             * GEOS <= 3.8 (geos_untyped_empty): 'GEOMETRYCOLLECTION EMPTY' != the literal -> try: i.geoms[0] raises
+             * IndexError -> dist_to_cp = None; break (UTL:279-289): the FIRST candidate that misses ends the search */
+            if (untyped_empty) return 0;
+            continue;
+        }
         if (cnt == 1) return 0;     /* Point has no .geoms -> except -> None, break */
         double d1 = hypot(a0x - hit[0].x, a0y - hit[0].y);
         double d2 = hypot(a0x - hit[1].x, a0y - hit[1].y);
@@ -463,7 +471,39 @@ int cno_collision_point(double a0x, double a0y, double a1x, double a1y, double o
 {
     double pc[64], ps[64];
     poly_tables(pc, ps);
-    return collision_point_impl(pc, ps, a0x, a0y, a1x, a1y, ox, oy, radius, dist);
+    return collision_point_impl(pc, ps, a0x, a0y, a1x, a1y, ox, oy, radius, dist, 0);
+}
+
+int cno_collision_point_geos(double a0x, double a0y, double a1x, double a1y, double ox, double oy, double radius,
+                             int untyped_empty, double* dist)
+{
+    double pc[64], ps[64];
+    poly_tables(pc, ps);
+    return collision_point_impl(pc, ps, a0x, a0y, a1x, a1y, ox, oy, radius, dist, untyped_empty);
+}
+
+/* UTL:317-323 compute_collision_prob(time_to_collision): min(1, 0.15 / ttc) -- negative for a negative ttc */
+double cno_collision_prob(double ttc) { return fmin(1.0, 0.15 / ttc); }
+/* UTL:326-345 compute_general_collision_prob(scan, max_range, min_range) */
+double cno_general_collision_prob(double d, double max_range, double min_range)
+{
+    return (d > max_range) ? 0.0 : (max_range - d) / (max_range - min_range);
+}
+/* ENV:882-883: sorted(entries, key=cp, reverse=True)[-K:] -- stable, descending, keep the LAST K (the K lowest CPs).
+ * idx_out[0..kept) = indices in output order; returns kept */
+int cno_topk(const double* cp, int n, int K, int32_t* idx_out)
+{
+    int idx[CNO_MAX_TRACKS];
+    if (n > CNO_MAX_TRACKS) n = CNO_MAX_TRACKS;
+    for (int i = 0; i < n; ++i) idx[i] = i;
+    for (int i = 1; i < n; ++i) { /* stable insertion sort, descending */
+        int q = idx[i]; int j = i - 1;
+        while (j >= 0 && cp[idx[j]] < cp[q]) { idx[j + 1] = idx[j]; --j; }
+        idx[j + 1] = q;
+    }
+    int first = n > K ? n - K : 0, kk = 0;
+    for (int i = first; i < n; ++i) idx_out[kk++] = idx[i];
+    return kk;
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -483,8 +523,11 @@ static double heading_to_goal(const cno_config* c, const env_t* e, double px, do
 
 static double dist3(double ax, double ay, double bx, double by)
 {
-    double dx = ax - bx, dy = ay - by, dz = 0.0;
-    return sqrt(dx * dx + dy * dy + dz * dz); /* np.linalg.norm of a 3-vector, ENV:191-197 */
+    /* np.linalg.norm(a - b) of a 3-vector (ENV:191-197) = sqrt(dot(d, d)), and numpy hands the dot to BLAS ddot, whose
+     * kernel accumulates with fused multiply-adds: acc = dx*dx; acc = fma(dy, dy, acc); acc = fma(dz, dz, acc) with dz = 0.
+     * Pinned by the function goldens hd_* / dist_out (256 of 256 values; the unfused sum matches 237). */
+    double dx = ax - bx, dy = ay - by;
+    return sqrt(fma(dy, dy, dx * dx));
 }
 
 static void waypoint_refresh(const cno_sim* s, env_t* e, double px, double py)
@@ -801,21 +844,21 @@ static void env_get_state(const cno_sim* s, env_t* e, const double* ranges, doub
             track_t* t = &e->tracks[i];
             double dcp;
             int has = collision_point_impl(s->poly_c, s->poly_s, e->agent_dq[0].x, e->agent_dq[0].y, vo_x, vo_y,
-                                           t->pose.x, t->pose.y, 0.178, &dcp);
+                                           t->pose.x, t->pose.y, 0.178, &dcp, c->geos_untyped_empty);
             double rv = agent_vel - obstacle_vel;
-            double gcp = (t->dist > c->max_scan_range) ? 0.0
-                        : (c->max_scan_range - t->dist) / (c->max_scan_range - c->min_scan_range);
+            double gcp = cno_general_collision_prob(t->dist, c->max_scan_range, c->min_scan_range);
             double ego, cpv;
             if (has) {
                 if (rv == 0) { cpv = 1.0 * gcp; ego = ego_prev; }
                 else {
                     double ttc = dcp / rv;
                     if (ttc == 0.0) { e->status |= ST_TTC_ZERO; ego = 1.0; } /* Python raises; measure-zero */
-                    else ego = fmin(1.0, 0.15 / ttc); /* UTL:319 min(1, 0.15/ttc); may be negative */
+                    else ego = cno_collision_prob(ttc); /* UTL:319 min(1, 0.15/ttc); may be negative */
                     cpv = 0.5 * ego + 0.5 * gcp;
                 }
             } else { ego = 0.0; cpv = 0.5 * 0.0 + 0.5 * gcp; }
             ego_prev = ego;
+            e->entry_cp[ne] = cpv; e->entry_ego[ne] = ego;
             cp[ne] = cpv;
             if (ne == 0 || ego > ego_max) ego_max = ego;
             ++ne;
@@ -825,21 +868,14 @@ static void env_get_state(const cno_sim* s, env_t* e, const double* ranges, doub
             e->collision_prob = 0.0; e->ego_score_cp = 0.0;
         } else { /* ENV:878-905 */
             e->ego_score_cp = ego_max;
-            int idx[CNO_MAX_TRACKS];
-            for (int i = 0; i < ne; ++i) idx[i] = i;
-            for (int i = 1; i < ne; ++i) { /* stable, descending (sorted(..., reverse=True)) */
-                int q = idx[i]; int j = i - 1;
-                while (j >= 0 && cp[idx[j]] < cp[q]) { idx[j + 1] = idx[j]; --j; }
-                idx[j + 1] = q;
-            }
-            int first = ne > K ? ne - K : 0; /* [-K:] keeps the K lowest when ne > K */
-            e->collision_prob = cp[idx[first]];
-            int kk = 0;
-            for (int i = first; i < ne; ++i, ++kk) {
-                track_t* t = &e->tracks[idx[i]];
+            int32_t keep[CNO_MAX_TRACKS];
+            int kept = cno_topk(cp, ne, K, keep);   /* [-K:] keeps the K lowest when ne > K */
+            e->collision_prob = cp[keep[0]];
+            for (int kk = 0; kk < kept; ++kk) {
+                track_t* t = &e->tracks[keep[kk]];
                 feat[4 * kk] = t->pose.x; feat[4 * kk + 1] = t->pose.y;
                 feat[4 * kk + 2] = t->vel.x; feat[4 * kk + 3] = t->vel.y;
-                topk_idx[kk] = idx[i];
+                topk_idx[kk] = keep[kk];
             }
         }
         /* ENV:990-996 */
@@ -1243,6 +1279,7 @@ int cno_get_debug(const cno_sim* s, int env, cno_debug* o)
     o->n_confirmed = e->n_confirmed; o->n_tracks = e->ntracks; o->n_entries = e->n_entries; o->status = e->status;
     o->bb = e->bb; o->collision_prob = e->collision_prob; o->ego_score = e->ego_score_cp;
     o->wpx = e->wpx; o->wpy = e->wpy;
+    for (int i = 0; i < e->n_entries && i < CNO_MAX_TRACKS; ++i) { o->entry_cp[i] = e->entry_cp[i]; o->entry_ego[i] = e->entry_ego[i]; }
     for (int i = 0; i < e->ntracks; ++i) {
         const track_t* t = &e->tracks[i];
         o->track_pose[i][0] = t->pose.x; o->track_pose[i][1] = t->pose.y;
@@ -1298,6 +1335,28 @@ int cno_ext_call(cno_sim* s, int env, const cno_ext_in* in, const double* ranges
 }
 
 void cno_ext_set_done(cno_sim* s, int env, int done) { s->envs[env].done = done; }
+
+/* function-level entry points on a handle (golden vectors of ENV:191-237, 1046-1162, 1285-1319) */
+double cno_heading_to_goal(cno_sim* s, int env, double wpx, double wpy, double px, double py, double yaw)
+{
+    env_t* e = &s->envs[env];
+    e->wpx = wpx; e->wpy = wpy;
+    return heading_to_goal(&s->cfg, e, px, py, yaw);
+}
+double cno_distance_to_goal(double px, double py, double wpx, double wpy) { return dist3(px, py, wpx, wpy); }
+int cno_in_box(double x, double y, double gx, double gy, double eps) { return in_box(x, y, gx, gy, eps); }
+/* Env.compute_reward(state, step_counter, done) with previous_heading / previous_distance / way-point preset */
+double cno_compute_reward(cno_sim* s, int env, double cur_head, double cur_dist, double prev_head, double prev_dist,
+                          double wpx, double wpy, double px, double py, int done)
+{
+    env_t* e = &s->envs[env];
+    double* st = (double*)calloc((size_t)s->D, sizeof(double));
+    st[s->n] = cur_head; st[s->n + 1] = cur_dist;
+    e->prev_head = prev_head; e->prev_dist = prev_dist; e->wpx = wpx; e->wpy = wpy;
+    double r = env_compute_reward(s, e, st, px, py, done);
+    free(st);
+    return r;
+}
 
 /* ------------------------------------------------------------------------------------------
  * Simulator-only entry points for oracle/harness (which plays Gazebo for the reference's Python)

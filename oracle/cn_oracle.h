@@ -80,6 +80,8 @@ typedef struct cno_debug {
     double track_vel[CNO_MAX_TRACKS][2];
     double track_t[CNO_MAX_TRACKS];
     int32_t track_dqlen[CNO_MAX_TRACKS];
+    double entry_cp[CNO_MAX_TRACKS];    /* CP of every entry before the top-K cut (ENV:818-860), n_entries of them */
+    double entry_ego[CNO_MAX_TRACKS];   /* ... and its ego score min(1, 0.15 / ttc) (negative for a negative ttc) */
 } cno_debug;
 
 int  cno_create(const cno_config* cfg, cno_sim** out);
@@ -128,7 +130,17 @@ void   cno_scan_to_points(const double* scan, int R, double px, double py, doubl
 int    cno_waypoint(double ax, double ay, double gx, double gy, double radius, double* wp);
 int    cno_collision_point(double a0x, double a0y, double a1x, double a1y,
                            double ox, double oy, double radius, double* dist);
+int    cno_collision_point_geos(double a0x, double a0y, double a1x, double a1y, double ox, double oy, double radius,
+                                int untyped_empty, double* dist);
 double cno_iou(double ax, double ay, double bx, double by, double half);
+double cno_collision_prob(double ttc);
+double cno_general_collision_prob(double d, double max_range, double min_range);
+int    cno_topk(const double* cp, int n, int K, int32_t* idx_out);
+double cno_heading_to_goal(cno_sim* s, int env, double wpx, double wpy, double px, double py, double yaw);
+double cno_distance_to_goal(double px, double py, double wpx, double wpy);
+int    cno_in_box(double x, double y, double gx, double gy, double eps);
+double cno_compute_reward(cno_sim* s, int env, double cur_head, double cur_dist, double prev_head, double prev_dist,
+                          double wpx, double wpy, double px, double py, int done);
 double cno_bbox_size(const double* pts, int n);
 int    cno_estimate_num_obs_scans(double d, double max_range, double min_range);
 void   cno_raycast(const cno_config* cfg, double rx, double ry, double ryaw,

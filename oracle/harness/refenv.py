@@ -188,6 +188,8 @@ class Harness(object):
         if params:
             self.params.update(params)
         self._install()
+        from . import shapely_shim
+        shapely_shim.UNTYPED_EMPTY = bool(getattr(c, "geos_untyped_empty", 0))    # cn_config.geos_untyped_empty
         self.utils = _load_py2("utils", os.path.join(REF_SRC, "utils.py"), {})
         self.envmod = _load_py2(self.ENV_MODULE, os.path.join(REF_SRC, self.ENV_MODULE + ".py"), {})
         for m in (self.utils, self.envmod):

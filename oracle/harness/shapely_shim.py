@@ -6,8 +6,9 @@ the reference tree, so this shim IS the definition of their behaviour for the or
 
   * Point(x, y).buffer(r).boundary  -> regular 64-gon ring (GEOS default 16 segments/quadrant),
     vertex k at (x + r*cos(-k*pi/32), y + r*sin(-k*pi/32))
-  * ring.intersection(LineString([a, b])) -> EMPTY / POINT / MULTIPOINT with GEOS >= 3.9 typed
-    empties (str() == 'LINESTRING EMPTY', the literal utils.py:279,306 compare against)
+  * ring.intersection(LineString([a, b])) -> EMPTY / POINT / MULTIPOINT; the empty result prints as
+    'LINESTRING EMPTY' (GEOS >= 3.9 typed empties, the literal utils.py:279,306 compare against) or, with
+    UNTYPED_EMPTY set, as 'GEOMETRYCOLLECTION EMPTY' (GEOS <= 3.8, the reference's Python-2.7 platform)
   * Polygon(4 corners): intersection/union areas for axis-aligned boxes (utils.py:440-443,
     455-458) and contains() (utils.py:197-209, dead code in the reference)
 
@@ -44,11 +45,18 @@ class _Disc(object):
         self.boundary = _Ring(cx, cy, r)
 
 
+# GEOS version switch (cn_config.geos_untyped_empty).  False: GEOS >= 3.9 typed empties -- an empty ring/line intersection
+# prints as 'LINESTRING EMPTY', the literal utils.py:279,306 compare against.  True: GEOS <= 3.8 (what shapely <= 1.7, the last
+# Python-2.7 release, links): the empty result is an untyped collection and prints as 'GEOMETRYCOLLECTION EMPTY'; its .geoms is
+# empty, so utils.py:281 `i.geoms[0]` raises IndexError and utils.py:308 `i.x` raises AttributeError.
+UNTYPED_EMPTY = False
+
+
 class _Empty(object):
     geoms = []
 
     def __str__(self):
-        return "LINESTRING EMPTY"
+        return "GEOMETRYCOLLECTION EMPTY" if UNTYPED_EMPTY else "LINESTRING EMPTY"
 
 
 class _MultiPoint(object):

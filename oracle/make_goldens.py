@@ -30,6 +30,9 @@ SEQ_CONFIGS = {
     "eval60": (dict(n_peds=60, max_steps=80, seed=13, min_scan_range=0.0, goal_x=-1.0, goal_y=1.0), 2,
                (0.05, 0.22, -1.0, 1.0)),
     "k4": (dict(n_peds=40, max_steps=100, seed=14, k_obstacles=4), 3, (0.0, 0.22, -2.0, 2.0)),
+    # the reference under GEOS <= 3.8 empty-result semantics (cn_config.geos_untyped_empty; shapely_shim.UNTYPED_EMPTY):
+    # get_collision_point gives up at the first candidate segment that misses (UTL:279-289)
+    "geos38": (dict(n_peds=60, max_steps=120, seed=15, geos_untyped_empty=1), 3, (0.0, 0.22, -2.0, 2.0)),
 }
 
 
@@ -177,6 +180,19 @@ def gen_func():
                                   [float(ob[i, 0]), float(ob[i, 1])], 0.178)
         out.append(np.nan if d is None else d)
     g["cp_a0"], g["cp_a1"], g["cp_ob"], g["cp_out"] = a0, a1, ob, np.array(out)
+    # ... and under GEOS <= 3.8 empty-result semantics (geos_untyped_empty): None at the first candidate that misses
+    from oracle.harness import shapely_shim
+    shapely_shim.UNTYPED_EMPTY = True
+    out = []
+    for i in range(n):
+        d = U.get_collision_point([[float(a0[i, 0]), float(a0[i, 1])], [float(a1[i, 0]), float(a1[i, 1])]],
+                                  [float(ob[i, 0]), float(ob[i, 1])], 0.178)
+        out.append(np.nan if d is None else d)
+    g["cp_out_geos38"] = np.array(out)
+    g["wp_out_geos38"] = np.array([U.get_local_goal_waypoints([float(g["wp_agent"][i, 0]), float(g["wp_agent"][i, 1])],
+                                                              [float(g["wp_goal"][i, 0]), float(g["wp_goal"][i, 1])], 0.3)
+                                   for i in range(512)])
+    shapely_shim.UNTYPED_EMPTY = False
     # the survey's spot value
     g["cp_spot"] = np.array([U.get_collision_point([[0, 0.5], [-0.03, 0.5]], [-0.5, 0.5], 0.178)])
     # A16/A20 is_associated / get_iou (UTL:435-460)

@@ -46,6 +46,7 @@ class CnoDebug(C.Structure):
         ("track_pose", C.c_double * 2 * MAX_TRACKS), ("track_dist", C.c_double * MAX_TRACKS),
         ("track_speed", C.c_double * MAX_TRACKS), ("track_vel", C.c_double * 2 * MAX_TRACKS),
         ("track_t", C.c_double * MAX_TRACKS), ("track_dqlen", C.c_int32 * MAX_TRACKS),
+        ("entry_cp", C.c_double * MAX_TRACKS), ("entry_ego", C.c_double * MAX_TRACKS),
     ]
 
 
@@ -112,6 +113,14 @@ def lib():
         L.cno_scan_to_points.argtypes = [dp, C.c_int, C.c_double, C.c_double, C.c_double, dp]
         L.cno_waypoint.argtypes = [C.c_double] * 5 + [dp]
         L.cno_collision_point.argtypes = [C.c_double] * 7 + [dp]
+        L.cno_collision_prob.argtypes = [C.c_double]; L.cno_collision_prob.restype = C.c_double
+        L.cno_general_collision_prob.argtypes = [C.c_double] * 3; L.cno_general_collision_prob.restype = C.c_double
+        L.cno_topk.argtypes = [dp, C.c_int, C.c_int, C.c_void_p]
+        L.cno_heading_to_goal.argtypes = [C.c_void_p, C.c_int] + [C.c_double] * 5; L.cno_heading_to_goal.restype = C.c_double
+        L.cno_distance_to_goal.argtypes = [C.c_double] * 4; L.cno_distance_to_goal.restype = C.c_double
+        L.cno_in_box.argtypes = [C.c_double] * 5
+        L.cno_compute_reward.argtypes = [C.c_void_p, C.c_int] + [C.c_double] * 8 + [C.c_int]; L.cno_compute_reward.restype = C.c_double
+        L.cno_collision_point_geos.argtypes = [C.c_double] * 7 + [C.c_int, dp]
         L.cno_iou.argtypes = [C.c_double] * 5; L.cno_iou.restype = C.c_double
         L.cno_bbox_size.argtypes = [dp, C.c_int]; L.cno_bbox_size.restype = C.c_double
         L.cno_estimate_num_obs_scans.argtypes = [C.c_double] * 3
@@ -215,7 +224,8 @@ class Oracle:
                     collision_prob=d.collision_prob, ego_score=d.ego_score, wp=(d.wpx, d.wpy),
                     track_pose=np.array(d.track_pose)[:n].copy(), track_dist=np.array(d.track_dist)[:n].copy(),
                     track_speed=np.array(d.track_speed)[:n].copy(), track_vel=np.array(d.track_vel)[:n].copy(),
-                    track_t=np.array(d.track_t)[:n].copy(), track_dqlen=np.array(d.track_dqlen)[:n].copy())
+                    track_t=np.array(d.track_t)[:n].copy(), track_dqlen=np.array(d.track_dqlen)[:n].copy(),
+                    entry_cp=np.array(d.entry_cp)[:d.n_entries].copy(), entry_ego=np.array(d.entry_ego)[:d.n_entries].copy())
 
     # ---- harness-facing simulator access -------------------------------------------------
     def hsim_reset(self, env=0):

@@ -94,6 +94,66 @@ def test_rollout_parity_other_k(oracle_mod, k):
     _compare_rollout(oracle_mod, steps=60, seed=13 + k, n_envs=16, n_peds=60, max_steps=40, k_obstacles=k)
 
 
+def test_rollout_parity_geos_untyped_empty(oracle_mod):
+    """cn_config.geos_untyped_empty = 1 (shapely <= 1.7 / GEOS <= 3.8, the reference's Python-2.7 platform): a candidate
+    segment that misses ends get_collision_point with None (UTL:279-289).  Dense room so that most tracks are affected."""
+    n_done, frac = _compare_rollout(oracle_mod, steps=100, seed=23, n_envs=64, n_peds=60, max_steps=50, geos_untyped_empty=1)
+    assert frac > 0.999
+    # and the switch is not a no-op: same seed, other setting, different collision probabilities somewhere
+    import torch
+    from crowdnav import Config
+    from crowdnav.env import VecEnv
+    outs = []
+    for flag in (0, 1):
+        env = VecEnv(Config(n_envs=64, n_peds=60, max_steps=50, seed=23, geos_untyped_empty=flag)); env.reset()
+        g = torch.Generator(device="cpu").manual_seed(1); acc = []
+        for t in range(40):
+            a = torch.stack([torch.rand(64, generator=g) * 0.22, torch.rand(64, generator=g) * 4 - 2], 1).cuda()
+            acc.append(env.step(a, auto_reset=True)[0].clone())
+        outs.append(torch.stack(acc))
+    assert not torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("case", ["cp_ties", "negative_ttc"])
+def test_scripted_collision_probability_corner_cases(oracle_mod, case):
+    """UTL:317-345 / ENV:882-883 corner cases provoked on purpose (the random rollouts only meet them by chance):
+    cp_ties      two static obstacles placed symmetrically ahead of the robot -> equal collision probabilities, the
+                 stable `sorted(..., reverse=True)[-K:]` decides the order of the feature rows;
+    negative_ttc a fast obstacle crossing ahead of a slow robot -> relative speed < 0 -> ttc < 0 -> a NEGATIVE ego
+                 score min(1, 0.15 / ttc) enters CP and the social-safety test.
+    GPU vs oracle on every step, and the oracle's per-entry values prove the case occurred."""
+    import torch
+    kw = dict(n_envs=1, n_peds=2, ped_mode=1, room_half=2.4, spawn_x=0.0, spawn_y=0.0, spawn_yaw=0.0, goal_x=2.0, goal_y=0.0,
+              start_x=0.0, start_y=0.0, max_steps=200, min_scan_range=0.0)
+    if case == "cp_ties":
+        init, vel, act = np.array([[[0.35, 0.2], [0.35, -0.2]]]), np.zeros((1, 2, 2)), (0.05, 0.0)
+    else:
+        init, vel, act = np.array([[[0.3, -0.5], [1.5, 1.5]]]), np.array([[[0.0, 0.3], [0.0, 0.0]]]), (0.02, 0.0)
+    torch_, env, orc = _pair(oracle_mod, **kw)
+    for e_ in (env, orc):
+        e_.set_ped_init(init); e_.set_ped_preset_vel(vel)
+    env.reset(); torch.cuda.synchronize()
+    assert np.array_equal(env.obs_f64.cpu().numpy(), orc.reset())
+    hits = 0
+    a = np.array([act], dtype=np.float32)
+    for t in range(60):
+        env.step(torch.from_numpy(a).cuda(), auto_reset=False); torch.cuda.synchronize()
+        oc, rc, dc, ic = orc.step(a.astype(np.float64), auto_reset=False)
+        assert np.array_equal(env.obs_f64.cpu().numpy(), oc), (case, t)
+        assert np.array_equal(env.topk_idx.cpu().numpy(), ic) and np.array_equal(env.done.cpu().numpy(), dc), (case, t)
+        assert float(env.reward[0].item()) == rc[0]
+        d, c = env.debug_env(0), orc.debug(0)
+        assert d["collision_prob"] == c["collision_prob"] and d["ego_score"] == c["ego_score"], (case, t)
+        cp, ego = c["entry_cp"], c["entry_ego"]
+        if case == "cp_ties":
+            hits += len(cp) >= 2 and len(set(cp.tolist())) < len(cp)
+        else:
+            hits += bool((ego < 0).any())
+        if dc[0]:
+            break
+    assert hits >= 5, (case, hits)
+
+
 def test_rollout_parity_scripted_crowd(oracle_mod):
     """ped_mode = 1: constant per-pedestrian velocities (the scripted crossing/towards/ahead crowds) in the
     5 x 5 m evaluation room with the evaluation goal/start (README "Start testing")."""
@@ -130,7 +190,7 @@ def test_rollout_parity_720_rays(oracle_mod):
     _compare_rollout(oracle_mod, steps=30, seed=11, n_envs=8, n_peds=100, n_rays=720, room_half=2.4, max_steps=25)
 
 
-@pytest.mark.parametrize("name", ["train20", "dense100", "eval60", "k4"])
+@pytest.mark.parametrize("name", ["train20", "dense100", "eval60", "k4", "geos38"])
 def test_reproduces_reference_golden_run(name):
     """N=1, driven only by the recorded actions: the HIP path reproduces what the REFERENCE's Python
     returned in the golden run (observations, rewards, done flags)."""
@@ -322,7 +382,7 @@ def test_reference_scenarios_presets(oracle_mod):
     assert open(path).readline().strip().split(",") == st.HEADERS
 
 
-@pytest.mark.parametrize("name", ["train20", "dense100", "eval60", "k4"])
+@pytest.mark.parametrize("name", ["train20", "dense100", "eval60", "k4", "geos38"])
 def test_golden_replay_through_the_kernel(name):
     """The kernel fed with EXACTLY what Gazebo/ROS handed the reference in the golden runs (lidar ranges, odom,
     clock, step counter; cn_observe_external) returns what the REFERENCE's own Python returned: observations,

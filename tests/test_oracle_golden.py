@@ -6,7 +6,7 @@ import pytest
 
 from conftest import load_seq
 
-SEQS = ["train20", "dense100", "eval60", "k4"]
+SEQS = ["train20", "dense100", "eval60", "k4", "geos38"]   # geos38: the reference under GEOS <= 3.8 empty-result semantics
 IN_KEYS = ("deque_x", "deque_y", "end_timestep", "px", "py", "yaw", "v", "w", "now", "step_counter", "is_reset")
 
 
@@ -38,7 +38,7 @@ def test_sequence_replay_bit_exact(oracle_mod, name):
         assert dbg["bb"] == z["bb"][i]
         assert tuple(o.counters()[0][:3]) == tuple(z["counters"][i])
         over_k += n > o.K
-    if name in ("dense100", "eval60", "k4"):
+    if name in ("dense100", "eval60", "k4", "geos38"):
         assert over_k > 0  # the "keep the K lowest" branch of ENV:882-883 is exercised
 
 
@@ -119,6 +119,64 @@ def test_function_level_goldens(oracle_mod):
         assert L.cno_estimate_num_obs_scans(dd, 0.6, 0.12) == int(e1)
         assert L.cno_estimate_num_obs_scans(dd, 0.6, 0.0) == int(e0)
     assert [L.cno_estimate_num_obs_scans(x, 0.6, 0.12) for x in (0.6, 0.36, 0.12)] == [3, 17, 32]
+
+
+def test_function_level_goldens_collision_probability_topk_heading_box_reward(oracle_mod):
+    """The rest of SURVEY 8c C3's function vectors: A23 compute_collision_prob (negative and tiny ttc included) and
+    compute_general_collision_prob, A24 the top-K rule on lists with ties, A7/A8 heading (with the starting_pose offset)
+    and distance, A28 the half-open goal box, A30 the full compute_reward sign table, and A22 get_collision_point
+    under GEOS <= 3.8 empty-result semantics (cn_config.geos_untyped_empty)."""
+    import ctypes as C
+    import os
+    from conftest import GOLDEN
+    L = oracle_mod.lib()
+    g = np.load(os.path.join(GOLDEN, "func.npz"))
+    # A23
+    for t, want in zip(g["cpttc_in"], g["cpttc_out"]):
+        assert L.cno_collision_prob(float(t)) == want
+    assert (g["cpttc_out"] < 0).sum() > 100 and L.cno_collision_prob(-1e-9) == 0.15 / -1e-9      # a negative ttc gives a negative score
+    for d, want in zip(g["gcp_in"], g["gcp_out"]):
+        assert L.cno_general_collision_prob(float(d), 0.6, 0.12) == want
+    # A24: K lowest kept, stable among ties
+    n_ties = 0
+    for row, want in zip(g["topk_cp"], g["topk_idx"]):
+        cp = np.ascontiguousarray(row[~np.isnan(row)])
+        out = np.full(8, -1, dtype=np.int32)
+        kept = L.cno_topk(cp.ctypes.data_as(C.POINTER(C.c_double)), len(cp), 8, out.ctypes.data)
+        assert kept == min(8, len(cp)) and np.array_equal(out, want), (cp, out, want)
+        n_ties += len(set(cp.tolist())) < len(cp)
+    assert n_ties > 50
+    # A7 / A8
+    o = oracle_mod.Oracle(n_envs=1, n_peds=4)
+    for i in range(len(g["hd_pos"])):
+        h = L.cno_heading_to_goal(o.h, 0, *g["hd_wp"][i], *g["hd_pos"][i], g["hd_yaw"][i])
+        assert abs(h - g["hd_out"][i]) <= 1e-15, i
+        assert L.cno_distance_to_goal(*g["hd_pos"][i], *g["hd_wp"][i]) == g["dist_out"][i]
+    # A28
+    for b, want in zip(g["box_in"], g["box_out"]):
+        assert bool(L.cno_in_box(b[0], b[1], -1.0, 1.0, 0.20)) == bool(want)
+    assert g["box_out"].sum() > 0 and not g["box_out"][-4:].all()      # the four corners: half-open on two sides
+    # A30: every sign combination of heading / distance change, done and not done (robot away from goal and way-point)
+    robot = o.sim_state(0)[0]
+    seen = set()
+    for ch, ph, cd, pd, done, want in g["reward_table"]:
+        r = L.cno_compute_reward(o.h, 0, ch, cd, ph, pd, 5.0, 5.0, robot[0], robot[1], int(done))
+        assert r == want, (ch, ph, cd, pd, done, r, want)
+        seen.add(want)
+    assert seen == {-2.0, -1.0, 0.0, -202.0, -201.0, -200.0}
+    # A22 under GEOS <= 3.8: the first candidate that misses ends the search with None
+    n_none = n_diff = 0
+    for i in range(len(g["cp_a0"])):
+        d = C.c_double(0.0)
+        has = L.cno_collision_point_geos(*g["cp_a0"][i], *g["cp_a1"][i], *g["cp_ob"][i], 0.178, 1, C.byref(d))
+        if np.isnan(g["cp_out_geos38"][i]):
+            assert has == 0, i
+            n_none += 1
+        else:
+            assert has == 1 and d.value == g["cp_out_geos38"][i], i
+        n_diff += np.isnan(g["cp_out_geos38"][i]) != np.isnan(g["cp_out"][i])
+    assert n_diff > 100 and n_none < len(g["cp_a0"])          # the switch matters: many typed-empty hits become None
+    assert np.array_equal(g["wp_out"], g["wp_out_geos38"])      # UTL:306-312: both branches flip the goal the same way
 
 
 # ---- obs_layout 1: environment_stage_1_original.py (363 inputs), SURVEY 8f N3 -----------------------------
