@@ -143,7 +143,8 @@ def test_scripted_collision_probability_corner_cases(oracle_mod, case):
         assert np.array_equal(env.topk_idx.cpu().numpy(), ic) and np.array_equal(env.done.cpu().numpy(), dc), (case, t)
         assert float(env.reward[0].item()) == rc[0]
         d, c = env.debug_env(0), orc.debug(0)
-        assert d["collision_prob"] == c["collision_prob"] and d["ego_score"] == c["ego_score"], (case, t)
+        # (device hypot vs libm hypot: the CP scalars may differ in the last bit, as in the golden replay test)
+        assert abs(d["collision_prob"] - c["collision_prob"]) <= 1e-12 and abs(d["ego_score"] - c["ego_score"]) <= 1e-12, (case, t)
         cp, ego = c["entry_cp"], c["entry_ego"]
         if case == "cp_ties":
             hits += len(cp) >= 2 and len(set(cp.tolist())) < len(cp)
