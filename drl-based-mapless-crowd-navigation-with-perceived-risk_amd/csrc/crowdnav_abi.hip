@@ -17,6 +17,8 @@
 extern "C" __global__ void cn_env_kernel(CnKParams p);
 extern "C" __global__ void cn_env_kernel_ext(CnKParams p);
 extern "C" __global__ void cn_env_kernel_same(CnKParams p);
+extern "C" __global__ void cn_env_kernel_gt(CnKParams p);
+extern "C" __global__ void cn_env_kernel_gt_same(CnKParams p);
 extern "C" __global__ void cn_env_kernel_orig(CnKParams p);
 extern "C" __global__ void cn_env_kernel_orig_ext(CnKParams p);
 extern "C" __global__ void cn_env_kernel_orig_same(CnKParams p);
@@ -171,7 +173,8 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
         !(c.risk_mode == CN_RISK_LIDAR_TRACKER || c.risk_mode == CN_RISK_GT))
         return fail(CN_ERR_CONFIG, "cn_create: config out of range");
     if (c.ped_contact) return fail(CN_ERR_CONFIG, "cn_create: ped_contact is not built yet");
-    if (c.risk_mode != CN_RISK_LIDAR_TRACKER) return fail(CN_ERR_CONFIG, "cn_create: risk_mode gt is not built yet");
+    if (c.risk_mode == CN_RISK_GT && c.obs_layout != CN_LAYOUT_RISK)
+        return fail(CN_ERR_CONFIG, "cn_create: risk_mode gt needs the risk observation layout (obs_layout 0)");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         return fail(CN_ERR_NO_DEVICE, "cn_create: no HIP device (libcrowdnav has no CPU fallback)");
@@ -248,6 +251,8 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
         HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
         HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_ext, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
         HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_same, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
+        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_gt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
+        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_gt_same, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
         HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_orig, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
         HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_orig_ext, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
         HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_orig_same, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
@@ -312,6 +317,14 @@ static int launch(cn_handle h, const CnKParams& kp, hipStream_t st)
             hipLaunchKernelGGL(cn_env_kernel_orig_same, dim3(kp.N), dim3(64), h->lds, st, kp);
         else
             hipLaunchKernelGGL(cn_env_kernel_orig, dim3(kp.N), dim3(64), h->lds, st, kp);
+    } else if (h->cfg.risk_mode == CN_RISK_GT) {
+        if (kp.mode == CN_MODE_EXT_STEP || kp.mode == CN_MODE_EXT_RESET)
+            return fail(CN_ERR_CONFIG, "cn_observe_external: risk_mode gt reads the library simulator's pedestrians; "
+                                       "external /scan + /odom only exist in lidar_tracker mode");
+        if (kp.mode == CN_MODE_STEP && kp.auto_reset == 1)
+            hipLaunchKernelGGL(cn_env_kernel_gt_same, dim3(kp.N), dim3(64), h->lds, st, kp);
+        else
+            hipLaunchKernelGGL(cn_env_kernel_gt, dim3(kp.N), dim3(64), h->lds, st, kp);
     } else if (kp.mode == CN_MODE_EXT_STEP || kp.mode == CN_MODE_EXT_RESET)
         hipLaunchKernelGGL(cn_env_kernel_ext, dim3(kp.N), dim3(64), h->lds, st, kp);
     else if (kp.mode == CN_MODE_STEP && kp.auto_reset == 1)   // step + reset of finished envs in the same launch

@@ -535,7 +535,7 @@ __device__ __forceinline__ double bbox_size(KP p, double* stage, int lane, int n
     return sum / (double)n;
 }
 
-template <bool EXT>
+template <bool EXT, bool GT = false>
 __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const Lds& L, int env, int lane, int step_counter,
                         float* obs32, float* fin32, double* obs64, int* done_out, bool have_tg = false, Trig tg = Trig{0.0, 0.0, 0.0, 0.0})
 {
@@ -581,13 +581,13 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
     double lc_n = 0.0, ls_n = 0.0, tS_n = 0.0, tC_n = 0.0;
     if (lane < R) {
         if (!EXT) { lc_n = lidc[lane]; ls_n = lids[lane]; }
-        if (lane >= 1) { tS_n = angs[R - 1 - lane]; tC_n = angc[R - 1 - lane]; }
+        if (!GT && lane >= 1) { tS_n = angs[R - 1 - lane]; tC_n = angc[R - 1 - lane]; }
     }
     for (int k = lane; k < R; k += 64) {
         const double lc = lc_n, ls = ls_n, tS = tS_n, tC = tC_n;
         if (k + 64 < R) {
             if (!EXT) { lc_n = lidc[k + 64]; ls_n = lids[k + 64]; }
-            tS_n = angs[R - 1 - (k + 64)]; tC_n = angc[R - 1 - (k + 64)];
+            if (!GT) { tS_n = angs[R - 1 - (k + 64)]; tC_n = angc[R - 1 - (k + 64)]; }
         }
         const double t = cast_ray<EXT>(p, L, env, k, ox, oy, sy, cy, nnear, wall_x, wall_y, lc, ls);
         if (k >= 1) {
@@ -601,10 +601,12 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
             else sc = r;
             smin = fmin(smin, sc);
             // sin/cos(radians(j * inc) - yaw) by angle addition from a host table of sin/cos(radians(j * inc))
+            if constexpr (!GT) {      // end points feed the segmentation only
             const double sa = fma(tS, cy, -(tC * sy)), ca = fma(tC, cy, tS * sy);
             L.ptx[j] = (int)cn_round_scaled(px + (sc * ca), 1000.0);
             L.pty[j] = (int)cn_round_scaled(py + (sc * sa) * -1.0, 1000.0);
             L.dmil[j] = (unsigned short)(int)cn_round_scaled(sc, 1000.0);
+            }
             double so = cn_np_around3(sc);  // ENV:1042
             o32[j] = (float)so;
             if (f32) f32[j] = (float)so;
@@ -628,6 +630,9 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
     }
 
     CN_T(5);
+    int ego_hit = 0;
+    double* const T = L.trk;      // track / entry table: [CN_TF_COUNT][tcap], shares LDS with the end points
+    if constexpr (!GT) {
     const int W = (n + 63) >> 6;  // 64-ray words; ray i = bit (i & 63) of word (i >> 6)
 #define WORD(id, q) L.w64[(id) * L.wstride + (q)]
 #define BIT(id, i) ((WORD(id, (i) >> 6) >> ((i) & 63)) & 1ull)
@@ -1005,7 +1010,7 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
     CN_SYNC();
 
     // ENV:637-654
-    int n_obst = 0, ego_hit = 0;
+    int n_obst = 0;
     for (int j = lane; j < nconf; j += 64) {
         if (L.cft[j] == TY_O) { n_obst += 1; if (L.cfd[j] < 0.140) ego_hit = 1; }
     }
@@ -1016,7 +1021,6 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
     CN_T(13);
     // ---- ENV:656-743 tracker -----------------------------------------------------------------------
     // The tracker table shares LDS with the end-point arrays (dead from here on): bring it in now.
-    double* T = L.trk;
     if (lane < e.ntracks) {
 #pragma unroll
         for (int f = 0; f < CN_TF_COUNT; ++f) T[f * L.tcap + lane] = L.gtrk[lane * CN_TF_COUNT + f];  // HBM: one 96-byte record per track
@@ -1122,6 +1126,79 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
         }
     }
     CN_SYNC();
+    } else {
+        // ---- risk_mode gt (SURVEY 7 "two risk-feature modes", include/crowdnav.h): rows A21-A24 fed with the simulator's own
+        // pedestrians instead of tracked lidar blobs -- the north star's "K-nearest perceived-risk feature extraction".
+        // An entry = a pedestrian within lidar range of the lidar origin and in line of sight (no other disc cuts the segment
+        // origin -> its nearest surface point), in id order.  lane = pedestrian; the blockers are walked as a bit mask.
+        //   pose = surface point nearest to the ROBOT, rounded like a scan end point; dist = |c - p| - r, rounded
+        //   vel  = -(true velocity) (ENV:806-811 subtract new from old); speed = |true velocity|; slot T holds the pedestrian id
+        const int P_ = p->P;
+        const double r_ = p->ped_radius, lim_ = p->lidar_max + r_, lim2_ = lim_ * lim_;
+        int nt_ = 0;
+        u64 hitm = 0ull;
+        for (int i0 = 0; i0 < P_; i0 += 64) {
+            const int i = i0 + lane;
+            bool inr = false, seg = false, blocked = false;
+            double cx = 0.0, cyy = 0.0, wx = 0.0, wy = 0.0, len2 = 0.0;
+            if (i < P_) {
+                cx = L.ped[2 * i]; cyy = L.ped[2 * i + 1];
+                const double ocx = cx - ox, ocy = cyy - oy;
+                const double dd2 = fma(ocx, ocx, ocy * ocy);
+                inr = dd2 <= lim2_;
+                if (inr) {
+                    const double dd = sqrt(dd2);
+                    if (dd > r_) {                            // (origin inside the disc: nothing can stand in front of it)
+                        seg = true;
+                        const double k_ = (dd - r_) / dd;     // origin -> nearest surface point = k_ * oc
+                        wx = k_ * ocx; wy = k_ * ocy;
+                        len2 = fma(wx, wx, wy * wy);
+                    }
+                }
+            }
+            for (int j0 = 0; j0 < P_; j0 += 64) {
+                const int jl = j0 + lane;
+                bool jin = false;
+                if (jl < P_) { const double qx = L.ped[2 * jl] - ox, qy = L.ped[2 * jl + 1] - oy; jin = fma(qx, qx, qy * qy) <= lim2_; }
+                u64 jm = __ballot(jin);
+                while (jm) {
+                    const int j = j0 + __builtin_ctzll(jm);
+                    jm &= jm - 1ull;
+                    const double qx = L.ped[2 * j] - ox, qy = L.ped[2 * j + 1] - oy;
+                    if (seg && j != i) {
+                        double tau = (len2 > 0.0) ? fma(qx, wx, qy * wy) / len2 : 0.0;
+                        tau = fmin(fmax(tau, 0.0), 1.0);
+                        const double ex = fma(tau, wx, -qx), ey = fma(tau, wy, -qy);
+                        if (fma(ex, ex, ey * ey) < r_ * r_) blocked = true;
+                    }
+                }
+            }
+            const bool vis = inr && !blocked;
+            const u64 vm = __ballot(vis);
+            const int slot = nt_ + __popcll(vm & ((1ull << lane) - 1ull));
+            bool close_ = false;
+            if (vis && slot < L.tcap) {
+                const double dx = cx - px, dy = cyy - py;
+                const double dp = sqrt(fma(dx, dx, dy * dy));
+                double sx_ = cx, sy_ = cyy;
+                if (dp > 0.0) { sx_ = cx - r_ * (dx / dp); sy_ = cyy - r_ * (dy / dp); }
+                const double dist = cn_py_round3(dp - r_);
+                const double vx = L.pedv[2 * i], vy = L.pedv[2 * i + 1];
+                TRK(CN_TF_PX, slot) = cn_py_round3(sx_); TRK(CN_TF_PY, slot) = cn_py_round3(sy_); TRK(CN_TF_DIST, slot) = dist;
+                TRK(CN_TF_D0X, slot) = 0.0; TRK(CN_TF_D0Y, slot) = 0.0; TRK(CN_TF_D1X, slot) = 0.0; TRK(CN_TF_D1Y, slot) = 0.0;
+                TRK(CN_TF_T, slot) = (double)i; TRK(CN_TF_SPEED, slot) = sqrt(fma(vx, vx, vy * vy));
+                TRK(CN_TF_VX, slot) = -vx; TRK(CN_TF_VY, slot) = -vy; TRK(CN_TF_DQLEN, slot) = 0.0;
+                close_ = dist < 0.140;
+            }
+            hitm |= __ballot(close_);
+            nt_ += __popcll(vm);
+        }
+        if (nt_ > L.tcap) { e.status |= CN_ST_TRACK_OVERFLOW; nt_ = L.tcap; }
+        e.ntracks = nt_; e.nconf = nt_;
+        if (nt_ > 0) e.obst_steps += 1;
+        ego_hit = hitm != 0ull;
+        CN_SYNC();
+    }
     CN_T(14);
     // ENV:745-760 speed of the tracks matched in this call
     if (lane < e.ntracks && TRK(CN_TF_DQLEN, lane) > 1.5) {
@@ -1149,7 +1226,7 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
         double agent_vel = sqrt(vx_ * vx_ + vy_ * vy_);
         double obstacle_vel = (nt == 0) ? 0.0 : TRK(CN_TF_SPEED, 0);  // ENV:787-793
         // ENV:800-815: per-track velocity; the relative-motion end point of the LAST track survives
-        if (lane < nt && TRK(CN_TF_DQLEN, lane) > 1.5) {
+        if (!GT && lane < nt && TRK(CN_TF_DQLEN, lane) > 1.5) {
             double chx = TRK(CN_TF_D0X, lane) - TRK(CN_TF_D1X, lane), chy = TRK(CN_TF_D0Y, lane) - TRK(CN_TF_D1Y, lane);
             TRK(CN_TF_VX, lane) = chx / ts; TRK(CN_TF_VY, lane) = chy / ts;
         }
@@ -1157,7 +1234,8 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
         if (nt > 0) {
             int l = nt - 1;
             double chx = 0.0, chy = 0.0;
-            if (TRK(CN_TF_DQLEN, l) > 1.5) { chx = TRK(CN_TF_D0X, l) - TRK(CN_TF_D1X, l); chy = TRK(CN_TF_D0Y, l) - TRK(CN_TF_D1Y, l); }
+            if (GT) { chx = TRK(CN_TF_VX, l) * ts; chy = TRK(CN_TF_VY, l) * ts; }   // displacement over the agent's timestep, old - new
+            else if (TRK(CN_TF_DQLEN, l) > 1.5) { chx = TRK(CN_TF_D0X, l) - TRK(CN_TF_D1X, l); chy = TRK(CN_TF_D0Y, l) - TRK(CN_TF_D1Y, l); }
             vo_x = e.dq1x + chx; vo_y = e.dq1y + chy;
         }
         CN_SYNC();
@@ -1280,7 +1358,7 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
                     int kk = rank - first;
                     L.tail[7 + 4 * kk + 0] = TRK(CN_TF_PX, lane); L.tail[7 + 4 * kk + 1] = TRK(CN_TF_PY, lane);
                     L.tail[7 + 4 * kk + 2] = TRK(CN_TF_VX, lane); L.tail[7 + 4 * kk + 3] = TRK(CN_TF_VY, lane);
-                    L.kidx[kk] = lane;
+                    L.kidx[kk] = GT ? (int)TRK(CN_TF_T, lane) : lane;     // gt: pedestrian id
                 }
             }
             unsigned long long mf = __ballot(rank == first);
@@ -1288,7 +1366,7 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
         }
         // ENV:990-996
         e.dq0x = e.dq1x; e.dq0y = e.dq1y; e.dq_len = 1;
-        if (lane < nt) TRK(CN_TF_T, lane) = now;
+        if (!GT && lane < nt) TRK(CN_TF_T, lane) = now;
     }
 #undef TRK
     CN_T(16);
@@ -1362,7 +1440,7 @@ __device__ __forceinline__ double compute_reward(KP p, const Poly& pg, EnvRegs& 
 
 }  // namespace
 
-template <bool EXT, bool TWO, int LAYOUT>
+template <bool EXT, bool TWO, int LAYOUT, bool GT = false>
 __device__ __forceinline__ void env_kernel_body()
 {
     KP p = (KP)__builtin_amdgcn_kernarg_segment_ptr();
@@ -1523,7 +1601,7 @@ __device__ __forceinline__ void env_kernel_body()
         CN_SYNC();
         if (ph_obs) {
             if constexpr (LAYOUT == 1) observe_original<EXT>(p, e, L, env, lane, sc, p->obs, fin, p->obs_f64, &done);
-            else observe<EXT>(p, pg, e, L, env, lane, sc, p->obs, fin, p->obs_f64, &done, have_trig, trig);
+            else observe<EXT, GT>(p, pg, e, L, env, lane, sc, p->obs, fin, p->obs_f64, &done, have_trig, trig);
         } else if constexpr (EXT) {
             // Env.compute_reward(state, step_counter, done) on its own (ENV:1046): heading and distance are state[n], state[n+1]
             // (LAYOUT 1: state[-2], state[-1] are what ORIG:324-330 reads), `done` is the caller's
@@ -1615,7 +1693,7 @@ __device__ __forceinline__ void env_kernel_body()
             observe_original<EXT>(p, e, L, env, lane, sc, p->obs, ext ? nullptr : p->final_obs, p->obs_f64, &done);
             r = compute_reward_original(p, e, L, done);
         } else {
-            observe<EXT>(p, pg, e, L, env, lane, sc, p->obs, ext ? nullptr : p->final_obs, p->obs_f64, &done);
+            observe<EXT, GT>(p, pg, e, L, env, lane, sc, p->obs, ext ? nullptr : p->final_obs, p->obs_f64, &done);
             r = compute_reward(p, pg, e, L, lane, done);
         }
         e.ep_ret += r;
@@ -1659,7 +1737,7 @@ __device__ __forceinline__ void env_kernel_body()
         e.prev_dist = dist3(e.rx, e.ry, e.wpx, e.wpy);        // ENV:1243 (unrounded)
         e.prev_head = heading_to_goal(p, e, e.rx, e.ry, e.ryaw);  // ENV:1244
         CN_SYNC();
-        observe<EXT>(p, pg, e, L, env, lane, 0, p->obs, nullptr, p->obs_f64, &d2);
+        observe<EXT, GT>(p, pg, e, L, env, lane, 0, p->obs, nullptr, p->obs_f64, &d2);
         }
         e.social_viol = 0; e.ego_viol = 0; e.obst_steps = 0;  // ENV:1260-1262
         if (!ext) {
@@ -1705,6 +1783,9 @@ __device__ __forceinline__ void env_kernel_body()
 extern "C" __global__ void CN_HOT_BOUNDS cn_env_kernel(CnKParams p) { env_kernel_body<false, false, 0>(); }
 extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_same(CnKParams p) { env_kernel_body<false, true, 0>(); }
 extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_ext(CnKParams p) { env_kernel_body<true, false, 0>(); }
+// risk_mode gt: the perceived-risk features from the simulator's own pedestrians (no segmentation, no tracker)
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_gt(CnKParams p) { env_kernel_body<false, false, 0, true>(); }
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_gt_same(CnKParams p) { env_kernel_body<false, true, 0, true>(); }
 // obs_layout 1 (environment_stage_1_original.py): same physics and lidar, no tracker
 extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_orig(CnKParams p) { env_kernel_body<false, false, 1>(); }
 extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_orig_same(CnKParams p) { env_kernel_body<false, true, 1>(); }

@@ -44,6 +44,7 @@ typedef struct {
     double t;     /* time stamp, or a duration after a match (ENV:710) */
     double speed; /* -1 until matched (ENV:667) */
     v2 vel;
+    int id;       /* risk_mode gt: the pedestrian this entry is */
 } track_t;
 
 typedef struct {
@@ -609,6 +610,10 @@ static void env_get_state(const cno_sim* s, env_t* e, const double* ranges, doub
     }
     /* ENV:297-305 is dead code (result unused) -> omitted */
 
+    cobj_t* conf = NULL;
+    int nconf = 0, gt_ego_hit = 0;
+    const int gt = (c->risk_mode == 1);
+    if (!gt) {
     /* ENV:317-327 */
     for (int i = 0; i < n; ++i) d[i] = cno_py_round(scan[i], 3);
 
@@ -717,8 +722,8 @@ static void env_get_state(const cno_sim* s, env_t* e, const double* ranges, doub
     }
     /* ENV:568-620 confirmation */
     int maxc = n / 4 + 2;
-    cobj_t* conf = (cobj_t*)malloc(sizeof(cobj_t) * (size_t)maxc);
-    int nconf = 0;
+    conf = (cobj_t*)malloc(sizeof(cobj_t) * (size_t)maxc);
+    nconf = 0;
     {
         int k0 = 0;
         while (k0 < n) {
@@ -803,6 +808,60 @@ static void env_get_state(const cno_sim* s, env_t* e, const double* ranges, doub
                 if (!checked[j] && conf[j].type == TY_O) track_new(e, &conf[j], now);
         }
     }
+    } else {
+        /* risk_mode gt ("two risk-feature modes"; include/crowdnav.h): rows A21-A24 fed with the simulator's own
+         * pedestrians instead of tracked lidar blobs.  An entry = a pedestrian that is within lidar range of the lidar origin
+         * and in line of sight (no other disc cuts the segment origin -> its nearest surface point), in id order:
+         *   pose  = the surface point nearest to the ROBOT (A18's "surface point" convention: end points are laid out from
+         *           the robot position), rounded to 3 decimals like a scan end point;  dist = |c - p| - r, rounded
+         *   vel   = -(true velocity): ENV:806-811 subtract new from old, so the reference's feature is the negated velocity
+         *   speed = |true velocity| (ENV:787-793 uses the FIRST entry's for every obstacle)
+         * then the reference's collision cone, CP and top-K arithmetic unchanged; topk_idx = pedestrian ids. */
+        const int P = c->n_peds;
+        const double r = c->ped_radius;
+        double sy_, cy_;
+        cno_det_sincos(yaw, &sy_, &cy_);
+        const double ox = fma(c->lidar_offset_x, cy_, px), oy = fma(c->lidar_offset_x, sy_, py);
+        const double lim = c->lidar_max + r;
+        e->ntracks = 0;
+        for (int i = 0; i < P; ++i) {
+            const double cx = e->ped_p[2 * i], cyy = e->ped_p[2 * i + 1];
+            const double ocx = cx - ox, ocy = cyy - oy;
+            const double dd2 = fma(ocx, ocx, ocy * ocy);
+            if (!(dd2 <= lim * lim)) continue;                       /* out of lidar range */
+            const double dd = sqrt(dd2);
+            int blocked = 0;
+            if (dd > r) {                                            /* (origin inside the disc: nothing can be in front of it) */
+                const double k_ = (dd - r) / dd;                     /* origin -> nearest surface point = k_ * oc */
+                const double wx = k_ * ocx, wy = k_ * ocy;
+                const double len2 = fma(wx, wx, wy * wy);
+                for (int j = 0; j < P && !blocked; ++j) {
+                    if (j == i) continue;
+                    const double qx = e->ped_p[2 * j] - ox, qy = e->ped_p[2 * j + 1] - oy;
+                    if (!(fma(qx, qx, qy * qy) <= lim * lim)) continue;
+                    double tau = (len2 > 0.0) ? fma(qx, wx, qy * wy) / len2 : 0.0;
+                    tau = fmin(fmax(tau, 0.0), 1.0);
+                    const double ex = fma(tau, wx, -qx), ey = fma(tau, wy, -qy);
+                    if (fma(ex, ex, ey * ey) < r * r) blocked = 1;
+                }
+            }
+            if (blocked) continue;
+            if (e->ntracks >= CNO_MAX_TRACKS) { e->status |= ST_TRACK_OVERFLOW; break; }
+            const double dx = cx - px, dy = cyy - py;
+            const double dp = sqrt(fma(dx, dx, dy * dy));
+            track_t* t = &e->tracks[e->ntracks++];
+            if (dp > 0.0) { t->pose.x = cno_py_round(cx - r * (dx / dp), 3); t->pose.y = cno_py_round(cyy - r * (dy / dp), 3); }
+            else { t->pose.x = cno_py_round(cx, 3); t->pose.y = cno_py_round(cyy, 3); }
+            t->dist = cno_py_round(dp - r, 3);
+            const double vx = e->ped_v[2 * i], vy = e->ped_v[2 * i + 1];
+            t->vel.x = -vx; t->vel.y = -vy;
+            t->speed = sqrt(fma(vx, vx, vy * vy));
+            t->dq_len = 0; t->t = now; t->id = i;
+            if (t->dist < 0.140) gt_ego_hit = 1;
+        }
+        e->n_confirmed = e->ntracks;
+        if (e->ntracks > 0) e->obst_steps += 1;
+    }
     /* ENV:745-760 speed of matched tracks */
     for (int i = 0; i < e->ntracks; ++i) {
         track_t* t = &e->tracks[i];
@@ -831,7 +890,8 @@ static void env_get_state(const cno_sim* s, env_t* e, const double* ranges, doub
         for (int i = 0; i < e->ntracks; ++i) { /* ENV:800-815: the last track's value survives */
             track_t* t = &e->tracks[i];
             double chx = 0, chy = 0;
-            if (t->dq_len > 1) {
+            if (gt) { chx = t->vel.x * ts; chy = t->vel.y * ts; }       /* displacement over the agent's timestep, old - new */
+            else if (t->dq_len > 1) {
                 chx = t->dq[0].x - t->dq[1].x; chy = t->dq[0].y - t->dq[1].y;
                 t->vel.x = chx / ts; t->vel.y = chy / ts;
             }
@@ -875,7 +935,7 @@ static void env_get_state(const cno_sim* s, env_t* e, const double* ranges, doub
                 track_t* t = &e->tracks[keep[kk]];
                 feat[4 * kk] = t->pose.x; feat[4 * kk + 1] = t->pose.y;
                 feat[4 * kk + 2] = t->vel.x; feat[4 * kk + 3] = t->vel.y;
-                topk_idx[kk] = keep[kk];
+                topk_idx[kk] = gt ? t->id : keep[kk];
             }
         }
         /* ENV:990-996 */
@@ -885,6 +945,7 @@ static void env_get_state(const cno_sim* s, env_t* e, const double* ranges, doub
     /* ENV:998-1005 safety counters */
     for (int j = 0; j < nconf; ++j)
         if (conf[j].type == TY_O && conf[j].dist < 0.140) { e->ego_viol += 1; break; }
+    if (gt && gt_ego_hit) e->ego_viol += 1;
     if (e->ego_score_cp > 0.4) e->social_viol += 1;
 
     /* ENV:1011-1023 done */

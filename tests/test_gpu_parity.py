@@ -94,6 +94,48 @@ def test_rollout_parity_other_k(oracle_mod, k):
     _compare_rollout(oracle_mod, steps=60, seed=13 + k, n_envs=16, n_peds=60, max_steps=40, k_obstacles=k)
 
 
+@pytest.mark.parametrize("mode", [True, "next"])
+def test_rollout_parity_gt_risk_mode(oracle_mod, mode):
+    """risk_mode = gt (row X1: the north star's "K-nearest perceived-risk feature extraction" on simulator pedestrians):
+    cn_env_kernel_gt / _gt_same against the oracle's restatement -- observation, reward, done, pedestrian-id indices."""
+    n_done, frac = _compare_rollout(oracle_mod, steps=150, seed=31, reset_mode=mode, n_envs=64, n_peds=20, max_steps=60, risk_mode=1)
+    assert n_done > 20 and frac > 0.999
+
+
+def test_gt_risk_mode_dense_and_semantics(oracle_mod):
+    """gt mode in a crowded room (> K entries: "keep the K lowest" on pedestrian ids) and what the indices mean: every
+    reported index is a pedestrian that is within lidar reach of the robot, rows come with the negated true velocity."""
+    import torch
+    n_done, frac = _compare_rollout(oracle_mod, steps=60, seed=32, n_envs=32, n_peds=100, max_steps=40, risk_mode=1, k_obstacles=4)
+    assert frac > 0.999
+    torch_, env, orc = _pair(oracle_mod, n_envs=16, n_peds=40, max_steps=200, seed=33, risk_mode=1)
+    env.reset(); orc.reset()
+    rng = np.random.default_rng(3)
+    seen = 0
+    for t in range(40):
+        act = np.stack([rng.uniform(0, 0.1, 16), rng.uniform(-1, 1, 16)], 1).astype(np.float32)
+        env.step(torch.from_numpy(act).cuda(), auto_reset=False); torch.cuda.synchronize()
+        oc, rc, dc, ic = orc.step(act.astype(np.float64), auto_reset=False)
+        idx = env.topk_idx.cpu().numpy()
+        assert np.array_equal(idx, ic) and np.array_equal(env.obs_f64.cpu().numpy(), oc)
+        for e_ in range(16):
+            g = env.debug_env(e_)
+            for k, pid in enumerate(idx[e_]):
+                if pid < 0:
+                    continue
+                seen += 1
+                c = g["ped_p"][pid]; d = np.hypot(*(c - g["robot"][:2]))
+                assert d <= 0.6 + 0.0505 + 0.04                        # within lidar reach (origin is 3.2 cm behind the robot centre)
+                row = oc[e_, 366 + 4 * k: 370 + 4 * k]
+                assert np.allclose(row[2:], np.around(-g["ped_v"][pid], 3), atol=1e-12)   # negated true velocity (ENV:806-811)
+                assert np.hypot(row[0] - c[0], row[1] - c[1]) <= 0.0505 + 2e-3          # a point on that pedestrian's surface
+    assert seen > 50
+    # the external-sensor entry point has no pedestrians to look at in this mode
+    import crowdnav
+    with pytest.raises(crowdnav.CrowdNavError):
+        env.observe_external(np.full((16, 360), np.inf), np.zeros((16, 10)), step_counter=[1] * 16)
+
+
 def test_rollout_parity_geos_untyped_empty(oracle_mod):
     """cn_config.geos_untyped_empty = 1 (shapely <= 1.7 / GEOS <= 3.8, the reference's Python-2.7 platform): a candidate
     segment that misses ends get_collision_point with None (UTL:279-289).  Dense room so that most tracks are affected."""

@@ -48,9 +48,10 @@ def groups(cfg, G):
     return (N * STEPS - resets) / dt / 1e6
 
 
-c2 = Config(n_envs=4096, ped_cycle_ms=1400)
-c16 = Config(n_envs=16384, ped_cycle_ms=1400)
-c5 = Config(n_envs=4096, n_peds=100, n_rays=720, room_half=2.4, ped_cycle_ms=1400)
+X = dict(risk_mode=int(os.environ.get("CN_RISK", 0)), obs_layout=int(os.environ.get("CN_LAYOUT", 0)))   # CN_RISK=1: gt mode
+c2 = Config(n_envs=4096, ped_cycle_ms=1400, **X)
+c16 = Config(n_envs=16384, ped_cycle_ms=1400, **X)
+c5 = Config(n_envs=4096, n_peds=100, n_rays=720, room_half=2.4, ped_cycle_ms=1400, **X)
 r = [one(c2, "next"), one(c2, "same"), groups(c2, 4), one(c16, "next"), groups(c16, 4), one(c5, "next"), groups(c5, 4)]
 print("%-28s 4096: 1-launch %6.2f  same-call %6.2f  4-groups %6.2f | 16384: 1-launch %6.2f  4-groups %6.2f | cfg5: %6.2f  4-groups %6.2f  (M env-steps/s)"
       % ((label,) + tuple(r)), flush=True)
