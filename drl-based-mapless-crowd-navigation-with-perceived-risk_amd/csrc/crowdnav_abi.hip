@@ -19,6 +19,10 @@ extern "C" __global__ void cn_env_kernel_ext(CnKParams p);
 extern "C" __global__ void cn_env_kernel_same(CnKParams p);
 extern "C" __global__ void cn_env_kernel_gt(CnKParams p);
 extern "C" __global__ void cn_env_kernel_gt_same(CnKParams p);
+extern "C" __global__ void cn_env_kernel_ct(CnKParams p);
+extern "C" __global__ void cn_env_kernel_ct_same(CnKParams p);
+extern "C" __global__ void cn_env_kernel_gt_ct(CnKParams p);
+extern "C" __global__ void cn_env_kernel_gt_ct_same(CnKParams p);
 extern "C" __global__ void cn_env_kernel_orig(CnKParams p);
 extern "C" __global__ void cn_env_kernel_orig_ext(CnKParams p);
 extern "C" __global__ void cn_env_kernel_orig_same(CnKParams p);
@@ -172,7 +176,6 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
         !(c.geos_untyped_empty == 0 || c.geos_untyped_empty == 1) || !(c.ped_contact == 0 || c.ped_contact == 1) ||
         !(c.risk_mode == CN_RISK_LIDAR_TRACKER || c.risk_mode == CN_RISK_GT))
         return fail(CN_ERR_CONFIG, "cn_create: config out of range");
-    if (c.ped_contact) return fail(CN_ERR_CONFIG, "cn_create: ped_contact is not built yet");
     if (c.risk_mode == CN_RISK_GT && c.obs_layout != CN_LAYOUT_RISK)
         return fail(CN_ERR_CONFIG, "cn_create: risk_mode gt needs the risk observation layout (obs_layout 0)");
     int ndev = 0;
@@ -190,6 +193,10 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
     h->max_conf = (R - 1) / 4 + 2;
     h->trk_cap = c.track_capacity ? c.track_capacity : (P <= 40 ? 32 : 64);
     h->lds = cn_lds_bytes(R, P, K, h->max_conf, h->trk_cap);
+    if (c.ped_contact && c.obs_layout != CN_LAYOUT_RISK)
+        return fail(CN_ERR_CONFIG, "cn_create: ped_contact is built for the risk observation layout (obs_layout 0) only");
+    if (c.ped_contact && 32 * (size_t)P > 16 * (size_t)(R - 1))   // contact corrections: 4 doubles per pedestrian in LDS regions A + B
+        return fail(CN_ERR_CONFIG, "cn_create: ped_contact needs n_peds <= (n_rays - 1) / 2");
     if (h->lds > 160 * 1024) { return fail(CN_ERR_CONFIG, "cn_create: per-env working set exceeds 160 KiB of LDS"); }
     // tables
     const int Wb = (R + 63) / 64;
@@ -251,6 +258,10 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
         HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
         HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_ext, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
         HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_same, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
+        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_ct, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
+        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_ct_same, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
+        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_gt_ct, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
+        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_gt_ct_same, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
         HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_gt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
         HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_gt_same, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
         HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_orig, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
@@ -317,20 +328,19 @@ static int launch(cn_handle h, const CnKParams& kp, hipStream_t st)
             hipLaunchKernelGGL(cn_env_kernel_orig_same, dim3(kp.N), dim3(64), h->lds, st, kp);
         else
             hipLaunchKernelGGL(cn_env_kernel_orig, dim3(kp.N), dim3(64), h->lds, st, kp);
-    } else if (h->cfg.risk_mode == CN_RISK_GT) {
-        if (kp.mode == CN_MODE_EXT_STEP || kp.mode == CN_MODE_EXT_RESET)
+    } else if (kp.mode == CN_MODE_EXT_STEP || kp.mode == CN_MODE_EXT_RESET) {
+        if (h->cfg.risk_mode == CN_RISK_GT)
             return fail(CN_ERR_CONFIG, "cn_observe_external: risk_mode gt reads the library simulator's pedestrians; "
                                        "external /scan + /odom only exist in lidar_tracker mode");
-        if (kp.mode == CN_MODE_STEP && kp.auto_reset == 1)
-            hipLaunchKernelGGL(cn_env_kernel_gt_same, dim3(kp.N), dim3(64), h->lds, st, kp);
-        else
-            hipLaunchKernelGGL(cn_env_kernel_gt, dim3(kp.N), dim3(64), h->lds, st, kp);
-    } else if (kp.mode == CN_MODE_EXT_STEP || kp.mode == CN_MODE_EXT_RESET)
         hipLaunchKernelGGL(cn_env_kernel_ext, dim3(kp.N), dim3(64), h->lds, st, kp);
-    else if (kp.mode == CN_MODE_STEP && kp.auto_reset == 1)   // step + reset of finished envs in the same launch
-        hipLaunchKernelGGL(cn_env_kernel_same, dim3(kp.N), dim3(64), h->lds, st, kp);
-    else
-        hipLaunchKernelGGL(cn_env_kernel, dim3(kp.N), dim3(64), h->lds, st, kp);
+    } else {
+        // simulated sensors: {lidar tracker, gt} x {no contact, contact} x {one observation per launch, step + same-call reset}
+        const bool same = kp.mode == CN_MODE_STEP && kp.auto_reset == 1;
+        const bool gt = h->cfg.risk_mode == CN_RISK_GT, ct = h->cfg.ped_contact != 0;
+        void (*fn)(CnKParams) = gt ? (ct ? (same ? cn_env_kernel_gt_ct_same : cn_env_kernel_gt_ct) : (same ? cn_env_kernel_gt_same : cn_env_kernel_gt))
+                                   : (ct ? (same ? cn_env_kernel_ct_same : cn_env_kernel_ct) : (same ? cn_env_kernel_same : cn_env_kernel));
+        hipLaunchKernelGGL(fn, dim3(kp.N), dim3(64), h->lds, st, kp);
+    }
     HIPCHK(hipGetLastError());
     return CN_OK;
 }

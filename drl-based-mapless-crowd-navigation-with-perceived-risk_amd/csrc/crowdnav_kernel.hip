@@ -296,6 +296,99 @@ __device__ __forceinline__ void robot_advance(KP p, EnvRegs& e, int ms)
     e.ryaw = th;
 }
 
+// cn_config.ped_contact = 1 (row A2; WORLD:86-145: rigid frictionless cylinders): the world advances in physics ticks of at
+// most 10 ms -- crowd velocity assignments falling inside a tick take effect at its start, the (kinematic) robot moves by the
+// mid-point rule, every pedestrian integrates into the room, then contacts are resolved Jacobi style from that state:
+// overlapping discs each back off half the penetration and give up half the closing speed (a head-on pair stops), a disc
+// overlapping the robot (radius robot_clearance) backs off all of it and loses its closing speed relative to the robot
+// (the robot pushes it).  lane = pedestrian; corrections are summed in ascending index order, exactly as the oracle does.
+// `corr`: 4 P doubles of LDS scratch (regions A + B are idle while the simulator runs).
+__device__ __forceinline__ void sim_advance_contact(KP p, EnvRegs& e, int env, int lane, double* ped_p, double* ped_v, double* corr, int ms)
+{
+    const int P = p->P, T = p->ped_cycle_ms;
+    const double lo = -p->room_half + p->ped_radius, hi = p->room_half - p->ped_radius;
+    const double r = p->ped_radius, rr2 = (2.0 * r) * (2.0 * r);
+    const double Rr = r + p->robot_clearance, Rr2 = Rr * Rr;
+    const long long gid = p->env_index_base + env;
+    const double* preset = p->ped_preset + (size_t)env * 2 * P;
+    const long long t0 = e.crowd_ms;
+    const double invT = 1.0 / (double)T;
+    long long cyc = (long long)((double)t0 * invT);
+    long long ph64 = t0 - cyc * (long long)T;
+    if (ph64 < 0) { cyc -= 1; ph64 += T; }
+    if (ph64 >= T) { cyc += 1; ph64 -= T; }
+    const int ph = (int)ph64;
+    for (int tt = 0; tt < ms; ) {
+        const int h = (ms - tt < 10) ? (ms - tt) : 10;
+        const double hs = cn_div1000((double)h);
+        // 1. assignments whose instant lies in [t0 + tt, t0 + tt + h): first instant >= t0 + tt is offs + m T
+        for (int i = lane; i < P; i += 64) {
+            const int offs = i * p->ped_stagger_ms;
+            const long long tq = cyc * (long long)T + (long long)(ph - offs) + (long long)tt;     // (t0 + tt) - offs
+            long long m = 0, a = -tq;                                                             // a: instant relative to t0 + tt
+            if (tq > 0) { m = (tq + T - 1) / T; a = m * (long long)T - tq; }
+            while (a < h) {
+                if (p->ped_mode == 0) {
+                    const uint64_t hbase = cn_mix64(p->seed ^ cn_mix64((uint64_t)gid));
+                    const uint64_t h1 = cn_mix64(hbase ^ ((1ull << 32) | (uint64_t)(uint32_t)i));
+                    const double u0 = (double)(cn_mix64(h1 ^ (uint64_t)(uint32_t)(2u * (unsigned)m)) >> 11) * (1.0 / 9007199254740992.0);
+                    const double u1 = (double)(cn_mix64(h1 ^ (uint64_t)(uint32_t)(2u * (unsigned)m + 1u)) >> 11) * (1.0 / 9007199254740992.0);
+                    ped_v[2 * i] = fma(2.0 * p->ped_vmax, u0, -p->ped_vmax);
+                    ped_v[2 * i + 1] = fma(2.0 * p->ped_vmax, u1, -p->ped_vmax);
+                } else { ped_v[2 * i] = preset[2 * i]; ped_v[2 * i + 1] = preset[2 * i + 1]; }
+                a += T; m += 1;
+            }
+        }
+        // 2. the robot (uniform), and its linear velocity in the world frame
+        robot_advance(p, e, h);
+        double syaw, cyaw;
+        cn_det_sincos(e.ryaw, &syaw, &cyaw);
+        const double rvx = e.rv * cyaw, rvy = e.rv * syaw;
+        // 3. integrate
+        for (int i = lane; i < P; i += 64) {
+            ped_p[2 * i] = cn_clamp(fma(ped_v[2 * i], hs, ped_p[2 * i]), lo, hi);
+            ped_p[2 * i + 1] = cn_clamp(fma(ped_v[2 * i + 1], hs, ped_p[2 * i + 1]), lo, hi);
+        }
+        CN_SYNC();
+        // 4. corrections from the post-integration state
+        for (int i = lane; i < P; i += 64) {
+            const double xi = ped_p[2 * i], yi = ped_p[2 * i + 1], vxi = ped_v[2 * i], vyi = ped_v[2 * i + 1];
+            double ax = 0.0, ay = 0.0, bx = 0.0, by = 0.0;
+            for (int j = 0; j < P; ++j) {
+                const double ddx = xi - ped_p[2 * j], ddy = yi - ped_p[2 * j + 1];
+                const double d2 = fma(ddx, ddx, ddy * ddy);
+                if (j == i || !(d2 < rr2) || !(d2 > 0.0)) continue;
+                const double d = sqrt(d2), nx = ddx / d, ny = ddy / d;
+                const double pen = 2.0 * r - d;
+                ax = fma(0.5 * pen, nx, ax); ay = fma(0.5 * pen, ny, ay);
+                const double vn = fma(vxi - ped_v[2 * j], nx, (vyi - ped_v[2 * j + 1]) * ny);
+                if (vn < 0.0) { bx = fma(-0.5 * vn, nx, bx); by = fma(-0.5 * vn, ny, by); }
+            }
+            {
+                const double ddx = xi - e.rx, ddy = yi - e.ry;
+                const double d2 = fma(ddx, ddx, ddy * ddy);
+                if (d2 < Rr2 && d2 > 0.0) {
+                    const double d = sqrt(d2), nx = ddx / d, ny = ddy / d;
+                    const double pen = Rr - d;
+                    ax = fma(pen, nx, ax); ay = fma(pen, ny, ay);
+                    const double vn = fma(vxi - rvx, nx, (vyi - rvy) * ny);
+                    if (vn < 0.0) { bx = fma(-vn, nx, bx); by = fma(-vn, ny, by); }
+                }
+            }
+            corr[4 * i] = ax; corr[4 * i + 1] = ay; corr[4 * i + 2] = bx; corr[4 * i + 3] = by;
+        }
+        CN_SYNC();
+        for (int i = lane; i < P; i += 64) {
+            ped_p[2 * i] = cn_clamp(ped_p[2 * i] + corr[4 * i], lo, hi);
+            ped_p[2 * i + 1] = cn_clamp(ped_p[2 * i + 1] + corr[4 * i + 1], lo, hi);
+            ped_v[2 * i] += corr[4 * i + 2]; ped_v[2 * i + 1] += corr[4 * i + 3];
+        }
+        CN_SYNC();
+        tt += h;
+    }
+    e.crowd_ms += ms;
+}
+
 __device__ __forceinline__ void sim_advance(KP p, EnvRegs& e, int env, int lane, double* ped_p, double* ped_v, int ms)
 {
     if (ms <= 0) return;
@@ -1440,7 +1533,7 @@ __device__ __forceinline__ double compute_reward(KP p, const Poly& pg, EnvRegs& 
 
 }  // namespace
 
-template <bool EXT, bool TWO, int LAYOUT, bool GT = false>
+template <bool EXT, bool TWO, int LAYOUT, bool GT = false, bool CT = false>
 __device__ __forceinline__ void env_kernel_body()
 {
     KP p = (KP)__builtin_amdgcn_kernarg_segment_ptr();
@@ -1557,11 +1650,14 @@ __device__ __forceinline__ void env_kernel_body()
                 const double t0 = e.clock;
                 e.rv = v; e.rw = w;                               // pub_cmd_vel.publish (ENV:1200)
                 e.clock += cn_div1000((double)p->dt_ms);              // time.sleep(0.15) (ENV:1201)
+                if constexpr (CT) sim_advance_contact(p, e, env, lane, L.ped, pedv, (double*)smem, p->dt_ms);
+                else {
                 if constexpr (LAYOUT == 0) { step_trig(p, e, lane, rs1, rc1, rs2, rc2, trig); have_trig = true; }
                 // pedestrians: ONE pass over [0, dt + scan latency], cut at dt (they are only looked at by the scan)
                 ped_advance(p, env, lane, L.ped, pedv, e.crowd_ms, e.crowd_ms + p->dt_ms + p->scan_latency_ms, p->dt_ms);
                 e.crowd_ms += p->dt_ms + p->scan_latency_ms;
                 if (have_trig) robot_advance_sc(p, e, p->dt_ms, rs1, rc1); else robot_advance(p, e, p->dt_ms);
+                }
                 CN_T(20);
                 end_timestep = e.clock - t0;                      // ENV:1202
                 deq_x = e.rx; deq_y = e.ry;
@@ -1578,7 +1674,8 @@ __device__ __forceinline__ void env_kernel_body()
             }
             if (!ext) {
                 e.clock += cn_div1000((double)p->scan_latency_ms);    // wait_for_message('scan') (ENV:1218)
-                if (have_trig) robot_advance_sc(p, e, p->scan_latency_ms, rs2, rc2); else robot_advance(p, e, p->scan_latency_ms);
+                if constexpr (CT) sim_advance_contact(p, e, env, lane, L.ped, pedv, (double*)smem, p->scan_latency_ms);
+                else if (have_trig) robot_advance_sc(p, e, p->scan_latency_ms, rs2, rc2); else robot_advance(p, e, p->scan_latency_ms);
                 CN_T(21);
             }
         } else {
@@ -1588,7 +1685,8 @@ __device__ __forceinline__ void env_kernel_body()
                 for (int i = lane; i < 2 * P; i += 64) { L.ped[i] = gped_init[i]; pedv[i] = 0.0; }
                 CN_SYNC();
                 e.clock += cn_div1000((double)p->scan_latency_ms);    // wait_for_message('scan') (ENV:1238)
-                sim_advance(p, e, env, lane, L.ped, pedv, p->scan_latency_ms);
+                if constexpr (CT) sim_advance_contact(p, e, env, lane, L.ped, pedv, (double*)smem, p->scan_latency_ms);
+                else sim_advance(p, e, env, lane, L.ped, pedv, p->scan_latency_ms);
             }
             if constexpr (LAYOUT == 1) {
                 e.prev_dist = dist3(e.rx, e.ry, p->goal_x, p->goal_y);   // ORIG:472 (unrounded)
@@ -1641,7 +1739,8 @@ __device__ __forceinline__ void env_kernel_body()
             e.social_viol = 0; e.ego_viol = 0; e.obst_steps = 0;  // ENV:1260-1262
             if (!ext) {
                 e.clock += cn_div1000((double)p->settle_ms);          // TRAIN:114 time.sleep(0.1)
-                sim_advance(p, e, env, lane, L.ped, pedv, p->settle_ms);
+                if constexpr (CT) sim_advance_contact(p, e, env, lane, L.ped, pedv, (double*)smem, p->settle_ms);
+                else sim_advance(p, e, env, lane, L.ped, pedv, p->settle_ms);
             }
             e.done = 0;                                           // TRAIN:116
             e.ep_step = 0; e.ep_ret = 0.0; e.pending = 0;
@@ -1668,9 +1767,12 @@ __device__ __forceinline__ void env_kernel_body()
             const double t0 = e.clock;
             e.rv = v; e.rw = w;                               // pub_cmd_vel.publish (ENV:1200)
             e.clock += cn_div1000((double)p->dt_ms);              // time.sleep(0.15) (ENV:1201)
+            if constexpr (CT) sim_advance_contact(p, e, env, lane, L.ped, pedv, (double*)smem, p->dt_ms);
+            else {
             ped_advance(p, env, lane, L.ped, pedv, e.crowd_ms, e.crowd_ms + p->dt_ms + p->scan_latency_ms, p->dt_ms);
             e.crowd_ms += p->dt_ms + p->scan_latency_ms;
             robot_advance(p, e, p->dt_ms);
+            }
             end_timestep = e.clock - t0;                      // ENV:1202
             deq_x = e.rx; deq_y = e.ry;
         } else {                                              // the caller ran the sleep; /odom said where we are
@@ -1685,7 +1787,8 @@ __device__ __forceinline__ void env_kernel_body()
         e.ts = end_timestep;                                  // ENV:1209
         if (!ext) {
             e.clock += cn_div1000((double)p->scan_latency_ms);    // wait_for_message('scan') (ENV:1218)
-            robot_advance(p, e, p->scan_latency_ms);
+            if constexpr (CT) sim_advance_contact(p, e, env, lane, L.ped, pedv, (double*)smem, p->scan_latency_ms);
+            else robot_advance(p, e, p->scan_latency_ms);
         }
         CN_SYNC();
         double r;
@@ -1724,7 +1827,8 @@ __device__ __forceinline__ void env_kernel_body()
         for (int i = lane; i < 2 * P; i += 64) { L.ped[i] = gped_init[i]; pedv[i] = 0.0; }
         CN_SYNC();
         e.clock += cn_div1000((double)p->scan_latency_ms);        // wait_for_message('scan') (ENV:1238)
-        sim_advance(p, e, env, lane, L.ped, pedv, p->scan_latency_ms);
+        if constexpr (CT) sim_advance_contact(p, e, env, lane, L.ped, pedv, (double*)smem, p->scan_latency_ms);
+        else sim_advance(p, e, env, lane, L.ped, pedv, p->scan_latency_ms);
         }
         CN_SYNC();
         int d2 = 0;
@@ -1742,7 +1846,8 @@ __device__ __forceinline__ void env_kernel_body()
         e.social_viol = 0; e.ego_viol = 0; e.obst_steps = 0;  // ENV:1260-1262
         if (!ext) {
         e.clock += cn_div1000((double)p->settle_ms);              // TRAIN:114 time.sleep(0.1)
-        sim_advance(p, e, env, lane, L.ped, pedv, p->settle_ms);
+        if constexpr (CT) sim_advance_contact(p, e, env, lane, L.ped, pedv, (double*)smem, p->settle_ms);
+        else sim_advance(p, e, env, lane, L.ped, pedv, p->settle_ms);
         }
         e.done = 0;                                           // TRAIN:116
         e.ep_step = 0; e.ep_ret = 0.0; e.pending = 0;
@@ -1786,6 +1891,11 @@ extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_ext(CnKParams p) 
 // risk_mode gt: the perceived-risk features from the simulator's own pedestrians (no segmentation, no tracker)
 extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_gt(CnKParams p) { env_kernel_body<false, false, 0, true>(); }
 extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_gt_same(CnKParams p) { env_kernel_body<false, true, 0, true>(); }
+// ped_contact = 1: the simulator with rigid contacts (10 ms physics ticks); separate instantiations keep the default kernels lean
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_ct(CnKParams p) { env_kernel_body<false, false, 0, false, true>(); }
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_ct_same(CnKParams p) { env_kernel_body<false, true, 0, false, true>(); }
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_gt_ct(CnKParams p) { env_kernel_body<false, false, 0, true, true>(); }
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_gt_ct_same(CnKParams p) { env_kernel_body<false, true, 0, true, true>(); }
 // obs_layout 1 (environment_stage_1_original.py): same physics and lidar, no tracker
 extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_orig(CnKParams p) { env_kernel_body<false, false, 1>(); }
 extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_orig_same(CnKParams p) { env_kernel_body<false, true, 1>(); }

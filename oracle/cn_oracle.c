@@ -246,9 +246,98 @@ static void robot_advance(const cno_sim* s, env_t* e, int64_t ms)
     e->ryaw = th;
 }
 
+/* cn_config.ped_contact = 1 (row A2; WORLD:86-145: rigid mu = 0 cylinders, r = 0.0505, 1 kg): the world advances in physics
+ * ticks of at most 10 ms.  Per tick, in this order:
+ *   1. crowd velocity assignments whose instant falls inside the tick [t, t + h) take effect at t (CROWD:98-144; exact when
+ *      every interval is a multiple of 10 ms, which the reference's 150 / 10 / 100 ms are);
+ *   2. the robot moves by the mid-point rule over h (it is kinematic: driven by its wheel controller, never pushed);
+ *   3. every pedestrian integrates x <- clamp(fma(v, h, x)) into the room;
+ *   4. contacts, Jacobi style (every correction is computed from the positions / velocities after step 3, summed in index
+ *      order, then applied): two overlapping discs each back off half the penetration along the centre line and, if they are
+ *      approaching, each gives up half the closing speed (inelastic, frictionless: a head-on pair stops); a disc overlapping
+ *      the robot (radius robot_clearance) backs off the whole penetration and loses its closing speed relative to the robot's
+ *      linear velocity (the robot pushes it);  then the room clamp again.
+ * A pedestrian's velocity persists until its next assignment, as a Gazebo body's twist does between set_model_state calls. */
+static void sim_advance_contact(const cno_sim* s, env_t* e, int64_t gid, int64_t ms)
+{
+    const cno_config* c = &s->cfg;
+    const int P = c->n_peds;
+    const double lo = -c->room_half + c->ped_radius, hi = c->room_half - c->ped_radius;
+    const double r = c->ped_radius, rr2 = (2.0 * r) * (2.0 * r);
+    const double Rr = r + c->robot_clearance, Rr2 = Rr * Rr;
+    const int64_t T = c->ped_cycle_ms;
+    double* dxy = (double*)malloc(sizeof(double) * 4 * (size_t)(P > 0 ? P : 1));
+    int64_t t = e->crowd_ms;
+    const int64_t t1 = t + ms;
+    while (t < t1) {
+        const int64_t h = (t1 - t < 10) ? (t1 - t) : 10;
+        const double hs = (double)h / 1000.0;
+        for (int i = 0; i < P; ++i) {                       /* 1. assignments with instant in [t, t + h) */
+            int64_t offs = (int64_t)i * c->ped_stagger_ms;
+            int64_t m = (t <= offs) ? 0 : (t - offs + T - 1) / T;
+            int64_t a = offs + m * T;
+            while (a < t + h) {
+                if (c->ped_mode == 0) {
+                    double u0 = cno_rng_u01(c->seed, gid, 1u, (uint32_t)i, (uint32_t)(2 * m));
+                    double u1 = cno_rng_u01(c->seed, gid, 1u, (uint32_t)i, (uint32_t)(2 * m + 1));
+                    e->ped_v[2 * i] = fma(2.0 * c->ped_vmax, u0, -c->ped_vmax);
+                    e->ped_v[2 * i + 1] = fma(2.0 * c->ped_vmax, u1, -c->ped_vmax);
+                } else {
+                    e->ped_v[2 * i] = e->ped_preset[2 * i]; e->ped_v[2 * i + 1] = e->ped_preset[2 * i + 1];
+                }
+                a += T; m += 1;
+            }
+        }
+        robot_advance(s, e, h);                              /* 2. */
+        double syaw, cyaw;
+        cno_det_sincos(e->ryaw, &syaw, &cyaw);
+        const double rvx = e->rv * cyaw, rvy = e->rv * syaw; /* the robot's linear velocity in the world frame */
+        for (int i = 0; i < P; ++i) {                       /* 3. */
+            e->ped_p[2 * i] = clampd(fma(e->ped_v[2 * i], hs, e->ped_p[2 * i]), lo, hi);
+            e->ped_p[2 * i + 1] = clampd(fma(e->ped_v[2 * i + 1], hs, e->ped_p[2 * i + 1]), lo, hi);
+        }
+        for (int i = 0; i < P; ++i) {                       /* 4. corrections from the post-integration state */
+            const double xi = e->ped_p[2 * i], yi = e->ped_p[2 * i + 1], vxi = e->ped_v[2 * i], vyi = e->ped_v[2 * i + 1];
+            double ax = 0.0, ay = 0.0, bx = 0.0, by = 0.0;   /* position and velocity corrections */
+            for (int j = 0; j < P; ++j) {
+                if (j == i) continue;
+                const double ddx = xi - e->ped_p[2 * j], ddy = yi - e->ped_p[2 * j + 1];
+                const double d2 = fma(ddx, ddx, ddy * ddy);
+                if (!(d2 < rr2) || !(d2 > 0.0)) continue;
+                const double d = sqrt(d2), nx = ddx / d, ny = ddy / d;
+                const double pen = 2.0 * r - d;
+                ax = fma(0.5 * pen, nx, ax); ay = fma(0.5 * pen, ny, ay);
+                const double vn = fma(vxi - e->ped_v[2 * j], nx, (vyi - e->ped_v[2 * j + 1]) * ny);
+                if (vn < 0.0) { bx = fma(-0.5 * vn, nx, bx); by = fma(-0.5 * vn, ny, by); }
+            }
+            {
+                const double ddx = xi - e->rx, ddy = yi - e->ry;
+                const double d2 = fma(ddx, ddx, ddy * ddy);
+                if (d2 < Rr2 && d2 > 0.0) {
+                    const double d = sqrt(d2), nx = ddx / d, ny = ddy / d;
+                    const double pen = Rr - d;
+                    ax = fma(pen, nx, ax); ay = fma(pen, ny, ay);
+                    const double vn = fma(vxi - rvx, nx, (vyi - rvy) * ny);
+                    if (vn < 0.0) { bx = fma(-vn, nx, bx); by = fma(-vn, ny, by); }
+                }
+            }
+            dxy[4 * i] = ax; dxy[4 * i + 1] = ay; dxy[4 * i + 2] = bx; dxy[4 * i + 3] = by;
+        }
+        for (int i = 0; i < P; ++i) {
+            e->ped_p[2 * i] = clampd(e->ped_p[2 * i] + dxy[4 * i], lo, hi);
+            e->ped_p[2 * i + 1] = clampd(e->ped_p[2 * i + 1] + dxy[4 * i + 1], lo, hi);
+            e->ped_v[2 * i] += dxy[4 * i + 2]; e->ped_v[2 * i + 1] += dxy[4 * i + 3];
+        }
+        t += h;
+    }
+    e->crowd_ms = t1;
+    free(dxy);
+}
+
 static void sim_advance(const cno_sim* s, env_t* e, int64_t gid, int64_t ms)
 {
     if (ms <= 0) return;
+    if (s->cfg.ped_contact) { sim_advance_contact(s, e, gid, ms); return; }
     ped_advance(s, e, gid, e->crowd_ms, e->crowd_ms + ms);
     e->crowd_ms += ms;
     robot_advance(s, e, ms);

@@ -136,6 +136,38 @@ def test_gt_risk_mode_dense_and_semantics(oracle_mod):
         env.observe_external(np.full((16, 360), np.inf), np.zeros((16, 10)), step_counter=[1] * 16)
 
 
+@pytest.mark.parametrize("risk_mode", [0, 1])
+def test_rollout_parity_contact_dynamics(oracle_mod, risk_mode):
+    """cn_config.ped_contact = 1 (row A2): rigid frictionless contact between pedestrians and with the robot, 10 ms physics
+    ticks.  60 walkers in the 2.8 m room collide all the time; cn_env_kernel_ct / _gt_ct (+ _same) against the oracle:
+    pedestrian states bit for bit, observation, reward, done, indices."""
+    import torch
+    for mode in (True, "next"):
+        n_done, frac = _compare_rollout(oracle_mod, steps=80, seed=51, reset_mode=mode, n_envs=32, n_peds=60, max_steps=40,
+                                        ped_contact=1, risk_mode=risk_mode, min_scan_range=0.0)
+        assert frac > 0.999
+    torch_, env, orc = _pair(oracle_mod, n_envs=8, n_peds=60, max_steps=300, seed=52, ped_contact=1, risk_mode=risk_mode, min_scan_range=0.0)
+    env.reset(); orc.reset()
+    rng = np.random.default_rng(4)
+    touching = 0
+    for t in range(60):
+        act = np.stack([rng.uniform(0, 0.22, 8), rng.uniform(-2, 2, 8)], 1).astype(np.float32)
+        env.step(torch.from_numpy(act).cuda(), auto_reset=False); torch.cuda.synchronize()
+        orc.step(act.astype(np.float64), auto_reset=False)
+    for e_ in range(8):
+        g = env.debug_env(e_); rb, pp, pv, _ = orc.sim_state(e_)
+        assert np.array_equal(g["ped_p"], pp) and np.array_equal(g["ped_v"], pv) and np.array_equal(g["robot"], rb)
+        d = np.hypot(pp[:, None, 0] - pp[None, :, 0], pp[:, None, 1] - pp[None, :, 1]) + np.eye(60)
+        touching += int((d < 2 * 0.0505 + 1e-3).sum())
+        assert d.min() > 2 * 0.0505 - 0.02          # no deep overlaps survive (they start from random, possibly overlapping, poses)
+    assert touching > 0                              # and contacts did happen
+    import crowdnav
+    from crowdnav import Config
+    from crowdnav.env import VecEnv
+    with pytest.raises(crowdnav.CrowdNavError):      # documented limits of the mode
+        VecEnv(Config(n_envs=2, ped_contact=1, obs_layout=1))
+
+
 def test_rollout_parity_geos_untyped_empty(oracle_mod):
     """cn_config.geos_untyped_empty = 1 (shapely <= 1.7 / GEOS <= 3.8, the reference's Python-2.7 platform): a candidate
     segment that misses ends get_collision_point with None (UTL:279-289).  Dense room so that most tracks are affected."""

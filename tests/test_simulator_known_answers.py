@@ -158,3 +158,72 @@ def test_rounding_restatements_match_python_and_numpy(oracle_mod):
             assert L.cno_py_round(x, nd) == round(x, nd), (x, nd)
             assert L.cno_np_around(x, nd) == float(np.around(np.float64(x), nd)), (x, nd)
             assert L.cno_np_around(x, nd) == float(round(np.float64(x), nd)), (x, nd)
+
+
+# ---- cn_config.ped_contact = 1 (row A2): frictionless rigid contact, WORLD:86-145 -------------------------------------
+def _contact_world(oracle_mod, init, vel, **kw):
+    init, vel = np.asarray(init, dtype=np.float64)[None], np.asarray(vel, dtype=np.float64)[None]
+    o = oracle_mod.Oracle(n_envs=1, n_peds=init.shape[1], ped_mode=1, ped_contact=1, ped_cycle_ms=100 * init.shape[1],
+                          room_half=2.4, spawn_x=-2.0, spawn_y=-2.0, spawn_yaw=0.0, **kw)
+    o.set_ped_init(init); o.set_ped_preset_vel(vel)
+    o.hsim_reset()
+    return o
+
+
+def test_contact_head_on_pair_stops(oracle_mod):
+    """Two discs approach head-on at +-0.2 m/s: they meet when the gap closes, stop (inelastic, equal mass) and never overlap
+    by more than one physics tick of closing motion; the line of centres keeps its direction (no tunnelling)."""
+    o = _contact_world(oracle_mod, [[-0.3, 0.0], [0.3, 0.0]], [[0.2, 0.0], [-0.2, 0.0]], ped_stagger_ms=0)
+    gaps = []
+    for _ in range(30):                                   # 3 s: the gap of 0.6 - 0.101 closes at 0.4 m/s after ~1.25 s
+        o.hsim_advance(100, 0.0, 0.0)
+        _, pp, pv, _ = o.sim_state()
+        gaps.append(pp[1, 0] - pp[0, 0])
+        assert abs(pp[0, 1]) < 1e-12 and abs(pp[1, 1]) < 1e-12
+    gaps = np.array(gaps)
+    assert (gaps > 2 * 0.0505 - 0.4 * 0.010 - 1e-9).all()         # never deeper than one 10 ms tick of closing speed
+    assert abs(gaps[-1] - 2 * 0.0505) < 5e-3                       # resting in contact
+    assert np.abs(pv[:, 0]).max() < 1e-9                           # stopped
+    assert gaps[0] < 0.6 and (np.diff(gaps) <= 1e-12).all()        # monotone approach, no bounce
+    # the preset velocity comes back at the next crowd assignment (set_model_state re-asserts the twist, CROWD:128-144)
+    # and the contact takes it away again within the same tick
+    o.hsim_advance(400, 0.0, 0.0)
+    _, pp, pv, _ = o.sim_state()
+    assert pp[1, 0] - pp[0, 0] > 2 * 0.0505 - 0.4 * 0.010 - 1e-9
+
+
+def test_contact_oblique_keeps_the_tangential_motion(oracle_mod):
+    """Frictionless: only the normal component of the relative velocity is removed."""
+    o = _contact_world(oracle_mod, [[-0.2, 0.0], [0.2, 0.0]], [[0.2, 0.1], [-0.2, 0.1]], ped_stagger_ms=0)
+    o.hsim_advance(2000, 0.0, 0.0)
+    _, pp, pv, _ = o.sim_state()
+    assert np.allclose(pv[:, 1], 0.1, atol=1e-9) and np.abs(pv[:, 0]).max() < 1e-6      # both keep drifting in +y, side by side
+    assert abs((pp[1, 0] - pp[0, 0]) - 2 * 0.0505) < 5e-3 and abs(pp[0, 1] - pp[1, 1]) < 1e-9
+
+
+def test_contact_robot_pushes_a_disc(oracle_mod):
+    """The robot is kinematic: a standing disc in its way is pushed ahead at the robot's speed and stays in front of it."""
+    o = _contact_world(oracle_mod, [[-1.5, -2.0]], [[0.0, 0.0]])
+    rc, r = 0.09, 0.0505                                   # robot_clearance (contact radius of the robot), ped_radius
+    for k in range(40):                                    # robot drives +x at 0.2 m/s from x = -2: contact after ~(0.5 - 0.1405) / 0.2 s
+        o.hsim_advance(100, 0.2, 0.0)
+        robot, pp, pv, _ = o.sim_state()
+        assert pp[0, 0] - robot[0] > rc + r - 0.2 * 0.010 - 1e-9          # never deeper than one tick of the robot's motion
+    assert abs((pp[0, 0] - robot[0]) - (rc + r)) < 3e-3 and abs(pv[0, 0] - 0.2) < 1e-9 and abs(pp[0, 1] + 2.0) < 1e-12
+    assert robot[0] > -2.0 + 0.2 * 3.9                     # the robot was not slowed down
+
+
+def test_contact_mode_without_contacts_is_the_plain_simulator(oracle_mod):
+    """Far-apart walkers: the 10 ms ticks change the rounding of the integration, nothing else (1e-12 over 30 s)."""
+    kw = dict(n_envs=2, n_peds=6, ped_vmax=0.05, room_half=3.0, max_steps=400, seed=5)
+    a, b = oracle_mod.Oracle(ped_contact=0, **kw), oracle_mod.Oracle(ped_contact=1, **kw)
+    init = np.array([[[-2.5, -2.5], [-2.5, 2.5], [2.5, 2.5], [0.0, 2.5], [0.0, -2.5], [2.5, -2.5]]] * 2)
+    for o in (a, b):
+        o.set_ped_init(init); o.reset()
+    for t in range(200):
+        act = np.array([[0.05, 0.3], [0.1, -0.2]])
+        a.step(act); b.step(act)
+    for e in range(2):
+        ra, pa, va, _ = a.sim_state(e); rb, pb, vb, _ = b.sim_state(e)
+        assert np.allclose(pa, pb, atol=1e-10) and np.array_equal(va, vb)
+        assert np.allclose(ra, rb, atol=1e-3)              # the robot's arc is integrated in 10 ms pieces (more accurate)
