@@ -24,6 +24,12 @@ def main():
     ap.add_argument("--min-scan", type=float, default=0.12)
     ap.add_argument("--verbose", type=int, default=5)
     ap.add_argument("--reset-mode", default="same", choices=["same", "next"])
+    ap.add_argument("--k", type=int, default=8)
+    ap.add_argument("--risk-mode", type=int, default=0)
+    ap.add_argument("--contact", type=int, default=0)
+    ap.add_argument("--geos", type=int, default=0)
+    ap.add_argument("--layout", type=int, default=0)
+    ap.add_argument("--vmax", type=float, default=0.2)
     a = ap.parse_args()
     import torch
     from crowdnav import Config
@@ -31,12 +37,16 @@ def main():
     from oracle import oracle
 
     cfg = Config(n_envs=a.envs, n_peds=a.peds, n_rays=a.rays, room_half=a.room, seed=a.seed, max_steps=a.max_steps,
-                 min_scan_range=a.min_scan)
+                 min_scan_range=a.min_scan, k_obstacles=a.k, risk_mode=a.risk_mode, ped_contact=a.contact,
+                 geos_untyped_empty=a.geos, obs_layout=a.layout, ped_vmax=a.vmax)
+    print("== parity_report", " ".join(sys.argv[1:]))
     env = VecEnv(cfg)
     env.enable_f64_obs()
     orc = oracle.Oracle(cfg.as_dict())
     oracle.set_num_threads(os.cpu_count() or 1)
     n = a.rays - 1
+    if a.layout == 1:
+        n = a.rays - 1 - 3          # layout 1 has a 4-value tail; the column split below is only indicative there
     o_g = env.reset(); torch.cuda.synchronize()
     o_c = orc.reset()
     g64 = env.obs_f64.cpu().numpy()

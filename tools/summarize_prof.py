@@ -12,28 +12,32 @@ def find(d, pat):
 
 
 def main(d):
-    st = find(os.path.join(d, "trace"), "*kernel_stats.csv")
-    if st:
-        print("== kernel stats (%s)" % os.path.relpath(st, d))
-        for row in csv.DictReader(open(st)):
-            print("  %-28s calls %6s  total %12s ns  avg %12s ns  %6s%%" % (
-                row.get("Name", "")[:28], row.get("Calls"), row.get("TotalDurationNs"), row.get("AverageNs"),
-                row.get("Percentage")))
-    tr = find(os.path.join(d, "trace"), "*kernel_trace.csv")
-    if tr:
-        legs = {}
-        for r in csv.DictReader(open(tr)):
-            kn = r["Kernel_Name"].split("(")[0].strip()
-            if not kn.startswith("cn_env_kernel"):
-                continue
-            g = int(r.get("Grid_Size_X", r.get("Grid_Size", 0)) or 0)
-            legs.setdefault((kn, g), []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-        # bench.py legs: cn_env_kernel_same (same-call reset), cn_env_kernel at the full grid (one launch per step),
-        # cn_env_kernel at grid / G (the stream-group leg: G launches in flight, so durations overlap)
-        print("== env kernel average duration by (kernel, grid = 64 x envs per launch):")
-        for (kn, g), dd in sorted(legs.items()):
-            print("  %-22s grid %7d (%5d envs)  launches %5d  avg %.1f us  min %.1f  max %.1f" % (
-                kn, g, g // 64, len(dd), sum(dd) / len(dd) / 1e3, min(dd) / 1e3, max(dd) / 1e3))
+    for tdir, what in (("trace", "bench.py --steps 300 --warmup 30"), ("trace_driver", "the driver's command: bench.py --steps 20 --warmup 5")):
+        st = find(os.path.join(d, tdir), "*kernel_stats.csv")
+        if st:
+            print("== kernel stats, %s (%s)" % (what, os.path.relpath(st, d)))
+            for row in csv.DictReader(open(st)):
+                if not row.get("Name", "").startswith("cn_"):
+                    continue
+                print("  %-28s calls %6s  total %12s ns  avg %12s ns  %6s%%" % (
+                    row.get("Name", "")[:28], row.get("Calls"), row.get("TotalDurationNs"), row.get("AverageNs"),
+                    row.get("Percentage")))
+        tr = find(os.path.join(d, tdir), "*kernel_trace.csv")
+        if tr:
+            legs = {}
+            for r in csv.DictReader(open(tr)):
+                kn = r["Kernel_Name"].split("(")[0].strip()
+                if not kn.startswith("cn_env_kernel"):
+                    continue
+                g = int(r.get("Grid_Size_X", r.get("Grid_Size", 0)) or 0)
+                legs.setdefault((kn, g), []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+            # bench.py legs: cn_env_kernel_same (same-call reset), cn_env_kernel at the full grid (one launch per step),
+            # cn_env_kernel at grid / G (the stream-group leg: G launches in flight, so durations overlap)
+            print("== env kernel average duration by (kernel, grid = 64 x envs per launch), %s:" % what)
+            for (kn, g), dd in sorted(legs.items()):
+                print("  %-22s grid %7d (%5d envs)  launches %5d  avg %.1f us  min %.1f  max %.1f" % (
+                    kn, g, g // 64, len(dd), sum(dd) / len(dd) / 1e3, min(dd) / 1e3, max(dd) / 1e3))
+    sq = {}
     for tag in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
         f = find(os.path.join(d, tag), "*counter_collection.csv")
         if not f:
@@ -50,6 +54,26 @@ def main(d):
         print("== %s (per cn_env_kernel dispatch of %d envs, mean of %s)" % (tag, gmax // 64, sorted(set(cnt.values()))))
         for k in sorted(acc):
             print("  %-24s %.6g" % (k, acc[k] / cnt[k]))
+            sq[k] = acc[k] / cnt[k]
+        sq["_envs"] = gmax // 64
+    if "SQ_INSTS_VALU" in sq and "SQ_BUSY_CYCLES" in sq:
+        import json
+        n = float(sq["_envs"])
+        # SQ_ACTIVE_INST_VALU counts quad-cycles per wave (MI355X_MICROARCH.md, "s_memtime tick vs SQ PMC units"); SQ_BUSY_CYCLES is
+        # summed over the 32 shader engines (8 XCDs x 4) in cycles, so the launch lasted SQ_BUSY_CYCLES / 32 cycles on 1024 SIMDs
+        kcycles = sq["SQ_BUSY_CYCLES"] / 32.0
+        out = {"valu_busy": 4.0 * sq["SQ_ACTIVE_INST_VALU"] / (1024.0 * kcycles),
+               "wave_instr_per_env_step": {"valu": sq["SQ_INSTS_VALU"] / n, "salu": sq.get("SQ_INSTS_SALU", 0) / n,
+                                           "lds": sq.get("SQ_INSTS_LDS", 0) / n},
+               "wave_quad_cycles_per_env_step": sq.get("SQ_WAVE_CYCLES", 0) / n,
+               "wait_any_frac": sq.get("SQ_WAIT_ANY", 0) / max(1.0, sq.get("SQ_WAVE_CYCLES", 1)),
+               "launch_cycles": kcycles, "envs_per_launch": n,
+               "source": "rocprofv3 --pmc SQ_* pass of this bench command, full-grid (one launch per step) dispatches: valu_busy = "
+                         "4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x SQ_BUSY_CYCLES / 32)"}
+        json.dump(out, open(os.path.join(d, "counters.json"), "w"), indent=1)
+        print("== counters.json: VALU busy %.3f, %.0f VALU + %.0f SALU + %.0f LDS wave instructions per env-step" % (
+            out["valu_busy"], out["wave_instr_per_env_step"]["valu"], out["wave_instr_per_env_step"]["salu"],
+            out["wave_instr_per_env_step"]["lds"]))
     # calibration: known 1 GiB streams at 4 and 8 bytes per lane -> KB reported per byte moved
     calib = {}
     for tag, ctr in (("calib_fetch", "FETCH_SIZE"), ("calib_write", "WRITE_SIZE")):
