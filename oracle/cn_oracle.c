@@ -647,6 +647,50 @@ static void track_new(env_t* e, const cobj_t* o, double now)
     t->vel.x = 0.0; t->vel.y = 0.0;
 }
 
+/* ENV:656-743 tracker (the same code block as RW:490-571): popleft, IoU arg-max per track with the first maximum winning,
+ * "delete only while len(tracks) > i" with the index drift of `keys.pop(i)`, unmatched 'o' objects become tracks. */
+static void tracker_update(env_t* e, const cobj_t* conf, int nconf, double now, int* tmp)
+{
+    if (e->ntracks == 0) {
+        for (int j = 0; j < nconf; ++j) if (conf[j].type == TY_O) track_new(e, &conf[j], now);
+    } else {
+        int nt0 = e->ntracks;
+        for (int i = 0; i < nt0; ++i) if (e->tracks[i].dq_len > 1) { /* ENV:678-680 popleft */
+            e->tracks[i].dq[0] = e->tracks[i].dq[1]; e->tracks[i].dq_len = 1;
+        }
+        if (nconf == 0) {
+            e->ntracks = 0; /* ENV:683-686 nets out to clearing every track */
+        } else {
+            int alive[CNO_MAX_TRACKS];
+            int* checked = tmp;
+            for (int j = 0; j < nconf; ++j) checked[j] = 0;
+            int cur = nt0; /* len(self.tracked_obstacles) */
+            for (int i = 0; i < nt0; ++i) {
+                alive[i] = 1;
+                track_t* t = &e->tracks[i];
+                int bj = 0; double best = -1.0;
+                for (int j = 0; j < nconf; ++j) { /* ENV:688-689, walls included */
+                    double u = cno_iou(t->pose.x, t->pose.y, conf[j].pose.x, conf[j].pose.y, 0.0505);
+                    if (u > best) { best = u; bj = j; } /* list.index(max): first maximum */
+                }
+                if (best > 0.0) { /* ENV:702-712 */
+                    t->pose = conf[bj].pose; t->dist = conf[bj].dist;
+                    t->dq[t->dq_len++] = conf[bj].pose;
+                    t->t = now - t->t;
+                    checked[bj] = 1;
+                } else if (cur > i) { /* ENV:715-717 */
+                    alive[i] = 0; cur -= 1;
+                }
+            }
+            int m = 0;
+            for (int i = 0; i < nt0; ++i) if (alive[i]) { if (m != i) e->tracks[m] = e->tracks[i]; ++m; }
+            e->ntracks = m;
+            for (int j = 0; j < nconf; ++j) /* ENV:723-743 */
+                if (!checked[j] && conf[j].type == TY_O) track_new(e, &conf[j], now);
+        }
+    }
+}
+
 static void env_get_state(const cno_sim* s, env_t* e, const double* ranges, double px, double py, double yaw,
                           double v, double w, int step_counter, double now, double* state, int* done_out,
                           int32_t* topk_idx)
@@ -858,45 +902,7 @@ static void env_get_state(const cno_sim* s, env_t* e, const double* ranges, doub
     for (int j = 0; j < nconf; ++j) n_obst += (conf[j].type == TY_O);
     if (n_obst > 0) e->obst_steps += 1;
 
-    /* ENV:656-743 tracker */
-    if (e->ntracks == 0) {
-        for (int j = 0; j < nconf; ++j) if (conf[j].type == TY_O) track_new(e, &conf[j], now);
-    } else {
-        int nt0 = e->ntracks;
-        for (int i = 0; i < nt0; ++i) if (e->tracks[i].dq_len > 1) { /* ENV:678-680 popleft */
-            e->tracks[i].dq[0] = e->tracks[i].dq[1]; e->tracks[i].dq_len = 1;
-        }
-        if (nconf == 0) {
-            e->ntracks = 0; /* ENV:683-686 nets out to clearing every track */
-        } else {
-            int alive[CNO_MAX_TRACKS];
-            int* checked = tmp;
-            for (int j = 0; j < nconf; ++j) checked[j] = 0;
-            int cur = nt0; /* len(self.tracked_obstacles) */
-            for (int i = 0; i < nt0; ++i) {
-                alive[i] = 1;
-                track_t* t = &e->tracks[i];
-                int bj = 0; double best = -1.0;
-                for (int j = 0; j < nconf; ++j) { /* ENV:688-689, walls included */
-                    double u = cno_iou(t->pose.x, t->pose.y, conf[j].pose.x, conf[j].pose.y, 0.0505);
-                    if (u > best) { best = u; bj = j; } /* list.index(max): first maximum */
-                }
-                if (best > 0.0) { /* ENV:702-712 */
-                    t->pose = conf[bj].pose; t->dist = conf[bj].dist;
-                    t->dq[t->dq_len++] = conf[bj].pose;
-                    t->t = now - t->t;
-                    checked[bj] = 1;
-                } else if (cur > i) { /* ENV:715-717 */
-                    alive[i] = 0; cur -= 1;
-                }
-            }
-            int m = 0;
-            for (int i = 0; i < nt0; ++i) if (alive[i]) { if (m != i) e->tracks[m] = e->tracks[i]; ++m; }
-            e->ntracks = m;
-            for (int j = 0; j < nconf; ++j) /* ENV:723-743 */
-                if (!checked[j] && conf[j].type == TY_O) track_new(e, &conf[j], now);
-        }
-    }
+    tracker_update(e, conf, nconf, now, tmp);
     } else {
         /* risk_mode gt ("two risk-feature modes"; include/crowdnav.h): rows A21-A24 fed with the simulator's own
          * pedestrians instead of tracked lidar blobs.  An entry = a pedestrian that is within lidar range of the lidar origin
@@ -1178,6 +1184,268 @@ static double orig_compute_reward(const cno_sim* s, env_t* e, const double* stat
  * Env.reset / Env.step flows
  * ---------------------------------------------------------------------------------------- */
 
+/* ------------------------------------------------------------------------------------------
+ * obs_layout 2: environment_stage_1_nobonus_realworld.py ("RW"), the 370-input physical-robot variant:
+ * 359 UNROUNDED sanitised ranges + heading + distance + rounded (x, y) + the constant yaw 3.14 + rounded twist features +
+ * pose and velocity of the ONE tracked obstacle with the highest collision probability.  Its segmentation is an older
+ * pipeline than ENV's: free-space rays are filtered out BEFORE the gradients, no way-points, the collision cone is cast
+ * against a ring of radius min_scan_range, and Env.step holds the command for 0.05 s but books 0.15 s (RW:880-883).
+ * ---------------------------------------------------------------------------------------- */
+static double rw_distance(const cno_config* c, double px, double py)
+{   /* RW:161-173: starting_point is added to the position here too */
+    return dist3(px + c->start_x, py + c->start_y, c->goal_x, c->goal_y);
+}
+static double rw_heading(const cno_config* c, double px, double py, double yaw)
+{   /* RW:186-200 */
+    double cx = px + c->start_x, cy = py + c->start_y;
+    double h = atan2(c->goal_y - cy, c->goal_x - cx) - yaw;
+    if (h > M_PI) h -= 2 * M_PI;
+    else if (h < -M_PI) h += 2 * M_PI;
+    return h;
+}
+
+static void rw_get_state(const cno_sim* s, env_t* e, const double* ranges, double px, double py, double yaw, double v,
+                         double w, int step_counter, double now, double* state, int* done_out)
+{
+    const cno_config* c = &s->cfg;
+    const int R = c->n_rays, n = R - 1;
+    const double MAXR = c->max_scan_range;
+    double distance_to_goal = cno_np_around(rw_distance(c, px, py), 2);   /* RW:209 round(np.float64, 2) */
+    double heading = cno_py_round(rw_heading(c, px, py, yaw), 2);         /* RW:210 */
+    double agent_vel_x = -1.0 * (v * cos(w)), agent_vel_y = v * sin(w);   /* RW:211-212 */
+    v2 closest_pose = { px, py }, closest_vel = { 0.0, 0.0 };             /* RW:215-216 */
+
+    double* scan = (double*)malloc(sizeof(double) * (size_t)n * 10 + sizeof(int) * (size_t)n * 8);
+    double* pts = scan + n;            /* 2n */
+    double* gtp = pts + 2 * n;         /* 2n */
+    double* fr = gtp + 2 * n;          /* n: filtered ranges */
+    double* g = fr + n;                /* n */
+    double* cg = g + n;                /* n */
+    double* ed = cg + n;               /* n: estimated (flattened) distances */
+    int* fi = (int*)(ed + n + 1);      /* filtered -> ray index */
+    int* cnone = fi + n;
+    int* Ttype = cnone + n;            /* 0 = None */
+    int* Tsrc = Ttype + n;             /* filtered index whose range / pose the entry carries */
+    int* et = Tsrc + n;                /* estimated types */
+    int* es = et + n;                  /* estimated source (filtered index) */
+    int* segend = es + n;
+    int* tmp = segend + n;
+
+    cno_scan_sanitize(ranges, R, MAXR, scan);                              /* RW:220 */
+    cno_scan_to_points(scan, R, px, py, yaw, pts);                         /* RW:225 */
+    if (step_counter == 0) {                                               /* RW:229-237 */
+        for (int i = 0; i < n; ++i) g[i] = MAXR;
+        cno_scan_to_points(g, R, px, py, yaw, gtp);
+        e->bb = cno_bbox_size(gtp, n);
+        v2 p = { cno_py_round(px, 3), cno_py_round(py, 3) };
+        if (e->agent_dq_len < 2) e->agent_dq[e->agent_dq_len++] = p;
+        else { e->agent_dq[0] = e->agent_dq[1]; e->agent_dq[1] = p; }
+    }
+    /* RW:239-247: obstacle regions / per-ray deques -- results never read.  RW:249-266: keep the rays that are not free space */
+    int F = 0;
+    for (int i = 0; i < n; ++i)
+        if (!(1.0 * MAXR <= scan[i] && scan[i] <= 1.0 * MAXR)) { fi[F] = i; fr[F] = scan[i]; ++F; }
+#define FPX(k) pts[2 * fi[k]]
+#define FPY(k) pts[2 * fi[k] + 1]
+    for (int i = 0; i < F; ++i) {                                          /* RW:268-282 gradients over the FILTERED list */
+        int j = (i == F - 1) ? 0 : i + 1;
+        double dy = FPY(i) - FPY(j);
+        double gr = (dy == 0) ? 0.0 : (FPX(i) - FPX(j)) / dy;
+        g[i] = cno_py_round(gr, 3);
+    }
+    {                                                                      /* RW:284-295 change of gradient */
+        int last_none = 1; double last = 0.0;
+        for (int i = 0; i < F; ++i) {
+            if (F == 1 || i == F - 1) { cnone[i] = last_none; cg[i] = last; }
+            else { double ch = fabs(g[i] - g[i + 1]); last = ch; last_none = 0; cnone[i] = 0; cg[i] = ch; }
+        }
+    }
+    {                                                                      /* RW:300-333 object-type machine */
+        int last_type = 0, last_src = -1, du = 0;
+        for (int i = 0; i < F; ++i) {
+            Ttype[i] = 0; Tsrc[i] = i;
+            if (i == F - 1) continue;
+            if (!cnone[i] && cg[i] == 0) { Ttype[i] = TY_W; last_type = TY_W; last_src = i; continue; }
+            int nz = !cnone[i + 1] && cg[i + 1] == 0;
+            if (du != 1) {
+                if (nz) { Ttype[i] = TY_W; last_type = TY_W; last_src = i; du = 0; }
+                else if (!cnone[i] && !cnone[i + 1] && fabs(cg[i] - cg[i + 1]) == 0) { Ttype[i] = TY_W; last_type = TY_W; last_src = i; du = 0; }
+                else { Ttype[i] = last_type; Tsrc[i] = last_src; du += 1; }   /* = last_type: carries THAT ray's range and pose */
+            } else {
+                Ttype[i] = TY_O; last_type = TY_O; last_src = i;
+                if (nz) du = 0;
+            }
+        }
+    }
+    /* RW:335-366: groups of consecutive typed entries (the last entry is never typed), flattened again */
+    int M = 0;
+    for (int i = 0; i + 1 < F; ++i)
+        if (Ttype[i] != 0) { et[M] = Ttype[i]; es[M] = Tsrc[i]; ed[M] = cno_py_round(fr[Tsrc[i]], 3); ++M; }
+#define EPX(k) FPX(es[k])
+#define EPY(k) FPY(es[k])
+    /* RW:368-403 segmentation by association of consecutive entries */
+    int nseg = 0;
+    for (int i = 0; i < M; ++i) {
+        if (i == M - 1) { segend[i] = 1; ++nseg; }                          /* both branches of RW:375-390 close the segment */
+        else if (cno_iou(EPX(i), EPY(i), EPX(i + 1), EPY(i + 1), e->bb) > 0.0) segend[i] = 0;
+        else { segend[i] = 1; ++nseg; }
+    }
+    /* RW:408-420: first and last segment joined (first ++ last) when their outer ends associate with twice the box */
+    int* order = tmp;          /* estimated index by position in the (possibly re-ordered) sequence */
+    int* oend = tmp + n;       /* hmm: tmp has n ints; use segend for the re-ordered ends instead */
+    (void)oend;
+    int merged = 0, first_end = -1, last_start = 0;
+    if (nseg > 1) {
+        for (int i = 0; i < M; ++i) if (segend[i]) { first_end = i; break; }
+        for (int i = M - 2; i >= 0; --i) if (segend[i]) { last_start = i + 1; break; }
+        if (cno_iou(EPX(0), EPY(0), EPX(M - 1), EPY(M - 1), e->bb * 2) > 0.0) merged = 1;
+    }
+    int L = 0;
+    if (merged) {
+        for (int i = 0; i <= first_end; ++i) order[L++] = i;
+        for (int i = last_start; i < M; ++i) order[L++] = i;
+        for (int i = first_end + 1; i < last_start; ++i) order[L++] = i;
+    } else for (int i = 0; i < M; ++i) order[L++] = i;
+    if (merged) nseg -= 1;
+    /* RW:426-468 confirmation */
+    int maxc = M + 1;
+    cobj_t* conf = (cobj_t*)malloc(sizeof(cobj_t) * (size_t)maxc);
+    int nconf = 0;
+    {
+        int k0 = 0;
+        while (k0 < L) {
+            int k1 = k0;                                                     /* [k0, k1]: one segment in `order` space */
+            if (merged && k0 == 0) k1 = first_end + (M - last_start);        /* the joined first segment */
+            else while (!segend[order[k1]]) ++k1;
+            int len = k1 - k0 + 1, no = 0, nw = 0;
+            for (int k = k0; k <= k1; ++k) { no += (et[order[k]] == TY_O); nw += (et[order[k]] == TY_W); }
+            int ce = order[k0 + len / 2];                                    /* Python-2 integer division */
+            double dm = ed[ce];
+            int est = cno_estimate_num_obs_scans(dm, c->max_scan_range, c->min_scan_range);
+            int mn = len < est ? len : est;
+            double score = (double)no / (double)mn;
+            int obj = -1;
+            if (no > 0 && nw > 0) {
+                if (score >= 0.5) obj = (no > nw) ? TY_O : TY_W;
+                else if (len <= est) obj = (no > nw) ? TY_O : TY_W;
+                else obj = TY_W;
+            } else {
+                int lim = nseg < est ? nseg : est;
+                if (len > lim) obj = (nw > 0) ? TY_W : TY_O;
+            }
+            if (obj >= 0) { conf[nconf].type = obj; conf[nconf].pose.x = EPX(ce); conf[nconf].pose.y = EPY(ce); conf[nconf].dist = dm; ++nconf; }
+            k0 = k1 + 1;
+        }
+    }
+    e->n_confirmed = nconf;
+    /* RW:478-571 tracker: the same block as ENV:656-743 */
+    tracker_update(e, conf, nconf, now, tmp);
+    for (int i = 0; i < e->ntracks; ++i) {                                   /* RW:573-589 */
+        track_t* t = &e->tracks[i];
+        if (t->dq_len > 1) t->speed = hypot(t->dq[0].y - t->dq[1].y, t->dq[0].x - t->dq[1].x) / t->t;
+    }
+    e->n_entries = 0;
+    if (e->agent_dq_len == 2) {                                              /* RW:595-700 */
+        double ts = e->agent_vel_timestep;
+        if (ts == 0.0) e->status |= ST_DT_ZERO;
+        double vx_ = (e->agent_dq[1].x - e->agent_dq[0].x) / ts, vy_ = (e->agent_dq[1].y - e->agent_dq[0].y) / ts;
+        double agent_vel = sqrt(pow(vx_, 2) + pow(vy_, 2));
+        double obstacle_vel = (e->ntracks == 0) ? 0.0 : e->tracks[0].speed;
+        double vo_x = e->agent_dq[1].x, vo_y = e->agent_dq[1].y;
+        for (int i = 0; i < e->ntracks; ++i) {
+            track_t* t = &e->tracks[i];
+            double chx = 0, chy = 0;
+            if (t->dq_len > 1) { chx = t->dq[0].x - t->dq[1].x; chy = t->dq[0].y - t->dq[1].y; t->vel.x = chx / ts; t->vel.y = chy / ts; }
+            vo_x = e->agent_dq[1].x + chx; vo_y = e->agent_dq[1].y + chy;
+        }
+        int ne = 0, best = -1; double bestcp = 0.0;
+        for (int i = 0; i < e->ntracks; ++i) {
+            track_t* t = &e->tracks[i];
+            double dcp;
+            int has = collision_point_impl(s->poly_c, s->poly_s, e->agent_dq[0].x, e->agent_dq[0].y, vo_x, vo_y, t->pose.x,
+                                           t->pose.y, c->min_scan_range, &dcp, c->geos_untyped_empty);   /* RW:637: radius = min_scan_range */
+            double rv = agent_vel - obstacle_vel;
+            double gcp = cno_general_collision_prob(t->dist, c->max_scan_range, c->min_scan_range);
+            double cpv;
+            if (has) {
+                if (rv == 0) cpv = 1.0 * gcp;
+                else {
+                    double ttc = dcp / rv;
+                    if (ttc == 0.0) { e->status |= ST_TTC_ZERO; cpv = 0.5 * 1.0 + 0.5 * gcp; }
+                    else cpv = 0.5 * cno_collision_prob(ttc) + 0.5 * gcp;
+                }
+            } else cpv = 0.5 * 0.0 + 0.5 * gcp;
+            e->entry_cp[ne] = cpv; e->entry_ego[ne] = 0.0;
+            if (ne == 0 || cpv >= bestcp) { bestcp = cpv; best = i; }          /* max((val, idx)): the LAST of equal maxima */
+            ++ne;
+        }
+        e->n_entries = ne;
+        if (ne == 0) e->collision_prob = 0.0;                                /* RW:663-666 */
+        else {
+            e->collision_prob = fmax(0.0, bestcp);                            /* RW:669 max(0.0, max(cp)) */
+            closest_pose = e->tracks[best].pose; closest_vel = e->tracks[best].vel;
+        }
+        /* RW:673-690 goal-reaching probability: computed, never read */
+        e->agent_dq[0] = e->agent_dq[1]; e->agent_dq_len = 1;              /* RW:693-699 */
+        for (int i = 0; i < e->ntracks; ++i) e->tracks[i].t = now;
+    }
+    for (int j = 0; j < nconf; ++j)                                          /* RW:702-706 */
+        if (conf[j].type == TY_O && conf[j].dist < 0.140) { e->ego_viol += 1; break; }
+    if (e->collision_prob > 0.4) e->social_viol += 1;                       /* RW:708 (None > 0.4 is False in Python 2) */
+    if (!e->done) {                                                          /* RW:715-728 */
+        double mn = scan[0];
+        for (int i = 1; i < n; ++i) if (scan[i] < mn) mn = scan[i];
+        if (mn < c->min_scan_range) e->done = 1;
+        if (in_box(px, py, c->goal_x, c->goal_y, 0.20)) e->done = 1;
+        if (step_counter >= c->max_steps) e->done = 1;
+    }
+    for (int i = 0; i < n; ++i) state[i] = scan[i];                          /* RW:730-747: nothing is rounded again */
+    state[n] = heading; state[n + 1] = distance_to_goal;
+    state[n + 2] = cno_py_round(px, 3); state[n + 3] = cno_py_round(py, 3);
+    state[n + 4] = cno_py_round(3.14, 3);                                    /* round(self.yaw, 3): the constructor's constant */
+    state[n + 5] = cno_py_round(agent_vel_x, 3); state[n + 6] = cno_py_round(agent_vel_y, 3);
+    state[n + 7] = closest_pose.x; state[n + 8] = closest_pose.y;
+    state[n + 9] = closest_vel.x; state[n + 10] = closest_vel.y;
+    *done_out = e->done;
+#undef FPX
+#undef FPY
+#undef EPX
+#undef EPY
+    free(conf);
+    free(scan);
+}
+
+/* RW:751-849: no way-point bonus; state[359] is the heading and state[360] the distance (labelled correctly here) */
+static double rw_compute_reward(const cno_sim* s, env_t* e, const double* state, double px, double py, int done)
+{
+    const cno_config* c = &s->cfg;
+    const int n = s->n;
+    double cur_head = state[n], cur_dist = state[n + 1];
+    double dd = cur_dist - e->prev_dist, hd = cur_head - e->prev_head;
+    int htg = 0, dtg = 0;
+    if (dd < 0) dtg = 1;
+    double ph = e->prev_head;
+    if (hd > 0) {
+        if (cur_head > 0 && ph < 0) htg = 1;
+        if (cur_head < 0 && ph < 0) htg = 1;
+        if (cur_head < 0 && ph > 0) htg = 1;
+        if (cur_head > 0 && ph > 0) htg = 0;
+    }
+    if (hd < 0) {
+        if (cur_head < 0 && ph > 0) htg = 1;
+        if (cur_head > 0 && ph > 0) htg = 1;
+        if (cur_head > 0 && ph < 0) htg = 1;
+        if (cur_head < 0 && ph < 0) htg = 0;
+    }
+    double reward = (double)(-2 + dtg + htg);
+    e->prev_dist = cur_dist; e->prev_head = cur_head;
+    if (done) {
+        if (in_box(px, py, c->goal_x, c->goal_y, 0.20)) { e->ep_failure = 0; e->ep_success = 1; reward = 200 + reward; }
+        else { e->ep_failure = 1; e->ep_success = 0; reward = -200 + reward; }
+    }
+    return reward;
+}
+
 static void env_init(const cno_sim* s, env_t* e)
 {
     const cno_config* c = &s->cfg;
@@ -1186,9 +1454,9 @@ static void env_init(const cno_sim* s, env_t* e)
     e->prev_dist = 0.0; e->prev_head = 0.0;
     e->done = 0;
     e->agent_dq_len = 0; e->agent_vel_timestep = 0.0;
-    e->bb = 0.0;
+    e->bb = (c->obs_layout == 2) ? 0.0210 : 0.0;                  /* RW:103 */
     e->ntracks = 0;
-    e->ego_score_cp = 0.0; e->collision_prob = 0.0;
+    e->ego_score_cp = 0.0; e->collision_prob = (c->obs_layout == 2) ? -INFINITY : 0.0;   /* RW:80 None: compares below any number in Python 2 */
     e->ego_viol = e->social_viol = e->obst_steps = 0;
     e->ep_success = e->ep_failure = 0;
     e->ep_step = 0; e->ep_return = 0.0; e->last_return = 0.0;
@@ -1210,6 +1478,10 @@ static void env_reset_flow(const cno_sim* s, env_t* e, int64_t gid, double* obs)
         e->prev_dist = dist3(e->rx, e->ry, c->goal_x, c->goal_y);  /* ORIG:472 (unrounded) */
         e->prev_head = orig_heading(c, e->rx, e->ry, e->ryaw);     /* ORIG:473 */
         orig_get_state(s, e, e->ranges, e->rx, e->ry, e->ryaw, 0, obs, &done);
+    } else if (c->obs_layout == 2) {                               /* RW:910-944 */
+        e->prev_dist = rw_distance(c, e->rx, e->ry);
+        e->prev_head = rw_heading(c, e->rx, e->ry, e->ryaw);
+        rw_get_state(s, e, e->ranges, e->rx, e->ry, e->ryaw, e->rv, e->rw, 0, e->clock, obs, &done);
     } else {
     e->prev_dist = dist3(e->rx, e->ry, e->wpx, e->wpy);           /* ENV:1243 (unrounded) */
     e->prev_head = heading_to_goal(c, e, e->rx, e->ry, e->ryaw);   /* ENV:1244 */
@@ -1233,6 +1505,12 @@ static void env_step_flow(const cno_sim* s, env_t* e, int64_t gid, double v, dou
     e->clock += (double)c->dt_ms / 1000.0;                         /* time.sleep(0.15) (ENV:1201) */
     sim_advance(s, e, gid, c->dt_ms);
     double end_timestep = e->clock - t0;                           /* ENV:1202 */
+    if (c->obs_layout == 2) {
+        /* RW:876-883: no sleep before the measurement, so end_timestep = 0 < 0.05 -> time.sleep(0.05 - 0) (the dt_ms of this
+         * layout) and `end_timestep += 0.05 - end_timestep + 0.1`: the command is held 0.05 s and booked as 0.15000000000000002 */
+        const double dts = (double)c->dt_ms / 1000.0;
+        end_timestep = 0.0 + ((dts - 0.0) + 0.1);
+    }
     v2 p = { cno_py_round(e->rx, 3), cno_py_round(e->ry, 3) };   /* ENV:1208 */
     if (e->agent_dq_len < 2) e->agent_dq[e->agent_dq_len++] = p;
     else { e->agent_dq[0] = e->agent_dq[1]; e->agent_dq[1] = p; }
@@ -1243,6 +1521,10 @@ static void env_step_flow(const cno_sim* s, env_t* e, int64_t gid, double v, dou
     if (c->obs_layout == 1) {                                      /* ORIG:404-454 */
         orig_get_state(s, e, e->ranges, e->rx, e->ry, e->ryaw, step_counter, obs, done);
         *reward = orig_compute_reward(s, e, obs, e->rx, e->ry, *done);
+        for (int k = 0; k < c->k_obstacles; ++k) topk_idx[k] = -1;
+    } else if (c->obs_layout == 2) {                               /* RW:898-901 */
+        rw_get_state(s, e, e->ranges, e->rx, e->ry, e->ryaw, e->rv, e->rw, step_counter, e->clock, obs, done);
+        *reward = rw_compute_reward(s, e, obs, e->rx, e->ry, *done);
         for (int k = 0; k < c->k_obstacles; ++k) topk_idx[k] = -1;
     } else {
     env_get_state(s, e, e->ranges, e->rx, e->ry, e->ryaw, e->rv, e->rw, step_counter, e->clock, obs, done, topk_idx);
@@ -1281,8 +1563,8 @@ int cno_create(const cno_config* cfg, cno_sim** out)
     cno_sim* s = (cno_sim*)calloc(1, sizeof(cno_sim));
     s->cfg = *cfg;
     s->n = cfg->n_rays - 1;
-    if (cfg->obs_layout != 0 && cfg->obs_layout != 1) return -2;
-    s->D = cfg->obs_layout == 1 ? s->n + 4 : s->n + 7 + 4 * cfg->k_obstacles;
+    if (cfg->obs_layout < 0 || cfg->obs_layout > 2) return -2;
+    s->D = cfg->obs_layout == 1 ? s->n + 4 : (cfg->obs_layout == 2 ? s->n + 11 : s->n + 7 + 4 * cfg->k_obstacles);
     int R = cfg->n_rays, P = cfg->n_peds;
     s->lidar_c = (double*)malloc(sizeof(double) * 2 * R);
     s->lidar_s = s->lidar_c + R;
@@ -1458,6 +1740,26 @@ int cno_ext_call(cno_sim* s, int env, const cno_ext_in* in, const double* ranges
         } else {
             orig_get_state(s, e, ranges, in->px, in->py, in->yaw, in->step_counter, obs, &d);
             double r = orig_compute_reward(s, e, obs, in->px, in->py, d);
+            if (reward) *reward = r;
+        }
+        if (done) *done = (uint8_t)d;
+        for (int k = 0; k < c->k_obstacles; ++k) idx[k] = -1;
+        return 0;
+    }
+    if (c->obs_layout == 2) {
+        if (in->is_reset) {
+            e->prev_dist = rw_distance(c, in->px, in->py);
+            e->prev_head = rw_heading(c, in->px, in->py, in->yaw);
+            rw_get_state(s, e, ranges, in->px, in->py, in->yaw, in->v, in->w, 0, in->now, obs, &d);
+            e->social_viol = 0; e->ego_viol = 0;
+            if (reward) *reward = 0.0;
+        } else {
+            v2 p = { cno_py_round(in->deque_x, 3), cno_py_round(in->deque_y, 3) };
+            if (e->agent_dq_len < 2) e->agent_dq[e->agent_dq_len++] = p;
+            else { e->agent_dq[0] = e->agent_dq[1]; e->agent_dq[1] = p; }
+            e->agent_vel_timestep = in->end_timestep;
+            rw_get_state(s, e, ranges, in->px, in->py, in->yaw, in->v, in->w, in->step_counter, in->now, obs, &d);
+            double r = rw_compute_reward(s, e, obs, in->px, in->py, d);
             if (reward) *reward = r;
         }
         if (done) *done = (uint8_t)d;

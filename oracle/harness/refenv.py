@@ -404,3 +404,31 @@ class HarnessOriginal(Harness):
         e = self.env
         return dict(status=(bool(e.episode_success), bool(e.episode_failure)),
                     prev=(float(e.previous_distance), float(e.previous_heading)))
+
+
+class HarnessRealworld(Harness):
+    """The same harness around environment_stage_1_nobonus_realworld.py (the 370-input physical-robot variant).
+    One Python-2 semantic is supplied by hand: `self.collision_prob = None` (RW:80) is compared with `> 0.4` at RW:708 before it
+    is ever assigned; Python 2 orders None below every number (the comparison is False), Python 3 raises -- so the attribute
+    starts as -inf here, which compares the same way and is never read otherwise."""
+    ENV_MODULE = "environment_stage_1_nobonus_realworld"
+
+    def _after_env(self, c):
+        self.env.collision_prob = float("-inf")
+        self._wrap_get_state()
+
+    def snapshot(self):
+        e = self.env
+        tr = list(e.tracked_obstacles.values())
+        return dict(
+            n_tracks=len(tr),
+            track_pose=np.array([t[1] for t in tr], dtype=np.float64).reshape(-1, 2),
+            track_dist=np.array([t[2] for t in tr], dtype=np.float64),
+            track_speed=np.array([t[5] for t in tr], dtype=np.float64),
+            track_vel=np.array([t[6] for t in tr], dtype=np.float64).reshape(-1, 2),
+            collision_prob=float(e.collision_prob),
+            counters=(int(e.ego_safety_violation_count), int(e.social_safety_violation_count)),
+            bb=float(e.bounding_box_size),
+            status=(bool(e.episode_success), bool(e.episode_failure)),
+            prev=(float(e.previous_distance), float(e.previous_heading)),
+        )

@@ -18,7 +18,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import oracle  # noqa: E402
-from oracle.harness.refenv import Harness, HarnessOriginal  # noqa: E402
+from oracle.harness.refenv import Harness, HarnessOriginal, HarnessRealworld  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
 MAXT = 24
@@ -134,6 +134,62 @@ def gen_seq_original(name, kw, episodes, arange):
     print("%-10s calls=%4d  done=%d (success %d)  %.0f KB" % (name, len(arrs["done"]), int(arrs["done"].sum()),
                                                               int(sum(1 for i in range(len(arrs["done"])) if arrs["done"][i] and arrs["status"][i][0])),
                                                               os.path.getsize(path) / 1024))
+
+
+RW_CONFIGS = {
+    # environment_stage_1_nobonus_realworld.py (obs_layout 2, 370 inputs): Env.step holds a command for 0.05 s (RW:880-883)
+    "rw20": (dict(n_peds=20, max_steps=250, seed=31, obs_layout=2, dt_ms=50), 5, (0.0, 0.22, -2.0, 2.0)),
+    "rw60": (dict(n_peds=60, max_steps=200, seed=32, obs_layout=2, dt_ms=50, min_scan_range=0.0, room_half=1.8), 3,
+             (0.05, 0.22, -1.0, 1.0)),
+}
+
+
+def gen_seq_realworld(name, kw, episodes, arange):
+    """Sequence goldens of the 370-input environment: what Gazebo/ROS handed get_state and what the reference returned
+    (obs[370], reward, done, counters, track table, collision probability, bbox size, previous distance / heading)."""
+    sim = oracle.Oracle(n_envs=1, **kw)
+    h = HarnessRealworld(sim)
+    rng = np.random.default_rng(kw["seed"])
+    cols = {k: [] for k in ("ranges", "px", "py", "yaw", "v", "w", "now", "step_counter", "is_reset", "deque_x", "deque_y",
+                            "end_timestep", "action", "obs", "reward", "done", "counters", "n_tracks", "track_pose",
+                            "track_dist", "track_speed", "track_vel", "collision_prob", "bb", "status", "prev")}
+
+    def push(rec, action, obs, reward, done):
+        snap = h.snapshot()
+        for k in ("ranges", "px", "py", "yaw", "v", "w", "now", "step_counter", "is_reset", "deque_x", "deque_y", "end_timestep"):
+            cols[k].append(rec[k])
+        cols["action"].append(action); cols["obs"].append(obs); cols["reward"].append(reward); cols["done"].append(done)
+        n = snap["n_tracks"]
+        assert n <= MAXT, n
+
+        def pad(a, shape):
+            out = np.zeros(shape); out[:n] = a
+            return out
+        cols["counters"].append(snap["counters"]); cols["n_tracks"].append(n)
+        cols["track_pose"].append(pad(snap["track_pose"], (MAXT, 2))); cols["track_dist"].append(pad(snap["track_dist"], (MAXT,)))
+        cols["track_speed"].append(pad(snap["track_speed"], (MAXT,))); cols["track_vel"].append(pad(snap["track_vel"], (MAXT, 2)))
+        cols["collision_prob"].append(snap["collision_prob"]); cols["bb"].append(snap["bb"])
+        cols["status"].append(snap["status"]); cols["prev"].append(snap["prev"])
+
+    for ep in range(episodes):
+        obs = h.reset()
+        push(h.trace[-1], (0.0, 0.0), obs, 0.0, False)
+        for st in range(kw["max_steps"]):
+            a = (float(np.float32(rng.uniform(arange[0], arange[1]))), float(np.float32(rng.uniform(arange[2], arange[3]))))
+            obs, r, d = h.step(a, st + 1)
+            push(h.trace[-1], a, obs, r, d)
+            if d:
+                break
+    arrs = {k: np.asarray(v) for k, v in cols.items()}
+    arrs["ped_init"] = sim.get_ped_init()
+    arrs["config_keys"] = np.array(sorted(kw.keys()))
+    arrs["config_vals"] = np.array([float(kw[k]) for k in sorted(kw.keys())])
+    path = os.path.join(OUT, "seq_%s.npz" % name)
+    np.savez_compressed(path, **arrs)
+    nt = arrs["n_tracks"]
+    print("%-10s calls=%4d  tracks mean %.2f max %d  done=%d (success %d)  %.0f KB" % (
+        name, len(nt), nt.mean(), nt.max(), int(arrs["done"].sum()),
+        int(sum(1 for i in range(len(nt)) if arrs["done"][i] and arrs["status"][i][0])), os.path.getsize(path) / 1024))
 
 
 def gen_func():
@@ -271,5 +327,8 @@ if __name__ == "__main__":
     for name, (kw, eps, ar) in ORIG_CONFIGS.items():
         if not only or name in only:
             gen_seq_original(name, kw, eps, ar)
+    for name, (kw, eps, ar) in RW_CONFIGS.items():
+        if not only or name in only:
+            gen_seq_realworld(name, kw, eps, ar)
     if not only or "func" in only:
         gen_func()

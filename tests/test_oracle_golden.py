@@ -217,3 +217,50 @@ def test_original_layout_full_simulation_reproduces_reference_run(oracle_mod, na
             obs = obs[0]
             assert r[0] == z["reward"][i] and bool(d[0]) == bool(z["done"][i]), (name, i)
         assert np.array_equal(obs, z["obs"][i]), (name, i)
+
+
+# ---- obs_layout 2: environment_stage_1_nobonus_realworld.py (370 inputs), SURVEY 8f N3 ------------------------
+RW_SEQS = ["rw20", "rw60"]
+
+
+@pytest.mark.parametrize("name", RW_SEQS)
+def test_realworld_layout_replay_bit_exact(oracle_mod, name):
+    """get_state / compute_reward of environment_stage_1_nobonus_realworld.py on the recorded /scan + /odom (RW:208-849):
+    observation (unrounded ranges, the one highest-CP obstacle), reward, done, safety counters, the track table, the
+    collision probability, bbox size, previous distance / heading."""
+    z, kw = load_seq(name)
+    o = oracle_mod.Oracle(n_envs=1, **kw)
+    assert o.D == 370
+    for i in range(len(z["now"])):
+        inp = {k: (int(z[k][i]) if k in ("step_counter", "is_reset") else float(z[k][i])) for k in IN_KEYS}
+        obs, r, d, idx = o.ext_call(0, z["ranges"][i], **inp)
+        if inp["is_reset"]:
+            o.ext_set_done(0, False)
+        else:
+            assert r == z["reward"][i] and d == bool(z["done"][i]), (name, i, r, z["reward"][i])
+        assert np.array_equal(obs, z["obs"][i]), (name, i, np.nonzero(obs != z["obs"][i])[0][:8])
+        dbg = o.debug(0)
+        n = int(z["n_tracks"][i])
+        assert dbg["n_tracks"] == n, (name, i)
+        assert np.array_equal(dbg["track_pose"], z["track_pose"][i][:n]) and np.array_equal(dbg["track_dist"], z["track_dist"][i][:n])
+        assert np.array_equal(dbg["track_speed"], z["track_speed"][i][:n]) and np.array_equal(dbg["track_vel"], z["track_vel"][i][:n])
+        assert dbg["collision_prob"] == z["collision_prob"][i] and dbg["bb"] == z["bb"][i], (name, i)
+        assert tuple(o.counters()[0][:2]) == tuple(z["counters"][i]), (name, i)
+        c = o.counters()[0]
+        assert (bool(c[4]), bool(c[5])) == tuple(bool(x) for x in z["status"][i]), (name, i)
+    assert z["end_timestep"][1] == 0.15000000000000002          # RW:880-883: 0.05 s held, 0.15 s booked
+
+
+@pytest.mark.parametrize("name", RW_SEQS)
+def test_realworld_layout_full_simulation_reproduces_reference_run(oracle_mod, name):
+    z, kw = load_seq(name)
+    o = oracle_mod.Oracle(n_envs=1, **kw)
+    o.set_ped_init(z["ped_init"])
+    for i in range(len(z["now"])):
+        if z["is_reset"][i]:
+            obs = o.reset()[0]
+        else:
+            obs, r, d, _ = o.step(z["action"][i][None, :], step_counter=[int(z["step_counter"][i])])
+            obs = obs[0]
+            assert r[0] == z["reward"][i] and bool(d[0]) == bool(z["done"][i]), (name, i)
+        assert np.abs(obs - z["obs"][i]).max() <= 1e-9, (name, i, np.abs(obs - z["obs"][i]).max())
