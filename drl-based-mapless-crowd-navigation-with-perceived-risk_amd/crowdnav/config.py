@@ -36,7 +36,8 @@ class Config:
     ped_cycle_ms: int = 0          # 0 -> 100 ms x n_peds (CROWD:128-144)
     ped_stagger_ms: int = 100      # CROWD:144
     track_capacity: int = 0        # tracker slots per env: 0 = auto (32 up to 40 pedestrians, else 64)
-    obs_layout: int = 0            # 0: environment_stage_1_nobonus (366 + 4K); 1: environment_stage_1_original (R-1 + 4)
+    obs_layout: int = 0            # 0: environment_stage_1_nobonus (366 + 4K); 1: environment_stage_1_original (R-1 + 4);
+                                   # 2: environment_stage_1_nobonus_realworld (R-1 + 11; use dt_ms=50, RW:880-883)
     geos_untyped_empty: int = 0    # 1: shapely <= 1.7 / GEOS <= 3.8 empty-result semantics at UTL:279,306 (the reference's platform)
     ped_contact: int = 0           # 1: frictionless rigid contact between pedestrians and with the robot (WORLD:86-145)
     risk_mode: int = 0             # 0: lidar segmentation + tracker (the reference); 1: "gt" -- simulator pedestrians
@@ -79,4 +80,6 @@ class Config:
     def obs_dim(self):
         if self.obs_layout == 1:
             return (self.n_rays - 1) + 4                        # ORIG:315-320 (363 at 360 rays)
+        if self.obs_layout == 2:
+            return (self.n_rays - 1) + 11                       # RW:730-747 (370 at 360 rays)
         return (self.n_rays - 1) + 7 + 4 * self.k_obstacles   # ENV:1038-1039, TRAIN:88

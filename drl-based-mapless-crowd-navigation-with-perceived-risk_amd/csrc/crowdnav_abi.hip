@@ -23,6 +23,9 @@ extern "C" __global__ void cn_env_kernel_ct(CnKParams p);
 extern "C" __global__ void cn_env_kernel_ct_same(CnKParams p);
 extern "C" __global__ void cn_env_kernel_gt_ct(CnKParams p);
 extern "C" __global__ void cn_env_kernel_gt_ct_same(CnKParams p);
+extern "C" __global__ void cn_env_kernel_rw(CnKParams p);
+extern "C" __global__ void cn_env_kernel_rw_same(CnKParams p);
+extern "C" __global__ void cn_env_kernel_rw_ext(CnKParams p);
 extern "C" __global__ void cn_env_kernel_orig(CnKParams p);
 extern "C" __global__ void cn_env_kernel_orig_ext(CnKParams p);
 extern "C" __global__ void cn_env_kernel_orig_same(CnKParams p);
@@ -65,7 +68,7 @@ static void destroy_handle(cn_env_s* h)
 }
 struct HandleDeleter { void operator()(cn_env_s* h) const { destroy_handle(h); } };
 
-static size_t lds_bytes_impl(int R, int P, int K, int max_conf, int trk_cap, bool near_separate)
+static size_t lds_bytes_impl(int R, int P, int K, int max_conf, int trk_cap, bool near_separate, int layout = 0)
 {
     // must mirror the carve in cn_env_kernel
     size_t n = (size_t)(R - 1), mc = (size_t)max_conf;
@@ -82,6 +85,7 @@ static size_t lds_bytes_impl(int R, int P, int K, int max_conf, int trk_cap, boo
     b += 8 * ((3 * Wn + 1) / 2);                  // wbase
     b += 8 * (size_t)(2 * P + 2) * 2;             // ped, pedv
     if (near_separate) b += 32 * (size_t)(P + 1); // near-pedestrian list in its own region
+    if (layout == CN_LAYOUT_REALWORLD) b = ((b + 15) & ~(size_t)15) + 12 * n + 16;   // filtered list, gradients, types (12 bytes per ray)
     return (b + 15) & ~(size_t)15;
 }
 
@@ -152,6 +156,9 @@ static int upload_initial_state(cn_env_s* h)
         double* s = &sd[(size_t)e * CN_SD_COUNT];
         s[CN_SD_RX] = c.spawn_x; s[CN_SD_RY] = c.spawn_y; s[CN_SD_RYAW] = c.spawn_yaw;
         s[CN_SD_WPX] = c.goal_x; s[CN_SD_WPY] = c.goal_y;
+        if (c.obs_layout == CN_LAYOUT_REALWORLD) {   // RW:80 `collision_prob = None` (below every number in Python 2), RW:103 bbox constant
+            s[CN_SD_CPROB] = -INFINITY; s[CN_SD_BB] = 0.0210;
+        }
     }
     HIPCHK(hipMemset(h->d_state, 0, (size_t)N * h->stride));
     FIELD(field_to_device(h, CN_ST_OFF_SD, sd.data(), CN_SD_COUNT * 8));
@@ -172,9 +179,11 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
     if (c.n_envs < 1 || c.n_peds < 0 || c.n_peds > 4096 || c.n_rays < 8 || c.n_rays > 1025 || c.k_obstacles < 1 ||
         c.k_obstacles > CN_MAX_K || c.ped_cycle_ms < 1 || c.dt_ms < 1 || c.scan_latency_ms < 1 || c.settle_ms < 0 ||
         c.max_steps < 1 || !(c.track_capacity == 0 || c.track_capacity == 32 || c.track_capacity == 64) ||
-        !(c.obs_layout == CN_LAYOUT_RISK || c.obs_layout == CN_LAYOUT_ORIGINAL) ||
+        !(c.obs_layout == CN_LAYOUT_RISK || c.obs_layout == CN_LAYOUT_ORIGINAL || c.obs_layout == CN_LAYOUT_REALWORLD) ||
         !(c.geos_untyped_empty == 0 || c.geos_untyped_empty == 1) || !(c.ped_contact == 0 || c.ped_contact == 1) ||
         !(c.risk_mode == CN_RISK_LIDAR_TRACKER || c.risk_mode == CN_RISK_GT))
+        return fail(CN_ERR_CONFIG, "cn_create: config out of range");
+    if (c.obs_layout == CN_LAYOUT_REALWORLD && (c.n_rays - 1 > 65535 / 2))
         return fail(CN_ERR_CONFIG, "cn_create: config out of range");
     if (c.risk_mode == CN_RISK_GT && c.obs_layout != CN_LAYOUT_RISK)
         return fail(CN_ERR_CONFIG, "cn_create: risk_mode gt needs the risk observation layout (obs_layout 0)");
@@ -189,10 +198,10 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
     h->cfg = c;
     h->device = device;
     const int N = c.n_envs, P = c.n_peds, R = c.n_rays, K = c.k_obstacles;
-    h->D = c.obs_layout == CN_LAYOUT_ORIGINAL ? (R - 1) + 4 : (R - 1) + 7 + 4 * K;
+    h->D = c.obs_layout == CN_LAYOUT_ORIGINAL ? (R - 1) + 4 : (c.obs_layout == CN_LAYOUT_REALWORLD ? (R - 1) + 11 : (R - 1) + 7 + 4 * K);
     h->max_conf = (R - 1) / 4 + 2;
     h->trk_cap = c.track_capacity ? c.track_capacity : (P <= 40 ? 32 : 64);
-    h->lds = cn_lds_bytes(R, P, K, h->max_conf, h->trk_cap);
+    h->lds = lds_bytes_impl(R, P, K, h->max_conf, h->trk_cap, cn_near_separate(R, P, K, h->max_conf, h->trk_cap) != 0, c.obs_layout);
     if (c.ped_contact && c.obs_layout != CN_LAYOUT_RISK)
         return fail(CN_ERR_CONFIG, "cn_create: ped_contact is built for the risk observation layout (obs_layout 0) only");
     if (c.ped_contact && 32 * (size_t)P > 16 * (size_t)(R - 1))   // contact corrections: 4 doubles per pedestrian in LDS regions A + B
@@ -264,6 +273,9 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
         HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_gt_ct_same, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
         HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_gt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
         HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_gt_same, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
+        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_rw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
+        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_rw_same, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
+        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_rw_ext, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
         HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_orig, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
         HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_orig_ext, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
         HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_orig_same, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
@@ -321,7 +333,14 @@ extern "C" int cn_set_ped_preset_vel(cn_handle h, const double* vxy)
 static int launch(cn_handle h, const CnKParams& kp, hipStream_t st)
 {
     DeviceScope scope(h->device);
-    if (h->cfg.obs_layout == CN_LAYOUT_ORIGINAL) {
+    if (h->cfg.obs_layout == CN_LAYOUT_REALWORLD) {
+        if (kp.mode == CN_MODE_EXT_STEP || kp.mode == CN_MODE_EXT_RESET)
+            hipLaunchKernelGGL(cn_env_kernel_rw_ext, dim3(kp.N), dim3(64), h->lds, st, kp);
+        else if (kp.mode == CN_MODE_STEP && kp.auto_reset == 1)
+            hipLaunchKernelGGL(cn_env_kernel_rw_same, dim3(kp.N), dim3(64), h->lds, st, kp);
+        else
+            hipLaunchKernelGGL(cn_env_kernel_rw, dim3(kp.N), dim3(64), h->lds, st, kp);
+    } else if (h->cfg.obs_layout == CN_LAYOUT_ORIGINAL) {
         if (kp.mode == CN_MODE_EXT_STEP || kp.mode == CN_MODE_EXT_RESET)
             hipLaunchKernelGGL(cn_env_kernel_orig_ext, dim3(kp.N), dim3(64), h->lds, st, kp);
         else if (kp.mode == CN_MODE_STEP && kp.auto_reset == 1)

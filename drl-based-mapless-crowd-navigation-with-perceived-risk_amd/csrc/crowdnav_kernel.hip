@@ -628,6 +628,118 @@ __device__ __forceinline__ double bbox_size(KP p, double* stage, int lane, int n
     return sum / (double)n;
 }
 
+// ---- ENV:656-743 tracker (the same block is RW:478-571), on the confirmed objects L.cfx / cfy / cfd / cft [nconf] ----------
+#define TRK(f, i) T[(f) * L.tcap + (i)]
+__device__ __forceinline__ void tracker_stage(KP p, EnvRegs& e, const Lds& L, double* const T, int lane, int nconf, double now)
+{
+    // ---- ENV:656-743 tracker -----------------------------------------------------------------------
+    // The tracker table shares LDS with the end-point arrays (dead from here on): bring it in now.
+    if (lane < e.ntracks) {
+#pragma unroll
+        for (int f = 0; f < CN_TF_COUNT; ++f) T[f * L.tcap + lane] = L.gtrk[lane * CN_TF_COUNT + f];  // HBM: one 96-byte record per track
+    }
+    CN_SYNC();
+    bool add_unchecked = false;
+    if (CN_ABLATE(16)) { e.ntracks = 0; nconf = 0; }
+    if (e.ntracks == 0) {
+        for (int j = lane; j < nconf; j += 64) L.checked[j] = 0;
+        add_unchecked = true;  // every 'o' object becomes a track
+    } else {
+        const int nt0 = e.ntracks;
+        if (lane < nt0 && TRK(CN_TF_DQLEN, lane) > 1.0) {  // ENV:678-680 popleft
+            TRK(CN_TF_D0X, lane) = TRK(CN_TF_D1X, lane); TRK(CN_TF_D0Y, lane) = TRK(CN_TF_D1Y, lane);
+            TRK(CN_TF_DQLEN, lane) = 1.0;
+        }
+        for (int j = lane; j < nconf; j += 64) L.checked[j] = 0;
+        CN_SYNC();
+        if (nconf == 0) {
+            e.ntracks = 0;  // ENV:683-686 nets out to clearing every track
+        } else {
+            unsigned long long alive = 0ull;
+            int cur = nt0;
+            // ENV:688-700: every track against every confirmed object (walls included), arg-max with the first maximum
+            // winning (list.index(max)).  Tiled 8 tracks x 8 objects per pass, lane = track * 8 + object: a lane keeps the
+            // best of ITS objects across the object tiles (ascending index, strict >), the 8 lanes of a track then reduce
+            // with the lower index winning ties.  One pass in the usual case; a crowded env (> 8 tracks or objects) pays
+            // ceil(nt / 8) * ceil(nconf / 8) passes instead of one serial wave-wide arg-max per track -- and a launch
+            // lasts as long as its most crowded env.
+            int mybj = 0; bool mymatch = false;                      // lane = track
+            for (int t0 = 0; t0 < nt0; t0 += 8) {
+                const int ti = t0 + (lane >> 3);
+                double best = -1.0; int bj = 0x7fffffff;
+                if (ti < nt0) {
+                    const double tx = TRK(CN_TF_PX, ti), ty_ = TRK(CN_TF_PY, ti);
+                    for (int oj = lane & 7; oj < nconf; oj += 8) {
+                        const double u = cn_iou3(tx, ty_, L.cfx[oj], L.cfy[oj], 0.0505);
+                        if (u > best) { best = u; bj = oj; }
+                    }
+                }
+#pragma unroll
+                for (int m = 4; m >= 1; m >>= 1) {
+                    double ob = cn_shfl_xor_d(best, m);
+                    int ojx = __shfl_xor(bj, m, 64);
+                    if (ob > best || (ob == best && ojx < bj)) { best = ob; bj = ojx; }
+                }
+                const u64 posm = __ballot(best > 0.0);             // bit 8 g (any lane of group g): track t0 + g matched
+                const int wb = __shfl(bj, (lane & 7) * 8, 64);     // lane t0 + g <- group g's winner
+                if ((lane >> 3) == (t0 >> 3)) { mybj = wb; mymatch = ((posm >> (8 * (lane & 7))) & 1ull) != 0ull; }
+            }
+            const u64 matchm = __ballot(mymatch && lane < nt0);
+            for (int i = 0; i < nt0; ++i) {                         // ENV:702-717, the order-dependent part (scalar)
+                if ((matchm >> i) & 1ull) alive |= (1ull << i);
+                else if (cur > i) cur -= 1;
+                else alive |= (1ull << i);
+            }
+            if (lane < nt0 && ((matchm >> lane) & 1ull)) {          // ENV:702-712
+                const int i = lane;
+                double cxj = L.cfx[mybj], cyj = L.cfy[mybj];
+                TRK(CN_TF_PX, i) = cxj; TRK(CN_TF_PY, i) = cyj; TRK(CN_TF_DIST, i) = L.cfd[mybj];
+                if (TRK(CN_TF_DQLEN, i) < 1.5) { TRK(CN_TF_D1X, i) = cxj; TRK(CN_TF_D1Y, i) = cyj; TRK(CN_TF_DQLEN, i) = 2.0; }
+                TRK(CN_TF_T, i) = now - TRK(CN_TF_T, i);
+                L.checked[mybj] = 1;
+            }
+            CN_SYNC();
+            // compact the survivors, order preserved
+            double rec[CN_TF_COUNT];
+            bool mine = (lane < nt0) && ((alive >> lane) & 1ull);
+            if (mine) {
+#pragma unroll
+                for (int f = 0; f < CN_TF_COUNT; ++f) rec[f] = TRK(f, lane);
+            }
+            CN_SYNC();
+            if (mine) {
+                int slot = __popcll(alive & ((1ull << lane) - 1ull));
+#pragma unroll
+                for (int f = 0; f < CN_TF_COUNT; ++f) TRK(f, slot) = rec[f];
+            }
+            e.ntracks = __popcll(alive);
+            add_unchecked = true;  // ENV:723-743
+        }
+    }
+    CN_SYNC();
+    if (add_unchecked) {
+        for (int j0 = 0; j0 < nconf; j0 += 64) {
+            int j = j0 + lane;
+            bool want = (j < nconf) && !L.checked[j] && (L.cft[j] == TY_O);
+            unsigned long long m = __ballot(want);
+            int slot = e.ntracks + __popcll(m & ((1ull << lane) - 1ull));
+            if (want) {
+                if (slot < L.tcap) {
+                    double cxj = L.cfx[j], cyj = L.cfy[j];
+                    TRK(CN_TF_PX, slot) = cxj; TRK(CN_TF_PY, slot) = cyj; TRK(CN_TF_DIST, slot) = L.cfd[j];
+                    TRK(CN_TF_D0X, slot) = cxj; TRK(CN_TF_D0Y, slot) = cyj; TRK(CN_TF_D1X, slot) = 0.0; TRK(CN_TF_D1Y, slot) = 0.0;
+                    TRK(CN_TF_T, slot) = now; TRK(CN_TF_SPEED, slot) = -1.0;
+                    TRK(CN_TF_VX, slot) = 0.0; TRK(CN_TF_VY, slot) = 0.0; TRK(CN_TF_DQLEN, slot) = 1.0;
+                }
+            }
+            int total = e.ntracks + __popcll(m);
+            if (total > L.tcap) { e.status |= CN_ST_TRACK_OVERFLOW; total = L.tcap; }
+            e.ntracks = total;
+        }
+    }
+    CN_SYNC();
+}
+
 template <bool EXT, bool GT = false>
 __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const Lds& L, int env, int lane, int step_counter,
                         float* obs32, float* fin32, double* obs64, int* done_out, bool have_tg = false, Trig tg = Trig{0.0, 0.0, 0.0, 0.0})
@@ -1112,113 +1224,7 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
     if (n_obst > 0) e.obst_steps += 1;
 
     CN_T(13);
-    // ---- ENV:656-743 tracker -----------------------------------------------------------------------
-    // The tracker table shares LDS with the end-point arrays (dead from here on): bring it in now.
-    if (lane < e.ntracks) {
-#pragma unroll
-        for (int f = 0; f < CN_TF_COUNT; ++f) T[f * L.tcap + lane] = L.gtrk[lane * CN_TF_COUNT + f];  // HBM: one 96-byte record per track
-    }
-    CN_SYNC();
-#define TRK(f, i) T[(f) * L.tcap + (i)]
-    bool add_unchecked = false;
-    if (CN_ABLATE(16)) { e.ntracks = 0; nconf = 0; }
-    if (e.ntracks == 0) {
-        for (int j = lane; j < nconf; j += 64) L.checked[j] = 0;
-        add_unchecked = true;  // every 'o' object becomes a track
-    } else {
-        const int nt0 = e.ntracks;
-        if (lane < nt0 && TRK(CN_TF_DQLEN, lane) > 1.0) {  // ENV:678-680 popleft
-            TRK(CN_TF_D0X, lane) = TRK(CN_TF_D1X, lane); TRK(CN_TF_D0Y, lane) = TRK(CN_TF_D1Y, lane);
-            TRK(CN_TF_DQLEN, lane) = 1.0;
-        }
-        for (int j = lane; j < nconf; j += 64) L.checked[j] = 0;
-        CN_SYNC();
-        if (nconf == 0) {
-            e.ntracks = 0;  // ENV:683-686 nets out to clearing every track
-        } else {
-            unsigned long long alive = 0ull;
-            int cur = nt0;
-            // ENV:688-700: every track against every confirmed object (walls included), arg-max with the first maximum
-            // winning (list.index(max)).  Tiled 8 tracks x 8 objects per pass, lane = track * 8 + object: a lane keeps the
-            // best of ITS objects across the object tiles (ascending index, strict >), the 8 lanes of a track then reduce
-            // with the lower index winning ties.  One pass in the usual case; a crowded env (> 8 tracks or objects) pays
-            // ceil(nt / 8) * ceil(nconf / 8) passes instead of one serial wave-wide arg-max per track -- and a launch
-            // lasts as long as its most crowded env.
-            int mybj = 0; bool mymatch = false;                      // lane = track
-            for (int t0 = 0; t0 < nt0; t0 += 8) {
-                const int ti = t0 + (lane >> 3);
-                double best = -1.0; int bj = 0x7fffffff;
-                if (ti < nt0) {
-                    const double tx = TRK(CN_TF_PX, ti), ty_ = TRK(CN_TF_PY, ti);
-                    for (int oj = lane & 7; oj < nconf; oj += 8) {
-                        const double u = cn_iou3(tx, ty_, L.cfx[oj], L.cfy[oj], 0.0505);
-                        if (u > best) { best = u; bj = oj; }
-                    }
-                }
-#pragma unroll
-                for (int m = 4; m >= 1; m >>= 1) {
-                    double ob = cn_shfl_xor_d(best, m);
-                    int ojx = __shfl_xor(bj, m, 64);
-                    if (ob > best || (ob == best && ojx < bj)) { best = ob; bj = ojx; }
-                }
-                const u64 posm = __ballot(best > 0.0);             // bit 8 g (any lane of group g): track t0 + g matched
-                const int wb = __shfl(bj, (lane & 7) * 8, 64);     // lane t0 + g <- group g's winner
-                if ((lane >> 3) == (t0 >> 3)) { mybj = wb; mymatch = ((posm >> (8 * (lane & 7))) & 1ull) != 0ull; }
-            }
-            const u64 matchm = __ballot(mymatch && lane < nt0);
-            for (int i = 0; i < nt0; ++i) {                         // ENV:702-717, the order-dependent part (scalar)
-                if ((matchm >> i) & 1ull) alive |= (1ull << i);
-                else if (cur > i) cur -= 1;
-                else alive |= (1ull << i);
-            }
-            if (lane < nt0 && ((matchm >> lane) & 1ull)) {          // ENV:702-712
-                const int i = lane;
-                double cxj = L.cfx[mybj], cyj = L.cfy[mybj];
-                TRK(CN_TF_PX, i) = cxj; TRK(CN_TF_PY, i) = cyj; TRK(CN_TF_DIST, i) = L.cfd[mybj];
-                if (TRK(CN_TF_DQLEN, i) < 1.5) { TRK(CN_TF_D1X, i) = cxj; TRK(CN_TF_D1Y, i) = cyj; TRK(CN_TF_DQLEN, i) = 2.0; }
-                TRK(CN_TF_T, i) = now - TRK(CN_TF_T, i);
-                L.checked[mybj] = 1;
-            }
-            CN_SYNC();
-            // compact the survivors, order preserved
-            double rec[CN_TF_COUNT];
-            bool mine = (lane < nt0) && ((alive >> lane) & 1ull);
-            if (mine) {
-#pragma unroll
-                for (int f = 0; f < CN_TF_COUNT; ++f) rec[f] = TRK(f, lane);
-            }
-            CN_SYNC();
-            if (mine) {
-                int slot = __popcll(alive & ((1ull << lane) - 1ull));
-#pragma unroll
-                for (int f = 0; f < CN_TF_COUNT; ++f) TRK(f, slot) = rec[f];
-            }
-            e.ntracks = __popcll(alive);
-            add_unchecked = true;  // ENV:723-743
-        }
-    }
-    CN_SYNC();
-    if (add_unchecked) {
-        for (int j0 = 0; j0 < nconf; j0 += 64) {
-            int j = j0 + lane;
-            bool want = (j < nconf) && !L.checked[j] && (L.cft[j] == TY_O);
-            unsigned long long m = __ballot(want);
-            int slot = e.ntracks + __popcll(m & ((1ull << lane) - 1ull));
-            if (want) {
-                if (slot < L.tcap) {
-                    double cxj = L.cfx[j], cyj = L.cfy[j];
-                    TRK(CN_TF_PX, slot) = cxj; TRK(CN_TF_PY, slot) = cyj; TRK(CN_TF_DIST, slot) = L.cfd[j];
-                    TRK(CN_TF_D0X, slot) = cxj; TRK(CN_TF_D0Y, slot) = cyj; TRK(CN_TF_D1X, slot) = 0.0; TRK(CN_TF_D1Y, slot) = 0.0;
-                    TRK(CN_TF_T, slot) = now; TRK(CN_TF_SPEED, slot) = -1.0;
-                    TRK(CN_TF_VX, slot) = 0.0; TRK(CN_TF_VY, slot) = 0.0; TRK(CN_TF_DQLEN, slot) = 1.0;
-                }
-            }
-            int total = e.ntracks + __popcll(m);
-            if (total > L.tcap) { e.status |= CN_ST_TRACK_OVERFLOW; total = L.tcap; }
-            e.ntracks = total;
-        }
-    }
-    CN_SYNC();
+    tracker_stage(p, e, L, T, lane, nconf, now);
     } else {
         // ---- risk_mode gt (SURVEY 7 "two risk-feature modes", include/crowdnav.h): rows A21-A24 fed with the simulator's own
         // pedestrians instead of tracked lidar blobs -- the north star's "K-nearest perceived-risk feature extraction".
@@ -1461,7 +1467,6 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
         e.dq0x = e.dq1x; e.dq0y = e.dq1y; e.dq_len = 1;
         if (!GT && lane < nt) TRK(CN_TF_T, lane) = now;
     }
-#undef TRK
     CN_T(16);
     // ENV:998-1005 safety counters
     if (ego_hit) e.ego_viol += 1;
@@ -1494,6 +1499,353 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
     }
     CN_SYNC();
     *done_out = e.done;
+}
+
+// ---- obs_layout 2: environment_stage_1_nobonus_realworld.py ("RW"), the 370-input physical-robot variant ------
+// 359 UNROUNDED sanitised ranges + heading + distance + rounded (x, y) + the constant yaw 3.14 + rounded twist features + pose and
+// velocity of the ONE tracked obstacle with the highest collision probability.  Its segmentation is an older pipeline than ENV's:
+// free-space rays are filtered out BEFORE the gradients (so neighbours are the next OCCUPIED rays), no way-points, the cone is cast
+// against a ring of radius min_scan_range, and the top-K rule is "the maximum, last index among ties".  This is the variant that
+// reads a physical lidar through cn_observe_external, one robot at a time: the lane-parallel parts are the ones that fall out for
+// free (ray cast, filter, gradients, association, tracker); the type machine and the confirmation walk their short lists on the
+// scalar unit.  L.rw*: the layout's own LDS region (12 bytes per ray).
+struct RwLds { unsigned short* fi; int* g; unsigned char* tt; unsigned short* ts; unsigned short* es; unsigned char* et; };
+
+__device__ __forceinline__ double rw_heading(KP p, double px, double py, double yaw)
+{   // RW:186-200 (starting_point added to the position)
+    double cx = px + p->start_x, cy = py + p->start_y;
+    double h = atan2(p->goal_y - cy, p->goal_x - cx) - yaw;
+    if (h > CN_PI) h -= 2 * CN_PI;
+    else if (h < -CN_PI) h += 2 * CN_PI;
+    return h;
+}
+__device__ __forceinline__ double rw_distance(KP p, double px, double py)
+{   // RW:161-173
+    return dist3(px + p->start_x, py + p->start_y, p->goal_x, p->goal_y);
+}
+
+template <bool EXT>
+__device__ __forceinline__ void observe_realworld(KP p, const Poly& pg, EnvRegs& e, const Lds& L, const RwLds& Q, int env, int lane,
+                                                  int step_counter, float* obs32, float* fin32, double* obs64, int* done_out)
+{
+    const int R = p->R, n = R - 1, D = n + 11;
+    const double MAXR = p->max_scan_range;
+    const double px = e.rx, py = e.ry, yaw = e.ryaw, v = e.rv, w = e.rw, now = e.clock;
+    const double distance_to_goal = cn_np_around2(rw_distance(p, px, py));      // RW:209
+    const double heading = cn_py_round2(rw_heading(p, px, py, yaw));            // RW:210
+    double sw_, cw_;
+    cn_det_sincos(w, &sw_, &cw_);
+    const double agent_vel_x = -1.0 * (v * cw_), agent_vel_y = v * sw_;         // RW:211-212
+    double clx = px, cly = py, clvx = 0.0, clvy = 0.0;                          // RW:215-216 closest obstacle pose / velocity
+
+    // ---- lidar + RW:220-225: sanitise, end points; the observation carries the UNROUNDED range ----------------------------------
+    double sy, cy;
+    cn_det_sincos(yaw, &sy, &cy);
+    const double ox = fma(p->lidar_offset_x, cy, px), oy = fma(p->lidar_offset_x, sy, py);
+    const double h = p->room_half;
+    const int nnear = near_peds(p, L, lane, ox, oy, sy, cy);
+    const bool wall_x = !(h - fabs(ox) > p->lidar_max + 1e-6);
+    const bool wall_y = !(h - fabs(oy) > p->lidar_max + 1e-6);
+    double smin = 1e300;
+    float* o32 = obs32 + (size_t)env * D;
+    float* f32 = fin32 ? fin32 + (size_t)env * D : nullptr;
+    double* o64 = obs64 ? obs64 + (size_t)env * D : nullptr;
+    for (int k = lane; k < R; k += 64) {
+        double lc = 0.0, ls = 0.0;
+        if (!EXT) { lc = p->lidar_c[k]; ls = p->lidar_s[k]; }
+        const double t = cast_ray<EXT>(p, L, env, k, ox, oy, sy, cy, nnear, wall_x, wall_y, lc, ls);
+        if (k >= 1) {
+            const int j = R - 1 - k;
+            double sc;
+            if (isinf(t) && t > 0) sc = MAXR;
+            else if (t != t) sc = 0.0;
+            else if (t == 0.0) sc = MAXR;
+            else if (t > MAXR) sc = MAXR;
+            else sc = t;
+            smin = fmin(smin, sc);
+            const double tS = p->ang_s[j], tC = p->ang_c[j];
+            const double sa = fma(tS, cy, -(tC * sy)), ca = fma(tC, cy, tS * sy);
+            L.ptx[j] = (int)cn_round_scaled(px + (sc * ca), 1000.0);
+            L.pty[j] = (int)cn_round_scaled(py + (sc * sa) * -1.0, 1000.0);
+            // bit 15: not a ground-truth (free-space) ray -- RW:249-255 tests the UNROUNDED range against max_scan_range
+            L.dmil[j] = (unsigned short)((int)cn_round_scaled(sc, 1000.0) | ((sc != MAXR) ? 0x8000 : 0));
+            o32[j] = (float)sc;
+            if (f32) f32[j] = (float)sc;
+            if (o64) o64[j] = sc;
+        }
+    }
+    smin = cn_wave_min_d(smin);
+    CN_SYNC();
+    if (step_counter == 0) {                                                    // RW:229-237
+        if (!EXT && p->bb_spawn_valid && px == p->spawn_x && py == p->spawn_y && yaw == p->spawn_yaw) e.bb = p->bb_spawn;
+        else e.bb = bbox_size(p, L.stage, lane, n, px, py, yaw);
+        double qx = cn_py_round3(px), qy = cn_py_round3(py);
+        if (e.dq_len < 2) { if (e.dq_len == 0) { e.dq0x = qx; e.dq0y = qy; } else { e.dq1x = qx; e.dq1y = qy; } e.dq_len += 1; }
+        else { e.dq0x = e.dq1x; e.dq0y = e.dq1y; e.dq1x = qx; e.dq1y = qy; }
+    }
+#define PX(i) cn_div1000((double)L.ptx[i])
+#define PY(i) cn_div1000((double)L.pty[i])
+    // ---- RW:257-266 the filtered list: rays that are not free space, in ray order -------------------------------------------------
+    int F = 0;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int i = i0 + lane;
+        const bool oc = (i < n) && (L.dmil[i] & 0x8000);
+        const u64 bo = __ballot(oc);
+        if (oc) Q.fi[F + __popcll(bo & ((1ull << lane) - 1ull))] = (unsigned short)i;
+        F += __popcll(bo);
+    }
+    CN_SYNC();
+    // ---- RW:268-282 gradients between CONSECUTIVE FILTERED end points (the last one against the first) ---------------------------
+    for (int c = lane; c < F; c += 64) {
+        const int i = Q.fi[c], j = Q.fi[(c == F - 1) ? 0 : c + 1];
+        const double dy = PY(i) - PY(j);
+        const double q = (dy == 0) ? 0.0 : (PX(i) - PX(j)) / dy;
+        Q.g[c] = (int)cn_round_scaled(q, 1000.0);
+    }
+    CN_SYNC();
+    // ---- RW:284-333 change of gradient + the object-type machine, on the scalar unit (F is a few dozen) --------------------------
+    // change c(i) = |g[i] - g[i+1]| for i < F-1 and c(F-1) = c(F-2) (`last_grad`); the machine never types entry F-1
+    if (lane == 0) {
+        int last_type = 0, last_src = 0, du = 0;
+        double c1 = (F >= 2) ? fabs(cn_div1000((double)Q.g[0]) - cn_div1000((double)Q.g[1])) : 0.0;   // c(0)
+        for (int i = 0; i + 1 < F; ++i) {
+            const double c0 = c1;                                                                     // c(i)
+            c1 = (i + 2 < F) ? fabs(cn_div1000((double)Q.g[i + 1]) - cn_div1000((double)Q.g[i + 2])) : c0;   // c(i+1); c(F-1) = c(F-2)
+            int ty, src = i;
+            if (c0 == 0) { ty = TY_W; last_type = TY_W; last_src = i; }
+            else if (du != 1) {
+                if (c1 == 0 || fabs(c0 - c1) == 0) { ty = TY_W; last_type = TY_W; last_src = i; du = 0; }
+                else { ty = last_type; src = last_src; du += 1; }        // = last_type: carries THAT entry's range and pose
+            } else {
+                ty = TY_O; last_type = TY_O; last_src = i;
+                if (c1 == 0) du = 0;
+            }
+            Q.tt[i] = (unsigned char)ty; Q.ts[i] = (unsigned short)src;
+        }
+        if (F >= 1) { Q.tt[F - 1] = 0; Q.ts[F - 1] = (unsigned short)(F - 1); }
+    }
+    CN_SYNC();
+    // ---- RW:335-366 the typed entries, flattened in order: type, source entry (its rounded range and pose travel with it) --------
+    int M = 0;
+    for (int i0 = 0; i0 + 1 < F; i0 += 64) {
+        const int i = i0 + lane;
+        const bool ok = (i + 1 < F) && (Q.tt[i] != 0);
+        const u64 bo = __ballot(ok);
+        if (ok) { const int m = M + __popcll(bo & ((1ull << lane) - 1ull)); Q.et[m] = Q.tt[i]; Q.es[m] = Q.ts[i]; }
+        M += __popcll(bo);
+    }
+    CN_SYNC();
+#define ERAY(m) ((int)Q.fi[Q.es[m]])
+    // ---- RW:368-403 segmentation: a segment closes after entry m unless m and m + 1 associate (bit words, entry space) -----------
+    u64* const segw = L.w64;                       // ceil(M / 64) words
+    const int Wm = (M + 63) >> 6;
+    int nseg = 0;
+    for (int q = 0; q < Wm; ++q) {
+        const int m = lane + 64 * q;
+        bool brk = false;
+        if (m < M) {
+            brk = true;
+            if (m < M - 1) { const int a = ERAY(m), b = ERAY(m + 1); brk = !cn_iou3_positive(PX(a), PY(a), PX(b), PY(b), e.bb); }
+        }
+        const u64 bw = __ballot(brk);
+        if (lane == 0) segw[q] = bw;
+        nseg += __popcll(bw);
+    }
+    CN_SYNC();
+    // RW:408-420 first ++ last when their outer ends associate with twice the box
+    bool merged = false; int first_end = -1, last_start = 0;
+    if (nseg > 1) {
+        for (int q = 0; q < Wm; ++q) { const u64 bw = uni64(segw[q]); if (bw) { first_end = 64 * q + __builtin_ctzll(bw); break; } }
+        for (int q = Wm - 1; q >= 0; --q) {
+            u64 bw = uni64(segw[q]);
+            if (q == Wm - 1) bw &= ~(1ull << ((M - 1) & 63));
+            if (bw) { last_start = 64 * q + 64 - __builtin_clzll(bw); break; }
+        }
+        const int a = ERAY(0), b = ERAY(M - 1);
+        merged = cn_iou3_positive(PX(a), PY(a), PX(b), PY(b), e.bb * 2);
+    }
+    if (merged) nseg -= 1;
+    // ---- RW:426-468 confirmation, one segment at a time (scalar unit); order space = [0..first_end] ++ [last_start..M-1] ++ rest ---
+    int nconf = 0;
+    {
+        const int nl = M - last_start;
+#define ORD(k) (merged ? ((k) <= first_end ? (k) : ((k) <= first_end + nl ? last_start + ((k) - first_end - 1) : (k) - nl)) : (k))
+        int k0 = 0;
+        while (k0 < M) {
+            int k1 = k0;
+            if (merged && k0 == 0) k1 = first_end + nl;
+            else { for (;;) { const int m = ORD(k1); if ((uni64(segw[m >> 6]) >> (m & 63)) & 1ull) break; ++k1; } }
+            const int len = k1 - k0 + 1;
+            int no = 0, nw = 0;
+            for (int k = k0 + lane; k <= k1; k += 64) { const int t_ = Q.et[ORD(k)]; no += (t_ == TY_O); nw += (t_ == TY_W); }
+            no = cn_wave_sum_i(no); nw = cn_wave_sum_i(nw);
+            const int ce = ORD(k0 + len / 2);                              // Python-2 integer division
+            const int ray = ERAY(ce);
+            const double dm = cn_div1000((double)(L.dmil[ray] & 0x7fff));
+            const int est = 3 + (int)floor(29 * (p->max_scan_range - dm) / (p->max_scan_range - p->min_scan_range));
+            const int mn = len < est ? len : est;
+            const double score = (double)no / (double)mn;
+            int obj = -1;
+            if (no > 0 && nw > 0) {
+                if (score >= 0.5) obj = (no > nw) ? TY_O : TY_W;
+                else if (len <= est) obj = (no > nw) ? TY_O : TY_W;
+                else obj = TY_W;
+            } else {
+                const int lim = nseg < est ? nseg : est;
+                if (len > lim) obj = (nw > 0) ? TY_W : TY_O;
+            }
+            if (obj >= 0) {
+                if (nconf < p->max_conf) { if (lane == 0) { L.cft[nconf] = obj; L.cfx[nconf] = PX(ray); L.cfy[nconf] = PY(ray); L.cfd[nconf] = dm; } nconf += 1; }
+                else e.status |= CN_ST_CONF_OVERFLOW;
+            }
+            k0 = k1 + 1;
+        }
+#undef ORD
+    }
+#undef ERAY
+#undef PX
+#undef PY
+    e.nconf = nconf;
+    CN_SYNC();
+    int ego_hit = 0;
+    for (int j = lane; j < nconf; j += 64) if (L.cft[j] == TY_O && L.cfd[j] < 0.140) ego_hit = 1;     // RW:702-706
+    ego_hit = __ballot(ego_hit != 0) != 0ull;
+    // ---- RW:478-589 tracker and speeds: the same block as ENV:656-760 -------------------------------------------------------------
+    double* const T = L.trk;
+    tracker_stage(p, e, L, T, lane, nconf, now);
+    if (lane < e.ntracks && TRK(CN_TF_DQLEN, lane) > 1.5) {
+        double dc = hypot(TRK(CN_TF_D0Y, lane) - TRK(CN_TF_D1Y, lane), TRK(CN_TF_D0X, lane) - TRK(CN_TF_D1X, lane));
+        TRK(CN_TF_SPEED, lane) = dc / TRK(CN_TF_T, lane);
+    }
+    CN_SYNC();
+    e.nent = 0;
+    // ---- RW:595-700 collision cone against a ring of radius min_scan_range; the obstacle with the highest CP (last among ties) ----
+    if (e.dq_len == 2) {
+        const double ts = e.ts;
+        if (ts == 0.0) e.status |= CN_ST_DT_ZERO;
+        const int nt = e.ntracks;
+        const double vx_ = (e.dq1x - e.dq0x) / ts, vy_ = (e.dq1y - e.dq0y) / ts;
+        const double agent_vel = sqrt(vx_ * vx_ + vy_ * vy_);
+        const double obstacle_vel = (nt == 0) ? 0.0 : TRK(CN_TF_SPEED, 0);
+        if (lane < nt && TRK(CN_TF_DQLEN, lane) > 1.5) {
+            double chx = TRK(CN_TF_D0X, lane) - TRK(CN_TF_D1X, lane), chy = TRK(CN_TF_D0Y, lane) - TRK(CN_TF_D1Y, lane);
+            TRK(CN_TF_VX, lane) = chx / ts; TRK(CN_TF_VY, lane) = chy / ts;
+        }
+        double vo_x = e.dq1x, vo_y = e.dq1y;
+        if (nt > 0) {
+            const int l = nt - 1;
+            double chx = 0.0, chy = 0.0;
+            if (TRK(CN_TF_DQLEN, l) > 1.5) { chx = TRK(CN_TF_D0X, l) - TRK(CN_TF_D1X, l); chy = TRK(CN_TF_D0Y, l) - TRK(CN_TF_D1Y, l); }
+            vo_x = e.dq1x + chx; vo_y = e.dq1y + chy;
+        }
+        CN_SYNC();
+        const double a0x = e.dq0x, a0y = e.dq0y;
+        const double gradient = (vo_y == 0.0) ? 0.0 : (vo_x - a0x) / vo_y - a0y;
+        const double bb0 = a0x - (gradient * a0y);
+        const int hi = (int)ceil(a0x + 3.5), lo = (int)floor(a0x - 3.5);
+        const double rv = agent_vel - obstacle_vel;
+        int best = -1; double bestcp = 0.0;
+        for (int i = 0; i < nt; ++i) {
+            const double tx = TRK(CN_TF_PX, i), ty_ = TRK(CN_TF_PY, i), td = TRK(CN_TF_DIST, i);
+            int has = 0; double dcp = 0.0;
+            for (int x2 = hi; x2 > lo; --x2) {
+                const double y2 = ((double)x2 * gradient) + bb0;
+                double hx = 0.0, hy = 0.0;
+                const u64 m = ring_segment(pg, lane, tx, ty_, p->min_scan_range, a0x, a0y, (double)x2, y2, &hx, &hy);
+                const int cnt = __popcll(m);
+                if (cnt == 0) { if (p->geos_untyped_empty) break; continue; }
+                if (cnt == 1) break;
+                const int l1 = __ffsll((long long)m) - 1, l2 = __ffsll((long long)(m & (m - 1ull))) - 1;
+                const double d1 = hypot(a0x - bcast_d(hx, l1), a0y - bcast_d(hy, l1));
+                const double d2 = hypot(a0x - bcast_d(hx, l2), a0y - bcast_d(hy, l2));
+                dcp = fmin(d1, d2); has = 1;
+                break;
+            }
+            const double gcp = (td > p->max_scan_range) ? 0.0 : (p->max_scan_range - td) / (p->max_scan_range - p->min_scan_range);
+            double cpv;
+            if (has) {
+                if (rv == 0) cpv = 1.0 * gcp;
+                else {
+                    const double ttc = dcp / rv;
+                    if (ttc == 0.0) { e.status |= CN_ST_TTC_ZERO; cpv = 0.5 * 1.0 + 0.5 * gcp; }
+                    else cpv = 0.5 * fmin(1.0, 0.15 / ttc) + 0.5 * gcp;
+                }
+            } else cpv = 0.5 * 0.0 + 0.5 * gcp;
+            if (i == 0 || cpv >= bestcp) { bestcp = cpv; best = i; }          // max((val, idx)): the LAST of equal maxima
+        }
+        e.nent = nt;
+        if (nt == 0) e.cprob = 0.0;
+        else {
+            e.cprob = fmax(0.0, bestcp);
+            clx = TRK(CN_TF_PX, best); cly = TRK(CN_TF_PY, best); clvx = TRK(CN_TF_VX, best); clvy = TRK(CN_TF_VY, best);
+        }
+        e.dq0x = e.dq1x; e.dq0y = e.dq1y; e.dq_len = 1;
+        if (lane < nt) TRK(CN_TF_T, lane) = now;
+    }
+    if (ego_hit) e.ego_viol += 1;
+    if (e.cprob > 0.4) e.social_viol += 1;                                      // RW:708 (None > 0.4 is False in Python 2: cprob starts at -inf)
+    if (!e.done) {                                                              // RW:715-728
+        if (smin < p->min_scan_range) e.done = 1;
+        if (in_box(px, py, p->goal_x, p->goal_y, 0.20)) e.done = 1;
+        if (step_counter >= p->max_steps) e.done = 1;
+    }
+    if (lane < 11) {                                                            // RW:730-747: nothing is rounded a second time
+        double tv;
+        switch (lane) {
+        case 0: tv = heading; break;
+        case 1: tv = distance_to_goal; break;
+        case 2: tv = cn_py_round3(px); break;
+        case 3: tv = cn_py_round3(py); break;
+        case 4: tv = cn_py_round3(3.14); break;                                 // round(self.yaw, 3): the constructor's constant
+        case 5: tv = cn_py_round3(agent_vel_x); break;
+        case 6: tv = cn_py_round3(agent_vel_y); break;
+        case 7: tv = clx; break;
+        case 8: tv = cly; break;
+        case 9: tv = clvx; break;
+        default: tv = clvy; break;
+        }
+        L.tail[lane] = tv;
+        o32[n + lane] = (float)tv;
+        if (f32) f32[n + lane] = (float)tv;
+        if (o64) o64[n + lane] = tv;
+    }
+    if (lane < e.ntracks) {
+#pragma unroll
+        for (int f = 0; f < CN_TF_COUNT; ++f) L.gtrk[lane * CN_TF_COUNT + f] = L.trk[f * L.tcap + lane];
+    }
+    CN_SYNC();
+    *done_out = e.done;
+}
+#undef TRK
+
+// RW:751-849: -2 per step, +1 for getting closer, +1 for turning towards the goal, +-200 at the end (no way-point bonus);
+// state[359] = heading and state[360] = distance are in L.tail[0..1]
+__device__ __forceinline__ double compute_reward_realworld(KP p, EnvRegs& e, const Lds& L, int done)
+{
+    const double cur_head = L.tail[0], cur_dist = L.tail[1];
+    const double dd = cur_dist - e.prev_dist, hd = cur_head - e.prev_head;
+    int htg = 0, dtg = 0;
+    if (dd < 0) dtg = 1;
+    const double ph = e.prev_head;
+    if (hd > 0) {
+        if (cur_head > 0 && ph < 0) htg = 1;
+        if (cur_head < 0 && ph < 0) htg = 1;
+        if (cur_head < 0 && ph > 0) htg = 1;
+        if (cur_head > 0 && ph > 0) htg = 0;
+    }
+    if (hd < 0) {
+        if (cur_head < 0 && ph > 0) htg = 1;
+        if (cur_head > 0 && ph > 0) htg = 1;
+        if (cur_head > 0 && ph < 0) htg = 1;
+        if (cur_head < 0 && ph < 0) htg = 0;
+    }
+    double reward = (double)(-2 + dtg + htg);
+    e.prev_dist = cur_dist; e.prev_head = cur_head;
+    if (done) {
+        if (in_box(e.rx, e.ry, p->goal_x, p->goal_y, 0.20)) { e.fail = 0; e.succ = 1; reward = 200 + reward; }
+        else { e.fail = 1; e.succ = 0; reward = -200 + reward; }
+    }
+    return reward;
 }
 
 // ENV:1046-1162 compute_reward; state[n] = heading, state[n+1] = distance are in L.tail[0..1]
@@ -1544,6 +1896,7 @@ __device__ __forceinline__ void env_kernel_body()
     const int R = p->R, n = R - 1, P = p->P, K = p->K;
 
     Lds L;
+    RwLds RQ = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     {
         // LDS map.  Region A: end points (integer thousandths) | tracker table.
         // Region B: gradients + alias sources | bbox staging | confirmed objects, CP, observation tail.
@@ -1576,7 +1929,17 @@ __device__ __forceinline__ void env_kernel_body()
         L.ped = (double*)Cw; Cw += 8 * (size_t)(2 * P + 2);
         L.pedv = (double*)Cw; Cw += 8 * (size_t)(2 * P + 2);
         L.nearp = p->near_sep ? (double*)Cw : (double*)B;   // ray loop only: region B is dead until the gradients are written
+        if (p->near_sep) Cw += 32 * (size_t)(P + 1);
         L.gtrk = p->trk + (size_t)env * CN_TF_COUNT * p->trk_cap;
+        if constexpr (LAYOUT == 2) {   // the real-world layout's own lists: 12 bytes per ray (cn_lds_bytes adds them)
+            char* Rw = (char*)(((size_t)Cw + 15) & ~(size_t)15);
+            RQ.g = (int*)Rw; Rw += 4 * (size_t)n;
+            RQ.fi = (unsigned short*)Rw; Rw += 2 * (size_t)n;
+            RQ.ts = (unsigned short*)Rw; Rw += 2 * (size_t)n;
+            RQ.es = (unsigned short*)Rw; Rw += 2 * (size_t)n;
+            RQ.tt = (unsigned char*)Rw; Rw += (size_t)n;
+            RQ.et = (unsigned char*)Rw;
+        }
     }
 
     CN_T(0);
@@ -1660,6 +2023,8 @@ __device__ __forceinline__ void env_kernel_body()
                 }
                 CN_T(20);
                 end_timestep = e.clock - t0;                      // ENV:1202
+                if constexpr (LAYOUT == 2)   // RW:876-883: held for dt (0.05 s), booked as `0.05 - 0 + 0.1` on top of the measured 0
+                    end_timestep = 0.0 + ((cn_div1000((double)p->dt_ms) - 0.0) + 0.1);
                 deq_x = e.rx; deq_y = e.ry;
                 fin = p->final_obs;
             } else {                                              // the caller ran the sleep; /odom said where we are
@@ -1691,6 +2056,9 @@ __device__ __forceinline__ void env_kernel_body()
             if constexpr (LAYOUT == 1) {
                 e.prev_dist = dist3(e.rx, e.ry, p->goal_x, p->goal_y);   // ORIG:472 (unrounded)
                 e.prev_head = orig_heading(p, e.rx, e.ry, e.ryaw);     // ORIG:473
+            } else if constexpr (LAYOUT == 2) {
+                e.prev_dist = rw_distance(p, e.rx, e.ry);                // RW:925-926 (unrounded)
+                e.prev_head = rw_heading(p, e.rx, e.ry, e.ryaw);
             } else {
             e.prev_dist = dist3(e.rx, e.ry, e.wpx, e.wpy);        // ENV:1243 (unrounded)
             e.prev_head = heading_to_goal(p, e, e.rx, e.ry, e.ryaw);  // ENV:1244
@@ -1699,11 +2067,12 @@ __device__ __forceinline__ void env_kernel_body()
         CN_SYNC();
         if (ph_obs) {
             if constexpr (LAYOUT == 1) observe_original<EXT>(p, e, L, env, lane, sc, p->obs, fin, p->obs_f64, &done);
+            else if constexpr (LAYOUT == 2) observe_realworld<EXT>(p, pg, e, L, RQ, env, lane, sc, p->obs, fin, p->obs_f64, &done);
             else observe<EXT, GT>(p, pg, e, L, env, lane, sc, p->obs, fin, p->obs_f64, &done, have_trig, trig);
         } else if constexpr (EXT) {
             // Env.compute_reward(state, step_counter, done) on its own (ENV:1046): heading and distance are state[n], state[n+1]
             // (LAYOUT 1: state[-2], state[-1] are what ORIG:324-330 reads), `done` is the caller's
-            const int D_ = (LAYOUT == 1) ? n + 4 : n + 7 + 4 * K;
+            const int D_ = (LAYOUT == 1) ? n + 4 : (LAYOUT == 2 ? n + 11 : n + 7 + 4 * K);
             if (lane < 4) {
                 const int src = (LAYOUT == 1) ? n + lane : n + (lane & 1);
                 L.tail[lane] = p->obs_f64 ? p->obs_f64[(size_t)env * D_ + src] : (double)p->obs[(size_t)env * D_ + src];
@@ -1713,18 +2082,19 @@ __device__ __forceinline__ void env_kernel_body()
         }
         if (!do_reset && !ph_rew) {
             if (lane == 0) p->done[env] = (uint8_t)done;           // get_state returns (state, self.done) (ENV:1044)
-            if (ph_obs && p->topk_idx && lane < K) p->topk_idx[(size_t)env * K + lane] = LAYOUT == 1 ? -1 : L.kidx[lane];
+            if (ph_obs && p->topk_idx && lane < K) p->topk_idx[(size_t)env * K + lane] = LAYOUT != 0 ? -1 : L.kidx[lane];
         } else
         if (!do_reset) {
             double r;
             if constexpr (LAYOUT == 1) r = compute_reward_original(p, e, L, done);
+            else if constexpr (LAYOUT == 2) r = compute_reward_realworld(p, e, L, done);
             else r = compute_reward(p, pg, e, L, lane, done);
             e.ep_ret += r;
             if (lane == 0) {
                 p->reward[env] = (float)r;
                 p->done[env] = (uint8_t)done;
             }
-            if (ph_obs && p->topk_idx && lane < K) p->topk_idx[(size_t)env * K + lane] = LAYOUT == 1 ? -1 : L.kidx[lane];
+            if (ph_obs && p->topk_idx && lane < K) p->topk_idx[(size_t)env * K + lane] = LAYOUT != 0 ? -1 : L.kidx[lane];
             if (done) {
                 if (!ext) { e.rv = 0.0; e.rw = 0.0; }             // pub_cmd_vel.publish(Twist()) (ENV:1160)
                 e.last_ret = e.ep_ret;
@@ -1774,6 +2144,8 @@ __device__ __forceinline__ void env_kernel_body()
             robot_advance(p, e, p->dt_ms);
             }
             end_timestep = e.clock - t0;                      // ENV:1202
+                if constexpr (LAYOUT == 2)   // RW:876-883: held for dt (0.05 s), booked as `0.05 - 0 + 0.1` on top of the measured 0
+                    end_timestep = 0.0 + ((cn_div1000((double)p->dt_ms) - 0.0) + 0.1);
             deq_x = e.rx; deq_y = e.ry;
         } else {                                              // the caller ran the sleep; /odom said where we are
             deq_x = od[6]; deq_y = od[7]; end_timestep = od[8];
@@ -1795,6 +2167,9 @@ __device__ __forceinline__ void env_kernel_body()
         if constexpr (LAYOUT == 1) {
             observe_original<EXT>(p, e, L, env, lane, sc, p->obs, ext ? nullptr : p->final_obs, p->obs_f64, &done);
             r = compute_reward_original(p, e, L, done);
+        } else if constexpr (LAYOUT == 2) {
+            observe_realworld<EXT>(p, pg, e, L, RQ, env, lane, sc, p->obs, ext ? nullptr : p->final_obs, p->obs_f64, &done);
+            r = compute_reward_realworld(p, e, L, done);
         } else {
             observe<EXT, GT>(p, pg, e, L, env, lane, sc, p->obs, ext ? nullptr : p->final_obs, p->obs_f64, &done);
             r = compute_reward(p, pg, e, L, lane, done);
@@ -1804,7 +2179,7 @@ __device__ __forceinline__ void env_kernel_body()
             p->reward[env] = (float)r;
             p->done[env] = (uint8_t)done;
         }
-        if (p->topk_idx && lane < K) p->topk_idx[(size_t)env * K + lane] = LAYOUT == 1 ? -1 : L.kidx[lane];
+        if (p->topk_idx && lane < K) p->topk_idx[(size_t)env * K + lane] = LAYOUT != 0 ? -1 : L.kidx[lane];
         if (done) {
             if (!ext) { e.rv = 0.0; e.rw = 0.0; }             // pub_cmd_vel.publish(Twist()) (ENV:1160)
             e.last_ret = e.ep_ret;
@@ -1837,6 +2212,11 @@ __device__ __forceinline__ void env_kernel_body()
             e.prev_head = orig_heading(p, e.rx, e.ry, e.ryaw);     // ORIG:473
             CN_SYNC();
             observe_original<EXT>(p, e, L, env, lane, 0, p->obs, nullptr, p->obs_f64, &d2);
+        } else if constexpr (LAYOUT == 2) {
+            e.prev_dist = rw_distance(p, e.rx, e.ry);
+            e.prev_head = rw_heading(p, e.rx, e.ry, e.ryaw);
+            CN_SYNC();
+            observe_realworld<EXT>(p, pg, e, L, RQ, env, lane, 0, p->obs, nullptr, p->obs_f64, &d2);
         } else {
         e.prev_dist = dist3(e.rx, e.ry, e.wpx, e.wpy);        // ENV:1243 (unrounded)
         e.prev_head = heading_to_goal(p, e, e.rx, e.ry, e.ryaw);  // ENV:1244
@@ -1896,6 +2276,10 @@ extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_ct(CnKParams p) {
 extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_ct_same(CnKParams p) { env_kernel_body<false, true, 0, false, true>(); }
 extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_gt_ct(CnKParams p) { env_kernel_body<false, false, 0, true, true>(); }
 extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_gt_ct_same(CnKParams p) { env_kernel_body<false, true, 0, true, true>(); }
+// obs_layout 2 (environment_stage_1_nobonus_realworld.py): the 370-input physical-robot variant
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_rw(CnKParams p) { env_kernel_body<false, false, 2>(); }
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_rw_same(CnKParams p) { env_kernel_body<false, true, 2>(); }
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_rw_ext(CnKParams p) { env_kernel_body<true, false, 2>(); }
 // obs_layout 1 (environment_stage_1_original.py): same physics and lidar, no tracker
 extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_orig(CnKParams p) { env_kernel_body<false, false, 1>(); }
 extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_orig_same(CnKParams p) { env_kernel_body<false, true, 1>(); }

@@ -44,7 +44,7 @@ enum { CN_ST_TRACK_OVERFLOW = 1, CN_ST_TTC_ZERO = 2, CN_ST_DT_ZERO = 4, CN_ST_CO
 
 /* Every field of Env.__init__'s rosparam reads (ENV:71-91), the robot/lidar constants of the
  * URDF/XACRO and world files, and the crowd node's constants.  SURVEY.md appendix B cites each. */
-enum { CN_LAYOUT_RISK = 0, CN_LAYOUT_ORIGINAL = 1 };
+enum { CN_LAYOUT_RISK = 0, CN_LAYOUT_ORIGINAL = 1, CN_LAYOUT_REALWORLD = 2 };
 /* where the perceived-risk features (rows A21-A24) take their obstacles from */
 enum { CN_RISK_LIDAR_TRACKER = 0, CN_RISK_GT = 1 };
 
@@ -63,7 +63,11 @@ typedef struct cn_config {
     int32_t track_capacity;  /* tracker slots per env: 0 = auto (32 for <= 40 pedestrians, else 64), or 32 / 64 */
     int32_t obs_layout;      /* CN_LAYOUT_RISK (0): environment_stage_1_nobonus.py, obs = R-1 + 7 + 4K (TD3 / DDPG trainers);
                               * CN_LAYOUT_ORIGINAL (1): environment_stage_1_original.py:278-402, obs = R-1 + 4 =
-                              * rounded ranges + heading + distance + rounded (x, y) (SAC / DQN / Q-learning trainers) */
+                              * rounded ranges + heading + distance + rounded (x, y) (SAC / DQN / Q-learning trainers);
+                              * CN_LAYOUT_REALWORLD (2): environment_stage_1_nobonus_realworld.py:208-749, obs = R-1 + 11 = unrounded
+                              * ranges + heading + distance + rounded (x, y) + the constant yaw 3.14 + rounded twist features +
+                              * pose and velocity of the one obstacle with the highest collision probability (the physical-robot
+                              * script: set dt_ms = 50, RW:880-883; normally driven through cn_observe_external) */
     int32_t geos_untyped_empty; /* shapely/GEOS version switch for UTL:279,306 `str(i) != 'LINESTRING EMPTY'`:
                               * 0: GEOS >= 3.9 typed empties (a miss prints 'LINESTRING EMPTY' and is skipped);
                               * 1: GEOS <= 3.8 (the reference's Python-2.7 / shapely <= 1.7 platform): a miss prints

@@ -703,3 +703,69 @@ def test_build_then_smoke_in_one_process():
     assert r.returncode == 0, r.stderr[-2000:]
     assert "smoke OK" in r.stdout
 
+
+
+# ---- obs_layout 2: environment_stage_1_nobonus_realworld.py (370 inputs), SURVEY 8f N3 ------------------------------
+@pytest.mark.parametrize("mode", [True, "next", False])
+def test_realworld_layout_rollout_parity(oracle_mod, mode):
+    """cn_env_kernel_rw / _rw_same against the oracle's restatement of environment_stage_1_nobonus_realworld.py (RW:208-849):
+    unrounded ranges, the one highest-CP obstacle, its own reward and 0.05 s / 0.15 s timestep quirk."""
+    n_done, exact = _compare_rollout(oracle_mod, steps=150, seed=61, reset_mode=mode, n_envs=64, n_peds=20, max_steps=80,
+                                     obs_layout=2, dt_ms=50)
+    assert (n_done > 20 or mode is False) and exact > 0.999
+
+
+def test_realworld_layout_other_shapes(oracle_mod):
+    n_done, exact = _compare_rollout(oracle_mod, steps=80, seed=62, n_envs=32, n_peds=100, max_steps=60, obs_layout=2, dt_ms=50,
+                                     min_scan_range=0.0)
+    assert exact > 0.999
+    _compare_rollout(oracle_mod, steps=60, seed=63, n_envs=16, n_peds=60, n_rays=181, max_steps=40, obs_layout=2, dt_ms=50)
+    _compare_rollout(oracle_mod, steps=40, seed=64, n_envs=8, n_peds=100, n_rays=720, room_half=2.4, max_steps=30, obs_layout=2,
+                     dt_ms=50, geos_untyped_empty=1)
+
+
+@pytest.mark.parametrize("name", ["rw20", "rw60"])
+def test_realworld_layout_golden_replay_and_run(name):
+    """Layout 2 against the REFERENCE's own Python: (a) the kernel fed with the recorded /scan + /odom (cn_observe_external,
+    the way a physical robot would drive it), (b) the full simulated path driven by the recorded actions."""
+    import torch
+    from crowdnav import Config
+    from crowdnav.env import VecEnv
+    z, kw = load_seq(name)
+    env = VecEnv(Config(n_envs=1, **kw))
+    assert env.D == 370
+    env.enable_f64_obs()
+    for i in range(len(z["now"])):
+        odom = [z["px"][i], z["py"][i], z["yaw"][i], z["v"][i], z["w"][i], z["now"][i], z["deque_x"][i], z["deque_y"][i],
+                z["end_timestep"][i], 0.0]
+        is_reset = bool(z["is_reset"][i])
+        env.observe_external(z["ranges"][i][None, :], [odom], step_counter=[int(z["step_counter"][i])], is_reset=is_reset)
+        torch.cuda.synchronize()
+        og = env.obs_f64[0].cpu().numpy()
+        assert np.abs(og - z["obs"][i]).max() <= TOL, (name, i, np.abs(og - z["obs"][i]).max())
+        if not is_reset:
+            assert float(env.reward[0].item()) == z["reward"][i] and bool(env.done[0].item()) == bool(z["done"][i]), (name, i)
+        d = env.debug_env(0)
+        n = int(z["n_tracks"][i])
+        assert d["n_tracks"] == n, (name, i)
+        assert np.array_equal(d["track_pose"], z["track_pose"][i][:n]) and np.array_equal(d["track_dist"], z["track_dist"][i][:n])
+        assert np.allclose(d["track_vel"], z["track_vel"][i][:n], rtol=1e-12, atol=0)
+        if np.isinf(z["collision_prob"][i]):        # RW:80 None, kept as -inf (below every number, as in Python 2) until the first cone
+            assert d["collision_prob"] == z["collision_prob"][i]
+        else:
+            assert abs(d["collision_prob"] - z["collision_prob"][i]) <= 1e-12
+        assert abs(d["bb"] - z["bb"][i]) <= 1e-15
+        c = env.counters()[0].cpu().tolist()
+        assert tuple(c[:2]) == tuple(int(x) for x in z["counters"][i]) and (bool(c[4]), bool(c[5])) == tuple(bool(x) for x in z["status"][i])
+    env2 = VecEnv(Config(n_envs=1, **kw))
+    env2.enable_f64_obs()
+    env2.set_ped_init(z["ped_init"])
+    for i in range(len(z["now"])):
+        if z["is_reset"][i]:
+            env2.reset()
+        else:
+            env2.step(torch.tensor(z["action"][i][None, :], dtype=torch.float32).cuda(), step_counter=[int(z["step_counter"][i])],
+                      auto_reset=False)
+            assert float(env2.reward[0].item()) == z["reward"][i] and bool(env2.done[0].item()) == bool(z["done"][i]), (name, i)
+        torch.cuda.synchronize()
+        assert np.abs(env2.obs_f64[0].cpu().numpy() - z["obs"][i]).max() <= TOL, (name, i)
