@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--geos", type=int, default=0)
     ap.add_argument("--layout", type=int, default=0)
     ap.add_argument("--vmax", type=float, default=0.2)
+    ap.add_argument("--dt-ms", type=int, default=150)
     a = ap.parse_args()
     import torch
     from crowdnav import Config
@@ -38,15 +39,15 @@ def main():
 
     cfg = Config(n_envs=a.envs, n_peds=a.peds, n_rays=a.rays, room_half=a.room, seed=a.seed, max_steps=a.max_steps,
                  min_scan_range=a.min_scan, k_obstacles=a.k, risk_mode=a.risk_mode, ped_contact=a.contact,
-                 geos_untyped_empty=a.geos, obs_layout=a.layout, ped_vmax=a.vmax)
+                 geos_untyped_empty=a.geos, obs_layout=a.layout, ped_vmax=a.vmax, dt_ms=a.dt_ms)
     print("== parity_report", " ".join(sys.argv[1:]))
     env = VecEnv(cfg)
     env.enable_f64_obs()
     orc = oracle.Oracle(cfg.as_dict())
     oracle.set_num_threads(os.cpu_count() or 1)
     n = a.rays - 1
-    if a.layout == 1:
-        n = a.rays - 1 - 3          # layout 1 has a 4-value tail; the column split below is only indicative there
+    if a.layout:
+        n = a.rays - 1 - 3          # layouts 1 / 2 have their own tails; the column split below is only indicative there
     o_g = env.reset(); torch.cuda.synchronize()
     o_c = orc.reset()
     g64 = env.obs_f64.cpu().numpy()

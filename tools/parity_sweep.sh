@@ -19,4 +19,6 @@ $R --envs 512 --steps 200 --peds 100 --risk-mode 1 --k 4
 $R --envs 512 --steps 200 --peds 60 --contact 1 --min-scan 0.0
 $R --envs 512 --steps 200 --peds 40 --contact 1 --risk-mode 1 --vmax 0.5
 $R --envs 1024 --steps 300 --layout 1
+$R --envs 1024 --steps 300 --layout 2 --dt-ms 50 --reset-mode next
+$R --envs 256 --steps 200 --layout 2 --dt-ms 50 --peds 100 --min-scan 0.0
 } 2>&1 | grep -v amdgpu.ids | tee "$OUT/parity_sweep.txt"
