@@ -253,5 +253,19 @@ class Oracle:
         self.L.cno_ext_set_done(self.h, env, int(done))
 
 
-def set_num_threads(n):
-    return lib().cno_set_num_threads(int(n))
+def usable_cpus():
+    """CPUs this process may really use: the affinity mask cut down by the cgroup quota (a GPU box reports its 100+ hardware
+    threads in os.cpu_count() while the container owns 16; OpenMP teams larger than that spin against each other)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(per))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+def set_num_threads(n=None):
+    """OpenMP threads over envs for the batched calls; None = every usable CPU."""
+    return lib().cno_set_num_threads(int(n if n is not None else usable_cpus()))

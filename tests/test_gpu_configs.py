@@ -19,6 +19,12 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-5
 
 
+@pytest.fixture(autouse=True)
+def _one_oracle_thread_afterwards(oracle_mod):
+    yield
+    oracle_mod.set_num_threads(1)
+
+
 def test_config2_full_size_4096_envs(oracle_mod):
     import torch
     from crowdnav import Config
@@ -27,7 +33,7 @@ def test_config2_full_size_4096_envs(oracle_mod):
     cfg = Config(n_envs=N, n_peds=20, n_rays=360, k_obstacles=8, max_steps=30, seed=1234, ped_cycle_ms=1400)
     env = VecEnv(cfg); env.enable_f64_obs()
     orc = oracle_mod.Oracle(cfg.as_dict())
-    oracle_mod.set_num_threads(os.cpu_count() or 1)
+    oracle_mod.set_num_threads()      # every usable CPU (cgroup-aware), back to 1 in the fixture below
     env.reset(); torch.cuda.synchronize()
     assert np.array_equal(env.obs_f64.cpu().numpy(), orc.reset())
     g = torch.Generator(device="cpu").manual_seed(7)
@@ -65,7 +71,7 @@ def test_config3_actor_in_the_loop_4096_envs(oracle_mod, sigma):
     with torch.no_grad():                 # spread the random-init actor's outputs so that the robots really move
         agent.actor.linear1.weight.mul_(4.0); agent.actor.linear3.weight.mul_(10.0)
     orc = oracle_mod.Oracle(cfg.as_dict())
-    oracle_mod.set_num_threads(os.cpu_count() or 1)
+    oracle_mod.set_num_threads()      # every usable CPU (cgroup-aware), back to 1 in the fixture below
     o0 = envs.reset(); torch.cuda.synchronize()
     oc = orc.reset()
     assert np.array_equal(o0.cpu().numpy(), oc.astype(np.float32))

@@ -44,7 +44,7 @@ def main():
     env = VecEnv(cfg)
     env.enable_f64_obs()
     orc = oracle.Oracle(cfg.as_dict())
-    oracle.set_num_threads(os.cpu_count() or 1)
+    oracle.set_num_threads()
     n = a.rays - 1
     if a.layout:
         n = a.rays - 1 - 3          # layouts 1 / 2 have their own tails; the column split below is only indicative there
