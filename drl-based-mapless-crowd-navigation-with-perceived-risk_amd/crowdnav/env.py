@@ -473,10 +473,14 @@ class Env:
 
     def get_social_safety_violation_status(self, step):
         c = self._v.counters()[0].cpu().numpy()
+        if self._v.cfg.obs_layout == 2:                  # RW:950-954 divides by the step count it is handed
+            return 1.0 - ((int(c[1]) * 1.0) / step)
         return 1.0 - ((int(c[1]) * 1.0) / int(c[2]))   # ZeroDivisionError if no obstacle was ever seen (ENV:1272)
 
     def get_ego_safety_violation_status(self, step):
         c = self._v.counters()[0].cpu().numpy()
+        if self._v.cfg.obs_layout == 2:                  # RW:956-960
+            return 1.0 - ((int(c[0]) * 1.0) / step)
         return 1.0 - ((int(c[0]) * 1.0) / int(c[2]))
 
     def shutdown(self):

@@ -724,6 +724,24 @@ def test_realworld_layout_other_shapes(oracle_mod):
                      dt_ms=50, geos_untyped_empty=1)
 
 
+def test_realworld_layout_env_wrapper_surface():
+    """The N = 1 `Env` mirror with obs_layout = 2: 370 float64 inputs, RW:950-960's safety scores divide by the step count."""
+    from crowdnav import Config
+    from crowdnav.env import Env
+    env = Env(action_dim=2, max_step=40, cfg=Config(n_envs=1, max_steps=40, obs_layout=2, dt_ms=50, seed=3))
+    obs = env.reset()
+    assert obs.shape == (370,) and obs.dtype == np.float64 and obs[363] == 3.14
+    done = False
+    for step in range(40):
+        obs, reward, done = env.step([0.15, 0.2], step + 1)
+        if done:
+            break
+    assert done and obs.shape == (370,) and reward in (-202.0, -201.0, -200.0, 198.0, 199.0, 200.0)
+    s_, f_ = env.get_episode_status()
+    assert s_ != f_
+    assert 0.0 <= env.get_social_safety_violation_status(step + 1) <= 1.0 and 0.0 <= env.get_ego_safety_violation_status(step + 1) <= 1.0
+
+
 @pytest.mark.parametrize("name", ["rw20", "rw60"])
 def test_realworld_layout_golden_replay_and_run(name):
     """Layout 2 against the REFERENCE's own Python: (a) the kernel fed with the recorded /scan + /odom (cn_observe_external,
