@@ -474,8 +474,13 @@ __device__ __forceinline__ double cast_ray(KP p, const Lds& L, int env, int k, d
         // A wall farther than lidar_max from the origin can only give t > lidar_max ("no return"), so its
         // divide is skipped when the whole env is out of its reach (uniform test, result unchanged).
         // (one divide per axis: the facing wall is selected first -- a wave has rays of both signs)
-        if (wall_x && dx != 0.0) t = fmin(t, ((dx > 0.0 ? h : -h) - ox) / dx);
-        if (wall_y && dy != 0.0) t = fmin(t, ((dy > 0.0 ? h : -h) - oy) / dy);
+        // Per ray the same argument again, before paying the divide: a / d <= lidar_max  <=>  a sign(d) <= lidar_max |d|
+        // (with slack; a quotient beyond lidar_max cannot change a range that is reported as "no return" above it).
+        // Rays of a 64-block point within 64 degrees of each other, so whole blocks skip the divide of a wall behind them.
+        const double ax = (dx > 0.0 ? h : -h) - ox, ay = (dy > 0.0 ? h : -h) - oy;
+        const double reach = p->lidar_max * (1.0 + 1e-9);
+        if (wall_x && dx != 0.0 && (dx > 0.0 ? ax : -ax) <= fma(reach, fabs(dx), 1e-12)) t = fmin(t, ax / dx);
+        if (wall_y && dy != 0.0 && (dy > 0.0 ? ay : -ay) <= fma(reach, fabs(dy), 1e-12)) t = fmin(t, ay / dy);
         if (t < p->lidar_min) t = p->lidar_min;
         const int q = k >> 6;                                  // this block of 64 rays (wave-uniform)
         auto test = [&](int c) {
@@ -852,22 +857,37 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
     // none = 1 (their other flags are never read: the machine masks everything with ~none).
     unsigned short* occlist = L.srcidx;            // free until the type machine records alias sources
     int nocc = 0;
+    u64 occraw = 0ull;                             // lane q keeps word q of the ray-space occupancy (range != 0.6)
     for (int q = 0; q < W; ++q) {
         const int i = lane + 64 * q;
         const bool oc = (i < n) && (L.dmil[i] != 600);
         if (i < n) L.gq[i] = GNONE;
         const u64 bo = __ballot(oc);
         if (oc) occlist[nocc + __popcll(bo & ((1ull << lane) - 1ull))] = (unsigned short)i;
+        if (lane == q) occraw = bo;
         nocc += __popcll(bo);
     }
     if (lane < W) { WORD(M_NONE, lane) = ~0ull; WORD(M_ZERO, lane) = 0ull; WORD(M_EQ, lane) = 0ull; WORD(M_NNONE, lane) = 0ull; WORD(M_NZERO, lane) = 0ull; }
     CN_SYNC();
-    for (int c = lane; c < nocc; c += 64) {
-        const int i = occlist[c];
-        const int j = (i == n - 1) ? 0 : i + 1;
-        double dy = PY(i) - PY(j);
-        double q = (dy == 0) ? 0.0 : (PX(i) - PX(j)) / dy;
-        L.gq[i] = (int)cn_round_scaled(q, 1000.0);
+    // two list entries per lane and pass (128 occupied rays cover almost every scan): both entries' index and end-point reads
+    // are issued before the first use, and the two divides overlap
+    for (int c0 = 0; c0 < nocc; c0 += 128) {
+        const int ca = c0 + lane, cb = ca + 64;
+        const bool two = c0 + 64 < nocc;                   // wave-uniform: is there a second entry for anyone?
+        const bool va = ca < nocc, vb = cb < nocc;
+        const int ia = va ? (int)occlist[ca] : 0, ib = vb ? (int)occlist[cb] : 0;
+        const int ja = (ia == n - 1) ? 0 : ia + 1, jb = (ib == n - 1) ? 0 : ib + 1;
+        const int xai = L.ptx[ia], yai = L.pty[ia], xaj = L.ptx[ja], yaj = L.pty[ja];
+        int xbi = 0, ybi = 0, xbj = 0, ybj = 0;
+        if (two) { xbi = L.ptx[ib]; ybi = L.pty[ib]; xbj = L.ptx[jb]; ybj = L.pty[jb]; }
+        const double dya = cn_div1000((double)yai) - cn_div1000((double)yaj);
+        const double qa = (dya == 0) ? 0.0 : (cn_div1000((double)xai) - cn_div1000((double)xaj)) / dya;
+        if (va) L.gq[ia] = (int)cn_round_scaled(qa, 1000.0);
+        if (two) {
+            const double dyb = cn_div1000((double)ybi) - cn_div1000((double)ybj);
+            const double qb = (dyb == 0) ? 0.0 : (cn_div1000((double)xbi) - cn_div1000((double)xbj)) / dyb;
+            if (vb) L.gq[ib] = (int)cn_round_scaled(qb, 1000.0);
+        }
     }
     // last occupied ray before n-1 (ENV:356-366 `last_grad`)
     int lastnn = -1;
@@ -882,15 +902,20 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
     double clast = CN_NAN;
     if (L.gq[n - 1] != GNONE && lastnn >= 0) clast = CHG(L.gq[lastnn], L.gq[lastnn + 1]);
     CN_T(6);
-    for (int c = lane; c < nocc; c += 64) {
-        const int i = occlist[c];
-        if (i < n - 1) {  // the machine never visits ray n-1 (ENV:380-381)
-            int g0 = L.gq[i], g1 = L.gq[i + 1];
-            double c0 = CHG(g0, g1);
-            if (c0 == c0) {                               // none = 0: the only rays the machine reads flags of
-                double c1 = (i + 1 < n - 1) ? CHG(g1, L.gq[i + 2]) : clast;
-                const bool zero = (c0 == 0), nnone = !(c1 == c1), nzero = (c1 == 0);
-                const bool eq = !nnone && (fabs(c0 - c1) == 0);
+    for (int c0 = 0; c0 < nocc; c0 += 128) {       // two list entries per lane and pass, reads batched
+        const int ca = c0 + lane, cb = ca + 64;
+        const int ia = (ca < nocc) ? (int)occlist[ca] : n, ib = (cb < nocc) ? (int)occlist[cb] : n;
+        const bool va = ia < n - 1, vb = ib < n - 1;     // the machine never visits ray n-1 (ENV:380-381)
+        int ga0 = GNONE, ga1 = GNONE, ga2 = GNONE, gb0 = GNONE, gb1 = GNONE, gb2 = GNONE;
+        if (va) { ga0 = L.gq[ia]; ga1 = L.gq[ia + 1]; if (ia + 1 < n - 1) ga2 = L.gq[ia + 2]; }
+        if (vb) { gb0 = L.gq[ib]; gb1 = L.gq[ib + 1]; if (ib + 1 < n - 1) gb2 = L.gq[ib + 2]; }
+        auto flags = [&](bool v_, int i, int g0, int g1, int g2) {
+            if (!v_) return;
+            double c0_ = CHG(g0, g1);
+            if (c0_ == c0_) {                             // none = 0: the only rays the machine reads flags of
+                double c1 = (i + 1 < n - 1) ? CHG(g1, g2) : clast;
+                const bool zero = (c0_ == 0), nnone = !(c1 == c1), nzero = (c1 == 0);
+                const bool eq = !nnone && (fabs(c0_ - c1) == 0);
                 const u64 bit = 1ull << (i & 63);
                 const int qw = i >> 6;
                 atomicAnd((unsigned long long*)&WORD(M_NONE, qw), ~bit);
@@ -899,7 +924,9 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
                 if (nnone) atomicOr((unsigned long long*)&WORD(M_NNONE, qw), bit);
                 if (nzero) atomicOr((unsigned long long*)&WORD(M_NZERO, qw), bit);
             }
-        }
+        };
+        flags(va, ia, ga0, ga1, ga2);
+        if (c0 + 64 < nocc) flags(vb, ib, gb0, gb1, gb2);
     }
 #undef CHG
     CN_SYNC();
@@ -980,30 +1007,20 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
             if (prev) { const int hb = 63 - __builtin_clzll(prev); ty = ((setW >> hb) & 1ull) ? TY_W : TY_O; src = 64 * q + hb; }
             if (ty == TY_W) isw |= bit;
             else if (ty == TY_O) iso |= bit;
-            if (ty != TY_NONE) { al |= bit; L.srcidx[64 * q + t] = (unsigned short)src; }
+            if (ty != TY_NONE) {
+                // ENV:433-445: the aliased ray carries the range and pose of the ray its list was created at.  Copied right
+                // here: sources are never aliased themselves, and both ends are occupied rays, so the occupancy words
+                // (range != 0.6) gathered before the gradients stay valid -- no separate pass over all rays.
+                const int i_ = 64 * q + t;
+                L.dmil[i_] = L.dmil[src]; L.ptx[i_] = L.ptx[src]; L.pty[i_] = L.pty[src];
+            }
         }
-        if (q < W) { WORD(M_ISW, q) = isw; WORD(M_ISO, q) = iso; WORD(M_ALIAS, q) = al; }
+        (void)al;
+        // (the flag-word slot M_NNONE is dead now: it takes the ray-space occupancy for the order/split words)
+        if (q < W) { WORD(M_ISW, q) = isw; WORD(M_ISO, q) = iso; WORD(M_NNONE, q) = occraw; }
     }
     CN_SYNC();
     CN_T(8);
-    // ENV:433-445: a typed ray carries the range and pose of the ray its list was created at.  In place:
-    // only aliased rays change, and the rays they copy from are never aliased themselves.
-    for (int q = 0; q < W; ++q) {
-        const int i = lane + 64 * q;
-        unsigned short dm = 600;
-        if (i < n) {
-            dm = L.dmil[i];
-            if (BIT(M_ALIAS, i)) {
-                int s_ = L.srcidx[i];
-                dm = L.dmil[s_];
-                L.dmil[i] = dm; L.ptx[i] = L.ptx[s_]; L.pty[i] = L.pty[s_];
-            }
-        }
-        // ray-space occupancy (range != 0.6) for the order/split words, in a flag-word slot that is dead by now
-        const u64 bo = __ballot((i < n) && (dm != 600));
-        if (lane == 0) WORD(M_NNONE, q) = bo;
-    }
-    CN_SYNC();
     CN_T(9);
     // ENV:448-485 association of consecutive rays; brk bit i = a segment closes after ray i.
     // is_associated = round(IoU, 3) > 0 of two squares of half-size bb about consecutive end points.  The end points are
@@ -1043,19 +1060,7 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
         }
         CN_SYNC();
     }
-    for (int q = 0; q < W; ++q) {
-        int i = lane + 64 * q;
-        bool brk = false;
-        if (i < n) {
-            brk = true;
-            if (i < n - 1) {
-                if (fast_assoc) {
-                    const int dxm = abs(L.ptx[i] - L.ptx[i + 1]), dym = abs(L.pty[i] - L.pty[i + 1]);
-                    brk = dym > (int)amax[min(dxm, K1 + 1)];
-                } else brk = !cn_iou3_positive(PX(i), PY(i), PX(i + 1), PY(i + 1), e.bb);
-            }
-        }
-        u64 bw = __ballot(brk);
+    auto note_breaks = [&](int q, u64 bw) {
         if (lane == 0) WORD(M_BRK, q) = bw;
         if (bw) {
             if (fe == n) fe = 64 * q + __builtin_ctzll(bw);
@@ -1063,6 +1068,45 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
             if (bl) lb = 64 * q + 63 - __builtin_clzll(bl);
             nsegs0 += __popcll(bw);
         }
+    };
+    int q_done = 0;
+    if (fast_assoc) {
+        // The first six 64-ray blocks (all of them up to 385 rays) in three batched steps -- every end-point read issued
+        // before the first use, then every table look-up, then the ballots -- instead of two dependent LDS round trips per
+        // block: this stage is pure LDS latency (a dozen integer instructions per block).
+        constexpr int QB = 6;
+        int dxm[QB], dym[QB], lim[QB];
+#pragma unroll
+        for (int q = 0; q < QB; ++q) {
+            const int i = lane + 64 * q;
+            dxm[q] = 0; dym[q] = 0;
+            if (q < W && i < n - 1) { dxm[q] = L.ptx[i] - L.ptx[i + 1]; dym[q] = L.pty[i] - L.pty[i + 1]; }
+        }
+#pragma unroll
+        for (int q = 0; q < QB; ++q) { dxm[q] = min(abs(dxm[q]), K1 + 1); lim[q] = (q < W) ? (int)amax[dxm[q]] : 0; }
+#pragma unroll
+        for (int q = 0; q < QB; ++q) {
+            if (q < W) {
+                const int i = lane + 64 * q;
+                const bool brk = (i < n) && ((i == n - 1) || abs(dym[q]) > lim[q]);
+                note_breaks(q, __ballot(brk));
+            }
+        }
+        q_done = W < QB ? W : QB;
+    }
+    for (int q = q_done; q < W; ++q) {
+        int i = lane + 64 * q;
+        bool brk = false;
+        if (i < n) {
+            brk = true;
+            if (i < n - 1) {
+                if (fast_assoc) {
+                    const int dx_ = abs(L.ptx[i] - L.ptx[i + 1]), dy_ = abs(L.pty[i] - L.pty[i + 1]);
+                    brk = dy_ > (int)amax[min(dx_, K1 + 1)];
+                } else brk = !cn_iou3_positive(PX(i), PY(i), PX(i + 1), PY(i + 1), e.bb);
+            }
+        }
+        note_breaks(q, __ballot(brk));
     }
     const int ls = lb + 1;            // start of the last segment
     // ENV:490-502 first <-> last with twice the box
