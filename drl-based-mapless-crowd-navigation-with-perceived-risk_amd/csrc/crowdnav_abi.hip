@@ -249,6 +249,7 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
     k.max_scan_range = c.max_scan_range; k.min_scan_range = c.min_scan_range; k.goal_x = c.goal_x; k.goal_y = c.goal_y;
     k.start_x = c.start_x; k.start_y = c.start_y; k.spawn_x = c.spawn_x; k.spawn_y = c.spawn_y; k.spawn_yaw = c.spawn_yaw;
     k.waypoint_radius = c.waypoint_radius; k.goal_eps = c.goal_eps; k.angle_inc_deg = angle_increment_deg(R); k.lidar_step = step;
+    { static const double trig[CN_TRIG_COUNT] = CN_TRIG_TABLE; static_assert(sizeof(trig) == sizeof(k.trig), "CnKParams::trig"); memcpy(k.trig, trig, sizeof(trig)); }
     k.blk_dir = h->d_lidar + 4 * (size_t)R; k.blk_cb = cos(32.5 * step); k.blk_sb = sin(32.5 * step);
     k.lidar_c = h->d_lidar; k.lidar_s = h->d_lidar + R; k.ang_s = h->d_lidar + 2 * R; k.ang_c = h->d_lidar + 3 * R; k.poly_c = h->d_poly; k.poly_s = h->d_poly + 64;
     k.state = h->d_state; k.state_stride = (int64_t)h->stride; k.ped_init = h->d_ped_init;

@@ -119,6 +119,99 @@ __host__ __device__ inline void cn_det_sincos(double x, double* sn, double* cs)
     }
 }
 
+// The same evaluation with its 16 constants read from a table in the constant address space (the kernel argument block).
+// Written as literals, each Horner step costs three VALU instructions on gfx950: the compiler emits v_fmac_f64 with the
+// 64-bit addend moved into the destination by two v_mov_b32 first.  From the table the addend is a scalar-register operand
+// of one v_fma_f64 (s_load runs on the scalar unit, beside the vector pipe the kernel is bound by).
+#define CN_TRIG_TABLE { 6.36619772367581382433e-01, 1.57079632673412561417e+00, 6.07710050630396597660e-11, 2.02226624879595063154e-21, \
+    -1.66666666666666324348e-01, 8.33333333332248946124e-03, -1.98412698298579493134e-04, 2.75573137070700676789e-06, \
+    -2.50507602534068634195e-08, 1.58969099521155010221e-10, \
+    4.16666666666666019037e-02, -1.38888888888741095749e-03, 2.48015872894767294178e-05, -2.75573143513906633035e-07, \
+    2.08757232129817482790e-09, -1.13596475577881948265e-11, \
+    /* [16..26] cn_atan2_t: Q(z) = (r - atan r) / r^3, z = r^2 <= tan^2(pi/8), degree 10 (tools/fit_atan.py: 7e-18 relative) */ \
+    3.33333333333333314830e-01, -1.99999999999955130336e-01, 1.42857142846651796741e-01, -1.11111110151467143425e-01, \
+    9.09090457366906051773e-02, -7.69218308734202632637e-02, 6.66450998981804459964e-02, -5.85813625190614653548e-02, \
+    5.08538348884283106233e-02, -3.92297445366122307653e-02, 1.91745435720213318331e-02, \
+    /* [27] tan(pi/8)  [28..33] pi/4, pi/2, pi as hi + lo */ \
+    0.41421356237309503, 7.85398163397448278999e-01, 3.06161699786838301793e-17, \
+    1.57079632679489655800e+00, 6.12323399573676603587e-17, 3.14159265358979311600e+00, 1.22464679914735317723e-16 }
+#define CN_TRIG_COUNT 34
+typedef const __attribute__((address_space(4))) double* cn_ktab;
+// fma(a, b, c) with the addend c in scalar registers, spelled out: for a uniform addend the compiler would pick the
+// two-address v_fmac_f64 and copy c into the destination with two v_mov_b32 first (three vector instructions per Horner step).
+__device__ __forceinline__ double cn_fma_s(double a, double b, double c)
+{
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c));
+    return d;
+}
+__device__ __forceinline__ void cn_det_sincos_t(cn_ktab t, double x, double* sn, double* cs)
+{
+    double fn = rint(x * t[0]);
+    double r = fma(-fn, t[1], x);
+    r = fma(-fn, t[2], r);
+    r = fma(-fn, t[3], r);
+    double z = r * r;
+    double ps = fma(z, t[9], t[8]);
+    ps = cn_fma_s(z, ps, t[7]);
+    ps = cn_fma_s(z, ps, t[6]);
+    ps = cn_fma_s(z, ps, t[5]);
+    ps = cn_fma_s(z, ps, t[4]);
+    double s = fma(r * z, ps, r);
+    double pc = fma(z, t[15], t[14]);
+    pc = cn_fma_s(z, pc, t[13]);
+    pc = cn_fma_s(z, pc, t[12]);
+    pc = cn_fma_s(z, pc, t[11]);
+    pc = cn_fma_s(z, pc, t[10]);
+    double c = fma(z * z, pc, fma(-0.5, z, 1.0));
+    const int q = (int)(long long)fn & 3;
+    const double a = (q & 1) ? c : s, b = (q & 1) ? s : c;     // q: 0 (s, c)  1 (c, -s)  2 (-s, -c)  3 (-c, s)
+    *sn = (q & 2) ? -a : a;
+    *cs = (q == 1 || q == 2) ? -b : b;
+}
+
+// atan2 for the heading to the goal (ENV:222-237, math.atan2), which is rounded to 2 decimals right after.  The device
+// library's atan2 costs ~110 vector instructions here, half of them v_mov_b32 of polynomial constants (see cn_fma_s); this
+// one is a divide, one Horner chain with scalar addends and the quadrant fix-ups:
+//   atan(mn / mx), mn <= mx:  mn <= tan(pi/8) mx ?  A(mn / mx)  :  pi/4 + A((mn - mx) / (mn + mx)),   A(r) = r - r z Q(z)
+// Within 2.5 ulp of the exact value on 4e7 points incl. the reference's 3-decimal coordinates, at most 1 ulp (4.4e-16)
+// from glibc's (tools/check_atan2.c); a different last bit changes the heading only when heading * 100 lies that close
+// to a half-integer.  Signed zeros as C99 (atan2(+-0, -0) = +-pi); infinite arguments do not occur (positions are finite).
+__device__ __forceinline__ double cn_atan2_t(cn_ktab t, double y, double x)
+{
+    const double ax = fabs(x), ay = fabs(y);
+    const double mx = fmax(ax, ay), mn = fmin(ax, ay);
+    const bool hi = mn > t[27] * mx;
+    const double num = hi ? mn - mx : mn, den = hi ? mn + mx : mx;
+    const double r = (mx == 0.0) ? 0.0 : num / den;
+    const double z = r * r;
+    double q = fma(z, t[26], t[25]);
+    q = cn_fma_s(z, q, t[24]);
+    q = cn_fma_s(z, q, t[23]);
+    q = cn_fma_s(z, q, t[22]);
+    q = cn_fma_s(z, q, t[21]);
+    q = cn_fma_s(z, q, t[20]);
+    q = cn_fma_s(z, q, t[19]);
+    q = cn_fma_s(z, q, t[18]);
+    q = cn_fma_s(z, q, t[17]);
+    q = cn_fma_s(z, q, t[16]);
+    double a = fma(-r, z * q, r);
+    if (hi) a = t[28] + (a + t[29]);
+    if (ay > ax) a = t[30] - (a - t[31]);
+    if (__double2hiint(x) < 0) a = t[32] - (a - t[33]);
+    return copysign(a, y);
+}
+
+// hypot() for lengths of a few metres: the device library's version wraps the same sqrt(fma(a, a, b b)), a = the larger
+// magnitude, in exponent scaling and inf/nan handling (frexp / ldexp / class tests, a third of its instructions) that
+// coordinates in thousandths of a metre never need.  hypot(x, 0) = |x| exactly, as in C.
+__device__ __forceinline__ double cn_hypot(double x, double y)
+{
+    const double ax = fabs(x), ay = fabs(y);
+    const double a = fmax(ax, ay), b = fmin(ax, ay);
+    return sqrt(fma(a, a, b * b));
+}
+
 // ---- counter-based RNG (CROWD:101-102 random.uniform) ---------------------------------------
 __host__ __device__ inline uint64_t cn_mix64(uint64_t z)
 {

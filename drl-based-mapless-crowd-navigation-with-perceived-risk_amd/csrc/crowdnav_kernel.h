@@ -24,6 +24,7 @@ struct CnKParams {
     double waypoint_radius, goal_eps, angle_inc_deg, lidar_step;
     double blk_cb, blk_sb;   // cos / sin of the half-width (32.5 lidar steps) of a 64-ray block (near-pedestrian block bits)
     const double* blk_dir;   // [ceil(R/64)][2] robot-frame direction of ray 64 q + 32 (clamped to R - 1)
+    double trig[34];         // constants of cn_det_sincos_t / cn_atan2_t (CN_TRIG_TABLE): scalar loads next to the polynomials
     double bb_spawn;         // bounding-box size (UTL:405-419) at the spawn pose, evaluated on the device by cn_create
     int64_t bb_spawn_valid;
     // tables (device)

@@ -76,7 +76,7 @@ __device__ __forceinline__ double heading_to_goal(KP p, const EnvRegs& e, double
 {
     // ENV:222-237 (adds starting_point to the position; ENV:191-209 does not)
     double cx = px + p->start_x, cy = py + p->start_y;
-    double ga = atan2(e.wpy - cy, e.wpx - cx);
+    double ga = cn_atan2_t(p->trig, e.wpy - cy, e.wpx - cx);
     double h = ga - yaw;
     if (h > CN_PI) h -= 2 * CN_PI;
     else if (h < -CN_PI) h += 2 * CN_PI;
@@ -277,7 +277,7 @@ __device__ __forceinline__ void step_trig(KP p, const EnvRegs& e, int lane, doub
     const double y2 = wrap_yaw(y1 + dth2);
     const double x = lane == 0 ? a1 : (lane == 1 ? a2 : (lane == 2 ? y2 : e.rw));
     double s_, c_;
-    cn_det_sincos(x, &s_, &c_);
+    cn_det_sincos_t(p->trig, x, &s_, &c_);
     s1 = lane_d(s_, 0); c1 = lane_d(c_, 0); s2 = lane_d(s_, 1); c2 = lane_d(c_, 1);
     tg.sy = lane_d(s_, 2); tg.cy = lane_d(c_, 2); tg.sw = lane_d(s_, 3); tg.cw = lane_d(c_, 3);
 }
@@ -286,7 +286,7 @@ __device__ __forceinline__ void robot_advance(KP p, EnvRegs& e, int ms)
     double dts = cn_div1000((double)ms);
     double ds = e.rv * dts, dth = e.rw * dts;
     double sn, cs;
-    cn_det_sincos(fma(0.5, dth, e.ryaw), &sn, &cs);
+    cn_det_sincos_t(p->trig, fma(0.5, dth, e.ryaw), &sn, &cs);
     double lim = p->room_half - p->robot_clearance;
     e.rx = cn_clamp(fma(ds, cs, e.rx), -lim, lim);
     e.ry = cn_clamp(fma(ds, sn, e.ry), -lim, lim);
@@ -342,7 +342,7 @@ __device__ __forceinline__ void sim_advance_contact(KP p, EnvRegs& e, int env, i
         // 2. the robot (uniform), and its linear velocity in the world frame
         robot_advance(p, e, h);
         double syaw, cyaw;
-        cn_det_sincos(e.ryaw, &syaw, &cyaw);
+        cn_det_sincos_t(p->trig, e.ryaw, &syaw, &cyaw);
         const double rvx = e.rv * cyaw, rvy = e.rv * syaw;
         // 3. integrate
         for (int i = lane; i < P; i += 64) {
@@ -512,7 +512,7 @@ __device__ __forceinline__ double cast_ray(KP p, const Lds& L, int env, int k, d
 // ORIG:244-260: heading straight to desired_point, no starting_pose offset
 __device__ __forceinline__ double orig_heading(KP p, double px, double py, double yaw)
 {
-    double ga = atan2(p->goal_y - py, p->goal_x - px);
+    double ga = cn_atan2_t(p->trig, p->goal_y - py, p->goal_x - px);
     double h = ga - yaw;
     if (h > CN_PI) h -= 2 * CN_PI;
     else if (h < -CN_PI) h += 2 * CN_PI;
@@ -529,7 +529,7 @@ __device__ __forceinline__ void observe_original(KP p, EnvRegs& e, const Lds& L,
     double dist = cn_np_around2(dist3(px, py, p->goal_x, p->goal_y));   // round(np.float64, 2), ORIG:280
     double head = cn_py_round2(orig_heading(p, px, py, yaw));        // ORIG:281
     double sy, cy;
-    cn_det_sincos(yaw, &sy, &cy);
+    cn_det_sincos_t(p->trig, yaw, &sy, &cy);
     const double ox = fma(p->lidar_offset_x, cy, px), oy = fma(p->lidar_offset_x, sy, py);
     const double h = p->room_half;
     const int nnear = near_peds(p, L, lane, ox, oy, sy, cy);
@@ -619,11 +619,11 @@ __device__ __forceinline__ double bbox_size(KP p, double* stage, int lane, int n
         if (i < n) {
             int j = (i == n - 1) ? 0 : i + 1;
             double s0, c0, s1, c1;
-            cn_det_sincos(((double)i * p->angle_inc_deg) * deg2rad - yaw, &s0, &c0);
-            cn_det_sincos(((double)j * p->angle_inc_deg) * deg2rad - yaw, &s1, &c1);
+            cn_det_sincos_t(p->trig, ((double)i * p->angle_inc_deg) * deg2rad - yaw, &s0, &c0);
+            cn_det_sincos_t(p->trig, ((double)j * p->angle_inc_deg) * deg2rad - yaw, &s1, &c1);
             double x0 = cn_py_round3(px + (MAXR * c0)), y0 = cn_py_round3(py + (MAXR * s0) * -1.0);
             double x1 = cn_py_round3(px + (MAXR * c1)), y1 = cn_py_round3(py + (MAXR * s1) * -1.0);
-            stage[lane] = hypot(x0 - x1, y0 - y1);
+            stage[lane] = cn_hypot(x0 - x1, y0 - y1);
         }
         CN_SYNC();
         int cnt = min(64, n - i0);
@@ -763,14 +763,14 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
     CN_T(24);
     // ENV:267-268: the angular velocity is used as the angle
     double sw_, cw_;
-    if (have_tg) { sw_ = tg.sw; cw_ = tg.cw; } else cn_det_sincos(w, &sw_, &cw_);
+    if (have_tg) { sw_ = tg.sw; cw_ = tg.cw; } else cn_det_sincos_t(p->trig, w, &sw_, &cw_);
     double agent_vel_x = -1.0 * (v * cw_);
     double agent_vel_y = v * sw_;
 
     CN_T(2);
     // ---- lidar raycast (XACRO:150-178) + UTL:375-392 sanitise + UTL:110-126 end points ----------
     double sy, cy;
-    if (have_tg) { sy = tg.sy; cy = tg.cy; } else cn_det_sincos(yaw, &sy, &cy);
+    if (have_tg) { sy = tg.sy; cy = tg.cy; } else cn_det_sincos_t(p->trig, yaw, &sy, &cy);
     const double ox = fma(p->lidar_offset_x, cy, px), oy = fma(p->lidar_offset_x, sy, py);
     const double h = p->room_half;
     const double deg2rad = CN_PI / 180.0;
@@ -1345,7 +1345,7 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
     CN_T(14);
     // ENV:745-760 speed of the tracks matched in this call
     if (lane < e.ntracks && TRK(CN_TF_DQLEN, lane) > 1.5) {
-        double dc = hypot(TRK(CN_TF_D0Y, lane) - TRK(CN_TF_D1Y, lane), TRK(CN_TF_D0X, lane) - TRK(CN_TF_D1X, lane));
+        double dc = cn_hypot(TRK(CN_TF_D0Y, lane) - TRK(CN_TF_D1Y, lane), TRK(CN_TF_D0X, lane) - TRK(CN_TF_D1X, lane));
         TRK(CN_TF_SPEED, lane) = dc / TRK(CN_TF_T, lane);
     }
     CN_SYNC();
@@ -1460,8 +1460,8 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
                     const double gcp = (td > p->max_scan_range) ? 0.0 : (p->max_scan_range - td) / (p->max_scan_range - p->min_scan_range);
                     double cpv;
                     if ((hasm >> lane) & 1ull) {
-                        const double d1 = hypot(a0x - hitp[lane], a0y - hitp[hcap + lane]);
-                        const double d2 = hypot(a0x - hitp[2 * hcap + lane], a0y - hitp[3 * hcap + lane]);
+                        const double d1 = cn_hypot(a0x - hitp[lane], a0y - hitp[hcap + lane]);
+                        const double d2 = cn_hypot(a0x - hitp[2 * hcap + lane], a0y - hitp[3 * hcap + lane]);
                         const double dcp = fmin(d1, d2);
                         if (rv == 0) { cpv = 1.0 * gcp; ego = 0.0; }
                         else {
@@ -1558,7 +1558,7 @@ struct RwLds { unsigned short* fi; int* g; unsigned char* tt; unsigned short* ts
 __device__ __forceinline__ double rw_heading(KP p, double px, double py, double yaw)
 {   // RW:186-200 (starting_point added to the position)
     double cx = px + p->start_x, cy = py + p->start_y;
-    double h = atan2(p->goal_y - cy, p->goal_x - cx) - yaw;
+    double h = cn_atan2_t(p->trig, p->goal_y - cy, p->goal_x - cx) - yaw;
     if (h > CN_PI) h -= 2 * CN_PI;
     else if (h < -CN_PI) h += 2 * CN_PI;
     return h;
@@ -1578,13 +1578,13 @@ __device__ __forceinline__ void observe_realworld(KP p, const Poly& pg, EnvRegs&
     const double distance_to_goal = cn_np_around2(rw_distance(p, px, py));      // RW:209
     const double heading = cn_py_round2(rw_heading(p, px, py, yaw));            // RW:210
     double sw_, cw_;
-    cn_det_sincos(w, &sw_, &cw_);
+    cn_det_sincos_t(p->trig, w, &sw_, &cw_);
     const double agent_vel_x = -1.0 * (v * cw_), agent_vel_y = v * sw_;         // RW:211-212
     double clx = px, cly = py, clvx = 0.0, clvy = 0.0;                          // RW:215-216 closest obstacle pose / velocity
 
     // ---- lidar + RW:220-225: sanitise, end points; the observation carries the UNROUNDED range ----------------------------------
     double sy, cy;
-    cn_det_sincos(yaw, &sy, &cy);
+    cn_det_sincos_t(p->trig, yaw, &sy, &cy);
     const double ox = fma(p->lidar_offset_x, cy, px), oy = fma(p->lidar_offset_x, sy, py);
     const double h = p->room_half;
     const int nnear = near_peds(p, L, lane, ox, oy, sy, cy);
@@ -1758,7 +1758,7 @@ __device__ __forceinline__ void observe_realworld(KP p, const Poly& pg, EnvRegs&
     double* const T = L.trk;
     tracker_stage(p, e, L, T, lane, nconf, now);
     if (lane < e.ntracks && TRK(CN_TF_DQLEN, lane) > 1.5) {
-        double dc = hypot(TRK(CN_TF_D0Y, lane) - TRK(CN_TF_D1Y, lane), TRK(CN_TF_D0X, lane) - TRK(CN_TF_D1X, lane));
+        double dc = cn_hypot(TRK(CN_TF_D0Y, lane) - TRK(CN_TF_D1Y, lane), TRK(CN_TF_D0X, lane) - TRK(CN_TF_D1X, lane));
         TRK(CN_TF_SPEED, lane) = dc / TRK(CN_TF_T, lane);
     }
     CN_SYNC();
@@ -1800,8 +1800,8 @@ __device__ __forceinline__ void observe_realworld(KP p, const Poly& pg, EnvRegs&
                 if (cnt == 0) { if (p->geos_untyped_empty) break; continue; }
                 if (cnt == 1) break;
                 const int l1 = __ffsll((long long)m) - 1, l2 = __ffsll((long long)(m & (m - 1ull))) - 1;
-                const double d1 = hypot(a0x - bcast_d(hx, l1), a0y - bcast_d(hy, l1));
-                const double d2 = hypot(a0x - bcast_d(hx, l2), a0y - bcast_d(hy, l2));
+                const double d1 = cn_hypot(a0x - bcast_d(hx, l1), a0y - bcast_d(hy, l1));
+                const double d2 = cn_hypot(a0x - bcast_d(hx, l2), a0y - bcast_d(hy, l2));
                 dcp = fmin(d1, d2); has = 1;
                 break;
             }
