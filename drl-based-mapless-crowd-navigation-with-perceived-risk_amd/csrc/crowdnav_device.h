@@ -145,6 +145,28 @@ __device__ __forceinline__ double cn_fma_s(double a, double b, double c)
     asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c));
     return d;
 }
+// fmin / fmax as the bare instruction.  Through the builtin the compiler first canonicalises every operand it cannot prove
+// free of signalling NaNs (v_max_f64 x, x, x: up to three instructions per min); the hardware instruction already returns
+// the other operand for a quiet NaN, which is all fmin()/fmax() promise and all these values can be.
+__device__ __forceinline__ double cn_vmin(double a, double b)
+{
+    double d;
+    asm("v_min_f64 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ double cn_vmax(double a, double b)
+{
+    double d;
+    asm("v_max_f64 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ double cn_vmax_s(double a, double b)     // b: wave-uniform, held in scalar registers
+{
+    double d;
+    asm("v_max_f64 %0, %1, %2" : "=v"(d) : "v"(a), "s"(b));
+    return d;
+}
+__device__ __forceinline__ double cn_vclamp(double x, double lo, double hi) { return cn_vmin(cn_vmax(x, lo), hi); }
 __device__ __forceinline__ void cn_det_sincos_t(cn_ktab t, double x, double* sn, double* cs)
 {
     double fn = rint(x * t[0]);
@@ -180,7 +202,7 @@ __device__ __forceinline__ void cn_det_sincos_t(cn_ktab t, double x, double* sn,
 __device__ __forceinline__ double cn_atan2_t(cn_ktab t, double y, double x)
 {
     const double ax = fabs(x), ay = fabs(y);
-    const double mx = fmax(ax, ay), mn = fmin(ax, ay);
+    const double mx = cn_vmax(ax, ay), mn = cn_vmin(ax, ay);
     const bool hi = mn > t[27] * mx;
     const double num = hi ? mn - mx : mn, den = hi ? mn + mx : mx;
     const double r = (mx == 0.0) ? 0.0 : num / den;
@@ -208,7 +230,7 @@ __device__ __forceinline__ double cn_atan2_t(cn_ktab t, double y, double x)
 __device__ __forceinline__ double cn_hypot(double x, double y)
 {
     const double ax = fabs(x), ay = fabs(y);
-    const double a = fmax(ax, ay), b = fmin(ax, ay);
+    const double a = cn_vmax(ax, ay), b = cn_vmin(ax, ay);
     return sqrt(fma(a, a, b * b));
 }
 
@@ -235,8 +257,8 @@ __device__ __forceinline__ double cn_iou3(double ax, double ay, double bx, doubl
 {
     double axp = ax + half, axm = ax - half, ayp = ay + half, aym = ay - half;
     double bxp = bx + half, bxm = bx - half, byp = by + half, bym = by - half;
-    double ix = fmin(axp, bxp) - fmax(axm, bxm);
-    double iy = fmin(ayp, byp) - fmax(aym, bym);
+    double ix = cn_vmin(axp, bxp) - cn_vmax(axm, bxm);
+    double iy = cn_vmin(ayp, byp) - cn_vmax(aym, bym);
     if (!(ix > 0.0 && iy > 0.0)) return 0.0;
     double inter = ix * iy;
     double area_a = (axp - axm) * (ayp - aym);
@@ -252,8 +274,8 @@ __device__ __forceinline__ bool cn_iou3_positive(double ax, double ay, double bx
 {
     double axp = ax + half, axm = ax - half, ayp = ay + half, aym = ay - half;
     double bxp = bx + half, bxm = bx - half, byp = by + half, bym = by - half;
-    double ix = fmin(axp, bxp) - fmax(axm, bxm);
-    double iy = fmin(ayp, byp) - fmax(aym, bym);
+    double ix = cn_vmin(axp, bxp) - cn_vmax(axm, bxm);
+    double iy = cn_vmin(ayp, byp) - cn_vmax(aym, bym);
     if (!(ix > 0.0 && iy > 0.0)) return false;
     double inter = ix * iy;
     double area_a = (axp - axm) * (ayp - aym);
@@ -301,13 +323,13 @@ __device__ __forceinline__ double cn_lane63_d(double v)
 __device__ __forceinline__ double cn_wave_min_d(double v)
 {
     const double id = INFINITY;
-    CN_DPP_REDUCE(double, cn_dpp_d, v, id, fmin);
+    CN_DPP_REDUCE(double, cn_dpp_d, v, id, cn_vmin);
     return cn_lane63_d(v);
 }
 __device__ __forceinline__ double cn_wave_max_d(double v)
 {
     const double id = -INFINITY;
-    CN_DPP_REDUCE(double, cn_dpp_d, v, id, fmax);
+    CN_DPP_REDUCE(double, cn_dpp_d, v, id, cn_vmax);
     return cn_lane63_d(v);
 }
 __device__ __forceinline__ int cn_add_i(int a, int b) { return a + b; }

@@ -199,14 +199,14 @@ __device__ __forceinline__ void ped_advance(KP p, int env, int lane, double* ped
         while (a < dt) {
             if (split > tc && a >= split) {                  // the cut comes first (an update AT the cut belongs to the second half)
                 double ds = cn_div1000((double)(split - tc));
-                x = cn_clamp(fma(vx, ds, x), lo, hi);
-                y = cn_clamp(fma(vy, ds, y), lo, hi);
+                x = cn_vclamp(fma(vx, ds, x), lo, hi);
+                y = cn_vclamp(fma(vy, ds, y), lo, hi);
                 tc = split;
             }
             if (a > tc) {
                 double ds = cn_div1000((double)(a - tc));    // == (a - tc) / 1000.0 exactly
-                x = cn_clamp(fma(vx, ds, x), lo, hi);
-                y = cn_clamp(fma(vy, ds, y), lo, hi);
+                x = cn_vclamp(fma(vx, ds, x), lo, hi);
+                y = cn_vclamp(fma(vy, ds, y), lo, hi);
                 tc = a;
             }
             if (p->ped_mode == 0) {  // CROWD:101-102: cn_rng_u01(seed, gid, 1, i, 2m | 2m+1); the env part of the key is
@@ -226,14 +226,14 @@ __device__ __forceinline__ void ped_advance(KP p, int env, int lane, double* ped
         }
         if (split > tc) {
             double ds = cn_div1000((double)(split - tc));
-            x = cn_clamp(fma(vx, ds, x), lo, hi);
-            y = cn_clamp(fma(vy, ds, y), lo, hi);
+            x = cn_vclamp(fma(vx, ds, x), lo, hi);
+            y = cn_vclamp(fma(vy, ds, y), lo, hi);
             tc = split;
         }
         if (dt > tc) {
             double ds = cn_div1000((double)(dt - tc));
-            x = cn_clamp(fma(vx, ds, x), lo, hi);
-            y = cn_clamp(fma(vy, ds, y), lo, hi);
+            x = cn_vclamp(fma(vx, ds, x), lo, hi);
+            y = cn_vclamp(fma(vy, ds, y), lo, hi);
         }
         ped_p[2 * i] = x; ped_p[2 * i + 1] = y;
         ped_v[2 * i] = vx; ped_v[2 * i + 1] = vy;
@@ -260,8 +260,8 @@ __device__ __forceinline__ void robot_advance_sc(KP p, EnvRegs& e, int ms, doubl
     double dts = cn_div1000((double)ms);
     double ds = e.rv * dts, dth = e.rw * dts;
     double lim = p->room_half - p->robot_clearance;
-    e.rx = cn_clamp(fma(ds, cs, e.rx), -lim, lim);
-    e.ry = cn_clamp(fma(ds, sn, e.ry), -lim, lim);
+    e.rx = cn_vclamp(fma(ds, cs, e.rx), -lim, lim);
+    e.ry = cn_vclamp(fma(ds, sn, e.ry), -lim, lim);
     e.ryaw = wrap_yaw(e.ryaw + dth);
 }
 // Env.step's two robot advances (dt, then the scan latency) with every sine and cosine the step needs evaluated in ONE pass:
@@ -288,8 +288,8 @@ __device__ __forceinline__ void robot_advance(KP p, EnvRegs& e, int ms)
     double sn, cs;
     cn_det_sincos_t(p->trig, fma(0.5, dth, e.ryaw), &sn, &cs);
     double lim = p->room_half - p->robot_clearance;
-    e.rx = cn_clamp(fma(ds, cs, e.rx), -lim, lim);
-    e.ry = cn_clamp(fma(ds, sn, e.ry), -lim, lim);
+    e.rx = cn_vclamp(fma(ds, cs, e.rx), -lim, lim);
+    e.ry = cn_vclamp(fma(ds, sn, e.ry), -lim, lim);
     double th = e.ryaw + dth;
     if (th > CN_PI) th -= 2.0 * CN_PI;
     else if (th <= -CN_PI) th += 2.0 * CN_PI;
@@ -346,8 +346,8 @@ __device__ __forceinline__ void sim_advance_contact(KP p, EnvRegs& e, int env, i
         const double rvx = e.rv * cyaw, rvy = e.rv * syaw;
         // 3. integrate
         for (int i = lane; i < P; i += 64) {
-            ped_p[2 * i] = cn_clamp(fma(ped_v[2 * i], hs, ped_p[2 * i]), lo, hi);
-            ped_p[2 * i + 1] = cn_clamp(fma(ped_v[2 * i + 1], hs, ped_p[2 * i + 1]), lo, hi);
+            ped_p[2 * i] = cn_vclamp(fma(ped_v[2 * i], hs, ped_p[2 * i]), lo, hi);
+            ped_p[2 * i + 1] = cn_vclamp(fma(ped_v[2 * i + 1], hs, ped_p[2 * i + 1]), lo, hi);
         }
         CN_SYNC();
         // 4. corrections from the post-integration state
@@ -379,8 +379,8 @@ __device__ __forceinline__ void sim_advance_contact(KP p, EnvRegs& e, int env, i
         }
         CN_SYNC();
         for (int i = lane; i < P; i += 64) {
-            ped_p[2 * i] = cn_clamp(ped_p[2 * i] + corr[4 * i], lo, hi);
-            ped_p[2 * i + 1] = cn_clamp(ped_p[2 * i + 1] + corr[4 * i + 1], lo, hi);
+            ped_p[2 * i] = cn_vclamp(ped_p[2 * i] + corr[4 * i], lo, hi);
+            ped_p[2 * i + 1] = cn_vclamp(ped_p[2 * i + 1] + corr[4 * i + 1], lo, hi);
             ped_v[2 * i] += corr[4 * i + 2]; ped_v[2 * i + 1] += corr[4 * i + 3];
         }
         CN_SYNC();
@@ -479,8 +479,8 @@ __device__ __forceinline__ double cast_ray(KP p, const Lds& L, int env, int k, d
         // Rays of a 64-block point within 64 degrees of each other, so whole blocks skip the divide of a wall behind them.
         const double ax = (dx > 0.0 ? h : -h) - ox, ay = (dy > 0.0 ? h : -h) - oy;
         const double reach = p->lidar_max * (1.0 + 1e-9);
-        if (wall_x && dx != 0.0 && (dx > 0.0 ? ax : -ax) <= fma(reach, fabs(dx), 1e-12)) t = fmin(t, ax / dx);
-        if (wall_y && dy != 0.0 && (dy > 0.0 ? ay : -ay) <= fma(reach, fabs(dy), 1e-12)) t = fmin(t, ay / dy);
+        if (wall_x && dx != 0.0 && (dx > 0.0 ? ax : -ax) <= fma(reach, fabs(dx), 1e-12)) t = cn_vmin(t, ax / dx);
+        if (wall_y && dy != 0.0 && (dy > 0.0 ? ay : -ay) <= fma(reach, fabs(dy), 1e-12)) t = cn_vmin(t, ay / dy);
         if (t < p->lidar_min) t = p->lidar_min;
         const int q = k >> 6;                                  // this block of 64 rays (wave-uniform)
         auto test = [&](int c) {
@@ -491,8 +491,8 @@ __device__ __forceinline__ double cast_ray(KP p, const Lds& L, int env, int k, d
                 double sq = sqrt(disc);
                 double t2 = b + sq;
                 if (t2 >= p->lidar_min) {
-                    double t1 = fmax(b - sq, p->lidar_min);
-                    t = fmin(t, t1);
+                    double t1 = cn_vmax_s(b - sq, p->lidar_min);
+                    t = cn_vmin(t, t1);
                 }
             }
         };
@@ -552,7 +552,7 @@ __device__ __forceinline__ void observe_original(KP p, EnvRegs& e, const Lds& L,
             if (isinf(r)) v = 0.6;                                    // ORIG:290-291: the literal, not max_scan_range
             else if (r != r) v = 0.0;
             else v = r;
-            smin = fmin(smin, v);
+            smin = cn_vmin(smin, v);
             double so = cn_py_round3(v);                              // ORIG:317
             o32[j] = (float)so;
             if (f32) f32[j] = (float)so;
@@ -809,7 +809,7 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
             else if (r == 0.0) sc = MAXR;
             else if (r > MAXR) sc = MAXR;
             else sc = r;
-            smin = fmin(smin, sc);
+            smin = cn_vmin(smin, sc);
             // sin/cos(radians(j * inc) - yaw) by angle addition from a host table of sin/cos(radians(j * inc))
             if constexpr (!GT) {      // end points feed the segmentation only
             const double sa = fma(tS, cy, -(tC * sy)), ca = fma(tC, cy, tS * sy);
@@ -1462,7 +1462,7 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
                     if ((hasm >> lane) & 1ull) {
                         const double d1 = cn_hypot(a0x - hitp[lane], a0y - hitp[hcap + lane]);
                         const double d2 = cn_hypot(a0x - hitp[2 * hcap + lane], a0y - hitp[3 * hcap + lane]);
-                        const double dcp = fmin(d1, d2);
+                        const double dcp = cn_vmin(d1, d2);
                         if (rv == 0) { cpv = 1.0 * gcp; ego = 0.0; }
                         else {
                             double ttc = dcp / rv;
@@ -1606,7 +1606,7 @@ __device__ __forceinline__ void observe_realworld(KP p, const Poly& pg, EnvRegs&
             else if (t == 0.0) sc = MAXR;
             else if (t > MAXR) sc = MAXR;
             else sc = t;
-            smin = fmin(smin, sc);
+            smin = cn_vmin(smin, sc);
             const double tS = p->ang_s[j], tC = p->ang_c[j];
             const double sa = fma(tS, cy, -(tC * sy)), ca = fma(tC, cy, tS * sy);
             L.ptx[j] = (int)cn_round_scaled(px + (sc * ca), 1000.0);
@@ -1802,7 +1802,7 @@ __device__ __forceinline__ void observe_realworld(KP p, const Poly& pg, EnvRegs&
                 const int l1 = __ffsll((long long)m) - 1, l2 = __ffsll((long long)(m & (m - 1ull))) - 1;
                 const double d1 = cn_hypot(a0x - bcast_d(hx, l1), a0y - bcast_d(hy, l1));
                 const double d2 = cn_hypot(a0x - bcast_d(hx, l2), a0y - bcast_d(hy, l2));
-                dcp = fmin(d1, d2); has = 1;
+                dcp = cn_vmin(d1, d2); has = 1;
                 break;
             }
             const double gcp = (td > p->max_scan_range) ? 0.0 : (p->max_scan_range - td) / (p->max_scan_range - p->min_scan_range);
