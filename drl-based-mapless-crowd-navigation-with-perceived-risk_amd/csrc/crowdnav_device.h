@@ -166,6 +166,21 @@ __device__ __forceinline__ double cn_vmax_s(double a, double b)     // b: wave-u
     asm("v_max_f64 %0, %1, %2" : "=v"(d) : "v"(a), "s"(b));
     return d;
 }
+// base[i] with a wave-uniform base and an unsigned 32-bit index: the byte offset stays a 32-bit VGPR next to the scalar
+// base (global_load/store ... v, s[base]) instead of a sign-extended 64-bit address built from four vector instructions.
+template <typename T> __device__ __forceinline__ T cn_ldg(const T* base, unsigned i)
+{
+    return *(const T*)((const char*)base + (size_t)(i * (unsigned)sizeof(T)));
+}
+template <typename T> __device__ __forceinline__ void cn_stg(T* base, unsigned i, T v)
+{
+    *(T*)((char*)base + (size_t)(i * (unsigned)sizeof(T))) = v;
+}
+// x with its sign flipped where s is negative (x * sign(s) for s != 0)
+__device__ __forceinline__ double cn_xorsign(double x, double s)
+{
+    return __hiloint2double(__double2hiint(x) ^ (__double2hiint(s) & (int)0x80000000), __double2loint(x));
+}
 __device__ __forceinline__ double cn_vclamp(double x, double lo, double hi) { return cn_vmin(cn_vmax(x, lo), hi); }
 __device__ __forceinline__ void cn_det_sincos_t(cn_ktab t, double x, double* sn, double* cs)
 {

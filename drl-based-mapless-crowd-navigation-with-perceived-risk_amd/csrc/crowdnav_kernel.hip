@@ -477,10 +477,10 @@ __device__ __forceinline__ double cast_ray(KP p, const Lds& L, int env, int k, d
         // Per ray the same argument again, before paying the divide: a / d <= lidar_max  <=>  a sign(d) <= lidar_max |d|
         // (with slack; a quotient beyond lidar_max cannot change a range that is reported as "no return" above it).
         // Rays of a 64-block point within 64 degrees of each other, so whole blocks skip the divide of a wall behind them.
-        const double ax = (dx > 0.0 ? h : -h) - ox, ay = (dy > 0.0 ? h : -h) - oy;
+        // (a sign(d) = h - o sign(d): the distance to the facing wall along the axis, two bit operations and a subtract)
         const double reach = p->lidar_max * (1.0 + 1e-9);
-        if (wall_x && dx != 0.0 && (dx > 0.0 ? ax : -ax) <= fma(reach, fabs(dx), 1e-12)) t = cn_vmin(t, ax / dx);
-        if (wall_y && dy != 0.0 && (dy > 0.0 ? ay : -ay) <= fma(reach, fabs(dy), 1e-12)) t = cn_vmin(t, ay / dy);
+        if (wall_x && dx != 0.0 && h - cn_xorsign(ox, dx) <= fma(reach, fabs(dx), 1e-12)) t = cn_vmin(t, (copysign(h, dx) - ox) / dx);
+        if (wall_y && dy != 0.0 && h - cn_xorsign(oy, dy) <= fma(reach, fabs(dy), 1e-12)) t = cn_vmin(t, (copysign(h, dy) - oy) / dy);
         if (t < p->lidar_min) t = p->lidar_min;
         const int q = k >> 6;                                  // this block of 64 rays (wave-uniform)
         auto test = [&](int c) {
@@ -795,20 +795,25 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
     }
     for (int k = lane; k < R; k += 64) {
         const double lc = lc_n, ls = ls_n, tS = tS_n, tC = tC_n;
-        if (k + 64 < R) {
-            if (!EXT) { lc_n = lidc[k + 64]; ls_n = lids[k + 64]; }
-            if (!GT) { tS_n = angs[R - 1 - (k + 64)]; tC_n = angc[R - 1 - (k + 64)]; }
+        if (k + 64 < R) {   // (unsigned 32-bit element offsets from the uniform table bases: one VALU instruction per address)
+            if (!EXT) { lc_n = cn_ldg(lidc, (unsigned)(k + 64)); ls_n = cn_ldg(lids, (unsigned)(k + 64)); }
+            if (!GT) { tS_n = cn_ldg(angs, (unsigned)(R - 1 - (k + 64))); tC_n = cn_ldg(angc, (unsigned)(R - 1 - (k + 64))); }
         }
         const double t = cast_ray<EXT>(p, L, env, k, ox, oy, sy, cy, nnear, wall_x, wall_y, lc, ls);
         if (k >= 1) {
-            int j = R - 1 - k;  // UTL:389-390 reverse, drop last
+            const unsigned j = (unsigned)(R - 1 - k);  // UTL:389-390 reverse, drop last
             double r = t;
             double sc;
-            if (isinf(r) && r > 0) sc = MAXR;
-            else if (r != r) sc = 0.0;                // UTL:380-381 NaN -> 0 (external scans only)
-            else if (r == 0.0) sc = MAXR;
-            else if (r > MAXR) sc = MAXR;
-            else sc = r;
+            if constexpr (EXT) {
+                if (isinf(r) && r > 0) sc = MAXR;
+                else if (r != r) sc = 0.0;                // UTL:380-381 NaN -> 0 (external scans only)
+                else if (r == 0.0) sc = MAXR;
+                else if (r > MAXR) sc = MAXR;
+                else sc = r;
+            } else {
+                // the simulated sensor returns +inf or a finite range >= lidar_min >= 0, never a NaN: the same chain, shorter
+                sc = (r == 0.0) ? MAXR : cn_vmin(r, MAXR);
+            }
             smin = cn_vmin(smin, sc);
             // sin/cos(radians(j * inc) - yaw) by angle addition from a host table of sin/cos(radians(j * inc))
             if constexpr (!GT) {      // end points feed the segmentation only
@@ -818,9 +823,9 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
             L.dmil[j] = (unsigned short)(int)cn_round_scaled(sc, 1000.0);
             }
             double so = cn_np_around3(sc);  // ENV:1042
-            o32[j] = (float)so;
-            if (f32) f32[j] = (float)so;
-            if (o64) o64[j] = so;
+            cn_stg(o32, j, (float)so);
+            if (f32) cn_stg(f32, j, (float)so);
+            if (o64) cn_stg(o64, j, so);
         }
     }
     CN_T(4);
