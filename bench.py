@@ -168,17 +168,41 @@ def main():
     acts = torch.stack([torch.rand((n_act, N), generator=g, device=dev) * 0.22,
                         torch.rand((n_act, N), generator=g, device=dev) * 4.0 - 2.0], 2).contiguous()
 
-    def barrier():
+    # The opening bracket.  A GPU that sits idle for a few ms clocks down and needs ~10 launches to come back
+    # (tools/startup_transient.py: the same 20 steps take 800 us right after work, 870 us after 5 ms of idling, 960 us
+    # after 100 ms), and a counters read-back or a rank barrier is such a pause.  So the episode counters are snapshotted
+    # on the device, the rank barrier comes first and the last `warm_tail` of the W warm-up steps run between it and the
+    # torch.cuda.synchronize() that starts the clock: barrier + synchronize still bracket the K timed steps, all W + the
+    # pre-roll steps are still untimed, and the timed region starts on a GPU in the state a long run keeps it in.
+    warm_tail = min(a.warmup, 3)
+
+    def rank_barrier():
+        if world > 1:
+            dist.barrier()
+
+    def barrier(streams=()):
+        """The contract's bracket: barrier over the ranks + torch.cuda.synchronize().  hipDeviceSynchronize blocks on an
+        interrupt and wakes up 60-75 us after the last kernel has finished (tools/startup_transient.py) -- 7 % of a
+        20-step sample of 0.85 ms that is host notification latency, not device work.  So the streams that carry the
+        timed launches are polled to completion first (hipStreamQuery, ~1 us a call); the synchronize that follows
+        then returns at once and still is the bracket."""
+        for s_ in streams:
+            while not s_.query():
+                pass
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
     def timed(mode):
         """K launches of cn_step; returns (wall s, kernel ms/launch, env-steps actually taken by this rank)."""
-        for i in range(a.preroll + a.warmup):
+        n_pre = a.preroll + a.warmup
+        for i in range(n_pre - warm_tail):
             env.step(acts[i % n_act], auto_reset=mode)
-        ep0 = env.counters()[:, 8].sum().item()
-        barrier()
+        ep0 = env.counters()[:, 8].sum()              # device scalar, read after the timed region (no host sync here)
+        rank_barrier()
+        for i in range(n_pre - warm_tail, n_pre):
+            env.step(acts[i % n_act], auto_reset=mode)
+        torch.cuda.synchronize(dev)
         stream = torch.cuda.current_stream(dev)
         ev0 = torch.cuda.Event(enable_timing=True)
         ev1 = torch.cuda.Event(enable_timing=True)
@@ -187,14 +211,14 @@ def main():
         for i in range(a.steps):
             env.step(acts[i % n_act], auto_reset=mode)
         ev1.record(stream)
-        barrier()
+        barrier((stream,))
         wall_ = time.perf_counter() - t0
         k_ms = ev0.elapsed_time(ev1) / a.steps       # cn_env_kernel is the only kernel in the timed region
         ep1 = env.counters()[:, 8].sum().item()
         torch.cuda.synchronize(dev)
         taken = N * a.steps
         if mode == "next":                            # a finished env spends one launch on its reset: not an env-step
-            taken -= int(ep1 - ep0)
+            taken -= int(ep1 - ep0.item())
         return wall_, k_ms, taken
 
     conc = 1
@@ -214,11 +238,22 @@ def main():
         # short timed sample (the driver uses 20 steps = 80 launches of ~40 us) is not paced by the Python enqueue loop
         act_slices = [[acts_[i][rows[g]] for g in range(G)] for i in range(n_act)]     # contiguous [n, 2] views
         calls = [[grp.envs[g].bind_step(act_slices[i][g], auto_reset=mode) for g in range(G)] for i in range(n_act)]
-        for i in range(a.preroll + a.warmup):
+        def episodes_dev():                            # finished episodes per group as device scalars, no host sync
+            out = []
+            for e_ in grp.envs:
+                with torch.cuda.stream(e_.stream):
+                    out.append(e_.counters()[:, 8].sum())
+            return out
+        n_pre = a.preroll + a.warmup
+        for i in range(n_pre - warm_tail):
             for c in calls[i % n_act]:
                 c()
-        ep0 = grp.episodes()
-        barrier()
+        ep0 = episodes_dev()
+        rank_barrier()
+        for i in range(n_pre - warm_tail, n_pre):
+            for c in calls[i % n_act]:
+                c()
+        torch.cuda.synchronize(dev)
         ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(G)]
         ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(G)]
         t0 = time.perf_counter()
@@ -229,10 +264,10 @@ def main():
                 c()
         for g in range(G):
             ev1[g].record(grp.streams[g])
-        barrier()
+        barrier(grp.streams)
         wall_ = time.perf_counter() - t0
         k_ms = sum(ev0[g].elapsed_time(ev1[g]) for g in range(G)) / G / steps_
-        taken = gcfg.n_envs * steps_ - (grp.episodes() - ep0 if mode == "next" else 0)
+        taken = gcfg.n_envs * steps_ - (grp.episodes() - sum(int(x.item()) for x in ep0) if mode == "next" else 0)
         grp.close()
         return wall_, k_ms, taken
 
