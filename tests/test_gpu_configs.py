@@ -1,9 +1,10 @@
-"""BASELINE.json configs 2, 3 and 4 at their FULL sizes against the CPU oracle, through the C-ABI (`-m gpu`).
+"""BASELINE.json configs 2, 3, 4 and 5 at their FULL sizes against the CPU oracle, through the C-ABI (`-m gpu`).
 
   config 2   4096 envs x 20 pedestrians x 360 rays, K = 8, one MI355X
   config 3   4096 envs, the TD3 actor in the loop (cn_actor_forward -> cn_step chains on 4 stream groups)
   config 4   envs sharded over ranks by global index, all-gather of episode returns: two ranks with the REAL kernel
              (two processes sharing cuda:0, gloo) against one handle
+  config 5   4096 envs x 100 pedestrians x 720 rays (dense crowd, the LDS-pressure case)
 
 Envs are independent, so the oracle needs < 1 s per config here (OpenMP over envs).  Bar: done flags and top-K
 indices bit-exact, observation / reward within 1e-5 (north_star); in practice everything is equal."""
@@ -52,6 +53,37 @@ def test_config2_full_size_4096_envs(oracle_mod):
         exact += int((og == oc).all(1).sum()); n_done += int(dc.sum())
     assert np.array_equal(env.counters().cpu().numpy()[:, :6], orc.counters())
     assert n_done > N // 2 and exact == STEPS * N
+
+
+def test_config5_full_size_dense_crowd_4096_envs(oracle_mod):
+    """4096 envs x 100 pedestrians x 720 rays in the 4.8 m room: every env every step against the oracle (the oracle needs
+    ~1 ms per env-step here, so 30 steps with OpenMP over the envs)."""
+    import torch
+    from crowdnav import Config
+    from crowdnav.env import VecEnv
+    N, STEPS = 4096, 30
+    cfg = Config(n_envs=N, n_peds=100, n_rays=720, k_obstacles=8, room_half=2.4, max_steps=12, seed=4321, ped_cycle_ms=1400)
+    env = VecEnv(cfg); env.enable_f64_obs()
+    orc = oracle_mod.Oracle(cfg.as_dict())
+    oracle_mod.set_num_threads()
+    env.reset(); torch.cuda.synchronize()
+    assert np.array_equal(env.obs_f64.cpu().numpy(), orc.reset())
+    g = torch.Generator(device="cpu").manual_seed(9)
+    n_done = exact = 0
+    for t in range(STEPS):
+        act = torch.stack([torch.rand(N, generator=g) * 0.22, torch.rand(N, generator=g) * 4 - 2], 1)
+        mode = "next" if t >= STEPS // 2 else "same"
+        env.step(act.cuda(), auto_reset=mode, want_final=True); torch.cuda.synchronize()
+        oc, rc, dc, ic, fc = orc.step(act.numpy().astype(np.float64), auto_reset=mode, want_final=True)
+        assert np.array_equal(env.done.cpu().numpy(), dc), t
+        assert np.array_equal(env.topk_idx.cpu().numpy(), ic), t
+        assert np.abs(env.reward.cpu().numpy() - rc).max() <= TOL, t
+        og = env.obs_f64.cpu().numpy()
+        assert np.abs(og - oc).max() <= TOL, t
+        exact += int((og == oc).all(1).sum()); n_done += int(dc.sum())
+    assert np.array_equal(env.counters().cpu().numpy()[:, :6], orc.counters())
+    assert (env.counters().cpu().numpy()[:, 6] == 0).all()          # status: no track / segment overflow in the dense crowd
+    assert n_done > N // 4 and exact == STEPS * N
 
 
 @pytest.mark.parametrize("sigma", [0.0, 1.0])
