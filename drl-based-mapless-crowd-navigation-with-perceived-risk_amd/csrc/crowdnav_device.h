@@ -239,6 +239,23 @@ __device__ __forceinline__ double cn_atan2_t(cn_ktab t, double y, double x)
     return copysign(a, y);
 }
 
+// sqrt() for the squares of lengths between a micrometre and a few metres (and exactly 0): the compiler's expansion of the
+// float64 square root -- v_rsq_f64 seed, one coupled Newton step on (g, h) ~ (sqrt x, 1 / (2 sqrt x)), two residual
+// corrections; correctly rounded -- without its exponent scaling for arguments below 2^-767 (five of its 17 instructions).
+// Same operations in the same order, so the same bits wherever the scaling was the identity; 0, +inf and NaN as sqrt().
+__device__ __forceinline__ double cn_sqrt(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = y * 0.5;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g); h = fma(h, r, h);
+    double d = fma(-g, g, x);
+    g = fma(d, h, g);
+    d = fma(-g, g, x);
+    g = fma(d, h, g);
+    return __builtin_amdgcn_class(x, 0x260) ? x : g;      // +-0, +inf: the seed is inf or 0 there
+}
+
 // hypot() for lengths of a few metres: the device library's version wraps the same sqrt(fma(a, a, b b)), a = the larger
 // magnitude, in exponent scaling and inf/nan handling (frexp / ldexp / class tests, a third of its instructions) that
 // coordinates in thousandths of a metre never need.  hypot(x, 0) = |x| exactly, as in C.
@@ -246,7 +263,7 @@ __device__ __forceinline__ double cn_hypot(double x, double y)
 {
     const double ax = fabs(x), ay = fabs(y);
     const double a = cn_vmax(ax, ay), b = cn_vmin(ax, ay);
-    return sqrt(fma(a, a, b * b));
+    return cn_sqrt(fma(a, a, b * b));
 }
 
 // ---- counter-based RNG (CROWD:101-102 random.uniform) ---------------------------------------

@@ -87,7 +87,7 @@ __device__ __forceinline__ double dist3(double ax, double ay, double bx, double 
 {
     // np.linalg.norm of the 3-vector (ENV:191-197) = sqrt(ddot(d, d)): BLAS accumulates with fma (pinned by the goldens)
     double dx = ax - bx, dy = ay - by;
-    return sqrt(fma(dy, dy, dx * dx));
+    return cn_sqrt(fma(dy, dy, dx * dx));
 }
 
 __device__ __forceinline__ bool in_box(double x, double y, double gx, double gy, double eps)
@@ -434,7 +434,7 @@ __device__ __forceinline__ int near_peds(KP p, const Lds& L, int lane, double ox
             u64 tag = ~0ull;
             if (cc > 0.0) {
                 const double rx_ = fma(cy, ocx, sy * ocy), ry_ = fma(cy, ocy, -(sy * ocx));     // oc in the robot frame
-                const double thr = fma(p->blk_cb, sqrt(cc), -(p->blk_sb * p->ped_radius)) - 1e-9;
+                const double thr = fma(p->blk_cb, cn_sqrt(cc), -(p->blk_sb * p->ped_radius)) - 1e-9;
                 tag = 0ull;
                 for (int q = 0; q < Wb; ++q)
                     if (fma(rx_, bd[2 * q], ry_ * bd[2 * q + 1]) >= thr) tag |= 1ull << q;
@@ -488,7 +488,7 @@ __device__ __forceinline__ double cast_ray(KP p, const Lds& L, int env, int k, d
             double b = fma(ocx, dx, ocy * dy);
             double disc = fma(b, b, -cc);
             if (disc >= 0.0) {
-                double sq = sqrt(disc);
+                double sq = cn_sqrt(disc);
                 double t2 = b + sq;
                 if (t2 >= p->lidar_min) {
                     double t1 = cn_vmax_s(b - sq, p->lidar_min);
@@ -1295,7 +1295,7 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
                 const double dd2 = fma(ocx, ocx, ocy * ocy);
                 inr = dd2 <= lim2_;
                 if (inr) {
-                    const double dd = sqrt(dd2);
+                    const double dd = cn_sqrt(dd2);
                     if (dd > r_) {                            // (origin inside the disc: nothing can stand in front of it)
                         seg = true;
                         const double k_ = (dd - r_) / dd;     // origin -> nearest surface point = k_ * oc
@@ -1327,14 +1327,14 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
             bool close_ = false;
             if (vis && slot < L.tcap) {
                 const double dx = cx - px, dy = cyy - py;
-                const double dp = sqrt(fma(dx, dx, dy * dy));
+                const double dp = cn_sqrt(fma(dx, dx, dy * dy));
                 double sx_ = cx, sy_ = cyy;
                 if (dp > 0.0) { sx_ = cx - r_ * (dx / dp); sy_ = cyy - r_ * (dy / dp); }
                 const double dist = cn_py_round3(dp - r_);
                 const double vx = L.pedv[2 * i], vy = L.pedv[2 * i + 1];
                 TRK(CN_TF_PX, slot) = cn_py_round3(sx_); TRK(CN_TF_PY, slot) = cn_py_round3(sy_); TRK(CN_TF_DIST, slot) = dist;
                 TRK(CN_TF_D0X, slot) = 0.0; TRK(CN_TF_D0Y, slot) = 0.0; TRK(CN_TF_D1X, slot) = 0.0; TRK(CN_TF_D1Y, slot) = 0.0;
-                TRK(CN_TF_T, slot) = (double)i; TRK(CN_TF_SPEED, slot) = sqrt(fma(vx, vx, vy * vy));
+                TRK(CN_TF_T, slot) = (double)i; TRK(CN_TF_SPEED, slot) = cn_sqrt(fma(vx, vx, vy * vy));
                 TRK(CN_TF_VX, slot) = -vx; TRK(CN_TF_VY, slot) = -vy; TRK(CN_TF_DQLEN, slot) = 0.0;
                 close_ = dist < 0.140;
             }
@@ -1371,7 +1371,7 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
         if (ts == 0.0) e.status |= CN_ST_DT_ZERO;
         const int nt = e.ntracks;
         double vx_ = (e.dq1x - e.dq0x) / ts, vy_ = (e.dq1y - e.dq0y) / ts;  // UTL:227-236
-        double agent_vel = sqrt(vx_ * vx_ + vy_ * vy_);
+        double agent_vel = cn_sqrt(vx_ * vx_ + vy_ * vy_);
         double obstacle_vel = (nt == 0) ? 0.0 : TRK(CN_TF_SPEED, 0);  // ENV:787-793
         // ENV:800-815: per-track velocity; the relative-motion end point of the LAST track survives
         if (!GT && lane < nt && TRK(CN_TF_DQLEN, lane) > 1.5) {
