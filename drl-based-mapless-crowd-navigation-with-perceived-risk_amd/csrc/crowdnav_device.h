@@ -145,6 +145,37 @@ __device__ __forceinline__ double cn_fma_s(double a, double b, double c)
     asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c));
     return d;
 }
+// sqrt() for the squares of lengths between a micrometre and a few metres (and exactly 0): the compiler's expansion of the
+// float64 square root -- v_rsq_f64 seed, one coupled Newton step on (g, h) ~ (sqrt x, 1 / (2 sqrt x)), two residual
+// corrections; correctly rounded -- without its exponent scaling for arguments below 2^-767 (five of its 17 instructions).
+// Same operations in the same order, so the same bits wherever the scaling was the identity; 0, +inf and NaN as sqrt().
+__device__ __forceinline__ double cn_sqrt(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = y * 0.5;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g); h = fma(h, r, h);
+    double d = fma(-g, g, x);
+    g = fma(d, h, g);
+    d = fma(-g, g, x);
+    g = fma(d, h, g);
+    return __builtin_amdgcn_class(x, 0x260) ? x : g;      // +-0, +inf: the seed is inf or 0 there
+}
+
+// a / b for a finite a and a normal, non-zero b whose quotient is neither huge nor denormal (every use states why): the
+// compiler's float64 division -- v_rcp_f64 seed, two Newton steps on the reciprocal, one residual correction of the quotient;
+// correctly rounded -- without v_div_scale x 2 / v_div_fmas' post-scale / v_div_fixup, which only act on extreme exponents,
+// zeros, infinities and NaNs.  Same operations in the same order: the same bits wherever those were the identity (8
+// instructions instead of 12).  b == 0 gives NaN here (not +-inf): callers guard it or discard the lane's result.
+__device__ __forceinline__ double cn_div(double a, double b)
+{
+    double y = __builtin_amdgcn_rcp(b);
+    y = fma(y, fma(-b, y, 1.0), y);
+    y = fma(y, fma(-b, y, 1.0), y);
+    const double q = a * y;
+    return fma(fma(-b, q, a), y, q);
+}
+
 // fmin / fmax as the bare instruction.  Through the builtin the compiler first canonicalises every operand it cannot prove
 // free of signalling NaNs (v_max_f64 x, x, x: up to three instructions per min); the hardware instruction already returns
 // the other operand for a quiet NaN, which is all fmin()/fmax() promise and all these values can be.
@@ -220,7 +251,7 @@ __device__ __forceinline__ double cn_atan2_t(cn_ktab t, double y, double x)
     const double mx = cn_vmax(ax, ay), mn = cn_vmin(ax, ay);
     const bool hi = mn > t[27] * mx;
     const double num = hi ? mn - mx : mn, den = hi ? mn + mx : mx;
-    const double r = (mx == 0.0) ? 0.0 : num / den;
+    const double r = (mx == 0.0) ? 0.0 : cn_div(num, den);      // den = mx or mn + mx >= the larger coordinate difference
     const double z = r * r;
     double q = fma(z, t[26], t[25]);
     q = cn_fma_s(z, q, t[24]);
@@ -237,23 +268,6 @@ __device__ __forceinline__ double cn_atan2_t(cn_ktab t, double y, double x)
     if (ay > ax) a = t[30] - (a - t[31]);
     if (__double2hiint(x) < 0) a = t[32] - (a - t[33]);
     return copysign(a, y);
-}
-
-// sqrt() for the squares of lengths between a micrometre and a few metres (and exactly 0): the compiler's expansion of the
-// float64 square root -- v_rsq_f64 seed, one coupled Newton step on (g, h) ~ (sqrt x, 1 / (2 sqrt x)), two residual
-// corrections; correctly rounded -- without its exponent scaling for arguments below 2^-767 (five of its 17 instructions).
-// Same operations in the same order, so the same bits wherever the scaling was the identity; 0, +inf and NaN as sqrt().
-__device__ __forceinline__ double cn_sqrt(double x)
-{
-    const double y = __builtin_amdgcn_rsq(x);
-    double g = x * y, h = y * 0.5;
-    const double r = fma(-h, g, 0.5);
-    g = fma(g, r, g); h = fma(h, r, h);
-    double d = fma(-g, g, x);
-    g = fma(d, h, g);
-    d = fma(-g, g, x);
-    g = fma(d, h, g);
-    return __builtin_amdgcn_class(x, 0x260) ? x : g;      // +-0, +inf: the seed is inf or 0 there
 }
 
 // hypot() for lengths of a few metres: the device library's version wraps the same sqrt(fma(a, a, b b)), a = the larger

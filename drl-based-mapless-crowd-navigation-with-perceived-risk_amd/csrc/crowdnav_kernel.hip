@@ -120,8 +120,8 @@ __device__ __forceinline__ unsigned long long ring_segment(const Poly& pg, int l
     if (den > 0.0) hit = (tn >= 0.0) && (tn <= den) && (un >= 0.0) && (un < den);
     else if (den < 0.0) hit = (tn <= 0.0) && (tn >= den) && (un <= 0.0) && (un > den);
     if (hit) {
-        double t = tn / den;
-        double u = un / den;
+        double t = cn_div(tn, den);      // hit lanes only: den != 0, |tn|, |un| <= |den|
+        double u = cn_div(un, den);
         hit = (t >= 0.0) && (t <= 1.0) && (u >= 0.0) && (u < 1.0);  // the oracle's test, on the quotients
         *hx = ax + t * rx;
         *hy = ay + t * ry;
@@ -479,8 +479,8 @@ __device__ __forceinline__ double cast_ray(KP p, const Lds& L, int env, int k, d
         // Rays of a 64-block point within 64 degrees of each other, so whole blocks skip the divide of a wall behind them.
         // (a sign(d) = h - o sign(d): the distance to the facing wall along the axis, two bit operations and a subtract)
         const double reach = p->lidar_max * (1.0 + 1e-9);
-        if (wall_x && dx != 0.0 && h - cn_xorsign(ox, dx) <= fma(reach, fabs(dx), 1e-12)) t = cn_vmin(t, (copysign(h, dx) - ox) / dx);
-        if (wall_y && dy != 0.0 && h - cn_xorsign(oy, dy) <= fma(reach, fabs(dy), 1e-12)) t = cn_vmin(t, (copysign(h, dy) - oy) / dy);
+        if (wall_x && dx != 0.0 && h - cn_xorsign(ox, dx) <= fma(reach, fabs(dx), 1e-12)) t = cn_vmin(t, cn_div(copysign(h, dx) - ox, dx));
+        if (wall_y && dy != 0.0 && h - cn_xorsign(oy, dy) <= fma(reach, fabs(dy), 1e-12)) t = cn_vmin(t, cn_div(copysign(h, dy) - oy, dy));
         if (t < p->lidar_min) t = p->lidar_min;
         const int q = k >> 6;                                  // this block of 64 rays (wave-uniform)
         auto test = [&](int c) {
@@ -886,11 +886,11 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
         int xbi = 0, ybi = 0, xbj = 0, ybj = 0;
         if (two) { xbi = L.ptx[ib]; ybi = L.pty[ib]; xbj = L.ptx[jb]; ybj = L.pty[jb]; }
         const double dya = cn_div1000((double)yai) - cn_div1000((double)yaj);
-        const double qa = (dya == 0) ? 0.0 : (cn_div1000((double)xai) - cn_div1000((double)xaj)) / dya;
+        const double qa = (dya == 0) ? 0.0 : cn_div(cn_div1000((double)xai) - cn_div1000((double)xaj), dya);   // |dy| >= 0.001 or the lane is discarded
         if (va) L.gq[ia] = (int)cn_round_scaled(qa, 1000.0);
         if (two) {
             const double dyb = cn_div1000((double)ybi) - cn_div1000((double)ybj);
-            const double qb = (dyb == 0) ? 0.0 : (cn_div1000((double)xbi) - cn_div1000((double)xbj)) / dyb;
+            const double qb = (dyb == 0) ? 0.0 : cn_div(cn_div1000((double)xbi) - cn_div1000((double)xbj), dyb);
             if (vb) L.gq[ib] = (int)cn_round_scaled(qb, 1000.0);
         }
     }
@@ -1470,9 +1470,9 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
                         const double dcp = cn_vmin(d1, d2);
                         if (rv == 0) { cpv = 1.0 * gcp; ego = 0.0; }
                         else {
-                            double ttc = dcp / rv;
+                            double ttc = cn_div(dcp, rv);        // rv != 0 here; a difference of two speeds, never denormal
                             if (ttc == 0.0) { ttc0 = true; ego = 1.0; }
-                            else ego = fmin(1.0, 0.15 / ttc);  // UTL:319
+                            else ego = fmin(1.0, cn_div(0.15, ttc));  // UTL:319
                             cpv = 0.5 * ego + 0.5 * gcp;
                         }
                     } else { ego = 0.0; cpv = 0.5 * 0.0 + 0.5 * gcp; }
