@@ -1,0 +1,14 @@
+#!/bin/bash
+# Everything under profiles/<tag>/ except the rocprofv3 passes (tools/profile.sh) and the parity sweep (tools/parity_sweep.sh),
+# in one go on the GPU box:  tools/regen_profiles.sh r02   -> gpurun_out/<tag>/*; copy what should be judged into profiles/<tag>/.
+TAG="${1:-r02}"; cd "$(dirname "$0")/.."; OUT="gpurun_out/$TAG"; mkdir -p "$OUT"
+F='amdgpu.ids'
+python bench.py 2>/dev/null | tail -1 > "$OUT/bench_n1.json"
+python bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > "$OUT/bench_n1_driver_command.json"
+python tools/stage_timing.py 256 2>&1 | grep -v $F > "$OUT/stage_timing.txt"
+python tools/wave_tail.py 2>&1 | grep -v $F > "$OUT/wave_tail.txt"
+python tools/tail_corr.py 2>&1 | grep -v $F > "$OUT/tail_corr.txt"
+python tools/bench_configs.py 2>&1 | grep -v $F > "$OUT/configs_1gpu.txt"
+{ python tools/quick_perf.py lidar-tracker; CN_RISK=1 python tools/quick_perf.py gt; CN_LAYOUT=1 python tools/quick_perf.py layout1; CN_LAYOUT=2 python tools/quick_perf.py layout2; } 2>&1 | grep -v $F > "$OUT/quick_perf.txt"
+python tools/startup_transient.py 24 3 2>&1 | grep -v $F > "$OUT/startup_transient.txt"
+tail -n 3 "$OUT"/bench_n1_driver_command.json | cut -c1-300; cat "$OUT/quick_perf.txt"
