@@ -183,6 +183,8 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
         !(c.geos_untyped_empty == 0 || c.geos_untyped_empty == 1) || !(c.ped_contact == 0 || c.ped_contact == 1) ||
         !(c.risk_mode == CN_RISK_LIDAR_TRACKER || c.risk_mode == CN_RISK_GT))
         return fail(CN_ERR_CONFIG, "cn_create: config out of range");
+    if (!(c.max_scan_range > c.min_scan_range))    // ENV:581, UTL:322 divide by their difference (ZeroDivisionError in the reference)
+        return fail(CN_ERR_CONFIG, "cn_create: max_scan_range must exceed min_scan_range");
     if (c.obs_layout == CN_LAYOUT_REALWORLD && (c.n_rays - 1 > 65535 / 2))
         return fail(CN_ERR_CONFIG, "cn_create: config out of range");
     if (c.risk_mode == CN_RISK_GT && c.obs_layout != CN_LAYOUT_RISK)
@@ -246,6 +248,7 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
     k.max_conf = h->max_conf; k.trk_cap = h->trk_cap; k.env_index_base = c.env_index_base; k.seed = c.seed;
     k.room_half = c.room_half; k.ped_radius = c.ped_radius; k.ped_vmax = c.ped_vmax; k.robot_clearance = c.robot_clearance;
     k.lidar_min = c.lidar_min; k.lidar_max = c.lidar_max; k.lidar_offset_x = c.lidar_offset_x;
+    k.ped_inv_cycle = 1.0 / (double)c.ped_cycle_ms;
     k.max_scan_range = c.max_scan_range; k.min_scan_range = c.min_scan_range; k.goal_x = c.goal_x; k.goal_y = c.goal_y;
     k.start_x = c.start_x; k.start_y = c.start_y; k.spawn_x = c.spawn_x; k.spawn_y = c.spawn_y; k.spawn_yaw = c.spawn_yaw;
     k.waypoint_radius = c.waypoint_radius; k.goal_eps = c.goal_eps; k.angle_inc_deg = angle_increment_deg(R); k.lidar_step = step;

@@ -176,6 +176,9 @@ __device__ __forceinline__ double cn_div(double a, double b)
     return fma(fma(-b, q, a), y, q);
 }
 
+// cn_div with IEEE results kept for a zero divisor (the flagged anomalies: a zero time step from external clocks)
+__device__ __forceinline__ double cn_div_z(double a, double b) { return (b == 0.0) ? a / b : cn_div(a, b); }
+
 // fmin / fmax as the bare instruction.  Through the builtin the compiler first canonicalises every operand it cannot prove
 // free of signalling NaNs (v_max_f64 x, x, x: up to three instructions per min); the hardware instruction already returns
 // the other operand for a quiet NaN, which is all fmin()/fmax() promise and all these values can be.

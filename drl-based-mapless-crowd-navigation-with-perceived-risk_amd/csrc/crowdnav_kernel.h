@@ -22,6 +22,7 @@ struct CnKParams {
     double room_half, ped_radius, ped_vmax, robot_clearance, lidar_min, lidar_max, lidar_offset_x;
     double max_scan_range, min_scan_range, goal_x, goal_y, start_x, start_y, spawn_x, spawn_y, spawn_yaw;
     double waypoint_radius, goal_eps, angle_inc_deg, lidar_step;
+    double ped_inv_cycle;    // 1.0 / ped_cycle_ms
     double blk_cb, blk_sb;   // cos / sin of the half-width (32.5 lidar steps) of a 64-ray block (near-pedestrian block bits)
     const double* blk_dir;   // [ceil(R/64)][2] robot-frame direction of ray 64 q + 32 (clamped to R - 1)
     double trig[34];         // constants of cn_det_sincos_t / cn_atan2_t (CN_TRIG_TABLE): scalar loads next to the polynomials

@@ -167,7 +167,7 @@ __device__ __forceinline__ void ped_advance(KP p, int env, int lane, double* ped
 {
     const double lo = -p->room_half + p->ped_radius, hi = p->room_half - p->ped_radius;
     const int T = p->ped_cycle_ms;
-    const double invT = 1.0 / (double)p->ped_cycle_ms;
+    const double invT = p->ped_inv_cycle;          // 1.0 / ped_cycle_ms, divided once on the host
     const long long gid = p->env_index_base + env;
     const double* preset = p->ped_preset + (size_t)env * 2 * p->P;
     // Per-env part of the schedule, once: t0 = cyc * T + ph.  Everything per pedestrian is then 32-bit
@@ -1231,9 +1231,9 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
             if (occ && len >= 4) {
                 m = ORDER(k0 + len / 2);  // ENV:577 Python-2 integer division
                 dm = cn_div1000((double)L.dmil[m]);
-                int est = 3 + (int)floor(29 * (p->max_scan_range - dm) / (p->max_scan_range - p->min_scan_range));
+                int est = 3 + (int)floor(cn_div(29 * (p->max_scan_range - dm), p->max_scan_range - p->min_scan_range));   // cn_create: max > min
                 int mn = len < est ? len : est;
-                double score = (double)no / (double)mn;
+                double score = cn_div((double)no, (double)mn);          // mn >= 3
                 int kinds = (no > 0) + (nw > 0) + (nn > 0);
                 if (kinds > 1) {
                     if (score >= 0.5) obj = (no > nw) ? TY_O : TY_W;
@@ -1351,7 +1351,7 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
     // ENV:745-760 speed of the tracks matched in this call
     if (lane < e.ntracks && TRK(CN_TF_DQLEN, lane) > 1.5) {
         double dc = cn_hypot(TRK(CN_TF_D0Y, lane) - TRK(CN_TF_D1Y, lane), TRK(CN_TF_D0X, lane) - TRK(CN_TF_D1X, lane));
-        TRK(CN_TF_SPEED, lane) = dc / TRK(CN_TF_T, lane);
+        TRK(CN_TF_SPEED, lane) = cn_div_z(dc, TRK(CN_TF_T, lane));
     }
     CN_SYNC();
 
@@ -1370,13 +1370,13 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
         const double ts = e.ts;
         if (ts == 0.0) e.status |= CN_ST_DT_ZERO;
         const int nt = e.ntracks;
-        double vx_ = (e.dq1x - e.dq0x) / ts, vy_ = (e.dq1y - e.dq0y) / ts;  // UTL:227-236
+        double vx_ = cn_div_z(e.dq1x - e.dq0x, ts), vy_ = cn_div_z(e.dq1y - e.dq0y, ts);  // UTL:227-236
         double agent_vel = cn_sqrt(vx_ * vx_ + vy_ * vy_);
         double obstacle_vel = (nt == 0) ? 0.0 : TRK(CN_TF_SPEED, 0);  // ENV:787-793
         // ENV:800-815: per-track velocity; the relative-motion end point of the LAST track survives
         if (!GT && lane < nt && TRK(CN_TF_DQLEN, lane) > 1.5) {
             double chx = TRK(CN_TF_D0X, lane) - TRK(CN_TF_D1X, lane), chy = TRK(CN_TF_D0Y, lane) - TRK(CN_TF_D1Y, lane);
-            TRK(CN_TF_VX, lane) = chx / ts; TRK(CN_TF_VY, lane) = chy / ts;
+            TRK(CN_TF_VX, lane) = cn_div_z(chx, ts); TRK(CN_TF_VY, lane) = cn_div_z(chy, ts);
         }
         double vo_x = e.dq1x, vo_y = e.dq1y;
         if (nt > 0) {
@@ -1389,7 +1389,7 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
         CN_SYNC();
         // UTL:251-293 collision point per track; lanes = the 64 ring edges
         const double a0x = e.dq0x, a0y = e.dq0y;
-        double gradient = (vo_y == 0.0) ? 0.0 : (vo_x - a0x) / vo_y - a0y;  // UTL:261 precedence as written
+        double gradient = (vo_y == 0.0) ? 0.0 : cn_div(vo_x - a0x, vo_y) - a0y;  // UTL:261 precedence as written
         double bb0 = a0x - (gradient * a0y);
         int hi = (int)ceil(a0x + 3.5), lo = (int)floor(a0x - 3.5);
         double ego_max = 0.0;
@@ -1462,7 +1462,7 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
                 bool ttc0 = false;
                 if (i < c1) {
                     const double td = TRK(CN_TF_DIST, i);
-                    const double gcp = (td > p->max_scan_range) ? 0.0 : (p->max_scan_range - td) / (p->max_scan_range - p->min_scan_range);
+                    const double gcp = (td > p->max_scan_range) ? 0.0 : cn_div(p->max_scan_range - td, p->max_scan_range - p->min_scan_range);
                     double cpv;
                     if ((hasm >> lane) & 1ull) {
                         const double d1 = cn_hypot(a0x - hitp[lane], a0y - hitp[hcap + lane]);
