@@ -68,6 +68,32 @@ static void destroy_handle(cn_env_s* h)
 }
 struct HandleDeleter { void operator()(cn_env_s* h) const { destroy_handle(h); } };
 
+// Host restatement of the kernel's association table for bb = bb_spawn (crowdnav_kernel.hip, "ENV:448-485"): the same IEEE
+// operations in the same order (+ - * / floor ceil; this file is compiled with -ffp-contract=off like the kernel), so the
+// table a wavefront copies equals the one it would compute.  tests/test_gpu_parity.py pins that (table on / table off).
+static void build_assoc_table(CnKParams& k, int16_t* tab)
+{
+    k.assoc_fast = 0; k.assoc_k1 = 0;
+    const double Tm = 2000.0 * k.bb_spawn;
+    const int K1 = (int)floor(Tm - 1e-7), K2 = (int)ceil(Tm + 1e-7);
+    if (!((K2 == K1 + 1) && K1 >= 0 && K1 <= 254)) return;
+    const double c_hi = 0.0005 * (1.0 + 1e-6), c_lo = 0.0005 * (1.0 - 1e-6);
+    const double T2 = Tm * Tm;
+    const double Phi = T2 * (2.0 * c_hi) / (1.0 + c_hi), Plo = T2 * (2.0 * c_lo) / (1.0 + c_lo);
+    for (int d = 0; d <= K1 + 1; ++d) {
+        int m = -1;
+        if (d <= K1) {
+            const double fx = Tm - (double)d;
+            const double mm = fmin(ceil(Tm - Phi / fx) - 1.0, (double)K1);
+            m = mm < 0.0 ? -1 : (int)mm;
+            if (m >= 0 && !(fx * (Tm - (double)m) > Phi)) return;
+            if (m + 1 <= K1 && !(fx * (Tm - (double)(m + 1)) < Plo)) return;
+        }
+        tab[d] = (int16_t)m;
+    }
+    k.assoc_k1 = K1; k.assoc_fast = 1;
+}
+
 static size_t lds_bytes_impl(int R, int P, int K, int max_conf, int trk_cap, bool near_separate, int layout = 0)
 {
     // must mirror the carve in cn_env_kernel
@@ -224,7 +250,7 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
     }
     for (int k = 0; k < 64; ++k) { double a = -(double)k * M_PI / 32.0; poly[k] = cos(a); poly[64 + k] = sin(a); }
     HIPCHK(hipMalloc(&h->d_lidar, lidar.size() * 8));
-    HIPCHK(hipMalloc(&h->d_poly, poly.size() * 8));
+    HIPCHK(hipMalloc(&h->d_poly, poly.size() * 8 + 512));      // + the association table (256 shorts, below)
     HIPCHK(hipMemcpy(h->d_lidar, lidar.data(), lidar.size() * 8, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->d_poly, poly.data(), poly.size() * 8, hipMemcpyHostToDevice));
     size_t pb = (size_t)N * (P > 0 ? P : 1) * 16;
@@ -265,6 +291,10 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
         (void)hipFree(d_out);
         HIPCHK(e1); HIPCHK(e2);
         k.bb_spawn_valid = 1;
+        int16_t tab[256] = {0};
+        build_assoc_table(k, tab);
+        k.assoc_tab = (const int16_t*)(h->d_poly + 128);
+        HIPCHK(hipMemcpy((void*)k.assoc_tab, tab, sizeof(tab), hipMemcpyHostToDevice));
     }
     if (h->lds > 64 * 1024)
     {

@@ -28,6 +28,11 @@ struct CnKParams {
     double trig[34];         // constants of cn_det_sincos_t / cn_atan2_t (CN_TRIG_TABLE): scalar loads next to the polynomials
     double bb_spawn;         // bounding-box size (UTL:405-419) at the spawn pose, evaluated on the device by cn_create
     int64_t bb_spawn_valid;
+    // The association table (see "ENV:448-485" in the kernel) for bounding-box size bb_spawn, built once by cn_create with the
+    // arithmetic the kernel would use: every env of a simulated run keeps that size from reset to reset, so a wavefront copies
+    // these <= 256 shorts instead of re-deriving them every observation (three float64 divides and ~80 more instructions).
+    int32_t assoc_k1, assoc_fast;     // K1; 1 = the integer test is valid for this size (assoc_tab holds K1 + 2 entries)
+    const int16_t* assoc_tab;         // device memory (a vector load from the kernel-argument block itself is a trip to host-visible memory)
     // tables (device)
     const double* lidar_c;  // [R] cos(k * span/(R-1)), deterministic sincos
     const double* lidar_s;  // [R]

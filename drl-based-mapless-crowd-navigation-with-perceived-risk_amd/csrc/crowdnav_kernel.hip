@@ -459,7 +459,7 @@ __device__ __forceinline__ int near_peds(KP p, const Lds& L, int lane, double ox
 }
 
 // Range of ray k: the sensor's own reading (EXT), or the nearest hit among the room walls and the near pedestrians.
-// lc, ls: ray k in the robot frame = the host table of cn_det_sincos(k * step), loaded by the caller one block ahead.
+// lc, ls: ray k in the robot frame = the host table of cn_det_sincos(k * step), loaded by the caller.
 template <bool EXT>
 __device__ __forceinline__ double cast_ray(KP p, const Lds& L, int env, int k, double ox, double oy, double sy,
                                            double cy, int nnear, bool wall_x, bool wall_y, double lc, double ls)
@@ -784,21 +784,20 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
     double* o64 = obs64 ? obs64 + (size_t)env * D : nullptr;
     // End points, rounded ranges and gradients are 3-decimal values: LDS keeps the integer thousandths
     // (x == cn_div1000(mil) bit for bit), which halves the working set and doubles the waves per CU.
-    // The four table values a ray needs (its direction, and sin/cos of its end-point angle) are loaded ONE BLOCK AHEAD, so
-    // that their L2 latency overlaps the previous block's arithmetic instead of heading every block's dependency chain.
+    // The four table values a ray needs (its direction, and sin/cos of its end-point angle) are loaded at the top of its block
+    // (loading them one block ahead measured the same -- three other waves cover the L2 latency -- and cost four 64-bit
+    // register copies per block).
     const double* const lidc = p->lidar_c; const double* const lids = p->lidar_s;
     const double* const angs = p->ang_s; const double* const angc = p->ang_c;
-    double lc_n = 0.0, ls_n = 0.0, tS_n = 0.0, tC_n = 0.0;
-    if (lane < R) {
-        if (!EXT) { lc_n = lidc[lane]; ls_n = lids[lane]; }
-        if (!GT && lane >= 1) { tS_n = angs[R - 1 - lane]; tC_n = angc[R - 1 - lane]; }
-    }
+    // lane d's entry of cn_create's association table, asked for now so that its L2 round trip is over when the association
+    // stage wants it (one VGPR held across the ray loop)
+    short assoc_pre = 0;
+    if (!GT && p->assoc_fast && lane <= p->assoc_k1 + 1) assoc_pre = p->assoc_tab[lane];
     for (int k = lane; k < R; k += 64) {
-        const double lc = lc_n, ls = ls_n, tS = tS_n, tC = tC_n;
-        if (k + 64 < R) {   // (unsigned 32-bit element offsets from the uniform table bases: one VALU instruction per address)
-            if (!EXT) { lc_n = cn_ldg(lidc, (unsigned)(k + 64)); ls_n = cn_ldg(lids, (unsigned)(k + 64)); }
-            if (!GT) { tS_n = cn_ldg(angs, (unsigned)(R - 1 - (k + 64))); tC_n = cn_ldg(angc, (unsigned)(R - 1 - (k + 64))); }
-        }
+        // (unsigned 32-bit element offsets from the uniform table bases: one VALU instruction per address)
+        double lc = 0.0, ls = 0.0, tS = 0.0, tC = 0.0;
+        if (!EXT) { lc = cn_ldg(lidc, (unsigned)k); ls = cn_ldg(lids, (unsigned)k); }
+        if (!GT && k >= 1) { tS = cn_ldg(angs, (unsigned)(R - 1 - k)); tC = cn_ldg(angc, (unsigned)(R - 1 - k)); }
         const double t = cast_ray<EXT>(p, L, env, k, ox, oy, sy, cy, nnear, wall_x, wall_y, lc, ls);
         if (k >= 1) {
             const unsigned j = (unsigned)(R - 1 - k);  // UTL:389-390 reverse, drop last
@@ -849,7 +848,7 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
     double* const T = L.trk;      // track / entry table: [CN_TF_COUNT][tcap], shares LDS with the end points
     if constexpr (!GT) {
     const int W = (n + 63) >> 6;  // 64-ray words; ray i = bit (i & 63) of word (i >> 6)
-#define WORD(id, q) L.w64[(id) * L.wstride + (q)]
+#define WORD(id, q) L.w64[__mul24((id), L.wstride) + (q)]   /* 24-bit multiply: full rate (v_mul_lo_u32 is quarter rate) */
 #define BIT(id, i) ((WORD(id, (i) >> 6) >> ((i) & 63)) & 1ull)
 #define PX(i) cn_div1000((double)L.ptx[i])
 #define PY(i) cn_div1000((double)L.pty[i])
@@ -1040,7 +1039,14 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
     bool fast_assoc;
     int K1;
     short* const amax = (short*)L.gq;                  // region B is free between the type machine and the confirmation
-    {
+    if (p->assoc_fast && e.bb == p->bb_spawn && !(CN_ABLATE(32))) {
+        // the table for the spawn pose's box size (every env of a simulated run), built by cn_create: a copy
+        // (its first 64 entries were requested before the ray loop, see assoc_pre)
+        K1 = p->assoc_k1; fast_assoc = true;
+        if (lane <= K1 + 1) amax[lane] = assoc_pre;
+        for (int d = lane + 64; d <= K1 + 1; d += 64) amax[d] = p->assoc_tab[d];
+        CN_SYNC();
+    } else {
         const double Tm = 2000.0 * e.bb;
         K1 = (int)floor(Tm - 1e-7);
         const int K2 = (int)ceil(Tm + 1e-7);
