@@ -70,7 +70,8 @@ struct HandleDeleter { void operator()(cn_env_s* h) const { destroy_handle(h); }
 
 // Host restatement of the kernel's association table for bb = bb_spawn (crowdnav_kernel.hip, "ENV:448-485"): the same IEEE
 // operations in the same order (+ - * / floor ceil; this file is compiled with -ffp-contract=off like the kernel), so the
-// table a wavefront copies equals the one it would compute.  tests/test_gpu_parity.py pins that (table on / table off).
+// table a wavefront copies equals the one it would compute.  Pinned by the rollout parity tests: the oracle evaluates the IoU
+// itself; simulated runs take the copied table, cn_observe_external replays (box size from the external scan) the computed one.
 static void build_assoc_table(CnKParams& k, int16_t* tab)
 {
     k.assoc_fast = 0; k.assoc_k1 = 0;
