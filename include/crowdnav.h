@@ -197,6 +197,12 @@ int cn_get_returns(cn_handle h, float* last_return, float* running_return, void*
  *   tracks [CN_MAX_TRACKS][12] one record per slot (CN_TF_*; the first track_capacity slots are used), ints[16] */
 int cn_debug_env(cn_handle h, int env, double* scalars, double* robot_ped, double* tracks, int32_t* ints);
 
+/* Sizing diagnostics (no handle, no GPU): LDS bytes one env of obs_layout 0 needs for n_rays / n_peds / k with max_conf
+ * confirmed-object slots ((n_rays - 1) / 4 + 2 inside cn_create) and track_capacity slots; cn_create refuses > 160 KiB.
+ * cn_near_separate: 1 when the near-pedestrian list gets its own LDS region at no cost in wavefronts per CU. */
+size_t cn_lds_bytes(int n_rays, int n_peds, int k, int max_conf, int track_capacity);
+int cn_near_separate(int n_rays, int n_peds, int k, int max_conf, int track_capacity);
+
 /* Whole-state snapshot for deterministic replay. */
 size_t cn_snapshot_size(cn_handle h);
 int cn_snapshot(cn_handle h, void* host_buf, size_t size);
