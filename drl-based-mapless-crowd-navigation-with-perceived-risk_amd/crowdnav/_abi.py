@@ -27,7 +27,7 @@ TF = dict(PX=0, PY=1, DIST=2, D0X=3, D0Y=4, D1X=5, D1Y=6, T=7, SPEED=8, VX=9, VY
 EXPORTS = ["cn_abi_version", "cn_last_error", "cn_create", "cn_destroy", "cn_obs_dim", "cn_config_of",
            "cn_set_ped_init", "cn_get_ped_init", "cn_set_ped_preset_vel", "cn_reset", "cn_step", "cn_observe_external",
            "cn_policy_tail", "cn_actor_forward", "cn_get_counters",
-           "cn_get_returns", "cn_debug_env", "cn_snapshot_size", "cn_snapshot", "cn_restore"]
+           "cn_get_returns", "cn_debug_env", "cn_lds_bytes", "cn_near_separate", "cn_snapshot_size", "cn_snapshot", "cn_restore"]
 
 
 class CnStepIO(C.Structure):
