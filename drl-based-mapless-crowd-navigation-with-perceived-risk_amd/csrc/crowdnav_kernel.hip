@@ -1476,9 +1476,11 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
                         const double dcp = cn_vmin(d1, d2);
                         if (rv == 0) { cpv = 1.0 * gcp; ego = 0.0; }
                         else {
-                            double ttc = cn_div(dcp, rv);        // rv != 0 here; a difference of two speeds, never denormal
+                            // rv != 0 here: a difference of two finite speeds in a simulated run (never denormal, never infinite).
+                            // External clocks can repeat a time stamp -> an infinite track speed: IEEE division there.
+                            double ttc = EXT ? dcp / rv : cn_div(dcp, rv);
                             if (ttc == 0.0) { ttc0 = true; ego = 1.0; }
-                            else ego = fmin(1.0, cn_div(0.15, ttc));  // UTL:319
+                            else ego = fmin(1.0, EXT ? 0.15 / ttc : cn_div(0.15, ttc));  // UTL:319
                             cpv = 0.5 * ego + 0.5 * gcp;
                         }
                     } else { ego = 0.0; cpv = 0.5 * 0.0 + 0.5 * gcp; }
