@@ -90,7 +90,7 @@ typedef struct cn_config {
     double lidar_span;       /* XACRO:159-160 -> 6.28 rad */
     double lidar_offset_x;   /* URDF:134-138 -> -0.032 */
     double max_scan_range;   /* turtlebot3_world.yaml:7 -> 0.6 */
-    double min_scan_range;   /* turtlebot3_world.yaml:8 -> 0.12 (0.0 for evaluation) */
+    double min_scan_range;   /* turtlebot3_world.yaml:8 -> 0.12 (0.0 for evaluation); must be < max_scan_range (ENV:581 divides by the difference) */
     double goal_x, goal_y;   /* desired_pose (turtlebot3_world.yaml:10-13) */
     double start_x, start_y; /* starting_pose: the heading offset of ENV:223-224 only */
     double spawn_x, spawn_y, spawn_yaw; /* launch-file spawn pose (1.0, -1.0, 3.14) */
