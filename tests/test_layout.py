@@ -56,6 +56,24 @@ def test_no_cpu_fallback():
         VecEnv(Config())
 
 
+def test_cn_create_rejects_configs_the_reference_cannot_run():
+    """Range checks come before any device work, so they are testable without a GPU.  max_scan_range == min_scan_range is a
+    ZeroDivisionError in the reference (ENV:581, UTL:322 divide by the difference)."""
+    import crowdnav
+    from crowdnav.config import Config
+    L = crowdnav.lib()
+    L.cn_last_error.restype = C.c_char_p
+    for bad, msg in ((dict(max_scan_range=0.5, min_scan_range=0.5), b"max_scan_range"),
+                     (dict(max_scan_range=0.1, min_scan_range=0.12), b"max_scan_range"),
+                     (dict(n_rays=4), b"out of range"), (dict(k_obstacles=0), b"out of range"),
+                     (dict(risk_mode=1, obs_layout=1), b"risk_mode gt")):
+        h = C.c_void_p()
+        cfg = Config(**bad).to_c()
+        rc = L.cn_create(C.byref(cfg), 0, C.byref(h))
+        assert rc == -2 and msg in L.cn_last_error(), (bad, rc, L.cn_last_error())
+        assert not h.value
+
+
 def test_product_never_references_the_oracle_or_the_reference_tree():
     bad = []
     for base, _, files in os.walk(PKG):
