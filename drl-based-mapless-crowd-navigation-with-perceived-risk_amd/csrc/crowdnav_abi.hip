@@ -463,7 +463,7 @@ extern "C" int cn_actor_forward(const cn_actor_weights* w, const float* obs, flo
         return fail(CN_ERR_CONFIG, "cn_actor_forward: hidden must be 256 and obs_dim_padded a multiple of 4");
     if (n == 0) return CN_OK;
     const int Dp = w->obs_dim_padded;
-    const size_t lds = sizeof(float) * (16 * (size_t)(Dp + 1) + 2 * 16 * 257);
+    const size_t lds = sizeof(float) * (16 * (size_t)(Dp + 1) + 5 * 16 * 257);     // X, four K-quarter partials, H
     if (lds > 160 * 1024) return fail(CN_ERR_CONFIG, "cn_actor_forward: observation too wide for one LDS tile");
     int dev = device;
     if (dev < 0) HIPCHK(hipGetDevice(&dev));
@@ -477,7 +477,7 @@ extern "C" int cn_actor_forward(const cn_actor_weights* w, const float* obs, flo
             if (dev < 64) attr_set[dev] = true;
         }
     }
-    hipLaunchKernelGGL(cn_actor_kernel, dim3((n + 15) / 16), dim3(256), lds, (hipStream_t)stream, obs, n, w->obs_dim, Dp,
+    hipLaunchKernelGGL(cn_actor_kernel, dim3((n + 15) / 16), dim3(1024), lds, (hipStream_t)stream, obs, n, w->obs_dim, Dp,
                        w->w1t, w->b1, w->w2t, w->b2, w->w3, w->b3, action, max_v, max_w, sigma, seed, counter);
     HIPCHK(hipGetLastError());
     return CN_OK;

@@ -2406,26 +2406,31 @@ extern "C" __global__ void cn_policy_tail_kernel(const float* __restrict__ logit
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define ACT_H 256
 #define ACT_M 16
+#define ACT_THREADS 1024
 
-template <bool RELU>
-__device__ __forceinline__ void actor_layer(const float* __restrict__ A, int lda, int Kp, const float* __restrict__ WT,
-                                            const float* __restrict__ bias, float* __restrict__ out, int ldo, int wave, int lane)
+// One wave's share of a layer: the K range [k_begin, k_end) (multiples of 4) of the four interleaved column tiles
+// col = 64 * cw + 4 * j + t, accumulated into `part` [16][ldo] WITHOUT bias (the quarters are summed in a fixed order after).
+// A workgroup is 16 waves = 4 column groups x 4 K quarters: a tile of 16 envs is one workgroup on one CU whatever the batch,
+// so the kernel's duration is this chain's latency, and four waves per SIMD (instead of one) both quarter the chain and
+// cover each other's L2 / LDS waits (27 us -> see DESIGN.md for a 4096-env batch; the MFMA floor of a 16-env tile is 9 us).
+__device__ __forceinline__ void actor_partial(const float* __restrict__ A, int lda, int k_begin, int k_end,
+                                              const float* __restrict__ WT, float* __restrict__ part, int ldo, int cw, int lane)
 {
     const int ai = lane & 15, ak = lane >> 4;
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
     const float* ap = A + ai * lda + ak;
-    const float* bp = WT + (size_t)ak * ACT_H + 64 * wave + 4 * ai;
-    // Software pipeline: the 16-byte weight loads of the NEXT block of 8 k-steps are in flight while the 32 MFMAs
-    // of the current block issue (one wave per SIMD here, so nothing else hides the L2 latency).
-    constexpr int U = 8;
+    const float* bp = WT + (size_t)ak * ACT_H + 64 * cw + 4 * ai;
+    // Software pipeline: the 16-byte weight loads of the NEXT block of U k-steps are in flight while the 4 U MFMAs of the
+    // current block issue.
+    constexpr int U = 4;
     float4 bcur[U], bnxt[U];
-    const int nblk = Kp / (4 * U), tail0 = nblk * 4 * U;
+    const int nblk = (k_end - k_begin) / (4 * U), tail0 = k_begin + nblk * 4 * U;
     if (nblk > 0) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) bcur[u] = *reinterpret_cast<const float4*>(bp + (size_t)(4 * u) * ACT_H);
+        for (int u = 0; u < U; ++u) bcur[u] = *reinterpret_cast<const float4*>(bp + (size_t)(k_begin + 4 * u) * ACT_H);
     }
     for (int blk = 0; blk < nblk; ++blk) {
-        const int k0 = blk * 4 * U;
+        const int k0 = k_begin + blk * 4 * U;
         if (blk + 1 < nblk) {
 #pragma unroll
             for (int u = 0; u < U; ++u) bnxt[u] = *reinterpret_cast<const float4*>(bp + (size_t)(k0 + 4 * U + 4 * u) * ACT_H);
@@ -2441,7 +2446,7 @@ __device__ __forceinline__ void actor_layer(const float* __restrict__ A, int lda
 #pragma unroll
         for (int u = 0; u < U; ++u) bcur[u] = bnxt[u];
     }
-    for (int k0 = tail0; k0 < Kp; k0 += 4) {   // remainder (Kp is a multiple of 4, not necessarily of 32)
+    for (int k0 = tail0; k0 < k_end; k0 += 4) {
         const float a = ap[k0];
         const float4 b = *reinterpret_cast<const float4*>(bp + (size_t)k0 * ACT_H);
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.x, acc0, 0, 0, 0);
@@ -2449,39 +2454,61 @@ __device__ __forceinline__ void actor_layer(const float* __restrict__ A, int lda
         acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.z, acc2, 0, 0, 0);
         acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.w, acc3, 0, 0, 0);
     }
-    const int colb = 64 * wave + 4 * ai, rowb = ak * 4;   // C/D: col = lane & 15, row = (lane >> 4) * 4 + reg
-    const float4 bb = *reinterpret_cast<const float4*>(bias + colb);
+    const int colb = 64 * cw + 4 * ai, rowb = ak * 4;   // C/D: col = lane & 15, row = (lane >> 4) * 4 + reg
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        float v0 = acc0[r] + bb.x, v1 = acc1[r] + bb.y, v2 = acc2[r] + bb.z, v3 = acc3[r] + bb.w;
-        if (RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
-        float* o = out + (rowb + r) * ldo + colb;
-        o[0] = v0; o[1] = v1; o[2] = v2; o[3] = v3;
+        float* o = part + (rowb + r) * ldo + colb;
+        o[0] = acc0[r]; o[1] = acc1[r]; o[2] = acc2[r]; o[3] = acc3[r];
     }
 }
 
-extern "C" __global__ void __launch_bounds__(256) cn_actor_kernel(const float* __restrict__ obs, int n, int D, int Dp,
+// H[r][c] = relu(((P0 + P1) + (P2 + P3))[r][c] + bias[c]): the K quarters in a fixed order, 4 elements per thread
+__device__ __forceinline__ void actor_reduce(const float* __restrict__ P, int pstride, const float* __restrict__ bias,
+                                             float* __restrict__ H, int ldh, int tid)
+{
+#pragma unroll
+    for (int i = 0; i < (ACT_M * ACT_H) / ACT_THREADS; ++i) {
+        const int idx = tid + i * ACT_THREADS, r = idx >> 8, c = idx & (ACT_H - 1);
+        const int o = r * ldh + c;
+        const float v = ((P[o] + P[pstride + o]) + (P[2 * pstride + o] + P[3 * pstride + o])) + bias[c];
+        H[o] = fmaxf(v, 0.f);
+    }
+}
+
+extern "C" __global__ void __launch_bounds__(ACT_THREADS) cn_actor_kernel(const float* __restrict__ obs, int n, int D, int Dp,
         const float* __restrict__ W1T, const float* __restrict__ b1, const float* __restrict__ W2T,
         const float* __restrict__ b2, const float* __restrict__ W3, const float* __restrict__ b3,
         float* __restrict__ action, float max_v, float max_w, float sigma, uint64_t seed, uint64_t counter)
 {
     extern __shared__ __attribute__((aligned(16))) float act_sm[];
-    const int ldx = Dp + 1, ldh = ACT_H + 1;
+    const int ldx = Dp + 1, ldh = ACT_H + 1, pstride = ACT_M * ldh;
     float* X = act_sm;                 // [16][Dp + 1]
-    float* H1 = X + ACT_M * ldx;       // [16][257]
-    float* H2 = H1 + ACT_M * ldh;      // [16][257]
+    float* P = X + ACT_M * ldx;        // [4][16][257] partial sums of the K quarters
+    float* H = P + 4 * pstride;        // [16][257] hidden activations (layer 1, then layer 2)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int cw = wave & 3, kq = wave >> 2;
     const int row0 = blockIdx.x * ACT_M;
-    for (int r = wave; r < ACT_M; r += 4) {   // one row per wave at a time: coalesced, no integer divide
+    {   // one row per wave: coalesced, no integer divide
+        const int r = wave;
         const bool live = (row0 + r < n);
         const float* src = obs + (size_t)(row0 + r) * D;
         for (int c = lane; c < Dp; c += 64) X[r * ldx + c] = (live && c < D) ? src[c] : 0.f;
     }
     __syncthreads();
-    actor_layer<true>(X, ldx, Dp, W1T, b1, H1, ldh, wave, lane);
+    {
+        const int steps = Dp >> 2, per = (steps + 3) >> 2;                 // k-steps of 4 per quarter
+        const int s0 = min(kq * per, steps), s1 = min(s0 + per, steps);
+        actor_partial(X, ldx, 4 * s0, 4 * s1, W1T, P + kq * pstride, ldh, cw, lane);
+    }
     __syncthreads();
-    actor_layer<true>(H1, ldh, ACT_H, W2T, b2, H2, ldh, wave, lane);
+    actor_reduce(P, pstride, b1, H, ldh, tid);
     __syncthreads();
+    actor_partial(H, ldh, kq * (ACT_H / 4), (kq + 1) * (ACT_H / 4), W2T, P + kq * pstride, ldh, cw, lane);
+    __syncthreads();
+    actor_reduce(P, pstride, b2, H, ldh, tid);
+    __syncthreads();
+    float* H2 = H;
+    if (tid < 256)
     {   // linear3 (TD3:101) + heads, exploration noise, clip: thread = (env i, output o, eighth of K), 32-term partial dots
         const int i = tid >> 4, o = (tid >> 3) & 1, part = tid & 7;
         const float* h = H2 + i * ldh + part * 32;
