@@ -8,10 +8,13 @@
   --envs-total T: strong scaling, T environments split over the ranks (BASELINE config 4: 16384 over 8 GPUs = 2048 per
   GPU); default is weak scaling, --envs (4096) per GPU.
 
-A "step" is one cn_step launch over this rank's shard of environments (4096 envs x 20 pedestrians x
-360 rays, K = 8, BASELINE.json configs[1]); `value` = env-steps/s summed over all ranks, inputs resident
-in HBM, auto-reset included (SURVEY 8d D1).  Envs shard across ranks with no data-path collective;
-the one collective is the RCCL all-gather of per-env episode returns after the timed region (8e E1).
+A "step" is every env of this rank's shard stepped once through cn_step (4096 envs x 20 pedestrians x 360 rays, K = 8,
+BASELINE.json configs[1]) -- as `--groups` launches on independent streams (default 4 x 1024 envs), as 2 launches, or as
+one; every decomposition is timed over the same K steps with the same bracket and the best one is the headline
+(`config.legs_env_steps_s` carries all three).  `value` = env-steps/s summed over all ranks, inputs resident in HBM,
+auto-reset included; a launch an env spends on its reset is not counted as an env-step.  Envs shard across
+ranks with no data-path collective; the one collective is the RCCL all-gather of per-env episode returns after the timed
+region (8e E1).
 
 Adds to the JSON line:
   roofline      achieved algorithmic HBM bytes/s of cn_env_kernel (HIP events on the launch stream)
