@@ -166,7 +166,8 @@ __device__ __forceinline__ double cn_sqrt(double x)
 // compiler's float64 division -- v_rcp_f64 seed, two Newton steps on the reciprocal, one residual correction of the quotient;
 // correctly rounded -- without v_div_scale x 2 / v_div_fmas' post-scale / v_div_fixup, which only act on extreme exponents,
 // zeros, infinities and NaNs.  Same operations in the same order: the same bits wherever those were the identity (8
-// instructions instead of 12).  b == 0 gives NaN here (not +-inf): callers guard it or discard the lane's result.
+// instructions instead of 12).  b == 0 gives NaN here (not +-inf): callers guard it or discard the lane's result; a numerator
+// of -0 over a positive b gives +0 where IEEE gives -0 (equal as numbers; tests/test_gpu_parity.py::test_device_math_*).
 __device__ __forceinline__ double cn_div(double a, double b)
 {
     double y = __builtin_amdgcn_rcp(b);

@@ -2537,6 +2537,38 @@ extern "C" __global__ void __launch_bounds__(ACT_THREADS) cn_actor_kernel(const 
 }
 
 #ifdef CN_TIMING
+// ---- device arithmetic under test (PROFILING BUILD ONLY; tests/test_gpu_parity.py::test_device_math_*): the hand-written
+// replacements for libm / compiler expansions, one element per thread.  op: 0 cn_sqrt(x)  1 cn_div(x, y)  2 cn_hypot(x, y)
+// 3 cn_atan2_t(x, y) = atan2 with x the ordinate (first argument) and y the abscissa  4, 5 sin, cos of cn_det_sincos_t(x)
+__global__ void cn_math_kernel(int op, const double* __restrict__ x, const double* __restrict__ y, double* __restrict__ out, int n,
+                               const double* __restrict__ trig)
+{
+    cn_ktab tab = (cn_ktab)trig;           // the env kernels read this table from their kernel-argument block
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double r = 0.0, s_, c_;
+    switch (op) {
+    case 0: r = cn_sqrt(x[i]); break;
+    case 1: r = cn_div(x[i], y[i]); break;
+    case 2: r = cn_hypot(x[i], y[i]); break;
+    case 3: r = cn_atan2_t(tab, x[i], y[i]); break;
+    case 4: cn_det_sincos_t(tab, x[i], &s_, &c_); r = s_; break;
+    default: cn_det_sincos_t(tab, x[i], &s_, &c_); r = c_; break;
+    }
+    out[i] = r;
+}
+extern "C" int cn_debug_math(int op, const double* x, const double* y, double* out, int n, void* stream)
+{
+    static const double trig[CN_TRIG_COUNT] = CN_TRIG_TABLE;
+    double* d = nullptr;
+    if (hipMalloc(&d, sizeof(trig)) != hipSuccess) return -1;
+    if (hipMemcpy(d, trig, sizeof(trig), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return -1; }
+    hipLaunchKernelGGL(cn_math_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, op, x, y, out, n, (const double*)d);
+    const hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    (void)hipFree(d);
+    return e == hipSuccess ? 0 : -1;
+}
+
 // ---- PMC calibration (PROFILING BUILD ONLY, libcrowdnav_timing.so; tools/calib_pmc.py): known-byte streaming reads / writes at the access widths the
 // env kernel uses, so FETCH_SIZE / WRITE_SIZE can be turned into bytes (MI355X_MICROARCH.md, HBM section).
 template <typename T>

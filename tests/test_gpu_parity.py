@@ -787,3 +787,60 @@ def test_realworld_layout_golden_replay_and_run(name):
             assert float(env2.reward[0].item()) == z["reward"][i] and bool(env2.done[0].item()) == bool(z["done"][i]), (name, i)
         torch.cuda.synchronize()
         assert np.abs(env2.obs_f64[0].cpu().numpy() - z["obs"][i]).max() <= TOL, (name, i)
+
+
+# ---- the hand-written device arithmetic (crowdnav_device.h) against libm, op by op --------------------------------------
+# The profiling build exports cn_debug_math (one element per thread); the product library does not.
+def _device_math(op, x, y=None):
+    import ctypes as C
+    import torch
+    import crowdnav
+    L = C.CDLL(crowdnav._abi.build_timing())
+    L.cn_debug_math.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    xd = torch.tensor(np.ascontiguousarray(x, dtype=np.float64), device="cuda")
+    yd = torch.tensor(np.ascontiguousarray(x if y is None else y, dtype=np.float64), device="cuda")
+    out = torch.empty_like(xd)
+    torch.cuda.synchronize()
+    assert L.cn_debug_math(op, xd.data_ptr(), yd.data_ptr(), out.data_ptr(), xd.numel(), None) == 0
+    return out.cpu().numpy()
+
+
+def test_device_math_sqrt_and_divide_are_correctly_rounded():
+    """cn_sqrt / cn_div are the compiler's correctly rounded expansions minus their range handling: bit-equal to IEEE sqrt and
+    division over the ranges the kernel feeds them (squares of lengths, quotients of lengths / speeds / times)."""
+    rng = np.random.default_rng(5)
+    x = np.concatenate([np.exp(rng.uniform(np.log(1e-14), np.log(1e4), 400000)), rng.integers(0, 4000, 50000) ** 2 / 1e6,
+                        [0.0, 1.0, 0.36, 2.0 ** -200, 2.0 ** 200, np.inf]])
+    assert np.array_equal(_device_math(0, x), np.sqrt(x))
+    a = np.concatenate([rng.uniform(-5, 5, 300000), rng.integers(-4000, 4000, 100000) / 1000.0, [0.0, 0.15, 1e-12]])
+    a[a == 0.0] = 0.0      # a numerator of -0 over a positive divisor gives +0 here, -0 in IEEE (equal as numbers): not fed by the kernel's uses that care
+    b = np.exp(rng.uniform(np.log(1e-17), np.log(1e17), a.size)) * rng.choice([-1.0, 1.0], a.size)
+    b[:1000] = rng.integers(1, 4000, 1000) / 1000.0
+    got = _device_math(1, a, b)
+    assert np.array_equal(got, a / b) and np.array_equal(np.signbit(got), np.signbit(a / b))
+
+
+def test_device_math_hypot_atan2_sincos(oracle_mod):
+    """cn_hypot within 1 ulp of hypot (and exact on an axis), cn_atan2_t within 4.5e-16 of atan2 with C99 signed zeros,
+    cn_det_sincos_t bit-equal to the oracle's deterministic sincos (the simulator's contract)."""
+    import ctypes as C
+    rng = np.random.default_rng(6)
+    x = np.concatenate([rng.uniform(-4, 4, 200000), rng.integers(-4000, 4000, 100000) / 1000.0, [0.0, 3.0, 0.0, -2.5]])
+    y = np.concatenate([rng.uniform(-4, 4, 200000), rng.integers(-4000, 4000, 100000) / 1000.0, [0.0, 0.0, -1.25, 0.0]])
+    h, ref = _device_math(2, x, y), np.hypot(x, y)
+    assert np.all(np.abs(h - ref) <= np.spacing(ref)) and np.array_equal(h[-3:], [3.0, 1.25, 2.5]) and h[-4] == 0.0
+    a, ref = _device_math(3, y, x), np.arctan2(y, x)          # op 3: (ordinate, abscissa)
+    assert np.abs(a - ref).max() <= 4.5e-16
+    zy = np.array([0.0, 0.0, -0.0, -0.0, 1.0, -1.0, 0.0, -0.0]); zx = np.array([0.0, -0.0, -0.0, 0.0, 0.0, 0.0, -1.0, -1.0])
+    za, zr = _device_math(3, zy, zx), np.arctan2(zy, zx)
+    assert np.array_equal(za, zr) and np.array_equal(np.signbit(za), np.signbit(zr))
+    t = np.concatenate([rng.uniform(-7, 7, 200000), rng.uniform(-1000, 1000, 50000), [0.0, np.pi / 2, -np.pi, 3 * np.pi / 4]])
+    L = oracle_mod.lib()
+    L.cno_det_sincos.argtypes = [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.cno_det_sincos.restype = None
+    rs, rc = np.empty_like(t), np.empty_like(t)
+    s_, c_ = C.c_double(), C.c_double()
+    for i, v in enumerate(t):
+        L.cno_det_sincos(float(v), C.byref(s_), C.byref(c_)); rs[i], rc[i] = s_.value, c_.value
+    assert np.array_equal(_device_math(4, t), rs) and np.array_equal(_device_math(5, t), rc)
+    assert np.abs(rs - np.sin(t)).max() < 2e-16 * 8 and np.abs(rc - np.cos(t)).max() < 2e-16 * 8
