@@ -349,6 +349,8 @@ def main():
     achieved_1 = B * N / (kernel_ms_1 * 1e-3) / 1e9
     counters = profiled_counters() if (a.peds, a.rays) == (20, 360) else None
     traffic = profiled_traffic() if (a.envs, a.peds, a.rays) == (4096, 20, 360) else None
+    valu_n = ((counters or {}).get("wave_instr_per_env_step") or {}).get("valu")
+    valu_peak = (1024 * 2.4e9 / (4.0 * valu_n)) if valu_n else None
     out = {
         "metric": baseline_metric(),
         "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -382,6 +384,10 @@ def main():
                      "binding": "instruction issue (f64 VALU) above ~8k resident envs; one wavefront's critical path at 4096",
                      "issue_bound_env_steps_s": plateau,
                      "frac_of_issue_bound": (value / world / plateau) if plateau else None,
+                     # the hardware ceiling of the binding unit: every wave64 VALU instruction occupies its SIMD's vector pipe
+                     # for 4 cycles; 1024 SIMDs x 2.4 GHz (MI355X_MICROARCH.md) / (4 x measured VALU instructions per env-step)
+                     "valu_peak_env_steps_s": valu_peak,
+                     "frac_of_valu_peak": (value / world / valu_peak) if valu_peak else None,
                      "valu_busy": (counters or {}).get("valu_busy"),
                      "wave_instr_per_env_step": (counters or {}).get("wave_instr_per_env_step"),
                      "counters_source": (counters or {}).get("source"),
