@@ -72,6 +72,17 @@ __device__ __forceinline__ double cn_np_around3(double x)
     double r = rint(x * 1000.0);
     return (fabs(r) < 2147483648.0) ? cn_div1000(r) : r / 1000.0;
 }
+// The same roundings for values a simulated run bounds far below 2^31 thousandths (coordinates, ranges, velocities of a room
+// of a few metres): without the range test and the generic-divide branch behind it (compare + exec save/restore + two
+// branches per use).  External data (odometry, scans) keeps the guarded forms.
+template <bool SMALL> __device__ __forceinline__ double cn_py_round3_t(double x)
+{
+    if constexpr (SMALL) return cn_div1000(cn_round_scaled(x, 1000.0)); else return cn_py_round3(x);
+}
+template <bool SMALL> __device__ __forceinline__ double cn_np_around3_t(double x)
+{
+    if constexpr (SMALL) return cn_div1000(rint(x * 1000.0)); else return cn_np_around3(x);
+}
 __device__ __forceinline__ double cn_np_around2(double x)
 {
     double r = rint(x * 100.0);

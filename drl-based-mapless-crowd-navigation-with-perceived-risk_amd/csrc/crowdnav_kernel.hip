@@ -640,8 +640,11 @@ __device__ __forceinline__ void tracker_stage(KP p, EnvRegs& e, const Lds& L, do
     // ---- ENV:656-743 tracker -----------------------------------------------------------------------
     // The tracker table shares LDS with the end-point arrays (dead from here on): bring it in now.
     if (lane < e.ntracks) {
+        // HBM: one 96-byte record per track, moved as six 16-byte pieces (records are 16-byte aligned: 96 = 6 x 16)
+        static_assert(CN_TF_COUNT % 2 == 0, "track record in 16-byte pieces");
+        const double2* rec2 = (const double2*)(L.gtrk + lane * CN_TF_COUNT);
 #pragma unroll
-        for (int f = 0; f < CN_TF_COUNT; ++f) T[f * L.tcap + lane] = L.gtrk[lane * CN_TF_COUNT + f];  // HBM: one 96-byte record per track
+        for (int f = 0; f < CN_TF_COUNT; f += 2) { const double2 v = rec2[f >> 1]; T[f * L.tcap + lane] = v.x; T[(f + 1) * L.tcap + lane] = v.y; }
     }
     CN_SYNC();
     bool add_unchecked = false;
@@ -821,7 +824,7 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
             L.pty[j] = (int)cn_round_scaled(py + (sc * sa) * -1.0, 1000.0);
             L.dmil[j] = (unsigned short)(int)cn_round_scaled(sc, 1000.0);
             }
-            double so = cn_np_around3(sc);  // ENV:1042
+            double so = cn_np_around3_t<!EXT>(sc);  // ENV:1042
             cn_stg(o32, j, (float)so);
             if (f32) cn_stg(f32, j, (float)so);
             if (o64) cn_stg(o64, j, so);
@@ -838,7 +841,7 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
         // longer than a stepping one, and a launch lasts as long as its slowest wavefront).
         if (!EXT && p->bb_spawn_valid && px == p->spawn_x && py == p->spawn_y && yaw == p->spawn_yaw) e.bb = p->bb_spawn;
         else e.bb = bbox_size(p, L.stage, lane, n, px, py, yaw);
-        double qx = cn_py_round3(px), qy = cn_py_round3(py);
+        double qx = cn_py_round3_t<!EXT>(px), qy = cn_py_round3_t<!EXT>(py);
         if (e.dq_len < 2) { if (e.dq_len == 0) { e.dq0x = qx; e.dq0y = qy; } else { e.dq1x = qx; e.dq1y = qy; } e.dq_len += 1; }
         else { e.dq0x = e.dq1x; e.dq0y = e.dq1y; e.dq1x = qx; e.dq1y = qy; }
     }
@@ -1537,12 +1540,12 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
     // ENV:1025-1042 observation tail
     if (lane < 7) {   // one rounding pass, lane = tail slot (heading and distance are already rounded)
         const double v = lane == 2 ? px : lane == 3 ? py : lane == 4 ? yaw : lane == 5 ? agent_vel_x : agent_vel_y;
-        const double r = cn_py_round3(v);
+        const double r = cn_py_round3_t<!EXT>(v);
         L.tail[lane] = lane == 0 ? heading : lane == 1 ? distance_to_goal : r;
     }
     CN_SYNC();
     for (int i = lane; i < 7 + 4 * K; i += 64) {
-        double so = cn_np_around3(L.tail[i]);
+        double so = cn_np_around3_t<!EXT>(L.tail[i]);
         L.tail[i] = so;
         o32[n + i] = (float)so;
         if (f32) f32[n + i] = (float)so;
@@ -1552,7 +1555,8 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
     // tracker table back to HBM (its LDS space is reused by the next observation's end points)
     if (lane < e.ntracks) {
 #pragma unroll
-        for (int f = 0; f < CN_TF_COUNT; ++f) L.gtrk[lane * CN_TF_COUNT + f] = L.trk[f * L.tcap + lane];
+        for (int f = 0; f < CN_TF_COUNT; f += 2)
+            ((double2*)(L.gtrk + lane * CN_TF_COUNT))[f >> 1] = make_double2(L.trk[f * L.tcap + lane], L.trk[(f + 1) * L.tcap + lane]);
     }
     CN_SYNC();
     *done_out = e.done;
@@ -1868,7 +1872,8 @@ __device__ __forceinline__ void observe_realworld(KP p, const Poly& pg, EnvRegs&
     }
     if (lane < e.ntracks) {
 #pragma unroll
-        for (int f = 0; f < CN_TF_COUNT; ++f) L.gtrk[lane * CN_TF_COUNT + f] = L.trk[f * L.tcap + lane];
+        for (int f = 0; f < CN_TF_COUNT; f += 2)
+            ((double2*)(L.gtrk + lane * CN_TF_COUNT))[f >> 1] = make_double2(L.trk[f * L.tcap + lane], L.trk[(f + 1) * L.tcap + lane]);
     }
     CN_SYNC();
     *done_out = e.done;
@@ -2088,7 +2093,7 @@ __device__ __forceinline__ void env_kernel_body()
                 deq_x = od[6]; deq_y = od[7]; end_timestep = od[8];
             }
             if (ph_pre) {
-            double qx = cn_py_round3(deq_x), qy = cn_py_round3(deq_y);  // ENV:1208
+            double qx = cn_py_round3_t<!EXT>(deq_x), qy = cn_py_round3_t<!EXT>(deq_y);  // ENV:1208
             if (e.dq_len == 0) { e.dq0x = qx; e.dq0y = qy; e.dq_len = 1; }
             else if (e.dq_len == 1) { e.dq1x = qx; e.dq1y = qy; e.dq_len = 2; }
             else { e.dq0x = e.dq1x; e.dq0y = e.dq1y; e.dq1x = qx; e.dq1y = qy; }
