@@ -88,6 +88,14 @@ __device__ __forceinline__ double cn_np_around2(double x)
     double r = rint(x * 100.0);
     return (fabs(r) < 2147483648.0) ? cn_div100(r) : r / 100.0;
 }
+template <bool SMALL> __device__ __forceinline__ double cn_py_round2_t(double x)
+{
+    if constexpr (SMALL) return cn_div100(cn_round_scaled(x, 100.0)); else return cn_py_round2(x);
+}
+template <bool SMALL> __device__ __forceinline__ double cn_np_around2_t(double x)
+{
+    if constexpr (SMALL) return cn_div100(rint(x * 100.0)); else return cn_np_around2(x);
+}
 
 // ---- deterministic sin/cos ----------------------------------------------------------------
 // Cody-Waite reduction by pi/2 + degree-13/14 minimax kernels; only + * fma rint, so host and

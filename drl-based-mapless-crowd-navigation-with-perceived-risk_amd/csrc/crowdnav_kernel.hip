@@ -759,8 +759,8 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
     // ENV:246-265
     CN_T(22);
     if (step_counter == 1) waypoint_refresh(p, pg, e, lane, px, py);
-    double distance_to_goal = cn_np_around2(dist3(px, py, e.wpx, e.wpy));
-    double heading = cn_py_round2(heading_to_goal(p, e, px, py, yaw));
+    double distance_to_goal = cn_np_around2_t<!EXT>(dist3(px, py, e.wpx, e.wpy));
+    double heading = cn_py_round2_t<!EXT>(heading_to_goal(p, e, px, py, yaw));
     CN_T(23);
     if (step_counter % 5 == 0 || distance_to_goal < e.prev_dist) waypoint_refresh(p, pg, e, lane, px, py);
     CN_T(24);
