@@ -225,6 +225,7 @@ def main():
         return wall_, k_ms, taken
 
     conc = 1
+    enq_ms = {}
     def timed_groups(G, mode="next", gcfg=None, gacts=None, steps=None):
         """The same N envs as G independent groups (crowdnav.env.VecEnvGroups): one step = every group stepped
         once, each on its own HIP stream, no join between groups inside the timed region.  Returns (wall s,
@@ -265,6 +266,7 @@ def main():
         for i in range(steps_):
             for c in calls[i % n_act]:
                 c()
+        enq_ms.setdefault(G, (time.perf_counter() - t0) * 1e3 / steps_)   # host time to enqueue one step of all groups (first leg with G)
         for g in range(G):
             ev1[g].record(grp.streams[g])
         barrier(grp.streams)
@@ -366,6 +368,8 @@ def main():
                                    N, a.peds, a.rays, a.k, a.preroll, G, n_launch),
                    "envs_per_gpu": N, "envs_total": N * world, "stream_groups": G, "stream_groups_requested": groups_requested,
                    "legs_env_steps_s": legs,
+                   # host time the enqueue loop needs per step of a group leg (a leg is host-paced when this approaches ms_per_step)
+                   "host_enqueue_ms_per_step": {"%d_groups" % k: v for k, v in sorted(enq_ms.items()) if k in (groups_requested, 2)},
                    "concurrent_hw_queues_found": conc, "parallelism": "env-sharded x%d" % world,
                    "one_launch_per_step_value": taken_1_all / wall_1, "one_launch_per_step_ms": wall_1 / a.steps * 1e3,
                    "same_call_reset_value": taken_same_all / wall_same, "same_call_reset_ms_per_step": wall_same / a.steps * 1e3,
