@@ -238,10 +238,10 @@ def main():
         conc = grp.concurrent
         grp.reset()
         rows = [grp.rows(g) for g in range(G)]
-        # pre-marshalled launches (VecEnv.bind_step): one ctypes call per launch, ~1.5 us of host time instead of ~7 us, so a
-        # short timed sample (the driver uses 20 steps = 80 launches of ~40 us) is not paced by the Python enqueue loop
-        act_slices = [[acts_[i][rows[g]] for g in range(G)] for i in range(n_act)]     # contiguous [n, 2] views
-        calls = [[grp.envs[g].bind_step(act_slices[i][g], auto_reset=mode) for g in range(G)] for i in range(n_act)]
+        # pre-marshalled launches: ~1.5 us of host time per foreign call instead of ~7 us for VecEnv.step, so a short timed
+        # sample (the driver uses 20 steps = 80 launches of ~40 us) is not paced by the Python enqueue loop
+        # one cn_step_multi per step: all groups' launches behind one foreign call
+        calls = [[grp.bind_step_all(acts_[i], auto_reset=mode)] for i in range(n_act)]
         def episodes_dev():                            # finished episodes per group as device scalars, no host sync
             out = []
             for e_ in grp.envs:

@@ -25,7 +25,7 @@ SI = dict(DONE=0, DQ_LEN=1, NTRACKS=2, EGO_VIOL=3, SOCIAL_VIOL=4, OBST_STEPS=5, 
 TF = dict(PX=0, PY=1, DIST=2, D0X=3, D0Y=4, D1X=5, D1Y=6, T=7, SPEED=8, VX=9, VY=10, DQLEN=11)
 
 EXPORTS = ["cn_abi_version", "cn_last_error", "cn_create", "cn_destroy", "cn_obs_dim", "cn_config_of",
-           "cn_set_ped_init", "cn_get_ped_init", "cn_set_ped_preset_vel", "cn_reset", "cn_step", "cn_observe_external",
+           "cn_set_ped_init", "cn_get_ped_init", "cn_set_ped_preset_vel", "cn_reset", "cn_step", "cn_step_multi", "cn_observe_external",
            "cn_policy_tail", "cn_actor_forward", "cn_get_counters",
            "cn_get_returns", "cn_debug_env", "cn_lds_bytes", "cn_near_separate", "cn_snapshot_size", "cn_snapshot", "cn_restore"]
 
@@ -120,6 +120,7 @@ def lib():
         L.cn_set_ped_preset_vel.argtypes = [vp, vp]
         L.cn_reset.argtypes = [vp, vp, vp, vp, vp]
         L.cn_step.argtypes = [vp, C.POINTER(CnStepIO), vp]
+        L.cn_step_multi.argtypes = [C.c_int, C.POINTER(vp), C.POINTER(CnStepIO), C.POINTER(vp)]
         L.cn_observe_external.argtypes = [vp, C.POINTER(CnExternalIO), vp]
         L.cn_policy_tail.argtypes = [vp, vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_uint64, C.c_uint64, C.c_int, vp]
         L.cn_actor_forward.argtypes = [C.POINTER(CnActorWeights), vp, vp, C.c_int, C.c_float, C.c_float, C.c_float,

@@ -343,6 +343,36 @@ class VecEnvGroups:
         self.join()
         return self.obs
 
+    def bind_step_all(self, action, auto_reset="next", want_final=False):
+        """One pre-marshalled cn_step_multi for all groups: `action` is the [N, 2] device buffer the policy writes in place
+        (each group reads its slice).  Returns a zero-argument callable that enqueues one step of every group with ONE
+        foreign call; outputs land in each group's obs / reward / done.  No fork / join: callers that need the groups ordered
+        against another stream use fork() / join() around their loop."""
+        G = self.G
+        ios = (_abi.CnStepIO * G)()
+        hs = (C.c_void_p * G)()
+        sts = (C.c_void_p * G)()
+        keep = [action]
+        ar = {False: 0, True: 1, None: 0, "same": 1, "next": 2}.get(auto_reset, auto_reset)
+        for g, e in enumerate(self.envs):
+            a = action[self.rows(g)]
+            assert a.device == e.device and a.dtype == torch.float32 and a.is_contiguous()
+            keep.append(a)
+            ios[g] = _abi.CnStepIO(action=a.data_ptr(), step_counter=None, obs=e.obs.data_ptr(),
+                                   final_obs=e.final_obs.data_ptr() if want_final else None,
+                                   obs_f64=e.obs_f64.data_ptr() if e.obs_f64 is not None else None,
+                                   reward=e.reward.data_ptr(), done=e.done.data_ptr(), topk_idx=e.topk_idx.data_ptr(),
+                                   auto_reset=ar, reserved=0)
+            hs[g] = e.h if not hasattr(e.h, "value") else e.h.value
+            sts[g] = e._stream().value
+        fn, check = self.envs[0].L.cn_step_multi, _abi.check
+
+        def call(_keep=(keep, ios, hs, sts)):
+            rc = fn(G, hs, ios, sts)
+            if rc:
+                check(rc)
+        return call
+
     def step_group(self, g, action, **kw):
         """Env.step for group g on its own stream; `action` is that group's [n, 2] slice."""
         return self.envs[g].step(action, **kw)

@@ -417,6 +417,16 @@ extern "C" int cn_step(cn_handle h, const cn_step_io* io, void* stream)
     return launch(h, kp, (hipStream_t)stream);
 }
 
+extern "C" int cn_step_multi(int n, const cn_handle* handles, const cn_step_io* ios, void* const* streams)
+{
+    if (n < 0 || (n > 0 && (!handles || !ios || !streams))) return fail(CN_ERR_ARG, "cn_step_multi: null argument");
+    for (int i = 0; i < n; ++i) {
+        const int rc = cn_step(handles[i], &ios[i], streams[i]);
+        if (rc != CN_OK) return rc;
+    }
+    return CN_OK;
+}
+
 extern "C" int cn_observe_external(cn_handle h, const cn_external_io* io, void* stream)
 {
     if (!h || !io || !io->ranges || !io->odom || !io->obs || !io->reward || !io->done)

@@ -162,6 +162,10 @@ int cn_set_ped_preset_vel(cn_handle h, const double* vxy_host);
  * (TRAIN:114-116).  mask: dev [N] or NULL (= all). obs_f64 may be NULL. */
 int cn_reset(cn_handle h, const uint8_t* mask, float* obs, double* obs_f64, void* stream);
 int cn_step(cn_handle h, const cn_step_io* io, void* stream);
+/* n calls of cn_step in one crossing of the boundary: handle i steps with ios[i] on streams[i] (env batches run as
+ * independent stream groups, DESIGN.md section 6: the launches are the same, the host thread pays the foreign-call
+ * overhead once per step instead of once per group).  Stops at the first error and returns it. */
+int cn_step_multi(int n, const cn_handle* handles, const cn_step_io* ios, void* const* streams);
 int cn_observe_external(cn_handle h, const cn_external_io* io, void* stream);
 
 /* The actor's output stage as one launch (no handle needed): action = clip(heads(logits) + N(0, sigma)).

@@ -367,6 +367,17 @@ def test_stream_groups_equal_one_handle(mode):
                 assert torch.equal(free.obs[rows], hist[t][0][rows]) and torch.equal(free.done[rows], hist[t][2][rows])
     free.join()
     torch.cuda.synchronize()
+    # cn_step_multi: one foreign call per step for all groups (what bench.py's group legs enqueue through)
+    multi = VecEnvGroups(cfg, groups=4)
+    multi.reset()
+    abuf = torch.zeros((96, 2), dtype=torch.float32, device="cuda")
+    call = multi.bind_step_all(abuf, auto_reset=mode)
+    for t in range(50):
+        abuf.copy_(acts[t])               # in place, on the current stream (the previous join ordered it after the last step)
+        multi.fork()                      # the groups' launches wait for it
+        call()
+        multi.join()
+        assert torch.equal(multi.obs, hist[t][0]) and torch.equal(multi.reward, hist[t][1]) and torch.equal(multi.done, hist[t][2]), t
     assert torch.equal(free.obs, hist[-1][0]) and torch.equal(free.reward, hist[-1][1])
     assert free.episodes() == int(full.counters()[:, 8].sum().item())
     assert torch.equal(free.returns()[0], full.returns()[0])
