@@ -1,24 +1,25 @@
 #!/bin/bash
 # The GPU-vs-oracle sweeps DESIGN.md quotes (every observation / reward / done flag / index / counter compared, zero
 # differences expected).  Writes gpurun_out/<tag>/parity_sweep.txt; copy it to profiles/<tag>/.
-#   tools/parity_sweep.sh r02
-TAG="${1:-r02}"; cd "$(dirname "$0")/.."; OUT="gpurun_out/$TAG"; mkdir -p "$OUT"
+#   tools/parity_sweep.sh r02 [scale]      scale multiplies every --steps (10 -> 36 M env-steps, ~10 min; output parity_sweep_x10.txt)
+TAG="${1:-r02}"; S="${2:-1}"; cd "$(dirname "$0")/.."; OUT="gpurun_out/$TAG"; mkdir -p "$OUT"
 R="python tools/parity_report.py --verbose 2"
+NAME=parity_sweep; [ "$S" != 1 ] && NAME="parity_sweep_x$S"
 {
-$R --envs 4096 --steps 100 --max-steps 60 --reset-mode next
-$R --envs 2048 --steps 400 --max-steps 120
-$R --envs 1024 --steps 300 --peds 60 --reset-mode next
-$R --envs 512 --steps 200 --peds 100 --max-steps 80
-$R --envs 256 --steps 150 --peds 100 --rays 720 --room 2.4
-$R --envs 512 --steps 300 --min-scan 0.0 --max-steps 500 --reset-mode next
-$R --envs 1024 --steps 300 --peds 14 --k 4
-$R --envs 512 --steps 200 --peds 200 --rays 1025 --room 2.4 --max-steps 80
-$R --envs 512 --steps 200 --peds 60 --geos 1
-$R --envs 1024 --steps 300 --risk-mode 1 --reset-mode next
-$R --envs 512 --steps 200 --peds 100 --risk-mode 1 --k 4
-$R --envs 512 --steps 200 --peds 60 --contact 1 --min-scan 0.0
-$R --envs 512 --steps 200 --peds 40 --contact 1 --risk-mode 1 --vmax 0.5
-$R --envs 1024 --steps 300 --layout 1
-$R --envs 1024 --steps 300 --layout 2 --dt-ms 50 --reset-mode next
-$R --envs 256 --steps 200 --layout 2 --dt-ms 50 --peds 100 --min-scan 0.0
-} 2>&1 | grep -v amdgpu.ids | tee "$OUT/parity_sweep.txt"
+$R --envs 4096 --steps $((100 * S)) --max-steps 60 --reset-mode next
+$R --envs 2048 --steps $((400 * S)) --max-steps 120
+$R --envs 1024 --steps $((300 * S)) --peds 60 --reset-mode next
+$R --envs 512 --steps $((200 * S)) --peds 100 --max-steps 80
+$R --envs 256 --steps $((150 * S)) --peds 100 --rays 720 --room 2.4
+$R --envs 512 --steps $((300 * S)) --min-scan 0.0 --max-steps 500 --reset-mode next
+$R --envs 1024 --steps $((300 * S)) --peds 14 --k 4
+$R --envs 512 --steps $((200 * S)) --peds 200 --rays 1025 --room 2.4 --max-steps 80
+$R --envs 512 --steps $((200 * S)) --peds 60 --geos 1
+$R --envs 1024 --steps $((300 * S)) --risk-mode 1 --reset-mode next
+$R --envs 512 --steps $((200 * S)) --peds 100 --risk-mode 1 --k 4
+$R --envs 512 --steps $((200 * S)) --peds 60 --contact 1 --min-scan 0.0
+$R --envs 512 --steps $((200 * S)) --peds 40 --contact 1 --risk-mode 1 --vmax 0.5
+$R --envs 1024 --steps $((300 * S)) --layout 1
+$R --envs 1024 --steps $((300 * S)) --layout 2 --dt-ms 50 --reset-mode next
+$R --envs 256 --steps $((200 * S)) --layout 2 --dt-ms 50 --peds 100 --min-scan 0.0
+} 2>&1 | grep -v amdgpu.ids | tee "$OUT/$NAME.txt"
