@@ -253,6 +253,9 @@ def main():
             for c in calls[i % n_act]:
                 c()
         ep0 = episodes_dev()
+        # the timed steps as ONE pre-marshalled cn_step_multi (steps_ x G entries, step-major): the host side of the timed
+        # region is then a C loop over hipLaunchKernel, as it would be in a C++ trainer, not a Python loop
+        timed_call = grp.bind_step_sequence([acts_[i % n_act] for i in range(steps_)], auto_reset=mode)
         rank_barrier()
         for i in range(n_pre - warm_tail, n_pre):
             for c in calls[i % n_act]:
@@ -263,9 +266,7 @@ def main():
         t0 = time.perf_counter()
         for g in range(G):
             ev0[g].record(grp.streams[g])
-        for i in range(steps_):
-            for c in calls[i % n_act]:
-                c()
+        timed_call()                                   # all steps_ x G launches: one cn_step_multi, a C loop
         enq_ms.setdefault(G, (time.perf_counter() - t0) * 1e3 / steps_)   # host time to enqueue one step of all groups (first leg with G)
         for g in range(G):
             ev1[g].record(grp.streams[g])

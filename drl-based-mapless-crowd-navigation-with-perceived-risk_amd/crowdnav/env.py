@@ -363,12 +363,43 @@ class VecEnvGroups:
                                    obs_f64=e.obs_f64.data_ptr() if e.obs_f64 is not None else None,
                                    reward=e.reward.data_ptr(), done=e.done.data_ptr(), topk_idx=e.topk_idx.data_ptr(),
                                    auto_reset=ar, reserved=0)
-            hs[g] = e.h if not hasattr(e.h, "value") else e.h.value
+            hs[g] = e.h.value
             sts[g] = e._stream().value
         fn, check = self.envs[0].L.cn_step_multi, _abi.check
 
         def call(_keep=(keep, ios, hs, sts)):
             rc = fn(G, hs, ios, sts)
+            if rc:
+                check(rc)
+        return call
+
+    def bind_step_sequence(self, actions, auto_reset="next"):
+        """K open-loop steps of every group behind ONE foreign call (cn_step_multi with K x G entries, step-major: the same
+        launches in the same order as K calls of bind_step_all's callable, enqueued by a C loop instead of a Python one).
+        actions: a sequence of K [N, 2] float32 device tensors (entries may repeat).  Returns a zero-argument callable."""
+        G, K = self.G, len(actions)
+        n = G * K
+        ios = (_abi.CnStepIO * n)()
+        hs = (C.c_void_p * n)()
+        sts = (C.c_void_p * n)()
+        keep = [actions]
+        ar = {False: 0, True: 1, None: 0, "same": 1, "next": 2}.get(auto_reset, auto_reset)
+        for i, action in enumerate(actions):
+            for g, e in enumerate(self.envs):
+                a = action[self.rows(g)]
+                assert a.device == e.device and a.dtype == torch.float32 and a.is_contiguous()
+                keep.append(a)
+                j = i * G + g
+                ios[j] = _abi.CnStepIO(action=a.data_ptr(), step_counter=None, obs=e.obs.data_ptr(), final_obs=None,
+                                       obs_f64=e.obs_f64.data_ptr() if e.obs_f64 is not None else None,
+                                       reward=e.reward.data_ptr(), done=e.done.data_ptr(), topk_idx=e.topk_idx.data_ptr(),
+                                       auto_reset=ar, reserved=0)
+                hs[j] = e.h.value
+                sts[j] = e._stream().value
+        fn, check = self.envs[0].L.cn_step_multi, _abi.check
+
+        def call(_keep=(keep, ios, hs, sts)):
+            rc = fn(n, hs, ios, sts)
             if rc:
                 check(rc)
         return call
