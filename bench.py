@@ -205,8 +205,10 @@ def main():
         rank_barrier()
         for i in range(n_pre - warm_tail, n_pre):
             env.step(acts[i % n_act], auto_reset=mode)
-        torch.cuda.synchronize(dev)
         stream = torch.cuda.current_stream(dev)
+        while not stream.query():                      # spin instead of sleeping in the synchronize (see timed_groups)
+            pass
+        torch.cuda.synchronize(dev)
         ev0 = torch.cuda.Event(enable_timing=True)
         ev1 = torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
@@ -260,6 +262,9 @@ def main():
         for i in range(n_pre - warm_tail, n_pre):
             for c in calls[i % n_act]:
                 c()
+        for s_ in grp.streams:                         # spin, do not sleep: a host core that blocked in hipDeviceSynchronize
+            while not s_.query():                      # comes back clocked down and its first launches cost 2-3x
+                pass
         torch.cuda.synchronize(dev)
         ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(G)]
         ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(G)]
