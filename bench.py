@@ -251,13 +251,13 @@ def main():
                     out.append(e_.counters()[:, 8].sum())
             return out
         n_pre = a.preroll + a.warmup
+        # the timed steps as ONE pre-marshalled cn_step_multi (steps_ x G entries, step-major): the host side of the timed
+        # region is then a C loop over hipLaunchKernel, as it would be in a C++ trainer, not a Python loop
+        timed_call = grp.bind_step_sequence([acts_[i % n_act] for i in range(steps_)], auto_reset=mode)
         for i in range(n_pre - warm_tail):
             for c in calls[i % n_act]:
                 c()
         ep0 = episodes_dev()
-        # the timed steps as ONE pre-marshalled cn_step_multi (steps_ x G entries, step-major): the host side of the timed
-        # region is then a C loop over hipLaunchKernel, as it would be in a C++ trainer, not a Python loop
-        timed_call = grp.bind_step_sequence([acts_[i % n_act] for i in range(steps_)], auto_reset=mode)
         rank_barrier()
         for i in range(n_pre - warm_tail, n_pre):
             for c in calls[i % n_act]:
