@@ -9,29 +9,40 @@
   GPU); default is weak scaling, --envs (4096) per GPU.
 
 A "step" is every env of this rank's shard stepped once through cn_step (4096 envs x 20 pedestrians x 360 rays, K = 8,
-BASELINE.json configs[1]) -- as `--groups` launches on independent streams (default 4 x 1024 envs), as 2 launches, or as
-one; every decomposition is timed over the same K steps with the same bracket and the best one is the headline
-(`config.legs_env_steps_s` carries all three).  `value` = env-steps/s summed over all ranks, inputs resident in HBM,
-auto-reset included; a launch an env spends on its reset is not counted as an env-step.  Envs shard across
-ranks with no data-path collective; the one collective is the RCCL all-gather of per-env episode returns after the timed
-region (8e E1).
+BASELINE.json configs[1]).  The shard runs as `--groups` independent stream groups (default 4 x 1024 envs), as 2, or as one
+launch per step.  Protocol (round 3; no choice is made on the reported sample):
+  1. after the W warm-up + pre-roll steps every decomposition runs ONE untimed-for-the-report probe of K steps; the best
+     probe decides which decomposition is the headline (`config.headline_choice`);
+  2. every decomposition is then timed `--repeats` (5) times: each sample = exactly K steps bracketed by barrier +
+     torch.cuda.synchronize() on both sides (max over ranks); `value` / `ms_per_step` are the MEDIAN sample of the headline
+     decomposition, `config.legs_env_steps_s` the medians of all of them, `config.samples_env_steps_s` every sample.
+`value` = env-steps/s summed over all ranks, inputs resident in HBM, auto-reset included; a launch an env
+spends on its reset is not counted as an env-step (counted exactly: finished-episode and reset-pending counters on the
+device before and after the K steps).  Envs shard across ranks with no data-path collective; the one collective is the
+RCCL all-gather of per-env episode returns after the timed region (8e E1).
 
 Adds to the JSON line:
-  roofline      achieved algorithmic HBM bytes/s of cn_env_kernel (HIP events on the launch stream)
-  cpu_baseline  the CPU oracle (plain-C port of the reference path, oracle/cn_oracle.c) timed on this
-                box's host cores on a bounded sample of the same workload (rank 0, N = 1 only)
+  roofline       achieved algorithmic HBM bytes/s of cn_env_kernel (HIP events on the launch streams); `frac` is priced with
+                 SURVEY 8(d) D4's 2400 B per env-step, `frac_f64_layout` with this build's float64 state layout
+  cpu_baseline   the CPU oracle (plain-C port of the reference path, oracle/cn_oracle.c) timed on this box's host cores on a
+                 bounded sample of the same workload (rank 0, N = 1 only), the reference's own Python rate beside it
+  config.other_configs   BASELINE configs[2] (TD3 actor in the loop) and configs[4] (100 pedestrians x 720 rays) under
+                 the same bracket, each with its own ms_per_step and D4-priced roofline fraction (N = 1 only)
 """
 import argparse
 import json
 import os
 import sys
 import time
+import zlib
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "drl-based-mapless-crowd-navigation-with-perceived-risk_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+N_ACT = 64             # distinct open-loop action tensors cycled through
 
 
 def algorithmic_bytes(P, R, K):
@@ -41,21 +52,31 @@ def algorithmic_bytes(P, R, K):
     return 64 * P + 4 * (R - 1 + 7 + 4 * K) + 4 * K + 2 * (24 * 8 + 16 * 4) + 8 + 4 + 1
 
 
-D4_BYTES_PER_ENV_STEP = 2400.0   # SURVEY 8(d) D4's own per-env-step figure (float32 state), for round-to-round comparison
+def d4_bytes(P, R, K):
+    """SURVEY 8(d) D4's own per-env-step figure (float32 state): 2400 B at 20 pedestrians x 360 rays, 6400 B at 100 x 720
+    (16 P of pedestrian state read + written, the observation and indices written once, ~0.4 KB of scalars)."""
+    if (P, R) == (20, 360):
+        return 2400.0
+    if (P, R) == (100, 720):
+        return 6400.0
+    return float(32 * P + 4 * (R - 1 + 7 + 4 * K) + 4 * K + 256 + 13)
 
 
-def profiled_counters():
-    """Issue-side figures of cn_env_kernel from the committed rocprofv3 PMC passes of this same command
-    (profiles/rNN/counters.json, written by tools/summarize_prof.py): VALU busy fraction and wave instructions per
-    env-step.  None when no profile is committed."""
+def profiled_json(name):
+    """profiles/rNN/<name> of the latest round IF it was taken with the kernel sources of this tree (csrc_hash stamp written by
+    tools/summarize_prof.py); (None, reason) otherwise -- a profile of another kernel says nothing about this one."""
     import glob
-    c = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "counters.json")))
+    from csrc_hash import csrc_hash
+    c = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", name)))
     if not c:
-        return None
+        return None, "no profile committed"
     try:
-        return json.load(open(c[-1]))
-    except Exception:
-        return None
+        d = json.load(open(c[-1]))
+    except Exception as ex:
+        return None, "unreadable %s: %s" % (c[-1], ex)
+    if d.get("csrc_hash") != csrc_hash():
+        return None, "%s was taken with csrc %s, this tree is %s" % (os.path.relpath(c[-1], ROOT), d.get("csrc_hash"), csrc_hash())
+    return d, os.path.relpath(c[-1], ROOT)
 
 
 def self_launch(a):
@@ -72,26 +93,12 @@ def self_launch(a):
     return subprocess.call(cmd, env=env)
 
 
-def profiled_traffic():
-    """HBM bytes per cn_env_kernel launch from the committed rocprofv3 PMC passes of this same command
-    (profiles/rNN/traffic.json: FETCH_SIZE and WRITE_SIZE from separate passes, calibrated on this box's
-    known-byte streams).  None when no profile is committed."""
-    import glob
-    c = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")))
-    if not c:
-        return None
-    try:
-        return float(json.load(open(c[-1]))["bytes_per_launch"])
-    except Exception:
-        return None
-
-
 def baseline_metric():
     """The metric string exactly as BASELINE.json spells it."""
     try:
         return json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
     except Exception:
-        return "env-steps/sec @4096 envs\u00d720 peds\u00d7360 rays; HBM GB/s vs roofline"
+        return "env-steps/sec @4096 envs×20 peds×360 rays; HBM GB/s vs roofline"
 
 
 def usable_cpus():
@@ -105,22 +112,30 @@ def usable_cpus():
     return max(1, n)
 
 
+def median_index(vals):
+    """Index of the median element (the lower middle one for an even count)."""
+    order = sorted(range(len(vals)), key=lambda i: vals[i])
+    return order[(len(vals) - 1) // 2]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--repeats", type=int, default=5, help="timed samples of K steps per decomposition; the median is reported")
     ap.add_argument("--envs", type=int, default=4096, help="environments per GPU (weak scaling)")
     ap.add_argument("--envs-total", type=int, default=0,
                     help="strong scaling: this many environments split evenly over the ranks (overrides --envs)")
     ap.add_argument("--preroll", type=int, default=200,
-                    help="untimed steps after every reset so that the timed sample sees de-phased envs and real resets")
+                    help="untimed steps after every reset so that the timed samples see de-phased envs and real resets")
     ap.add_argument("--no-plateau", action="store_true", help="skip the 16384-env issue-bound measurement")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the BASELINE configs[2] / configs[4] legs")
     ap.add_argument("--peds", type=int, default=20)
     ap.add_argument("--rays", type=int, default=360)
     ap.add_argument("--k", type=int, default=8)
     ap.add_argument("--groups", type=int, default=4,
-                    help="headline leg: the rank's envs as this many independent stream groups (1 = one launch per step)")
+                    help="largest decomposition tried: the rank's envs as this many independent stream groups")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     a = ap.parse_args()
@@ -130,7 +145,7 @@ def main():
     import torch
     import torch.distributed as dist
     from crowdnav import Config
-    from crowdnav.env import VecEnv, VecEnvGroups
+    from crowdnav.env import VecEnvGroups, concurrent_streams
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -160,167 +175,206 @@ def main():
         N = a.envs_total // world
     else:
         N = a.envs
+    K, R = max(1, a.steps), max(1, a.repeats)
     cfg = Config(n_envs=N, n_peds=a.peds, n_rays=a.rays, k_obstacles=a.k, max_steps=1000, seed=1234,
                  env_index_base=rank * N, ped_cycle_ms=1400,
                  room_half=2.40 if a.peds > 50 else 1.40)
-    env = VecEnv(cfg, device=dev_index)
-    env.reset()
-    # open-loop actions v ~ U(0, 0.22), w ~ U(-2, 2): counter-based, seed 1234 + global env index
-    g = torch.Generator(device=dev).manual_seed(1234 + rank)
-    n_act = 64
-    acts = torch.stack([torch.rand((n_act, N), generator=g, device=dev) * 0.22,
-                        torch.rand((n_act, N), generator=g, device=dev) * 4.0 - 2.0], 2).contiguous()
 
-    # The opening bracket.  A GPU that sits idle for a few ms clocks down and needs ~10 launches to come back
-    # (tools/startup_transient.py: the same 20 steps take 800 us right after work, 870 us after 5 ms of idling, 960 us
-    # after 100 ms), and a counters read-back or a rank barrier is such a pause.  So the episode counters are snapshotted
-    # on the device, the rank barrier comes first and the last `warm_tail` of the W warm-up steps run between it and the
-    # torch.cuda.synchronize() that starts the clock: barrier + synchronize still bracket the K timed steps, all W + the
-    # pre-roll steps are still untimed, and the timed region starts on a GPU in the state a long run keeps it in.
+    def open_loop_actions(n, seed):
+        """v ~ U(0, 0.22), w ~ U(-2, 2): N_ACT tensors [n, 2] resident in HBM"""
+        g = torch.Generator(device=dev).manual_seed(seed)
+        return torch.stack([torch.rand((N_ACT, n), generator=g, device=dev) * 0.22,
+                            torch.rand((N_ACT, n), generator=g, device=dev) * 4.0 - 2.0], 2).contiguous()
+
+    acts = open_loop_actions(N, 1234 + rank)
+    # streams that really run concurrently (HIP maps streams onto a few hardware queues), probed once for every leg
+    Gmax = max(1, a.groups)
+    streams, conc = concurrent_streams(Gmax, dev_index)
     warm_tail = min(a.warmup, 3)
 
     def rank_barrier():
         if world > 1:
             dist.barrier()
 
-    def barrier(streams=()):
-        """The contract's bracket: barrier over the ranks + torch.cuda.synchronize().  hipDeviceSynchronize blocks on an
-        interrupt and wakes up 60-75 us after the last kernel has finished (tools/startup_transient.py) -- 7 % of a
-        20-step sample of 0.85 ms that is host notification latency, not device work.  So the streams that carry the
-        timed launches are polled to completion first (hipStreamQuery, ~1 us a call); the synchronize that follows
-        then returns at once and still is the bracket."""
-        for s_ in streams:
+    def bracket(strs):
+        """The contract's bracket: barrier over the ranks + torch.cuda.synchronize().  The streams that carry the launches are
+        polled to completion first (hipStreamQuery), so that the synchronize returns at once instead of sleeping on an
+        interrupt and waking up 60-75 us late (tools/startup_transient.py)."""
+        for s_ in strs:
             while not s_.query():
                 pass
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    def timed(mode):
-        """K launches of cn_step; returns (wall s, kernel ms/launch, env-steps actually taken by this rank)."""
-        n_pre = a.preroll + a.warmup
-        for i in range(n_pre - warm_tail):
-            env.step(acts[i % n_act], auto_reset=mode)
-        ep0 = env.counters()[:, 8].sum()              # device scalar, read after the timed region (no host sync here)
         rank_barrier()
-        for i in range(n_pre - warm_tail, n_pre):
-            env.step(acts[i % n_act], auto_reset=mode)
-        stream = torch.cuda.current_stream(dev)
-        while not stream.query():                      # spin instead of sleeping in the synchronize (see timed_groups)
-            pass
         torch.cuda.synchronize(dev)
-        ev0 = torch.cuda.Event(enable_timing=True)
-        ev1 = torch.cuda.Event(enable_timing=True)
-        t0 = time.perf_counter()
-        ev0.record(stream)
-        for i in range(a.steps):
-            env.step(acts[i % n_act], auto_reset=mode)
-        ev1.record(stream)
-        barrier((stream,))
-        wall_ = time.perf_counter() - t0
-        k_ms = ev0.elapsed_time(ev1) / a.steps       # cn_env_kernel is the only kernel in the timed region
-        ep1 = env.counters()[:, 8].sum().item()
-        torch.cuda.synchronize(dev)
-        taken = N * a.steps
-        if mode == "next":                            # a finished env spends one launch on its reset: not an env-step
-            taken -= int(ep1 - ep0.item())
-        return wall_, k_ms, taken
 
-    conc = 1
-    enq_ms = {}
-    def timed_groups(G, mode="next", gcfg=None, gacts=None, steps=None):
-        """The same N envs as G independent groups (crowdnav.env.VecEnvGroups): one step = every group stepped
-        once, each on its own HIP stream, no join between groups inside the timed region.  Returns (wall s,
-        mean per-stream ms/launch from HIP events on each group's stream, env-steps taken)."""
-        gcfg = gcfg or cfg
-        acts_ = gacts if gacts is not None else acts
-        steps_ = steps or a.steps
-        grp = VecEnvGroups(gcfg, groups=G, device=dev_index)
-        nonlocal conc
-        conc = grp.concurrent
-        grp.reset()
-        rows = [grp.rows(g) for g in range(G)]
-        # pre-marshalled launches: ~1.5 us of host time per foreign call instead of ~7 us for VecEnv.step, so a short timed
-        # sample (the driver uses 20 steps = 80 launches of ~40 us) is not paced by the Python enqueue loop
-        # one cn_step_multi per step: all groups' launches behind one foreign call
-        calls = [[grp.bind_step_all(acts_[i], auto_reset=mode)] for i in range(n_act)]
-        def episodes_dev():                            # finished episodes per group as device scalars, no host sync
+    class Leg:
+        """One decomposition of a config: its envs as G stream groups (G = 1: one launch per step), open loop or with the TD3
+        actor in the loop (each group's act -> step chain on its own stream, crowdnav.rollout.rollout_groups)."""
+
+        def __init__(self, lcfg, G, mode="next", lacts=None, agent=None):
+            self.cfg, self.G, self.mode, self.agent = lcfg, G, mode, agent
+            self.grp = VecEnvGroups(lcfg, groups=G, device=dev_index, streams=streams[:G] if G <= len(streams) else None)
+            self.grp.reset()
+            self.enq_ms = None
+            if agent is None:
+                self.calls = [self.grp.bind_step_all(lacts[i], auto_reset=mode) for i in range(N_ACT)]
+                # the K timed steps as ONE pre-marshalled cn_step_multi (K x G entries): the host side of a sample is a C loop
+                self.timed_call = self.grp.bind_step_sequence([lacts[i % N_ACT] for i in range(K)], auto_reset=mode)
+            else:
+                agent.sync_fused_weights()
+                self.act = torch.zeros((lcfg.n_envs, 2), dtype=torch.float32, device=dev)
+                chain = []
+                for g in range(G):
+                    rows = self.grp.rows(g)
+                    chain.append(agent.bind_act_mfma(self.grp.obs[rows], self.act[rows], add_noise=True,
+                                                     stream=self.grp.streams[g], noise_seed=agent.group_noise_seed(g)))
+                    chain.append(self.grp.envs[g].bind_step(self.act[rows], auto_reset=mode))
+                self.chain = chain
+
+        def run(self, k, i0=0):
+            if self.agent is None:
+                for i in range(k):
+                    self.calls[(i0 + i) % N_ACT]()
+            else:
+                for _ in range(k):
+                    for c in self.chain:
+                        c()
+
+        def _reset_launch_marker(self):
+            """finished episodes minus pending resets, summed over this leg's envs, as device scalars (no host sync): the
+            difference of two markers is exactly the number of launches envs spent on a reset in between (auto_reset 2)"""
             out = []
-            for e_ in grp.envs:
+            for e_ in self.grp.envs:
                 with torch.cuda.stream(e_.stream):
-                    out.append(e_.counters()[:, 8].sum())
+                    c = e_.counters()
+                    out.append((c[:, 8].sum() - c[:, 9].sum()).clone())
             return out
-        n_pre = a.preroll + a.warmup
-        # the timed steps as ONE pre-marshalled cn_step_multi (steps_ x G entries, step-major): the host side of the timed
-        # region is then a C loop over hipLaunchKernel, as it would be in a C++ trainer, not a Python loop
-        timed_call = grp.bind_step_sequence([acts_[i % n_act] for i in range(steps_)], auto_reset=mode)
-        for i in range(n_pre - warm_tail):
-            for c in calls[i % n_act]:
-                c()
-        ep0 = episodes_dev()
-        rank_barrier()
-        for i in range(n_pre - warm_tail, n_pre):
-            for c in calls[i % n_act]:
-                c()
-        for s_ in grp.streams:                         # spin, do not sleep: a host core that blocked in hipDeviceSynchronize
-            while not s_.query():                      # comes back clocked down and its first launches cost 2-3x
-                pass
-        torch.cuda.synchronize(dev)
-        ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(G)]
-        ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(G)]
-        t0 = time.perf_counter()
-        for g in range(G):
-            ev0[g].record(grp.streams[g])
-        timed_call()                                   # all steps_ x G launches: one cn_step_multi, a C loop
-        enq_ms.setdefault(G, (time.perf_counter() - t0) * 1e3 / steps_)   # host time to enqueue one step of all groups (first leg with G)
-        for g in range(G):
-            ev1[g].record(grp.streams[g])
-        barrier(grp.streams)
-        wall_ = time.perf_counter() - t0
-        k_ms = sum(ev0[g].elapsed_time(ev1[g]) for g in range(G)) / G / steps_
-        taken = gcfg.n_envs * steps_ - (grp.episodes() - sum(int(x.item()) for x in ep0) if mode == "next" else 0)
-        grp.close()
-        return wall_, k_ms, taken
 
-    # legs: reset inside the same call (auto_reset = 1); next-step reset (auto_reset = 2) as one launch per step;
-    # next-step reset with the envs as `--groups` independent stream groups (the headline when groups > 1)
-    wall_same, kms_same, taken_same = timed("same")
-    env.reset()
-    wall_1, kernel_ms_1, taken_1 = timed("next")
-    G = max(1, a.groups)
-    if G > 1:
-        wall, kernel_ms, taken = timed_groups(G)
-    else:
-        wall, kernel_ms, taken = wall_1, kernel_ms_1, taken_1
-    # A third decomposition of the same step: 2 groups.  4 groups need a launch every ~10 us from the host thread; on a slow or
-    # busy host a short sample is then paced by the enqueue loop (20-step samples: 84 M with 4 groups, 92 M with 2 on one
-    # box; 91-93 M with 4 on others), while 2048-env launches need half the launch rate and give 94 % of the 4-group rate.
-    G2 = 2 if G > 2 and N % 2 == 0 else 0
-    conc_requested = conc                              # concurrent streams found for the requested group count
-    wall_2, kernel_ms_2, taken_2 = timed_groups(G2) if G2 else (wall_1, kernel_ms_1, taken_1)
-    conc = conc_requested
-    # Issue-bound ceiling of this kernel on this GPU, measured in the same run: 16384 resident envs in 4 stream groups
-    # (every SIMD has work in every phase; DESIGN.md section 6).  Rank 0 of a single-GPU run only.
+        def sample(self, steps=None):
+            """exactly K steps between two brackets -> (wall s, mean ms per launch on its stream, env-steps taken)"""
+            steps = K if steps is None else steps
+            grp, G = self.grp, self.G
+            rank_barrier()
+            self.run(warm_tail)                        # the last warm-up steps run after the rank barrier (no idle gap)
+            m0 = self._reset_launch_marker()
+            for s_ in grp.streams:
+                while not s_.query():
+                    pass
+            torch.cuda.synchronize(dev)
+            ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(G)]
+            ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(G)]
+            t0 = time.perf_counter()
+            for g in range(G):
+                ev0[g].record(grp.streams[g])
+            if self.agent is None and steps == K:
+                self.timed_call()
+            else:
+                self.run(steps)
+            t_enq = time.perf_counter() - t0
+            for g in range(G):
+                ev1[g].record(grp.streams[g])
+            bracket(grp.streams)
+            wall = time.perf_counter() - t0
+            if self.enq_ms is None:
+                self.enq_ms = t_enq * 1e3 / steps
+            k_ms = sum(ev0[g].elapsed_time(ev1[g]) for g in range(G)) / G / steps
+            taken = self.cfg.n_envs * steps
+            if self.mode == "next":
+                m1 = self._reset_launch_marker()
+                torch.cuda.synchronize(dev)
+                taken -= int(sum(x.item() for x in m1) - sum(x.item() for x in m0))
+            return wall, k_ms, taken
+
+        def close(self):
+            self.grp.close()
+
+    def reduce_samples(samples):
+        """per-sample (wall, kernel ms, taken) over the ranks: max wall, mean kernel ms, summed env-steps"""
+        if world == 1:
+            return samples, None
+        t = torch.tensor(samples, dtype=torch.float64, device=cdev)          # [n, 3]
+        mx = t.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = t.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        allr = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(allr, t)
+        out = [(float(mx[i, 0]), float(sm[i, 1]) / world, float(sm[i, 2])) for i in range(len(samples))]
+        return out, [x.cpu().tolist() for x in allr]
+
+    def measure(lcfg, candidates, lacts=None, agent=None, mode="next", repeats=R, probe=True):
+        """Every candidate decomposition of one config: pre-roll + warm-up, one probe of K steps each (decides the headline),
+        then `repeats` timed samples each.  Returns a dict with the chosen decomposition's median sample and all legs."""
+        legs = {}
+        for G in candidates:
+            lg = Leg(lcfg, G, mode=mode, lacts=lacts, agent=agent)
+            lg.run(a.preroll + a.warmup - warm_tail)
+            legs[G] = lg
+        probes = {}
+        if probe and len(candidates) > 1:
+            raw = [legs[G].sample() for G in candidates]
+            red, _ = reduce_samples(raw)
+            probes = {G: red[i][2] / red[i][0] for i, G in enumerate(candidates)}
+            chosen = max(candidates, key=lambda G: probes[G])
+        else:
+            chosen = candidates[0]
+        out = {"chosen": chosen, "probe_env_steps_s": {"%d" % G: v for G, v in probes.items()}, "legs": {}}
+        for G in candidates:
+            raw = [legs[G].sample() for _ in range(repeats)]
+            red, per_rank = reduce_samples(raw)
+            vals = [s[2] / s[0] for s in red]
+            mi = median_index(vals)
+            out["legs"][G] = {"median": vals[mi], "samples": vals, "wall": red[mi][0], "kernel_ms": red[mi][1],
+                              "taken": red[mi][2], "enq_ms": legs[G].enq_ms,
+                              "per_rank": [pr[mi] for pr in per_rank] if per_rank else None}
+            legs[G].close()
+        return out
+
+    cands = [Gmax] + [g for g in (2, 1) if g < Gmax and N % g == 0]
+    main_m = measure(cfg, cands, lacts=acts)
+    same_m = measure(cfg, [1], lacts=acts, mode="same", repeats=min(R, 3), probe=False)
+    G = main_m["chosen"]
+    hl = main_m["legs"][G]
+    value, wall, kernel_ms, taken_all = hl["median"], hl["wall"], hl["kernel_ms"], hl["taken"]
+    one = main_m["legs"].get(1)
+
+    # Issue-bound ceiling of this kernel on this GPU, measured in the same run: 16384 resident envs in stream groups
+    # (every SIMD has work in every phase; DESIGN.md section 6).  Single-GPU run only.
     plateau = None
-    if world == 1 and not a.no_plateau and (a.peds, a.rays) == (20, 360):
+    single_default = world == 1 and (a.peds, a.rays) == (20, 360)
+    if single_default and not a.no_plateau:
         import dataclasses
         pcfg = dataclasses.replace(cfg, n_envs=16384)
-        gp = torch.Generator(device=dev).manual_seed(99)
-        pacts = torch.stack([torch.rand((n_act, 16384), generator=gp, device=dev) * 0.22,
-                             torch.rand((n_act, 16384), generator=gp, device=dev) * 4.0 - 2.0], 2).contiguous()
-        pw, pk, pt = timed_groups(max(1, a.groups), gcfg=pcfg, gacts=pacts, steps=max(50, min(a.steps, 300)))
-        plateau = pt / pw
-        del pacts
+        pm = measure(pcfg, [Gmax], lacts=open_loop_actions(16384, 99), repeats=1, probe=False)
+        plateau = pm["legs"][Gmax]["median"]
+
+    # BASELINE configs[2] (TD3 actor in the loop: random-init 398-256-256-2 actor, sigma = 1 exploration, cn_actor_forward ->
+    # cn_step chains) and configs[4] (100 pedestrians x 720 rays in the 4.8 m room) under the same bracket and protocol
+    other = None
+    if single_default and N == 4096 and not a.no_other_configs:
+        from crowdnav.td3 import Agent
+        other = {}
+        agent = Agent(obs_dim=cfg.obs_dim, device="cuda:%d" % dev_index, seed=0, memory_size=16)
+        m3 = measure(cfg, cands, agent=agent, repeats=min(R, 3))
+        c5 = Config(n_envs=N, n_peds=100, n_rays=720, k_obstacles=a.k, max_steps=1000, seed=1234, ped_cycle_ms=1400, room_half=2.40)
+        m5 = measure(c5, [Gmax, 1] if Gmax > 1 else [1], lacts=acts, repeats=min(R, 3))
+        for key, m, P_, R_, what in (("configs[2]", m3, 20, 360, "4096 envs x 20 pedestrians x 360 rays, K=8, TD3 actor in the loop "
+                                      "(cn_actor_forward f32-MFMA actor + exploration noise -> cn_step, per stream group)"),
+                                     ("configs[4]", m5, 100, 720, "4096 envs x 100 pedestrians x 720 rays, K=8, room 4.8 m, open loop")):
+            l_ = m["legs"][m["chosen"]]
+            d4 = d4_bytes(P_, R_, a.k)
+            other[key] = {"workload": what, "value": l_["median"], "unit": "env-steps/s", "ms_per_step": l_["wall"] / K * 1e3,
+                          "stream_groups": m["chosen"], "samples_env_steps_s": l_["samples"],
+                          "legs_env_steps_s": {"%d_groups" % g: v["median"] for g, v in m["legs"].items()},
+                          "probe_env_steps_s": m["probe_env_steps_s"],
+                          "roofline": {"bound": "hbm", "bytes_per_env_step_d4": d4, "achieved": l_["median"] * d4 / 1e9,
+                                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": l_["median"] * d4 / 1e9 / HBM_PEAK_GBS}}
+
+    gather = None
     if world > 1:
-        t = torch.tensor([wall, float(taken), wall_same, float(taken_same), wall_1, float(taken_1), wall_2, float(taken_2)],
-                         dtype=torch.float64, device=cdev)
-        tm = t.clone(); dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-        ts = t.clone(); dist.all_reduce(ts, op=dist.ReduceOp.SUM)
-        wall, wall_same, wall_1, wall_2 = float(tm[0].item()), float(tm[2].item()), float(tm[4].item()), float(tm[6].item())
-        taken_all, taken_same_all, taken_1_all, taken_2_all = (float(ts[1].item()), float(ts[3].item()), float(ts[5].item()),
-                                                               float(ts[7].item()))
-        # the path's one exchange: all-gather of per-env episode returns over xGMI (SURVEY 8e)
-        ret, _ = env.returns()
+        # the path's one exchange: all-gather of per-env episode returns over xGMI (SURVEY 8e).  A fresh handle stepped a few
+        # hundred launches so that every env has finished episodes to report.
+        lg = Leg(cfg, 1, lacts=acts)
+        lg.run(a.preroll)
+        ret, _ = lg.grp.envs[0].returns()
+        torch.cuda.synchronize(dev)
         ret = ret.to(cdev)
         gathered = torch.empty(world * N, dtype=torch.float32, device=cdev)
         dist.all_gather_into_tensor(gathered, ret)     # first call builds the communicator rings: not timed
@@ -331,80 +385,86 @@ def main():
             dist.all_gather_into_tensor(gathered, ret)
         torch.cuda.synchronize(dev)
         gather_ms = (time.perf_counter() - tg0) * 1e3 / 10
-        # every rank holds every env's return; rank r's slice must be what rank r computed
+        # every rank holds every env's return; rank r's slice must be what rank r computed, and all ranks must agree
         assert torch.equal(gathered[rank * N:(rank + 1) * N], ret)
-    else:
-        taken_all, taken_same_all, taken_1_all, taken_2_all, gather_ms = (float(taken), float(taken_same), float(taken_1),
-                                                                          float(taken_2), None)
+        gh = gathered.cpu().numpy()
+        crc = zlib.crc32(gh.tobytes())
+        crcs = torch.tensor([crc], dtype=torch.int64, device=cdev)
+        allc = [torch.empty_like(crcs) for _ in range(world)]
+        dist.all_gather(allc, crcs)
+        seen = torch.tensor([1.0], device=cdev); dist.all_reduce(seen)
+        try:
+            ver = ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception:
+            ver = None
+        gather = {"ms": gather_ms, "bytes_per_rank": 4 * N, "ranks_seen": int(seen.item()),
+                  "crc32_of_gathered_returns": crc, "all_ranks_agree": all(int(c.item()) == crc for c in allc),
+                  "sum_of_gathered_returns": float(gh.astype("float64").sum()), "nonzero_returns": int((gh != 0).sum()),
+                  "collective": "gloo (dry run)" if dry else "rccl", "rccl_version": ver}
+        lg.close()
 
-    # Headline = the best of the next-step-reset legs (the same K steps of the same envs, decomposed into `--groups`, 2 or 1
-    # launches per step); the JSON says which one and carries the others.  A runtime that maps every stream onto one hardware
-    # queue makes the one-launch leg the headline, a slow host the 2-group leg.  Decided on the rank-aggregated numbers, so
-    # every rank agrees.
-    groups_requested = G
-    legs = {"%d_groups" % G: taken_all / wall, "1_launch": taken_1_all / wall_1}
-    if G2:
-        legs["2_groups"] = taken_2_all / wall_2
-        if taken_2_all / wall_2 > taken_all / wall:
-            G, wall, kernel_ms, taken_all = 2, wall_2, kernel_ms_2, taken_2_all
-    if G > 1 and taken_1_all / wall_1 > taken_all / wall:
-        G, wall, kernel_ms, taken_all = 1, wall_1, kernel_ms_1, taken_1_all
-    value = taken_all / wall
     B = algorithmic_bytes(a.peds, a.rays, a.k)
+    D4 = d4_bytes(a.peds, a.rays, a.k)
     n_launch = N // G                                  # envs per cn_env_kernel launch in the headline leg
     # every launch moves its envs' state, reset or step; G launches are in flight at once, one per stream
     achieved = G * B * n_launch / (kernel_ms * 1e-3) / 1e9
-    achieved_1 = B * N / (kernel_ms_1 * 1e-3) / 1e9
-    counters = profiled_counters() if (a.peds, a.rays) == (20, 360) else None
-    traffic = profiled_traffic() if (a.envs, a.peds, a.rays) == (4096, 20, 360) else None
-    valu_n = ((counters or {}).get("wave_instr_per_env_step") or {}).get("valu")
-    valu_peak = (1024 * 2.4e9 / (4.0 * valu_n)) if valu_n else None
+    achieved_d4 = G * D4 * n_launch / (kernel_ms * 1e-3) / 1e9
+    counters, counters_src = profiled_json("counters.json") if (a.peds, a.rays) == (20, 360) else (None, "other workload")
+    traffic, traffic_src = profiled_json("traffic.json") if (N, a.peds, a.rays) == (4096, 20, 360) else (None, "other workload")
+    traffic_b = float(traffic["bytes_per_launch"]) * n_launch / 4096.0 if traffic else None
     out = {
         "metric": baseline_metric(),
         "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": wall / a.steps * 1e3, "higher_is_better": True, "scaling": "strong" if a.envs_total else "weak",
+        "ms_per_step": wall / K * 1e3, "higher_is_better": True, "scaling": "strong" if a.envs_total else "weak",
         "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "%s: %d envs/GPU x %d pedestrians x %d rays, K=%d, lidar-tracker risk features, "
                                "next-step auto-reset (reset launches not counted as env-steps), open-loop "
                                "U(0,0.22)xU(-2,2) actions, %d untimed pre-roll steps; one step = every env stepped once, "
-                               "the envs running as %d independent stream group(s) of %d" % (
+                               "the envs running as %d independent stream group(s) of %d; median of %d samples of %d steps" % (
                                    ("BASELINE configs[3] shape, %d envs total over %d GPU(s) (strong scaling)" % (a.envs_total, world))
                                    if a.envs_total else ("BASELINE configs[1] per GPU (weak scaling over %d GPU(s))" % world),
-                                   N, a.peds, a.rays, a.k, a.preroll, G, n_launch),
-                   "envs_per_gpu": N, "envs_total": N * world, "stream_groups": G, "stream_groups_requested": groups_requested,
-                   "legs_env_steps_s": legs,
-                   # host time the enqueue loop needs per step of a group leg (a leg is host-paced when this approaches ms_per_step)
-                   "host_enqueue_ms_per_step": {"%d_groups" % k: v for k, v in sorted(enq_ms.items()) if k in (groups_requested, 2)},
+                                   N, a.peds, a.rays, a.k, a.preroll, G, n_launch, R, K),
+                   "envs_per_gpu": N, "envs_total": N * world, "stream_groups": G, "stream_groups_requested": Gmax,
+                   "repeats": R, "samples_env_steps_s": hl["samples"],
+                   "headline_choice": {"rule": "best untimed probe of K steps among the decompositions, taken before the timed samples",
+                                       "probe_env_steps_s": main_m["probe_env_steps_s"], "chosen_groups": G},
+                   "legs_env_steps_s": {"%d_groups" % g: v["median"] for g, v in main_m["legs"].items()},
+                   "legs_samples_env_steps_s": {"%d_groups" % g: v["samples"] for g, v in main_m["legs"].items()},
+                   # host time the enqueue loop needs per step of a leg (a leg is host-paced when this approaches ms_per_step)
+                   "host_enqueue_ms_per_step": {"%d_groups" % g: v["enq_ms"] for g, v in main_m["legs"].items()},
                    "concurrent_hw_queues_found": conc, "parallelism": "env-sharded x%d" % world,
-                   "one_launch_per_step_value": taken_1_all / wall_1, "one_launch_per_step_ms": wall_1 / a.steps * 1e3,
-                   "same_call_reset_value": taken_same_all / wall_same, "same_call_reset_ms_per_step": wall_same / a.steps * 1e3,
-                   "returns_allgather_ms": gather_ms},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic * n_launch / 4096.0 if traffic is not None else None,
+                   "one_launch_per_step_value": one["median"] if one else None,
+                   "one_launch_per_step_ms": one["wall"] / K * 1e3 if one else None,
+                   "same_call_reset_value": same_m["legs"][1]["median"],
+                   "same_call_reset_ms_per_step": same_m["legs"][1]["wall"] / K * 1e3,
+                   "per_rank": ([{"rank": r_, "wall_ms": pr[0] * 1e3, "env_steps": pr[2], "value": pr[2] / pr[0]}
+                                 for r_, pr in enumerate(hl["per_rank"])] if hl["per_rank"] else None),
+                   "returns_allgather": gather,
+                   "other_configs": other},
+        "roofline": {"bound": "hbm", "achieved": achieved_d4, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     # priced with SURVEY 8(d) D4's per-env-step figure (float32 state), the contract's definition
+                     "frac": achieved_d4 / HBM_PEAK_GBS, "bytes_per_env_step": D4,
+                     # the same speed priced with the bytes this build's float64 state layout really has to move
+                     "achieved_f64_layout": achieved, "frac_f64_layout": achieved / HBM_PEAK_GBS, "bytes_per_env_step_f64_layout": B,
+                     "traffic": traffic_b,
                      "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE+WRITE_SIZE, calibrated; profiles/)",
-                     "algorithmic_bytes_per_launch": B * n_launch, "envs_per_launch": n_launch,
+                     "traffic_source": traffic_src,
+                     "algorithmic_bytes_per_launch": D4 * n_launch, "envs_per_launch": n_launch,
                      "concurrent_launches": G,
-                     "kernel": "cn_env_kernel", "kernel_ms": kernel_ms, "bytes_per_env_step": B,
-                     # the same speed priced with SURVEY 8(d) D4's 2400 B per env-step (float32 state), so that the HBM
-                     # fraction stays comparable across rounds whatever the state dtype is
-                     "frac_d4": G * D4_BYTES_PER_ENV_STEP * n_launch / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "kernel": "cn_env_kernel", "kernel_ms": kernel_ms,
                      # what actually binds: instruction issue (float64 VALU) and one wavefront's critical path, not HBM
                      "binding": "instruction issue (f64 VALU) above ~8k resident envs; one wavefront's critical path at 4096",
                      "issue_bound_env_steps_s": plateau,
                      "frac_of_issue_bound": (value / world / plateau) if plateau else None,
-                     # the hardware ceiling of the binding unit: every wave64 VALU instruction occupies its SIMD's vector pipe
-                     # for 4 cycles; 1024 SIMDs x 2.4 GHz (MI355X_MICROARCH.md) / (4 x measured VALU instructions per env-step)
-                     "valu_peak_env_steps_s": valu_peak,
-                     "frac_of_valu_peak": (value / world / valu_peak) if valu_peak else None,
                      "valu_busy": (counters or {}).get("valu_busy"),
                      "wave_instr_per_env_step": (counters or {}).get("wave_instr_per_env_step"),
-                     "counters_source": (counters or {}).get("source"),
+                     "counters_source": counters_src,
                      "note": "achieved = concurrent_launches x algorithmic bytes per launch / mean launch duration on "
-                             "its own stream (HIP events per group stream)",
-                     "one_launch_per_step": {"envs_per_launch": N, "kernel_ms": kernel_ms_1, "achieved": achieved_1,
-                                             "frac": achieved_1 / HBM_PEAK_GBS}},
+                             "its own stream (HIP events per group stream, the headline's median sample)",
+                     "one_launch_per_step": ({"envs_per_launch": N, "kernel_ms": one["kernel_ms"],
+                                              "achieved": D4 * N / (one["kernel_ms"] * 1e-3) / 1e9,
+                                              "frac": D4 * N / (one["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS} if one else None)},
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         from oracle import oracle
@@ -420,7 +480,7 @@ def main():
             orc.step(acts_c[0], auto_reset=True)
             tc0 = time.perf_counter(); k = 0
             while time.perf_counter() - tc0 < seconds:
-                orc.step(acts_c[k % n_act], auto_reset=True); k += 1
+                orc.step(acts_c[k % N_ACT], auto_reset=True); k += 1
             tc = time.perf_counter() - tc0
             return n_s * k / tc, k, tc
 
@@ -432,7 +492,11 @@ def main():
                                "sample": "oracle/cn_oracle.c (plain-C port of the reference path) on the same "
                                          "workload: %d envs x %d steps on 1 thread (%.1f s) and %d envs x %d steps "
                                          "with OpenMP over envs on %d threads (%.1f s)" % (256, k1, t1c, n_all, kall,
-                                                                                           ncpu, tallc)}
+                                                                                           ncpu, tallc),
+                               # the reference's own Python (environment_stage_1_nobonus.py under oracle/harness, sleeps
+                               # virtualised) cannot travel to the GPU box; BASELINE.md's figure, measured in the container
+                               "reference_python": {"value": 102.0, "unit": "env-steps/s", "cores": 1, "where": "container",
+                                                    "source": "BASELINE.md"}}
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -9,6 +9,7 @@ PyTorch is used only for device memory and streams.
 """
 import contextlib
 import ctypes as C
+import time
 
 import numpy as np
 import torch
@@ -457,11 +458,14 @@ class VecEnvGroups:
 class Env:
     """Drop-in for the reference's `Env` (ENV:42): same constructor, methods, return types."""
 
-    def __init__(self, action_dim=2, max_step=200, cfg=None, device=0, **kw):
+    def __init__(self, action_dim=2, max_step=200, cfg=None, device=0, linear_forward_speed=0.5, linear_turn_speed=0.05,
+                 angular_speed=0.3, **kw):
         if cfg is None:
             cfg = Config(n_envs=1, max_steps=max_step, **kw)
         assert cfg.n_envs == 1
         self.action_dim = action_dim
+        # configs/turtlebot3_world.yaml:2-4 (ENV:85-87): the three discrete actions of mode="discrete"
+        self.linear_forward_speed, self.linear_turn_speed, self.angular_speed = linear_forward_speed, linear_turn_speed, angular_speed
         self.max_steps = cfg.max_steps
         self.k_obstacle_count = cfg.k_obstacles
         self._v = VecEnv(cfg, device=device)
@@ -477,11 +481,17 @@ class Env:
         self._ext_odom = None
         return self._v.obs_f64[0].cpu().numpy()
 
-    def step(self, action, step_counter, mode="continuous"):
-        """Env.step (ENV:1164-1225).  The reference's default is mode="discrete" (the DQN / Q-learning trainers, out of
-        scope); every trainer on this path passes "continuous" (TRAIN:125), which is the default here."""
-        if mode != "continuous":
-            raise NotImplementedError("only mode='continuous' (the TD3/DDPG/SAC path, ENV:1178-1188) is implemented")
+    def step(self, action, step_counter, mode="discrete"):
+        """Env.step (ENV:1164-1225), same default mode as the reference.  mode="discrete" (ENV:1165-1177, the DQN /
+        Q-learning trainers): action 0 / 1 / 2 = forward / turn left / turn right with the speeds of
+        configs/turtlebot3_world.yaml:2-4; anything else is the continuous (v, w) pair every trainer on this path
+        passes (TRAIN:125)."""
+        if mode == "discrete":
+            a = int(action)
+            if a not in (0, 1, 2):      # the reference leaves linear_speed unbound here (UnboundLocalError)
+                raise ValueError("discrete action must be 0 (forward), 1 (left) or 2 (right)")
+            action = ((self.linear_forward_speed, 0.0), (self.linear_turn_speed, self.angular_speed),
+                      (self.linear_turn_speed, -1 * self.angular_speed))[a]
         self._act[0, 0] = float(action[0]); self._act[0, 1] = float(action[1])
         self._v.step(self._act, step_counter=[int(step_counter)], auto_reset=False)
         torch.cuda.synchronize(self._v.device)
@@ -491,7 +501,8 @@ class Env:
 
     # ---- the two halves of Env.step, callable on their own like the reference's (ENV:1222-1223) -------------
     def odom_callback(self, x, y, yaw, linear_x, angular_z, now=None):
-        """What the /odom subscriber stores (ENV:239-243) plus the wall clock get_state will read (time.time()).
+        """What the /odom subscriber stores (ENV:239-243) plus the clock get_state will read: `now`, or -- as the
+        reference does (ENV:666, 710 call time.time()) -- the wall clock at the moment get_state runs.
         Until the next step()/reset(), get_state / compute_reward use THIS pose instead of the library simulator's."""
         self._ext_odom = [float(x), float(y), float(yaw), float(linear_x), float(angular_z),
                           float(now) if now is not None else None]
@@ -509,8 +520,9 @@ class Env:
         ext = getattr(self, "_ext_odom", None)
         if ext is not None:
             od[:5] = ext[:5]
-            if ext[5] is not None:
-                od[5] = ext[5]
+            # no explicit clock: the wall clock, read now.  (The simulator's own clock only advances inside cn_step; an
+            # external flow that kept reading it would hand the tracker dt = 0: infinite speeds, CN_ST_DT_ZERO.)
+            od[5] = ext[5] if ext[5] is not None else time.time()
         return od
 
     def get_state(self, scan, step_counter=0, action=(0, 0)):
@@ -523,8 +535,16 @@ class Env:
         self.done = bool(self._v.done[0].item())
         return list(self._v.obs_f64[0].cpu().numpy()), self.done
 
-    def compute_reward(self, state, step_counter, done):
-        """Env.compute_reward(state, step_counter, done) -> (reward, done) (ENV:1046-1162)."""
+    def compute_reward(self, state, *args):
+        """Env.compute_reward(state, step_counter, done) -> (reward, done) (ENV:1046-1162).  The other two layouts'
+        scripts take (state, done) (ORIG:324, RW:751); both spellings are accepted for them."""
+        if len(args) == 2:
+            step_counter, done = args
+        elif len(args) == 1 and self._v.cfg.obs_layout in (1, 2):
+            step_counter, done = 0, args[0]
+        else:
+            raise TypeError("compute_reward(state, step_counter, done)" +
+                            (" or compute_reward(state, done)" if self._v.cfg.obs_layout in (1, 2) else ""))
         self._v.obs_f64[0].copy_(torch.as_tensor(np.asarray(state, dtype=np.float64)))
         self._v.done[0] = int(bool(done))
         self._v.observe_external(np.zeros((1, self._v.R)), [self._odom()], step_counter=[int(step_counter)],

@@ -222,6 +222,96 @@ def test_config4_two_ranks_with_the_real_kernel():
     assert np.array_equal(allobs, env.obs.cpu().numpy())
 
 
+def test_config4_full_workload_16384_envs_as_8_shards(oracle_mod):
+    """BASELINE configs[3] at ITS workload on one GPU: 16384 envs x 20 pedestrians x 360 rays as the 8 shards the 8 ranks
+    would own (8 handles x 2048 envs, env_index_base = 2048 r, each on its own stream), every env every step against the
+    oracle (one 16384-env oracle, OpenMP over envs) and against ONE 16384-env handle, in both reset conventions; then the
+    host-side equivalent of the path's one exchange: the concatenated per-shard returns equal the single handle's."""
+    import torch
+    from crowdnav import Config
+    from crowdnav.env import VecEnv
+    N, S, STEPS = 16384, 8, 24
+    n = N // S
+    cfg = Config(n_envs=N, n_peds=20, n_rays=360, k_obstacles=8, max_steps=18, seed=4321, ped_cycle_ms=1400)
+    import dataclasses
+    shards = [VecEnv(dataclasses.replace(cfg, n_envs=n, env_index_base=r * n), stream=torch.cuda.Stream()) for r in range(S)]
+    one = VecEnv(cfg)
+    orc = oracle_mod.Oracle(cfg.as_dict())
+    oracle_mod.set_num_threads()
+    for e in shards:
+        e.reset()
+    one.reset()
+    torch.cuda.synchronize()
+    oc = orc.reset()
+    assert np.array_equal(torch.cat([e.obs for e in shards]).cpu().numpy(), oc.astype(np.float32))
+    assert np.array_equal(one.obs.cpu().numpy(), oc.astype(np.float32))
+    g = torch.Generator(device="cpu").manual_seed(17)
+    n_done = 0
+    for t in range(STEPS):
+        act = torch.stack([torch.rand(N, generator=g) * 0.22, torch.rand(N, generator=g) * 4 - 2], 1)
+        mode = "next" if t >= STEPS // 2 else "same"
+        ad = act.cuda()
+        torch.cuda.synchronize()
+        for r, e in enumerate(shards):
+            e.step(ad[r * n:(r + 1) * n], auto_reset=mode)
+        one.step(ad, auto_reset=mode)
+        torch.cuda.synchronize()
+        oc, rc, dc, ic = orc.step(act.numpy().astype(np.float64), auto_reset=mode)
+        dg = torch.cat([e.done for e in shards]).cpu().numpy()
+        assert np.array_equal(dg, dc), t                                                       # bit-exact
+        assert np.array_equal(torch.cat([e.topk_idx for e in shards]).cpu().numpy(), ic), t    # bit-exact
+        assert np.abs(torch.cat([e.reward for e in shards]).cpu().numpy() - rc).max() <= TOL, t
+        og = torch.cat([e.obs for e in shards])
+        assert np.array_equal(og.cpu().numpy(), oc.astype(np.float32)), t
+        assert torch.equal(og, one.obs) and torch.equal(torch.cat([e.done for e in shards]), one.done), t
+        n_done += int(dc.sum())
+    assert n_done > N // 2
+    rets = [e.returns()[0] for e in shards]          # each on its shard's stream
+    cnts = [e.counters() for e in shards]
+    torch.cuda.synchronize()
+    ret = torch.cat(rets)
+    assert torch.equal(ret, one.returns()[0])
+    assert np.abs(ret.cpu().numpy() - orc.returns()).max() <= 1e-3
+    assert np.array_equal(torch.cat(cnts).cpu().numpy()[:, :6], orc.counters())
+
+
+def test_bind_step_sequence_equals_step_by_step():
+    """VecEnvGroups.bind_step_sequence -- the path bench.py's timed region goes through (K steps x G groups behind ONE
+    cn_step_multi call, a C loop over the launches) -- leaves every env where K calls of VecEnv.step leave it: observations,
+    rewards, done flags, indices, counters, returns, and the snapshot of the whole state."""
+    import torch
+    from crowdnav import Config
+    from crowdnav.env import VecEnv, VecEnvGroups
+    cfg = Config(n_envs=256, seed=9, max_steps=25, ped_cycle_ms=1400)
+    Ksteps = 40
+    g = torch.Generator(device="cpu").manual_seed(3)
+    acts = torch.stack([torch.rand((16, 256), generator=g) * 0.22, torch.rand((16, 256), generator=g) * 4 - 2], 2).cuda().contiguous()
+    for G, mode in ((4, "next"), (2, "same"), (1, "next")):
+        full = VecEnv(cfg)
+        grp = VecEnvGroups(cfg, groups=G)
+        assert torch.equal(full.reset(), grp.reset())
+        seq = [acts[i % 16] for i in range(Ksteps)]
+        call = grp.bind_step_sequence(seq, auto_reset=mode)
+        torch.cuda.synchronize()
+        call()
+        grp.join()
+        for a_ in seq:
+            full.step(a_, auto_reset=mode)
+        torch.cuda.synchronize()
+        assert torch.equal(grp.obs, full.obs) and torch.equal(grp.reward, full.reward) and torch.equal(grp.done, full.done)
+        assert torch.equal(grp.topk_idx, full.topk_idx)
+        assert torch.equal(grp.counters(), full.counters())
+        assert torch.equal(grp.returns()[0], full.returns()[0])
+        assert int(full.counters()[:, 8].sum().item()) > 0                 # episodes really ended inside the sequence
+        # a second sequence call continues from there (the bench repeats its timed call)
+        call(); grp.join()
+        for a_ in seq:
+            full.step(a_, auto_reset=mode)
+        torch.cuda.synchronize()
+        assert torch.equal(grp.obs, full.obs) and torch.equal(grp.counters(), full.counters())
+        grp.close(); full.close()
+
+
 def test_bench_self_launches_two_ranks():
     """`python bench.py --gpus 2` with no launcher environment re-executes itself under torch.distributed.run and prints
     ONE JSON line with n_gpus = 2 and a measured all-gather (dry run: both ranks share cuda:0 over gloo, so the numbers
@@ -234,7 +324,7 @@ def test_bench_self_launches_two_ranks():
         env.pop(k, None)
     for extra, per_gpu, scaling in ((["--envs", "256"], 256, "weak"), (["--envs-total", "512"], 256, "strong")):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
-                            "--preroll", "5", "--groups", "2", "--no-cpu-baseline"] + extra,
+                            "--preroll", "5", "--groups", "2", "--repeats", "2", "--no-cpu-baseline"] + extra,
                            capture_output=True, text=True, timeout=900, env=env)
         assert r.returncode == 0, r.stderr[-3000:]
         lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -242,7 +332,10 @@ def test_bench_self_launches_two_ranks():
         out = json.loads(lines[0])
         assert out["n_gpus"] == 2 and out["scaling"] == scaling
         assert out["config"]["envs_per_gpu"] == per_gpu and out["config"]["envs_total"] == 2 * per_gpu
-        assert out["config"]["returns_allgather_ms"] is not None and out["value"] > 0
+        ga = out["config"]["returns_allgather"]
+        assert ga["ms"] is not None and ga["ranks_seen"] == 2 and ga["all_ranks_agree"] and out["value"] > 0
+        pr = out["config"]["per_rank"]
+        assert [p_["rank"] for p_ in pr] == [0, 1] and all(p_["value"] > 0 for p_ in pr)
 
 
 def test_td3_update_on_the_gpu_matches_reference_learn():

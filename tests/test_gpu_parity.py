@@ -411,6 +411,64 @@ def test_env_wrapper_has_reference_surface():
     env.shutdown()
 
 
+def test_env_wrapper_discrete_mode_and_wall_clock_default(oracle_mod):
+    """Env.step's default mode is the reference's "discrete" (ENV:1164-1177): actions 0 / 1 / 2 are the twists of
+    configs/turtlebot3_world.yaml:2-4, and the run equals the continuous one fed with those twists.  A purely external flow
+    (odom_callback without a clock, get_state twice) reads the wall clock like the reference's time.time(): the tracker sees
+    dt > 0, track speeds are finite and CN_ST_DT_ZERO is never raised."""
+    import time
+    from crowdnav import _abi
+    from crowdnav.env import Env
+    a, b = Env(action_dim=3, max_step=40, seed=11), Env(action_dim=3, max_step=40, seed=11)
+    assert np.array_equal(a.reset(), b.reset())
+    twist = {0: (0.5, 0.0), 1: (0.05, 0.3), 2: (0.05, -0.3)}
+    for step in range(12):
+        k = step % 3
+        oa, ra, da = a.step(k, step + 1)                       # mode defaults to "discrete"
+        ob, rb, db = b.step(twist[k], step + 1, mode="continuous")
+        assert np.array_equal(oa, ob) and ra == rb and da == db
+        if da:
+            break
+    with pytest.raises(ValueError):
+        a.step(3, 1)
+    # external flow without an explicit clock: a disc that moves between two scans gets a finite speed
+    env = Env(action_dim=2, max_step=100, n_peds=1, seed=3)
+    env.reset()
+    orc = oracle_mod.Oracle(dict(n_envs=1, n_peds=1))
+    speeds = []
+    for i in range(4):
+        orc.set_ped_init(np.array([[[0.62 - 0.01 * i, -1.0]]]))   # 0.38 m ahead of the robot (it faces -x), closing in
+        orc.hsim_reset(0)
+        scan = orc.hsim_scan(0)
+        env.odom_callback(1.0, -1.0, 3.14, 0.0, 0.0)              # now=None -> time.time()
+        env.append_agent_pose(1.0, -1.0, 0.15)
+        state, done = env.get_state(scan, i + 1)
+        d = env._v.debug_env(0)
+        assert not (d["status"] & 4), "CN_ST_DT_ZERO: get_state saw a zero time step"
+        speeds.extend(d["track_speed"].tolist())
+        time.sleep(0.002)
+    assert speeds and all(np.isfinite(s) for s in speeds) and any(s > 0 for s in speeds)
+
+
+def test_env_wrapper_compute_reward_signatures():
+    """ENV:1046 compute_reward(state, step_counter, done); ORIG:324 and RW:751 compute_reward(state, done)."""
+    from crowdnav.env import Env
+    for layout, dt in ((1, 150), (2, 50)):
+        env = Env(action_dim=2, max_step=50, obs_layout=layout, dt_ms=dt, seed=2)
+        env.reset()
+        s, r, d = env.step([0.1, 0.1], 1, mode="continuous")
+        snap = env._v.snapshot()
+        r2, d2 = env.compute_reward(list(s), False)
+        env._v.restore(snap)
+        r3, d3 = env.compute_reward(list(s), 2, False)
+        assert (r2, d2) == (r3, d3) and isinstance(r2, float) and isinstance(d2, bool)
+    env = Env(action_dim=2, max_step=50, seed=2)
+    env.reset()
+    s, r, d = env.step([0.1, 0.1], 1, mode="continuous")
+    with pytest.raises(TypeError):
+        env.compute_reward(list(s), False)
+
+
 def test_actor_in_the_loop_rollout_config3():
     """BASELINE config 3 shape at test size: a random-initialised 398->256->256->2 TD3 actor produces the
     actions on the device; the batched loop keeps TRAIN:104-168's bookkeeping per env."""
@@ -744,7 +802,7 @@ def test_realworld_layout_env_wrapper_surface():
     assert obs.shape == (370,) and obs.dtype == np.float64 and obs[363] == 3.14
     done = False
     for step in range(40):
-        obs, reward, done = env.step([0.15, 0.2], step + 1)
+        obs, reward, done = env.step([0.15, 0.2], step + 1, mode="continuous")
         if done:
             break
     assert done and obs.shape == (370,) and reward in (-202.0, -201.0, -200.0, 198.0, 199.0, 200.0)

@@ -8,11 +8,11 @@ REPO="$PWD"
 export TMPDIR=/tmp
 OUT="$REPO/gpurun_out/prof_$TAG"
 mkdir -p "$OUT"
-BENCH="python $REPO/bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-plateau $*"
+BENCH="python $REPO/bench.py --steps 300 --warmup 30 --repeats 3 --no-cpu-baseline --no-plateau --no-other-configs $*"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- $BENCH > "$OUT/bench_trace.log" 2>&1
 # the driver's own command (20 timed steps after 5 warm-up steps and the fixed 200-step pre-roll)
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_driver" -o trace -- python $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-plateau > "$OUT/bench_trace_driver.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_driver" -o trace -- python $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-plateau --no-other-configs > "$OUT/bench_trace_driver.log" 2>&1
 rocprofv3 --output-format csv --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -o pmc -- $BENCH > "$OUT/bench_pmc_fetch.log" 2>&1
 rocprofv3 --output-format csv --pmc WRITE_SIZE -d "$OUT/pmc_write" -o pmc -- $BENCH > "$OUT/bench_pmc_write.log" 2>&1
 rocprofv3 --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_ANY \

@@ -5,6 +5,9 @@ import glob
 import os
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from csrc_hash import csrc_hash   # stamps counters.json / traffic.json: bench.py only quotes a profile of THIS kernel
+
 
 def find(d, pat):
     r = glob.glob(os.path.join(d, "**", pat), recursive=True)
@@ -67,7 +70,8 @@ def main(d):
                                            "lds": sq.get("SQ_INSTS_LDS", 0) / n},
                "wave_quad_cycles_per_env_step": sq.get("SQ_WAVE_CYCLES", 0) / n,
                "wait_any_frac": sq.get("SQ_WAIT_ANY", 0) / max(1.0, sq.get("SQ_WAVE_CYCLES", 1)),
-               "launch_cycles": kcycles, "envs_per_launch": n,
+               "launch_cycles": kcycles, "envs_per_launch": n, "csrc_hash": csrc_hash(),
+               "lds_bank_conflict_frac": (sq["SQ_LDS_BANK_CONFLICT"] / sq["SQ_LDS_IDX_ACTIVE"]) if sq.get("SQ_LDS_IDX_ACTIVE") else None,
                "source": "rocprofv3 --pmc SQ_* pass of this bench command, full-grid (one launch per step) dispatches: valu_busy = "
                          "4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x SQ_BUSY_CYCLES / 32)"}
         json.dump(out, open(os.path.join(d, "counters.json"), "w"), indent=1)
@@ -111,7 +115,7 @@ def main(d):
             # the env kernel's reads are 8-byte lanes; its writes are ~60 % 4-byte (observation) and ~40 % 8-byte (state)
             wfac = 0.6 * wr4 + 0.4 * wr8
             out = {"fetch_kb": fsz, "write_kb": wsz, "fetch_factor_read8": fe, "write_factor_mix": wfac,
-                   "bytes_per_launch": fsz * 1024 * fe + wsz * 1024 * wfac,
+                   "bytes_per_launch": fsz * 1024 * fe + wsz * 1024 * wfac, "csrc_hash": csrc_hash(),
                    "note": "per cn_env_kernel launch of the full 4096-env grid (next-step-reset, one launch per step), "
                            "corrected with this box's calibration; a stream-group launch of n envs moves n/4096 of it"}
             json.dump(out, open(os.path.join(d, "traffic.json"), "w"), indent=1)
