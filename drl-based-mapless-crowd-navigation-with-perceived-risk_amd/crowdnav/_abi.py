@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_PKG, "lib", "libcrowdnav.so")
 BUILD_SH = os.path.join(_PKG, "csrc", "build.sh")
 
 CN_MAX_TRACKS = 64
-EXPECTED_ABI = 3       # the version the ctypes structs below were written against (include/crowdnav.h CN_ABI_VERSION)
+EXPECTED_ABI = 4       # the version the ctypes structs below were written against (include/crowdnav.h CN_ABI_VERSION)
 CN_PHASE_ALL, CN_PHASE_PRE, CN_PHASE_GET_STATE, CN_PHASE_REWARD = 0, 1, 2, 4
 CN_SD_COUNT = 24
 CN_SI_COUNT = 16
@@ -40,6 +40,54 @@ class CnExternalIO(C.Structure):
     _fields_ = [("ranges", C.c_void_p), ("odom", C.c_void_p), ("step_counter", C.c_void_p), ("obs", C.c_void_p),
                 ("obs_f64", C.c_void_p), ("reward", C.c_void_p), ("done", C.c_void_p), ("topk_idx", C.c_void_p),
                 ("is_reset", C.c_int32), ("phase", C.c_int32)]
+
+
+CN_SNAPSHOT_MAGIC = 0x50414E534E43        # "CNSNAP"
+
+
+class CnSnapshotHeader(C.Structure):
+    """Mirror of `cn_snapshot_header` (include/crowdnav.h): what a snapshot blob starts with."""
+    _fields_ = [("magic", C.c_uint64), ("abi_version", C.c_int32), ("header_bytes", C.c_int32),
+                ("sd_count", C.c_int32), ("si_count", C.c_int32), ("tf_count", C.c_int32), ("track_capacity", C.c_int32),
+                ("total_bytes", C.c_uint64), ("config", CnConfig)]
+
+
+def split_snapshot(buf):
+    """A cn_snapshot blob (uint8 array) -> (header, dict of arrays): sd [N,24] f64, si [N,16] i32, ped_p / ped_v [N,P,2],
+    trk [N,cap,12], ped_init / ped_preset [N,P,2], ped_aux [N,P,3].  Views into `buf`."""
+    import numpy as np
+    buf = np.ascontiguousarray(buf, dtype=np.uint8)
+    hd = CnSnapshotHeader.from_buffer_copy(buf[:C.sizeof(CnSnapshotHeader)].tobytes())
+    if hd.magic != CN_SNAPSHOT_MAGIC or hd.header_bytes != C.sizeof(CnSnapshotHeader):
+        raise CrowdNavError("not a libcrowdnav snapshot (magic / header size)")
+    N, P, cap = hd.config.n_envs, hd.config.n_peds, hd.track_capacity
+    off = [hd.header_bytes]
+
+    def take(shape, dtype):
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        a = buf[off[0]:off[0] + n].view(dtype).reshape(shape)
+        off[0] += n
+        return a
+    out = dict(sd=take((N, hd.sd_count), np.float64), si=take((N, hd.si_count), np.int32), ped_p=take((N, P, 2), np.float64),
+               ped_v=take((N, P, 2), np.float64), trk=take((N, cap, hd.tf_count), np.float64), ped_init=take((N, P, 2), np.float64),
+               ped_preset=take((N, P, 2), np.float64), ped_aux=take((N, P, 3), np.float64))
+    if off[0] != hd.total_bytes or off[0] > buf.size:
+        raise CrowdNavError("truncated snapshot: %d bytes, header says %d" % (buf.size, hd.total_bytes))
+    return hd, out
+
+
+def join_snapshot(hd, arrays):
+    """Inverse of split_snapshot: header + arrays -> blob for cn_restore."""
+    import numpy as np
+    parts = [np.frombuffer(bytes(hd), dtype=np.uint8)]
+    for k, dt in (("sd", np.float64), ("si", np.int32), ("ped_p", np.float64), ("ped_v", np.float64), ("trk", np.float64),
+                  ("ped_init", np.float64), ("ped_preset", np.float64), ("ped_aux", np.float64)):
+        parts.append(np.ascontiguousarray(arrays[k], dtype=dt).reshape(-1).view(np.uint8))
+    return np.concatenate(parts)
+
+
+def config_to_dict(c):
+    return {name: getattr(c, name) for name, _ in CnConfig._fields_}
 
 
 class CnActorWeights(C.Structure):

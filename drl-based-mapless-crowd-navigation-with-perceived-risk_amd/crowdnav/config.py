@@ -12,6 +12,7 @@ class CnConfig(C.Structure):
         ("max_steps", C.c_int32), ("ped_mode", C.c_int32), ("dt_ms", C.c_int32), ("scan_latency_ms", C.c_int32),
         ("settle_ms", C.c_int32), ("ped_cycle_ms", C.c_int32), ("ped_stagger_ms", C.c_int32), ("track_capacity", C.c_int32),
         ("obs_layout", C.c_int32), ("geos_untyped_empty", C.c_int32), ("ped_contact", C.c_int32), ("risk_mode", C.c_int32),
+        ("py2_round", C.c_int32), ("reserved1", C.c_int32),
         ("env_index_base", C.c_int64), ("seed", C.c_uint64),
         ("room_half", C.c_double), ("ped_radius", C.c_double), ("ped_vmax", C.c_double),
         ("robot_clearance", C.c_double), ("lidar_min", C.c_double), ("lidar_max", C.c_double),
@@ -19,6 +20,8 @@ class CnConfig(C.Structure):
         ("min_scan_range", C.c_double), ("goal_x", C.c_double), ("goal_y", C.c_double),
         ("start_x", C.c_double), ("start_y", C.c_double), ("spawn_x", C.c_double), ("spawn_y", C.c_double),
         ("spawn_yaw", C.c_double), ("waypoint_radius", C.c_double), ("goal_eps", C.c_double),
+        ("sf_tau", C.c_double), ("sf_A", C.c_double), ("sf_B", C.c_double), ("sf_wall_A", C.c_double),
+        ("sf_wall_B", C.c_double), ("sf_goal_eps", C.c_double),
     ]
 
 
@@ -29,7 +32,7 @@ class Config:
     n_rays: int = 360              # XACRO:157
     k_obstacles: int = 8           # ENV:55 / TRAIN:50
     max_steps: int = 1000          # configs/td3.yaml nsteps
-    ped_mode: int = 0              # 0 random-velocity walkers (CROWD:98-126), 1 constant preset table
+    ped_mode: int = 0              # 0 random-velocity walkers (CROWD:98-126), 1 constant preset table, 2 social force (sf_* below)
     dt_ms: int = 150               # ENV:1201
     scan_latency_ms: int = 10      # virtual /scan wait
     settle_ms: int = 100           # TRAIN:114
@@ -41,6 +44,8 @@ class Config:
     geos_untyped_empty: int = 0    # 1: shapely <= 1.7 / GEOS <= 3.8 empty-result semantics at UTL:279,306 (the reference's platform)
     ped_contact: int = 0           # 1: frictionless rigid contact between pedestrians and with the robot (WORLD:86-145)
     risk_mode: int = 0             # 0: lidar segmentation + tracker (the reference); 1: "gt" -- simulator pedestrians
+    py2_round: int = 0             # 1: Python-2.7 round() -- exact ties away from zero, round(np.float64) = the builtin (the reference's platform)
+    reserved1: int = 0
     env_index_base: int = 0
     seed: int = 1234
     room_half: float = 1.40        # WORLD:926-1108
@@ -62,6 +67,12 @@ class Config:
     spawn_yaw: float = 3.14
     waypoint_radius: float = 0.3   # ENV:250
     goal_eps: float = 0.20         # ENV:1285
+    sf_tau: float = 0.5            # ped_mode 2: relaxation time (Helbing & Molnar 1995)
+    sf_A: float = 0.8              # pedestrian / robot repulsion strength, m/s^2
+    sf_B: float = 0.10             # ... and range, m
+    sf_wall_A: float = 1.0         # wall repulsion strength, m/s^2
+    sf_wall_B: float = 0.05        # ... and range, m
+    sf_goal_eps: float = 0.10      # goal reached within this distance -> next goal
 
     def resolved(self):
         d = asdict(self)

@@ -219,6 +219,31 @@ class VecEnv:
         buf = np.ascontiguousarray(buf, dtype=np.uint8)
         _abi.check(self.L.cn_restore(self.h, buf.ctypes.data, buf.size))
 
+    def save_snapshot(self, path):
+        """The whole state of this handle as an .npz: the header spelled out -- ABI version, every cn_config
+        field (env_index_base, seed, layout and mode switches), tracker capacity -- next to the SoA fields of
+        cn_snapshot (sd, si, ped_p, ped_v, trk, ped_init, ped_preset, ped_aux) and the raw blob.  load_snapshot() restores
+        it (cn_restore refuses a header that does not match this handle); the CPU oracle (test infrastructure) loads the
+        same file to continue a GPU run step by step (tools/bisect_divergence.py)."""
+        blob = self.snapshot()
+        hd, arrs = _abi.split_snapshot(blob)
+        cfgd = _abi.config_to_dict(hd.config)
+        np.savez_compressed(path, format=np.array("crowdnav-snapshot-1"), abi_version=np.int32(hd.abi_version),
+                            track_capacity=np.int32(hd.track_capacity),
+                            config_keys=np.array(list(cfgd.keys())), config_vals=np.array([float(v) for v in cfgd.values()]),
+                            config_seed=np.uint64(cfgd["seed"]), config_env_index_base=np.int64(cfgd["env_index_base"]),
+                            blob=blob, **{k: np.array(v) for k, v in arrs.items()})
+        return path
+
+    def load_snapshot(self, path):
+        """Restore a state written by save_snapshot.  The SoA arrays of the file are authoritative (they may have been
+        edited, e.g. by tools/bisect_divergence.py); the header must match this handle (ABI version and configuration)."""
+        z = np.load(path if str(path).endswith(".npz") else str(path) + ".npz")
+        if str(z["format"]) != "crowdnav-snapshot-1":
+            raise _abi.CrowdNavError("%s is not a crowdnav snapshot file" % path)
+        hd, _ = _abi.split_snapshot(z["blob"])
+        self.restore(_abi.join_snapshot(hd, {k: z[k] for k in ("sd", "si", "ped_p", "ped_v", "trk", "ped_init", "ped_preset", "ped_aux")}))
+
 
 def concurrent_streams(want, device=0, candidates=None):
     """`want` torch streams that really run concurrently with each other on `device`.

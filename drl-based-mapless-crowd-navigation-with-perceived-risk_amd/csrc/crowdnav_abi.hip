@@ -23,6 +23,10 @@ extern "C" __global__ void cn_env_kernel_ct(CnKParams p);
 extern "C" __global__ void cn_env_kernel_ct_same(CnKParams p);
 extern "C" __global__ void cn_env_kernel_gt_ct(CnKParams p);
 extern "C" __global__ void cn_env_kernel_gt_ct_same(CnKParams p);
+extern "C" __global__ void cn_env_kernel_sf(CnKParams p);
+extern "C" __global__ void cn_env_kernel_sf_same(CnKParams p);
+extern "C" __global__ void cn_env_kernel_gt_sf(CnKParams p);
+extern "C" __global__ void cn_env_kernel_gt_sf_same(CnKParams p);
 extern "C" __global__ void cn_env_kernel_rw(CnKParams p);
 extern "C" __global__ void cn_env_kernel_rw_same(CnKParams p);
 extern "C" __global__ void cn_env_kernel_rw_ext(CnKParams p);
@@ -45,6 +49,7 @@ struct cn_env_s {
     size_t lds;
     CnKParams kp;        // template with state/table pointers filled in
     double *d_lidar = nullptr, *d_poly = nullptr, *d_ped_init = nullptr, *d_ped_preset = nullptr, *d_trk = nullptr;
+    double* d_ped_aux = nullptr;      // [N, P, 3] ped_mode 2: goal x, goal y, goal counter
     char* d_state = nullptr;          // N per-env records (crowdnav_kernel.h: sd | si | ped_p | ped_v | pad), `stride` bytes apart
     size_t stride;
     std::vector<double> ped_init;
@@ -63,7 +68,7 @@ static void destroy_handle(cn_env_s* h)
     DeviceScope scope(h->device);
     (void)hipFree(h->d_lidar); (void)hipFree(h->d_poly); (void)hipFree(h->d_state);
     (void)hipFree(h->d_ped_init); (void)hipFree(h->d_ped_preset);
-    (void)hipFree(h->d_trk);
+    (void)hipFree(h->d_trk); (void)hipFree(h->d_ped_aux);
     delete h;
 }
 struct HandleDeleter { void operator()(cn_env_s* h) const { destroy_handle(h); } };
@@ -196,6 +201,19 @@ static int upload_initial_state(cn_env_s* h)
         HIPCHK(hipMemset(h->d_ped_preset, 0, (size_t)N * P * 16));
     }
     HIPCHK(hipMemset(h->d_trk, 0, (size_t)N * CN_TF_COUNT * h->trk_cap * 8));
+    {   // ped_mode 2: every pedestrian's first goal (goal 0 of its counter-based sequence); zeros otherwise
+        std::vector<double> aux((size_t)N * (P > 0 ? P : 1) * 3, 0.0);
+        if (c.ped_mode == 2) {
+            const double lo = -c.room_half + 0.1, span = 2.0 * c.room_half - 0.2;
+            for (int e = 0; e < N; ++e)
+                for (int i = 0; i < P; ++i) {
+                    double* a = &aux[((size_t)e * P + i) * 3];
+                    a[0] = fma(span, cn_rng_u01(c.seed, c.env_index_base + e, 3u, (uint32_t)i, 0u), lo);
+                    a[1] = fma(span, cn_rng_u01(c.seed, c.env_index_base + e, 3u, (uint32_t)i, 1u), lo);
+                }
+        }
+        HIPCHK(hipMemcpy(h->d_ped_aux, aux.data(), aux.size() * 8, hipMemcpyHostToDevice));
+    }
     return CN_OK;
 }
 
@@ -208,8 +226,13 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
         c.max_steps < 1 || !(c.track_capacity == 0 || c.track_capacity == 32 || c.track_capacity == 64) ||
         !(c.obs_layout == CN_LAYOUT_RISK || c.obs_layout == CN_LAYOUT_ORIGINAL || c.obs_layout == CN_LAYOUT_REALWORLD) ||
         !(c.geos_untyped_empty == 0 || c.geos_untyped_empty == 1) || !(c.ped_contact == 0 || c.ped_contact == 1) ||
-        !(c.risk_mode == CN_RISK_LIDAR_TRACKER || c.risk_mode == CN_RISK_GT))
+        !(c.risk_mode == CN_RISK_LIDAR_TRACKER || c.risk_mode == CN_RISK_GT) || !(c.py2_round == 0 || c.py2_round == 1) ||
+        c.ped_mode < 0 || c.ped_mode > 2)
         return fail(CN_ERR_CONFIG, "cn_create: config out of range");
+    if (c.ped_mode == 2 && (c.ped_contact || c.obs_layout != CN_LAYOUT_RISK || !(c.sf_tau > 0.0) || !(c.sf_B > 0.0) ||
+                            !(c.sf_wall_B > 0.0) || !(c.sf_goal_eps >= 0.0) || 64 * (size_t)c.n_peds > 16 * (size_t)(c.n_rays - 1)))
+        return fail(CN_ERR_CONFIG, "cn_create: ped_mode 2 (social force) needs obs_layout 0, ped_contact 0, positive sf_tau / sf_B / "
+                                   "sf_wall_B and n_peds <= (n_rays - 1) / 4");
     if (!(c.max_scan_range > c.min_scan_range))    // ENV:581, UTL:322 divide by their difference (ZeroDivisionError in the reference)
         return fail(CN_ERR_CONFIG, "cn_create: max_scan_range must exceed min_scan_range");
     if (c.obs_layout == CN_LAYOUT_REALWORLD && (c.n_rays - 1 > 65535 / 2))
@@ -260,6 +283,7 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
     HIPCHK(hipMalloc(&h->d_ped_init, pb));
     HIPCHK(hipMalloc(&h->d_ped_preset, pb));
     HIPCHK(hipMalloc(&h->d_trk, (size_t)N * CN_TF_COUNT * h->trk_cap * 8));
+    HIPCHK(hipMalloc(&h->d_ped_aux, (size_t)N * (P > 0 ? P : 1) * 24));
     h->ped_init.resize((size_t)N * P * 2);
     for (int e = 0; e < N; ++e) default_ped_init(c, e, &h->ped_init[(size_t)e * P * 2]);
     int rc = upload_initial_state(h);
@@ -270,7 +294,9 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
     k.N = N; k.P = P; k.R = R; k.K = K;
     k.max_steps = c.max_steps; k.ped_mode = c.ped_mode; k.dt_ms = c.dt_ms; k.scan_latency_ms = c.scan_latency_ms;
     k.settle_ms = c.settle_ms; k.ped_cycle_ms = c.ped_cycle_ms; k.ped_stagger_ms = c.ped_stagger_ms;
-    k.geos_untyped_empty = c.geos_untyped_empty; k.ped_contact = c.ped_contact; k.risk_mode = c.risk_mode;
+    k.geos_untyped_empty = c.geos_untyped_empty; k.ped_contact = c.ped_contact; k.risk_mode = c.risk_mode; k.py2_round = c.py2_round;
+    k.sf_tau = c.sf_tau; k.sf_A = c.sf_A; k.sf_B = c.sf_B; k.sf_wall_A = c.sf_wall_A; k.sf_wall_B = c.sf_wall_B;
+    k.sf_goal_eps2 = c.sf_goal_eps * c.sf_goal_eps;
     k.near_sep = cn_near_separate(R, P, K, h->max_conf, h->trk_cap);
     k.max_conf = h->max_conf; k.trk_cap = h->trk_cap; k.env_index_base = c.env_index_base; k.seed = c.seed;
     k.room_half = c.room_half; k.ped_radius = c.ped_radius; k.ped_vmax = c.ped_vmax; k.robot_clearance = c.robot_clearance;
@@ -283,7 +309,7 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
     k.blk_dir = h->d_lidar + 4 * (size_t)R; k.blk_cb = cos(32.5 * step); k.blk_sb = sin(32.5 * step);
     k.lidar_c = h->d_lidar; k.lidar_s = h->d_lidar + R; k.ang_s = h->d_lidar + 2 * R; k.ang_c = h->d_lidar + 3 * R; k.poly_c = h->d_poly; k.poly_s = h->d_poly + 64;
     k.state = h->d_state; k.state_stride = (int64_t)h->stride; k.ped_init = h->d_ped_init;
-    k.ped_preset = h->d_ped_preset; k.trk = h->d_trk;
+    k.ped_preset = h->d_ped_preset; k.trk = h->d_trk; k.ped_aux = h->d_ped_aux;
     {   // the reset path's bounding-box size at the spawn pose (a constant of the configuration), from the device's own arithmetic
         double* d_out = nullptr;
         HIPCHK(hipMalloc(&d_out, sizeof(double)));
@@ -306,6 +332,10 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
         HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_ct_same, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
         HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_gt_ct, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
         HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_gt_ct_same, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
+        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_sf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
+        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_sf_same, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
+        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_gt_sf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
+        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_gt_sf_same, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
         HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_gt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
         HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_gt_same, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
         HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_rw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
@@ -390,9 +420,11 @@ static int launch(cn_handle h, const CnKParams& kp, hipStream_t st)
     } else {
         // simulated sensors: {lidar tracker, gt} x {no contact, contact} x {one observation per launch, step + same-call reset}
         const bool same = kp.mode == CN_MODE_STEP && kp.auto_reset == 1;
-        const bool gt = h->cfg.risk_mode == CN_RISK_GT, ct = h->cfg.ped_contact != 0;
-        void (*fn)(CnKParams) = gt ? (ct ? (same ? cn_env_kernel_gt_ct_same : cn_env_kernel_gt_ct) : (same ? cn_env_kernel_gt_same : cn_env_kernel_gt))
-                                   : (ct ? (same ? cn_env_kernel_ct_same : cn_env_kernel_ct) : (same ? cn_env_kernel_same : cn_env_kernel));
+        const bool gt = h->cfg.risk_mode == CN_RISK_GT, ct = h->cfg.ped_contact != 0, sf = h->cfg.ped_mode == 2;
+        void (*fn)(CnKParams) = gt ? (sf ? (same ? cn_env_kernel_gt_sf_same : cn_env_kernel_gt_sf)
+                                         : ct ? (same ? cn_env_kernel_gt_ct_same : cn_env_kernel_gt_ct) : (same ? cn_env_kernel_gt_same : cn_env_kernel_gt))
+                                   : (sf ? (same ? cn_env_kernel_sf_same : cn_env_kernel_sf)
+                                         : ct ? (same ? cn_env_kernel_ct_same : cn_env_kernel_ct) : (same ? cn_env_kernel_same : cn_env_kernel));
         hipLaunchKernelGGL(fn, dim3(kp.N), dim3(64), h->lds, st, kp);
     }
     HIPCHK(hipGetLastError());
@@ -538,12 +570,25 @@ extern "C" int cn_debug_env(cn_handle h, int env, double* scalars, double* robot
     return CN_OK;
 }
 
-// snapshot layout: sd | si | ped_p | ped_v | trk
+// snapshot layout (include/crowdnav.h): cn_snapshot_header | sd | si | ped_p | ped_v | trk | ped_init | ped_preset | ped_aux
+static size_t snapshot_payload(cn_handle h)
+{
+    size_t N = h->cfg.n_envs, P = h->cfg.n_peds;
+    return N * (CN_SD_COUNT * 8 + CN_SI_COUNT * 4 + 2 * P * 16 + (size_t)CN_TF_COUNT * h->trk_cap * 8 + 2 * P * 16 + P * 24);
+}
 extern "C" size_t cn_snapshot_size(cn_handle h)
 {
     if (!h) return 0;
-    size_t N = h->cfg.n_envs, P = h->cfg.n_peds;
-    return N * (CN_SD_COUNT * 8 + CN_SI_COUNT * 4 + 2 * P * 16 + (size_t)CN_TF_COUNT * h->trk_cap * 8);
+    return sizeof(cn_snapshot_header) + snapshot_payload(h);
+}
+
+static void fill_header(cn_handle h, cn_snapshot_header* hd)
+{
+    memset(hd, 0, sizeof(*hd));
+    hd->magic = CN_SNAPSHOT_MAGIC; hd->abi_version = CN_ABI_VERSION; hd->header_bytes = (int32_t)sizeof(cn_snapshot_header);
+    hd->sd_count = CN_SD_COUNT; hd->si_count = CN_SI_COUNT; hd->tf_count = CN_TF_COUNT; hd->track_capacity = h->trk_cap;
+    hd->total_bytes = sizeof(cn_snapshot_header) + snapshot_payload(h);
+    hd->config = h->cfg;
 }
 
 extern "C" int cn_snapshot(cn_handle h, void* buf, size_t size)
@@ -554,30 +599,71 @@ extern "C" int cn_snapshot(cn_handle h, void* buf, size_t size)
     HIPCHK(hipDeviceSynchronize());
     size_t N = h->cfg.n_envs, P = h->cfg.n_peds;
     char* q = (char*)buf;
+    cn_snapshot_header hd;
+    fill_header(h, &hd);
+    memcpy(q, &hd, sizeof(hd)); q += sizeof(hd);
     FIELD(field_to_host(h, CN_ST_OFF_SD, q, CN_SD_COUNT * 8)); q += N * CN_SD_COUNT * 8;
     FIELD(field_to_host(h, CN_ST_OFF_SI, q, CN_SI_COUNT * 4)); q += N * CN_SI_COUNT * 4;
     if (P) {
         FIELD(field_to_host(h, CN_ST_OFF_PED_P, q, P * 16)); q += N * P * 16;
         FIELD(field_to_host(h, CN_ST_OFF_PED_V(P), q, P * 16)); q += N * P * 16;
     }
-    HIPCHK(hipMemcpy(q, h->d_trk, N * CN_TF_COUNT * h->trk_cap * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(q, h->d_trk, N * CN_TF_COUNT * h->trk_cap * 8, hipMemcpyDeviceToHost)); q += N * CN_TF_COUNT * h->trk_cap * 8;
+    if (P) {
+        HIPCHK(hipMemcpy(q, h->d_ped_init, N * P * 16, hipMemcpyDeviceToHost)); q += N * P * 16;
+        HIPCHK(hipMemcpy(q, h->d_ped_preset, N * P * 16, hipMemcpyDeviceToHost)); q += N * P * 16;
+        HIPCHK(hipMemcpy(q, h->d_ped_aux, N * P * 24, hipMemcpyDeviceToHost)); q += N * P * 24;
+    }
     return CN_OK;
+}
+
+// first field of the two configurations that differs (nullptr: identical)
+static const char* config_mismatch(const cn_config& a, const cn_config& b)
+{
+#define CN_CMP(f) if (memcmp(&a.f, &b.f, sizeof(a.f)) != 0) return #f;
+    CN_CMP(n_envs) CN_CMP(n_peds) CN_CMP(n_rays) CN_CMP(k_obstacles) CN_CMP(max_steps) CN_CMP(ped_mode) CN_CMP(dt_ms)
+    CN_CMP(scan_latency_ms) CN_CMP(settle_ms) CN_CMP(ped_cycle_ms) CN_CMP(ped_stagger_ms) CN_CMP(track_capacity) CN_CMP(obs_layout)
+    CN_CMP(geos_untyped_empty) CN_CMP(ped_contact) CN_CMP(risk_mode) CN_CMP(py2_round) CN_CMP(env_index_base) CN_CMP(seed)
+    CN_CMP(room_half) CN_CMP(ped_radius) CN_CMP(ped_vmax) CN_CMP(robot_clearance) CN_CMP(lidar_min) CN_CMP(lidar_max) CN_CMP(lidar_span)
+    CN_CMP(lidar_offset_x) CN_CMP(max_scan_range) CN_CMP(min_scan_range) CN_CMP(goal_x) CN_CMP(goal_y) CN_CMP(start_x) CN_CMP(start_y)
+    CN_CMP(spawn_x) CN_CMP(spawn_y) CN_CMP(spawn_yaw) CN_CMP(waypoint_radius) CN_CMP(goal_eps)
+    CN_CMP(sf_tau) CN_CMP(sf_A) CN_CMP(sf_B) CN_CMP(sf_wall_A) CN_CMP(sf_wall_B) CN_CMP(sf_goal_eps)
+#undef CN_CMP
+    return nullptr;
 }
 
 extern "C" int cn_restore(cn_handle h, const void* buf, size_t size)
 {
     if (!h || !buf) return fail(CN_ERR_ARG, "cn_restore: null argument");
-    if (size < cn_snapshot_size(h)) return fail(CN_ERR_SIZE, "cn_restore: buffer too small");
+    if (size < sizeof(cn_snapshot_header)) return fail(CN_ERR_SIZE, "cn_restore: buffer smaller than a snapshot header");
+    cn_snapshot_header hd;
+    memcpy(&hd, buf, sizeof(hd));
+    if (hd.magic != CN_SNAPSHOT_MAGIC) return fail(CN_ERR_ARG, "cn_restore: not a libcrowdnav snapshot (bad magic)");
+    if (hd.abi_version != CN_ABI_VERSION || hd.header_bytes != (int32_t)sizeof(cn_snapshot_header))
+        return fail(CN_ERR_CONFIG, "cn_restore: snapshot written by ABI version " + std::to_string(hd.abi_version) +
+                                   ", this library is ABI " + std::to_string(CN_ABI_VERSION));
+    if (hd.sd_count != CN_SD_COUNT || hd.si_count != CN_SI_COUNT || hd.tf_count != CN_TF_COUNT || hd.track_capacity != h->trk_cap)
+        return fail(CN_ERR_CONFIG, "cn_restore: snapshot record layout (sd / si / track fields, tracker slots) differs from this handle's");
+    if (const char* f = config_mismatch(hd.config, h->cfg))
+        return fail(CN_ERR_CONFIG, std::string("cn_restore: the snapshot was taken under another configuration: cn_config.") + f +
+                                   " differs (a state only means something under the configuration that produced it)");
+    if (hd.total_bytes != cn_snapshot_size(h) || size < hd.total_bytes) return fail(CN_ERR_SIZE, "cn_restore: truncated snapshot");
     DeviceScope scope(h->device);
     HIPCHK(hipDeviceSynchronize());
     size_t N = h->cfg.n_envs, P = h->cfg.n_peds;
-    const char* q = (const char*)buf;
+    const char* q = (const char*)buf + sizeof(hd);
     FIELD(field_to_device(h, CN_ST_OFF_SD, q, CN_SD_COUNT * 8)); q += N * CN_SD_COUNT * 8;
     FIELD(field_to_device(h, CN_ST_OFF_SI, q, CN_SI_COUNT * 4)); q += N * CN_SI_COUNT * 4;
     if (P) {
         FIELD(field_to_device(h, CN_ST_OFF_PED_P, q, P * 16)); q += N * P * 16;
         FIELD(field_to_device(h, CN_ST_OFF_PED_V(P), q, P * 16)); q += N * P * 16;
     }
-    HIPCHK(hipMemcpy(h->d_trk, q, N * CN_TF_COUNT * h->trk_cap * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_trk, q, N * CN_TF_COUNT * h->trk_cap * 8, hipMemcpyHostToDevice)); q += N * CN_TF_COUNT * h->trk_cap * 8;
+    if (P) {
+        h->ped_init.assign((const double*)q, (const double*)q + N * P * 2);
+        HIPCHK(hipMemcpy(h->d_ped_init, q, N * P * 16, hipMemcpyHostToDevice)); q += N * P * 16;
+        HIPCHK(hipMemcpy(h->d_ped_preset, q, N * P * 16, hipMemcpyHostToDevice)); q += N * P * 16;
+        HIPCHK(hipMemcpy(h->d_ped_aux, q, N * P * 24, hipMemcpyHostToDevice)); q += N * P * 24;
+    }
     return CN_OK;
 }

@@ -11,9 +11,14 @@
 #define CN_PI 3.14159265358979323846
 
 // ---- Python / numpy rounding -------------------------------------------------------------
-// Python-3 round(x, nd): correctly rounded decimal (ties-to-even on the exact binary value).
+// cn_config.py2_round, read IN PLACE from the kernel-argument block and only inside the (rare) exact-tie branch: the flag costs
+// the common path nothing.  0: Python-3 round() (ties-to-even on the exact binary value); 1: Python-2.7 round() (floatobject.c
+// _Py_double_round: correctly rounded, an exact tie goes away from zero).
+typedef const __attribute__((address_space(4))) int32_t* cn_kflag;
+
+// Python round(x, nd) scaled by p = 10^nd, i.e. its integral part: round(x, 3) == cn_div1000(cn_round_scaled(x, 1000, py2)).
 // x*p = y + err exactly (fma); rint(y) can only be misled when y is exactly a half-integer.
-__device__ __forceinline__ double cn_py_round(double x, double p)
+__device__ __forceinline__ double cn_round_scaled(double x, double p, cn_kflag py2)
 {
     double y = x * p;
     double r = rint(y);
@@ -22,10 +27,12 @@ __device__ __forceinline__ double cn_py_round(double x, double p)
         double err = fma(x, p, -y);
         if (err > 0.0) r = y + 0.5;
         else if (err < 0.0) r = y - 0.5;
+        else if (*py2) r = y + copysign(0.5, y);     // exact tie under Python 2.7: half away from zero
     }
-    return r / p;
+    return r;
 }
-// numpy around / round(np.float64, nd): multiply, rint, divide (ENV:255, ENV:1042)
+__device__ __forceinline__ double cn_py_round(double x, double p, cn_kflag py2) { return cn_round_scaled(x, p, py2) / p; }
+// numpy around / round(np.float64, nd) under Python 3: multiply, rint, divide (ENV:255, ENV:1042)
 __device__ __forceinline__ double cn_np_around(double x, double p) { return rint(x * p) / p; }
 
 // ---- exact division by 1000 / 100 without the divide sequence ------------------------------------
@@ -44,27 +51,14 @@ __device__ __forceinline__ double cn_div100(double r)
     double q = r * CN_INV100;
     return fma(fma(-q, 100.0, r), CN_INV100, q);
 }
-// the integral part of Python round(x, 3): round(x, 3) == cn_div1000(cn_round3_mil(x)) bit for bit
-__device__ __forceinline__ double cn_round_scaled(double x, double p)
+__device__ __forceinline__ double cn_py_round3(double x, cn_kflag py2)
 {
-    double y = x * p;
-    double r = rint(y);
-    double d = y - r;
-    if (fabs(d) == 0.5) {
-        double err = fma(x, p, -y);
-        if (err > 0.0) r = y + 0.5;
-        else if (err < 0.0) r = y - 0.5;
-    }
-    return r;
-}
-__device__ __forceinline__ double cn_py_round3(double x)
-{
-    double r = cn_round_scaled(x, 1000.0);
+    double r = cn_round_scaled(x, 1000.0, py2);
     return (fabs(r) < 2147483648.0) ? cn_div1000(r) : r / 1000.0;
 }
-__device__ __forceinline__ double cn_py_round2(double x)
+__device__ __forceinline__ double cn_py_round2(double x, cn_kflag py2)
 {
-    double r = cn_round_scaled(x, 100.0);
+    double r = cn_round_scaled(x, 100.0, py2);
     return (fabs(r) < 2147483648.0) ? cn_div100(r) : r / 100.0;
 }
 __device__ __forceinline__ double cn_np_around3(double x)
@@ -75,9 +69,9 @@ __device__ __forceinline__ double cn_np_around3(double x)
 // The same roundings for values a simulated run bounds far below 2^31 thousandths (coordinates, ranges, velocities of a room
 // of a few metres): without the range test and the generic-divide branch behind it (compare + exec save/restore + two
 // branches per use).  External data (odometry, scans) keeps the guarded forms.
-template <bool SMALL> __device__ __forceinline__ double cn_py_round3_t(double x)
+template <bool SMALL> __device__ __forceinline__ double cn_py_round3_t(double x, cn_kflag py2)
 {
-    if constexpr (SMALL) return cn_div1000(cn_round_scaled(x, 1000.0)); else return cn_py_round3(x);
+    if constexpr (SMALL) return cn_div1000(cn_round_scaled(x, 1000.0, py2)); else return cn_py_round3(x, py2);
 }
 template <bool SMALL> __device__ __forceinline__ double cn_np_around3_t(double x)
 {
@@ -88,13 +82,22 @@ __device__ __forceinline__ double cn_np_around2(double x)
     double r = rint(x * 100.0);
     return (fabs(r) < 2147483648.0) ? cn_div100(r) : r / 100.0;
 }
-template <bool SMALL> __device__ __forceinline__ double cn_py_round2_t(double x)
+template <bool SMALL> __device__ __forceinline__ double cn_py_round2_t(double x, cn_kflag py2)
 {
-    if constexpr (SMALL) return cn_div100(cn_round_scaled(x, 100.0)); else return cn_py_round2(x);
+    if constexpr (SMALL) return cn_div100(cn_round_scaled(x, 100.0, py2)); else return cn_py_round2(x, py2);
 }
 template <bool SMALL> __device__ __forceinline__ double cn_np_around2_t(double x)
 {
     if constexpr (SMALL) return cn_div100(rint(x * 100.0)); else return cn_np_around2(x);
+}
+// round(np.float64, 2) (ENV:255, ORIG:280, RW:209): numpy's multiply / rint / divide under Python 3; under Python 2.7 the builtin
+// takes the value as a C double and rounds it like any float.  The two only differ when x * 100 lands exactly on a half-integer.
+template <bool SMALL> __device__ __forceinline__ double cn_round_np64_2_t(double x, cn_kflag py2)
+{
+    const double y = x * 100.0;
+    double r = rint(y);
+    if (fabs(y - r) == 0.5 && *py2) r = cn_round_scaled(x, 100.0, py2);
+    if constexpr (SMALL) return cn_div100(r); else return (fabs(r) < 2147483648.0) ? cn_div100(r) : r / 100.0;
 }
 
 // ---- deterministic sin/cos ----------------------------------------------------------------
@@ -136,6 +139,36 @@ __host__ __device__ inline void cn_det_sincos(double x, double* sn, double* cs)
     case 2: *sn = -s; *cs = -c; break;
     default: *sn = -c; *cs = s; break;
     }
+}
+
+// Deterministic exp (ped_mode 2, the social-force repulsions): Cody-Waite reduction by ln 2, degree-13 Taylor polynomial on
+// |r| <= ln2 / 2, 2^k through the exponent field -- only + * fma rint, the same sequence as the CPU oracle's, so the same bits.
+// |x| <= 700 (callers pass arguments in [-12, ~2]).
+__host__ __device__ inline double cn_det_exp(double x)
+{
+    const double LOG2E = 1.44269504088896338700e+00, LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
+    if (x < -700.0) return 0.0;
+    if (x > 700.0) return INFINITY;
+    const double kf = rint(x * LOG2E);
+    double r = fma(-kf, LN2_HI, x);
+    r = fma(-kf, LN2_LO, r);
+    double q = 1.0 / 6227020800.0;
+    q = fma(q, r, 1.0 / 479001600.0);
+    q = fma(q, r, 1.0 / 39916800.0);
+    q = fma(q, r, 1.0 / 3628800.0);
+    q = fma(q, r, 1.0 / 362880.0);
+    q = fma(q, r, 1.0 / 40320.0);
+    q = fma(q, r, 1.0 / 5040.0);
+    q = fma(q, r, 1.0 / 720.0);
+    q = fma(q, r, 1.0 / 120.0);
+    q = fma(q, r, 1.0 / 24.0);
+    q = fma(q, r, 1.0 / 6.0);
+    q = fma(q, r, 0.5);
+    q = fma(q, r, 1.0);
+    q = fma(q, r, 1.0);
+    union { unsigned long long u; double d; } sc;
+    sc.u = (unsigned long long)((long long)kf + 1023) << 52;
+    return q * sc.d;
 }
 
 // The same evaluation with its 16 constants read from a table in the constant address space (the kernel argument block).
@@ -322,7 +355,7 @@ __host__ __device__ inline double cn_rng_u01(uint64_t seed, int64_t env, uint32_
 __host__ __device__ inline double cn_clamp(double x, double lo, double hi) { return fmin(fmax(x, lo), hi); }
 
 // ---- UTL:422-460 IoU of two axis-aligned squares, rounded to 3 decimals ---------------------
-__device__ __forceinline__ double cn_iou3(double ax, double ay, double bx, double by, double half)
+__device__ __forceinline__ double cn_iou3(double ax, double ay, double bx, double by, double half, cn_kflag py2)
 {
     double axp = ax + half, axm = ax - half, ayp = ay + half, aym = ay - half;
     double bxp = bx + half, bxm = bx - half, byp = by + half, bym = by - half;
@@ -333,13 +366,13 @@ __device__ __forceinline__ double cn_iou3(double ax, double ay, double bx, doubl
     double area_a = (axp - axm) * (ayp - aym);
     double area_b = (bxp - bxm) * (byp - bym);
     double uni = area_a + area_b - inter;
-    return cn_py_round3(inter / uni);
+    return cn_py_round3(inter / uni, py2);
 }
 
 // round(IoU, 3) > 0 without the divide in the common cases.  The boxes either do not overlap (IoU = 0) or overlap
 // well: inter > 0.00075 * union means the quotient exceeds 0.00075 (1 - 2^-52), which rounds to >= 0.001.  Only the
 // sliver in between takes the exact path, so the result equals cn_iou3(...) > 0.0 always.
-__device__ __forceinline__ bool cn_iou3_positive(double ax, double ay, double bx, double by, double half)
+__device__ __forceinline__ bool cn_iou3_positive(double ax, double ay, double bx, double by, double half, cn_kflag py2)
 {
     double axp = ax + half, axm = ax - half, ayp = ay + half, aym = ay - half;
     double bxp = bx + half, bxm = bx - half, byp = by + half, bym = by - half;
@@ -351,7 +384,7 @@ __device__ __forceinline__ bool cn_iou3_positive(double ax, double ay, double bx
     double area_b = (bxp - bxm) * (byp - bym);
     double uni = area_a + area_b - inter;
     if (inter > 0.00075 * uni) return true;
-    return cn_py_round3(inter / uni) > 0.0;
+    return cn_py_round3(inter / uni, py2) > 0.0;
 }
 
 // ---- wave64 helpers ---------------------------------------------------------------------------

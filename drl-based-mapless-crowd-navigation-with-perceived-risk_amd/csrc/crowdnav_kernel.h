@@ -15,7 +15,7 @@ struct CnKParams {
     int32_t near_sep;        // near-pedestrian list: 1 = own LDS region, 0 = overlaid on region B (cn_near_separate)
     int32_t ablate;          // PROFILING BUILD ONLY (cn_debug_set_ablate): skips stages, results are then invalid
     int32_t ext_phase;       // cn_external_io.phase (CN_PHASE_* mask, 0 = whole flow); CN_MODE_EXT_STEP only
-    int32_t geos_untyped_empty, ped_contact, risk_mode;   // cn_config switches
+    int32_t geos_untyped_empty, ped_contact, risk_mode, py2_round;   // cn_config switches
     int64_t env_index_base;
     uint64_t seed;
     // constants (cn_config)
@@ -23,6 +23,7 @@ struct CnKParams {
     double max_scan_range, min_scan_range, goal_x, goal_y, start_x, start_y, spawn_x, spawn_y, spawn_yaw;
     double waypoint_radius, goal_eps, angle_inc_deg, lidar_step;
     double ped_inv_cycle;    // 1.0 / ped_cycle_ms
+    double sf_tau, sf_A, sf_B, sf_wall_A, sf_wall_B, sf_goal_eps2;   // ped_mode 2 (social force): cn_config.sf_*, goal radius squared
     double blk_cb, blk_sb;   // cos / sin of the half-width (32.5 lidar steps) of a 64-ray block (near-pedestrian block bits)
     const double* blk_dir;   // [ceil(R/64)][2] robot-frame direction of ray 64 q + 32 (clamped to R - 1)
     double trig[34];         // constants of cn_det_sincos_t / cn_atan2_t (CN_TRIG_TABLE): scalar loads next to the polynomials
@@ -48,6 +49,7 @@ struct CnKParams {
     const double* ped_init; // [N, P, 2]
     const double* ped_preset; // [N, P, 2]
     double* trk;            // [N, trk_cap, CN_TF_COUNT]: one contiguous 96-byte record per track slot
+    double* ped_aux;        // [N, P, 3] ped_mode 2: goal x, goal y, goal counter of every pedestrian
     // caller-owned I/O (device)
     const float* action;
     const int32_t* step_counter;

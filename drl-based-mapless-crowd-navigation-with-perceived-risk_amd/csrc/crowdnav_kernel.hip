@@ -44,6 +44,7 @@ namespace {
 // entry and, with 106 SGPRs per wave, spills most of it into VGPR lanes -- 1037 v_readlane reloads, a sixth of the kernel's
 // VALU instructions and a third of the ray loop.  Read in place they are scalar loads next to their uses.
 typedef const __attribute__((address_space(4))) CnKParams* KP;
+#define PY2 (&p->py2_round)      /* cn_config.py2_round, dereferenced only inside a rounding's exact-tie branch (crowdnav_device.h) */
 
 struct EnvRegs {  // per-env scalars, uniform across the wave
     double rx, ry, ryaw, rv, rw, clock, wpx, wpy, prev_dist, prev_head;
@@ -389,6 +390,115 @@ __device__ __forceinline__ void sim_advance_contact(KP p, EnvRegs& e, int env, i
     e.crowd_ms += ms;
 }
 
+// cn_config.ped_mode = 2 (BASELINE north_star "per-env pedestrian social-force integration"; the model is stated in
+// include/crowdnav.h and restated by the oracle's sim_advance_sf): Helbing-Molnar goal attraction + exponential repulsion from the
+// other pedestrians, the four walls and the robot, on physics ticks of at most 10 ms.  lane = pedestrian; every acceleration is
+// evaluated from the tick-start pedestrian state (Jacobi) in the oracle's order -- goal, pedestrians by index, walls -x +x -y +y,
+// robot -- then v (capped at 1.3 v0), then x, clamped into the room.  The pair loop reads pedestrian j's position as an LDS
+// broadcast (one address for the whole wave).  `scr`: 8 P doubles of LDS scratch (regions A + B are idle while the simulator
+// runs): next state [4 P] and this call's copy of the goal records + desired speeds [4 P] (goal x, y, counter, v0), so that the
+// 16 ticks of a step pay no global-memory round trip and no RNG evaluation.
+__device__ __forceinline__ void sim_advance_sf(KP p, EnvRegs& e, int env, int lane, double* ped_p, double* ped_v, double* scr, int ms)
+{
+    const int P = p->P;
+    const double H = p->room_half, r = p->ped_radius, lo = -H + r, hi = H - r;
+    const double A = p->sf_A, B = p->sf_B, Aw = p->sf_wall_A, Bw = p->sf_wall_B, tau = p->sf_tau;
+    const double Rr = r + p->robot_clearance;
+    const double cut = fma(12.0, B, 2.0 * r) + 1e-6, cut2 = cut * cut;        // beyond it the exponent is certainly below -12
+    const long long gid = p->env_index_base + env;
+    double* const gaux = p->ped_aux + (size_t)env * 3 * P;
+    double* const nxt = scr;
+    double* const aux = scr + 4 * P;
+    for (int i = lane; i < P; i += 64) {
+        aux[4 * i] = gaux[3 * i]; aux[4 * i + 1] = gaux[3 * i + 1]; aux[4 * i + 2] = gaux[3 * i + 2];
+        aux[4 * i + 3] = p->ped_vmax * fma(0.5, cn_rng_u01(p->seed, gid, 4u, (uint32_t)i, 0u), 0.5);     // desired speed v0
+    }
+    CN_SYNC();
+    for (int tt = 0; tt < ms; ) {
+        const int h = (ms - tt < 10) ? (ms - tt) : 10;
+        const double hs = cn_div1000((double)h);
+        robot_advance(p, e, h);
+        for (int i0 = 0; i0 < P; i0 += 64) {
+            const int i = i0 + lane;
+            const bool act = i < P;
+            double xi = 0.0, yi = 0.0, vxi = 0.0, vyi = 0.0, v0 = 0.0, gx = 0.0, gy = 0.0;
+            if (act) {
+                xi = ped_p[2 * i]; yi = ped_p[2 * i + 1]; vxi = ped_v[2 * i]; vyi = ped_v[2 * i + 1];
+                gx = aux[4 * i]; gy = aux[4 * i + 1]; v0 = aux[4 * i + 3];
+            }
+            double gdx = gx - xi, gdy = gy - yi, gd2 = fma(gdx, gdx, gdy * gdy);
+            if (act && gd2 <= p->sf_goal_eps2) {                 // goal reached: the next one of this pedestrian's sequence (stream 3)
+                const uint32_t m = (uint32_t)aux[4 * i + 2] + 1u;
+                const double glo = -H + 0.1, gspan = 2.0 * H - 0.2;
+                gx = fma(gspan, cn_rng_u01(p->seed, gid, 3u, (uint32_t)i, 2u * m), glo);
+                gy = fma(gspan, cn_rng_u01(p->seed, gid, 3u, (uint32_t)i, 2u * m + 1u), glo);
+                aux[4 * i] = gx; aux[4 * i + 1] = gy; aux[4 * i + 2] = (double)m;
+                gdx = gx - xi; gdy = gy - yi; gd2 = fma(gdx, gdx, gdy * gdy);
+            }
+            double ex = 0.0, ey = 0.0;
+            if (gd2 > 0.0) { const double ginv = 1.0 / sqrt(gd2); ex = gdx * ginv; ey = gdy * ginv; }
+            double ax = (v0 * ex - vxi) / tau, ay = (v0 * ey - vyi) / tau;
+            for (int j = 0; j < P; ++j) {
+                const double ddx = xi - ped_p[2 * j], ddy = yi - ped_p[2 * j + 1];
+                const double d2 = fma(ddx, ddx, ddy * ddy);
+                if (act && j != i && d2 > 0.0 && !(d2 > cut2)) {
+                    const double d = sqrt(d2), arg = (2.0 * r - d) / B;
+                    if (!(arg < -12.0)) {
+                        const double f = (A * cn_det_exp(arg)) * (1.0 / d);
+                        ax = fma(f, ddx, ax); ay = fma(f, ddy, ay);
+                    }
+                }
+            }
+            if (act) {
+                {   // walls: distance from the centre to the wall plane, pushing inwards
+                    double arg = (r - (xi + H)) / Bw;
+                    if (!(arg < -12.0)) ax = ax + Aw * cn_det_exp(arg);
+                    arg = (r - (H - xi)) / Bw;
+                    if (!(arg < -12.0)) ax = ax - Aw * cn_det_exp(arg);
+                    arg = (r - (yi + H)) / Bw;
+                    if (!(arg < -12.0)) ay = ay + Aw * cn_det_exp(arg);
+                    arg = (r - (H - yi)) / Bw;
+                    if (!(arg < -12.0)) ay = ay - Aw * cn_det_exp(arg);
+                }
+                {   // the robot, where this tick leaves it
+                    const double ddx = xi - e.rx, ddy = yi - e.ry;
+                    const double d2 = fma(ddx, ddx, ddy * ddy);
+                    if (d2 > 0.0) {
+                        const double d = sqrt(d2), arg = (Rr - d) / B;
+                        if (!(arg < -12.0)) {
+                            const double f = (A * cn_det_exp(arg)) * (1.0 / d);
+                            ax = fma(f, ddx, ax); ay = fma(f, ddy, ay);
+                        }
+                    }
+                }
+                double vx = fma(ax, hs, vxi), vy = fma(ay, hs, vyi);
+                const double cap = 1.3 * v0, s2 = fma(vx, vx, vy * vy);
+                if (s2 > cap * cap) { const double k = cap / sqrt(s2); vx = vx * k; vy = vy * k; }
+                nxt[4 * i] = cn_clamp(fma(vx, hs, xi), lo, hi); nxt[4 * i + 1] = cn_clamp(fma(vy, hs, yi), lo, hi);
+                nxt[4 * i + 2] = vx; nxt[4 * i + 3] = vy;
+            }
+        }
+        CN_SYNC();
+        for (int i = lane; i < P; i += 64) {
+            ped_p[2 * i] = nxt[4 * i]; ped_p[2 * i + 1] = nxt[4 * i + 1];
+            ped_v[2 * i] = nxt[4 * i + 2]; ped_v[2 * i + 1] = nxt[4 * i + 3];
+        }
+        CN_SYNC();
+        tt += h;
+    }
+    for (int i = lane; i < P; i += 64) { gaux[3 * i] = aux[4 * i]; gaux[3 * i + 1] = aux[4 * i + 1]; gaux[3 * i + 2] = aux[4 * i + 2]; }
+    CN_SYNC();
+    e.crowd_ms += ms;
+}
+
+// the tick-based simulators: SIM 1 = rigid contact (cn_config.ped_contact), SIM 2 = social force (cn_config.ped_mode 2)
+template <int SIM>
+__device__ __forceinline__ void sim_advance_ticks(KP p, EnvRegs& e, int env, int lane, double* ped_p, double* ped_v, double* scr, int ms)
+{
+    if constexpr (SIM == 2) sim_advance_sf(p, e, env, lane, ped_p, ped_v, scr, ms);
+    else sim_advance_contact(p, e, env, lane, ped_p, ped_v, scr, ms);
+}
+
 __device__ __forceinline__ void sim_advance(KP p, EnvRegs& e, int env, int lane, double* ped_p, double* ped_v, int ms)
 {
     if (ms <= 0) return;
@@ -526,8 +636,8 @@ __device__ __forceinline__ void observe_original(KP p, EnvRegs& e, const Lds& L,
 {
     const int R = p->R, n = R - 1, D = n + 4;
     const double px = e.rx, py = e.ry, yaw = e.ryaw;
-    double dist = cn_np_around2(dist3(px, py, p->goal_x, p->goal_y));   // round(np.float64, 2), ORIG:280
-    double head = cn_py_round2(orig_heading(p, px, py, yaw));        // ORIG:281
+    double dist = cn_round_np64_2_t<false>(dist3(px, py, p->goal_x, p->goal_y), PY2);   // round(np.float64, 2), ORIG:280
+    double head = cn_py_round2(orig_heading(p, px, py, yaw), PY2);        // ORIG:281
     double sy, cy;
     cn_det_sincos_t(p->trig, yaw, &sy, &cy);
     const double ox = fma(p->lidar_offset_x, cy, px), oy = fma(p->lidar_offset_x, sy, py);
@@ -553,7 +663,7 @@ __device__ __forceinline__ void observe_original(KP p, EnvRegs& e, const Lds& L,
             else if (r != r) v = 0.0;
             else v = r;
             smin = cn_vmin(smin, v);
-            double so = cn_py_round3(v);                              // ORIG:317
+            double so = cn_py_round3(v, PY2);                              // ORIG:317
             o32[j] = (float)so;
             if (f32) f32[j] = (float)so;
             if (o64) o64[j] = so;
@@ -565,7 +675,7 @@ __device__ __forceinline__ void observe_original(KP p, EnvRegs& e, const Lds& L,
         if (in_box(px, py, p->goal_x, p->goal_y, 0.20)) e.done = 1;     // ORIG:307-309 (epsilon default, ORIG:500)
         if (step_counter >= p->max_steps) e.done = 1;                  // ORIG:311-313
     }
-    const double x3 = cn_py_round3(px), y3 = cn_py_round3(py);        // ORIG:315
+    const double x3 = cn_py_round3(px, PY2), y3 = cn_py_round3(py, PY2);        // ORIG:315
     if (lane < 4) {
         double tv = lane == 0 ? head : lane == 1 ? dist : lane == 2 ? x3 : y3;
         L.tail[lane] = tv;
@@ -621,8 +731,8 @@ __device__ __forceinline__ double bbox_size(KP p, double* stage, int lane, int n
             double s0, c0, s1, c1;
             cn_det_sincos_t(p->trig, ((double)i * p->angle_inc_deg) * deg2rad - yaw, &s0, &c0);
             cn_det_sincos_t(p->trig, ((double)j * p->angle_inc_deg) * deg2rad - yaw, &s1, &c1);
-            double x0 = cn_py_round3(px + (MAXR * c0)), y0 = cn_py_round3(py + (MAXR * s0) * -1.0);
-            double x1 = cn_py_round3(px + (MAXR * c1)), y1 = cn_py_round3(py + (MAXR * s1) * -1.0);
+            double x0 = cn_py_round3(px + (MAXR * c0), PY2), y0 = cn_py_round3(py + (MAXR * s0) * -1.0, PY2);
+            double x1 = cn_py_round3(px + (MAXR * c1), PY2), y1 = cn_py_round3(py + (MAXR * s1) * -1.0, PY2);
             stage[lane] = cn_hypot(x0 - x1, y0 - y1);
         }
         CN_SYNC();
@@ -678,7 +788,7 @@ __device__ __forceinline__ void tracker_stage(KP p, EnvRegs& e, const Lds& L, do
                 if (ti < nt0) {
                     const double tx = TRK(CN_TF_PX, ti), ty_ = TRK(CN_TF_PY, ti);
                     for (int oj = lane & 7; oj < nconf; oj += 8) {
-                        const double u = cn_iou3(tx, ty_, L.cfx[oj], L.cfy[oj], 0.0505);
+                        const double u = cn_iou3(tx, ty_, L.cfx[oj], L.cfy[oj], 0.0505, PY2);
                         if (u > best) { best = u; bj = oj; }
                     }
                 }
@@ -759,8 +869,8 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
     // ENV:246-265
     CN_T(22);
     if (step_counter == 1) waypoint_refresh(p, pg, e, lane, px, py);
-    double distance_to_goal = cn_np_around2_t<!EXT>(dist3(px, py, e.wpx, e.wpy));
-    double heading = cn_py_round2_t<!EXT>(heading_to_goal(p, e, px, py, yaw));
+    double distance_to_goal = cn_round_np64_2_t<!EXT>(dist3(px, py, e.wpx, e.wpy), PY2);   // round(np.float64, 2), ENV:255
+    double heading = cn_py_round2_t<!EXT>(heading_to_goal(p, e, px, py, yaw), PY2);
     CN_T(23);
     if (step_counter % 5 == 0 || distance_to_goal < e.prev_dist) waypoint_refresh(p, pg, e, lane, px, py);
     CN_T(24);
@@ -820,9 +930,9 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
             // sin/cos(radians(j * inc) - yaw) by angle addition from a host table of sin/cos(radians(j * inc))
             if constexpr (!GT) {      // end points feed the segmentation only
             const double sa = fma(tS, cy, -(tC * sy)), ca = fma(tC, cy, tS * sy);
-            L.ptx[j] = (int)cn_round_scaled(px + (sc * ca), 1000.0);
-            L.pty[j] = (int)cn_round_scaled(py + (sc * sa) * -1.0, 1000.0);
-            L.dmil[j] = (unsigned short)(int)cn_round_scaled(sc, 1000.0);
+            L.ptx[j] = (int)cn_round_scaled(px + (sc * ca), 1000.0, PY2);
+            L.pty[j] = (int)cn_round_scaled(py + (sc * sa) * -1.0, 1000.0, PY2);
+            L.dmil[j] = (unsigned short)(int)cn_round_scaled(sc, 1000.0, PY2);
             }
             double so = cn_np_around3_t<!EXT>(sc);  // ENV:1042
             cn_stg(o32, j, (float)so);
@@ -841,7 +951,7 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
         // longer than a stepping one, and a launch lasts as long as its slowest wavefront).
         if (!EXT && p->bb_spawn_valid && px == p->spawn_x && py == p->spawn_y && yaw == p->spawn_yaw) e.bb = p->bb_spawn;
         else e.bb = bbox_size(p, L.stage, lane, n, px, py, yaw);
-        double qx = cn_py_round3_t<!EXT>(px), qy = cn_py_round3_t<!EXT>(py);
+        double qx = cn_py_round3_t<!EXT>(px, PY2), qy = cn_py_round3_t<!EXT>(py, PY2);
         if (e.dq_len < 2) { if (e.dq_len == 0) { e.dq0x = qx; e.dq0y = qy; } else { e.dq1x = qx; e.dq1y = qy; } e.dq_len += 1; }
         else { e.dq0x = e.dq1x; e.dq0y = e.dq1y; e.dq1x = qx; e.dq1y = qy; }
     }
@@ -889,11 +999,11 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
         if (two) { xbi = L.ptx[ib]; ybi = L.pty[ib]; xbj = L.ptx[jb]; ybj = L.pty[jb]; }
         const double dya = cn_div1000((double)yai) - cn_div1000((double)yaj);
         const double qa = (dya == 0) ? 0.0 : cn_div(cn_div1000((double)xai) - cn_div1000((double)xaj), dya);   // |dy| >= 0.001 or the lane is discarded
-        if (va) L.gq[ia] = (int)cn_round_scaled(qa, 1000.0);
+        if (va) L.gq[ia] = (int)cn_round_scaled(qa, 1000.0, PY2);
         if (two) {
             const double dyb = cn_div1000((double)ybi) - cn_div1000((double)ybj);
             const double qb = (dyb == 0) ? 0.0 : cn_div(cn_div1000((double)xbi) - cn_div1000((double)xbj), dyb);
-            if (vb) L.gq[ib] = (int)cn_round_scaled(qb, 1000.0);
+            if (vb) L.gq[ib] = (int)cn_round_scaled(qb, 1000.0, PY2);
         }
     }
     // last occupied ray before n-1 (ENV:356-366 `last_grad`)
@@ -1117,14 +1227,14 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
                 if (fast_assoc) {
                     const int dx_ = abs(L.ptx[i] - L.ptx[i + 1]), dy_ = abs(L.pty[i] - L.pty[i + 1]);
                     brk = dy_ > (int)amax[min(dx_, K1 + 1)];
-                } else brk = !cn_iou3_positive(PX(i), PY(i), PX(i + 1), PY(i + 1), e.bb);
+                } else brk = !cn_iou3_positive(PX(i), PY(i), PX(i + 1), PY(i + 1), e.bb, PY2);
             }
         }
         note_breaks(q, __ballot(brk));
     }
     const int ls = lb + 1;            // start of the last segment
     // ENV:490-502 first <-> last with twice the box
-    bool merge = (nsegs0 > 1) && cn_iou3_positive(PX(0), PY(0), PX(n - 1), PY(n - 1), e.bb * 2);
+    bool merge = (nsegs0 > 1) && cn_iou3_positive(PX(0), PY(0), PX(n - 1), PY(n - 1), e.bb * 2, PY2);
     CN_SYNC();
     CN_T(10);
     // order-space: position k -> ray.  merged: [0..fe] ++ [ls..n-1] ++ [fe+1..ls-1]
@@ -1339,9 +1449,9 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
                 const double dp = cn_sqrt(fma(dx, dx, dy * dy));
                 double sx_ = cx, sy_ = cyy;
                 if (dp > 0.0) { sx_ = cx - r_ * (dx / dp); sy_ = cyy - r_ * (dy / dp); }
-                const double dist = cn_py_round3(dp - r_);
+                const double dist = cn_py_round3(dp - r_, PY2);
                 const double vx = L.pedv[2 * i], vy = L.pedv[2 * i + 1];
-                TRK(CN_TF_PX, slot) = cn_py_round3(sx_); TRK(CN_TF_PY, slot) = cn_py_round3(sy_); TRK(CN_TF_DIST, slot) = dist;
+                TRK(CN_TF_PX, slot) = cn_py_round3(sx_, PY2); TRK(CN_TF_PY, slot) = cn_py_round3(sy_, PY2); TRK(CN_TF_DIST, slot) = dist;
                 TRK(CN_TF_D0X, slot) = 0.0; TRK(CN_TF_D0Y, slot) = 0.0; TRK(CN_TF_D1X, slot) = 0.0; TRK(CN_TF_D1Y, slot) = 0.0;
                 TRK(CN_TF_T, slot) = (double)i; TRK(CN_TF_SPEED, slot) = cn_sqrt(fma(vx, vx, vy * vy));
                 TRK(CN_TF_VX, slot) = -vx; TRK(CN_TF_VY, slot) = -vy; TRK(CN_TF_DQLEN, slot) = 0.0;
@@ -1540,7 +1650,7 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
     // ENV:1025-1042 observation tail
     if (lane < 7) {   // one rounding pass, lane = tail slot (heading and distance are already rounded)
         const double v = lane == 2 ? px : lane == 3 ? py : lane == 4 ? yaw : lane == 5 ? agent_vel_x : agent_vel_y;
-        const double r = cn_py_round3_t<!EXT>(v);
+        const double r = cn_py_round3_t<!EXT>(v, PY2);
         L.tail[lane] = lane == 0 ? heading : lane == 1 ? distance_to_goal : r;
     }
     CN_SYNC();
@@ -1592,8 +1702,8 @@ __device__ __forceinline__ void observe_realworld(KP p, const Poly& pg, EnvRegs&
     const int R = p->R, n = R - 1, D = n + 11;
     const double MAXR = p->max_scan_range;
     const double px = e.rx, py = e.ry, yaw = e.ryaw, v = e.rv, w = e.rw, now = e.clock;
-    const double distance_to_goal = cn_np_around2(rw_distance(p, px, py));      // RW:209
-    const double heading = cn_py_round2(rw_heading(p, px, py, yaw));            // RW:210
+    const double distance_to_goal = cn_round_np64_2_t<false>(rw_distance(p, px, py), PY2);      // RW:209 round(np.float64, 2)
+    const double heading = cn_py_round2(rw_heading(p, px, py, yaw), PY2);            // RW:210
     double sw_, cw_;
     cn_det_sincos_t(p->trig, w, &sw_, &cw_);
     const double agent_vel_x = -1.0 * (v * cw_), agent_vel_y = v * sw_;         // RW:211-212
@@ -1626,10 +1736,10 @@ __device__ __forceinline__ void observe_realworld(KP p, const Poly& pg, EnvRegs&
             smin = cn_vmin(smin, sc);
             const double tS = p->ang_s[j], tC = p->ang_c[j];
             const double sa = fma(tS, cy, -(tC * sy)), ca = fma(tC, cy, tS * sy);
-            L.ptx[j] = (int)cn_round_scaled(px + (sc * ca), 1000.0);
-            L.pty[j] = (int)cn_round_scaled(py + (sc * sa) * -1.0, 1000.0);
+            L.ptx[j] = (int)cn_round_scaled(px + (sc * ca), 1000.0, PY2);
+            L.pty[j] = (int)cn_round_scaled(py + (sc * sa) * -1.0, 1000.0, PY2);
             // bit 15: not a ground-truth (free-space) ray -- RW:249-255 tests the UNROUNDED range against max_scan_range
-            L.dmil[j] = (unsigned short)((int)cn_round_scaled(sc, 1000.0) | ((sc != MAXR) ? 0x8000 : 0));
+            L.dmil[j] = (unsigned short)((int)cn_round_scaled(sc, 1000.0, PY2) | ((sc != MAXR) ? 0x8000 : 0));
             o32[j] = (float)sc;
             if (f32) f32[j] = (float)sc;
             if (o64) o64[j] = sc;
@@ -1640,7 +1750,7 @@ __device__ __forceinline__ void observe_realworld(KP p, const Poly& pg, EnvRegs&
     if (step_counter == 0) {                                                    // RW:229-237
         if (!EXT && p->bb_spawn_valid && px == p->spawn_x && py == p->spawn_y && yaw == p->spawn_yaw) e.bb = p->bb_spawn;
         else e.bb = bbox_size(p, L.stage, lane, n, px, py, yaw);
-        double qx = cn_py_round3(px), qy = cn_py_round3(py);
+        double qx = cn_py_round3(px, PY2), qy = cn_py_round3(py, PY2);
         if (e.dq_len < 2) { if (e.dq_len == 0) { e.dq0x = qx; e.dq0y = qy; } else { e.dq1x = qx; e.dq1y = qy; } e.dq_len += 1; }
         else { e.dq0x = e.dq1x; e.dq0y = e.dq1y; e.dq1x = qx; e.dq1y = qy; }
     }
@@ -1661,7 +1771,7 @@ __device__ __forceinline__ void observe_realworld(KP p, const Poly& pg, EnvRegs&
         const int i = Q.fi[c], j = Q.fi[(c == F - 1) ? 0 : c + 1];
         const double dy = PY(i) - PY(j);
         const double q = (dy == 0) ? 0.0 : (PX(i) - PX(j)) / dy;
-        Q.g[c] = (int)cn_round_scaled(q, 1000.0);
+        Q.g[c] = (int)cn_round_scaled(q, 1000.0, PY2);
     }
     CN_SYNC();
     // ---- RW:284-333 change of gradient + the object-type machine, on the scalar unit (F is a few dozen) --------------------------
@@ -1706,7 +1816,7 @@ __device__ __forceinline__ void observe_realworld(KP p, const Poly& pg, EnvRegs&
         bool brk = false;
         if (m < M) {
             brk = true;
-            if (m < M - 1) { const int a = ERAY(m), b = ERAY(m + 1); brk = !cn_iou3_positive(PX(a), PY(a), PX(b), PY(b), e.bb); }
+            if (m < M - 1) { const int a = ERAY(m), b = ERAY(m + 1); brk = !cn_iou3_positive(PX(a), PY(a), PX(b), PY(b), e.bb, PY2); }
         }
         const u64 bw = __ballot(brk);
         if (lane == 0) segw[q] = bw;
@@ -1723,7 +1833,7 @@ __device__ __forceinline__ void observe_realworld(KP p, const Poly& pg, EnvRegs&
             if (bw) { last_start = 64 * q + 64 - __builtin_clzll(bw); break; }
         }
         const int a = ERAY(0), b = ERAY(M - 1);
-        merged = cn_iou3_positive(PX(a), PY(a), PX(b), PY(b), e.bb * 2);
+        merged = cn_iou3_positive(PX(a), PY(a), PX(b), PY(b), e.bb * 2, PY2);
     }
     if (merged) nseg -= 1;
     // ---- RW:426-468 confirmation, one segment at a time (scalar unit); order space = [0..first_end] ++ [last_start..M-1] ++ rest ---
@@ -1855,11 +1965,11 @@ __device__ __forceinline__ void observe_realworld(KP p, const Poly& pg, EnvRegs&
         switch (lane) {
         case 0: tv = heading; break;
         case 1: tv = distance_to_goal; break;
-        case 2: tv = cn_py_round3(px); break;
-        case 3: tv = cn_py_round3(py); break;
-        case 4: tv = cn_py_round3(3.14); break;                                 // round(self.yaw, 3): the constructor's constant
-        case 5: tv = cn_py_round3(agent_vel_x); break;
-        case 6: tv = cn_py_round3(agent_vel_y); break;
+        case 2: tv = cn_py_round3(px, PY2); break;
+        case 3: tv = cn_py_round3(py, PY2); break;
+        case 4: tv = cn_py_round3(3.14, PY2); break;                                 // round(self.yaw, 3): the constructor's constant
+        case 5: tv = cn_py_round3(agent_vel_x, PY2); break;
+        case 6: tv = cn_py_round3(agent_vel_y, PY2); break;
         case 7: tv = clx; break;
         case 8: tv = cly; break;
         case 9: tv = clvx; break;
@@ -1947,7 +2057,7 @@ __device__ __forceinline__ double compute_reward(KP p, const Poly& pg, EnvRegs& 
 
 }  // namespace
 
-template <bool EXT, bool TWO, int LAYOUT, bool GT = false, bool CT = false>
+template <bool EXT, bool TWO, int LAYOUT, bool GT = false, int SIM = 0>
 __device__ __forceinline__ void env_kernel_body()
 {
     KP p = (KP)__builtin_amdgcn_kernarg_segment_ptr();
@@ -2075,7 +2185,7 @@ __device__ __forceinline__ void env_kernel_body()
                 const double t0 = e.clock;
                 e.rv = v; e.rw = w;                               // pub_cmd_vel.publish (ENV:1200)
                 e.clock += cn_div1000((double)p->dt_ms);              // time.sleep(0.15) (ENV:1201)
-                if constexpr (CT) sim_advance_contact(p, e, env, lane, L.ped, pedv, (double*)smem, p->dt_ms);
+                if constexpr (SIM != 0) sim_advance_ticks<SIM>(p, e, env, lane, L.ped, pedv, (double*)smem, p->dt_ms);
                 else {
                 if constexpr (LAYOUT == 0) { step_trig(p, e, lane, rs1, rc1, rs2, rc2, trig); have_trig = true; }
                 // pedestrians: ONE pass over [0, dt + scan latency], cut at dt (they are only looked at by the scan)
@@ -2093,7 +2203,7 @@ __device__ __forceinline__ void env_kernel_body()
                 deq_x = od[6]; deq_y = od[7]; end_timestep = od[8];
             }
             if (ph_pre) {
-            double qx = cn_py_round3_t<!EXT>(deq_x), qy = cn_py_round3_t<!EXT>(deq_y);  // ENV:1208
+            double qx = cn_py_round3_t<!EXT>(deq_x, PY2), qy = cn_py_round3_t<!EXT>(deq_y, PY2);  // ENV:1208
             if (e.dq_len == 0) { e.dq0x = qx; e.dq0y = qy; e.dq_len = 1; }
             else if (e.dq_len == 1) { e.dq1x = qx; e.dq1y = qy; e.dq_len = 2; }
             else { e.dq0x = e.dq1x; e.dq0y = e.dq1y; e.dq1x = qx; e.dq1y = qy; }
@@ -2101,7 +2211,7 @@ __device__ __forceinline__ void env_kernel_body()
             }
             if (!ext) {
                 e.clock += cn_div1000((double)p->scan_latency_ms);    // wait_for_message('scan') (ENV:1218)
-                if constexpr (CT) sim_advance_contact(p, e, env, lane, L.ped, pedv, (double*)smem, p->scan_latency_ms);
+                if constexpr (SIM != 0) sim_advance_ticks<SIM>(p, e, env, lane, L.ped, pedv, (double*)smem, p->scan_latency_ms);
                 else if (have_trig) robot_advance_sc(p, e, p->scan_latency_ms, rs2, rc2); else robot_advance(p, e, p->scan_latency_ms);
                 CN_T(21);
             }
@@ -2112,7 +2222,7 @@ __device__ __forceinline__ void env_kernel_body()
                 for (int i = lane; i < 2 * P; i += 64) { L.ped[i] = gped_init[i]; pedv[i] = 0.0; }
                 CN_SYNC();
                 e.clock += cn_div1000((double)p->scan_latency_ms);    // wait_for_message('scan') (ENV:1238)
-                if constexpr (CT) sim_advance_contact(p, e, env, lane, L.ped, pedv, (double*)smem, p->scan_latency_ms);
+                if constexpr (SIM != 0) sim_advance_ticks<SIM>(p, e, env, lane, L.ped, pedv, (double*)smem, p->scan_latency_ms);
                 else sim_advance(p, e, env, lane, L.ped, pedv, p->scan_latency_ms);
             }
             if constexpr (LAYOUT == 1) {
@@ -2171,7 +2281,7 @@ __device__ __forceinline__ void env_kernel_body()
             e.social_viol = 0; e.ego_viol = 0; e.obst_steps = 0;  // ENV:1260-1262
             if (!ext) {
                 e.clock += cn_div1000((double)p->settle_ms);          // TRAIN:114 time.sleep(0.1)
-                if constexpr (CT) sim_advance_contact(p, e, env, lane, L.ped, pedv, (double*)smem, p->settle_ms);
+                if constexpr (SIM != 0) sim_advance_ticks<SIM>(p, e, env, lane, L.ped, pedv, (double*)smem, p->settle_ms);
                 else sim_advance(p, e, env, lane, L.ped, pedv, p->settle_ms);
             }
             e.done = 0;                                           // TRAIN:116
@@ -2199,7 +2309,7 @@ __device__ __forceinline__ void env_kernel_body()
             const double t0 = e.clock;
             e.rv = v; e.rw = w;                               // pub_cmd_vel.publish (ENV:1200)
             e.clock += cn_div1000((double)p->dt_ms);              // time.sleep(0.15) (ENV:1201)
-            if constexpr (CT) sim_advance_contact(p, e, env, lane, L.ped, pedv, (double*)smem, p->dt_ms);
+            if constexpr (SIM != 0) sim_advance_ticks<SIM>(p, e, env, lane, L.ped, pedv, (double*)smem, p->dt_ms);
             else {
             ped_advance(p, env, lane, L.ped, pedv, e.crowd_ms, e.crowd_ms + p->dt_ms + p->scan_latency_ms, p->dt_ms);
             e.crowd_ms += p->dt_ms + p->scan_latency_ms;
@@ -2213,7 +2323,7 @@ __device__ __forceinline__ void env_kernel_body()
             deq_x = od[6]; deq_y = od[7]; end_timestep = od[8];
         }
         {
-            double qx = cn_py_round3(deq_x), qy = cn_py_round3(deq_y);  // ENV:1208
+            double qx = cn_py_round3(deq_x, PY2), qy = cn_py_round3(deq_y, PY2);  // ENV:1208
             if (e.dq_len == 0) { e.dq0x = qx; e.dq0y = qy; e.dq_len = 1; }
             else if (e.dq_len == 1) { e.dq1x = qx; e.dq1y = qy; e.dq_len = 2; }
             else { e.dq0x = e.dq1x; e.dq0y = e.dq1y; e.dq1x = qx; e.dq1y = qy; }
@@ -2221,7 +2331,7 @@ __device__ __forceinline__ void env_kernel_body()
         e.ts = end_timestep;                                  // ENV:1209
         if (!ext) {
             e.clock += cn_div1000((double)p->scan_latency_ms);    // wait_for_message('scan') (ENV:1218)
-            if constexpr (CT) sim_advance_contact(p, e, env, lane, L.ped, pedv, (double*)smem, p->scan_latency_ms);
+            if constexpr (SIM != 0) sim_advance_ticks<SIM>(p, e, env, lane, L.ped, pedv, (double*)smem, p->scan_latency_ms);
             else robot_advance(p, e, p->scan_latency_ms);
         }
         CN_SYNC();
@@ -2264,7 +2374,7 @@ __device__ __forceinline__ void env_kernel_body()
         for (int i = lane; i < 2 * P; i += 64) { L.ped[i] = gped_init[i]; pedv[i] = 0.0; }
         CN_SYNC();
         e.clock += cn_div1000((double)p->scan_latency_ms);        // wait_for_message('scan') (ENV:1238)
-        if constexpr (CT) sim_advance_contact(p, e, env, lane, L.ped, pedv, (double*)smem, p->scan_latency_ms);
+        if constexpr (SIM != 0) sim_advance_ticks<SIM>(p, e, env, lane, L.ped, pedv, (double*)smem, p->scan_latency_ms);
         else sim_advance(p, e, env, lane, L.ped, pedv, p->scan_latency_ms);
         }
         CN_SYNC();
@@ -2288,7 +2398,7 @@ __device__ __forceinline__ void env_kernel_body()
         e.social_viol = 0; e.ego_viol = 0; e.obst_steps = 0;  // ENV:1260-1262
         if (!ext) {
         e.clock += cn_div1000((double)p->settle_ms);              // TRAIN:114 time.sleep(0.1)
-        if constexpr (CT) sim_advance_contact(p, e, env, lane, L.ped, pedv, (double*)smem, p->settle_ms);
+        if constexpr (SIM != 0) sim_advance_ticks<SIM>(p, e, env, lane, L.ped, pedv, (double*)smem, p->settle_ms);
         else sim_advance(p, e, env, lane, L.ped, pedv, p->settle_ms);
         }
         e.done = 0;                                           // TRAIN:116
@@ -2334,10 +2444,15 @@ extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_ext(CnKParams p) 
 extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_gt(CnKParams p) { env_kernel_body<false, false, 0, true>(); }
 extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_gt_same(CnKParams p) { env_kernel_body<false, true, 0, true>(); }
 // ped_contact = 1: the simulator with rigid contacts (10 ms physics ticks); separate instantiations keep the default kernels lean
-extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_ct(CnKParams p) { env_kernel_body<false, false, 0, false, true>(); }
-extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_ct_same(CnKParams p) { env_kernel_body<false, true, 0, false, true>(); }
-extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_gt_ct(CnKParams p) { env_kernel_body<false, false, 0, true, true>(); }
-extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_gt_ct_same(CnKParams p) { env_kernel_body<false, true, 0, true, true>(); }
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_ct(CnKParams p) { env_kernel_body<false, false, 0, false, 1>(); }
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_ct_same(CnKParams p) { env_kernel_body<false, true, 0, false, 1>(); }
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_gt_ct(CnKParams p) { env_kernel_body<false, false, 0, true, 1>(); }
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_gt_ct_same(CnKParams p) { env_kernel_body<false, true, 0, true, 1>(); }
+// ped_mode = 2: social-force pedestrians (10 ms physics ticks), for both risk modes
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_sf(CnKParams p) { env_kernel_body<false, false, 0, false, 2>(); }
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_sf_same(CnKParams p) { env_kernel_body<false, true, 0, false, 2>(); }
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_gt_sf(CnKParams p) { env_kernel_body<false, false, 0, true, 2>(); }
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_gt_sf_same(CnKParams p) { env_kernel_body<false, true, 0, true, 2>(); }
 // obs_layout 2 (environment_stage_1_nobonus_realworld.py): the 370-input physical-robot variant
 extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_rw(CnKParams p) { env_kernel_body<false, false, 2>(); }
 extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_rw_same(CnKParams p) { env_kernel_body<false, true, 2>(); }

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CN_ABI_VERSION 3
+#define CN_ABI_VERSION 4
 #define CN_MAX_TRACKS 64      /* largest per-env capacity of the obstacle tracker (ENV:656-743): one lane per track */
 #define CN_MAX_K 16
 
@@ -54,7 +54,10 @@ typedef struct cn_config {
     int32_t n_rays;          /* R lidar samples (XACRO:157 -> 360); the observation uses R-1 */
     int32_t k_obstacles;     /* K tracked obstacles in the observation (ENV:55 -> 8) */
     int32_t max_steps;       /* Env(max_step=...) (ENV:43,91) */
-    int32_t ped_mode;        /* 0: U(-vmax,vmax) velocity per cycle (CROWD:98-126); 1: constant preset table */
+    int32_t ped_mode;        /* 0: U(-vmax,vmax) velocity per cycle (CROWD:98-126); 1: constant preset table;
+                              * 2: social-force pedestrians (BASELINE north_star; Helbing-Molnar: goal attraction + pedestrian,
+                              *    wall and robot repulsion, 10 ms ticks; sf_* below; no reference source -- CROWD:98-126 is a
+                              *    random-velocity walker -- so it is pinned by analytic known-answer cases only) */
     int32_t dt_ms;           /* time.sleep(0.15) in Env.step (ENV:1201) -> 150 */
     int32_t scan_latency_ms; /* wait_for_message('scan') (ENV:1218,1238) -> 10 */
     int32_t settle_ms;       /* trainer's time.sleep(0.1) after reset (TRAIN:114) -> 100 */
@@ -79,6 +82,12 @@ typedef struct cn_config {
     int32_t risk_mode;       /* CN_RISK_LIDAR_TRACKER (0): the reference's lidar segmentation + tracker (ENV:329-760);
                               * CN_RISK_GT (1): A21-A24 fed with the simulator's own pedestrians (nearest surface point,
                               *    true velocity) within lidar range and line of sight; indices = pedestrian ids */
+    int32_t py2_round;       /* 0: Python-3 round() (ties-to-even on the exact binary value; round(np.float64, n) is numpy's
+                              *    multiply / rint / divide) -- what the goldens were recorded under;
+                              * 1: Python-2.7 round(), the reference's platform (README.md:108-110): exact ties go AWAY from zero,
+                              *    and round(np.float64, n) is the builtin's correctly rounded decimal too (ENV:255, ORIG:280, RW:209).
+                              *    Every round() site: ENV:1208, 329-346, 1025-1042, UTL:122-123, 460 ... (np.around at ENV:1042 stays numpy) */
+    int32_t reserved1;
     int64_t env_index_base;  /* global index of env 0: RNG streams are keyed by global index */
     uint64_t seed;
     double room_half;        /* WORLD:926-1108 -> 1.40 */
@@ -96,6 +105,18 @@ typedef struct cn_config {
     double spawn_x, spawn_y, spawn_yaw; /* launch-file spawn pose (1.0, -1.0, 3.14) */
     double waypoint_radius;  /* ENV:250 -> 0.3 */
     double goal_eps;         /* ENV:1285,1303 -> 0.20 */
+    /* ped_mode 2 (social force).  Per pedestrian i: desired speed v0_i = ped_vmax (0.5 + 0.5 u_i), a goal point drawn uniformly
+     * in the room (re-drawn when within sf_goal_eps of it), and per 10 ms tick
+     *   a = (v0 e_goal - v) / sf_tau + sum_j sf_A exp((2 r - d_ij) / sf_B) n_ij          (other pedestrians, index order)
+     *     + sum_walls sf_wall_A exp((r - d_w) / sf_wall_B) n_w                            (-x, +x, -y, +y)
+     *     + sf_A exp((r + robot_clearance - d_ir) / sf_B) n_ir                            (the robot)
+     *   v <- v + a h, |v| capped at 1.3 v0;  x <- clamp(x + v h) into the room   (semi-implicit Euler, h = 0.01 s) */
+    double sf_tau;           /* relaxation time -> 0.5 s (Helbing & Molnar 1995) */
+    double sf_A;             /* pedestrian / robot repulsion strength, m/s^2 -> 0.8 (2.1 at full walking speed, scaled to 0.2 m/s crowds) */
+    double sf_B;             /* ... and range, m -> 0.10 */
+    double sf_wall_A;        /* wall repulsion strength, m/s^2 -> 1.0 */
+    double sf_wall_B;        /* ... and range, m -> 0.05 */
+    double sf_goal_eps;      /* a goal counts as reached within this distance -> 0.10 */
 } cn_config;
 
 typedef struct cn_env_s* cn_handle;
@@ -207,7 +228,23 @@ int cn_debug_env(cn_handle h, int env, double* scalars, double* robot_ped, doubl
 size_t cn_lds_bytes(int n_rays, int n_peds, int k, int max_conf, int track_capacity);
 int cn_near_separate(int n_rays, int n_peds, int k, int max_conf, int track_capacity);
 
-/* Whole-state snapshot for deterministic replay. */
+/* Whole-state snapshot for deterministic replay and for stepping the CPU oracle from a GPU state.
+ * Blob = cn_snapshot_header | sd [N][CN_SD_COUNT] f64 | si [N][CN_SI_COUNT] i32 | ped_p [N][P][2] f64 | ped_v [N][P][2] f64
+ *        | trk [N][track_capacity][CN_TF_COUNT] f64 | ped_init [N][P][2] f64 | ped_preset [N][P][2] f64 | ped_aux [N][P][3] f64
+ * (ped_aux: goal x, y and goal counter of ped_mode 2; zeros otherwise).  The header carries the ABI version and the FULL cn_config of the handle
+ * that wrote it (env_index_base, seed, layout and mode switches included): cn_restore refuses a blob whose header does not
+ * match the restoring handle field for field (CN_ERR_CONFIG, the message names the first field that differs) -- a state only
+ * means something under the configuration that produced it.  crowdnav.env.VecEnv.save_snapshot / load_snapshot wrap the blob
+ * in an .npz with the header spelled out; oracle/ (test infrastructure) loads that file into the CPU oracle. */
+#define CN_SNAPSHOT_MAGIC 0x50414E534E43ull       /* "CNSNAP" little-endian */
+typedef struct cn_snapshot_header {
+    uint64_t magic;
+    int32_t abi_version;       /* CN_ABI_VERSION of the writer */
+    int32_t header_bytes;      /* sizeof(cn_snapshot_header) */
+    int32_t sd_count, si_count, tf_count, track_capacity;   /* CN_SD_COUNT, CN_SI_COUNT, CN_TF_COUNT, resolved tracker slots */
+    uint64_t total_bytes;      /* header + payload */
+    cn_config config;
+} cn_snapshot_header;
 size_t cn_snapshot_size(cn_handle h);
 int cn_snapshot(cn_handle h, void* host_buf, size_t size);
 int cn_restore(cn_handle h, const void* host_buf, size_t size);

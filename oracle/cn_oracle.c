@@ -55,6 +55,7 @@ typedef struct {
     double* ped_init;
     double* ped_preset;
     double* ranges;
+    double* ped_aux;   /* ped_mode 2: [P][3] goal x, goal y, goal counter */
     int64_t crowd_ms;
     /* virtual clock */
     double clock;
@@ -79,6 +80,8 @@ typedef struct {
     int status;
     int n_confirmed, n_entries;
     int pending_reset;
+    int episodes;                                      /* finished episodes since creation */
+    int last_ego_viol, last_social_viol, last_obst_steps, last_ep_steps;   /* the last finished episode's counters (TRAIN:142-147) */
 } env_t;
 
 struct cno_sim {
@@ -96,8 +99,14 @@ static int g_threads = 1;
  * numeric helpers
  * ---------------------------------------------------------------------------------------- */
 
-/* Python 3 round(x, nd): correctly rounded to nd decimals, ties-to-even on the exact value,
- * then the nearest double of that decimal.  x*p = y + err exactly (fma), so the only case the
+/* cn_config.py2_round of the handle whose call is running (set on entry of every public function that takes a handle;
+ * read-only inside the OpenMP region).  0: Python-3 round(), 1: Python-2.7 round() (floatobject.c _Py_double_round: correctly
+ * rounded, an EXACT tie -- 2-valuation of x equal to -(nd + 1) -- goes away from zero). */
+static int g_py2 = 0;
+void cno_set_py2_round(int on) { g_py2 = on ? 1 : 0; }
+
+/* Python round(x, nd): correctly rounded to nd decimals -- ties-to-even on the exact value (Python 3) or away from zero
+ * (Python 2.7, g_py2) -- then the nearest double of that decimal.  x*p = y + err exactly (fma), so the only case the
  * rounded product can mislead rint() is y landing exactly on a half-integer. */
 double cno_py_round(double x, int nd)
 {
@@ -110,16 +119,21 @@ double cno_py_round(double x, int nd)
         double err = fma(x, p, -y);
         if (err > 0.0) r = y + 0.5;
         else if (err < 0.0) r = y - 0.5;
+        else if (g_py2) r = y + copysign(0.5, y);     /* exact tie: Python 2.7 rounds half away from zero */
     }
     return r / p;
 }
 
-/* numpy around / round(np.float64, nd): multiply, rint, divide */
+/* numpy around / round(np.float64, nd) under Python 3: multiply, rint, divide */
 double cno_np_around(double x, int nd)
 {
     double p = (nd == 3) ? 1000.0 : (nd == 2 ? 100.0 : pow(10.0, nd));
     return rint(x * p) / p;
 }
+
+/* round(np.float64, nd) (ENV:255, ORIG:280, RW:209): Python 3 dispatches to np.float64.__round__ (numpy's arithmetic); the
+ * Python-2.7 builtin converts its argument to a C double and rounds it like any float */
+static double round_np64(double x, int nd) { return g_py2 ? cno_py_round(x, nd) : cno_np_around(x, nd); }
 
 /* Deterministic sin/cos used by the simulator (physics + lidar direction table): only + * fma
  * and rint, so every IEEE-754 implementation returns the same bits.  Cody-Waite reduction by
@@ -334,9 +348,134 @@ static void sim_advance_contact(const cno_sim* s, env_t* e, int64_t gid, int64_t
     free(dxy);
 }
 
+/* Deterministic exp used by the social-force model: only + * fma rint and an exponent-field scaling, so every IEEE-754
+ * implementation returns the same bits (the GPU kernel evaluates the same sequence).  Cody-Waite reduction by ln 2, degree-13
+ * Taylor polynomial on |r| <= ln2 / 2 (truncation 4e-18 relative), |x| <= 700. */
+double cno_det_exp(double x)
+{
+    const double LOG2E = 1.44269504088896338700e+00, LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
+    if (x < -700.0) return 0.0;
+    if (x > 700.0) return INFINITY;
+    const double kf = rint(x * LOG2E);
+    double r = fma(-kf, LN2_HI, x);
+    r = fma(-kf, LN2_LO, r);
+    double q = 1.0 / 6227020800.0;                  /* 1/13! */
+    q = fma(q, r, 1.0 / 479001600.0);               /* 1/12! */
+    q = fma(q, r, 1.0 / 39916800.0);
+    q = fma(q, r, 1.0 / 3628800.0);
+    q = fma(q, r, 1.0 / 362880.0);
+    q = fma(q, r, 1.0 / 40320.0);
+    q = fma(q, r, 1.0 / 5040.0);
+    q = fma(q, r, 1.0 / 720.0);
+    q = fma(q, r, 1.0 / 120.0);
+    q = fma(q, r, 1.0 / 24.0);
+    q = fma(q, r, 1.0 / 6.0);
+    q = fma(q, r, 0.5);
+    q = fma(q, r, 1.0);
+    q = fma(q, r, 1.0);
+    union { uint64_t u; double d; } sc;
+    sc.u = (uint64_t)((int64_t)kf + 1023) << 52;     /* 2^k, k in [-1010, 1010] */
+    return q * sc.d;
+}
+
+/* ped_mode 2: goal m of pedestrian i = uniform in the room shrunk by 0.1 m, counter-based (stream 3); desired speed (stream 4) */
+static void sf_goal(const cno_config* c, int64_t gid, int i, uint32_t m, double* gx, double* gy)
+{
+    const double lo = -c->room_half + 0.1, span = 2.0 * c->room_half - 0.2;
+    *gx = fma(span, cno_rng_u01(c->seed, gid, 3u, (uint32_t)i, 2u * m), lo);
+    *gy = fma(span, cno_rng_u01(c->seed, gid, 3u, (uint32_t)i, 2u * m + 1u), lo);
+}
+static double sf_desired_speed(const cno_config* c, int64_t gid, int i)
+{
+    return c->ped_vmax * fma(0.5, cno_rng_u01(c->seed, gid, 4u, (uint32_t)i, 0u), 0.5);
+}
+
+/* cn_config.ped_mode = 2 (BASELINE north_star "per-env pedestrian social-force integration"; include/crowdnav.h states the
+ * model): Helbing-Molnar goal attraction + exponential repulsion from the other pedestrians, the four walls and the robot, on
+ * physics ticks of at most 10 ms.  Per tick: the (kinematic) robot moves by the mid-point rule; every pedestrian's acceleration
+ * is evaluated from the tick-start pedestrian state (Jacobi) and the robot's new position, contributions summed in the order
+ * goal, pedestrians by index, walls -x +x -y +y, robot; semi-implicit Euler (v first, capped at 1.3 v0, then x, clamped into
+ * the room).  Contributions whose exponent is below -12 are dropped (6e-6 of the strength).  A goal within sf_goal_eps at a
+ * tick start is replaced by the next one of the pedestrian's sequence.  No reference source (CROWD:98-126 is a random-velocity
+ * walker): pinned by the analytic cases of tests/test_simulator_known_answers.py. */
+static void sim_advance_sf(const cno_sim* s, env_t* e, int64_t gid, int64_t ms)
+{
+    const cno_config* c = &s->cfg;
+    const int P = c->n_peds;
+    const double H = c->room_half, r = c->ped_radius, lo = -H + r, hi = H - r;
+    const double A = c->sf_A, B = c->sf_B, Aw = c->sf_wall_A, Bw = c->sf_wall_B, tau = c->sf_tau;
+    const double eps2 = c->sf_goal_eps * c->sf_goal_eps, Rr = r + c->robot_clearance;
+    double* nxt = (double*)malloc(sizeof(double) * 4 * (size_t)(P > 0 ? P : 1));
+    int64_t t = 0;
+    while (t < ms) {
+        const int64_t h = (ms - t < 10) ? (ms - t) : 10;
+        const double hs = (double)h / 1000.0;
+        robot_advance(s, e, h);
+        for (int i = 0; i < P; ++i) {
+            const double xi = e->ped_p[2 * i], yi = e->ped_p[2 * i + 1], vxi = e->ped_v[2 * i], vyi = e->ped_v[2 * i + 1];
+            const double v0 = sf_desired_speed(c, gid, i);
+            double gx = e->ped_aux[3 * i], gy = e->ped_aux[3 * i + 1];
+            double gdx = gx - xi, gdy = gy - yi, gd2 = fma(gdx, gdx, gdy * gdy);
+            if (gd2 <= eps2) {                                   /* goal reached: the next one of this pedestrian's sequence */
+                const uint32_t m = (uint32_t)e->ped_aux[3 * i + 2] + 1u;
+                sf_goal(c, gid, i, m, &gx, &gy);
+                e->ped_aux[3 * i] = gx; e->ped_aux[3 * i + 1] = gy; e->ped_aux[3 * i + 2] = (double)m;
+                gdx = gx - xi; gdy = gy - yi; gd2 = fma(gdx, gdx, gdy * gdy);
+            }
+            double ex = 0.0, ey = 0.0;
+            if (gd2 > 0.0) { const double ginv = 1.0 / sqrt(gd2); ex = gdx * ginv; ey = gdy * ginv; }
+            double ax = (v0 * ex - vxi) / tau, ay = (v0 * ey - vyi) / tau;
+            for (int j = 0; j < P; ++j) {
+                if (j == i) continue;
+                const double ddx = xi - e->ped_p[2 * j], ddy = yi - e->ped_p[2 * j + 1];
+                const double d2 = fma(ddx, ddx, ddy * ddy);
+                if (!(d2 > 0.0)) continue;
+                const double d = sqrt(d2), arg = (2.0 * r - d) / B;
+                if (arg < -12.0) continue;
+                const double f = (A * cno_det_exp(arg)) * (1.0 / d);
+                ax = fma(f, ddx, ax); ay = fma(f, ddy, ay);
+            }
+            {   /* walls: distance from the centre to the wall plane, pushing inwards */
+                double arg = (r - (xi + H)) / Bw;
+                if (!(arg < -12.0)) ax = ax + Aw * cno_det_exp(arg);
+                arg = (r - (H - xi)) / Bw;
+                if (!(arg < -12.0)) ax = ax - Aw * cno_det_exp(arg);
+                arg = (r - (yi + H)) / Bw;
+                if (!(arg < -12.0)) ay = ay + Aw * cno_det_exp(arg);
+                arg = (r - (H - yi)) / Bw;
+                if (!(arg < -12.0)) ay = ay - Aw * cno_det_exp(arg);
+            }
+            {   /* the robot, where the tick leaves it */
+                const double ddx = xi - e->rx, ddy = yi - e->ry;
+                const double d2 = fma(ddx, ddx, ddy * ddy);
+                if (d2 > 0.0) {
+                    const double d = sqrt(d2), arg = (Rr - d) / B;
+                    if (!(arg < -12.0)) {
+                        const double f = (A * cno_det_exp(arg)) * (1.0 / d);
+                        ax = fma(f, ddx, ax); ay = fma(f, ddy, ay);
+                    }
+                }
+            }
+            double vx = fma(ax, hs, vxi), vy = fma(ay, hs, vyi);
+            const double cap = 1.3 * v0, s2 = fma(vx, vx, vy * vy);
+            if (s2 > cap * cap) { const double k = cap / sqrt(s2); vx = vx * k; vy = vy * k; }
+            nxt[4 * i] = clampd(fma(vx, hs, xi), lo, hi); nxt[4 * i + 1] = clampd(fma(vy, hs, yi), lo, hi);
+            nxt[4 * i + 2] = vx; nxt[4 * i + 3] = vy;
+        }
+        for (int i = 0; i < P; ++i) {
+            e->ped_p[2 * i] = nxt[4 * i]; e->ped_p[2 * i + 1] = nxt[4 * i + 1];
+            e->ped_v[2 * i] = nxt[4 * i + 2]; e->ped_v[2 * i + 1] = nxt[4 * i + 3];
+        }
+        t += h;
+    }
+    e->crowd_ms += ms;
+    free(nxt);
+}
+
 static void sim_advance(const cno_sim* s, env_t* e, int64_t gid, int64_t ms)
 {
     if (ms <= 0) return;
+    if (s->cfg.ped_mode == 2) { sim_advance_sf(s, e, gid, ms); return; }
     if (s->cfg.ped_contact) { sim_advance_contact(s, e, gid, ms); return; }
     ped_advance(s, e, gid, e->crowd_ms, e->crowd_ms + ms);
     e->crowd_ms += ms;
@@ -702,7 +841,7 @@ static void env_get_state(const cno_sim* s, env_t* e, const double* ranges, doub
     /* ENV:246-253 */
     if (step_counter == 1) waypoint_refresh(s, e, px, py);
     /* ENV:255-257: distance is np.float64 -> numpy rounding; heading is a Python float */
-    double distance_to_goal = cno_np_around(dist3(px, py, e->wpx, e->wpy), 2);
+    double distance_to_goal = round_np64(dist3(px, py, e->wpx, e->wpy), 2);     /* round(np.float64, 2), ENV:255 */
     double heading = cno_py_round(heading_to_goal(c, e, px, py, yaw), 2);
     /* ENV:259-265 */
     if (step_counter % 5 == 0 || distance_to_goal < e->prev_dist) waypoint_refresh(s, e, px, py);
@@ -1125,7 +1264,7 @@ static void orig_get_state(const cno_sim* s, env_t* e, const double* ranges, dou
 {
     const cno_config* c = &s->cfg;
     const int R = c->n_rays, n = R - 1;
-    double dist = cno_np_around(dist3(px, py, c->goal_x, c->goal_y), 2); /* round(np.float64, 2), ORIG:280 */
+    double dist = round_np64(dist3(px, py, c->goal_x, c->goal_y), 2);    /* round(np.float64, 2), ORIG:280 */
     double head = cno_py_round(orig_heading(c, px, py, yaw), 2);          /* ORIG:281 */
     const double min_range = 0.105;                                       /* ORIG:282 */
     double mn = INFINITY;
@@ -1210,7 +1349,7 @@ static void rw_get_state(const cno_sim* s, env_t* e, const double* ranges, doubl
     const cno_config* c = &s->cfg;
     const int R = c->n_rays, n = R - 1;
     const double MAXR = c->max_scan_range;
-    double distance_to_goal = cno_np_around(rw_distance(c, px, py), 2);   /* RW:209 round(np.float64, 2) */
+    double distance_to_goal = round_np64(rw_distance(c, px, py), 2);      /* RW:209 round(np.float64, 2) */
     double heading = cno_py_round(rw_heading(c, px, py, yaw), 2);         /* RW:210 */
     double agent_vel_x = -1.0 * (v * cos(w)), agent_vel_y = v * sin(w);   /* RW:211-212 */
     v2 closest_pose = { px, py }, closest_vel = { 0.0, 0.0 };             /* RW:215-216 */
@@ -1560,6 +1699,8 @@ int cno_create(const cno_config* cfg, cno_sim** out)
     if (cfg->n_envs < 1 || cfg->n_peds < 0 || cfg->n_rays < 8 || cfg->k_obstacles < 1 || cfg->k_obstacles > 16)
         return -2;
     if (cfg->ped_cycle_ms < 1 || cfg->dt_ms < 1) return -2;
+    if (cfg->ped_mode < 0 || cfg->ped_mode > 2) return -2;
+    if (cfg->ped_mode == 2 && (cfg->ped_contact || !(cfg->sf_tau > 0.0) || !(cfg->sf_B > 0.0) || !(cfg->sf_wall_B > 0.0))) return -2;
     cno_sim* s = (cno_sim*)calloc(1, sizeof(cno_sim));
     s->cfg = *cfg;
     s->n = cfg->n_rays - 1;
@@ -1574,13 +1715,16 @@ int cno_create(const cno_config* cfg, cno_sim** out)
     s->envs = (env_t*)calloc((size_t)cfg->n_envs, sizeof(env_t));
     for (int e = 0; e < cfg->n_envs; ++e) {
         env_t* en = &s->envs[e];
-        en->ped_p = (double*)calloc((size_t)(8 * (P > 0 ? P : 1)) + R, sizeof(double));
+        en->ped_p = (double*)calloc((size_t)(11 * (P > 0 ? P : 1)) + R, sizeof(double));
         en->ped_v = en->ped_p + 2 * P;
         en->ped_init = en->ped_v + 2 * P;
         en->ped_preset = en->ped_init + 2 * P;
-        en->ranges = en->ped_preset + 2 * P;
+        en->ped_aux = en->ped_preset + 2 * P;
+        en->ranges = en->ped_aux + 3 * P;
         env_init(s, en);
         default_ped_init(s, e, en->ped_init);
+        if (cfg->ped_mode == 2)
+            for (int i = 0; i < P; ++i) sf_goal(cfg, cfg->env_index_base + e, i, 0u, &en->ped_aux[3 * i], &en->ped_aux[3 * i + 1]);
         en->rx = cfg->spawn_x; en->ry = cfg->spawn_y; en->ryaw = cfg->spawn_yaw;
         memcpy(en->ped_p, en->ped_init, sizeof(double) * 2 * P);
     }
@@ -1633,6 +1777,7 @@ int cno_set_num_threads(int n)
 int cno_reset(cno_sim* s, const uint8_t* mask, double* obs)
 {
     int N = s->cfg.n_envs;
+    g_py2 = s->cfg.py2_round;
 #pragma omp parallel for num_threads(g_threads) schedule(static)
     for (int e = 0; e < N; ++e) {
         if (mask && !mask[e]) continue;
@@ -1645,6 +1790,7 @@ int cno_step(cno_sim* s, const double* action, const int32_t* step_counter, int 
              double* final_obs, double* reward, uint8_t* done, int32_t* topk_idx)
 {
     int N = s->cfg.n_envs, K = s->cfg.k_obstacles;
+    g_py2 = s->cfg.py2_round;
 #pragma omp parallel for num_threads(g_threads) schedule(static)
     for (int e = 0; e < N; ++e) {
         env_t* en = &s->envs[e];
@@ -1670,6 +1816,9 @@ int cno_step(cno_sim* s, const double* action, const int32_t* step_counter, int 
         if (final_obs) memcpy(final_obs + (size_t)e * s->D, o, sizeof(double) * s->D);
         if (d) {
             en->last_return = en->ep_return;
+            en->episodes += 1;
+            en->last_ego_viol = en->ego_viol; en->last_social_viol = en->social_viol;
+            en->last_obst_steps = en->obst_steps; en->last_ep_steps = en->ep_step;
             if (auto_reset == 1) env_reset_flow(s, en, gid, o);
             else if (auto_reset == 2) en->pending_reset = 1;
         }
@@ -1731,6 +1880,7 @@ int cno_ext_call(cno_sim* s, int env, const cno_ext_in* in, const double* ranges
     int32_t idx_local[16];
     int32_t* idx = topk_idx ? topk_idx : idx_local;
     int d = 0;
+    g_py2 = c->py2_round;
     if (c->obs_layout == 1) {
         if (in->is_reset) {
             e->prev_dist = dist3(in->px, in->py, c->goal_x, c->goal_y);
@@ -1793,6 +1943,7 @@ double cno_heading_to_goal(cno_sim* s, int env, double wpx, double wpy, double p
 {
     env_t* e = &s->envs[env];
     e->wpx = wpx; e->wpy = wpy;
+    g_py2 = s->cfg.py2_round;
     return heading_to_goal(&s->cfg, e, px, py, yaw);
 }
 double cno_distance_to_goal(double px, double py, double wpx, double wpy) { return dist3(px, py, wpx, wpy); }
@@ -1834,5 +1985,106 @@ int cno_set_robot(cno_sim* s, int env, double x, double y, double yaw)
 {
     env_t* e = &s->envs[env];
     e->rx = x; e->ry = y; e->ryaw = yaw;
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * State exchange in the PRODUCT's snapshot layout (include/crowdnav.h: CN_SD_*, CN_SI_*, CN_TF_*): lets a test
+ * seed this oracle from a GPU snapshot and step both side by side (tools/bisect_divergence.py), and read the oracle's state
+ * back field by field.  sd[24] f64, si[16] i32, ped_p / ped_v [P][2], trk [trk_cap][12], ped_init / ped_preset [P][2],
+ * ped_aux [P][3].  Any pointer may be NULL.
+ * ---------------------------------------------------------------------------------------- */
+enum { SD_RX = 0, SD_RY, SD_RYAW, SD_RV, SD_RW, SD_CLOCK, SD_WPX, SD_WPY, SD_PREV_DIST, SD_PREV_HEAD, SD_DQ0X, SD_DQ0Y, SD_DQ1X,
+       SD_DQ1Y, SD_TS, SD_BB, SD_EGO, SD_CPROB, SD_EP_RETURN, SD_LAST_RETURN, SD_LAST_EGO_VIOL, SD_LAST_SOCIAL_VIOL,
+       SD_LAST_OBST_STEPS, SD_LAST_EP_STEPS, SD_COUNT = 24 };
+enum { SI_DONE = 0, SI_DQ_LEN, SI_NTRACKS, SI_EGO_VIOL, SI_SOCIAL_VIOL, SI_OBST_STEPS, SI_SUCCESS, SI_FAILURE, SI_EP_STEP, SI_STATUS,
+       SI_NCONF, SI_NENTRIES, SI_CROWD_LO, SI_CROWD_HI, SI_PENDING_RESET, SI_EPISODES, SI_COUNT = 16 };
+enum { TF_PX = 0, TF_PY, TF_DIST, TF_D0X, TF_D0Y, TF_D1X, TF_D1Y, TF_T, TF_SPEED, TF_VX, TF_VY, TF_DQLEN, TF_COUNT = 12 };
+
+int cno_set_state(cno_sim* s, int env, const double* sd, const int32_t* si, const double* ped_p, const double* ped_v,
+                  const double* trk, int trk_cap, const double* ped_init, const double* ped_preset, const double* ped_aux)
+{
+    if (!s || env < 0 || env >= s->cfg.n_envs) return -1;
+    env_t* e = &s->envs[env];
+    const int P = s->cfg.n_peds;
+    if (sd) {
+        e->rx = sd[SD_RX]; e->ry = sd[SD_RY]; e->ryaw = sd[SD_RYAW]; e->rv = sd[SD_RV]; e->rw = sd[SD_RW];
+        e->clock = sd[SD_CLOCK]; e->wpx = sd[SD_WPX]; e->wpy = sd[SD_WPY];
+        e->prev_dist = sd[SD_PREV_DIST]; e->prev_head = sd[SD_PREV_HEAD];
+        e->agent_dq[0].x = sd[SD_DQ0X]; e->agent_dq[0].y = sd[SD_DQ0Y]; e->agent_dq[1].x = sd[SD_DQ1X]; e->agent_dq[1].y = sd[SD_DQ1Y];
+        e->agent_vel_timestep = sd[SD_TS]; e->bb = sd[SD_BB]; e->ego_score_cp = sd[SD_EGO]; e->collision_prob = sd[SD_CPROB];
+        e->ep_return = sd[SD_EP_RETURN]; e->last_return = sd[SD_LAST_RETURN];
+        e->last_ego_viol = (int)sd[SD_LAST_EGO_VIOL]; e->last_social_viol = (int)sd[SD_LAST_SOCIAL_VIOL];
+        e->last_obst_steps = (int)sd[SD_LAST_OBST_STEPS]; e->last_ep_steps = (int)sd[SD_LAST_EP_STEPS];
+    }
+    if (si) {
+        e->done = si[SI_DONE]; e->agent_dq_len = si[SI_DQ_LEN]; e->ntracks = si[SI_NTRACKS];
+        e->ego_viol = si[SI_EGO_VIOL]; e->social_viol = si[SI_SOCIAL_VIOL]; e->obst_steps = si[SI_OBST_STEPS];
+        e->ep_success = si[SI_SUCCESS]; e->ep_failure = si[SI_FAILURE]; e->ep_step = si[SI_EP_STEP]; e->status = si[SI_STATUS];
+        e->n_confirmed = si[SI_NCONF]; e->n_entries = si[SI_NENTRIES];
+        e->crowd_ms = (int64_t)(((uint64_t)(uint32_t)si[SI_CROWD_HI] << 32) | (uint32_t)si[SI_CROWD_LO]);
+        e->pending_reset = si[SI_PENDING_RESET]; e->episodes = si[SI_EPISODES];
+        if (e->ntracks < 0 || e->ntracks > CNO_MAX_TRACKS) return -2;
+    }
+    if (ped_p) memcpy(e->ped_p, ped_p, sizeof(double) * 2 * P);
+    if (ped_v) memcpy(e->ped_v, ped_v, sizeof(double) * 2 * P);
+    if (ped_init) memcpy(e->ped_init, ped_init, sizeof(double) * 2 * P);
+    if (ped_preset) memcpy(e->ped_preset, ped_preset, sizeof(double) * 2 * P);
+    if (ped_aux) memcpy(e->ped_aux, ped_aux, sizeof(double) * 3 * P);
+    if (trk) {
+        if (e->ntracks > trk_cap) return -2;
+        for (int i = 0; i < e->ntracks; ++i) {
+            const double* r = trk + (size_t)i * TF_COUNT;
+            track_t* t = &e->tracks[i];
+            t->pose.x = r[TF_PX]; t->pose.y = r[TF_PY]; t->dist = r[TF_DIST];
+            t->dq[0].x = r[TF_D0X]; t->dq[0].y = r[TF_D0Y]; t->dq[1].x = r[TF_D1X]; t->dq[1].y = r[TF_D1Y];
+            t->t = r[TF_T]; t->speed = r[TF_SPEED]; t->vel.x = r[TF_VX]; t->vel.y = r[TF_VY]; t->dq_len = (int)r[TF_DQLEN];
+            t->id = (s->cfg.risk_mode == 1) ? (int)r[TF_T] : 0;      /* gt mode keeps the pedestrian id in the T slot */
+        }
+    }
+    return 0;
+}
+
+int cno_get_state(const cno_sim* s, int env, double* sd, int32_t* si, double* ped_p, double* ped_v, double* trk, int trk_cap,
+                  double* ped_aux)
+{
+    if (!s || env < 0 || env >= s->cfg.n_envs) return -1;
+    const env_t* e = &s->envs[env];
+    const int P = s->cfg.n_peds;
+    if (sd) {
+        memset(sd, 0, sizeof(double) * SD_COUNT);
+        sd[SD_RX] = e->rx; sd[SD_RY] = e->ry; sd[SD_RYAW] = e->ryaw; sd[SD_RV] = e->rv; sd[SD_RW] = e->rw;
+        sd[SD_CLOCK] = e->clock; sd[SD_WPX] = e->wpx; sd[SD_WPY] = e->wpy;
+        sd[SD_PREV_DIST] = e->prev_dist; sd[SD_PREV_HEAD] = e->prev_head;
+        sd[SD_DQ0X] = e->agent_dq[0].x; sd[SD_DQ0Y] = e->agent_dq[0].y; sd[SD_DQ1X] = e->agent_dq[1].x; sd[SD_DQ1Y] = e->agent_dq[1].y;
+        sd[SD_TS] = e->agent_vel_timestep; sd[SD_BB] = e->bb; sd[SD_EGO] = e->ego_score_cp; sd[SD_CPROB] = e->collision_prob;
+        sd[SD_EP_RETURN] = e->ep_return; sd[SD_LAST_RETURN] = e->last_return;
+        sd[SD_LAST_EGO_VIOL] = e->last_ego_viol; sd[SD_LAST_SOCIAL_VIOL] = e->last_social_viol;
+        sd[SD_LAST_OBST_STEPS] = e->last_obst_steps; sd[SD_LAST_EP_STEPS] = e->last_ep_steps;
+    }
+    if (si) {
+        memset(si, 0, sizeof(int32_t) * SI_COUNT);
+        si[SI_DONE] = e->done; si[SI_DQ_LEN] = e->agent_dq_len; si[SI_NTRACKS] = e->ntracks;
+        si[SI_EGO_VIOL] = e->ego_viol; si[SI_SOCIAL_VIOL] = e->social_viol; si[SI_OBST_STEPS] = e->obst_steps;
+        si[SI_SUCCESS] = e->ep_success; si[SI_FAILURE] = e->ep_failure; si[SI_EP_STEP] = e->ep_step; si[SI_STATUS] = e->status;
+        si[SI_NCONF] = e->n_confirmed; si[SI_NENTRIES] = e->n_entries;
+        si[SI_CROWD_LO] = (int32_t)(uint32_t)((uint64_t)e->crowd_ms & 0xffffffffull);
+        si[SI_CROWD_HI] = (int32_t)(uint32_t)((uint64_t)e->crowd_ms >> 32);
+        si[SI_PENDING_RESET] = e->pending_reset; si[SI_EPISODES] = e->episodes;
+    }
+    if (ped_p) memcpy(ped_p, e->ped_p, sizeof(double) * 2 * P);
+    if (ped_v) memcpy(ped_v, e->ped_v, sizeof(double) * 2 * P);
+    if (ped_aux) memcpy(ped_aux, e->ped_aux, sizeof(double) * 3 * P);
+    if (trk) {
+        memset(trk, 0, sizeof(double) * (size_t)trk_cap * TF_COUNT);
+        for (int i = 0; i < e->ntracks && i < trk_cap; ++i) {
+            double* r = trk + (size_t)i * TF_COUNT;
+            const track_t* t = &e->tracks[i];
+            r[TF_PX] = t->pose.x; r[TF_PY] = t->pose.y; r[TF_DIST] = t->dist;
+            r[TF_D0X] = t->dq[0].x; r[TF_D0Y] = t->dq[0].y; r[TF_D1X] = t->dq[1].x; r[TF_D1Y] = t->dq[1].y;
+            r[TF_T] = (s->cfg.risk_mode == 1) ? (double)t->id : t->t; r[TF_SPEED] = t->speed;
+            r[TF_VX] = t->vel.x; r[TF_VY] = t->vel.y; r[TF_DQLEN] = (double)t->dq_len;
+        }
+    }
     return 0;
 }

@@ -31,7 +31,7 @@ typedef struct cno_config {
     int32_t n_rays;          /* R: lidar samples (360); observation uses R-1 */
     int32_t k_obstacles;     /* K (ENV:55) */
     int32_t max_steps;       /* ENV:91 */
-    int32_t ped_mode;        /* 0 = random-velocity walkers (CROWD:98-126), 1 = constant preset velocities */
+    int32_t ped_mode;        /* 0 = random-velocity walkers (CROWD:98-126), 1 = constant preset velocities, 2 = social force */
     int32_t dt_ms;           /* control period, time.sleep(0.15) ENV:1201 -> 150 */
     int32_t scan_latency_ms; /* virtual /scan wait (harness: 10) */
     int32_t settle_ms;       /* trainer's time.sleep(0.1) after reset, TRAIN:114 -> 100 */
@@ -42,6 +42,8 @@ typedef struct cno_config {
     int32_t geos_untyped_empty; /* 1: GEOS <= 3.8 / shapely <= 1.7 untyped empties at UTL:279,306 (see include/crowdnav.h) */
     int32_t ped_contact;     /* 1: frictionless rigid contact pedestrian-pedestrian and pedestrian-robot */
     int32_t risk_mode;       /* 0: lidar tracker (reference); 1: gt (simulator pedestrians feed A21-A24) */
+    int32_t py2_round;       /* 1: Python-2.7 round(): exact ties away from zero, round(np.float64, n) = the builtin (include/crowdnav.h) */
+    int32_t reserved1;
     int64_t env_index_base;  /* global index of env 0 (multi-GPU sharding) */
     uint64_t seed;
     double room_half;        /* inner half extent of the square room (WORLD:926-1108 -> 1.40) */
@@ -59,6 +61,8 @@ typedef struct cno_config {
     double spawn_x, spawn_y, spawn_yaw; /* launch-file spawn pose */
     double waypoint_radius;  /* 0.3 (ENV:250) */
     double goal_eps;         /* 0.20 (ENV:1285,1303) */
+    /* ped_mode 2: social-force pedestrians (defined in include/crowdnav.h; no reference source) */
+    double sf_tau, sf_A, sf_B, sf_wall_A, sf_wall_B, sf_goal_eps;
 } cno_config;
 
 typedef struct cno_sim cno_sim;
@@ -146,6 +150,14 @@ int    cno_estimate_num_obs_scans(double d, double max_range, double min_range);
 void   cno_raycast(const cno_config* cfg, double rx, double ry, double ryaw,
                    const double* ped_xy, int P, double* ranges);
 double cno_rng_u01(uint64_t seed, int64_t env, uint32_t stream, uint32_t a, uint32_t b);
+
+/* state exchange in the product's snapshot layout (include/crowdnav.h CN_SD_* / CN_SI_* / CN_TF_*) */
+int    cno_set_state(cno_sim* s, int env, const double* sd, const int32_t* si, const double* ped_p, const double* ped_v,
+                     const double* trk, int trk_cap, const double* ped_init, const double* ped_preset, const double* ped_aux);
+int    cno_get_state(const cno_sim* s, int env, double* sd, int32_t* si, double* ped_p, double* ped_v, double* trk, int trk_cap,
+                     double* ped_aux);
+double cno_det_exp(double x);
+void   cno_set_py2_round(int on);   /* for the function-level entry points that take no handle */
 
 /* simulator-only entry points used by oracle/harness (it plays Gazebo for the reference) */
 int    cno_hsim_reset(cno_sim* s, int env);

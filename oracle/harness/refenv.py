@@ -117,6 +117,21 @@ def _py2div(a, b):
     return a / b
 
 
+def py2_round(x, ndigits=0):
+    """Python 2.7's builtin round (floatobject.c `_Py_double_round`): the argument is taken as a C double (so np.float64 goes
+    the same way as float -- Python 3 would dispatch to numpy's multiply / rint / divide), rounded CORRECTLY to `ndigits`
+    decimals with an exact tie going away from zero, and returned as a float.  decimal does the exact arithmetic:
+    Decimal(float) is exact and ROUND_HALF_UP is "ties away from zero"."""
+    import decimal
+    x = float(x)
+    if x != x or x in (float("inf"), float("-inf")):
+        return x
+    q = decimal.Decimal(1).scaleb(-int(ndigits))
+    with decimal.localcontext() as ctx:
+        ctx.prec = 400
+        return float(decimal.Decimal(x).quantize(q, rounding=decimal.ROUND_HALF_UP))
+
+
 class _DivRewriter(ast.NodeTransformer):
     def visit_BinOp(self, node):
         self.generic_visit(node)
@@ -190,8 +205,11 @@ class Harness(object):
         self._install()
         from . import shapely_shim
         shapely_shim.UNTYPED_EMPTY = bool(getattr(c, "geos_untyped_empty", 0))    # cn_config.geos_untyped_empty
-        self.utils = _load_py2("utils", os.path.join(REF_SRC, "utils.py"), {})
-        self.envmod = _load_py2(self.ENV_MODULE, os.path.join(REF_SRC, self.ENV_MODULE + ".py"), {})
+        # cn_config.py2_round: the reference's platform is Python 2.7 (README.md:108-110); its round() differs from Python 3's
+        # on exact ties and on np.float64 arguments.  A module-level `round` shadows the builtin inside the reference's modules.
+        extra = {"round": py2_round} if getattr(c, "py2_round", 0) else {}
+        self.utils = _load_py2("utils", os.path.join(REF_SRC, "utils.py"), dict(extra))
+        self.envmod = _load_py2(self.ENV_MODULE, os.path.join(REF_SRC, self.ENV_MODULE + ".py"), dict(extra))
         for m in (self.utils, self.envmod):
             m.time = self.time_mod
             m.math = self.math_mod

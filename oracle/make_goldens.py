@@ -34,11 +34,64 @@ SEQ_CONFIGS = {
     # get_collision_point gives up at the first candidate segment that misses (UTL:279-289)
     "geos38": (dict(n_peds=60, max_steps=120, seed=15, geos_untyped_empty=1), 3, (0.0, 0.22, -2.0, 2.0)),
 }
+# the reference under Python-2.7 round() (cn_config.py2_round; harness refenv.py2_round), fed by TieSim: sensor data on exact ties
+TIE_CONFIGS = {
+    "py2tie": (dict(n_peds=40, max_steps=60, seed=16, py2_round=1), 3, (0.0, 0.22, -2.0, 2.0)),
+}
 
 
-def gen_seq(name, kw, episodes, arange):
+class TieSim(object):
+    """Plays Gazebo for the harness like oracle.Oracle does, but puts a share of what it hands to the reference EXACTLY on decimal
+    ties -- lidar ranges and robot coordinates on odd multiples of 1/16 (ties of round(x, 3): ENV:324-327, 1025, 1208, UTL:122-123),
+    and on the first calls a pose 0.625 m from the goal (a tie of ENV:255's round(np.float64, 2)) -- so that a Python-2.7 round()
+    (cn_config.py2_round) and a Python-3 one give different runs.  The simulator underneath keeps its own (unsnapped) state: the
+    reference only ever sees what this object returns, and that is what the golden records."""
+
+    def __init__(self, sim, seed):
+        self.sim, self.cfg = sim, sim.cfg
+        self.rng = np.random.default_rng(seed)
+        self.calls = 0
+        self._key, self._snapped = None, None      # one snapped pose per simulator state: the harness reads the pose several times
+
+    def hsim_reset(self, env=0):
+        self.sim.hsim_reset(env)
+
+    def hsim_advance(self, ms, v, w, env=0):
+        self.sim.hsim_advance(ms, v, w, env)
+
+    def hsim_scan(self, env=0):
+        r = self.sim.hsim_scan(env)
+        ties = np.array([0.1875, 0.3125, 0.4375, 0.5625])
+        fin = np.isfinite(r) & (self.rng.uniform(size=r.shape) < 0.35)
+        idx = np.abs(r[fin, None] - ties[None, :]).argmin(1)
+        r[fin] = ties[idx]
+        return r
+
+    def sim_state(self, env=0):
+        robot, pp, pv, rg = self.sim.sim_state(env)
+        key = robot.tobytes()
+        if key != self._key:
+            self._key = key
+            robot = robot.copy()
+            self.calls += 1
+            if self.calls <= 2:
+                robot[0], robot[1] = -0.375, 1.0                     # 0.625 m from the goal (-1, 1): round(0.625, 2) is a tie
+            else:
+                for k in (0, 1):
+                    if self.rng.uniform() < 0.5:
+                        robot[k] = (2.0 * np.floor(robot[k] * 8.0) + 1.0) / 16.0     # an odd multiple of 1/16 nearby
+            self._snapped = robot
+        return self._snapped.copy(), pp, pv, rg
+
+    def get_ped_init(self):
+        return self.sim.get_ped_init()
+
+
+def gen_seq(name, kw, episodes, arange, tie_sim=False):
     cfgkw = dict(n_envs=1, **kw)
     sim = oracle.Oracle(**cfgkw)
+    if tie_sim:
+        sim = TieSim(sim, kw["seed"])
     h = Harness(sim)
     rng = np.random.default_rng(kw["seed"])
     rows = []
@@ -324,6 +377,9 @@ if __name__ == "__main__":
     for name, (kw, eps, ar) in SEQ_CONFIGS.items():
         if not only or name in only:
             gen_seq(name, kw, eps, ar)
+    for name, (kw, eps, ar) in TIE_CONFIGS.items():
+        if not only or name in only:
+            gen_seq(name, kw, eps, ar, tie_sim=True)
     for name, (kw, eps, ar) in ORIG_CONFIGS.items():
         if not only or name in only:
             gen_seq_original(name, kw, eps, ar)

@@ -20,6 +20,7 @@ class CnoConfig(C.Structure):
         ("max_steps", C.c_int32), ("ped_mode", C.c_int32), ("dt_ms", C.c_int32), ("scan_latency_ms", C.c_int32),
         ("settle_ms", C.c_int32), ("ped_cycle_ms", C.c_int32), ("ped_stagger_ms", C.c_int32), ("reserved0", C.c_int32),
         ("obs_layout", C.c_int32), ("geos_untyped_empty", C.c_int32), ("ped_contact", C.c_int32), ("risk_mode", C.c_int32),
+        ("py2_round", C.c_int32), ("reserved1", C.c_int32),
         ("env_index_base", C.c_int64), ("seed", C.c_uint64),
         ("room_half", C.c_double), ("ped_radius", C.c_double), ("ped_vmax", C.c_double),
         ("robot_clearance", C.c_double), ("lidar_min", C.c_double), ("lidar_max", C.c_double),
@@ -27,6 +28,8 @@ class CnoConfig(C.Structure):
         ("min_scan_range", C.c_double), ("goal_x", C.c_double), ("goal_y", C.c_double),
         ("start_x", C.c_double), ("start_y", C.c_double), ("spawn_x", C.c_double), ("spawn_y", C.c_double),
         ("spawn_yaw", C.c_double), ("waypoint_radius", C.c_double), ("goal_eps", C.c_double),
+        ("sf_tau", C.c_double), ("sf_A", C.c_double), ("sf_B", C.c_double), ("sf_wall_A", C.c_double),
+        ("sf_wall_B", C.c_double), ("sf_goal_eps", C.c_double),
     ]
 
 
@@ -53,10 +56,11 @@ class CnoDebug(C.Structure):
 # Reference defaults (SURVEY.md appendix B cites every value).
 DEFAULTS = dict(
     n_envs=1, n_peds=20, n_rays=360, k_obstacles=8, max_steps=1000, ped_mode=0, dt_ms=150, scan_latency_ms=10,
-    settle_ms=100, ped_cycle_ms=0, ped_stagger_ms=100, reserved0=0, obs_layout=0, geos_untyped_empty=0, ped_contact=0, risk_mode=0, env_index_base=0, seed=1234,
+    settle_ms=100, ped_cycle_ms=0, ped_stagger_ms=100, reserved0=0, obs_layout=0, geos_untyped_empty=0, ped_contact=0, risk_mode=0, py2_round=0, reserved1=0, env_index_base=0, seed=1234,
     room_half=1.40, ped_radius=0.0505, ped_vmax=0.2, robot_clearance=0.09, lidar_min=0.08, lidar_max=0.60,
     lidar_span=6.28, lidar_offset_x=-0.032, max_scan_range=0.6, min_scan_range=0.12, goal_x=-1.0, goal_y=1.0,
     start_x=0.75, start_y=-0.75, spawn_x=1.0, spawn_y=-1.0, spawn_yaw=3.14, waypoint_radius=0.3, goal_eps=0.20,
+    sf_tau=0.5, sf_A=0.8, sf_B=0.10, sf_wall_A=1.0, sf_wall_B=0.05, sf_goal_eps=0.10,
 )
 
 
@@ -127,6 +131,10 @@ def lib():
         L.cno_raycast.argtypes = [C.POINTER(CnoConfig), C.c_double, C.c_double, C.c_double, dp, C.c_int, dp]
         L.cno_rng_u01.argtypes = [C.c_uint64, C.c_int64, C.c_uint32, C.c_uint32, C.c_uint32]
         L.cno_rng_u01.restype = C.c_double
+        L.cno_set_state.argtypes = [C.c_void_p, C.c_int, dp, C.c_void_p, dp, dp, dp, C.c_int, dp, dp, dp]
+        L.cno_get_state.argtypes = [C.c_void_p, C.c_int, dp, C.c_void_p, dp, dp, dp, C.c_int, dp]
+        L.cno_det_exp.argtypes = [C.c_double]; L.cno_det_exp.restype = C.c_double
+        L.cno_set_py2_round.argtypes = [C.c_int]; L.cno_set_py2_round.restype = None
         L.cno_hsim_reset.argtypes = [C.c_void_p, C.c_int]
         L.cno_hsim_advance.argtypes = [C.c_void_p, C.c_int, C.c_int32, C.c_double, C.c_double]
         L.cno_hsim_scan.argtypes = [C.c_void_p, C.c_int, dp]
@@ -227,6 +235,23 @@ class Oracle:
                     track_t=np.array(d.track_t)[:n].copy(), track_dqlen=np.array(d.track_dqlen)[:n].copy(),
                     entry_cp=np.array(d.entry_cp)[:d.n_entries].copy(), entry_ego=np.array(d.entry_ego)[:d.n_entries].copy())
 
+    # ---- state exchange in the product's snapshot layout ------------------
+    def set_state(self, env, sd, si, ped_p, ped_v, trk, ped_init=None, ped_preset=None, ped_aux=None):
+        c = lambda a, dt: None if a is None else np.ascontiguousarray(a, dtype=dt)
+        sd, si, ped_p, ped_v, trk = c(sd, np.float64), c(si, np.int32), c(ped_p, np.float64), c(ped_v, np.float64), c(trk, np.float64)
+        ped_init, ped_preset, ped_aux = c(ped_init, np.float64), c(ped_preset, np.float64), c(ped_aux, np.float64)
+        q = lambda a: None if a is None else _dp(a)
+        rc = self.L.cno_set_state(self.h, int(env), q(sd), si.ctypes.data if si is not None else None, q(ped_p), q(ped_v), q(trk),
+                                  int(trk.shape[0]) if trk is not None else 0, q(ped_init), q(ped_preset), q(ped_aux))
+        if rc != 0:
+            raise RuntimeError("cno_set_state failed: %d" % rc)
+
+    def get_state(self, env, trk_cap=MAX_TRACKS):
+        sd = np.zeros(24); si = np.zeros(16, dtype=np.int32); pp = np.zeros((self.P, 2)); pv = np.zeros((self.P, 2))
+        trk = np.zeros((trk_cap, 12)); aux = np.zeros((self.P, 3))
+        self.L.cno_get_state(self.h, int(env), _dp(sd), si.ctypes.data, _dp(pp), _dp(pv), _dp(trk), int(trk_cap), _dp(aux))
+        return dict(sd=sd, si=si, ped_p=pp, ped_v=pv, trk=trk, ped_aux=aux)
+
     # ---- harness-facing simulator access -------------------------------------------------
     def hsim_reset(self, env=0):
         self.L.cno_hsim_reset(self.h, env)
@@ -251,6 +276,25 @@ class Oracle:
 
     def ext_set_done(self, env, done):
         self.L.cno_ext_set_done(self.h, env, int(done))
+
+
+def load_snapshot(path):
+    """An Oracle seeded from a GPU snapshot file (crowdnav.env.VecEnv.save_snapshot): the configuration comes
+    from the file's header, every env's state from its SoA arrays.  Stepping this oracle and the restored GPU handle with the
+    same actions must then agree step for step -- tools/bisect_divergence.py reports the first env / field that does not."""
+    z = np.load(path if str(path).endswith(".npz") else str(path) + ".npz")
+    if str(z["format"]) != "crowdnav-snapshot-1":
+        raise ValueError("%s is not a crowdnav snapshot file" % path)
+    kw = {str(k): float(v) for k, v in zip(z["config_keys"], z["config_vals"])}
+    ints = [n for n, t in CnoConfig._fields_ if t in (C.c_int32, C.c_int64, C.c_uint64)]
+    kw.pop("track_capacity", None)
+    cfg = {k: (int(v) if k in ints else v) for k, v in kw.items()}
+    cfg["seed"] = int(z["config_seed"]); cfg["env_index_base"] = int(z["config_env_index_base"])     # exact 64-bit values
+    o = Oracle(cfg)
+    for e in range(o.N):
+        o.set_state(e, z["sd"][e], z["si"][e], z["ped_p"][e], z["ped_v"][e], z["trk"][e], z["ped_init"][e], z["ped_preset"][e],
+                    z["ped_aux"][e])
+    return o
 
 
 def usable_cpus():

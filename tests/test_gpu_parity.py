@@ -315,6 +315,99 @@ def test_snapshot_restore_replays_bit_exact():
         assert torch.equal(o, o0) and torch.equal(r, r0) and torch.equal(d, d0)
 
 
+def test_snapshot_file_seeds_the_oracle_and_header_is_checked(oracle_mod, tmp_path):
+    """VecEnv.save_snapshot writes header (ABI version, full cn_config) + SoA state; the CPU oracle loaded from
+    that file continues the GPU run step for step -- outputs AND the whole state record, 50 further steps, both reset
+    conventions (tools/bisect_divergence.py) --; load_snapshot restores it into a fresh handle; cn_restore refuses a blob whose
+    header does not match the restoring handle and names the field."""
+    import sys
+    import torch
+    import crowdnav
+    from crowdnav import Config, _abi
+    from crowdnav.env import VecEnv
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from bisect_divergence import bisect
+    for extra, mode in ((dict(), "next"), (dict(n_peds=60, k_obstacles=4, min_scan_range=0.0), "same"), (dict(risk_mode=1), "next"),
+                        (dict(ped_contact=1, n_peds=40), "same")):
+        cfg = Config(n_envs=48, seed=21, max_steps=30, ped_cycle_ms=1400, **extra)
+        env = VecEnv(cfg)
+        env.reset()
+        g = torch.Generator(device="cpu").manual_seed(1)
+        for t in range(37):                      # mid-episode for most envs, a few pending resets in "next" mode
+            act = torch.stack([torch.rand(48, generator=g) * 0.22, torch.rand(48, generator=g) * 4 - 2], 1)
+            env.step(act.cuda(), auto_reset=mode)
+        path = env.save_snapshot(str(tmp_path / ("snap_%s_%d" % (mode, len(extra)))) + ".npz")
+        z = np.load(path)
+        assert int(z["abi_version"]) == _abi.EXPECTED_ABI and "seed" in list(z["config_keys"]) and z["sd"].shape == (48, 24)
+        assert int(z["si"][:, 2].max()) > 0 or cfg.risk_mode == 1         # live tracks in the table
+        assert bisect(path, steps=50, seed=5, auto_reset=mode, verbose=False) is None
+        # the same file restores a fresh handle of the same configuration: both continue identically
+        env2 = VecEnv(cfg)
+        env2.load_snapshot(path)
+        act = torch.stack([torch.rand(48, generator=g) * 0.22, torch.rand(48, generator=g) * 4 - 2], 1).cuda()
+        for _ in range(5):
+            env.step(act, auto_reset=mode); env2.step(act, auto_reset=mode)
+        torch.cuda.synchronize()
+        assert torch.equal(env.obs, env2.obs) and torch.equal(env.done, env2.done) and np.array_equal(env.snapshot(), env2.snapshot())
+    # header checks
+    blob = env.snapshot()
+    other = VecEnv(Config(n_envs=48, seed=22, max_steps=30, ped_cycle_ms=1400, ped_contact=1, n_peds=40))
+    with pytest.raises(crowdnav.CrowdNavError, match="cn_config.seed"):
+        other.restore(blob)
+    other = VecEnv(Config(n_envs=48, seed=21, max_steps=30, ped_cycle_ms=1400, ped_contact=1, n_peds=40, env_index_base=48))
+    with pytest.raises(crowdnav.CrowdNavError, match="cn_config.env_index_base"):
+        other.restore(blob)
+    bad = blob.copy(); bad[0] ^= 0xFF
+    with pytest.raises(crowdnav.CrowdNavError, match="magic"):
+        env.restore(bad)
+    bad = blob.copy(); bad[8] = 3                                     # abi_version field
+    with pytest.raises(crowdnav.CrowdNavError, match="ABI version 3"):
+        env.restore(bad)
+    with pytest.raises(crowdnav.CrowdNavError):
+        env.restore(blob[:blob.size // 2])
+
+
+@pytest.mark.parametrize("risk_mode", [0, 1])
+def test_rollout_parity_social_force_pedestrians(oracle_mod, risk_mode, tmp_path):
+    """cn_config.ped_mode = 2 (row X2, the north star's "per-env pedestrian social-force integration"): cn_env_kernel_sf / _gt_sf
+    (+ _same) against the oracle's restatement -- observation, reward, done, indices through the usual rollout comparison, then
+    pedestrian positions, velocities, goals and goal counters bit for bit through a snapshot (tools/bisect_divergence.py)."""
+    import sys
+    import torch
+    from crowdnav import Config
+    from crowdnav.env import VecEnv
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from bisect_divergence import bisect
+    for mode in (True, "next"):
+        n_done, frac = _compare_rollout(oracle_mod, steps=80, seed=61, reset_mode=mode, n_envs=32, n_peds=20, max_steps=40,
+                                        ped_mode=2, risk_mode=risk_mode)
+        assert n_done > 10 and frac > 0.999
+    # a denser room with stronger forces, more than 64 pedestrians (two lane passes), goals reached all the time
+    cfg = Config(n_envs=24, n_peds=80, n_rays=360, ped_mode=2, risk_mode=risk_mode, seed=62, max_steps=50, room_half=1.8,
+                 sf_A=1.5, sf_B=0.15, sf_goal_eps=0.3, min_scan_range=0.0)
+    env = VecEnv(cfg)
+    env.reset()
+    g = torch.Generator(device="cpu").manual_seed(2)
+    for t in range(20):
+        act = torch.stack([torch.rand(24, generator=g) * 0.22, torch.rand(24, generator=g) * 4 - 2], 1)
+        env.step(act.cuda(), auto_reset="next")
+    path = env.save_snapshot(str(tmp_path / "sf.npz"))
+    z = np.load(path)
+    assert z["ped_aux"][:, :, 2].sum() > 24                    # goals have been reached and re-drawn
+    assert np.abs(z["ped_v"]).max() > 0.02
+    assert bisect(path, steps=40, seed=3, auto_reset="next", verbose=False) is None
+    # the switch is off by default and refuses what it does not support
+    import crowdnav
+    with pytest.raises(crowdnav.CrowdNavError):
+        VecEnv(Config(n_envs=2, ped_mode=2, ped_contact=1))
+    with pytest.raises(crowdnav.CrowdNavError):
+        VecEnv(Config(n_envs=2, ped_mode=2, obs_layout=1))
+    with pytest.raises(crowdnav.CrowdNavError):
+        VecEnv(Config(n_envs=2, ped_mode=2, n_peds=100))        # 8 P doubles of LDS scratch must fit under the end points
+
+
 def test_sharding_is_invariant_to_the_split():
     """Envs are keyed by global index: 2 shards of 16 == 1 handle of 32 (the multi-GPU layout)."""
     import torch
@@ -526,7 +619,7 @@ def test_reference_scenarios_presets(oracle_mod):
     assert open(path).readline().strip().split(",") == st.HEADERS
 
 
-@pytest.mark.parametrize("name", ["train20", "dense100", "eval60", "k4", "geos38"])
+@pytest.mark.parametrize("name", ["train20", "dense100", "eval60", "k4", "geos38", "py2tie"])
 def test_golden_replay_through_the_kernel(name):
     """The kernel fed with EXACTLY what Gazebo/ROS handed the reference in the golden runs (lidar ranges, odom,
     clock, step counter; cn_observe_external) returns what the REFERENCE's own Python returned: observations,
@@ -560,6 +653,19 @@ def test_golden_replay_through_the_kernel(name):
         assert np.allclose(d["wp"], z["wp"][i], rtol=0, atol=1e-15) and abs(d["bb"] - z["bb"][i]) <= 1e-15
         assert tuple(env.counters()[0, :3].cpu().tolist()) == tuple(int(c) for c in z["counters"][i])
     assert n_exact >= 0.995 * len(z["now"])
+    if name == "py2tie":
+        # the golden is the reference under Python-2.7 round() fed with sensor data on exact decimal ties: with the switch off
+        # (Python-3 ties-to-even, numpy rounding of np.float64) the same inputs must give a visibly different run
+        env3 = VecEnv(Config(n_envs=1, **dict(kw, py2_round=0)))
+        env3.enable_f64_obs()
+        differ = 0
+        for i in range(len(z["now"])):
+            odom = [z["px"][i], z["py"][i], z["yaw"][i], z["v"][i], z["w"][i], z["now"][i], z["deque_x"][i], z["deque_y"][i],
+                    z["end_timestep"][i], 0.0]
+            env3.observe_external(z["ranges"][i][None, :], [odom], step_counter=[int(z["step_counter"][i])], is_reset=bool(z["is_reset"][i]))
+            torch.cuda.synchronize()
+            differ += int(not np.array_equal(env3.obs_f64[0].cpu().numpy(), z["obs"][i]))
+        assert differ > 20
 
 
 # ---- obs_layout 1: environment_stage_1_original.py (363 inputs), SURVEY 8f N3 -----------------------------

@@ -24,13 +24,15 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(L, s), "libcrowdnav.so does not export %s" % s
     assert set(syms) == set(crowdnav._abi.EXPORTS)
-    assert L.cn_abi_version() == crowdnav._abi.EXPECTED_ABI == 3
+    assert L.cn_abi_version() == crowdnav._abi.EXPECTED_ABI == 4
 
 
 def test_config_struct_matches_header_and_oracle():
     from crowdnav.config import CnConfig, Config
     from oracle import oracle
-    assert C.sizeof(CnConfig) == C.sizeof(oracle.CnoConfig) == 16 * 4 + 8 + 8 + 19 * 8
+    assert C.sizeof(CnConfig) == C.sizeof(oracle.CnoConfig) == 18 * 4 + 8 + 8 + 25 * 8
+    from crowdnav._abi import CnSnapshotHeader
+    assert C.sizeof(CnSnapshotHeader) == 8 + 6 * 4 + 8 + C.sizeof(CnConfig)      # cn_snapshot_header (include/crowdnav.h)
     assert [f[0].replace("track_capacity", "reserved0") for f in CnConfig._fields_] == [f[0] for f in oracle.CnoConfig._fields_]
     d = Config().as_dict()
     for k, v in oracle.DEFAULTS.items():

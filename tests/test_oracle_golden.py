@@ -7,10 +7,13 @@ import pytest
 from conftest import load_seq
 
 SEQS = ["train20", "dense100", "eval60", "k4", "geos38"]   # geos38: the reference under GEOS <= 3.8 empty-result semantics
+# py2tie: the reference under Python-2.7 round() (cn_config.py2_round), its sensor data placed on exact decimal ties by
+# oracle/make_goldens.py's TieSim -- replay only (the poses it was fed are not the simulator's)
+REPLAY_SEQS = SEQS + ["py2tie"]
 IN_KEYS = ("deque_x", "deque_y", "end_timestep", "px", "py", "yaw", "v", "w", "now", "step_counter", "is_reset")
 
 
-@pytest.mark.parametrize("name", SEQS)
+@pytest.mark.parametrize("name", REPLAY_SEQS)
 def test_sequence_replay_bit_exact(oracle_mod, name):
     z, kw = load_seq(name)
     o = oracle_mod.Oracle(n_envs=1, **kw)
@@ -40,6 +43,36 @@ def test_sequence_replay_bit_exact(oracle_mod, name):
         over_k += n > o.K
     if name in ("dense100", "eval60", "k4", "geos38"):
         assert over_k > 0  # the "keep the K lowest" branch of ENV:882-883 is exercised
+
+
+def test_py2_round_switch_changes_the_run_on_ties(oracle_mod):
+    """The py2tie inputs sit on exact ties (ranges and coordinates on odd multiples of 1/16, a pose 0.625 m from the goal):
+    replayed with Python-3 rounding (py2_round = 0) the run must differ from the reference's Python-2.7 one, starting with
+    ENV:255's round(np.float64(0.625), 2) = 0.63 (Python 2.7) vs 0.62 (numpy) on the very first call."""
+    z, kw = load_seq("py2tie")
+    assert kw["py2_round"] == 1
+    o = oracle_mod.Oracle(n_envs=1, **dict(kw, py2_round=0))
+    differ = 0
+    for i in range(len(z["now"])):
+        inp = {k: (int(z[k][i]) if k in ("step_counter", "is_reset") else float(z[k][i])) for k in IN_KEYS}
+        obs, r, d, idx = o.ext_call(0, z["ranges"][i], **inp)
+        if inp["is_reset"]:
+            o.ext_set_done(0, False)
+        if i == 0:
+            assert obs[360] == 0.62 and z["obs"][0][360] == 0.63
+        differ += int(not np.array_equal(obs, z["obs"][i]))
+    assert differ > 20
+    L = oracle_mod.lib()
+    try:                                    # the rounding primitive itself: exact ties away from zero, everything else unchanged
+        L.cno_set_py2_round(1)
+        for x, nd, want in ((0.0625, 3, 0.063), (-0.0625, 3, -0.063), (0.125, 2, 0.13), (0.3125, 3, 0.313), (2.675, 2, 2.67),
+                            (0.0624999999, 3, 0.062), (-0.375, 2, -0.38), (1.0005, 3, 1.0)):
+            assert L.cno_py_round(x, nd) == want, (x, nd)
+        L.cno_set_py2_round(0)
+        for x, nd, want in ((0.0625, 3, 0.062), (-0.0625, 3, -0.062), (0.125, 2, 0.12), (0.3125, 3, 0.312), (2.675, 2, 2.67)):
+            assert L.cno_py_round(x, nd) == want, (x, nd)
+    finally:
+        L.cno_set_py2_round(0)
 
 
 @pytest.mark.parametrize("name", SEQS)
@@ -264,3 +297,39 @@ def test_realworld_layout_full_simulation_reproduces_reference_run(oracle_mod, n
             obs = obs[0]
             assert r[0] == z["reward"][i] and bool(d[0]) == bool(z["done"][i]), (name, i)
         assert np.abs(obs - z["obs"][i]).max() <= 1e-9, (name, i, np.abs(obs - z["obs"][i]).max())
+
+
+def test_state_exchange_round_trip_and_first_difference(oracle_mod):
+    """SURVEY 8f N4, CPU half: the oracle's state in the product's snapshot layout (cno_get_state / cno_set_state) seeds a
+    second oracle that then continues identically; tools/bisect_divergence.first_state_difference names the field that differs."""
+    import os
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from bisect_divergence import first_state_difference
+    kw = dict(n_envs=6, n_peds=30, seed=4, max_steps=25)
+    a, b = oracle_mod.Oracle(**kw), oracle_mod.Oracle(**kw)
+    a.reset()
+    rng = np.random.default_rng(0)
+    for t in range(40):
+        a.step(np.stack([rng.uniform(0, 0.22, 6), rng.uniform(-2, 2, 6)], 1), auto_reset="next")
+    for e in range(6):
+        st = a.get_state(e)
+        b.set_state(e, st["sd"], st["si"], st["ped_p"], st["ped_v"], st["trk"], a.get_ped_init()[e], None, st["ped_aux"])
+        assert first_state_difference(st, b.get_state(e), e) is None
+    assert a.get_state(0)["si"][15] > 0 and max(a.get_state(e)["si"][2] for e in range(6)) > 0     # episodes finished, live tracks
+    for t in range(30):
+        act = np.stack([rng.uniform(0, 0.22, 6), rng.uniform(-2, 2, 6)], 1)
+        ra, rb = a.step(act, auto_reset="next"), b.step(act, auto_reset="next")
+        assert all(np.array_equal(x, y) for x, y in zip(ra, rb)), t
+    for e in range(6):
+        assert first_state_difference(a.get_state(e), b.get_state(e), e) is None
+    st = a.get_state(2)
+    st["ped_p"][7, 1] += 1e-9
+    assert first_state_difference(st, b.get_state(2), 2)[0] == "ped_p[7].y"
+    st = a.get_state(3)
+    st["sd"][6] += 1.0
+    assert first_state_difference(st, b.get_state(3), 3)[0] == "sd.WPX"
+    st = a.get_state(1)
+    st["si"][3] += 1
+    assert first_state_difference(st, b.get_state(1), 1) == ("si.EGO_VIOL", int(st["si"][3]), int(st["si"][3]) - 1)

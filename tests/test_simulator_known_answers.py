@@ -227,3 +227,120 @@ def test_contact_mode_without_contacts_is_the_plain_simulator(oracle_mod):
         ra, pa, va, _ = a.sim_state(e); rb, pb, vb, _ = b.sim_state(e)
         assert np.allclose(pa, pb, atol=1e-10) and np.array_equal(va, vb)
         assert np.allclose(ra, rb, atol=1e-3)              # the robot's arc is integrated in 10 ms pieces (more accurate)
+
+
+# ---- cn_config.ped_mode = 2: social-force pedestrians (BASELINE north_star; include/crowdnav.h states the model) -------------
+# No reference source (CROWD:98-126 is a random-velocity walker), so the model is pinned by analytic cases: relaxation to the
+# desired speed, antisymmetric pair repulsion, the wall stand-off distance, the goal sequence, and the deterministic exp.
+def _sf_world(oracle_mod, pos, goals, **kw):
+    pos, goals = np.asarray(pos, dtype=np.float64), np.asarray(goals, dtype=np.float64)
+    P = len(pos)
+    cfg = dict(n_envs=1, n_peds=P, ped_mode=2, room_half=6.0, spawn_x=5.5, spawn_y=5.5, spawn_yaw=0.0, seed=77)
+    cfg.update(kw)
+    o = oracle_mod.Oracle(**cfg)
+    o.set_ped_init(pos[None])
+    o.hsim_reset()
+    aux = np.concatenate([goals, np.zeros((P, 1))], 1)
+    o.set_state(0, None, None, None, None, None, ped_aux=aux)
+    L = oracle_mod.lib()
+    v0 = np.array([o.cfg.ped_vmax * (0.5 + 0.5 * L.cno_rng_u01(o.cfg.seed, 0, 4, i, 0)) for i in range(P)])
+    return o, v0
+
+
+def test_det_exp_matches_libm(oracle_mod):
+    L = oracle_mod.lib()
+    xs = np.concatenate([np.linspace(-12.5, 3.0, 40001), [0.0, -1.0, 1.0, -0.5 * math.log(2), 0.5 * math.log(2), -700.0, 700.0]])
+    worst = max(abs(L.cno_det_exp(float(x)) / math.exp(x) - 1.0) for x in xs)
+    assert worst < 4e-16
+    assert L.cno_det_exp(0.0) == 1.0 and L.cno_det_exp(-701.0) == 0.0 and math.isinf(L.cno_det_exp(701.0))
+
+
+def test_social_force_relaxes_to_the_desired_speed(oracle_mod):
+    """One pedestrian, nothing within reach: dv/dt = (v0 e - v) / tau with explicit 10 ms ticks, v_n = v0 (1 - (1 - h / tau)^n)."""
+    o, v0 = _sf_world(oracle_mod, [[-4.0, 0.0]], [[4.0, 0.0]])
+    assert 0.1 <= v0[0] <= 0.2                            # ped_vmax (0.5 + 0.5 u)
+    for n in (1, 10, 50, 300):
+        o.hsim_reset(); o.set_state(0, None, None, None, None, None, ped_aux=[[4.0, 0.0, 0.0]])
+        o.hsim_advance(10 * n, 0.0, 0.0)
+        _, pp, pv, _ = o.sim_state()
+        want = v0[0] * (1.0 - (1.0 - 0.01 / 0.5) ** n)
+        assert abs(pv[0, 0] - want) < 1e-13 and pv[0, 1] == 0.0 and pp[0, 1] == 0.0, n
+    assert abs(pv[0, 0] - v0[0]) < 3e-3 * v0[0]           # 3 s = 6 tau: within 0.3 % of the desired speed
+    # position = h * sum of the velocities (semi-implicit Euler: v first, then x)
+    want_x = -4.0 + 0.01 * sum(v0[0] * (1.0 - 0.98 ** k) for k in range(1, 301))
+    assert abs(pp[0, 0] - want_x) < 1e-12
+
+
+def test_social_force_pair_repulsion_is_antisymmetric_and_has_the_stated_strength(oracle_mod):
+    """Two pedestrians 0.2 m apart, goals straight ahead in +y: after one tick from rest the x-velocities are exactly opposite and
+    equal h A exp((2 r - d) / B); they drift apart until the force has faded, never crossing."""
+    o, v0 = _sf_world(oracle_mod, [[-0.1, 0.0], [0.1, 0.0]], [[-0.1, 5.0], [0.1, 5.0]])
+    c = o.cfg
+    o.hsim_advance(10, 0.0, 0.0)
+    _, pp, pv, _ = o.sim_state()
+    f = c.sf_A * math.exp((2 * c.ped_radius - 0.2) / c.sf_B)
+    assert pv[0, 0] == -pv[1, 0] and abs(pv[1, 0] - f * 0.01) < 1e-15
+    assert np.allclose(pv[:, 1], v0 * 0.01 / c.sf_tau, rtol=0, atol=1e-15)      # the goal term alone drives y
+    gaps = []
+    for _ in range(100):
+        o.hsim_advance(100, 0.0, 0.0)
+        _, pp, pv, _ = o.sim_state()
+        gaps.append(pp[1, 0] - pp[0, 0])
+    gaps = np.array(gaps)
+    assert gaps[0] > 0.2 and gaps.max() > 0.35 and (gaps > 0.2).all()           # pushed apart, never through each other
+    assert (pp[:, 1] > 0.9).all()                                              # ... while both keep walking to their goals
+
+
+def test_social_force_wall_stand_off(oracle_mod):
+    """A pedestrian whose goal lies behind the +x wall stops where the wall's push equals the goal's pull:
+    v0 / tau = A_w exp((r - d) / B_w)  ->  d = r - B_w ln(v0 / (tau A_w))."""
+    o, v0 = _sf_world(oracle_mod, [[1.0, 0.3]], [[9.0, 0.3]], room_half=2.0, spawn_x=-1.8, spawn_y=-1.8)
+    c = o.cfg
+    o.hsim_advance(60000, 0.0, 0.0)
+    _, pp, pv, _ = o.sim_state()
+    d_eq = c.ped_radius - c.sf_wall_B * math.log(v0[0] / (c.sf_tau * c.sf_wall_A))
+    assert abs((2.0 - pp[0, 0]) - d_eq) < 1e-6 and abs(pv[0, 0]) < 1e-7 and abs(pp[0, 1] - 0.3) < 1e-9
+    assert d_eq > c.ped_radius                                                   # it stands off, it is not clamped into the wall
+
+
+def test_social_force_goal_sequence_and_robot_repulsion(oracle_mod):
+    """A goal within sf_goal_eps is replaced by the next one of the pedestrian's counter-based sequence (stream 3, uniform in the
+    room shrunk by 0.1 m); a robot parked next to a pedestrian pushes it away along the line of centres."""
+    o, v0 = _sf_world(oracle_mod, [[0.0, 0.0], [3.0, 3.0]], [[0.05, 0.0], [3.0, -3.0]])
+    L = oracle_mod.lib()
+    c = o.cfg
+    o.hsim_advance(10, 0.0, 0.0)
+    aux = o.get_state(0)["ped_aux"]
+    lo, span = -c.room_half + 0.1, 2 * c.room_half - 0.2
+    assert aux[0, 2] == 1.0 and aux[1, 2] == 0.0                                  # pedestrian 0 was within 0.1 m of its goal
+    assert aux[0, 0] == lo + span * L.cno_rng_u01(c.seed, 0, 3, 0, 2) or abs(aux[0, 0] - (lo + span * L.cno_rng_u01(c.seed, 0, 3, 0, 2))) < 1e-15
+    assert abs(aux[0, 1] - (lo + span * L.cno_rng_u01(c.seed, 0, 3, 0, 3))) < 1e-15
+    assert np.array_equal(aux[1, :2], [3.0, -3.0])
+    # robot 0.2 m to the left of a pedestrian at rest whose goal is straight up: the push is +x
+    o2, _ = _sf_world(oracle_mod, [[0.0, 0.0]], [[0.0, 5.0]], spawn_x=-0.2, spawn_y=0.0)
+    o2.hsim_advance(10, 0.0, 0.0)
+    _, pp, pv, _ = o2.sim_state()
+    f = c.sf_A * math.exp((c.ped_radius + c.robot_clearance - 0.2) / c.sf_B)
+    assert abs(pv[0, 0] - f * 0.01) < 1e-15 and pv[0, 1] > 0.0
+
+
+def test_social_force_crowd_keeps_moving_and_mostly_apart(oracle_mod):
+    """Twenty pedestrians in the training room for 60 s: nobody leaves the room, speeds stay under the 1.3 v0 cap, goals keep
+    being reached, and overlaps (the model has no hard contact) are rare and shallow."""
+    o = oracle_mod.Oracle(n_envs=4, n_peds=20, ped_mode=2, seed=5, max_steps=100000)
+    o.reset()
+    L = oracle_mod.lib()
+    overlap = deep = 0
+    for t in range(375):
+        o.step(np.zeros((4, 2)))
+        for e in range(4):
+            _, pp, pv, _ = o.sim_state(e)
+            assert np.abs(pp).max() <= 1.4 - 0.0505 + 1e-12
+            d = np.hypot(pp[:, None, 0] - pp[None, :, 0], pp[:, None, 1] - pp[None, :, 1]) + np.eye(20)
+            overlap += int((d < 0.101).sum()) // 2; deep += int((d < 0.06).sum()) // 2
+    for e in range(4):
+        _, pp, pv, _ = o.sim_state(e)
+        v0 = np.array([0.2 * (0.5 + 0.5 * L.cno_rng_u01(5, e, 4, i, 0)) for i in range(20)])
+        assert (np.hypot(pv[:, 0], pv[:, 1]) <= 1.3 * v0 + 1e-12).all()
+        assert o.get_state(e)["ped_aux"][:, 2].sum() >= 20        # on average every pedestrian reached a goal
+    assert overlap < 0.02 * 375 * 4 * 190 and deep == 0

@@ -1,0 +1,137 @@
+#!/usr/bin/env python
+"""Step the GPU library and the CPU oracle side by side FROM A SNAPSHOT and report the first env / field that differs
+("snapshot/restore + replay format, so a GPU/CPU divergence can be bisected step by step").
+
+    python tools/bisect_divergence.py state.npz [--steps 50] [--seed 0] [--auto-reset next|same|none]
+
+state.npz is what crowdnav.env.VecEnv.save_snapshot wrote (header: ABI version + the full cn_config; SoA state).  The GPU handle
+is created from the header's configuration and restored from the file (cn_restore checks the header); the oracle is seeded from
+the same arrays (oracle.load_snapshot).  Both are stepped with the same seeded actions; after every step the outputs
+(observation, reward, done, top-K indices) and then the whole state record -- every CN_SD_* / CN_SI_* scalar, pedestrian
+positions and velocities, the live rows of the tracker table -- are compared.  Prints the first difference (step, env, field,
+both values) and exits 1, or "no divergence" and exits 0.  Test infrastructure (it loads the oracle): not part of the product.
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "drl-based-mapless-crowd-navigation-with-perceived-risk_amd"))
+
+SD_NAMES = ["RX", "RY", "RYAW", "RV", "RW", "CLOCK", "WPX", "WPY", "PREV_DIST", "PREV_HEAD", "DQ0X", "DQ0Y", "DQ1X", "DQ1Y", "TS",
+            "BB", "EGO", "CPROB", "EP_RETURN", "LAST_RETURN", "LAST_EGO_VIOL", "LAST_SOCIAL_VIOL", "LAST_OBST_STEPS", "LAST_EP_STEPS"]
+SI_NAMES = ["DONE", "DQ_LEN", "NTRACKS", "EGO_VIOL", "SOCIAL_VIOL", "OBST_STEPS", "SUCCESS", "FAILURE", "EP_STEP", "STATUS", "NCONF",
+            "NENTRIES", "CROWD_LO", "CROWD_HI", "PENDING_RESET", "EPISODES"]
+TF_NAMES = ["PX", "PY", "DIST", "D0X", "D0Y", "D1X", "D1Y", "T", "SPEED", "VX", "VY", "DQLEN"]
+
+
+def first_state_difference(gpu, orc_state, env, risk_mode=0):
+    """gpu: the env's rows of a split snapshot (sd, si, ped_p, ped_v, trk); orc_state: Oracle.get_state(env).
+    Returns None or (field name, gpu value, oracle value).  Slots the two sides legitimately leave different are skipped: the
+    second deque entry of a track that holds one (the oracle keeps a stale value, the kernel zeroes new tracks), rows beyond
+    NTRACKS, the deque fields in gt mode (the table is rebuilt from the pedestrians every step), and the second agent-deque
+    entry while DQ_LEN < 2."""
+    sd_g, si_g = gpu["sd"], gpu["si"]
+    sd_o, si_o = orc_state["sd"], orc_state["si"]
+    for k, name in enumerate(SI_NAMES):
+        if int(si_g[k]) != int(si_o[k]):
+            return ("si." + name, int(si_g[k]), int(si_o[k]))
+    dq_len = int(si_g[1])
+    for k, name in enumerate(SD_NAMES):
+        if name in ("DQ1X", "DQ1Y") and dq_len < 2:
+            continue
+        if name in ("DQ0X", "DQ0Y") and dq_len < 1:
+            continue
+        a, b = float(sd_g[k]), float(sd_o[k])
+        if a != b and not (a != a and b != b):
+            return ("sd." + name, a, b)
+    for name in ("ped_p", "ped_v"):
+        d = np.nonzero(gpu[name] != orc_state[name])
+        if d[0].size:
+            i, c = int(d[0][0]), int(d[1][0])
+            return ("%s[%d].%s" % (name, i, "xy"[c]), float(gpu[name][i, c]), float(orc_state[name][i, c]))
+    if "ped_aux" in gpu and "ped_aux" in orc_state:
+        d = np.nonzero(gpu["ped_aux"] != orc_state["ped_aux"])
+        if d[0].size:
+            i, c = int(d[0][0]), int(d[1][0])
+            return ("ped_aux[%d].%s" % (i, ("goal_x", "goal_y", "goal_counter")[c]), float(gpu["ped_aux"][i, c]),
+                    float(orc_state["ped_aux"][i, c]))
+    nt = int(si_g[2])
+    for t in range(nt):
+        dql = int(gpu["trk"][t, 11])
+        for f, name in enumerate(TF_NAMES):
+            if risk_mode == 1 and name in ("D0X", "D0Y", "D1X", "D1Y", "DQLEN"):
+                continue
+            if name in ("D1X", "D1Y") and dql < 2:
+                continue
+            a, b = float(gpu["trk"][t, f]), float(orc_state["trk"][t, f])
+            if a != b and not (a != a and b != b):
+                return ("trk[%d].%s" % (t, name), a, b)
+    return None
+
+
+def bisect(path, steps=50, seed=0, auto_reset="next", device=0, verbose=True):
+    """Returns None (no divergence within `steps`) or a dict(step, env, field, gpu, oracle)."""
+    import torch
+    from crowdnav import _abi
+    from crowdnav.config import Config
+    from crowdnav.env import VecEnv
+    from oracle import oracle
+    z = np.load(path if str(path).endswith(".npz") else str(path) + ".npz")
+    hd, _ = _abi.split_snapshot(z["blob"])
+    cfgd = _abi.config_to_dict(hd.config)
+    cfgd.pop("reserved1", None)
+    cfg = Config(**{k: v for k, v in cfgd.items() if k in Config.__dataclass_fields__})
+    env = VecEnv(cfg, device=device)
+    env.enable_f64_obs()
+    env.load_snapshot(path)
+    orc = oracle.load_snapshot(path)
+    oracle.set_num_threads()
+    mode = {"none": False, "same": "same", "next": "next"}[auto_reset]
+    rng = np.random.default_rng(seed)
+    N = env.N
+
+    def report(step, e, field, a, b):
+        out = dict(step=step, env=int(e), field=field, gpu=a, oracle=b)
+        if verbose:
+            print("first divergence: step %d, env %d (global %d), %s: gpu %r  oracle %r" % (
+                step, e, cfg.env_index_base + e, field, a, b))
+        return out
+
+    for t in range(steps):
+        act = np.stack([rng.uniform(0, 0.22, N), rng.uniform(-2, 2, N)], 1).astype(np.float32)
+        env.step(torch.from_numpy(act).to(env.device), auto_reset=mode)
+        torch.cuda.synchronize(env.device)
+        oc, rc, dc, ic = orc.step(act.astype(np.float64), auto_reset=mode)
+        for name, g, o in (("done", env.done.cpu().numpy(), dc), ("topk_idx", env.topk_idx.cpu().numpy(), ic),
+                           ("reward", env.reward.cpu().numpy(), rc.astype(np.float32)), ("obs", env.obs_f64.cpu().numpy(), oc)):
+            bad = np.nonzero((g != o) if g.ndim == 1 else (g != o).any(1))[0]
+            if bad.size:
+                e = int(bad[0])
+                if g.ndim == 1:
+                    return report(t, e, name, g[e].item(), o[e].item())
+                c = int(np.nonzero(g[e] != o[e])[0][0])
+                return report(t, e, "%s[%d]" % (name, c), g[e, c].item(), o[e, c].item())
+        _, arrs = _abi.split_snapshot(env.snapshot())
+        for e in range(N):
+            d = first_state_difference({k: arrs[k][e] for k in ("sd", "si", "ped_p", "ped_v", "trk", "ped_aux")},
+                                       orc.get_state(e, trk_cap=arrs["trk"].shape[1]), e, risk_mode=cfg.risk_mode)
+            if d is not None:
+                return report(t, e, "state." + d[0], d[1], d[2])
+    if verbose:
+        print("no divergence in %d steps x %d envs (outputs and full state records equal)" % (steps, N))
+    return None
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("snapshot")
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--auto-reset", default="next", choices=["next", "same", "none"])
+    ap.add_argument("--device", type=int, default=0)
+    a = ap.parse_args()
+    sys.exit(1 if bisect(a.snapshot, a.steps, a.seed, a.auto_reset, a.device) else 0)
