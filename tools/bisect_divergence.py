@@ -30,7 +30,10 @@ TF_NAMES = ["PX", "PY", "DIST", "D0X", "D0Y", "D1X", "D1Y", "T", "SPEED", "VX", 
 
 def first_state_difference(gpu, orc_state, env, risk_mode=0):
     """gpu: the env's rows of a split snapshot (sd, si, ped_p, ped_v, trk); orc_state: Oracle.get_state(env).
-    Returns None or (field name, gpu value, oracle value).  Slots the two sides legitimately leave different are skipped: the
+    Returns None or (field name, gpu value, oracle value).  Everything is compared for equality except the values behind which
+    the two sides run different (documented) libm-class functions -- a track's speed (ENV:745-760: device cn_hypot vs libm hypot,
+    <= 1 ulp apart), the ego score / collision probability computed from it, and the UNROUNDED heading a reset stores as
+    previous_heading (ENV:1244: device cn_atan2_t vs libm atan2) -- which are compared to 1e-12 relative.  Slots the two sides legitimately leave different are skipped: the
     second deque entry of a track that holds one (the oracle keeps a stale value, the kernel zeroes new tracks), rows beyond
     NTRACKS, the deque fields in gt mode (the table is rebuilt from the pedestrians every step), and the second agent-deque
     entry while DQ_LEN < 2."""
@@ -47,6 +50,8 @@ def first_state_difference(gpu, orc_state, env, risk_mode=0):
             continue
         a, b = float(sd_g[k]), float(sd_o[k])
         if a != b and not (a != a and b != b):
+            if name in ("EGO", "CPROB", "PREV_HEAD") and abs(a - b) <= 1e-12 * max(abs(a), abs(b)):
+                continue
             return ("sd." + name, a, b)
     for name in ("ped_p", "ped_v"):
         d = np.nonzero(gpu[name] != orc_state[name])
@@ -69,6 +74,8 @@ def first_state_difference(gpu, orc_state, env, risk_mode=0):
                 continue
             a, b = float(gpu["trk"][t, f]), float(orc_state["trk"][t, f])
             if a != b and not (a != a and b != b):
+                if name == "SPEED" and abs(a - b) <= 1e-12 * max(abs(a), abs(b)):
+                    continue
                 return ("trk[%d].%s" % (t, name), a, b)
     return None
 
