@@ -42,8 +42,12 @@ class EpisodeStats:
         self.rows.append([len(self.rows) + 1, bool(success), bool(failure), float(reward), int(steps), float(ego),
                           float(social), float(timelapse)])
 
-    def add_from_counters(self, c, episode_return, timelapse=0.0):
-        """One row from an env's cn_get_counters record taken after the launch in which it finished."""
+    def add_from_counters(self, c, episode_return, timelapse=None, step_seconds=0.16):
+        """One row from an env's cn_get_counters record taken after the launch in which it finished.  timelapse: TRAIN:141's
+        `time.time() - start_time`; by default the episode's own (virtual) duration, steps x (time.sleep(0.15) + the /scan
+        wait) -- what the reference measures when it is not slowed down by its host."""
+        if timelapse is None:
+            timelapse = int(c[13]) * step_seconds
         seen = int(c[12])
         ego = 1.0 - int(c[10]) * 1.0 / seen if seen else float("nan")      # ENV:1277-1283 (ZeroDivisionError there)
         soc = 1.0 - int(c[11]) * 1.0 / seen if seen else float("nan")      # ENV:1269-1275
@@ -131,6 +135,7 @@ def evaluate(env, agent, episodes_per_env=1, max_launches=100000):
     stats = EpisodeStats()
     env.reset()
     obs = env.obs
+    step_s = (env.cfg.dt_ms + env.cfg.scan_latency_ms) / 1000.0           # one Env.step in the env's own clock
     finished = torch.zeros(env.N, dtype=torch.int64, device=obs.device)   # per-env count of recorded episodes
     launches = 0
     while int(finished.min().item()) < episodes_per_env and launches < max_launches:
@@ -141,7 +146,7 @@ def evaluate(env, agent, episodes_per_env=1, max_launches=100000):
         if bool(take.any()):
             c = env.counters().cpu(); ret = env.returns()[0].cpu()
             for e in torch.nonzero(take.cpu()).flatten().tolist():
-                stats.add_from_counters(c[e], ret[e].item())
+                stats.add_from_counters(c[e], ret[e].item(), step_seconds=step_s)      # timelapse = the episode's duration (TRAIN:141)
             finished += take.to(finished.dtype)
     return stats
 

@@ -61,6 +61,15 @@ class DeviceReplay:
         self.pos = (self.pos + n) % self.cap
         self.size = min(self.cap, self.size + n)
 
+    def add_masked(self, s, a, r, s2, d, keep):
+        """add() for the rows where `keep` (bool [n]) is set -- the others are not transitions (an env's reset launch under the
+        next-step reset convention).  One host read of the count per call."""
+        k = int(keep.sum().item())
+        if k == s.shape[0]:
+            return self.add(s, a, r, s2, d)
+        if k:
+            self.add(s[keep], a[keep], r[keep], s2[keep], d[keep])
+
     def sample(self, batch):
         idx = torch.randint(0, self.size, (batch,), device=self.s.device)
         return self.s[idx], self.a[idx], self.r[idx], self.s2[idx], self.d[idx]

@@ -6,9 +6,11 @@
 What it keeps from the reference loop: Agent hyper-parameters (TRAIN:62-72), exploration noise sigma = 1.0 with the
 clip to v in [0, 0.22], w in [-2, 2], 1-based per-env step counters, `learn()` only once the replay holds more than a
 batch, target-network checkpoints named td3_{actor,critic1,critic2}_model_ep<N>.pt, one CSV row per finished episode
-(utils.record_data schema).  What is batched: N envs step per launch with same-call auto-reset, each launch stores N
-transitions (terminal transitions keep the observation Env.step returned, `final_obs`), and `--updates` TD3 updates
-of `--batch` samples follow each launch (the reference does one update of 128 per single env step)."""
+(utils.record_data schema).  What is batched: N envs step per launch with the NEXT-STEP reset convention (the fast kernel,
+one observation per wavefront: a finished env spends its next launch on Env.reset, and that launch is not a transition --
+it is masked out of the replay; the observation a finished env returns is the terminal one, so it is the transition's
+s' as it stands), and `--updates` TD3 updates of `--batch` samples follow each launch (the reference does one update of
+128 per single env step)."""
 import argparse
 import os
 import time
@@ -59,11 +61,15 @@ def train(a):
     ret_w = 0.0
     next_ckpt = a.checkpoint_every
     log = open(os.path.join(a.out, "progress.txt"), "a")
+    resetting = torch.zeros(env.N, dtype=torch.bool, device=obs.device)   # envs whose NEXT launch is their Env.reset
+    env_steps = 0
     for it in range(1, a.launches + 1):
         act = agent.act_fused(obs, add_noise=True)                     # TD3:196-223, sigma = 1.0, clipped
         prev = obs.clone()
-        obs, reward, done = env.step(act, auto_reset="same", want_final=True)
-        agent.memory.add(prev, act, reward, env.final_obs, done)        # TRAIN:129-131
+        obs, reward, done = env.step(act, auto_reset="next")
+        agent.memory.add_masked(prev, act, reward, obs, done, ~resetting)   # TRAIN:129-131; s' of a finished env = its terminal obs
+        env_steps += env.N - int(resetting.sum().item())
+        resetting = done.bool().clone()
         if len(agent.memory) > a.batch:
             for u in range(a.updates):
                 agent.learn(it * a.updates + u)                          # TRAIN:132-136
@@ -83,7 +89,7 @@ def train(a):
                 next_ckpt += a.checkpoint_every
         if it % a.log_every == 0 and done_w:
             line = "launch %6d  env-steps %10d  episodes %8d  success %.3f  mean return %8.1f  replay %8d  %.0f s" % (
-                it, it * env.N, episodes, succ_w / done_w, ret_w / done_w, len(agent.memory), time.time() - t0)
+                it, env_steps, episodes, succ_w / done_w, ret_w / done_w, len(agent.memory), time.time() - t0)
             print(line, flush=True); log.write(line + "\n"); log.flush()
             succ_w = done_w = 0; ret_w = 0.0
     agent.save(a.out, episodes)

@@ -2057,15 +2057,31 @@ __device__ __forceinline__ double compute_reward(KP p, const Poly& pg, EnvRegs& 
 
 }  // namespace
 
-template <bool EXT, bool TWO, int LAYOUT, bool GT = false, int SIM = 0>
-__device__ __forceinline__ void env_kernel_body()
+// `env`, `lane`: this wavefront's environment and lane; `smem`: its LDS working set (cn_lds_bytes).  The per-launch kernels pass
+// blockIdx.x / threadIdx.x / the block's dynamic LDS; the fused rollout kernel (FUSED, cn_rollout_kernel below) runs 16 of these per
+// workgroup, `t` steps into its launch, with the step's outputs going to slot t of the caller's trajectory buffers.
+template <bool EXT, bool TWO, int LAYOUT, bool GT = false, int SIM = 0, bool FUSED = false>
+__device__ __forceinline__ void env_kernel_body(const int env, const int lane, char* const smem, const long long t = 0)
 {
     KP p = (KP)__builtin_amdgcn_kernarg_segment_ptr();
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int env = blockIdx.x, lane = threadIdx.x;
-    if (env >= p->N) return;
-    if (p->mode == CN_MODE_RESET && p->mask && !p->mask[env]) return;
+    if constexpr (FUSED) {
+        // Inside the rollout kernel's step loop everything below is loop-invariant as far as the compiler can see, and it hoists
+        // it: ~100 kernel parameters and every lane-derived mask would stay live across the whole step (350 VGPR spills, 1 KB of
+        // scratch per lane).  Laundering the kernarg pointer through an empty asm once per step keeps the loads next to their uses.
+        unsigned long long pp = (unsigned long long)p;
+        asm volatile("" : "+s"(pp));
+        p = (KP)pp;
+    }
+    if constexpr (!FUSED) {
+        if (env >= p->N) return;
+        if (p->mode == CN_MODE_RESET && p->mask && !p->mask[env]) return;
+    }
     const int R = p->R, n = R - 1, P = p->P, K = p->K;
+    // where this step's outputs go: the caller's buffers, or (FUSED) slot t of its trajectory buffers (stride 0 = in place)
+    auto io_obs = [&]() -> float* { if constexpr (FUSED) return p->obs + (size_t)((t + 1) * p->roll_obs_stride); else return p->obs; };
+    auto io_reward = [&]() -> float* { if constexpr (FUSED) return p->reward + (size_t)(t * p->roll_reward_stride); else return p->reward; };
+    auto io_done = [&]() -> uint8_t* { if constexpr (FUSED) return p->done + (size_t)(t * p->roll_done_stride); else return p->done; };
+    auto io_topk = [&]() -> int32_t* { if constexpr (FUSED) return p->topk_idx ? p->topk_idx + (size_t)(t * p->roll_topk_stride) : nullptr; else return p->topk_idx; };
 
     Lds L;
     RwLds RQ = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -2163,8 +2179,8 @@ __device__ __forceinline__ void env_kernel_body()
         if (p->mode == CN_MODE_STEP && p->auto_reset == 2 && e.pending) {
             do_reset = true;
             e.pending = 0;
-            if (lane == 0) { p->reward[env] = 0.0f; p->done[env] = 0; }
-            if (p->topk_idx && lane < K) p->topk_idx[(size_t)env * K + lane] = -1;
+            if (lane == 0) { io_reward()[env] = 0.0f; io_done()[env] = 0; }
+            if (io_topk() && lane < K) io_topk()[(size_t)env * K + lane] = -1;
         }
         int sc = 0;
         float* fin = nullptr;
@@ -2238,9 +2254,9 @@ __device__ __forceinline__ void env_kernel_body()
         }
         CN_SYNC();
         if (ph_obs) {
-            if constexpr (LAYOUT == 1) observe_original<EXT>(p, e, L, env, lane, sc, p->obs, fin, p->obs_f64, &done);
-            else if constexpr (LAYOUT == 2) observe_realworld<EXT>(p, pg, e, L, RQ, env, lane, sc, p->obs, fin, p->obs_f64, &done);
-            else observe<EXT, GT>(p, pg, e, L, env, lane, sc, p->obs, fin, p->obs_f64, &done, have_trig, trig);
+            if constexpr (LAYOUT == 1) observe_original<EXT>(p, e, L, env, lane, sc, io_obs(), fin, p->obs_f64, &done);
+            else if constexpr (LAYOUT == 2) observe_realworld<EXT>(p, pg, e, L, RQ, env, lane, sc, io_obs(), fin, p->obs_f64, &done);
+            else observe<EXT, GT>(p, pg, e, L, env, lane, sc, io_obs(), fin, p->obs_f64, &done, have_trig, trig);
         } else if constexpr (EXT) {
             // Env.compute_reward(state, step_counter, done) on its own (ENV:1046): heading and distance are state[n], state[n+1]
             // (LAYOUT 1: state[-2], state[-1] are what ORIG:324-330 reads), `done` is the caller's
@@ -2249,12 +2265,12 @@ __device__ __forceinline__ void env_kernel_body()
                 const int src = (LAYOUT == 1) ? n + lane : n + (lane & 1);
                 L.tail[lane] = p->obs_f64 ? p->obs_f64[(size_t)env * D_ + src] : (double)p->obs[(size_t)env * D_ + src];
             }
-            done = p->done[env] ? 1 : 0;
+            done = io_done()[env] ? 1 : 0;
             CN_SYNC();
         }
         if (!do_reset && !ph_rew) {
-            if (lane == 0) p->done[env] = (uint8_t)done;           // get_state returns (state, self.done) (ENV:1044)
-            if (ph_obs && p->topk_idx && lane < K) p->topk_idx[(size_t)env * K + lane] = LAYOUT != 0 ? -1 : L.kidx[lane];
+            if (lane == 0) io_done()[env] = (uint8_t)done;           // get_state returns (state, self.done) (ENV:1044)
+            if (ph_obs && io_topk() && lane < K) io_topk()[(size_t)env * K + lane] = LAYOUT != 0 ? -1 : L.kidx[lane];
         } else
         if (!do_reset) {
             double r;
@@ -2263,10 +2279,10 @@ __device__ __forceinline__ void env_kernel_body()
             else r = compute_reward(p, pg, e, L, lane, done);
             e.ep_ret += r;
             if (lane == 0) {
-                p->reward[env] = (float)r;
-                p->done[env] = (uint8_t)done;
+                io_reward()[env] = (float)r;
+                io_done()[env] = (uint8_t)done;
             }
-            if (ph_obs && p->topk_idx && lane < K) p->topk_idx[(size_t)env * K + lane] = LAYOUT != 0 ? -1 : L.kidx[lane];
+            if (ph_obs && io_topk() && lane < K) io_topk()[(size_t)env * K + lane] = LAYOUT != 0 ? -1 : L.kidx[lane];
             if (done) {
                 if (!ext) { e.rv = 0.0; e.rw = 0.0; }             // pub_cmd_vel.publish(Twist()) (ENV:1160)
                 e.last_ret = e.ep_ret;
@@ -2297,8 +2313,8 @@ __device__ __forceinline__ void env_kernel_body()
     if (p->mode == CN_MODE_STEP && p->auto_reset == 2 && e.pending) {
         need_reset = true;
         e.pending = 0;
-        if (lane == 0) { p->reward[env] = 0.0f; p->done[env] = 0; }
-        if (p->topk_idx && lane < K) p->topk_idx[(size_t)env * K + lane] = -1;
+        if (lane == 0) { io_reward()[env] = 0.0f; io_done()[env] = 0; }
+        if (io_topk() && lane < K) io_topk()[(size_t)env * K + lane] = -1;
     } else if (p->mode == CN_MODE_STEP || p->mode == CN_MODE_EXT_STEP) {
         // ---- Env.step (ENV:1164-1225), continuous mode ---------------------------------------------
         e.ep_step += 1;
@@ -2348,10 +2364,10 @@ __device__ __forceinline__ void env_kernel_body()
         }
         e.ep_ret += r;
         if (lane == 0) {
-            p->reward[env] = (float)r;
-            p->done[env] = (uint8_t)done;
+            io_reward()[env] = (float)r;
+            io_done()[env] = (uint8_t)done;
         }
-        if (p->topk_idx && lane < K) p->topk_idx[(size_t)env * K + lane] = LAYOUT != 0 ? -1 : L.kidx[lane];
+        if (io_topk() && lane < K) io_topk()[(size_t)env * K + lane] = LAYOUT != 0 ? -1 : L.kidx[lane];
         if (done) {
             if (!ext) { e.rv = 0.0; e.rw = 0.0; }             // pub_cmd_vel.publish(Twist()) (ENV:1160)
             e.last_ret = e.ep_ret;
@@ -2437,30 +2453,30 @@ __device__ __forceinline__ void env_kernel_body()
 #else
 #define CN_HOT_BOUNDS __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
 #endif
-extern "C" __global__ void CN_HOT_BOUNDS cn_env_kernel(CnKParams p) { env_kernel_body<false, false, 0>(); }
-extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_same(CnKParams p) { env_kernel_body<false, true, 0>(); }
-extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_ext(CnKParams p) { env_kernel_body<true, false, 0>(); }
+extern "C" __global__ void CN_HOT_BOUNDS cn_env_kernel(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, false, 0>(blockIdx.x, threadIdx.x, cn_smem); }
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_same(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, true, 0>(blockIdx.x, threadIdx.x, cn_smem); }
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_ext(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<true, false, 0>(blockIdx.x, threadIdx.x, cn_smem); }
 // risk_mode gt: the perceived-risk features from the simulator's own pedestrians (no segmentation, no tracker)
-extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_gt(CnKParams p) { env_kernel_body<false, false, 0, true>(); }
-extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_gt_same(CnKParams p) { env_kernel_body<false, true, 0, true>(); }
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_gt(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, false, 0, true>(blockIdx.x, threadIdx.x, cn_smem); }
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_gt_same(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, true, 0, true>(blockIdx.x, threadIdx.x, cn_smem); }
 // ped_contact = 1: the simulator with rigid contacts (10 ms physics ticks); separate instantiations keep the default kernels lean
-extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_ct(CnKParams p) { env_kernel_body<false, false, 0, false, 1>(); }
-extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_ct_same(CnKParams p) { env_kernel_body<false, true, 0, false, 1>(); }
-extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_gt_ct(CnKParams p) { env_kernel_body<false, false, 0, true, 1>(); }
-extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_gt_ct_same(CnKParams p) { env_kernel_body<false, true, 0, true, 1>(); }
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_ct(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, false, 0, false, 1>(blockIdx.x, threadIdx.x, cn_smem); }
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_ct_same(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, true, 0, false, 1>(blockIdx.x, threadIdx.x, cn_smem); }
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_gt_ct(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, false, 0, true, 1>(blockIdx.x, threadIdx.x, cn_smem); }
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_gt_ct_same(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, true, 0, true, 1>(blockIdx.x, threadIdx.x, cn_smem); }
 // ped_mode = 2: social-force pedestrians (10 ms physics ticks), for both risk modes
-extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_sf(CnKParams p) { env_kernel_body<false, false, 0, false, 2>(); }
-extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_sf_same(CnKParams p) { env_kernel_body<false, true, 0, false, 2>(); }
-extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_gt_sf(CnKParams p) { env_kernel_body<false, false, 0, true, 2>(); }
-extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_gt_sf_same(CnKParams p) { env_kernel_body<false, true, 0, true, 2>(); }
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_sf(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, false, 0, false, 2>(blockIdx.x, threadIdx.x, cn_smem); }
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_sf_same(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, true, 0, false, 2>(blockIdx.x, threadIdx.x, cn_smem); }
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_gt_sf(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, false, 0, true, 2>(blockIdx.x, threadIdx.x, cn_smem); }
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_gt_sf_same(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, true, 0, true, 2>(blockIdx.x, threadIdx.x, cn_smem); }
 // obs_layout 2 (environment_stage_1_nobonus_realworld.py): the 370-input physical-robot variant
-extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_rw(CnKParams p) { env_kernel_body<false, false, 2>(); }
-extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_rw_same(CnKParams p) { env_kernel_body<false, true, 2>(); }
-extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_rw_ext(CnKParams p) { env_kernel_body<true, false, 2>(); }
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_rw(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, false, 2>(blockIdx.x, threadIdx.x, cn_smem); }
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_rw_same(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, true, 2>(blockIdx.x, threadIdx.x, cn_smem); }
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_rw_ext(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<true, false, 2>(blockIdx.x, threadIdx.x, cn_smem); }
 // obs_layout 1 (environment_stage_1_original.py): same physics and lidar, no tracker
-extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_orig(CnKParams p) { env_kernel_body<false, false, 1>(); }
-extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_orig_same(CnKParams p) { env_kernel_body<false, true, 1>(); }
-extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_orig_ext(CnKParams p) { env_kernel_body<true, false, 1>(); }
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_orig(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, false, 1>(blockIdx.x, threadIdx.x, cn_smem); }
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_orig_same(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, true, 1>(blockIdx.x, threadIdx.x, cn_smem); }
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_orig_ext(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<true, false, 1>(blockIdx.x, threadIdx.x, cn_smem); }
 
 // cn_create: bbox_size() at the spawn pose, evaluated once by the same device code the step kernel would run
 extern "C" __global__ void __launch_bounds__(64) cn_bbox_kernel(CnKParams pv, double* out)
@@ -2520,114 +2536,147 @@ extern "C" __global__ void cn_policy_tail_kernel(const float* __restrict__ logit
 // ---- fused TD3 actor: 3 x Linear(256) + ReLU + output stage in ONE launch (the caller of the hot path, A33) -------
 // Actor.forward (TD3:96-106) + Agent.act's noise and clip (TD3:209-215) for a tile of 16 environments per workgroup,
 // on the f32-input matrix cores: v_mfma_f32_16x16x4_f32 (exact f32: a k-ordered fmaf chain, same precision as the
-// reference's fp32 PyTorch actor).  Lane l feeds A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15]; the four
-// column tiles of a wave interleave their columns (col = 64*wave + 4*j + t) so one 16-byte load of the K-major
-// weights feeds all four MFMAs.  Activations never leave LDS; weights stream from L2 (670 KB, shared by all tiles).
+// reference's fp32 PyTorch actor).  Lane l feeds A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15].
+// Round 3: every wave runs the FULL K range of its own 256 / NW columns (NW = 8 waves: two interleaved column tiles per wave,
+// col = 32 wave + 2 j + t, one 8-byte load of the K-major weights feeds both MFMAs), so there are no K-split partial sums
+// to park in LDS and re-add: the tile needs X [16][Dp + 1] and one hidden buffer [16][257] -- 42 KB instead of 108 KB, 512
+// threads instead of 1024 -- which is what lets an actor workgroup sit on a CU NEXT TO a dozen environment wavefronts
+// (rollout_groups: one group's actor overlaps the others' env steps; before, it had to wait for 108 KB of LDS to drain).
+// Activations never leave LDS; weights stream from L2 (670 KB, shared by all tiles).
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define ACT_H 256
 #define ACT_M 16
-#define ACT_THREADS 1024
+#define ACT_THREADS 512            /* cn_actor_kernel: 8 waves */
+#define ROLL_THREADS 1024          /* cn_rollout_kernel: 16 waves = 16 environments */
 
-// One wave's share of a layer: the K range [k_begin, k_end) (multiples of 4) of the four interleaved column tiles
-// col = 64 * cw + 4 * j + t, accumulated into `part` [16][ldo] WITHOUT bias (the quarters are summed in a fixed order after).
-// A workgroup is 16 waves = 4 column groups x 4 K quarters: a tile of 16 envs is one workgroup on one CU whatever the batch,
-// so the kernel's duration is this chain's latency, and four waves per SIMD (instead of one) both quarter the chain and
-// cover each other's L2 / LDS waits (27 us -> see DESIGN.md for a 4096-env batch; the MFMA floor of a 16-env tile is 9 us).
-__device__ __forceinline__ void actor_partial(const float* __restrict__ A, int lda, int k_begin, int k_end,
-                                              const float* __restrict__ WT, float* __restrict__ part, int ldo, int cw, int lane)
+// U k-steps (4 k each) of this lane's weight operands: B[k = 4 u + (lane >> 4)][this wave's TPW interleaved columns]
+template <int TPW, int U> struct ActW { float b[U][TPW]; };
+template <int TPW, int U>
+__device__ __forceinline__ void actor_wload(ActW<TPW, U>& w, const float* __restrict__ bp, int k0)
+{
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        if constexpr (TPW == 2) { const float2 v = *reinterpret_cast<const float2*>(bp + (size_t)(k0 + 4 * u) * ACT_H); w.b[u][0] = v.x; w.b[u][1] = v.y; }
+        else w.b[u][0] = bp[(size_t)(k0 + 4 * u) * ACT_H];
+    }
+}
+// this lane's weight pointer: row (lane >> 4) of WT, first of the wave's columns
+template <int TPW> __device__ __forceinline__ const float* actor_wptr(const float* __restrict__ WT, int wave, int lane)
+{
+    return WT + (size_t)(lane >> 4) * ACT_H + 16 * TPW * wave + TPW * (lane & 15);
+}
+
+// One layer for this wave's columns: out[r][c] = relu(sum_k A[r][k] WT[k][c] + bias[c]), K = multiple of 4, k ascending.
+// TPW = column tiles per wave (2 for 8 waves, 1 for 16): col = 16 TPW wave + TPW j + t.  `first`: the weights of the first
+// block, loaded by the caller BEFORE the barrier that releases A (their L2 round trip overlaps the staging / the previous
+// layer's tail).  The loop keeps the NEXT block of U k-steps in flight while this block's TPW U MFMAs issue: an L2 hit takes
+// ~1.5 k cycles, so the distance has to be worth that many cycles of matrix-core work (U = 8: 8 TPW MFMAs x 32 cycles x the 2-4
+// waves of the SIMD); with U = 4 every block waited for its loads and the tile took 22 us against an MFMA floor of 8.7.
+template <int TPW, int U>
+__device__ __forceinline__ void actor_layer(const float* __restrict__ A, int lda, int K, const float* __restrict__ WT,
+                                            const float* __restrict__ bias, float* __restrict__ out, int ldo, int wave, int lane,
+                                            const ActW<TPW, U>& first)
 {
     const int ai = lane & 15, ak = lane >> 4;
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+    const int colb = 16 * TPW * wave + TPW * ai;
+    f32x4 acc[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float* ap = A + ai * lda + ak;
-    const float* bp = WT + (size_t)ak * ACT_H + 64 * cw + 4 * ai;
-    // Software pipeline: the 16-byte weight loads of the NEXT block of U k-steps are in flight while the 4 U MFMAs of the
-    // current block issue.
-    constexpr int U = 4;
-    float4 bcur[U], bnxt[U];
-    const int nblk = (k_end - k_begin) / (4 * U), tail0 = k_begin + nblk * 4 * U;
-    if (nblk > 0) {
+    const float* bp = actor_wptr<TPW>(WT, wave, lane);
+    // two register blocks, ping-pong: block b's MFMAs run on one while the other receives block b + 1 (a copy `cur = nxt` at the
+    // end of an iteration would wait for the loads it is supposed to hide).  The scheduling barriers keep the compiler from
+    // sinking the loads below the MFMAs.
+    ActW<TPW, U> w0 = first, w1;
+    const int nblk = K / (4 * U), tail0 = nblk * 4 * U;
+    auto mma = [&](const ActW<TPW, U>& w, int k0) {
+        float a[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) bcur[u] = *reinterpret_cast<const float4*>(bp + (size_t)(k_begin + 4 * u) * ACT_H);
-    }
-    for (int blk = 0; blk < nblk; ++blk) {
-        const int k0 = k_begin + blk * 4 * U;
-        if (blk + 1 < nblk) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) bnxt[u] = *reinterpret_cast<const float4*>(bp + (size_t)(k0 + 4 * U + 4 * u) * ACT_H);
-        }
+        for (int u = 0; u < U; ++u) a[u] = ap[k0 + 4 * u];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const float a = ap[k0 + 4 * u];
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bcur[u].x, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bcur[u].y, acc1, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bcur[u].z, acc2, 0, 0, 0);
-            acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bcur[u].w, acc3, 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], w.b[u][t], acc[t], 0, 0, 0);
         }
-#pragma unroll
-        for (int u = 0; u < U; ++u) bcur[u] = bnxt[u];
+    };
+    for (int blk = 0; blk < nblk; blk += 2) {
+        if (blk + 1 < nblk) actor_wload<TPW, U>(w1, bp, (blk + 1) * 4 * U);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(w0, blk * 4 * U);
+        __builtin_amdgcn_sched_barrier(0);
+        if (blk + 1 < nblk) {
+            if (blk + 2 < nblk) actor_wload<TPW, U>(w0, bp, (blk + 2) * 4 * U);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(w1, (blk + 1) * 4 * U);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
-    for (int k0 = tail0; k0 < k_end; k0 += 4) {
+    for (int k0 = tail0; k0 < K; k0 += 4) {
         const float a = ap[k0];
-        const float4 b = *reinterpret_cast<const float4*>(bp + (size_t)k0 * ACT_H);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.x, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.y, acc1, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.z, acc2, 0, 0, 0);
-        acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.w, acc3, 0, 0, 0);
-    }
-    const int colb = 64 * cw + 4 * ai, rowb = ak * 4;   // C/D: col = lane & 15, row = (lane >> 4) * 4 + reg
+        ActW<TPW, 1> wt;
+        actor_wload<TPW, 1>(wt, bp, k0);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        float* o = part + (rowb + r) * ldo + colb;
-        o[0] = acc0[r]; o[1] = acc1[r]; o[2] = acc2[r]; o[3] = acc3[r];
+        for (int t = 0; t < TPW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wt.b[0][t], acc[t], 0, 0, 0);
+    }
+    const int rowb = ak * 4;                            // C/D: col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const float bv = bias[colb + t];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[(rowb + r) * ldo + colb + t] = fmaxf(acc[t][r] + bv, 0.f);
     }
 }
 
-// H[r][c] = relu(((P0 + P1) + (P2 + P3))[r][c] + bias[c]): the K quarters in a fixed order, 4 elements per thread
-__device__ __forceinline__ void actor_reduce(const float* __restrict__ P, int pstride, const float* __restrict__ bias,
-                                             float* __restrict__ H, int ldh, int tid)
-{
-#pragma unroll
-    for (int i = 0; i < (ACT_M * ACT_H) / ACT_THREADS; ++i) {
-        const int idx = tid + i * ACT_THREADS, r = idx >> 8, c = idx & (ACT_H - 1);
-        const int o = r * ldh + c;
-        const float v = ((P[o] + P[pstride + o]) + (P[2 * pstride + o] + P[3 * pstride + o])) + bias[c];
-        H[o] = fmaxf(v, 0.f);
-    }
-}
-
-extern "C" __global__ void __launch_bounds__(ACT_THREADS) cn_actor_kernel(const float* __restrict__ obs, int n, int D, int Dp,
+// One tile of 16 environments through the actor (TD3:96-106 + 209-215), by the NW waves of a workgroup (all of its threads must
+// call this).  obs / action: the tile's first row; n_live: rows of the tile that exist; act_sm: 16 (Dp + 1) + 16 * 257 floats of
+// LDS.  Ends with the actions in global memory (the caller synchronises before anyone reads them).
+template <int NW>
+__device__ __forceinline__ void actor_tile(const float* __restrict__ obs, int n_live, int row0, int D, int Dp,
         const float* __restrict__ W1T, const float* __restrict__ b1, const float* __restrict__ W2T,
         const float* __restrict__ b2, const float* __restrict__ W3, const float* __restrict__ b3,
-        float* __restrict__ action, float max_v, float max_w, float sigma, uint64_t seed, uint64_t counter)
+        float* __restrict__ action, float* __restrict__ action2, float max_v, float max_w, float sigma, uint64_t seed, uint64_t counter,
+        float* __restrict__ act_sm)
 {
-    extern __shared__ __attribute__((aligned(16))) float act_sm[];
-    const int ldx = Dp + 1, ldh = ACT_H + 1, pstride = ACT_M * ldh;
-    float* X = act_sm;                 // [16][Dp + 1]
-    float* P = X + ACT_M * ldx;        // [4][16][257] partial sums of the K quarters
-    float* H = P + 4 * pstride;        // [16][257] hidden activations (layer 1, then layer 2)
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int cw = wave & 3, kq = wave >> 2;
-    const int row0 = blockIdx.x * ACT_M;
-    {   // one row per wave: coalesced, no integer divide
-        const int r = wave;
-        const bool live = (row0 + r < n);
-        const float* src = obs + (size_t)(row0 + r) * D;
-        for (int c = lane; c < Dp; c += 64) X[r * ldx + c] = (live && c < D) ? src[c] : 0.f;
+    constexpr int TPW = 16 / NW, U = 8;
+    const int ldx = Dp + 1, ldh = ACT_H + 1;
+    float* X = act_sm;                 // [16][Dp + 1]; layer 2 writes its output here (the observations are dead by then)
+    float* H = X + ACT_M * ldx;        // [16][257] hidden activations of layer 1
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    ActW<TPW, U> w1, w2;
+    actor_wload<TPW, U>(w1, actor_wptr<TPW>(W1T, wave, lane), 0);      // in flight while the observations are staged
+    // Staging the tile: rows by wave, coalesced.  Every load of a chunk (8 x 64 columns of each of the wave's rows) is issued
+    // before the first store: written as `X[c] = src[c]` the loop paid one L2 round trip per 64 columns, in series -- 7 to 14 of
+    // them, half of the tile's latency.
+    constexpr int RPW = ACT_M / NW, CH = 8;
+    for (int c0 = 0; c0 < Dp; c0 += 64 * CH) {
+        float v[RPW][CH];
+#pragma unroll
+        for (int q = 0; q < RPW; ++q) {
+            const int r = wave + q * NW;
+            const float* src = obs + (size_t)r * D;
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const int c = c0 + lane + 64 * j;
+                v[q][j] = (r < n_live && c < D) ? src[c] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < RPW; ++q) {
+            const int r = wave + q * NW;
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const int c = c0 + lane + 64 * j;
+                if (c < Dp) X[r * ldx + c] = v[q][j];
+            }
+        }
     }
     __syncthreads();
-    {
-        const int steps = Dp >> 2, per = (steps + 3) >> 2;                 // k-steps of 4 per quarter
-        const int s0 = min(kq * per, steps), s1 = min(s0 + per, steps);
-        actor_partial(X, ldx, 4 * s0, 4 * s1, W1T, P + kq * pstride, ldh, cw, lane);
-    }
+    actor_layer<TPW, U>(X, ldx, Dp, W1T, b1, H, ldh, wave, lane, w1);
+    actor_wload<TPW, U>(w2, actor_wptr<TPW>(W2T, wave, lane), 0);      // ... and while the slowest wave finishes layer 1
     __syncthreads();
-    actor_reduce(P, pstride, b1, H, ldh, tid);
+    float* H2 = X;
+    actor_layer<TPW, U>(H, ldh, ACT_H, W2T, b2, H2, ldh, wave, lane, w2);
     __syncthreads();
-    actor_partial(H, ldh, kq * (ACT_H / 4), (kq + 1) * (ACT_H / 4), W2T, P + kq * pstride, ldh, cw, lane);
-    __syncthreads();
-    actor_reduce(P, pstride, b2, H, ldh, tid);
-    __syncthreads();
-    float* H2 = H;
     if (tid < 256)
     {   // linear3 (TD3:101) + heads, exploration noise, clip: thread = (env i, output o, eighth of K), 32-term partial dots
         const int i = tid >> 4, o = (tid >> 3) & 1, part = tid & 7;
@@ -2652,9 +2701,63 @@ extern "C" __global__ void __launch_bounds__(ACT_THREADS) cn_actor_kernel(const 
             val += sigma * rr_ * ((o == 0) ? c_ : s_);
         }
         val = (o == 0) ? fminf(fmaxf(val, 0.0f), max_v) : fminf(fmaxf(val, -max_w), max_w);
-        if (part == 0 && e < n) action[2 * (size_t)e + o] = val;
+        if (part == 0 && i < n_live) {
+            action[2 * (size_t)i + o] = val;
+            if (action2) action2[2 * (size_t)i + o] = val;
+        }
     }
 }
+
+extern "C" __global__ void __launch_bounds__(ACT_THREADS) cn_actor_kernel(const float* __restrict__ obs, int n, int D, int Dp,
+        const float* __restrict__ W1T, const float* __restrict__ b1, const float* __restrict__ W2T,
+        const float* __restrict__ b2, const float* __restrict__ W3, const float* __restrict__ b3,
+        float* __restrict__ action, float max_v, float max_w, float sigma, uint64_t seed, uint64_t counter)
+{
+    extern __shared__ __attribute__((aligned(16))) float act_sm[];
+    const int row0 = blockIdx.x * ACT_M;
+    actor_tile<ACT_THREADS / 64>(obs + (size_t)row0 * D, min(ACT_M, n - row0), row0, D, Dp, W1T, b1, W2T, b2, W3, b3,
+                                 action + 2 * (size_t)row0, nullptr, max_v, max_w, sigma, seed, counter, act_sm);
+}
+
+// ---- the fused rollout: T steps of [actor -> Env.step] in ONE launch (BASELINE configs[2]) -------------------------
+// A workgroup = 16 wavefronts = the 16 environments of one actor tile.  Per step: the 1024 threads run the tile through the actor
+// (f32 matrix cores) on the observations of slot t -> actions; barrier; every wavefront advances ITS environment by one control
+// period exactly as cn_env_kernel does (next-step reset convention, auto_reset = 2) and writes observation / reward / done / indices
+// to slot t + 1 / t of the caller's trajectory buffers; barrier.  No launch boundary, no grid-wide tail and no observation re-read
+// between the policy and the environment: a tile runs ahead of the others at its own pace, and the matrix cores of one CU work
+// while the vector units of another are in the environment phase.  The env LDS working sets are dead during the actor phase, so
+// the actor's tile buffers overlay them.  Same arithmetic as cn_actor_forward + cn_step chained on a stream: bit-identical
+// trajectories (tests/test_gpu_configs.py::test_fused_rollout_equals_the_chain).
+#ifndef CN_TIMING      /* not in the profiling build: with the stage stamps compiled in, this kernel trips an LLVM register-allocation
+                        * assertion ("even aligned vector registers"); cn_rollout reports CN_ERR_CONFIG there */
+template <bool GT>
+__device__ __forceinline__ void rollout_body()
+{
+    KP p = (KP)__builtin_amdgcn_kernarg_segment_ptr();
+    extern __shared__ __attribute__((aligned(16))) char cn_smem[];
+    // the wave index is wave-uniform, but only readfirstlane tells the compiler so: everything derived from `env` (state record,
+    // LDS base, every per-env scalar) then stays on the scalar unit, as it does in the one-wave-per-block kernels
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int row0 = blockIdx.x * ACT_M, env = row0 + wave;
+    const int D = p->R - 1 + 7 + 4 * p->K;
+    char* const mine = cn_smem + (size_t)wave * (size_t)p->roll_lds_per_env;
+    for (long long t = 0; t < p->roll_steps; ++t) {
+        const float* obs_t = p->obs + (size_t)(t * p->roll_obs_stride) + (size_t)row0 * D;
+        float* act_t = p->roll_action_traj ? p->roll_action_traj + (size_t)(t * p->roll_action_stride) + 2 * (size_t)row0 : nullptr;
+        actor_tile<ROLL_THREADS / 64>(obs_t, ACT_M, row0, D, p->act_Dp, p->act_w1t, p->act_b1, p->act_w2t, p->act_b2, p->act_w3, p->act_b3,
+                   const_cast<float*>(p->action) + 2 * (size_t)row0, act_t, p->act_max_v, p->act_max_w, p->act_sigma, p->act_seed,
+                   p->act_counter + (uint64_t)t, (float*)cn_smem);
+        __syncthreads();
+        int lane_ = lane;
+        asm volatile("" : "+v"(lane_));          // ... and the lane id, for the same reason
+        lane_ &= 63;
+        env_kernel_body<false, false, 0, GT, 0, true>(env, lane_, mine, t);
+        __syncthreads();
+    }
+}
+extern "C" __global__ void __launch_bounds__(ROLL_THREADS) cn_rollout_kernel(CnKParams p) { rollout_body<false>(); }
+extern "C" __global__ void __launch_bounds__(ROLL_THREADS) cn_rollout_kernel_gt(CnKParams p) { rollout_body<true>(); }
+#endif
 
 #ifdef CN_TIMING
 // ---- device arithmetic under test (PROFILING BUILD ONLY; tests/test_gpu_parity.py::test_device_math_*): the hand-written

@@ -129,6 +129,96 @@ def test_config3_actor_in_the_loop_4096_envs(oracle_mod, sigma):
     envs.close()
 
 
+@pytest.mark.parametrize("risk_mode", [0, 1])
+def test_fused_rollout_equals_the_chain(oracle_mod, risk_mode):
+    """cn_rollout -- T steps of [TD3 actor -> Env.step] in one launch, a workgroup owning 16 envs throughout -- leaves the same
+    trajectory, bit for bit, as cn_actor_forward -> cn_step (next-step reset) chained per step: observations, actions,
+    rewards, done flags, indices at every step (trajectory buffers), the final state (snapshot), counters and returns; with
+    and without exploration noise, in place and into trajectory buffers, across two consecutive calls.  The chain itself is
+    checked against the oracle at every step here too (the GPU's own actions drive it)."""
+    import torch
+    from crowdnav import Config
+    from crowdnav.env import VecEnv
+    from crowdnav.td3 import Agent
+    N, T = 512, 30
+    cfg = Config(n_envs=N, n_peds=20, max_steps=20, seed=31, ped_cycle_ms=1400, risk_mode=risk_mode)
+    for sigma in (0.0, 1.0):
+        chain, fused, inplace = VecEnv(cfg), VecEnv(cfg), VecEnv(cfg)
+        orc = oracle_mod.Oracle(cfg.as_dict())
+        oracle_mod.set_num_threads()
+        ag = [Agent(obs_dim=chain.D, device="cuda", seed=5, memory_size=16, explore_sigma=sigma) for _ in range(3)]
+        for a_ in ag:
+            with torch.no_grad():
+                a_.actor.linear1.weight.mul_(4.0); a_.actor.linear3.weight.mul_(10.0)
+        o0 = chain.reset(); fused.reset(); inplace.reset(); torch.cuda.synchronize()
+        assert np.array_equal(o0.cpu().numpy(), orc.reset().astype(np.float32))
+        D, K = chain.D, chain.K
+        for call in range(2):                    # the second call continues from where the first one stopped
+            traj = dict(obs=torch.zeros((T + 1, N, D), device="cuda"), action=torch.zeros((T, N, 2), device="cuda"),
+                        reward=torch.zeros((T, N), device="cuda"), done=torch.zeros((T, N), dtype=torch.uint8, device="cuda"),
+                        topk_idx=torch.zeros((T, N, K), dtype=torch.int32, device="cuda"))
+            fused.rollout_fused(ag[1], T, add_noise=sigma > 0, traj=traj)
+            inplace.rollout_fused(ag[2], T, add_noise=sigma > 0)
+            n_done = 0
+            for t in range(T):
+                act = ag[0].act_mfma(chain.obs, add_noise=sigma > 0)
+                prev = chain.obs.clone()
+                chain.step(act, auto_reset="next")
+                torch.cuda.synchronize()
+                assert torch.equal(traj["obs"][t], prev) and torch.equal(traj["action"][t], act), (call, t)
+                assert torch.equal(traj["obs"][t + 1], chain.obs) and torch.equal(traj["reward"][t], chain.reward), (call, t)
+                assert torch.equal(traj["done"][t], chain.done) and torch.equal(traj["topk_idx"][t], chain.topk_idx), (call, t)
+                oc, rc, dc, ic = orc.step(act.cpu().numpy().astype(np.float64), auto_reset="next")
+                assert np.array_equal(chain.done.cpu().numpy(), dc) and np.array_equal(chain.topk_idx.cpu().numpy(), ic), (call, t)
+                assert np.array_equal(chain.obs.cpu().numpy(), oc.astype(np.float32)), (call, t)
+                n_done += int(dc.sum())
+            assert n_done > N // 2
+            for other in (fused, inplace):
+                assert torch.equal(other.obs, chain.obs) and torch.equal(other.reward, chain.reward) and torch.equal(other.done, chain.done)
+                assert np.array_equal(other.snapshot(), chain.snapshot())
+                assert torch.equal(other.counters(), chain.counters()) and torch.equal(other.returns()[0], chain.returns()[0])
+            assert torch.equal(inplace.topk_idx, chain.topk_idx)
+        for e_ in (chain, fused, inplace):
+            e_.close()
+    import crowdnav
+    with pytest.raises(crowdnav.CrowdNavError):          # one actor tile = 16 environments = one workgroup
+        VecEnv(Config(n_envs=24)).rollout_fused(ag[0], 1)
+    with pytest.raises(crowdnav.CrowdNavError):
+        VecEnv(Config(n_envs=16, ped_contact=1)).rollout_fused(ag[0], 1)
+
+
+def test_batched_trainer_runs_on_the_next_step_reset_kernel(tmp_path):
+    """crowdnav.train (TRAIN:40-168 batched) on the fast one-observation kernel: a finished env's next launch is its reset and
+    is masked out of the replay, so the buffer holds exactly the env-steps taken; terminal transitions carry done = 1 and the
+    terminal observation; evaluation rows carry the episode's duration (TRAIN:141 timelapse)."""
+    import argparse
+    import torch
+    from crowdnav import train as T
+    a = T.main.__globals__["argparse"].Namespace(scenario="bench", envs=64, launches=120, max_steps=25, updates=1, batch=64, memory=20000,
+                                                 checkpoint_every=10 ** 9, log_every=10 ** 9, ped_vmax=None, seed=3, device=0,
+                                                 out=str(tmp_path / "run"), csv=True, load=None, load_episode=0, evaluate=False,
+                                                 episodes_per_env=1)
+    agent, episodes = T.train(a)
+    m = agent.memory
+    assert episodes > 64 and len(m) == m.size
+    # 120 launches x 64 envs, minus one launch per finished episode (except episodes that finished in the very last launch)
+    assert 120 * 64 - episodes <= len(m) <= 120 * 64 - episodes + 64
+    d = m.d[:m.size, 0]
+    assert 0 < int(d.sum().item()) <= episodes
+    # a terminal transition's s' is the terminal observation, not a fresh episode's first one: the robot is where the episode
+    # ended, i.e. either inside the goal box, at max_steps, or with a scan below min_scan_range (0.12)
+    term = torch.nonzero(d > 0).flatten()[:50]
+    assert (m.s2[term, :359].min(1).values < 0.6).any()
+    import csv
+    rows = list(csv.reader(open(os.path.join(a.out, "td3_training.csv"))))
+    assert rows[0][-1] == "timelapse" and len(rows) - 1 == episodes
+    from crowdnav.env import VecEnv
+    from crowdnav import Config
+    from crowdnav.rollout import evaluate
+    st = evaluate(VecEnv(Config(n_envs=32, max_steps=20, seed=4)), agent)
+    assert len(st.rows) == 32 and all(abs(r[7] - r[4] * 0.16) < 1e-9 and r[7] > 0 for r in st.rows)
+
+
 def test_episode_stats_rows_match_the_reference_run():
     """SURVEY 8a A33 "pinned by": the batched loop's per-episode rows (EpisodeStats: success, failure, return, steps,
     ego / social safety scores) equal the tuples of the golden run the REFERENCE's Python produced (`train20`: five
