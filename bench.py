@@ -210,12 +210,17 @@ def main():
         """One decomposition of a config: its envs as G stream groups (G = 1: one launch per step), open loop or with the TD3
         actor in the loop (each group's act -> step chain on its own stream, crowdnav.rollout.rollout_groups)."""
 
-        def __init__(self, lcfg, G, mode="next", lacts=None, agent=None, fused=False):
-            self.cfg, self.G, self.mode, self.agent, self.fused = lcfg, G, mode, agent, fused
+        def __init__(self, lcfg, G, mode="next", lacts=None, agent=None, fused=False, sequence=False):
+            self.cfg, self.G, self.mode, self.agent, self.fused, self.sequence = lcfg, G, mode, agent, fused, sequence
             self.grp = VecEnvGroups(lcfg, groups=G, device=dev_index, streams=streams[:G] if G <= len(streams) else None)
             self.grp.reset()
             self.enq_ms = None
-            if agent is None:
+            if sequence:
+                # cn_step_sequence: the K timed steps as ONE launch of persistent wavefronts (open-loop actions [K, N, 2] in HBM)
+                self.calls = [self.grp.bind_step_all(lacts[i], auto_reset=mode) for i in range(N_ACT)]
+                self.seq_actions = lacts[torch.arange(K, device=dev) % N_ACT].contiguous()
+                self.timed_call = self.grp.envs[0].bind_step_sequence(self.seq_actions)
+            elif agent is None:
                 self.calls = [self.grp.bind_step_all(lacts[i], auto_reset=mode) for i in range(N_ACT)]
                 # the K timed steps as ONE pre-marshalled cn_step_multi (K x G entries): the host side of a sample is a C loop
                 self.timed_call = self.grp.bind_step_sequence([lacts[i % N_ACT] for i in range(K)], auto_reset=mode)
@@ -304,14 +309,17 @@ def main():
         out = [(float(mx[i, 0]), float(sm[i, 1]) / world, float(sm[i, 2])) for i in range(len(samples))]
         return out, [x.cpu().tolist() for x in allr]
 
-    def measure(lcfg, candidates, lacts=None, agent=None, mode="next", repeats=R, probe=True, fused_leg=False):
+    def measure(lcfg, candidates, lacts=None, agent=None, mode="next", repeats=R, probe=True, fused_leg=False, sequence_leg=False):
         """Every candidate decomposition of one config: pre-roll + warm-up, one probe of K steps each (decides the headline),
         then `repeats` timed samples each.  Returns a dict with the chosen decomposition's median sample and all legs."""
         legs = {}
         if fused_leg:
             candidates = list(candidates) + ["fused"]
+        if sequence_leg:
+            candidates = list(candidates) + ["sequence"]
         for G in candidates:
-            lg = Leg(lcfg, 1, agent=agent, fused=True) if G == "fused" else Leg(lcfg, G, mode=mode, lacts=lacts, agent=agent)
+            lg = (Leg(lcfg, 1, agent=agent, fused=True) if G == "fused" else
+                  Leg(lcfg, 1, lacts=lacts, sequence=True) if G == "sequence" else Leg(lcfg, G, mode=mode, lacts=lacts, agent=agent))
             lg.run(a.preroll + a.warmup - warm_tail)
             legs[G] = lg
         probes = {}
@@ -335,10 +343,14 @@ def main():
         return out
 
     cands = [Gmax] + [g for g in (2, 1) if g < Gmax and N % g == 0]
-    main_m = measure(cfg, cands, lacts=acts)
+    main_m = measure(cfg, cands, lacts=acts, sequence_leg=(a.peds, a.rays) == (20, 360))
     same_m = measure(cfg, [1], lacts=acts, mode="same", repeats=min(R, 3), probe=False)
-    G = main_m["chosen"]
-    hl = main_m["legs"][G]
+    def leg_name(g):
+        return g if isinstance(g, str) else "%d_groups" % g
+
+    Gc = main_m["chosen"]                              # an int (stream groups) or "sequence" (one cn_step_sequence launch of K steps)
+    G = 1 if isinstance(Gc, str) else Gc
+    hl = main_m["legs"][Gc]
     value, wall, kernel_ms, taken_all = hl["median"], hl["wall"], hl["kernel_ms"], hl["taken"]
     one = main_m["legs"].get(1)
 
@@ -371,7 +383,7 @@ def main():
                           "decomposition": ("one fused cn_rollout launch for the K steps" if m["chosen"] == "fused"
                                             else "%d stream group(s)" % m["chosen"]),
                           "samples_env_steps_s": l_["samples"],
-                          "legs_env_steps_s": {(g if g == "fused" else "%d_groups" % g): v["median"] for g, v in m["legs"].items()},
+                          "legs_env_steps_s": {leg_name(g): v["median"] for g, v in m["legs"].items()},
                           "probe_env_steps_s": m["probe_env_steps_s"],
                           "roofline": {"bound": "hbm", "bytes_per_env_step_d4": d4, "achieved": l_["median"] * d4 / 1e9,
                                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": l_["median"] * d4 / 1e9 / HBM_PEAK_GBS}}
@@ -430,18 +442,21 @@ def main():
         "config": {"workload": "%s: %d envs/GPU x %d pedestrians x %d rays, K=%d, lidar-tracker risk features, "
                                "next-step auto-reset (reset launches not counted as env-steps), open-loop "
                                "U(0,0.22)xU(-2,2) actions, %d untimed pre-roll steps; one step = every env stepped once, "
-                               "the envs running as %d independent stream group(s) of %d; median of %d samples of %d steps" % (
+                               "%s; median of %d samples of %d steps" % (
                                    ("BASELINE configs[3] shape, %d envs total over %d GPU(s) (strong scaling)" % (a.envs_total, world))
                                    if a.envs_total else ("BASELINE configs[1] per GPU (weak scaling over %d GPU(s))" % world),
-                                   N, a.peds, a.rays, a.k, a.preroll, G, n_launch, R, K),
+                                   N, a.peds, a.rays, a.k, a.preroll,
+                                   ("the K steps enqueued as ONE cn_step_sequence launch (persistent wavefronts, actions [K, N, 2] in HBM)"
+                                    if isinstance(Gc, str) else "the envs running as %d independent stream group(s) of %d" % (G, n_launch)), R, K),
                    "envs_per_gpu": N, "envs_total": N * world, "stream_groups": G, "stream_groups_requested": Gmax,
+                   "decomposition": leg_name(Gc),
                    "repeats": R, "samples_env_steps_s": hl["samples"],
                    "headline_choice": {"rule": "best untimed probe of K steps among the decompositions, taken before the timed samples",
-                                       "probe_env_steps_s": main_m["probe_env_steps_s"], "chosen_groups": G},
-                   "legs_env_steps_s": {"%d_groups" % g: v["median"] for g, v in main_m["legs"].items()},
-                   "legs_samples_env_steps_s": {"%d_groups" % g: v["samples"] for g, v in main_m["legs"].items()},
+                                       "probe_env_steps_s": main_m["probe_env_steps_s"], "chosen": leg_name(Gc)},
+                   "legs_env_steps_s": {leg_name(g): v["median"] for g, v in main_m["legs"].items()},
+                   "legs_samples_env_steps_s": {leg_name(g): v["samples"] for g, v in main_m["legs"].items()},
                    # host time the enqueue loop needs per step of a leg (a leg is host-paced when this approaches ms_per_step)
-                   "host_enqueue_ms_per_step": {"%d_groups" % g: v["enq_ms"] for g, v in main_m["legs"].items()},
+                   "host_enqueue_ms_per_step": {leg_name(g): v["enq_ms"] for g, v in main_m["legs"].items()},
                    "concurrent_hw_queues_found": conc, "parallelism": "env-sharded x%d" % world,
                    "one_launch_per_step_value": one["median"] if one else None,
                    "one_launch_per_step_ms": one["wall"] / K * 1e3 if one else None,
@@ -461,7 +476,7 @@ def main():
                      "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": D4 * n_launch, "envs_per_launch": n_launch,
                      "concurrent_launches": G,
-                     "kernel": "cn_env_kernel", "kernel_ms": kernel_ms,
+                     "kernel": "cn_env_kernel_seq (kernel_ms = launch duration / K)" if isinstance(Gc, str) else "cn_env_kernel", "kernel_ms": kernel_ms,
                      # what actually binds: instruction issue (float64 VALU) and one wavefront's critical path, not HBM
                      "binding": "instruction issue (f64 VALU) above ~8k resident envs; one wavefront's critical path at 4096",
                      "issue_bound_env_steps_s": plateau,

@@ -161,6 +161,61 @@ class VecEnv:
                 check(rc)
         return call
 
+    def step_sequence(self, actions, traj=None):
+        """T = len(actions) calls of step(auto_reset="next") with OPEN-LOOP actions as ONE launch (cn_step_sequence): every
+        wavefront keeps its env for the whole launch and walks the T steps at its own pace.  actions: [T, N, 2] float32 device
+        tensor (or [N, 2] with `traj["steps"]` / an int second argument is not supported -- pass an expanded tensor).
+        traj: None -- every step overwrites self.obs / reward / done / topk_idx in place -- or a dict of preallocated device
+        tensors obs [T, N, D], reward [T, N], done [T, N] uint8, optionally topk_idx [T, N, K] (slot t = what step t returned).
+        Bit-identical to the T calls.  Enqueues only; returns env-steps issued."""
+        a = actions
+        assert isinstance(a, torch.Tensor) and a.device == self.device and a.dtype == torch.float32 and a.dim() == 3 and a.shape[1:] == (self.N, 2)
+        T = int(a.shape[0])
+        if T > 1 and a.stride(0) == 0:
+            astride = 0                                  # an expanded [N, 2]: the same actions held for T steps
+            assert a[0].is_contiguous()
+        else:
+            assert a.is_contiguous()
+            astride = 2 * self.N
+        io = _abi.CnSequenceIO()
+        io.action, io.action_stride, io.n_steps = a.data_ptr(), astride, T
+        if traj is None:
+            io.obs, io.reward, io.done, io.topk_idx = self.obs.data_ptr(), self.reward.data_ptr(), self.done.data_ptr(), self.topk_idx.data_ptr()
+        else:
+            N, D, K = self.N, self.D, self.K
+            o, r, d = traj["obs"], traj["reward"], traj["done"]
+            assert tuple(o.shape) == (T, N, D) and o.dtype == torch.float32 and o.is_contiguous()
+            assert tuple(r.shape) == (T, N) and r.dtype == torch.float32 and r.is_contiguous()
+            assert tuple(d.shape) == (T, N) and d.dtype == torch.uint8 and d.is_contiguous()
+            io.obs, io.reward, io.done = o.data_ptr(), r.data_ptr(), d.data_ptr()
+            io.obs_stride, io.reward_stride, io.done_stride = N * D, N, N
+            tk = traj.get("topk_idx")
+            if tk is not None:
+                assert tuple(tk.shape) == (T, N, K) and tk.dtype == torch.int32 and tk.is_contiguous()
+                io.topk_idx, io.topk_stride = tk.data_ptr(), N * K
+        _abi.check(self.L.cn_step_sequence(self.h, C.byref(io), self._stream()))
+        self._keep_seq = (io, a, traj)
+        if traj is not None:
+            with self._on_stream():
+                self.obs.copy_(traj["obs"][T - 1]); self.reward.copy_(traj["reward"][T - 1]); self.done.copy_(traj["done"][T - 1])
+        return T * self.N
+
+    def bind_step_sequence(self, actions):
+        """Pre-marshalled step_sequence (in place) for a fixed [T, N, 2] action tensor: a zero-argument callable that only enqueues."""
+        a = actions
+        assert a.device == self.device and a.dtype == torch.float32 and a.is_contiguous() and a.shape[1:] == (self.N, 2)
+        io = _abi.CnSequenceIO()
+        io.action, io.action_stride, io.n_steps = a.data_ptr(), 2 * self.N, int(a.shape[0])
+        io.obs, io.reward, io.done, io.topk_idx = self.obs.data_ptr(), self.reward.data_ptr(), self.done.data_ptr(), self.topk_idx.data_ptr()
+        ref, st, h, fn, check = C.byref(io), self._stream(), self.h, self.L.cn_step_sequence, _abi.check
+        keep = (io, a)
+
+        def call(_keep=keep):
+            rc = fn(h, ref, st)
+            if rc:
+                check(rc)
+        return call
+
     def rollout_fused(self, agent, n_steps, add_noise=True, traj=None, noise_seed=None):
         """`n_steps` of [agent.act -> Env.step] for every env as ONE launch (cn_rollout): a workgroup owns 16 envs for the whole
         launch, the TD3 actor runs on the matrix cores between the env steps, next-step reset convention.  Starts from the

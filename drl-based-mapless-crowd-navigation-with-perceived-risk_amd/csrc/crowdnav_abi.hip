@@ -33,6 +33,8 @@ extern "C" __global__ void cn_env_kernel_rw_ext(CnKParams p);
 extern "C" __global__ void cn_env_kernel_orig(CnKParams p);
 extern "C" __global__ void cn_env_kernel_orig_ext(CnKParams p);
 extern "C" __global__ void cn_env_kernel_orig_same(CnKParams p);
+extern "C" __global__ void cn_env_kernel_seq(CnKParams p);
+extern "C" __global__ void cn_env_kernel_gt_seq(CnKParams p);
 #ifndef CN_TIMING
 extern "C" __global__ void cn_rollout_kernel(CnKParams p);
 extern "C" __global__ void cn_rollout_kernel_gt(CnKParams p);
@@ -525,6 +527,30 @@ extern "C" int cn_actor_forward(const cn_actor_weights* w, const float* obs, flo
     }
     hipLaunchKernelGGL(cn_actor_kernel, dim3((n + 15) / 16), dim3(512), lds, (hipStream_t)stream, obs, n, w->obs_dim, Dp,
                        w->w1t, w->b1, w->w2t, w->b2, w->w3, w->b3, action, max_v, max_w, sigma, seed, counter);
+    HIPCHK(hipGetLastError());
+    return CN_OK;
+}
+
+extern "C" int cn_step_sequence(cn_handle h, const cn_sequence_io* io, void* stream)
+{
+    if (!h || !io || !io->action || !io->obs || !io->reward || !io->done) return fail(CN_ERR_ARG, "cn_step_sequence: null argument");
+    if (h->cfg.obs_layout != CN_LAYOUT_RISK || h->cfg.ped_contact || h->cfg.ped_mode == 2)
+        return fail(CN_ERR_CONFIG, "cn_step_sequence: built for obs_layout 0 with the plain simulator (no contact / social-force ticks)");
+    if (io->n_steps < 0 || io->action_stride < 0 || io->obs_stride < 0 || io->reward_stride < 0 || io->done_stride < 0 || io->topk_stride < 0)
+        return fail(CN_ERR_ARG, "cn_step_sequence: negative step count or stride");
+    if (io->n_steps == 0) return CN_OK;
+    CnKParams kp = h->kp;
+    kp.mode = CN_MODE_STEP; kp.auto_reset = 2;
+    kp.action = io->action; kp.step_counter = nullptr; kp.final_obs = nullptr; kp.obs_f64 = nullptr;
+    // the step body writes observation slot t + 1 (cn_rollout's convention: slot 0 = the observation before the first step);
+    // here slot t is step t's, so the base moves back by one stride
+    kp.obs = io->obs - io->obs_stride; kp.reward = io->reward; kp.done = io->done; kp.topk_idx = io->topk_idx;
+    kp.roll_steps = io->n_steps; kp.roll_action_in_stride = io->action_stride; kp.roll_obs_stride = io->obs_stride;
+    kp.roll_reward_stride = io->reward_stride; kp.roll_done_stride = io->done_stride; kp.roll_topk_stride = io->topk_stride;
+    DeviceScope scope(h->device);
+    void (*fn)(CnKParams) = h->cfg.risk_mode == CN_RISK_GT ? cn_env_kernel_gt_seq : cn_env_kernel_seq;
+    if (h->lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
+    hipLaunchKernelGGL(fn, dim3(h->cfg.n_envs), dim3(64), h->lds, (hipStream_t)stream, kp);
     HIPCHK(hipGetLastError());
     return CN_OK;
 }

@@ -66,7 +66,7 @@ struct CnKParams {
     // elements between consecutive steps' slots of the trajectory buffers (0 = every step in place)
     const float *act_w1t, *act_b1, *act_w2t, *act_b2, *act_w3, *act_b3;
     float* roll_action_traj;
-    int64_t roll_steps, roll_obs_stride, roll_reward_stride, roll_done_stride, roll_topk_stride, roll_action_stride, roll_lds_per_env;
+    int64_t roll_steps, roll_obs_stride, roll_reward_stride, roll_done_stride, roll_topk_stride, roll_action_stride, roll_lds_per_env, roll_action_in_stride;
     uint64_t act_seed, act_counter;
     int32_t act_Dp, act_reserved;
     float act_max_v, act_max_w, act_sigma, act_reserved2;

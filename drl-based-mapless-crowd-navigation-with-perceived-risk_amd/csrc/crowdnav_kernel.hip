@@ -2081,6 +2081,7 @@ __device__ __forceinline__ void env_kernel_body(const int env, const int lane, c
     auto io_obs = [&]() -> float* { if constexpr (FUSED) return p->obs + (size_t)((t + 1) * p->roll_obs_stride); else return p->obs; };
     auto io_reward = [&]() -> float* { if constexpr (FUSED) return p->reward + (size_t)(t * p->roll_reward_stride); else return p->reward; };
     auto io_done = [&]() -> uint8_t* { if constexpr (FUSED) return p->done + (size_t)(t * p->roll_done_stride); else return p->done; };
+    auto io_action = [&]() -> const float* { if constexpr (FUSED) return p->action + (size_t)(t * p->roll_action_in_stride); else return p->action; };
     auto io_topk = [&]() -> int32_t* { if constexpr (FUSED) return p->topk_idx ? p->topk_idx + (size_t)(t * p->roll_topk_stride) : nullptr; else return p->topk_idx; };
 
     Lds L;
@@ -2197,7 +2198,7 @@ __device__ __forceinline__ void env_kernel_body(const int env, const int lane, c
             sc = p->step_counter ? p->step_counter[env] : e.ep_step;
             double deq_x, deq_y, end_timestep;
             if (!ext) {
-                const double v = (double)p->action[2 * env], w = (double)p->action[2 * env + 1];
+                const double v = (double)io_action()[2 * env], w = (double)io_action()[2 * env + 1];
                 const double t0 = e.clock;
                 e.rv = v; e.rw = w;                               // pub_cmd_vel.publish (ENV:1200)
                 e.clock += cn_div1000((double)p->dt_ms);              // time.sleep(0.15) (ENV:1201)
@@ -2321,7 +2322,7 @@ __device__ __forceinline__ void env_kernel_body(const int env, const int lane, c
         const int sc = p->step_counter ? p->step_counter[env] : e.ep_step;
         double deq_x, deq_y, end_timestep;
         if (!ext) {
-            const double v = (double)p->action[2 * env], w = (double)p->action[2 * env + 1];
+            const double v = (double)io_action()[2 * env], w = (double)io_action()[2 * env + 1];
             const double t0 = e.clock;
             e.rv = v; e.rw = w;                               // pub_cmd_vel.publish (ENV:1200)
             e.clock += cn_div1000((double)p->dt_ms);              // time.sleep(0.15) (ENV:1201)
@@ -2456,6 +2457,27 @@ __device__ __forceinline__ void env_kernel_body(const int env, const int lane, c
 extern "C" __global__ void CN_HOT_BOUNDS cn_env_kernel(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, false, 0>(blockIdx.x, threadIdx.x, cn_smem); }
 extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_same(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, true, 0>(blockIdx.x, threadIdx.x, cn_smem); }
 extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_ext(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<true, false, 0>(blockIdx.x, threadIdx.x, cn_smem); }
+// cn_step_sequence: T control periods per launch with OPEN-LOOP actions (resident in HBM: [T][N][2], or one [N][2] held for T
+// periods).  One wavefront keeps its environment for the whole launch and walks its T steps at its own pace: no launch boundary,
+// no device-wide join between steps -- the launch ends with its slowest wavefront's T steps, not with T x the slowest single
+// step -- and after a few steps the wavefronts of a SIMD are out of phase (they stop contending for the same unit at the same
+// time), which is what one launch per step can never be.  Each step is exactly cn_env_kernel's (next-step reset convention) and
+// writes its observation / reward / done / indices to slot t of the caller's buffers (stride 0: in place).
+template <bool GT>
+__device__ __forceinline__ void sequence_body()
+{
+    extern __shared__ __attribute__((aligned(16))) char cn_smem[];
+    KP p = (KP)__builtin_amdgcn_kernarg_segment_ptr();
+    const long long T = p->roll_steps;
+    for (long long t = 0; t < T; ++t) {
+        int lane_ = threadIdx.x;
+        asm volatile("" : "+v"(lane_));          // per-step laundering, as in the fused rollout: nothing is hoisted out of the step loop
+        lane_ &= 63;
+        env_kernel_body<false, false, 0, GT, 0, true>(blockIdx.x, lane_, cn_smem, t);
+    }
+}
+extern "C" __global__ void CN_HOT_BOUNDS cn_env_kernel_seq(CnKParams p) { sequence_body<false>(); }
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_gt_seq(CnKParams p) { sequence_body<true>(); }
 // risk_mode gt: the perceived-risk features from the simulator's own pedestrians (no segmentation, no tracker)
 extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_gt(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, false, 0, true>(blockIdx.x, threadIdx.x, cn_smem); }
 extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_gt_same(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, true, 0, true>(blockIdx.x, threadIdx.x, cn_smem); }

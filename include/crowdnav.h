@@ -207,6 +207,25 @@ typedef struct cn_actor_weights {
 int cn_actor_forward(const cn_actor_weights* w, const float* obs, float* action, int n, float max_v, float max_w,
                      float sigma, uint64_t seed, uint64_t counter, int device, void* stream);
 
+/* n_steps calls of cn_step (auto_reset = 2, the next-step reset convention) with OPEN-LOOP actions -- scripted or recorded
+ * actions, action repeat, the uniform-random warm-up phase of an off-policy learner -- as ONE launch: a wavefront keeps its
+ * environment for the whole launch and walks its steps at its own pace (no launch boundary and no device-wide join between
+ * steps).  Results are bit-identical to n_steps cn_step calls.  Slot t of a buffer starts `stride` ELEMENTS after slot t - 1;
+ * stride 0 = one slot (actions: the same [N, 2] held for every step; outputs: every step overwrites the slot).
+ *   action  dev n_steps slots [N, 2] float32;  obs dev n_steps slots [N, D] float32 (slot t = the observation step t returns)
+ *   reward / done / topk_idx (or NULL): n_steps slots [N] / [N] / [N, K]
+ * Requirements: obs_layout 0, plain simulator (ped_contact 0, ped_mode 0 / 1). */
+typedef struct cn_sequence_io {
+    const float* action;
+    float* obs;
+    float* reward;
+    uint8_t* done;
+    int32_t* topk_idx;
+    int64_t action_stride, obs_stride, reward_stride, done_stride, topk_stride;
+    int32_t n_steps, reserved;
+} cn_sequence_io;
+int cn_step_sequence(cn_handle h, const cn_sequence_io* io, void* stream);
+
 /* The caller's rollout loop -- `for step: action = agent.act(state); state, reward, done = env.step(action, ...)`
  * (start_td3_training.py:118-127) -- for N environments and `n_steps` steps as ONE launch: per step the TD3 actor (as
  * cn_actor_forward, exploration noise keyed by (seed, counter + step, row)) runs on the current observations, then every

@@ -365,6 +365,57 @@ def test_config4_full_workload_16384_envs_as_8_shards(oracle_mod):
     assert np.array_equal(torch.cat(cnts).cpu().numpy()[:, :6], orc.counters())
 
 
+@pytest.mark.parametrize("risk_mode", [0, 1])
+def test_step_sequence_kernel_equals_step_by_step(oracle_mod, risk_mode):
+    """cn_step_sequence -- T open-loop steps in ONE launch, every wavefront keeping its env and walking the T steps at its own
+    pace -- leaves the trajectory T calls of cn_step (next-step reset) leave: observations, rewards, done flags and indices of
+    EVERY step (trajectory buffers), the final state record (snapshot), counters and returns; in place and into trajectory
+    buffers, with per-step actions and with one action held for T steps, across consecutive calls.  The step-by-step run is
+    checked against the oracle at every step as well."""
+    import torch
+    from crowdnav import Config
+    from crowdnav.env import VecEnv
+    N, T = 640, 45
+    cfg = Config(n_envs=N, n_peds=20, max_steps=18, seed=43, ped_cycle_ms=1400, risk_mode=risk_mode)
+    ref, seq, inplace = VecEnv(cfg), VecEnv(cfg), VecEnv(cfg)
+    orc = oracle_mod.Oracle(cfg.as_dict())
+    oracle_mod.set_num_threads()
+    o0 = ref.reset(); seq.reset(); inplace.reset(); torch.cuda.synchronize()
+    assert np.array_equal(o0.cpu().numpy(), orc.reset().astype(np.float32))
+    g = torch.Generator(device="cpu").manual_seed(6)
+    D, K = ref.D, ref.K
+    for call in range(3):
+        acts = torch.stack([torch.rand((T, N), generator=g) * 0.22, torch.rand((T, N), generator=g) * 4 - 2], 2).cuda().contiguous()
+        if call == 2:
+            acts = acts[:1].expand(T, N, 2)                   # action repeat: one [N, 2] held for T steps (stride 0)
+        traj = dict(obs=torch.zeros((T, N, D), device="cuda"), reward=torch.zeros((T, N), device="cuda"),
+                    done=torch.zeros((T, N), dtype=torch.uint8, device="cuda"), topk_idx=torch.zeros((T, N, K), dtype=torch.int32, device="cuda"))
+        seq.step_sequence(acts, traj=traj)
+        if call == 2:
+            inplace.step_sequence(acts)
+        else:
+            inplace.bind_step_sequence(acts)()
+        n_done = 0
+        for t in range(T):
+            ref.step(acts[t].contiguous(), auto_reset="next")
+            torch.cuda.synchronize()
+            assert torch.equal(traj["obs"][t], ref.obs) and torch.equal(traj["reward"][t], ref.reward), (call, t)
+            assert torch.equal(traj["done"][t], ref.done) and torch.equal(traj["topk_idx"][t], ref.topk_idx), (call, t)
+            oc, rc, dc, ic = orc.step(acts[t].cpu().numpy().astype(np.float64), auto_reset="next")
+            assert np.array_equal(ref.done.cpu().numpy(), dc) and np.array_equal(ref.topk_idx.cpu().numpy(), ic), (call, t)
+            assert np.array_equal(ref.obs.cpu().numpy(), oc.astype(np.float32)), (call, t)
+            n_done += int(dc.sum())
+        assert n_done > N
+        for other in (seq, inplace):
+            assert torch.equal(other.obs, ref.obs) and torch.equal(other.reward, ref.reward) and torch.equal(other.done, ref.done)
+            assert np.array_equal(other.snapshot(), ref.snapshot())
+            assert torch.equal(other.counters(), ref.counters()) and torch.equal(other.returns()[0], ref.returns()[0])
+        assert torch.equal(inplace.topk_idx, ref.topk_idx)
+    import crowdnav
+    with pytest.raises(crowdnav.CrowdNavError):
+        VecEnv(Config(n_envs=16, obs_layout=1)).step_sequence(torch.zeros((2, 16, 2), device="cuda"))
+
+
 def test_bind_step_sequence_equals_step_by_step():
     """VecEnvGroups.bind_step_sequence -- the path bench.py's timed region goes through (K steps x G groups behind ONE
     cn_step_multi call, a C loop over the launches) -- leaves every env where K calls of VecEnv.step leave it: observations,

@@ -31,6 +31,8 @@ def main():
     ap.add_argument("--layout", type=int, default=0)
     ap.add_argument("--vmax", type=float, default=0.2)
     ap.add_argument("--dt-ms", type=int, default=150)
+    ap.add_argument("--py2", type=int, default=0, help="cn_config.py2_round")
+    ap.add_argument("--ped-mode", type=int, default=0, help="2 = social-force pedestrians")
     a = ap.parse_args()
     import torch
     from crowdnav import Config
@@ -39,7 +41,7 @@ def main():
 
     cfg = Config(n_envs=a.envs, n_peds=a.peds, n_rays=a.rays, room_half=a.room, seed=a.seed, max_steps=a.max_steps,
                  min_scan_range=a.min_scan, k_obstacles=a.k, risk_mode=a.risk_mode, ped_contact=a.contact,
-                 geos_untyped_empty=a.geos, obs_layout=a.layout, ped_vmax=a.vmax, dt_ms=a.dt_ms)
+                 geos_untyped_empty=a.geos, obs_layout=a.layout, ped_vmax=a.vmax, dt_ms=a.dt_ms, py2_round=a.py2, ped_mode=a.ped_mode)
     print("== parity_report", " ".join(sys.argv[1:]))
     env = VecEnv(cfg)
     env.enable_f64_obs()

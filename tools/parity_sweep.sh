@@ -2,7 +2,7 @@
 # The GPU-vs-oracle sweeps DESIGN.md quotes (every observation / reward / done flag / index / counter compared, zero
 # differences expected).  Writes gpurun_out/<tag>/parity_sweep.txt; copy it to profiles/<tag>/.
 #   tools/parity_sweep.sh r02 [scale]      scale multiplies every --steps (10 -> 36 M env-steps, ~10 min; output parity_sweep_x10.txt)
-TAG="${1:-r02}"; S="${2:-1}"; cd "$(dirname "$0")/.."; OUT="gpurun_out/$TAG"; mkdir -p "$OUT"
+TAG="${1:-r03}"; S="${2:-1}"; cd "$(dirname "$0")/.."; OUT="gpurun_out/$TAG"; mkdir -p "$OUT"
 R="python tools/parity_report.py --verbose 2"
 NAME=parity_sweep; [ "$S" != 1 ] && NAME="parity_sweep_x$S"
 {
@@ -22,4 +22,10 @@ $R --envs 512 --steps $((200 * S)) --peds 40 --contact 1 --risk-mode 1 --vmax 0.
 $R --envs 1024 --steps $((300 * S)) --layout 1
 $R --envs 1024 --steps $((300 * S)) --layout 2 --dt-ms 50 --reset-mode next
 $R --envs 256 --steps $((200 * S)) --layout 2 --dt-ms 50 --peds 100 --min-scan 0.0
+# round 3: the reference's own platform (Python-2.7 round() + GEOS <= 3.8), alone and together; social-force pedestrians
+$R --envs 2048 --steps $((200 * S)) --py2 1 --reset-mode next
+$R --envs 1024 --steps $((200 * S)) --peds 60 --py2 1 --geos 1
+$R --envs 512 --steps $((200 * S)) --layout 2 --dt-ms 50 --py2 1
+$R --envs 1024 --steps $((200 * S)) --ped-mode 2 --reset-mode next
+$R --envs 512 --steps $((150 * S)) --ped-mode 2 --peds 60 --risk-mode 1 --min-scan 0.0
 } 2>&1 | grep -v amdgpu.ids | tee "$OUT/$NAME.txt"
