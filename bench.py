@@ -210,8 +210,8 @@ def main():
         """One decomposition of a config: its envs as G stream groups (G = 1: one launch per step), open loop or with the TD3
         actor in the loop (each group's act -> step chain on its own stream, crowdnav.rollout.rollout_groups)."""
 
-        def __init__(self, lcfg, G, mode="next", lacts=None, agent=None, fused=False, sequence=False):
-            self.cfg, self.G, self.mode, self.agent, self.fused, self.sequence = lcfg, G, mode, agent, fused, sequence
+        def __init__(self, lcfg, G, mode="next", lacts=None, agent=None, sequence=False):
+            self.cfg, self.G, self.mode, self.agent, self.sequence = lcfg, G, mode, agent, sequence
             self.grp = VecEnvGroups(lcfg, groups=G, device=dev_index, streams=streams[:G] if G <= len(streams) else None)
             self.grp.reset()
             self.enq_ms = None
@@ -224,8 +224,6 @@ def main():
                 self.calls = [self.grp.bind_step_all(lacts[i], auto_reset=mode) for i in range(N_ACT)]
                 # the K timed steps as ONE pre-marshalled cn_step_multi (K x G entries): the host side of a sample is a C loop
                 self.timed_call = self.grp.bind_step_sequence([lacts[i % N_ACT] for i in range(K)], auto_reset=mode)
-            elif fused:
-                agent.sync_fused_weights()       # cn_rollout: the K steps of [actor -> step] as ONE launch (G must be 1)
             else:
                 agent.sync_fused_weights()
                 self.act = torch.zeros((lcfg.n_envs, 2), dtype=torch.float32, device=dev)
@@ -238,10 +236,7 @@ def main():
                 self.chain = chain
 
         def run(self, k, i0=0):
-            if self.fused:
-                if k > 0:
-                    self.grp.envs[0].rollout_fused(self.agent, k)
-            elif self.agent is None:
+            if self.agent is None:
                 for i in range(k):
                     self.calls[(i0 + i) % N_ACT]()
             else:
@@ -309,17 +304,14 @@ def main():
         out = [(float(mx[i, 0]), float(sm[i, 1]) / world, float(sm[i, 2])) for i in range(len(samples))]
         return out, [x.cpu().tolist() for x in allr]
 
-    def measure(lcfg, candidates, lacts=None, agent=None, mode="next", repeats=R, probe=True, fused_leg=False, sequence_leg=False):
+    def measure(lcfg, candidates, lacts=None, agent=None, mode="next", repeats=R, probe=True, sequence_leg=False):
         """Every candidate decomposition of one config: pre-roll + warm-up, one probe of K steps each (decides the headline),
         then `repeats` timed samples each.  Returns a dict with the chosen decomposition's median sample and all legs."""
         legs = {}
-        if fused_leg:
-            candidates = list(candidates) + ["fused"]
         if sequence_leg:
             candidates = list(candidates) + ["sequence"]
         for G in candidates:
-            lg = (Leg(lcfg, 1, agent=agent, fused=True) if G == "fused" else
-                  Leg(lcfg, 1, lacts=lacts, sequence=True) if G == "sequence" else Leg(lcfg, G, mode=mode, lacts=lacts, agent=agent))
+            lg = Leg(lcfg, 1, lacts=lacts, sequence=True) if G == "sequence" else Leg(lcfg, G, mode=mode, lacts=lacts, agent=agent)
             lg.run(a.preroll + a.warmup - warm_tail)
             legs[G] = lg
         probes = {}
@@ -371,17 +363,16 @@ def main():
         from crowdnav.td3 import Agent
         other = {}
         agent = Agent(obs_dim=cfg.obs_dim, device="cuda:%d" % dev_index, seed=0, memory_size=16)
-        m3 = measure(cfg, cands, agent=agent, repeats=min(R, 3), fused_leg=True)
+        m3 = measure(cfg, cands, agent=agent, repeats=min(R, 3))
         c5 = Config(n_envs=N, n_peds=100, n_rays=720, k_obstacles=a.k, max_steps=1000, seed=1234, ped_cycle_ms=1400, room_half=2.40)
         m5 = measure(c5, [Gmax, 1] if Gmax > 1 else [1], lacts=acts, repeats=min(R, 3))
         for key, m, P_, R_, what in (("configs[2]", m3, 20, 360, "4096 envs x 20 pedestrians x 360 rays, K=8, TD3 actor in the loop "
-                                      "(f32-MFMA actor + exploration noise -> Env.step: cn_actor_forward -> cn_step chains per stream group, or fused cn_rollout)"),
+                                      "(f32-MFMA actor + exploration noise -> Env.step: a cn_actor_forward -> cn_step chain per stream group)"),
                                      ("configs[4]", m5, 100, 720, "4096 envs x 100 pedestrians x 720 rays, K=8, room 4.8 m, open loop")):
             l_ = m["legs"][m["chosen"]]
             d4 = d4_bytes(P_, R_, a.k)
             other[key] = {"workload": what, "value": l_["median"], "unit": "env-steps/s", "ms_per_step": l_["wall"] / K * 1e3,
-                          "decomposition": ("one fused cn_rollout launch for the K steps" if m["chosen"] == "fused"
-                                            else "%d stream group(s)" % m["chosen"]),
+                          "decomposition": "%d stream group(s)" % m["chosen"],
                           "samples_env_steps_s": l_["samples"],
                           "legs_env_steps_s": {leg_name(g): v["median"] for g, v in m["legs"].items()},
                           "probe_env_steps_s": m["probe_env_steps_s"],

@@ -26,7 +26,7 @@ TF = dict(PX=0, PY=1, DIST=2, D0X=3, D0Y=4, D1X=5, D1Y=6, T=7, SPEED=8, VX=9, VY
 
 EXPORTS = ["cn_abi_version", "cn_last_error", "cn_create", "cn_destroy", "cn_obs_dim", "cn_config_of",
            "cn_set_ped_init", "cn_get_ped_init", "cn_set_ped_preset_vel", "cn_reset", "cn_step", "cn_step_multi", "cn_observe_external",
-           "cn_policy_tail", "cn_actor_forward", "cn_rollout", "cn_step_sequence", "cn_get_counters",
+           "cn_policy_tail", "cn_actor_forward", "cn_step_sequence", "cn_get_counters",
            "cn_get_returns", "cn_debug_env", "cn_lds_bytes", "cn_near_separate", "cn_snapshot_size", "cn_snapshot", "cn_restore"]
 
 
@@ -101,16 +101,6 @@ class CnSequenceIO(C.Structure):
     _fields_ = [("action", C.c_void_p), ("obs", C.c_void_p), ("reward", C.c_void_p), ("done", C.c_void_p), ("topk_idx", C.c_void_p),
                 ("action_stride", C.c_int64), ("obs_stride", C.c_int64), ("reward_stride", C.c_int64), ("done_stride", C.c_int64),
                 ("topk_stride", C.c_int64), ("n_steps", C.c_int32), ("reserved", C.c_int32)]
-
-
-class CnRolloutIO(C.Structure):
-    """Mirror of `cn_rollout_io` (include/crowdnav.h)."""
-    _fields_ = [("actor", C.c_void_p), ("action", C.c_void_p), ("obs", C.c_void_p), ("reward", C.c_void_p), ("done", C.c_void_p),
-                ("topk_idx", C.c_void_p), ("action_traj", C.c_void_p),
-                ("obs_stride", C.c_int64), ("reward_stride", C.c_int64), ("done_stride", C.c_int64), ("topk_stride", C.c_int64),
-                ("action_stride", C.c_int64), ("n_steps", C.c_int32), ("reserved", C.c_int32),
-                ("max_v", C.c_float), ("max_w", C.c_float), ("sigma", C.c_float), ("reserved2", C.c_float),
-                ("seed", C.c_uint64), ("counter", C.c_uint64)]
 
 
 class CrowdNavError(RuntimeError):
@@ -190,7 +180,6 @@ def lib():
         L.cn_policy_tail.argtypes = [vp, vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_uint64, C.c_uint64, C.c_int, vp]
         L.cn_actor_forward.argtypes = [C.POINTER(CnActorWeights), vp, vp, C.c_int, C.c_float, C.c_float, C.c_float,
                                        C.c_uint64, C.c_uint64, C.c_int, vp]
-        L.cn_rollout.argtypes = [vp, C.POINTER(CnRolloutIO), vp]
         L.cn_step_sequence.argtypes = [vp, C.POINTER(CnSequenceIO), vp]
         L.cn_get_counters.argtypes = [vp, vp, vp]
         L.cn_get_returns.argtypes = [vp, vp, vp, vp]

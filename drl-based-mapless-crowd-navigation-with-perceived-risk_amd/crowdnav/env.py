@@ -216,53 +216,6 @@ class VecEnv:
                 check(rc)
         return call
 
-    def rollout_fused(self, agent, n_steps, add_noise=True, traj=None, noise_seed=None):
-        """`n_steps` of [agent.act -> Env.step] for every env as ONE launch (cn_rollout): a workgroup owns 16 envs for the whole
-        launch, the TD3 actor runs on the matrix cores between the env steps, next-step reset convention.  Starts from the
-        observations in self.obs (reset() or the previous step) and leaves the last ones there.
-        traj: None -- every step overwrites self.obs / reward / done / topk_idx in place (evaluation, benchmarking) -- or a dict
-        of preallocated device tensors obs [T + 1, N, D] (slot 0 is filled from self.obs here), action [T, N, 2], reward [T, N],
-        done [T, N] uint8, optionally topk_idx [T, N, K]: the transitions (obs[t], action[t], reward[t], obs[t + 1], done[t]);
-        a step with done[t - 1] = 1 is the env's reset, not a transition.  Bit-identical to chaining agent.act_mfma and
-        step(auto_reset="next").  Enqueues only; returns env-steps issued."""
-        if not hasattr(agent, "_fw_struct"):
-            agent.sync_fused_weights()
-        if getattr(self, "_roll_act", None) is None:
-            self._roll_act = torch.zeros((self.N, 2), dtype=torch.float32, device=self.device)
-        T = int(n_steps)
-        io = _abi.CnRolloutIO()
-        io.actor = C.addressof(agent._fw_struct)
-        io.action = self._roll_act.data_ptr()
-        if traj is None:
-            io.obs, io.reward, io.done, io.topk_idx, io.action_traj = (self.obs.data_ptr(), self.reward.data_ptr(), self.done.data_ptr(),
-                                                                       self.topk_idx.data_ptr(), None)
-        else:
-            N, D, K = self.N, self.D, self.K
-            o, a, r, d = traj["obs"], traj["action"], traj["reward"], traj["done"]
-            assert tuple(o.shape) == (T + 1, N, D) and o.dtype == torch.float32 and o.is_contiguous()
-            assert tuple(a.shape) == (T, N, 2) and a.dtype == torch.float32 and a.is_contiguous()
-            assert tuple(r.shape) == (T, N) and r.dtype == torch.float32 and r.is_contiguous()
-            assert tuple(d.shape) == (T, N) and d.dtype == torch.uint8 and d.is_contiguous()
-            with self._on_stream():
-                o[0].copy_(self.obs)
-            io.obs, io.reward, io.done, io.action_traj = o.data_ptr(), r.data_ptr(), d.data_ptr(), a.data_ptr()
-            io.obs_stride, io.reward_stride, io.done_stride, io.action_stride = N * D, N, N, 2 * N
-            tk = traj.get("topk_idx")
-            if tk is not None:
-                assert tuple(tk.shape) == (T, N, K) and tk.dtype == torch.int32 and tk.is_contiguous()
-                io.topk_idx, io.topk_stride = tk.data_ptr(), N * K
-        io.n_steps = T
-        io.max_v, io.max_w, io.sigma = agent.max_v, agent.max_w, (agent.explore_sigma if add_noise else 0.0)
-        io.seed = agent._noise_seed if noise_seed is None else int(noise_seed)
-        io.counter = agent._fused_calls + 1          # step t draws with counter + t: the calls a per-step chain would have made
-        agent._fused_calls += T
-        _abi.check(self.L.cn_rollout(self.h, C.byref(io), self._stream()))
-        self._keep_roll = (io, traj, agent._fw, agent._fw_struct)
-        if traj is not None:
-            with self._on_stream():                  # the current observation / outputs, where the per-step calls leave them
-                self.obs.copy_(traj["obs"][T]); self.reward.copy_(traj["reward"][T - 1]); self.done.copy_(traj["done"][T - 1])
-        return T * self.N
-
     def observe_external(self, ranges, odom, step_counter=None, is_reset=False, phase=0):
         """Env.get_state + Env.compute_reward on externally supplied /scan and /odom (Gazebo, a physical robot,
         or a recorded run): ranges [N,R] float64, odom [N,10] float64 = x, y, yaw, v, w, time.time(),

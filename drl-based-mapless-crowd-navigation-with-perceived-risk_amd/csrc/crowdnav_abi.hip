@@ -35,10 +35,6 @@ extern "C" __global__ void cn_env_kernel_orig_ext(CnKParams p);
 extern "C" __global__ void cn_env_kernel_orig_same(CnKParams p);
 extern "C" __global__ void cn_env_kernel_seq(CnKParams p);
 extern "C" __global__ void cn_env_kernel_gt_seq(CnKParams p);
-#ifndef CN_TIMING
-extern "C" __global__ void cn_rollout_kernel(CnKParams p);
-extern "C" __global__ void cn_rollout_kernel_gt(CnKParams p);
-#endif
 extern "C" __global__ void cn_bbox_kernel(CnKParams p, double* out);
 extern "C" __global__ void cn_gather_kernel(CnKParams p, float* last_ret, float* run_ret, int32_t* counters);
 
@@ -553,47 +549,6 @@ extern "C" int cn_step_sequence(cn_handle h, const cn_sequence_io* io, void* str
     hipLaunchKernelGGL(fn, dim3(h->cfg.n_envs), dim3(64), h->lds, (hipStream_t)stream, kp);
     HIPCHK(hipGetLastError());
     return CN_OK;
-}
-
-extern "C" int cn_rollout(cn_handle h, const cn_rollout_io* io, void* stream)
-{
-    if (!h || !io || !io->actor || !io->action || !io->obs || !io->reward || !io->done)
-        return fail(CN_ERR_ARG, "cn_rollout: null argument");
-    const cn_actor_weights* w = io->actor;
-    if (!w->w1t || !w->b1 || !w->w2t || !w->b2 || !w->w3 || !w->b3) return fail(CN_ERR_ARG, "cn_rollout: null actor weights");
-    if (h->cfg.obs_layout != CN_LAYOUT_RISK || h->cfg.ped_contact || h->cfg.ped_mode == 2)
-        return fail(CN_ERR_CONFIG, "cn_rollout: the fused rollout is built for obs_layout 0 with the plain simulator (no contact / social-force ticks)");
-    if (h->cfg.n_envs % 16) return fail(CN_ERR_CONFIG, "cn_rollout: n_envs must be a multiple of 16 (one actor tile = 16 environments = one workgroup)");
-    if (w->hidden != 256 || w->obs_dim != h->D || w->obs_dim_padded < w->obs_dim || (w->obs_dim_padded & 3))
-        return fail(CN_ERR_CONFIG, "cn_rollout: actor must be obs_dim -> 256 -> 256 -> 2 with obs_dim = cn_obs_dim() and obs_dim_padded a multiple of 4");
-    if (io->n_steps < 0 || io->obs_stride < 0 || io->reward_stride < 0 || io->done_stride < 0 || io->topk_stride < 0 || io->action_stride < 0)
-        return fail(CN_ERR_ARG, "cn_rollout: negative step count or stride");
-    if (io->n_steps == 0) return CN_OK;
-#ifdef CN_TIMING
-    return fail(CN_ERR_CONFIG, "cn_rollout: not built into the profiling library (libcrowdnav_timing.so)");
-#else
-    const size_t lds_env = (h->lds + 15) & ~(size_t)15;
-    const size_t lds_act = sizeof(float) * (16 * (size_t)(w->obs_dim_padded + 1) + 16 * 257);
-    const size_t lds = 16 * lds_env > lds_act ? 16 * lds_env : lds_act;
-    if (lds > 160 * 1024) return fail(CN_ERR_CONFIG, "cn_rollout: 16 environments' working sets exceed 160 KiB of LDS (fewer rays / pedestrians)");
-    CnKParams kp = h->kp;
-    kp.mode = CN_MODE_STEP; kp.auto_reset = 2;
-    kp.action = io->action; kp.step_counter = nullptr; kp.obs = io->obs; kp.final_obs = nullptr; kp.obs_f64 = nullptr;
-    kp.reward = io->reward; kp.done = io->done; kp.topk_idx = io->topk_idx;
-    kp.act_w1t = w->w1t; kp.act_b1 = w->b1; kp.act_w2t = w->w2t; kp.act_b2 = w->b2; kp.act_w3 = w->w3; kp.act_b3 = w->b3;
-    kp.act_Dp = w->obs_dim_padded; kp.act_max_v = io->max_v; kp.act_max_w = io->max_w; kp.act_sigma = io->sigma;
-    kp.act_seed = io->seed; kp.act_counter = io->counter;
-    kp.roll_action_traj = io->action_traj; kp.roll_steps = io->n_steps; kp.roll_obs_stride = io->obs_stride;
-    kp.roll_reward_stride = io->reward_stride; kp.roll_done_stride = io->done_stride; kp.roll_topk_stride = io->topk_stride;
-    kp.roll_action_stride = io->action_stride; kp.roll_lds_per_env = (int64_t)lds_env;
-    DeviceScope scope(h->device);
-    const bool gt = h->cfg.risk_mode == CN_RISK_GT;
-    void (*fn)(CnKParams) = gt ? cn_rollout_kernel_gt : cn_rollout_kernel;
-    if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    hipLaunchKernelGGL(fn, dim3(h->cfg.n_envs / 16), dim3(1024), lds, (hipStream_t)stream, kp);
-    HIPCHK(hipGetLastError());
-    return CN_OK;
-#endif
 }
 
 extern "C" int cn_get_counters(cn_handle h, int32_t* out, void* stream)

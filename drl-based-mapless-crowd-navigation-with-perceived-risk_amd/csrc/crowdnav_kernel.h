@@ -62,14 +62,9 @@ struct CnKParams {
     float* reward;
     uint8_t* done;
     int32_t* topk_idx;
-    // cn_rollout (the fused actor -> step loop, cn_rollout_kernel): actor weights (K-major, as cn_actor_weights), steps per launch,
-    // elements between consecutive steps' slots of the trajectory buffers (0 = every step in place)
-    const float *act_w1t, *act_b1, *act_w2t, *act_b2, *act_w3, *act_b3;
-    float* roll_action_traj;
-    int64_t roll_steps, roll_obs_stride, roll_reward_stride, roll_done_stride, roll_topk_stride, roll_action_stride, roll_lds_per_env, roll_action_in_stride;
-    uint64_t act_seed, act_counter;
-    int32_t act_Dp, act_reserved;
-    float act_max_v, act_max_w, act_sigma, act_reserved2;
+    // cn_step_sequence (cn_env_kernel_seq): steps per launch and the elements between consecutive steps' slots of the action /
+    // output buffers (0 = one slot: the same actions every step / every step's outputs in place)
+    int64_t roll_steps, roll_action_in_stride, roll_obs_stride, roll_reward_stride, roll_done_stride, roll_topk_stride;
     long long* timing;      // profiling build only: [N, 32] s_memtime stamps
 };
 

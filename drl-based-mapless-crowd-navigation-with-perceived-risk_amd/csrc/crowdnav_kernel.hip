@@ -897,9 +897,10 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
     double* o64 = obs64 ? obs64 + (size_t)env * D : nullptr;
     // End points, rounded ranges and gradients are 3-decimal values: LDS keeps the integer thousandths
     // (x == cn_div1000(mil) bit for bit), which halves the working set and doubles the waves per CU.
-    // The four table values a ray needs (its direction, and sin/cos of its end-point angle) are loaded at the top of its block
-    // (loading them one block ahead measured the same -- three other waves cover the L2 latency -- and cost four 64-bit
-    // register copies per block).
+    // The four table values a ray needs (its direction, and sin/cos of its end-point angle) are loaded at the top of its block.
+    // Loading them one block ahead measured the same twice: in round 2, and in round 3 with __builtin_amdgcn_sched_barrier(0)
+    // pinning the loads ahead of the previous block's body (the compiler otherwise sinks them back to their uses) -- 86.4 vs
+    // 86.7 M one launch, 107.8 vs 107.6 M in groups, same box: the L2 round trips are not what the wavefronts wait for.
     const double* const lidc = p->lidar_c; const double* const lids = p->lidar_s;
     const double* const angs = p->ang_s; const double* const angc = p->ang_c;
     // lane d's entry of cn_create's association table, asked for now so that its L2 round trip is over when the association
@@ -2058,16 +2059,16 @@ __device__ __forceinline__ double compute_reward(KP p, const Poly& pg, EnvRegs& 
 }  // namespace
 
 // `env`, `lane`: this wavefront's environment and lane; `smem`: its LDS working set (cn_lds_bytes).  The per-launch kernels pass
-// blockIdx.x / threadIdx.x / the block's dynamic LDS; the fused rollout kernel (FUSED, cn_rollout_kernel below) runs 16 of these per
-// workgroup, `t` steps into its launch, with the step's outputs going to slot t of the caller's trajectory buffers.
+// blockIdx.x / threadIdx.x / the block's dynamic LDS; the multi-step kernel (FUSED, cn_env_kernel_seq below) calls this once per
+// step, `t` steps into its launch, with the step's actions / outputs at slot t of the caller's buffers.
 template <bool EXT, bool TWO, int LAYOUT, bool GT = false, int SIM = 0, bool FUSED = false>
 __device__ __forceinline__ void env_kernel_body(const int env, const int lane, char* const smem, const long long t = 0)
 {
     KP p = (KP)__builtin_amdgcn_kernarg_segment_ptr();
     if constexpr (FUSED) {
-        // Inside the rollout kernel's step loop everything below is loop-invariant as far as the compiler can see, and it hoists
-        // it: ~100 kernel parameters and every lane-derived mask would stay live across the whole step (350 VGPR spills, 1 KB of
-        // scratch per lane).  Laundering the kernarg pointer through an empty asm once per step keeps the loads next to their uses.
+        // Inside the multi-step kernel's step loop everything below is loop-invariant as far as the compiler can see, and it
+        // hoists it: ~100 kernel parameters and every lane-derived mask would stay live across the whole step (hundreds of VGPR
+        // spills).  Laundering the kernarg pointer through an empty asm once per step keeps the loads next to their uses.
         unsigned long long pp = (unsigned long long)p;
         asm volatile("" : "+s"(pp));
         p = (KP)pp;
@@ -2471,7 +2472,7 @@ __device__ __forceinline__ void sequence_body()
     const long long T = p->roll_steps;
     for (long long t = 0; t < T; ++t) {
         int lane_ = threadIdx.x;
-        asm volatile("" : "+v"(lane_));          // per-step laundering, as in the fused rollout: nothing is hoisted out of the step loop
+        asm volatile("" : "+v"(lane_));          // per-step laundering (see env_kernel_body): nothing is hoisted out of the step loop
         lane_ &= 63;
         env_kernel_body<false, false, 0, GT, 0, true>(blockIdx.x, lane_, cn_smem, t);
     }
@@ -2569,7 +2570,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define ACT_H 256
 #define ACT_M 16
 #define ACT_THREADS 512            /* cn_actor_kernel: 8 waves */
-#define ROLL_THREADS 1024          /* cn_rollout_kernel: 16 waves = 16 environments */
 
 // U k-steps (4 k each) of this lane's weight operands: B[k = 4 u + (lane >> 4)][this wave's TPW interleaved columns]
 template <int TPW, int U> struct ActW { float b[U][TPW]; };
@@ -2740,46 +2740,6 @@ extern "C" __global__ void __launch_bounds__(ACT_THREADS) cn_actor_kernel(const 
     actor_tile<ACT_THREADS / 64>(obs + (size_t)row0 * D, min(ACT_M, n - row0), row0, D, Dp, W1T, b1, W2T, b2, W3, b3,
                                  action + 2 * (size_t)row0, nullptr, max_v, max_w, sigma, seed, counter, act_sm);
 }
-
-// ---- the fused rollout: T steps of [actor -> Env.step] in ONE launch (BASELINE configs[2]) -------------------------
-// A workgroup = 16 wavefronts = the 16 environments of one actor tile.  Per step: the 1024 threads run the tile through the actor
-// (f32 matrix cores) on the observations of slot t -> actions; barrier; every wavefront advances ITS environment by one control
-// period exactly as cn_env_kernel does (next-step reset convention, auto_reset = 2) and writes observation / reward / done / indices
-// to slot t + 1 / t of the caller's trajectory buffers; barrier.  No launch boundary, no grid-wide tail and no observation re-read
-// between the policy and the environment: a tile runs ahead of the others at its own pace, and the matrix cores of one CU work
-// while the vector units of another are in the environment phase.  The env LDS working sets are dead during the actor phase, so
-// the actor's tile buffers overlay them.  Same arithmetic as cn_actor_forward + cn_step chained on a stream: bit-identical
-// trajectories (tests/test_gpu_configs.py::test_fused_rollout_equals_the_chain).
-#ifndef CN_TIMING      /* not in the profiling build: with the stage stamps compiled in, this kernel trips an LLVM register-allocation
-                        * assertion ("even aligned vector registers"); cn_rollout reports CN_ERR_CONFIG there */
-template <bool GT>
-__device__ __forceinline__ void rollout_body()
-{
-    KP p = (KP)__builtin_amdgcn_kernarg_segment_ptr();
-    extern __shared__ __attribute__((aligned(16))) char cn_smem[];
-    // the wave index is wave-uniform, but only readfirstlane tells the compiler so: everything derived from `env` (state record,
-    // LDS base, every per-env scalar) then stays on the scalar unit, as it does in the one-wave-per-block kernels
-    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int row0 = blockIdx.x * ACT_M, env = row0 + wave;
-    const int D = p->R - 1 + 7 + 4 * p->K;
-    char* const mine = cn_smem + (size_t)wave * (size_t)p->roll_lds_per_env;
-    for (long long t = 0; t < p->roll_steps; ++t) {
-        const float* obs_t = p->obs + (size_t)(t * p->roll_obs_stride) + (size_t)row0 * D;
-        float* act_t = p->roll_action_traj ? p->roll_action_traj + (size_t)(t * p->roll_action_stride) + 2 * (size_t)row0 : nullptr;
-        actor_tile<ROLL_THREADS / 64>(obs_t, ACT_M, row0, D, p->act_Dp, p->act_w1t, p->act_b1, p->act_w2t, p->act_b2, p->act_w3, p->act_b3,
-                   const_cast<float*>(p->action) + 2 * (size_t)row0, act_t, p->act_max_v, p->act_max_w, p->act_sigma, p->act_seed,
-                   p->act_counter + (uint64_t)t, (float*)cn_smem);
-        __syncthreads();
-        int lane_ = lane;
-        asm volatile("" : "+v"(lane_));          // ... and the lane id, for the same reason
-        lane_ &= 63;
-        env_kernel_body<false, false, 0, GT, 0, true>(env, lane_, mine, t);
-        __syncthreads();
-    }
-}
-extern "C" __global__ void __launch_bounds__(ROLL_THREADS) cn_rollout_kernel(CnKParams p) { rollout_body<false>(); }
-extern "C" __global__ void __launch_bounds__(ROLL_THREADS) cn_rollout_kernel_gt(CnKParams p) { rollout_body<true>(); }
-#endif
 
 #ifdef CN_TIMING
 // ---- device arithmetic under test (PROFILING BUILD ONLY; tests/test_gpu_parity.py::test_device_math_*): the hand-written

@@ -226,34 +226,6 @@ typedef struct cn_sequence_io {
 } cn_sequence_io;
 int cn_step_sequence(cn_handle h, const cn_sequence_io* io, void* stream);
 
-/* The caller's rollout loop -- `for step: action = agent.act(state); state, reward, done = env.step(action, ...)`
- * (start_td3_training.py:118-127) -- for N environments and `n_steps` steps as ONE launch: per step the TD3 actor (as
- * cn_actor_forward, exploration noise keyed by (seed, counter + step, row)) runs on the current observations, then every
- * environment steps with the next-step reset convention (cn_step_io.auto_reset = 2).  One workgroup owns 16 environments (one
- * actor tile) for the whole launch, so there is no launch boundary, no device-wide join and no observation round trip between
- * policy and environment.  Results are bit-identical to chaining cn_actor_forward and cn_step on a stream.
- * Trajectory buffers: slot s of a buffer starts `stride` ELEMENTS after slot s - 1; stride 0 = every step overwrites slot 0.
- *   obs     dev [(n_steps + 1) slots][N, D] float32: slot 0 holds the current observations on entry (from cn_reset / the last
- *           step); step t reads slot t and writes slot t + 1 (the same buffer when obs_stride = 0)
- *   action  dev [N, 2] float32 work buffer (holds the last actions on exit); action_traj (or NULL): n_steps slots [N, 2]
- *   reward / done / topk_idx (or NULL): n_steps slots [N] / [N] / [N, K]
- * A step an environment spends on its reset (the one after done = 1) has reward 0, done 0 and is not a transition.
- * Requirements: obs_layout 0, plain simulator (ped_contact 0, ped_mode 0 / 1), n_envs a multiple of 16. */
-typedef struct cn_rollout_io {
-    const cn_actor_weights* actor;   /* host struct of device pointers, as for cn_actor_forward */
-    float* action;
-    float* obs;
-    float* reward;
-    uint8_t* done;
-    int32_t* topk_idx;
-    float* action_traj;
-    int64_t obs_stride, reward_stride, done_stride, topk_stride, action_stride;
-    int32_t n_steps, reserved;
-    float max_v, max_w, sigma, reserved2;
-    uint64_t seed, counter;
-} cn_rollout_io;
-int cn_rollout(cn_handle h, const cn_rollout_io* io, void* stream);
-
 /* get_episode_status / get_*_safety_violation_status inputs (ENV:1265-1283).
  * out: dev [N,14] = ego_viol, social_viol, obstacle_present_steps, ep_steps, success, failure, status, n_tracks,
  *                  episodes finished since cn_create, reset pending (auto_reset == 2),

@@ -129,64 +129,6 @@ def test_config3_actor_in_the_loop_4096_envs(oracle_mod, sigma):
     envs.close()
 
 
-@pytest.mark.parametrize("risk_mode", [0, 1])
-def test_fused_rollout_equals_the_chain(oracle_mod, risk_mode):
-    """cn_rollout -- T steps of [TD3 actor -> Env.step] in one launch, a workgroup owning 16 envs throughout -- leaves the same
-    trajectory, bit for bit, as cn_actor_forward -> cn_step (next-step reset) chained per step: observations, actions,
-    rewards, done flags, indices at every step (trajectory buffers), the final state (snapshot), counters and returns; with
-    and without exploration noise, in place and into trajectory buffers, across two consecutive calls.  The chain itself is
-    checked against the oracle at every step here too (the GPU's own actions drive it)."""
-    import torch
-    from crowdnav import Config
-    from crowdnav.env import VecEnv
-    from crowdnav.td3 import Agent
-    N, T = 512, 30
-    cfg = Config(n_envs=N, n_peds=20, max_steps=20, seed=31, ped_cycle_ms=1400, risk_mode=risk_mode)
-    for sigma in (0.0, 1.0):
-        chain, fused, inplace = VecEnv(cfg), VecEnv(cfg), VecEnv(cfg)
-        orc = oracle_mod.Oracle(cfg.as_dict())
-        oracle_mod.set_num_threads()
-        ag = [Agent(obs_dim=chain.D, device="cuda", seed=5, memory_size=16, explore_sigma=sigma) for _ in range(3)]
-        for a_ in ag:
-            with torch.no_grad():
-                a_.actor.linear1.weight.mul_(4.0); a_.actor.linear3.weight.mul_(10.0)
-        o0 = chain.reset(); fused.reset(); inplace.reset(); torch.cuda.synchronize()
-        assert np.array_equal(o0.cpu().numpy(), orc.reset().astype(np.float32))
-        D, K = chain.D, chain.K
-        for call in range(2):                    # the second call continues from where the first one stopped
-            traj = dict(obs=torch.zeros((T + 1, N, D), device="cuda"), action=torch.zeros((T, N, 2), device="cuda"),
-                        reward=torch.zeros((T, N), device="cuda"), done=torch.zeros((T, N), dtype=torch.uint8, device="cuda"),
-                        topk_idx=torch.zeros((T, N, K), dtype=torch.int32, device="cuda"))
-            fused.rollout_fused(ag[1], T, add_noise=sigma > 0, traj=traj)
-            inplace.rollout_fused(ag[2], T, add_noise=sigma > 0)
-            n_done = 0
-            for t in range(T):
-                act = ag[0].act_mfma(chain.obs, add_noise=sigma > 0)
-                prev = chain.obs.clone()
-                chain.step(act, auto_reset="next")
-                torch.cuda.synchronize()
-                assert torch.equal(traj["obs"][t], prev) and torch.equal(traj["action"][t], act), (call, t)
-                assert torch.equal(traj["obs"][t + 1], chain.obs) and torch.equal(traj["reward"][t], chain.reward), (call, t)
-                assert torch.equal(traj["done"][t], chain.done) and torch.equal(traj["topk_idx"][t], chain.topk_idx), (call, t)
-                oc, rc, dc, ic = orc.step(act.cpu().numpy().astype(np.float64), auto_reset="next")
-                assert np.array_equal(chain.done.cpu().numpy(), dc) and np.array_equal(chain.topk_idx.cpu().numpy(), ic), (call, t)
-                assert np.array_equal(chain.obs.cpu().numpy(), oc.astype(np.float32)), (call, t)
-                n_done += int(dc.sum())
-            assert n_done > N // 2
-            for other in (fused, inplace):
-                assert torch.equal(other.obs, chain.obs) and torch.equal(other.reward, chain.reward) and torch.equal(other.done, chain.done)
-                assert np.array_equal(other.snapshot(), chain.snapshot())
-                assert torch.equal(other.counters(), chain.counters()) and torch.equal(other.returns()[0], chain.returns()[0])
-            assert torch.equal(inplace.topk_idx, chain.topk_idx)
-        for e_ in (chain, fused, inplace):
-            e_.close()
-    import crowdnav
-    with pytest.raises(crowdnav.CrowdNavError):          # one actor tile = 16 environments = one workgroup
-        VecEnv(Config(n_envs=24)).rollout_fused(ag[0], 1)
-    with pytest.raises(crowdnav.CrowdNavError):
-        VecEnv(Config(n_envs=16, ped_contact=1)).rollout_fused(ag[0], 1)
-
-
 def test_batched_trainer_runs_on_the_next_step_reset_kernel(tmp_path):
     """crowdnav.train (TRAIN:40-168 batched) on the fast one-observation kernel: a finished env's next launch is its reset and
     is masked out of the replay, so the buffer holds exactly the env-steps taken; terminal transitions carry done = 1 and the

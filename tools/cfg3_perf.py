@@ -1,12 +1,12 @@
 #!/usr/bin/env python
-"""BASELINE configs[2] (TD3 actor in the loop) decompositions side by side: one act -> step chain, rollout_groups with 2 / 4 stream
-groups, the fused cn_rollout launch.  Resets subtracted (next-step reset)."""
+"""BASELINE configs[2] (TD3 actor in the loop) decompositions side by side: one act -> step chain and rollout_groups with 2 / 4
+stream groups.  Resets subtracted (next-step reset)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "drl-based-mapless-crowd-navigation-with-perceived-risk_amd"))
 import torch
 from crowdnav import Config
-from crowdnav.env import VecEnv, VecEnvGroups
+from crowdnav.env import VecEnvGroups
 from crowdnav.rollout import rollout_groups
 from crowdnav.td3 import Agent
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
@@ -30,11 +30,3 @@ for G in (1, 2, 4):
         m1 = marker(g.envs)
     print("rollout_groups G=%d: %.4f ms/step %.2f M env-steps/s" % (G, dt / K * 1e3, (N * K - (m1 - m0)) / dt / 1e6))
     g.close()
-env = VecEnv(cfg); env.reset()
-agent = Agent(obs_dim=env.D, device="cuda", seed=0, memory_size=16)
-env.rollout_fused(agent, 200); torch.cuda.synchronize()
-for rep in range(2):
-    m0 = marker([env]); torch.cuda.synchronize(); t0 = time.perf_counter()
-    env.rollout_fused(agent, K); torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    m1 = marker([env])
-print("fused cn_rollout   : %.4f ms/step %.2f M env-steps/s" % (dt / K * 1e3, (N * K - (m1 - m0)) / dt / 1e6))
