@@ -846,7 +846,8 @@ def test_error_codes_and_limits():
     L = crowdnav.lib()
     h = C.c_void_p()
     for kw, code in ((dict(n_envs=0), -2), (dict(k_obstacles=17), -2), (dict(n_rays=4), -2), (dict(track_capacity=48), -2),
-                     (dict(n_peds=5000), -2)):
+                     (dict(n_peds=5000), -2), (dict(py2_round=2), -2), (dict(ped_mode=3), -2), (dict(ped_mode=2, sf_tau=0.0), -2),
+                     (dict(ped_mode=2, ped_contact=1), -2)):
         cfg = Config(**kw).to_c()
         rc = L.cn_create(C.byref(cfg), 0, C.byref(h))
         assert rc == code, (kw, rc, L.cn_last_error())
@@ -857,6 +858,7 @@ def test_error_codes_and_limits():
     assert L.cn_step(h, None, None) == -1 and b"null" in L.cn_last_error()
     assert L.cn_reset(h, None, None, None, None) == -1
     assert L.cn_snapshot(h, C.c_void_p(1), 8) == -5              # buffer too small
+    assert L.cn_step_sequence(h, None, None) == -1 and b"null" in L.cn_last_error()
     L.cn_destroy(h)
     # 1024 rays x 128 pedestrians still fits (LDS sized per configuration)
     from crowdnav.env import VecEnv

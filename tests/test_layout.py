@@ -68,7 +68,9 @@ def test_cn_create_rejects_configs_the_reference_cannot_run():
     for bad, msg in ((dict(max_scan_range=0.5, min_scan_range=0.5), b"max_scan_range"),
                      (dict(max_scan_range=0.1, min_scan_range=0.12), b"max_scan_range"),
                      (dict(n_rays=4), b"out of range"), (dict(k_obstacles=0), b"out of range"),
-                     (dict(risk_mode=1, obs_layout=1), b"risk_mode gt")):
+                     (dict(risk_mode=1, obs_layout=1), b"risk_mode gt"), (dict(py2_round=3), b"out of range"),
+                     (dict(ped_mode=2, sf_B=0.0), b"social force"), (dict(ped_mode=2, obs_layout=1), b"social force"),
+                     (dict(ped_mode=2, n_peds=100, n_rays=360), b"social force")):
         h = C.c_void_p()
         cfg = Config(**bad).to_c()
         rc = L.cn_create(C.byref(cfg), 0, C.byref(h))
