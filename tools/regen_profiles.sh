@@ -9,7 +9,7 @@ python tools/stage_timing.py 256 2>&1 | grep -v $F > "$OUT/stage_timing.txt"
 python tools/wave_tail.py 2>&1 | grep -v $F > "$OUT/wave_tail.txt"
 python tools/tail_corr.py 2>&1 | grep -v $F > "$OUT/tail_corr.txt"
 python tools/bench_configs.py 2>&1 | grep -v $F > "$OUT/configs_1gpu.txt"
-{ python tools/quick_perf.py lidar-tracker; CN_RISK=1 python tools/quick_perf.py gt; CN_LAYOUT=1 python tools/quick_perf.py layout1; CN_LAYOUT=2 python tools/quick_perf.py layout2; } 2>&1 | grep -v $F > "$OUT/quick_perf.txt"
+{ python tools/quick_perf.py lidar-tracker; CN_RISK=1 python tools/quick_perf.py gt; CN_LAYOUT=1 python tools/quick_perf.py layout1; CN_LAYOUT=2 python tools/quick_perf.py layout2; CN_PY2=1 CN_GEOS=1 python tools/quick_perf.py py2+geos38; CN_PED_MODE=2 python tools/quick_perf.py social-force; } 2>&1 | grep -v $F > "$OUT/quick_perf.txt"
 python tools/startup_transient.py 24 3 2>&1 | grep -v $F > "$OUT/startup_transient.txt"
 python tools/cfg3_perf.py 2>&1 | grep -v $F > "$OUT/config3_decompositions.txt"
 { python tools/seq_perf.py 4096; python tools/seq_perf.py 16384; } 2>&1 | grep -v $F > "$OUT/step_sequence.txt"
