@@ -12,7 +12,7 @@ class CnConfig(C.Structure):
         ("max_steps", C.c_int32), ("ped_mode", C.c_int32), ("dt_ms", C.c_int32), ("scan_latency_ms", C.c_int32),
         ("settle_ms", C.c_int32), ("ped_cycle_ms", C.c_int32), ("ped_stagger_ms", C.c_int32), ("track_capacity", C.c_int32),
         ("obs_layout", C.c_int32), ("geos_untyped_empty", C.c_int32), ("ped_contact", C.c_int32), ("risk_mode", C.c_int32),
-        ("py2_round", C.c_int32), ("reserved1", C.c_int32),
+        ("py2_round", C.c_int32), ("sf_tick_ms", C.c_int32),
         ("env_index_base", C.c_int64), ("seed", C.c_uint64),
         ("room_half", C.c_double), ("ped_radius", C.c_double), ("ped_vmax", C.c_double),
         ("robot_clearance", C.c_double), ("lidar_min", C.c_double), ("lidar_max", C.c_double),
@@ -45,7 +45,7 @@ class Config:
     ped_contact: int = 0           # 1: frictionless rigid contact between pedestrians and with the robot (WORLD:86-145)
     risk_mode: int = 0             # 0: lidar segmentation + tracker (the reference); 1: "gt" -- simulator pedestrians
     py2_round: int = 0             # 1: Python-2.7 round() -- exact ties away from zero, round(np.float64) = the builtin (the reference's platform)
-    reserved1: int = 0
+    sf_tick_ms: int = 0            # ped_mode 2: physics tick of the social-force integrator in ms (0 -> 10)
     env_index_base: int = 0
     seed: int = 1234
     room_half: float = 1.40        # WORLD:926-1108

@@ -232,7 +232,7 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
         c.ped_mode < 0 || c.ped_mode > 2)
         return fail(CN_ERR_CONFIG, "cn_create: config out of range");
     if (c.ped_mode == 2 && (c.ped_contact || c.obs_layout != CN_LAYOUT_RISK || !(c.sf_tau > 0.0) || !(c.sf_B > 0.0) ||
-                            !(c.sf_wall_B > 0.0) || !(c.sf_goal_eps >= 0.0) || 64 * (size_t)c.n_peds > 16 * (size_t)(c.n_rays - 1)))
+                            !(c.sf_wall_B > 0.0) || !(c.sf_goal_eps >= 0.0) || c.sf_tick_ms < 0 || 64 * (size_t)c.n_peds > 16 * (size_t)(c.n_rays - 1)))
         return fail(CN_ERR_CONFIG, "cn_create: ped_mode 2 (social force) needs obs_layout 0, ped_contact 0, positive sf_tau / sf_B / "
                                    "sf_wall_B and n_peds <= (n_rays - 1) / 4");
     if (!(c.max_scan_range > c.min_scan_range))    // ENV:581, UTL:322 divide by their difference (ZeroDivisionError in the reference)
@@ -298,7 +298,9 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
     k.settle_ms = c.settle_ms; k.ped_cycle_ms = c.ped_cycle_ms; k.ped_stagger_ms = c.ped_stagger_ms;
     k.geos_untyped_empty = c.geos_untyped_empty; k.ped_contact = c.ped_contact; k.risk_mode = c.risk_mode; k.py2_round = c.py2_round;
     k.sf_tau = c.sf_tau; k.sf_A = c.sf_A; k.sf_B = c.sf_B; k.sf_wall_A = c.sf_wall_A; k.sf_wall_B = c.sf_wall_B;
-    k.sf_goal_eps2 = c.sf_goal_eps * c.sf_goal_eps;
+    k.sf_goal_eps2 = c.sf_goal_eps * c.sf_goal_eps; k.sf_tick_ms = c.sf_tick_ms > 0 ? c.sf_tick_ms : 10;
+    // pair matrix G [P][P] + next state + goal records in the simulator's LDS scratch (regions A + B, 16 (R - 1) bytes)?
+    k.sf_pair_matrix = (c.ped_mode == 2 && P >= 2 && P < 256 && 8 * (size_t)P * P + 64 * (size_t)P + (size_t)P * (P - 1) + 16 <= 16 * (size_t)(R - 1)) ? 1 : 0;
     k.near_sep = cn_near_separate(R, P, K, h->max_conf, h->trk_cap);
     k.max_conf = h->max_conf; k.trk_cap = h->trk_cap; k.env_index_base = c.env_index_base; k.seed = c.seed;
     k.room_half = c.room_half; k.ped_radius = c.ped_radius; k.ped_vmax = c.ped_vmax; k.robot_clearance = c.robot_clearance;
@@ -649,7 +651,7 @@ static const char* config_mismatch(const cn_config& a, const cn_config& b)
 #define CN_CMP(f) if (memcmp(&a.f, &b.f, sizeof(a.f)) != 0) return #f;
     CN_CMP(n_envs) CN_CMP(n_peds) CN_CMP(n_rays) CN_CMP(k_obstacles) CN_CMP(max_steps) CN_CMP(ped_mode) CN_CMP(dt_ms)
     CN_CMP(scan_latency_ms) CN_CMP(settle_ms) CN_CMP(ped_cycle_ms) CN_CMP(ped_stagger_ms) CN_CMP(track_capacity) CN_CMP(obs_layout)
-    CN_CMP(geos_untyped_empty) CN_CMP(ped_contact) CN_CMP(risk_mode) CN_CMP(py2_round) CN_CMP(env_index_base) CN_CMP(seed)
+    CN_CMP(geos_untyped_empty) CN_CMP(ped_contact) CN_CMP(risk_mode) CN_CMP(py2_round) CN_CMP(sf_tick_ms) CN_CMP(env_index_base) CN_CMP(seed)
     CN_CMP(room_half) CN_CMP(ped_radius) CN_CMP(ped_vmax) CN_CMP(robot_clearance) CN_CMP(lidar_min) CN_CMP(lidar_max) CN_CMP(lidar_span)
     CN_CMP(lidar_offset_x) CN_CMP(max_scan_range) CN_CMP(min_scan_range) CN_CMP(goal_x) CN_CMP(goal_y) CN_CMP(start_x) CN_CMP(start_y)
     CN_CMP(spawn_x) CN_CMP(spawn_y) CN_CMP(spawn_yaw) CN_CMP(waypoint_radius) CN_CMP(goal_eps)

@@ -16,6 +16,7 @@ struct CnKParams {
     int32_t ablate;          // PROFILING BUILD ONLY (cn_debug_set_ablate): skips stages, results are then invalid
     int32_t ext_phase;       // cn_external_io.phase (CN_PHASE_* mask, 0 = whole flow); CN_MODE_EXT_STEP only
     int32_t geos_untyped_empty, ped_contact, risk_mode, py2_round;   // cn_config switches
+    int32_t sf_tick_ms, sf_pair_matrix;   // ped_mode 2: physics tick; 1 = the pair matrix fits in the simulator's LDS scratch
     int64_t env_index_base;
     uint64_t seed;
     // constants (cn_config)

@@ -395,7 +395,8 @@ __device__ __forceinline__ void sim_advance_contact(KP p, EnvRegs& e, int env, i
 // other pedestrians, the four walls and the robot, on physics ticks of at most 10 ms.  lane = pedestrian; every acceleration is
 // evaluated from the tick-start pedestrian state (Jacobi) in the oracle's order -- goal, pedestrians by index, walls -x +x -y +y,
 // robot -- then v (capped at 1.3 v0), then x, clamped into the room.  The pair loop reads pedestrian j's position as an LDS
-// broadcast (one address for the whole wave).  `scr`: 8 P doubles of LDS scratch (regions A + B are idle while the simulator
+// broadcast (one address for the whole wave).  `scr`: 8 P doubles of LDS scratch (+ P^2 doubles + P (P - 1) / 2 shorts when
+// cn_create found room for the pair matrix) (regions A + B are idle while the simulator
 // runs): next state [4 P] and this call's copy of the goal records + desired speeds [4 P] (goal x, y, counter, v0), so that the
 // 16 ticks of a step pay no global-memory round trip and no RNG evaluation.
 __device__ __forceinline__ void sim_advance_sf(KP p, EnvRegs& e, int env, int lane, double* ped_p, double* ped_v, double* scr, int ms)
@@ -409,15 +410,45 @@ __device__ __forceinline__ void sim_advance_sf(KP p, EnvRegs& e, int env, int la
     double* const gaux = p->ped_aux + (size_t)env * 3 * P;
     double* const nxt = scr;
     double* const aux = scr + 4 * P;
+    // Small crowds (the pair matrix fits in the scratch: P <= 22 at 360 rays): the pair term g_ij = A e^{(2r - d)/B} / d is
+    // symmetric in (i, j) bit for bit (d^2 is built from squares of the same differences), so each unordered pair is evaluated
+    // ONCE, lane = pair over all 64 lanes (P (P - 1) / 2 = 190 pairs = 3 passes at P = 20 instead of 20 loop iterations with 20
+    // active lanes), into G [P][P]; the per-pedestrian sum then only reads g and applies it in the oracle's order.
+    const bool pairm = p->sf_pair_matrix != 0;
+    double* const G = scr + 8 * P;
+    unsigned short* const plist = (unsigned short*)(G + P * P);      // pair t -> (i << 8) | j, i < j, row-major
+    const int npairs = (P * (P - 1)) >> 1;
     for (int i = lane; i < P; i += 64) {
         aux[4 * i] = gaux[3 * i]; aux[4 * i + 1] = gaux[3 * i + 1]; aux[4 * i + 2] = gaux[3 * i + 2];
         aux[4 * i + 3] = p->ped_vmax * fma(0.5, cn_rng_u01(p->seed, gid, 4u, (uint32_t)i, 0u), 0.5);     // desired speed v0
+        if (pairm) {
+            const int base = (i * (2 * P - i - 1)) >> 1;
+            for (int j = i + 1; j < P; ++j) plist[base + (j - i - 1)] = (unsigned short)((i << 8) | j);
+        }
     }
     CN_SYNC();
+    const int tick = p->sf_tick_ms;
     for (int tt = 0; tt < ms; ) {
-        const int h = (ms - tt < 10) ? (ms - tt) : 10;
+        const int h = (ms - tt < tick) ? (ms - tt) : tick;
         const double hs = cn_div1000((double)h);
         robot_advance(p, e, h);
+        if (pairm) {
+            for (int t0 = 0; t0 < npairs; t0 += 64) {
+                const int t = t0 + lane;
+                if (t < npairs) {
+                    const int ij = plist[t], i = ij >> 8, j = ij & 255;
+                    const double ddx = ped_p[2 * i] - ped_p[2 * j], ddy = ped_p[2 * i + 1] - ped_p[2 * j + 1];
+                    const double d2 = fma(ddx, ddx, ddy * ddy);
+                    double g = CN_NAN;
+                    if (d2 > 0.0 && !(d2 > cut2)) {
+                        const double d = sqrt(d2), arg = (2.0 * r - d) / B;
+                        if (!(arg < -12.0)) g = (A * cn_det_exp(arg)) * (1.0 / d);
+                    }
+                    G[i * P + j] = g; G[j * P + i] = g;
+                }
+            }
+            CN_SYNC();
+        }
         for (int i0 = 0; i0 < P; i0 += 64) {
             const int i = i0 + lane;
             const bool act = i < P;
@@ -438,6 +469,13 @@ __device__ __forceinline__ void sim_advance_sf(KP p, EnvRegs& e, int env, int la
             double ex = 0.0, ey = 0.0;
             if (gd2 > 0.0) { const double ginv = 1.0 / sqrt(gd2); ex = gdx * ginv; ey = gdy * ginv; }
             double ax = (v0 * ex - vxi) / tau, ay = (v0 * ey - vyi) / tau;
+            if (pairm) {
+                for (int j = 0; j < P; ++j) {
+                    const double g = act ? G[i * P + j] : CN_NAN;
+                    const double ddx = xi - ped_p[2 * j], ddy = yi - ped_p[2 * j + 1];
+                    if (j != i && g == g) { ax = fma(g, ddx, ax); ay = fma(g, ddy, ay); }     // NaN = no contribution (skipped pair)
+                }
+            } else
             for (int j = 0; j < P; ++j) {
                 const double ddx = xi - ped_p[2 * j], ddy = yi - ped_p[2 * j + 1];
                 const double d2 = fma(ddx, ddx, ddy * ddy);

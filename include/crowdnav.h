@@ -87,7 +87,9 @@ typedef struct cn_config {
                               * 1: Python-2.7 round(), the reference's platform (README.md:108-110): exact ties go AWAY from zero,
                               *    and round(np.float64, n) is the builtin's correctly rounded decimal too (ENV:255, ORIG:280, RW:209).
                               *    Every round() site: ENV:1208, 329-346, 1025-1042, UTL:122-123, 460 ... (np.around at ENV:1042 stays numpy) */
-    int32_t reserved1;
+    int32_t sf_tick_ms;      /* ped_mode 2: physics tick of the social-force integrator, ms; 0 -> 10 (the contact model's tick).  The model is
+                              * an explicit scheme, so the tick is part of its definition: 10 ms resolves a 0.2 m/s crowd to 2 mm per tick,
+                              * 50 ms (the usual choice for social-force crowds, tau = 0.5 s) costs a fifth */
     int64_t env_index_base;  /* global index of env 0: RNG streams are keyed by global index */
     uint64_t seed;
     double room_half;        /* WORLD:926-1108 -> 1.40 */
@@ -110,7 +112,7 @@ typedef struct cn_config {
      *   a = (v0 e_goal - v) / sf_tau + sum_j sf_A exp((2 r - d_ij) / sf_B) n_ij          (other pedestrians, index order)
      *     + sum_walls sf_wall_A exp((r - d_w) / sf_wall_B) n_w                            (-x, +x, -y, +y)
      *     + sf_A exp((r + robot_clearance - d_ir) / sf_B) n_ir                            (the robot)
-     *   v <- v + a h, |v| capped at 1.3 v0;  x <- clamp(x + v h) into the room   (semi-implicit Euler, h = 0.01 s) */
+     *   v <- v + a h, |v| capped at 1.3 v0;  x <- clamp(x + v h) into the room   (semi-implicit Euler, h = sf_tick_ms) */
     double sf_tau;           /* relaxation time -> 0.5 s (Helbing & Molnar 1995) */
     double sf_A;             /* pedestrian / robot repulsion strength, m/s^2 -> 0.8 (2.1 at full walking speed, scaled to 0.2 m/s crowds) */
     double sf_B;             /* ... and range, m -> 0.10 */

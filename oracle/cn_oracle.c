@@ -392,7 +392,7 @@ static double sf_desired_speed(const cno_config* c, int64_t gid, int i)
 
 /* cn_config.ped_mode = 2 (BASELINE north_star "per-env pedestrian social-force integration"; include/crowdnav.h states the
  * model): Helbing-Molnar goal attraction + exponential repulsion from the other pedestrians, the four walls and the robot, on
- * physics ticks of at most 10 ms.  Per tick: the (kinematic) robot moves by the mid-point rule; every pedestrian's acceleration
+ * physics ticks of at most sf_tick_ms (10 ms by default).  Per tick: the (kinematic) robot moves by the mid-point rule; every pedestrian's acceleration
  * is evaluated from the tick-start pedestrian state (Jacobi) and the robot's new position, contributions summed in the order
  * goal, pedestrians by index, walls -x +x -y +y, robot; semi-implicit Euler (v first, capped at 1.3 v0, then x, clamped into
  * the room).  Contributions whose exponent is below -12 are dropped (6e-6 of the strength).  A goal within sf_goal_eps at a
@@ -406,9 +406,10 @@ static void sim_advance_sf(const cno_sim* s, env_t* e, int64_t gid, int64_t ms)
     const double A = c->sf_A, B = c->sf_B, Aw = c->sf_wall_A, Bw = c->sf_wall_B, tau = c->sf_tau;
     const double eps2 = c->sf_goal_eps * c->sf_goal_eps, Rr = r + c->robot_clearance;
     double* nxt = (double*)malloc(sizeof(double) * 4 * (size_t)(P > 0 ? P : 1));
+    const int64_t tick = c->sf_tick_ms > 0 ? c->sf_tick_ms : 10;
     int64_t t = 0;
     while (t < ms) {
-        const int64_t h = (ms - t < 10) ? (ms - t) : 10;
+        const int64_t h = (ms - t < tick) ? (ms - t) : tick;
         const double hs = (double)h / 1000.0;
         robot_advance(s, e, h);
         for (int i = 0; i < P; ++i) {
@@ -1700,7 +1701,7 @@ int cno_create(const cno_config* cfg, cno_sim** out)
         return -2;
     if (cfg->ped_cycle_ms < 1 || cfg->dt_ms < 1) return -2;
     if (cfg->ped_mode < 0 || cfg->ped_mode > 2) return -2;
-    if (cfg->ped_mode == 2 && (cfg->ped_contact || !(cfg->sf_tau > 0.0) || !(cfg->sf_B > 0.0) || !(cfg->sf_wall_B > 0.0))) return -2;
+    if (cfg->ped_mode == 2 && (cfg->ped_contact || !(cfg->sf_tau > 0.0) || !(cfg->sf_B > 0.0) || !(cfg->sf_wall_B > 0.0) || cfg->sf_tick_ms < 0)) return -2;
     cno_sim* s = (cno_sim*)calloc(1, sizeof(cno_sim));
     s->cfg = *cfg;
     s->n = cfg->n_rays - 1;

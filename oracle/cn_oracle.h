@@ -43,7 +43,7 @@ typedef struct cno_config {
     int32_t ped_contact;     /* 1: frictionless rigid contact pedestrian-pedestrian and pedestrian-robot */
     int32_t risk_mode;       /* 0: lidar tracker (reference); 1: gt (simulator pedestrians feed A21-A24) */
     int32_t py2_round;       /* 1: Python-2.7 round(): exact ties away from zero, round(np.float64, n) = the builtin (include/crowdnav.h) */
-    int32_t reserved1;
+    int32_t sf_tick_ms;      /* ped_mode 2: physics tick in ms (0 -> 10) */
     int64_t env_index_base;  /* global index of env 0 (multi-GPU sharding) */
     uint64_t seed;
     double room_half;        /* inner half extent of the square room (WORLD:926-1108 -> 1.40) */

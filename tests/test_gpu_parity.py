@@ -384,6 +384,11 @@ def test_rollout_parity_social_force_pedestrians(oracle_mod, risk_mode, tmp_path
         n_done, frac = _compare_rollout(oracle_mod, steps=80, seed=61, reset_mode=mode, n_envs=32, n_peds=20, max_steps=40,
                                         ped_mode=2, risk_mode=risk_mode)
         assert n_done > 10 and frac > 0.999
+    # 50 ms ticks (160 ms = 3 x 50 + 10), with the pair matrix in LDS (20 pedestrians) and without (30: it no longer fits)
+    for P in (20, 30):
+        n_done, frac = _compare_rollout(oracle_mod, steps=60, seed=63 + P, reset_mode="next", n_envs=32, n_peds=P, max_steps=40,
+                                        ped_mode=2, risk_mode=risk_mode, sf_tick_ms=50, sf_A=1.2)
+        assert frac > 0.999
     # a denser room with stronger forces, more than 64 pedestrians (two lane passes), goals reached all the time
     cfg = Config(n_envs=24, n_peds=80, n_rays=360, ped_mode=2, risk_mode=risk_mode, seed=62, max_steps=50, room_half=1.8,
                  sf_A=1.5, sf_B=0.15, sf_goal_eps=0.3, min_scan_range=0.0)

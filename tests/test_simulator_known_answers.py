@@ -271,6 +271,20 @@ def test_social_force_relaxes_to_the_desired_speed(oracle_mod):
     assert abs(pp[0, 0] - want_x) < 1e-12
 
 
+def test_social_force_tick_is_part_of_the_model(oracle_mod):
+    """sf_tick_ms: the explicit scheme's step.  With 50 ms ticks the relaxation follows v_n = v0 (1 - (1 - 0.05 / tau)^n); an advance
+    that is not a multiple of the tick ends with a shorter one (160 ms = 3 x 50 + 10)."""
+    o, v0 = _sf_world(oracle_mod, [[-4.0, 0.0]], [[4.0, 0.0]], sf_tick_ms=50)
+    o.hsim_advance(500, 0.0, 0.0)
+    _, pp, pv, _ = o.sim_state()
+    assert abs(pv[0, 0] - v0[0] * (1.0 - 0.9 ** 10)) < 1e-13
+    o.hsim_reset(); o.set_state(0, None, None, None, None, None, ped_aux=[[4.0, 0.0, 0.0]])
+    o.hsim_advance(160, 0.0, 0.0)
+    _, pp, pv, _ = o.sim_state()
+    want = v0[0] * (1.0 - 0.9 ** 3); want = want + (v0[0] - want) / 0.5 * 0.01
+    assert abs(pv[0, 0] - want) < 1e-13
+
+
 def test_social_force_pair_repulsion_is_antisymmetric_and_has_the_stated_strength(oracle_mod):
     """Two pedestrians 0.2 m apart, goals straight ahead in +y: after one tick from rest the x-velocities are exactly opposite and
     equal h A exp((2 r - d) / B); they drift apart until the force has faded, never crossing."""

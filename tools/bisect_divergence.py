@@ -90,7 +90,6 @@ def bisect(path, steps=50, seed=0, auto_reset="next", device=0, verbose=True):
     z = np.load(path if str(path).endswith(".npz") else str(path) + ".npz")
     hd, _ = _abi.split_snapshot(z["blob"])
     cfgd = _abi.config_to_dict(hd.config)
-    cfgd.pop("reserved1", None)
     cfg = Config(**{k: v for k, v in cfgd.items() if k in Config.__dataclass_fields__})
     env = VecEnv(cfg, device=device)
     env.enable_f64_obs()

@@ -28,4 +28,5 @@ $R --envs 1024 --steps $((200 * S)) --peds 60 --py2 1 --geos 1
 $R --envs 512 --steps $((200 * S)) --layout 2 --dt-ms 50 --py2 1
 $R --envs 1024 --steps $((200 * S)) --ped-mode 2 --reset-mode next
 $R --envs 512 --steps $((150 * S)) --ped-mode 2 --peds 60 --risk-mode 1 --min-scan 0.0
+$R --envs 1024 --steps $((200 * S)) --ped-mode 2 --sf-tick 50 --reset-mode next
 } 2>&1 | grep -v amdgpu.ids | tee "$OUT/$NAME.txt"

@@ -50,7 +50,7 @@ def groups(cfg, G):
 
 X = dict(risk_mode=int(os.environ.get("CN_RISK", 0)), obs_layout=int(os.environ.get("CN_LAYOUT", 0)),      # CN_RISK=1: gt mode
          py2_round=int(os.environ.get("CN_PY2", 0)), geos_untyped_empty=int(os.environ.get("CN_GEOS", 0)),  # the reference's own platform
-         ped_mode=int(os.environ.get("CN_PED_MODE", 0)))                                                    # 2: social-force pedestrians
+         ped_mode=int(os.environ.get("CN_PED_MODE", 0)), sf_tick_ms=int(os.environ.get("CN_SF_TICK", 0)))                                                    # 2: social-force pedestrians
 c2 = Config(n_envs=4096, ped_cycle_ms=1400, **X)
 c16 = Config(n_envs=16384, ped_cycle_ms=1400, **X)
 c5 = Config(n_envs=4096, n_peds=100, n_rays=720, room_half=2.4, ped_cycle_ms=1400, **X)
