@@ -673,6 +673,69 @@ def test_golden_replay_through_the_kernel(name):
         assert differ > 20
 
 
+@pytest.mark.parametrize("layout", [0, 1, 2])
+def test_external_scans_with_nan_zero_inf_and_out_of_range_values(oracle_mod, layout):
+    """What a physical lidar delivers (UTL:375-392, ORIG:288-300, RW:220-225): NaN, 0.0, +inf, returns beyond max_scan_range and
+    below lidar_min, whole scans of one value -- with odometry jumping around and clocks that repeat -- through
+    cn_observe_external against the oracle's restatement fed with the same messages, call by call: observation, reward, done,
+    indices, counters, status bits (a repeated clock raises CN_ST_DT_ZERO on both sides, a zero ttc CN_ST_TTC_ZERO)."""
+    import torch
+    from crowdnav import Config
+    from crowdnav.env import VecEnv
+    kw = dict(n_envs=1, n_peds=0, max_steps=60, seed=3, obs_layout=layout, dt_ms=50 if layout == 2 else 150)
+    env = VecEnv(Config(**kw)); env.enable_f64_obs()
+    orc = oracle_mod.Oracle(**kw)
+    rng = np.random.default_rng(layout + 5)
+    R = 360
+    now = 10.0
+    px, py, yaw = 1.0, -1.0, 3.14
+    worst = 0.0
+    for i in range(80):
+        is_reset = i % 27 == 0
+        r = rng.uniform(0.05, 0.9, R)
+        kind = i % 9
+        if kind == 1:
+            r[:] = np.inf
+        elif kind == 2:
+            r[:] = 0.0
+        elif kind == 3:
+            r[:] = np.nan
+        elif kind == 4:
+            r[:] = 0.3                                    # one flat arc all around
+        else:
+            m = rng.uniform(size=R)
+            r[m < 0.25] = np.inf; r[(m >= 0.25) & (m < 0.30)] = 0.0; r[(m >= 0.30) & (m < 0.35)] = np.nan
+            a, b = sorted(rng.integers(0, R, 2))
+            r[a:b] = np.clip(0.25 + 0.1 * np.sin(np.arange(b - a) * 0.2), 0.08, 0.6)     # a blob the segmentation can confirm
+        px += rng.uniform(-0.05, 0.05); py += rng.uniform(-0.05, 0.05); yaw = float(rng.uniform(-3.14, 3.14))
+        if i % 11 != 5:
+            now += 0.16                                   # i % 11 == 5: the clock repeats (dt = 0 in the tracker)
+        v, w = float(rng.uniform(0, 0.22)), float(rng.uniform(-2, 2))
+        sc = 0 if is_reset else (i % 27)
+        inp = dict(deque_x=px + 0.001, deque_y=py - 0.001, end_timestep=0.15, px=px, py=py, yaw=yaw, v=v, w=w, now=now,
+                   step_counter=sc, is_reset=int(is_reset))
+        oc, rc, dc, ic = orc.ext_call(0, r, **inp)
+        if is_reset:
+            orc.ext_set_done(0, False)
+        odom = [px, py, yaw, v, w, now, inp["deque_x"], inp["deque_y"], 0.15, 0.0]
+        env.observe_external(r[None, :], [odom], step_counter=[sc], is_reset=is_reset)
+        torch.cuda.synchronize()
+        og = env.obs_f64[0].cpu().numpy()
+        assert np.isfinite(og).all() and np.isfinite(oc).all(), i
+        worst = max(worst, float(np.abs(og - oc).max()))
+        assert np.abs(og - oc).max() <= TOL, (layout, i, kind)
+        if not is_reset:
+            assert float(env.reward[0].item()) == rc and bool(env.done[0].item()) == dc, (layout, i)
+            if layout == 0:
+                assert np.array_equal(env.topk_idx[0].cpu().numpy(), ic), (layout, i)
+        else:
+            env.done[0] = 0                               # TRAIN:116
+        assert tuple(env.counters()[0, :3].cpu().tolist()) == tuple(orc.counters()[0][:3]), (layout, i)
+        if layout != 1:
+            assert env.debug_env(0)["status"] & 7 == orc.debug(0)["status"] & 7, (layout, i)
+    assert worst <= 1e-12
+
+
 # ---- obs_layout 1: environment_stage_1_original.py (363 inputs), SURVEY 8f N3 -----------------------------
 @pytest.mark.parametrize("mode", [True, "next", False])
 def test_original_layout_rollout_parity(oracle_mod, mode):
