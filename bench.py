@@ -210,9 +210,13 @@ def main():
         """One decomposition of a config: its envs as G stream groups (G = 1: one launch per step), open loop or with the TD3
         actor in the loop (each group's act -> step chain on its own stream, crowdnav.rollout.rollout_groups)."""
 
-        def __init__(self, lcfg, G, mode="next", lacts=None, agent=None, sequence=False):
+        def __init__(self, lcfg, G, mode="next", lacts=None, agent=None, sequence=False, arbitration=None):
             self.cfg, self.G, self.mode, self.agent, self.sequence = lcfg, G, mode, agent, sequence
-            self.grp = VecEnvGroups(lcfg, groups=G, device=dev_index, streams=streams[:G] if G <= len(streams) else None)
+            # arbitration None: the library's defaults (cn_set_arbitration) -- one launch per step picks the fair kernel when it
+            # fills the device on its own, overlapping stream groups stay on the hardware's oldest-first order
+            self.grp = VecEnvGroups(lcfg, groups=G, device=dev_index, streams=streams[:G] if G <= len(streams) else None,
+                                    arbitration=arbitration)
+            self.arbitration = "rotating per step (sequence kernel)" if sequence else self.grp.envs[0].arbitration
             self.grp.reset()
             self.enq_ms = None
             if sequence:
@@ -309,9 +313,12 @@ def main():
         then `repeats` timed samples each.  Returns a dict with the chosen decomposition's median sample and all legs."""
         legs = {}
         if sequence_leg:
-            candidates = list(candidates) + ["sequence"]
+            # + the A/B of cn_set_arbitration on one launch per step (only where the library's default is the fair kernel)
+            candidates = list(candidates) + (["1_groups_oldest_first"] if 1 in candidates and lcfg.n_envs >= 2048 else []) + ["sequence"]
         for G in candidates:
-            lg = Leg(lcfg, 1, lacts=lacts, sequence=True) if G == "sequence" else Leg(lcfg, G, mode=mode, lacts=lacts, agent=agent)
+            lg = (Leg(lcfg, 1, lacts=lacts, sequence=True) if G == "sequence" else
+                  Leg(lcfg, 1, mode=mode, lacts=lacts, agent=agent, arbitration="oldest_first") if G == "1_groups_oldest_first" else
+                  Leg(lcfg, G, mode=mode, lacts=lacts, agent=agent))
             lg.run(a.preroll + a.warmup - warm_tail)
             legs[G] = lg
         probes = {}
@@ -330,7 +337,7 @@ def main():
             vals = [s[2] / s[0] for s in red]
             mi = median_index(vals)
             out["legs"][G] = {"median": vals[mi], "samples": vals, "wall": red[mi][0], "kernel_ms": red[mi][1],
-                              "taken": red[mi][2], "enq_ms": legs[G].enq_ms,
+                              "taken": red[mi][2], "enq_ms": legs[G].enq_ms, "arbitration": legs[G].arbitration,
                               "per_rank": [pr[mi] for pr in per_rank] if per_rank else None}
             legs[G].close()
         return out
@@ -439,7 +446,7 @@ def main():
                                    if a.envs_total else ("BASELINE configs[1] per GPU (weak scaling over %d GPU(s))" % world),
                                    N, a.peds, a.rays, a.k, a.preroll,
                                    ("the K steps enqueued as ONE cn_step_sequence launch (persistent wavefronts, actions [K, N, 2] in HBM)"
-                                    if isinstance(Gc, str) else "the envs running as %d independent stream group(s) of %d" % (G, n_launch)), R, K),
+                                    if Gc == "sequence" else "the envs running as %d independent stream group(s) of %d" % (G, n_launch)), R, K),
                    "envs_per_gpu": N, "envs_total": N * world, "stream_groups": G, "stream_groups_requested": Gmax,
                    "decomposition": leg_name(Gc),
                    "repeats": R, "samples_env_steps_s": hl["samples"],
@@ -447,6 +454,8 @@ def main():
                                        "probe_env_steps_s": main_m["probe_env_steps_s"], "chosen": leg_name(Gc)},
                    "legs_env_steps_s": {leg_name(g): v["median"] for g, v in main_m["legs"].items()},
                    "legs_samples_env_steps_s": {leg_name(g): v["samples"] for g, v in main_m["legs"].items()},
+                   # include/crowdnav.h cn_set_arbitration: which issue order each leg's kernel ran with
+                   "legs_arbitration": {leg_name(g): v["arbitration"] for g, v in main_m["legs"].items()},
                    # host time the enqueue loop needs per step of a leg (a leg is host-paced when this approaches ms_per_step)
                    "host_enqueue_ms_per_step": {leg_name(g): v["enq_ms"] for g, v in main_m["legs"].items()},
                    "concurrent_hw_queues_found": conc, "parallelism": "env-sharded x%d" % world,
@@ -468,7 +477,8 @@ def main():
                      "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": D4 * n_launch, "envs_per_launch": n_launch,
                      "concurrent_launches": G,
-                     "kernel": "cn_env_kernel_seq (kernel_ms = launch duration / K)" if isinstance(Gc, str) else "cn_env_kernel", "kernel_ms": kernel_ms,
+                     "kernel": ("cn_env_kernel_seq (kernel_ms = launch duration / K)" if Gc == "sequence" else
+                                "cn_env_kernel_fair" if hl["arbitration"] == "fair" else "cn_env_kernel"), "kernel_ms": kernel_ms,
                      # what actually binds: instruction issue (float64 VALU) and one wavefront's critical path, not HBM
                      "binding": "instruction issue (f64 VALU) above ~8k resident envs; one wavefront's critical path at 4096",
                      "issue_bound_env_steps_s": plateau,

@@ -17,6 +17,7 @@ CN_PHASE_ALL, CN_PHASE_PRE, CN_PHASE_GET_STATE, CN_PHASE_REWARD = 0, 1, 2, 4
 CN_SD_COUNT = 24
 CN_SI_COUNT = 16
 CN_TF_COUNT = 12
+CN_ARB_AUTO, CN_ARB_OLDEST_FIRST, CN_ARB_FAIR = 0, 1, 2      # include/crowdnav.h: cn_set_arbitration
 CN_COUNTER_COLS = 14
 SD = dict(RX=0, RY=1, RYAW=2, RV=3, RW=4, CLOCK=5, WPX=6, WPY=7, PREV_DIST=8, PREV_HEAD=9, DQ0X=10, DQ0Y=11,
           DQ1X=12, DQ1Y=13, TS=14, BB=15, EGO=16, CPROB=17, EP_RETURN=18, LAST_RETURN=19)
@@ -25,7 +26,8 @@ SI = dict(DONE=0, DQ_LEN=1, NTRACKS=2, EGO_VIOL=3, SOCIAL_VIOL=4, OBST_STEPS=5, 
 TF = dict(PX=0, PY=1, DIST=2, D0X=3, D0Y=4, D1X=5, D1Y=6, T=7, SPEED=8, VX=9, VY=10, DQLEN=11)
 
 EXPORTS = ["cn_abi_version", "cn_last_error", "cn_create", "cn_destroy", "cn_obs_dim", "cn_config_of",
-           "cn_set_ped_init", "cn_get_ped_init", "cn_set_ped_preset_vel", "cn_reset", "cn_step", "cn_step_multi", "cn_observe_external",
+           "cn_set_ped_init", "cn_get_ped_init", "cn_set_ped_preset_vel", "cn_reset", "cn_step", "cn_step_multi", "cn_set_arbitration", "cn_get_arbitration",
+           "cn_observe_external",
            "cn_policy_tail", "cn_actor_forward", "cn_step_sequence", "cn_get_counters",
            "cn_get_returns", "cn_debug_env", "cn_lds_bytes", "cn_near_separate", "cn_snapshot_size", "cn_snapshot", "cn_restore"]
 
@@ -176,6 +178,8 @@ def lib():
         L.cn_reset.argtypes = [vp, vp, vp, vp, vp]
         L.cn_step.argtypes = [vp, C.POINTER(CnStepIO), vp]
         L.cn_step_multi.argtypes = [C.c_int, C.POINTER(vp), C.POINTER(CnStepIO), C.POINTER(vp)]
+        L.cn_set_arbitration.argtypes = [vp, C.c_int]
+        L.cn_get_arbitration.argtypes = [vp]
         L.cn_observe_external.argtypes = [vp, C.POINTER(CnExternalIO), vp]
         L.cn_policy_tail.argtypes = [vp, vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_uint64, C.c_uint64, C.c_int, vp]
         L.cn_actor_forward.argtypes = [C.POINTER(CnActorWeights), vp, vp, C.c_int, C.c_float, C.c_float, C.c_float,

@@ -23,10 +23,11 @@ def _ptr(t):
 
 
 class VecEnv:
-    def __init__(self, cfg=None, device=0, stream=None, out=None, **kw):
+    def __init__(self, cfg=None, device=0, stream=None, out=None, arbitration="auto", **kw):
         """stream: a torch.cuda.Stream every launch of this handle goes to (default: the current stream at
         call time).  out: dict of preallocated output tensors (obs, final_obs, reward, done, topk_idx) --
-        VecEnvGroups passes row slices of one [N_total, ...] allocation."""
+        VecEnvGroups passes row slices of one [N_total, ...] allocation.  arbitration: "auto" | "oldest_first" | "fair"
+        (cn_set_arbitration: how the environments that share a SIMD share its issue slots; timing only, never a result)."""
         self.cfg = cfg if cfg is not None else Config(**kw)
         self.stream = stream
         if not torch.cuda.is_available():
@@ -37,6 +38,7 @@ class VecEnv:
         ccfg = self.cfg.to_c()
         _abi.check(self.L.cn_create(C.byref(ccfg), int(device), C.byref(self.h)))
         self.N, self.P, self.R, self.K = self.cfg.n_envs, self.cfg.n_peds, self.cfg.n_rays, self.cfg.k_obstacles
+        self.set_arbitration(arbitration)
         self.D = self.L.cn_obs_dim(self.h)
         N, D, K, dev = self.N, self.D, self.K, self.device
         out = out or {}
@@ -56,6 +58,22 @@ class VecEnv:
         self._counters = torch.zeros((N, _abi.CN_COUNTER_COLS), dtype=torch.int32, device=dev)
         self._ret = torch.zeros(N, dtype=torch.float32, device=dev)
         self._run = torch.zeros(N, dtype=torch.float32, device=dev)
+
+    ARBITRATION = {"auto": _abi.CN_ARB_AUTO, "oldest_first": _abi.CN_ARB_OLDEST_FIRST, "fair": _abi.CN_ARB_FAIR}
+
+    def set_arbitration(self, mode):
+        """cn_set_arbitration: "auto" (fair when this handle's launch fills the device on its own), "oldest_first", "fair"."""
+        if mode not in self.ARBITRATION:
+            raise ValueError("arbitration must be one of %s" % sorted(self.ARBITRATION))
+        _abi.check(self.L.cn_set_arbitration(self.h, self.ARBITRATION[mode]))
+
+    @property
+    def arbitration(self):
+        """What cn_step uses for this handle right now: "oldest_first" or "fair"."""
+        rc = self.L.cn_get_arbitration(self.h)
+        if rc < 0:
+            _abi.check(rc)
+        return {_abi.CN_ARB_OLDEST_FIRST: "oldest_first", _abi.CN_ARB_FAIR: "fair"}[rc]
 
     def close(self):
         if getattr(self, "h", None):
@@ -366,7 +384,12 @@ class VecEnvGroups:
     either works per group on `streams[g]` (double-buffered sampler: actor of group A overlaps the env step
     of group B) or calls `join()` to make the current stream wait for every group."""
 
-    def __init__(self, cfg=None, groups=2, device=0, streams=None, **kw):
+    def __init__(self, cfg=None, groups=2, device=0, streams=None, arbitration=None, **kw):
+        """arbitration (default: "oldest_first" for groups > 1, "auto" for one group): the groups' launches overlap on the device
+        by design, which is where the hardware's oldest-first issue order is the better pipeline (cn_set_arbitration; 4 groups
+        of 1024: 108 M env-steps/s against 102 M with "fair")."""
+        if arbitration is None:
+            arbitration = "oldest_first" if groups > 1 else "auto"
         cfg = cfg if cfg is not None else Config(**kw)
         assert cfg.n_envs % groups == 0, "n_envs must divide evenly into groups"
         self.cfg, self.G, self.N = cfg, groups, cfg.n_envs
@@ -390,7 +413,7 @@ class VecEnvGroups:
             sl = slice(g * n, (g + 1) * n)
             out = dict(obs=self.obs[sl], final_obs=self.final_obs[sl], reward=self.reward[sl], done=self.done[sl],
                        topk_idx=self.topk_idx[sl])
-            self.envs.append(VecEnv(self._group_cfg(g), device=device, stream=streams[g], out=out))
+            self.envs.append(VecEnv(self._group_cfg(g), device=device, stream=streams[g], out=out, arbitration=arbitration))
         self.streams = [e.stream for e in self.envs]
 
     def _group_cfg(self, g):

@@ -15,6 +15,7 @@
 #include "crowdnav_kernel.h"
 
 extern "C" __global__ void cn_env_kernel(CnKParams p);
+extern "C" __global__ void cn_env_kernel_fair(CnKParams p);
 extern "C" __global__ void cn_env_kernel_ext(CnKParams p);
 extern "C" __global__ void cn_env_kernel_same(CnKParams p);
 extern "C" __global__ void cn_env_kernel_gt(CnKParams p);
@@ -55,6 +56,8 @@ struct cn_env_s {
     char* d_state = nullptr;          // N per-env records (crowdnav_kernel.h: sd | si | ped_p | ped_v | pad), `stride` bytes apart
     size_t stride;
     std::vector<double> ped_init;
+    int arbitration = CN_ARB_AUTO;    // cn_set_arbitration
+    int n_cus = 0;                    // compute units of `device` (CN_ARB_AUTO: fair from 2 wavefronts per SIMD = 8 x n_cus envs)
 };
 
 // RAII: run on the handle's device even if the calling thread's current device is another one
@@ -251,6 +254,7 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
     cn_env_s* h = guard.get();
     h->cfg = c;
     h->device = device;
+    { int ncu = 0; if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess) h->n_cus = ncu; }
     const int N = c.n_envs, P = c.n_peds, R = c.n_rays, K = c.k_obstacles;
     h->D = c.obs_layout == CN_LAYOUT_ORIGINAL ? (R - 1) + 4 : (c.obs_layout == CN_LAYOUT_REALWORLD ? (R - 1) + 11 : (R - 1) + 7 + 4 * K);
     h->max_conf = (R - 1) / 4 + 2;
@@ -330,6 +334,7 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
     if (h->lds > 64 * 1024)
     {
         HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
+        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_fair, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
         HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_ext, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
         HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_same, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
         HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_ct, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
@@ -399,7 +404,15 @@ extern "C" int cn_set_ped_preset_vel(cn_handle h, const double* vxy)
     return CN_OK;
 }
 
-static int launch(cn_handle h, const CnKParams& kp, hipStream_t st)
+// Does a cn_step launch of this handle use the fair kernel?  (`overlapped`: the call is one of several in a cn_step_multi)
+static bool fair_launch(const cn_env_s* h, bool overlapped)
+{
+    if (h->arbitration == CN_ARB_FAIR) return true;
+    if (h->arbitration == CN_ARB_OLDEST_FIRST || overlapped) return false;
+    return h->n_cus > 0 && h->cfg.n_envs >= 8 * h->n_cus;
+}
+
+static int launch(cn_handle h, const CnKParams& kp, hipStream_t st, bool overlapped = false)
 {
     DeviceScope scope(h->device);
     if (h->cfg.obs_layout == CN_LAYOUT_REALWORLD) {
@@ -429,6 +442,7 @@ static int launch(cn_handle h, const CnKParams& kp, hipStream_t st)
                                          : ct ? (same ? cn_env_kernel_gt_ct_same : cn_env_kernel_gt_ct) : (same ? cn_env_kernel_gt_same : cn_env_kernel_gt))
                                    : (sf ? (same ? cn_env_kernel_sf_same : cn_env_kernel_sf)
                                          : ct ? (same ? cn_env_kernel_ct_same : cn_env_kernel_ct) : (same ? cn_env_kernel_same : cn_env_kernel));
+        if (fn == cn_env_kernel && fair_launch(h, overlapped)) fn = cn_env_kernel_fair;
         hipLaunchKernelGGL(fn, dim3(kp.N), dim3(64), h->lds, st, kp);
     }
     HIPCHK(hipGetLastError());
@@ -443,21 +457,41 @@ extern "C" int cn_reset(cn_handle h, const uint8_t* mask, float* obs, double* ob
     return launch(h, kp, (hipStream_t)stream);
 }
 
-extern "C" int cn_step(cn_handle h, const cn_step_io* io, void* stream)
+static int step_one(cn_handle h, const cn_step_io* io, void* stream, bool overlapped)
 {
     if (!h || !io || !io->action || !io->obs || !io->reward || !io->done) return fail(CN_ERR_ARG, "cn_step: null argument");
     CnKParams kp = h->kp;
     kp.mode = CN_MODE_STEP; kp.auto_reset = io->auto_reset;
     kp.action = io->action; kp.step_counter = io->step_counter; kp.obs = io->obs; kp.final_obs = io->final_obs;
     kp.obs_f64 = io->obs_f64; kp.reward = io->reward; kp.done = io->done; kp.topk_idx = io->topk_idx;
-    return launch(h, kp, (hipStream_t)stream);
+    return launch(h, kp, (hipStream_t)stream, overlapped);
+}
+
+extern "C" int cn_step(cn_handle h, const cn_step_io* io, void* stream) { return step_one(h, io, stream, false); }
+
+extern "C" int cn_set_arbitration(cn_handle h, int mode)
+{
+    if (!h) return fail(CN_ERR_ARG, "cn_set_arbitration: null handle");
+    if (mode != CN_ARB_AUTO && mode != CN_ARB_OLDEST_FIRST && mode != CN_ARB_FAIR)
+        return fail(CN_ERR_ARG, "cn_set_arbitration: mode must be CN_ARB_AUTO (0), CN_ARB_OLDEST_FIRST (1) or CN_ARB_FAIR (2)");
+    h->arbitration = mode;
+    return CN_OK;
+}
+
+extern "C" int cn_get_arbitration(cn_handle h)
+{
+    if (!h) return fail(CN_ERR_ARG, "cn_get_arbitration: null handle");
+    const bool has_variant = h->cfg.obs_layout == CN_LAYOUT_RISK && h->cfg.risk_mode != CN_RISK_GT && !h->cfg.ped_contact && h->cfg.ped_mode != 2;
+    return has_variant && fair_launch(h, false) ? CN_ARB_FAIR : CN_ARB_OLDEST_FIRST;
 }
 
 extern "C" int cn_step_multi(int n, const cn_handle* handles, const cn_step_io* ios, void* const* streams)
 {
     if (n < 0 || (n > 0 && (!handles || !ios || !streams))) return fail(CN_ERR_ARG, "cn_step_multi: null argument");
+    bool overlapped = false;        // more than one handle in the call: their launches are meant to overlap (CN_ARB_AUTO -> oldest-first)
+    for (int i = 1; i < n; ++i) overlapped = overlapped || handles[i] != handles[0];
     for (int i = 0; i < n; ++i) {
-        const int rc = cn_step(handles[i], &ios[i], streams[i]);
+        const int rc = step_one(handles[i], &ios[i], streams[i], overlapped);
         if (rc != CN_OK) return rc;
     }
     return CN_OK;

@@ -23,12 +23,33 @@
                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 
 // Stage time stamps (PROFILING BUILD ONLY: build.sh timing -> libcrowdnav_timing.so; tools/stage_timing.py)
+// ---- issue arbitration between the wavefronts of a SIMD (tools/wave_fairness.py, profiles/r03/arbitration.txt) ------------
+// A SIMD's arbiter serves its OLDEST wavefront first.  With four environments per SIMD that start together (one launch of 4096
+// environments) their lifetimes come out 62.7k / 69.3k / 77.9k / 88.1k ticks by entry rank: the launch lasts as long as the
+// wave that was starved, and that wave runs its last quarter almost alone on a SIMD that is then mostly idle.
+//  * FAIR kernels (cn_env_kernel_fair; cn_handle arbitration CN_ARB_FAIR) lower a wave's s_setprio level as it advances --
+//    3 until the gradients are done, 2 until the association, 1 until the tracker, 0 for the cone / reward / write-back -- so
+//    the wave that is BEHIND gets the issue slots and the four finish together (71.4k / 75.0k / 78.7k / 82.6k): one launch
+//    per step 86.6 -> 93.5 M env-steps/s.  It costs throughput when launches OVERLAP on a SIMD (4 stream groups: 108 -> 102 M;
+//    the oldest-first order is the better pipeline there), hence a per-handle switch and not the default for small launches.
+//  * the sequence kernels rotate the levels over the four wave slots every control period (slot + t) & 3: every wave spends a
+//    quarter of its steps at each level, so all four finish their T steps together instead of 0 / 9 / 20 / 29 % apart:
+//    cn_step_sequence 99.5 -> 112 M at T = 1000, 92.9 -> 102 M at T = 20.
+// Priorities change WHEN a wave's instructions issue, never what they compute: every parity test runs on both.
+__device__ __forceinline__ void cn_setprio_uniform(int v)      // v: wave-uniform, 0..3 (s_setprio takes an immediate)
+{
+    if (v == 0) __builtin_amdgcn_s_setprio(0); else if (v == 1) __builtin_amdgcn_s_setprio(1);
+    else if (v == 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(3);
+}
+// at stage stamp k (a literal; FAIR is a template parameter of the enclosing function): the four level changes of a FAIR kernel
+#define CN_FAIR_AT(k) do { if constexpr (FAIR) { if ((k) == 0) __builtin_amdgcn_s_setprio(3); else if ((k) == 7) __builtin_amdgcn_s_setprio(2); \
+                           else if ((k) == 11) __builtin_amdgcn_s_setprio(1); else if ((k) == 15) __builtin_amdgcn_s_setprio(0); } } while (0)
 #ifdef CN_TIMING
 #define CN_ABLATE(bit) (p->ablate & (bit))   /* stage-skipping mask of tools/ablate.py: timing build only */
-#define CN_T(k) do { if (p->timing && lane == 0) p->timing[(size_t)env * 32 + (k)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#define CN_T(k) do { CN_FAIR_AT(k); if (p->timing && lane == 0) p->timing[(size_t)env * 32 + (k)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define CN_ABLATE(bit) 0
-#define CN_T(k) do { } while (0)
+#define CN_T(k) CN_FAIR_AT(k)
 #endif
 
 #define TY_NONE 0
@@ -896,7 +917,7 @@ __device__ __forceinline__ void tracker_stage(KP p, EnvRegs& e, const Lds& L, do
     CN_SYNC();
 }
 
-template <bool EXT, bool GT = false>
+template <bool EXT, bool GT = false, bool FAIR = false>
 __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const Lds& L, int env, int lane, int step_counter,
                         float* obs32, float* fin32, double* obs64, int* done_out, bool have_tg = false, Trig tg = Trig{0.0, 0.0, 0.0, 0.0})
 {
@@ -2099,7 +2120,7 @@ __device__ __forceinline__ double compute_reward(KP p, const Poly& pg, EnvRegs& 
 // `env`, `lane`: this wavefront's environment and lane; `smem`: its LDS working set (cn_lds_bytes).  The per-launch kernels pass
 // blockIdx.x / threadIdx.x / the block's dynamic LDS; the multi-step kernel (FUSED, cn_env_kernel_seq below) calls this once per
 // step, `t` steps into its launch, with the step's actions / outputs at slot t of the caller's buffers.
-template <bool EXT, bool TWO, int LAYOUT, bool GT = false, int SIM = 0, bool FUSED = false>
+template <bool EXT, bool TWO, int LAYOUT, bool GT = false, int SIM = 0, bool FUSED = false, bool FAIR = false>
 __device__ __forceinline__ void env_kernel_body(const int env, const int lane, char* const smem, const long long t = 0)
 {
     KP p = (KP)__builtin_amdgcn_kernarg_segment_ptr();
@@ -2171,6 +2192,12 @@ __device__ __forceinline__ void env_kernel_body(const int env, const int lane, c
     }
 
     CN_T(0);
+#ifdef CN_TIMING
+    if (p->timing && lane == 0) {      // where this wavefront runs: HW_ID (wave slot, SIMD, CU, SE) and XCC_ID -- tools/wave_fairness.py
+        p->timing[(size_t)env * 32 + 25] = (long long)__builtin_amdgcn_s_getreg(4 | (31 << 11));
+        p->timing[(size_t)env * 32 + 26] = (long long)__builtin_amdgcn_s_getreg(20 | (31 << 11));
+    }
+#endif
     Poly pg;
     pg.c0 = p->poly_c[lane]; pg.s0 = p->poly_s[lane]; pg.c1 = p->poly_c[(lane + 1) & 63]; pg.s1 = p->poly_s[(lane + 1) & 63];
 
@@ -2296,7 +2323,7 @@ __device__ __forceinline__ void env_kernel_body(const int env, const int lane, c
         if (ph_obs) {
             if constexpr (LAYOUT == 1) observe_original<EXT>(p, e, L, env, lane, sc, io_obs(), fin, p->obs_f64, &done);
             else if constexpr (LAYOUT == 2) observe_realworld<EXT>(p, pg, e, L, RQ, env, lane, sc, io_obs(), fin, p->obs_f64, &done);
-            else observe<EXT, GT>(p, pg, e, L, env, lane, sc, io_obs(), fin, p->obs_f64, &done, have_trig, trig);
+            else observe<EXT, GT, FAIR>(p, pg, e, L, env, lane, sc, io_obs(), fin, p->obs_f64, &done, have_trig, trig);
         } else if constexpr (EXT) {
             // Env.compute_reward(state, step_counter, done) on its own (ENV:1046): heading and distance are state[n], state[n+1]
             // (LAYOUT 1: state[-2], state[-1] are what ORIG:324-330 reads), `done` is the caller's
@@ -2399,7 +2426,7 @@ __device__ __forceinline__ void env_kernel_body(const int env, const int lane, c
             observe_realworld<EXT>(p, pg, e, L, RQ, env, lane, sc, p->obs, ext ? nullptr : p->final_obs, p->obs_f64, &done);
             r = compute_reward_realworld(p, e, L, done);
         } else {
-            observe<EXT, GT>(p, pg, e, L, env, lane, sc, p->obs, ext ? nullptr : p->final_obs, p->obs_f64, &done);
+            observe<EXT, GT, FAIR>(p, pg, e, L, env, lane, sc, p->obs, ext ? nullptr : p->final_obs, p->obs_f64, &done);
             r = compute_reward(p, pg, e, L, lane, done);
         }
         e.ep_ret += r;
@@ -2449,7 +2476,7 @@ __device__ __forceinline__ void env_kernel_body(const int env, const int lane, c
         e.prev_dist = dist3(e.rx, e.ry, e.wpx, e.wpy);        // ENV:1243 (unrounded)
         e.prev_head = heading_to_goal(p, e, e.rx, e.ry, e.ryaw);  // ENV:1244
         CN_SYNC();
-        observe<EXT, GT>(p, pg, e, L, env, lane, 0, p->obs, nullptr, p->obs_f64, &d2);
+        observe<EXT, GT, FAIR>(p, pg, e, L, env, lane, 0, p->obs, nullptr, p->obs_f64, &d2);
         }
         e.social_viol = 0; e.ego_viol = 0; e.obst_steps = 0;  // ENV:1260-1262
         if (!ext) {
@@ -2494,6 +2521,7 @@ __device__ __forceinline__ void env_kernel_body(const int env, const int lane, c
 #define CN_HOT_BOUNDS __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
 #endif
 extern "C" __global__ void CN_HOT_BOUNDS cn_env_kernel(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, false, 0>(blockIdx.x, threadIdx.x, cn_smem); }
+extern "C" __global__ void CN_HOT_BOUNDS cn_env_kernel_fair(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, false, 0, false, 0, false, true>(blockIdx.x, threadIdx.x, cn_smem); }
 extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_same(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, true, 0>(blockIdx.x, threadIdx.x, cn_smem); }
 extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_ext(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<true, false, 0>(blockIdx.x, threadIdx.x, cn_smem); }
 // cn_step_sequence: T control periods per launch with OPEN-LOOP actions (resident in HBM: [T][N][2], or one [N][2] held for T
@@ -2508,10 +2536,12 @@ __device__ __forceinline__ void sequence_body()
     extern __shared__ __attribute__((aligned(16))) char cn_smem[];
     KP p = (KP)__builtin_amdgcn_kernarg_segment_ptr();
     const long long T = p->roll_steps;
+    const int wslot = (int)__builtin_amdgcn_s_getreg(4 | (1 << 11));     // HW_ID.wave_id & 3: this wave's slot on its SIMD
     for (long long t = 0; t < T; ++t) {
         int lane_ = threadIdx.x;
         asm volatile("" : "+v"(lane_));          // per-step laundering (see env_kernel_body): nothing is hoisted out of the step loop
         lane_ &= 63;
+        cn_setprio_uniform((int)(t + wslot) & 3);      // see "issue arbitration" at the top: every slot gets every level in turn
         env_kernel_body<false, false, 0, GT, 0, true>(blockIdx.x, lane_, cn_smem, t);
     }
 }

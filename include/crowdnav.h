@@ -185,6 +185,21 @@ int cn_set_ped_preset_vel(cn_handle h, const double* vxy_host);
  * (TRAIN:114-116).  mask: dev [N] or NULL (= all). obs_f64 may be NULL. */
 int cn_reset(cn_handle h, const uint8_t* mask, float* obs, double* obs_f64, void* stream);
 int cn_step(cn_handle h, const cn_step_io* io, void* stream);
+/* Issue arbitration between the environments that share a SIMD (one environment = one wavefront).
+ * The hardware serves a SIMD's OLDEST wavefront first; when the environments on a SIMD start together (a launch that fills
+ * the device by itself) the launch then lasts as long as the wavefront that was starved.  CN_ARB_FAIR runs cn_step's kernel
+ * with falling s_setprio levels -- whoever is behind gets the issue slots, all finish together: +8 % for one launch of 4096
+ * environments per step -- and costs ~5 % when launches of several handles OVERLAP on the device (stream groups), where
+ * oldest-first is the better pipeline.  CN_ARB_AUTO (the default): fair when this handle's launch alone puts at least two
+ * wavefronts on every SIMD of the device (n_envs >= 8 x compute units) and it is stepped by cn_step or by a cn_step_multi
+ * that names no other handle; oldest-first inside a cn_step_multi over several handles.  Changes when instructions issue, never a result.  Only the default configuration's kernel
+ * (obs_layout 0, lidar_tracker, no contact / social force, reset on the next step or none) has a fair variant: elsewhere
+ * the setting is accepted and ignored.  cn_get_arbitration returns what cn_step would use: CN_ARB_OLDEST_FIRST or CN_ARB_FAIR. */
+#define CN_ARB_AUTO 0
+#define CN_ARB_OLDEST_FIRST 1
+#define CN_ARB_FAIR 2
+int cn_set_arbitration(cn_handle h, int mode);
+int cn_get_arbitration(cn_handle h);
 /* n calls of cn_step in one crossing of the boundary: handle i steps with ios[i] on streams[i] (env batches run as
  * independent stream groups, DESIGN.md section 6: the launches are the same, the host thread pays the foreign-call
  * overhead once per step instead of once per group).  Stops at the first error and returns it. */

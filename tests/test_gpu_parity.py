@@ -15,12 +15,12 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-5
 
 
-def _pair(oracle_mod, **kw):
+def _pair(oracle_mod, arbitration="auto", **kw):
     import torch
     from crowdnav import Config
     from crowdnav.env import VecEnv
     cfg = Config(**kw)
-    env = VecEnv(cfg)
+    env = VecEnv(cfg, arbitration=arbitration)
     env.enable_f64_obs()
     orc = oracle_mod.Oracle(cfg.as_dict())
     return torch, env, orc
@@ -72,10 +72,46 @@ def test_rollout_parity_train_config(oracle_mod):
     assert frac > 0.999
 
 
-def test_rollout_parity_next_step_reset_mode(oracle_mod):
-    # auto_reset = 2: a finished env spends the next call on its reset (action ignored, reward 0, done 0)
-    n_done, frac = _compare_rollout(oracle_mod, steps=150, seed=4, reset_mode="next", n_envs=64, n_peds=20, max_steps=50)
+@pytest.mark.parametrize("arbitration", ["oldest_first", "fair"])
+def test_rollout_parity_next_step_reset_mode(oracle_mod, arbitration):
+    # auto_reset = 2: a finished env spends the next call on its reset (action ignored, reward 0, done 0); on both kernels
+    # of cn_set_arbitration (cn_env_kernel / cn_env_kernel_fair: s_setprio changes when instructions issue, not what they compute)
+    n_done, frac = _compare_rollout(oracle_mod, steps=150, seed=4, reset_mode="next", n_envs=64, n_peds=20, max_steps=50,
+                                    arbitration=arbitration)
     assert n_done > 20 and frac > 0.999
+
+
+def test_arbitration_switch_rule_and_identical_results():
+    """cn_set_arbitration / cn_get_arbitration (include/crowdnav.h): the auto rule (fair from two wavefronts per SIMD = 8 x
+    compute units environments, oldest-first below and for configurations without a fair kernel), the error path, and that the
+    two kernels leave the same outputs AND the same state records behind, byte for byte, over 120 steps of 2048 environments."""
+    import torch
+    from crowdnav import Config, _abi
+    from crowdnav.env import VecEnv, VecEnvGroups
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    small, big = VecEnv(Config(n_envs=8 * ncu - 1)), VecEnv(Config(n_envs=8 * ncu, max_steps=40))
+    assert small.arbitration == "oldest_first" and big.arbitration == "fair"
+    small.set_arbitration("fair"); assert small.arbitration == "fair"
+    for kw in (dict(obs_layout=1), dict(risk_mode=1), dict(ped_contact=1), dict(ped_mode=2)):
+        e = VecEnv(Config(n_envs=64, **kw), arbitration="fair")
+        assert e.arbitration == "oldest_first", kw                 # accepted and ignored: no fair variant of that kernel
+        e.reset(); e.step(torch.zeros((64, 2), device="cuda"), auto_reset="next"); torch.cuda.synchronize(); e.close()
+    assert all(g.arbitration == "oldest_first" for g in VecEnvGroups(Config(n_envs=16 * ncu), groups=2).envs)
+    with pytest.raises(ValueError):
+        small.set_arbitration("youngest")
+    assert small.L.cn_set_arbitration(small.h, 7) == -1 and b"CN_ARB" in small.L.cn_last_error()
+    small.close()
+    other = VecEnv(Config(n_envs=8 * ncu, max_steps=40), arbitration="oldest_first")
+    assert other.arbitration == "oldest_first"
+    big.reset(); other.reset()
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for t in range(120):
+        a = torch.stack([torch.rand(big.N, generator=g, device="cuda") * 0.22, torch.rand(big.N, generator=g, device="cuda") * 4 - 2], 1)
+        big.step(a, auto_reset="next"); other.step(a, auto_reset="next")
+        for name in ("obs", "reward", "done", "topk_idx"):
+            assert torch.equal(getattr(big, name), getattr(other, name)), (name, t)
+    assert big.counters()[:, 8].sum().item() > 1000                 # episodes ended and were reset along the way
+    assert bytes(big.snapshot()[_abi.C.sizeof(_abi.CnSnapshotHeader):]) == bytes(other.snapshot()[_abi.C.sizeof(_abi.CnSnapshotHeader):])
 
 
 def test_rollout_parity_dense_crowd(oracle_mod):

@@ -24,7 +24,7 @@ def acts_for(N):
 
 
 def one(cfg, mode):
-    env = VecEnv(cfg); env.reset(); N = env.N; acts = acts_for(N)
+    env = VecEnv(cfg, arbitration=os.environ.get("CN_ARB", "auto")); env.reset(); N = env.N; acts = acts_for(N)
     for i in range(PRE): env.step(acts[i % 16], auto_reset=mode)
     ep0 = env.counters()[:, 8].sum().item(); torch.cuda.synchronize(); t0 = time.perf_counter()
     for i in range(STEPS): env.step(acts[i % 16], auto_reset=mode)
@@ -35,7 +35,7 @@ def one(cfg, mode):
 
 
 def groups(cfg, G):
-    envs = VecEnvGroups(cfg, groups=G); envs.reset(); N = envs.N; acts = acts_for(N)
+    envs = VecEnvGroups(cfg, groups=G, arbitration=os.environ.get("CN_GROUP_ARB") or None); envs.reset(); N = envs.N; acts = acts_for(N)
     rows = [envs.rows(g) for g in range(G)]
     def loop(k):
         for i in range(k):
