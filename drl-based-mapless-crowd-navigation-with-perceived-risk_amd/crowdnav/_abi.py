@@ -28,7 +28,7 @@ TF = dict(PX=0, PY=1, DIST=2, D0X=3, D0Y=4, D1X=5, D1Y=6, T=7, SPEED=8, VX=9, VY
 EXPORTS = ["cn_abi_version", "cn_last_error", "cn_create", "cn_destroy", "cn_obs_dim", "cn_config_of",
            "cn_set_ped_init", "cn_get_ped_init", "cn_set_ped_preset_vel", "cn_reset", "cn_step", "cn_step_multi", "cn_set_arbitration", "cn_get_arbitration",
            "cn_observe_external",
-           "cn_policy_tail", "cn_actor_forward", "cn_step_sequence", "cn_get_counters",
+           "cn_policy_tail", "cn_actor_pack_weights", "cn_actor_forward", "cn_step_sequence", "cn_get_counters",
            "cn_get_returns", "cn_debug_env", "cn_lds_bytes", "cn_near_separate", "cn_snapshot_size", "cn_snapshot", "cn_restore"]
 
 
@@ -93,7 +93,7 @@ def config_to_dict(c):
 
 
 class CnActorWeights(C.Structure):
-    _fields_ = [("w1t", C.c_void_p), ("b1", C.c_void_p), ("w2t", C.c_void_p), ("b2", C.c_void_p), ("w3", C.c_void_p),
+    _fields_ = [("w1p", C.c_void_p), ("b1", C.c_void_p), ("w2p", C.c_void_p), ("b2", C.c_void_p), ("w3", C.c_void_p),
                 ("b3", C.c_void_p), ("obs_dim", C.c_int32), ("obs_dim_padded", C.c_int32), ("hidden", C.c_int32),
                 ("reserved", C.c_int32)]
 
@@ -182,6 +182,7 @@ def lib():
         L.cn_get_arbitration.argtypes = [vp]
         L.cn_observe_external.argtypes = [vp, C.POINTER(CnExternalIO), vp]
         L.cn_policy_tail.argtypes = [vp, vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_uint64, C.c_uint64, C.c_int, vp]
+        L.cn_actor_pack_weights.argtypes = [vp, C.c_int, vp, C.c_int, vp]
         L.cn_actor_forward.argtypes = [C.POINTER(CnActorWeights), vp, vp, C.c_int, C.c_float, C.c_float, C.c_float,
                                        C.c_uint64, C.c_uint64, C.c_int, vp]
         L.cn_step_sequence.argtypes = [vp, C.POINTER(CnSequenceIO), vp]

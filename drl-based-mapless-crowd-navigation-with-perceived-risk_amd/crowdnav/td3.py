@@ -149,20 +149,28 @@ class Agent:
         self._noise_seed, self._fused_calls = int(seed), int(calls)
 
     def sync_fused_weights(self):
-        """(Re)build the K-major float32 copies cn_actor_forward reads; call after the actor's weights change."""
+        """(Re)build the packed float32 copies cn_actor_forward reads (cn_actor_pack_weights); call after the actor's weights change."""
         import ctypes as C
         from . import _abi
         a = self.actor
         D = a.linear1.in_features
-        Dp = (D + 3) // 4 * 4
+        Dp = (D + 31) // 32 * 32          # zero rows up to the packed layout's block of 32 inputs
         with torch.no_grad():
             w1t = torch.zeros((Dp, 256), dtype=torch.float32, device=self.device)
             w1t[:D] = a.linear1.weight.detach().t()
-            self._fw = dict(w1t=w1t.contiguous(), b1=a.linear1.bias.detach().float().contiguous(),
-                            w2t=a.linear2.weight.detach().t().contiguous().float(), b2=a.linear2.bias.detach().float().contiguous(),
+            w2t = a.linear2.weight.detach().t().contiguous().float()
+            L = _abi.lib()
+            w1p, w2p = torch.empty_like(w1t), torch.empty_like(w2t)
+            st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            # K-major -> the order the kernel's wavefronts consume (16-byte loads, 4 KB contiguous per wavefront and block)
+            _abi.check(L.cn_actor_pack_weights(C.c_void_p(w1t.data_ptr()), Dp, C.c_void_p(w1p.data_ptr()), self._dev_index, st))
+            _abi.check(L.cn_actor_pack_weights(C.c_void_p(w2t.data_ptr()), 256, C.c_void_p(w2p.data_ptr()), self._dev_index, st))
+            torch.cuda.current_stream(self.device).synchronize()       # w1t / w2t die with this scope
+            self._fw = dict(w1p=w1p, b1=a.linear1.bias.detach().float().contiguous(),
+                            w2p=w2p, b2=a.linear2.bias.detach().float().contiguous(),
                             w3=a.linear3.weight.detach().float().contiguous(), b3=a.linear3.bias.detach().float().contiguous())
         f = self._fw
-        self._fw_struct = _abi.CnActorWeights(w1t=f["w1t"].data_ptr(), b1=f["b1"].data_ptr(), w2t=f["w2t"].data_ptr(),
+        self._fw_struct = _abi.CnActorWeights(w1p=f["w1p"].data_ptr(), b1=f["b1"].data_ptr(), w2p=f["w2p"].data_ptr(),
                                               b2=f["b2"].data_ptr(), w3=f["w3"].data_ptr(), b3=f["b3"].data_ptr(),
                                               obs_dim=D, obs_dim_padded=Dp, hidden=256, reserved=0)
 

@@ -534,13 +534,27 @@ extern "C" __global__ void cn_actor_kernel(const float* obs, int n, int D, int D
                                            const float* W2T, const float* b2, const float* W3, const float* b3, float* action,
                                            float max_v, float max_w, float sigma, uint64_t seed, uint64_t counter);
 
+extern "C" __global__ void cn_actor_pack_kernel(const float* wt, int K, float* packed);
+extern "C" int cn_actor_pack_weights(const float* wt, int k_rows, float* packed, int device, void* stream)
+{
+    if (!wt || !packed || wt == packed) return fail(CN_ERR_ARG, "cn_actor_pack_weights: null or aliasing argument");
+    if (k_rows < 32 || (k_rows & 31)) return fail(CN_ERR_CONFIG, "cn_actor_pack_weights: k_rows must be a positive multiple of 32");
+    int dev = device;
+    if (dev < 0) HIPCHK(hipGetDevice(&dev));
+    DeviceScope scope(dev);
+    const int total = k_rows * 256;
+    hipLaunchKernelGGL(cn_actor_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, wt, k_rows, packed);
+    HIPCHK(hipGetLastError());
+    return CN_OK;
+}
+
 extern "C" int cn_actor_forward(const cn_actor_weights* w, const float* obs, float* action, int n, float max_v, float max_w,
                                 float sigma, uint64_t seed, uint64_t counter, int device, void* stream)
 {
-    if (!w || !obs || !action || n < 0 || !w->w1t || !w->b1 || !w->w2t || !w->b2 || !w->w3 || !w->b3)
+    if (!w || !obs || !action || n < 0 || !w->w1p || !w->b1 || !w->w2p || !w->b2 || !w->w3 || !w->b3)
         return fail(CN_ERR_ARG, "cn_actor_forward: null argument");
-    if (w->hidden != 256 || w->obs_dim < 1 || w->obs_dim_padded < w->obs_dim || (w->obs_dim_padded & 3))
-        return fail(CN_ERR_CONFIG, "cn_actor_forward: hidden must be 256 and obs_dim_padded a multiple of 4");
+    if (w->hidden != 256 || w->obs_dim < 1 || w->obs_dim_padded < w->obs_dim || (w->obs_dim_padded & 31))
+        return fail(CN_ERR_CONFIG, "cn_actor_forward: hidden must be 256 and obs_dim_padded a multiple of 32 (the packed layout of cn_actor_pack_weights)");
     if (n == 0) return CN_OK;
     const int Dp = w->obs_dim_padded;
     const size_t lds = sizeof(float) * (16 * (size_t)(Dp + 1) + 16 * 257);         // X (layer 2 reuses it), H
@@ -558,7 +572,7 @@ extern "C" int cn_actor_forward(const cn_actor_weights* w, const float* obs, flo
         }
     }
     hipLaunchKernelGGL(cn_actor_kernel, dim3((n + 15) / 16), dim3(512), lds, (hipStream_t)stream, obs, n, w->obs_dim, Dp,
-                       w->w1t, w->b1, w->w2t, w->b2, w->w3, w->b3, action, max_v, max_w, sigma, seed, counter);
+                       w->w1p, w->b1, w->w2p, w->b2, w->w3, w->b3, action, max_v, max_w, sigma, seed, counter);
     HIPCHK(hipGetLastError());
     return CN_OK;
 }

@@ -2639,101 +2639,131 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define ACT_M 16
 #define ACT_THREADS 512            /* cn_actor_kernel: 8 waves */
 
-// U k-steps (4 k each) of this lane's weight operands: B[k = 4 u + (lane >> 4)][this wave's TPW interleaved columns]
-template <int TPW, int U> struct ActW { float b[U][TPW]; };
-template <int TPW, int U>
-__device__ __forceinline__ void actor_wload(ActW<TPW, U>& w, const float* __restrict__ bp, int k0)
+// Weights arrive PACKED in the order the matrix cores consume them (cn_actor_pack_weights / cn_actor_pack_kernel below): for a
+// layer with K inputs (a multiple of 32) and 256 outputs, block b = 8 k-steps of 4, wave w = 32 columns, q = a pair of k-steps,
+//   P[((((b 8 + w) 4 + q) 64 + lane) 4 + j] = W^T[k = 32 b + 4 (2 q + (j >> 1)) + (lane >> 4)][c = 32 w + 2 (lane & 15) + (j & 1)]
+// so a lane's operands for one block are FOUR 16-byte loads 1 KB apart and a wave's are 4 KB contiguous.  With the K-major
+// layout the same operands were eight 8-byte loads (16 lanes x 8 B on each of 4 rows per instruction); tools/micro/l2_stream.hip:
+// a workgroup streaming a shared 688 KB array out of L2 gets 70-73 GB/s with global_load_dwordx2 and 114-139 GB/s with
+// dwordx4 -- and the tile's two layers ran at exactly that dwordx2 pace (19.5 B/clk per CU in both), whatever the prefetch depth.
+#define ACT_U 8                    /* k-steps per pipelined block */
+struct ActW { float4 v[ACT_U / 2]; };
+__device__ __forceinline__ void actor_wload(ActW& w, const float4* __restrict__ bp, int blk)
 {
+    const float4* q = bp + (size_t)blk * (8 * 4 * 64);
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-        if constexpr (TPW == 2) { const float2 v = *reinterpret_cast<const float2*>(bp + (size_t)(k0 + 4 * u) * ACT_H); w.b[u][0] = v.x; w.b[u][1] = v.y; }
-        else w.b[u][0] = bp[(size_t)(k0 + 4 * u) * ACT_H];
-    }
+    for (int i = 0; i < ACT_U / 2; ++i) w.v[i] = q[i * 64];
 }
-// this lane's weight pointer: row (lane >> 4) of WT, first of the wave's columns
-template <int TPW> __device__ __forceinline__ const float* actor_wptr(const float* __restrict__ WT, int wave, int lane)
+// this lane's first operand in a packed layer
+__device__ __forceinline__ const float4* actor_wptr(const float* __restrict__ WP, int wave, int lane)
 {
-    return WT + (size_t)(lane >> 4) * ACT_H + 16 * TPW * wave + TPW * (lane & 15);
+    return reinterpret_cast<const float4*>(WP) + (size_t)wave * (4 * 64) + lane;
+}
+extern "C" __global__ void cn_actor_pack_kernel(const float* __restrict__ wt, int K, float* __restrict__ packed)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;        // index into `packed`
+    if (idx >= K * ACT_H) return;
+    const int j = idx & 3, lane = (idx >> 2) & 63, q = (idx >> 8) & 3, w = (idx >> 10) & 7, b = idx >> 13;
+    const int k = 32 * b + 4 * (2 * q + (j >> 1)) + (lane >> 4), c = 32 * w + 2 * (lane & 15) + (j & 1);
+    packed[idx] = wt[(size_t)k * ACT_H + c];
 }
 
-// One layer for this wave's columns: out[r][c] = relu(sum_k A[r][k] WT[k][c] + bias[c]), K = multiple of 4, k ascending.
-// TPW = column tiles per wave (2 for 8 waves, 1 for 16): col = 16 TPW wave + TPW j + t.  `first`: the weights of the first
-// block, loaded by the caller BEFORE the barrier that releases A (their L2 round trip overlaps the staging / the previous
-// layer's tail).  The loop keeps the NEXT block of U k-steps in flight while this block's TPW U MFMAs issue: an L2 hit takes
-// ~1.5 k cycles, so the distance has to be worth that many cycles of matrix-core work (U = 8: 8 TPW MFMAs x 32 cycles x the 2-4
-// waves of the SIMD); with U = 4 every block waited for its loads and the tile took 22 us against an MFMA floor of 8.7.
-template <int TPW, int U>
-__device__ __forceinline__ void actor_layer(const float* __restrict__ A, int lda, int K, const float* __restrict__ WT,
+// One layer for this wave's 32 columns (two interleaved 16-column tiles: col = 32 wave + 2 j + t):
+// out[r][c] = relu(sum_k A[r][k] W^T[k][c] + bias[c]), K a multiple of 32, k ascending.  `first`: the weights of block 0,
+// requested by the caller BEFORE the barrier that releases A (their L2 round trip overlaps the staging / the previous layer's
+// tail).  The loop keeps the NEXT block -- its weights from L2 AND its A operands from LDS -- in flight while this block's 16
+// MFMAs issue, and its body is BRANCH-FREE on purpose: with `if (blk + 2 < nblk) load` in it the compiler's s_waitcnt counting
+// merged the "loaded" and "not loaded" paths and waited for the block it had just requested.  The last pair re-requests the
+// final block instead (clamped, never skipped).
+struct ActA { float a[ACT_U]; };
+__device__ __forceinline__ void actor_aload(ActA& x, const float* ap, int k0)
+{
+#pragma unroll
+    for (int u = 0; u < ACT_U; ++u) x.a[u] = ap[k0 + 4 * u];
+}
+__device__ __forceinline__ void actor_layer(const float* __restrict__ A, int lda, int K, const float* __restrict__ WP,
                                             const float* __restrict__ bias, float* __restrict__ out, int ldo, int wave, int lane,
-                                            const ActW<TPW, U>& first)
+                                            const ActW& first)
 {
     const int ai = lane & 15, ak = lane >> 4;
-    const int colb = 16 * TPW * wave + TPW * ai;
-    f32x4 acc[TPW];
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int colb = 32 * wave + 2 * ai;
+    f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
     const float* ap = A + ai * lda + ak;
-    const float* bp = actor_wptr<TPW>(WT, wave, lane);
+    const float4* bp = actor_wptr(WP, wave, lane);
     // two register blocks, ping-pong: block b's MFMAs run on one while the other receives block b + 1 (a copy `cur = nxt` at the
     // end of an iteration would wait for the loads it is supposed to hide).  The scheduling barriers keep the compiler from
     // sinking the loads below the MFMAs.
-    ActW<TPW, U> w0 = first, w1;
-    const int nblk = K / (4 * U), tail0 = nblk * 4 * U;
-    auto mma = [&](const ActW<TPW, U>& w, int k0) {
-        float a[U];
+    ActW w0 = first, w1;
+    ActA a0, a1;
+    const int nblk = K / (4 * ACT_U);
+    auto mma = [&](const ActW& w, const ActA& x) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) a[u] = ap[k0 + 4 * u];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-#pragma unroll
-            for (int t = 0; t < TPW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], w.b[u][t], acc[t], 0, 0, 0);
+        for (int i = 0; i < ACT_U / 2; ++i) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.a[2 * i], w.v[i].x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.a[2 * i], w.v[i].y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.a[2 * i + 1], w.v[i].z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.a[2 * i + 1], w.v[i].w, acc1, 0, 0, 0);
         }
     };
-    for (int blk = 0; blk < nblk; blk += 2) {
-        if (blk + 1 < nblk) actor_wload<TPW, U>(w1, bp, (blk + 1) * 4 * U);
+    actor_aload(a0, ap, 0);
+    int blk = 0;
+#ifndef ACT_ABLATE
+#define ACT_ABLATE 0        /* experiments only: 1 = no weight loads in the loop, 2 = no A loads, 3 = neither */
+#endif
+    if (ACT_ABLATE & 1) w1 = w0;
+    if (ACT_ABLATE & 2) a1 = a0;
+    for (; blk + 1 < nblk; blk += 2) {
+        if (!(ACT_ABLATE & 1)) actor_wload(w1, bp, blk + 1);
+        if (!(ACT_ABLATE & 2)) actor_aload(a1, ap, (blk + 1) * 4 * ACT_U);
         __builtin_amdgcn_sched_barrier(0);
-        mma(w0, blk * 4 * U);
+        mma(w0, a0);
         __builtin_amdgcn_sched_barrier(0);
-        if (blk + 1 < nblk) {
-            if (blk + 2 < nblk) actor_wload<TPW, U>(w0, bp, (blk + 2) * 4 * U);
-            __builtin_amdgcn_sched_barrier(0);
-            mma(w1, (blk + 1) * 4 * U);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        const int nb = min(blk + 2, nblk - 1);
+        if (!(ACT_ABLATE & 1)) actor_wload(w0, bp, nb);
+        if (!(ACT_ABLATE & 2)) actor_aload(a0, ap, nb * 4 * ACT_U);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(w1, a1);
+        __builtin_amdgcn_sched_barrier(0);
     }
-    for (int k0 = tail0; k0 < K; k0 += 4) {
-        const float a = ap[k0];
-        ActW<TPW, 1> wt;
-        actor_wload<TPW, 1>(wt, bp, k0);
-#pragma unroll
-        for (int t = 0; t < TPW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wt.b[0][t], acc[t], 0, 0, 0);
-    }
+    if (blk < nblk) mma(w0, a0);                        // odd block count: the last pair left block nblk - 1 in w0 / a0
     const int rowb = ak * 4;                            // C/D: col = lane & 15, row = (lane >> 4) * 4 + reg
+    const float bv0 = bias[colb], bv1 = bias[colb + 1];
 #pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-        const float bv = bias[colb + t];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) out[(rowb + r) * ldo + colb + t] = fmaxf(acc[t][r] + bv, 0.f);
+    for (int r = 0; r < 4; ++r) {
+        out[(rowb + r) * ldo + colb] = fmaxf(acc0[r] + bv0, 0.f);
+        out[(rowb + r) * ldo + colb + 1] = fmaxf(acc1[r] + bv1, 0.f);
     }
 }
 
+#ifdef CN_TIMING
+// profiling build: s_memtime stamps of workgroup b's wave 0 at [b][8] (tools/actor_timing.py)
+__device__ long long* cn_actor_timing = nullptr;
+extern "C" int cn_debug_set_actor_timing(long long* dev_buf)
+{
+    return hipMemcpyToSymbol(HIP_SYMBOL(cn_actor_timing), &dev_buf, sizeof(dev_buf)) == hipSuccess ? 0 : -4;
+}
+#define ACT_T(k) do { if (cn_actor_timing && threadIdx.x == 0) cn_actor_timing[(size_t)blockIdx.x * 8 + (k)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define ACT_T(k) do { } while (0)
+#endif
 // One tile of 16 environments through the actor (TD3:96-106 + 209-215), by the NW waves of a workgroup (all of its threads must
 // call this).  obs / action: the tile's first row; n_live: rows of the tile that exist; act_sm: 16 (Dp + 1) + 16 * 257 floats of
 // LDS.  Ends with the actions in global memory (the caller synchronises before anyone reads them).
-template <int NW>
+template <int NW>        // NW = 8 (the packed weight layout is laid out for 8 waves x 32 columns)
 __device__ __forceinline__ void actor_tile(const float* __restrict__ obs, int n_live, int row0, int D, int Dp,
         const float* __restrict__ W1T, const float* __restrict__ b1, const float* __restrict__ W2T,
         const float* __restrict__ b2, const float* __restrict__ W3, const float* __restrict__ b3,
         float* __restrict__ action, float* __restrict__ action2, float max_v, float max_w, float sigma, uint64_t seed, uint64_t counter,
         float* __restrict__ act_sm)
 {
-    constexpr int TPW = 16 / NW, U = 8;
+    static_assert(NW == 8, "packed weights: 8 waves x 32 columns");
     const int ldx = Dp + 1, ldh = ACT_H + 1;
     float* X = act_sm;                 // [16][Dp + 1]; layer 2 writes its output here (the observations are dead by then)
     float* H = X + ACT_M * ldx;        // [16][257] hidden activations of layer 1
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    ActW<TPW, U> w1, w2;
-    actor_wload<TPW, U>(w1, actor_wptr<TPW>(W1T, wave, lane), 0);      // in flight while the observations are staged
+    ActW w1, w2;
+    ACT_T(0);
+    actor_wload(w1, actor_wptr(W1T, wave, lane), 0);                   // in flight while the observations are staged
     // Staging the tile: rows by wave, coalesced.  Every load of a chunk (8 x 64 columns of each of the wave's rows) is issued
     // before the first store: written as `X[c] = src[c]` the loop paid one L2 round trip per 64 columns, in series -- 7 to 14 of
     // them, half of the tile's latency.
@@ -2760,25 +2790,39 @@ __device__ __forceinline__ void actor_tile(const float* __restrict__ obs, int n_
             }
         }
     }
+    ACT_T(1);
     __syncthreads();
-    actor_layer<TPW, U>(X, ldx, Dp, W1T, b1, H, ldh, wave, lane, w1);
-    actor_wload<TPW, U>(w2, actor_wptr<TPW>(W2T, wave, lane), 0);      // ... and while the slowest wave finishes layer 1
+    ACT_T(2);
+    actor_layer(X, ldx, Dp, W1T, b1, H, ldh, wave, lane, w1);
+    actor_wload(w2, actor_wptr(W2T, wave, lane), 0);                   // ... and while the slowest wave finishes layer 1
+    ACT_T(3);
     __syncthreads();
+    ACT_T(4);
     float* H2 = X;
-    actor_layer<TPW, U>(H, ldh, ACT_H, W2T, b2, H2, ldh, wave, lane, w2);
+    // linear3's weights for the last stage (thread = (env i, output o, eighth of K)): requested now, used after layer 2
+    float w3r[32];
+    float b3r = 0.f;
+    if (tid < 256) {
+        const float* w = W3 + ((tid >> 3) & 1) * ACT_H + (tid & 7) * 32;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) w3r[k] = w[k];
+        b3r = b3[(tid >> 3) & 1];
+    }
+    actor_layer(H, ldh, ACT_H, W2T, b2, H2, ldh, wave, lane, w2);
+    ACT_T(5);
     __syncthreads();
+    ACT_T(6);
     if (tid < 256)
     {   // linear3 (TD3:101) + heads, exploration noise, clip: thread = (env i, output o, eighth of K), 32-term partial dots
         const int i = tid >> 4, o = (tid >> 3) & 1, part = tid & 7;
         const float* h = H2 + i * ldh + part * 32;
-        const float* w = W3 + o * ACT_H + part * 32;
         float acc = 0.f;
 #pragma unroll
-        for (int k = 0; k < 32; ++k) acc = fmaf(h[k], w[k], acc);
+        for (int k = 0; k < 32; ++k) acc = fmaf(h[k], w3r[k], acc);
         acc += __shfl_xor(acc, 1, 64);
         acc += __shfl_xor(acc, 2, 64);
         acc += __shfl_xor(acc, 4, 64);
-        const float logit = acc + b3[o];
+        const float logit = acc + b3r;
         const int e = row0 + i;
         float val = (o == 0) ? max_v / (1.0f + __expf(-logit)) : max_w * tanhf(logit);
         if (sigma > 0.0f) {   // same generator as cn_policy_tail_kernel: keyed by (seed, counter, env row)
@@ -2796,6 +2840,7 @@ __device__ __forceinline__ void actor_tile(const float* __restrict__ obs, int n_
             if (action2) action2[2 * (size_t)i + o] = val;
         }
     }
+    ACT_T(7);
 }
 
 extern "C" __global__ void __launch_bounds__(ACT_THREADS) cn_actor_kernel(const float* __restrict__ obs, int n, int D, int Dp,

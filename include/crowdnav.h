@@ -214,13 +214,19 @@ int cn_policy_tail(const float* logits, float* action, int n, float max_v, float
 
 /* The whole TD3 actor as one launch: Actor.forward (td3.py:96-106: Linear(obs_dim,256)-ReLU-Linear(256,256)-ReLU-
  * Linear(256,2), sigmoid*max_v / tanh*max_w heads) + Agent.act's exploration noise and clip (td3.py:209-215), in
- * float32 on the f32 matrix cores.  Weights are caller-owned device arrays in K-major layout:
- *   w1t [obs_dim_padded][256] = linear1.weight^T with zero rows up to a multiple of 4, w2t [256][256] = linear2.weight^T,
- *   w3 [2][256] = linear3.weight, biases as in PyTorch.  obs: dev [n, obs_dim] float32; action: dev [n,2]. */
+ * float32 on the f32 matrix cores.  Weights are caller-owned device arrays:
+ *   w1p = cn_actor_pack_weights(linear1.weight^T [obs_dim_padded][256], zero rows from obs_dim up to a multiple of 32),
+ *   w2p = cn_actor_pack_weights(linear2.weight^T [256][256]), w3 [2][256] = linear3.weight, biases as in PyTorch.
+ * obs: dev [n, obs_dim] float32; action: dev [n,2].
+ * cn_actor_pack_weights reorders a K-major [k_rows][256] float32 matrix (k_rows a multiple of 32) into the order the kernel's
+ * wavefronts consume it -- packed[((((b*8 + w)*4 + q)*64 + lane)*4 + j] = wt[32 b + 4 (2 q + (j >> 1)) + (lane >> 4)][32 w +
+ * 2 (lane & 15) + (j & 1)] -- so every lane streams 16-byte loads out of L2 and a wavefront's block is 4 KB contiguous
+ * (k_rows * 256 floats, same size as the input; in and out must not alias).  Call it once per weight update. */
 typedef struct cn_actor_weights {
-    const float* w1t; const float* b1; const float* w2t; const float* b2; const float* w3; const float* b3;
+    const float* w1p; const float* b1; const float* w2p; const float* b2; const float* w3; const float* b3;
     int32_t obs_dim, obs_dim_padded, hidden, reserved;
 } cn_actor_weights;
+int cn_actor_pack_weights(const float* wt_dev, int k_rows, float* packed_dev, int device, void* stream);
 int cn_actor_forward(const cn_actor_weights* w, const float* obs, float* action, int n, float max_v, float max_w,
                      float sigma, uint64_t seed, uint64_t counter, int device, void* stream);
 

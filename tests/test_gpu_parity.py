@@ -923,10 +923,11 @@ def test_graphed_rollout_replays():
 
 def test_mfma_actor_matches_the_torch_actor():
     """cn_actor_forward (one kernel, f32 matrix cores) vs the PyTorch fp32 actor of td3.py:81-106: same actions
-    up to float32 summation order; ragged batch sizes; K = 4 layout (382 inputs, not a multiple of 4 -> padded)."""
+    up to float32 summation order; ragged batch sizes; input widths that are not multiples of 32 (zero-padded rows of the
+    packed first layer: 398 -> 416, 382 -> 384, 370 -> 384) and one that is (384)."""
     import torch
     from crowdnav.td3 import Agent
-    for obs_dim, n in ((398, 4096), (398, 37), (382, 1000), (370, 16)):
+    for obs_dim, n in ((398, 4096), (398, 37), (382, 1000), (370, 16), (384, 100)):
         agent = Agent(obs_dim=obs_dim, device="cuda", seed=obs_dim, memory_size=16)
         with torch.no_grad():   # asymmetric, non-trivial weights so a transposed tile would show
             for p_ in agent.actor.parameters():
@@ -940,6 +941,36 @@ def test_mfma_actor_matches_the_torch_actor():
         noisy = agent.act_mfma(obs, add_noise=True)
         assert float(noisy[:, 0].min()) >= 0.0 and float(noisy[:, 0].max()) <= 0.22 and float(noisy[:, 1].abs().max()) <= 2.0
         assert not torch.equal(noisy, got)
+
+
+def test_actor_weight_packing_layout_and_errors():
+    """cn_actor_pack_weights: the documented permutation (include/crowdnav.h), element for element, for both layer shapes;
+    k_rows that is not a multiple of 32, aliasing buffers and an unpadded obs_dim_padded in cn_actor_forward come back as codes."""
+    import ctypes as C
+    import torch
+    from crowdnav import _abi
+    L = _abi.lib()
+    for K in (32, 256, 416):
+        wt = torch.arange(K * 256, dtype=torch.float32, device="cuda").reshape(K, 256).contiguous()
+        out = torch.empty_like(wt)
+        assert L.cn_actor_pack_weights(C.c_void_p(wt.data_ptr()), K, C.c_void_p(out.data_ptr()), 0, None) == 0
+        torch.cuda.synchronize()
+        idx = np.arange(K * 256)
+        j, lane, q, w, b = idx & 3, (idx >> 2) & 63, (idx >> 8) & 3, (idx >> 10) & 7, idx >> 13
+        k = 32 * b + 4 * (2 * q + (j >> 1)) + (lane >> 4)
+        c = 32 * w + 2 * (lane & 15) + (j & 1)
+        assert np.array_equal(out.cpu().numpy().reshape(-1), (k * 256 + c).astype(np.float32))
+        assert len(set((k * 256 + c).tolist())) == K * 256                       # a permutation: every weight exactly once
+    wt = torch.zeros((48, 256), device="cuda"); out = torch.empty_like(wt)
+    assert L.cn_actor_pack_weights(C.c_void_p(wt.data_ptr()), 48, C.c_void_p(out.data_ptr()), 0, None) == -2
+    assert b"multiple of 32" in L.cn_last_error()
+    assert L.cn_actor_pack_weights(C.c_void_p(wt.data_ptr()), 32, C.c_void_p(wt.data_ptr()), 0, None) == -1
+    z = torch.zeros(416 * 256, device="cuda")
+    w = _abi.CnActorWeights(w1p=z.data_ptr(), b1=z.data_ptr(), w2p=z.data_ptr(), b2=z.data_ptr(), w3=z.data_ptr(), b3=z.data_ptr(),
+                            obs_dim=398, obs_dim_padded=400, hidden=256, reserved=0)
+    obs = torch.zeros((16, 398), device="cuda"); act = torch.zeros((16, 2), device="cuda")
+    assert L.cn_actor_forward(C.byref(w), C.c_void_p(obs.data_ptr()), C.c_void_p(act.data_ptr()), 16, 0.22, 2.0, 0.0, 1, 1, 0, None) == -2
+    assert b"multiple of 32" in L.cn_last_error()
 
 
 def test_error_codes_and_limits():

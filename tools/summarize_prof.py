@@ -46,19 +46,25 @@ def main(d):
         if not f:
             print("== %s: no counter csv" % tag)
             continue
-        acc, cnt = {}, {}
-        rows = [r for r in csv.DictReader(open(f)) if r.get("Kernel_Name", "").split("(")[0].strip() == "cn_env_kernel"]
-        gmax = max([int(r.get("Grid_Size", 0) or 0) for r in rows] or [0])
-        for row in rows:
-            if int(row.get("Grid_Size", 0) or 0) != gmax:      # the one-launch-per-step leg only (full grid)
+        allrows = list(csv.DictReader(open(f)))
+        # the one-launch-per-step legs (full grid): cn_env_kernel_fair is what cn_step launches for a handle that fills the device
+        # (CN_ARB_AUTO), cn_env_kernel the same step under the hardware's oldest-first issue order (bench leg 1_groups_oldest_first)
+        for kname in ("cn_env_kernel", "cn_env_kernel_fair"):
+            acc, cnt = {}, {}
+            rows = [r for r in allrows if r.get("Kernel_Name", "").split("(")[0].strip() == kname]
+            gmax = max([int(r.get("Grid_Size", 0) or 0) for r in rows] or [0])
+            for row in rows:
+                if int(row.get("Grid_Size", 0) or 0) != gmax:
+                    continue
+                k = row["Counter_Name"]; v = float(row["Counter_Value"])
+                acc[k] = acc.get(k, 0.0) + v; cnt[k] = cnt.get(k, 0) + 1
+            if not acc:
                 continue
-            k = row["Counter_Name"]; v = float(row["Counter_Value"])
-            acc[k] = acc.get(k, 0.0) + v; cnt[k] = cnt.get(k, 0) + 1
-        print("== %s (per cn_env_kernel dispatch of %d envs, mean of %s)" % (tag, gmax // 64, sorted(set(cnt.values()))))
-        for k in sorted(acc):
-            print("  %-24s %.6g" % (k, acc[k] / cnt[k]))
-            sq[k] = acc[k] / cnt[k]
-        sq["_envs"] = gmax // 64
+            print("== %s (per %s dispatch of %d envs, mean of %s)" % (tag, kname, gmax // 64, sorted(set(cnt.values()))))
+            for k in sorted(acc):
+                print("  %-24s %.6g" % (k, acc[k] / cnt[k]))
+                sq[k] = acc[k] / cnt[k]                # the later (fair) kernel's figures are the ones counters.json keeps
+            sq["_envs"] = gmax // 64; sq["_kernel"] = kname
     if "SQ_INSTS_VALU" in sq and "SQ_BUSY_CYCLES" in sq:
         import json
         n = float(sq["_envs"])
@@ -70,7 +76,7 @@ def main(d):
                                            "lds": sq.get("SQ_INSTS_LDS", 0) / n},
                "wave_quad_cycles_per_env_step": sq.get("SQ_WAVE_CYCLES", 0) / n,
                "wait_any_frac": sq.get("SQ_WAIT_ANY", 0) / max(1.0, sq.get("SQ_WAVE_CYCLES", 1)),
-               "launch_cycles": kcycles, "envs_per_launch": n, "csrc_hash": csrc_hash(),
+               "launch_cycles": kcycles, "envs_per_launch": n, "csrc_hash": csrc_hash(), "kernel": sq.get("_kernel"),
                "lds_bank_conflict_frac": (sq["SQ_LDS_BANK_CONFLICT"] / sq["SQ_LDS_IDX_ACTIVE"]) if sq.get("SQ_LDS_IDX_ACTIVE") else None,
                "source": "rocprofv3 --pmc SQ_* pass of this bench command, full-grid (one launch per step) dispatches: valu_busy = "
                          "4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x SQ_BUSY_CYCLES / 32)"}
@@ -104,7 +110,7 @@ def main(d):
             for tag, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
                 ff = find(os.path.join(d, tag), "*counter_collection.csv")
                 rows = [r for r in csv.DictReader(open(ff))
-                        if r.get("Kernel_Name", "").split("(")[0].strip() == "cn_env_kernel" and r["Counter_Name"] == ctr]
+                        if r.get("Kernel_Name", "").split("(")[0].strip() in ("cn_env_kernel", "cn_env_kernel_fair") and r["Counter_Name"] == ctr]
                 gmax = max(int(r.get("Grid_Size", 0) or 0) for r in rows)
                 vals = [float(r["Counter_Value"]) for r in rows if int(r.get("Grid_Size", 0) or 0) == gmax]
                 m = sum(vals) / max(1, len(vals))   # the one-launch-per-step leg (4096 envs per launch)

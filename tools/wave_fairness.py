@@ -2,7 +2,7 @@
 """Do the wavefronts that share a SIMD share it fairly?  (profiling build: s_memtime at entry / exit + HW_ID / XCC_ID per wave.)
 For one-launch-per-step at N envs: groups the waves of each launch by (XCC, SE, CU, SIMD), ranks them by entry time and prints
 lifetime and exit time by rank -- an arbiter that favours the oldest wave shows up as lifetimes growing with rank and the SIMD's
-last exit far behind its first.  Usage: python tools/wave_fairness.py [N]"""
+last exit far behind its first.  Usage: [CN_ARB=fair] python tools/wave_fairness.py [N]"""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "drl-based-mapless-crowd-navigation-with-perceived-risk_amd"))
@@ -12,7 +12,8 @@ _abi.LIB_PATH = os.path.abspath(os.environ["CN_LIB"]) if os.environ.get("CN_LIB"
 from crowdnav import Config
 from crowdnav.env import VecEnv
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-env = VecEnv(Config(n_envs=N, ped_cycle_ms=1400)); env.reset()
+env = VecEnv(Config(n_envs=N, ped_cycle_ms=1400), arbitration=os.environ.get("CN_ARB", "oldest_first")); env.reset()
+print("N = %d, arbitration %s (CN_ARB=oldest_first|fair)" % (N, env.arbitration))
 tb = torch.zeros((N, 32), dtype=torch.int64, device="cuda")
 env.L.cn_debug_set_timing(env.h, C.c_void_p(tb.data_ptr()))
 g = torch.Generator(device="cuda").manual_seed(1)

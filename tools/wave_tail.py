@@ -11,7 +11,8 @@ _abi.LIB_PATH = _abi.LIB_PATH.replace("libcrowdnav.so", "libcrowdnav_timing.so")
 from crowdnav import Config
 from crowdnav.env import VecEnv
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-env = VecEnv(Config(n_envs=N, ped_cycle_ms=1400)); env.reset()
+env = VecEnv(Config(n_envs=N, ped_cycle_ms=1400), arbitration=os.environ.get("CN_ARB", "auto")); env.reset()
+print("N = %d, arbitration %s (CN_ARB=auto|oldest_first|fair)" % (N, env.arbitration))
 tb = torch.zeros((N, 32), dtype=torch.int64, device="cuda")
 env.L.cn_debug_set_timing(env.h, C.c_void_p(tb.data_ptr()))
 g = torch.Generator(device="cuda").manual_seed(1)
