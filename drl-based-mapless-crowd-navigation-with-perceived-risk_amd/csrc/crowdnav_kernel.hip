@@ -2648,16 +2648,19 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // dwordx4 -- and the tile's two layers ran at exactly that dwordx2 pace (19.5 B/clk per CU in both), whatever the prefetch depth.
 #define ACT_U 8                    /* k-steps per pipelined block */
 struct ActW { float4 v[ACT_U / 2]; };
-__device__ __forceinline__ void actor_wload(ActW& w, const float4* __restrict__ bp, int blk)
+// A lane's operands of block `blk`: uniform base (SGPR pair, advanced per block on the scalar unit) + this lane's 32-bit
+// offset + an immediate -- global_load_dwordx4 v, v_off, s[base] offset:1024 i -- so the loop has no 64-bit vector address
+// arithmetic (with a per-lane pointer every load cost a v_add_co / v_addc pair and their s_nop).
+struct ActWPtr { const float4* base; unsigned off; };
+__device__ __forceinline__ void actor_wload(ActW& w, const ActWPtr bp, int blk)
 {
-    const float4* q = bp + (size_t)blk * (8 * 4 * 64);
+    const float4* q = bp.base + (size_t)blk * (8 * 4 * 64);
 #pragma unroll
-    for (int i = 0; i < ACT_U / 2; ++i) w.v[i] = q[i * 64];
+    for (int i = 0; i < ACT_U / 2; ++i) w.v[i] = q[bp.off + (unsigned)(i * 64)];
 }
-// this lane's first operand in a packed layer
-__device__ __forceinline__ const float4* actor_wptr(const float* __restrict__ WP, int wave, int lane)
+__device__ __forceinline__ ActWPtr actor_wptr(const float* __restrict__ WP, int wave, int lane)
 {
-    return reinterpret_cast<const float4*>(WP) + (size_t)wave * (4 * 64) + lane;
+    return ActWPtr{reinterpret_cast<const float4*>(WP) + (size_t)wave * (4 * 64), (unsigned)lane};
 }
 extern "C" __global__ void cn_actor_pack_kernel(const float* __restrict__ wt, int K, float* __restrict__ packed)
 {
@@ -2681,18 +2684,34 @@ __device__ __forceinline__ void actor_aload(ActA& x, const float* ap, int k0)
 #pragma unroll
     for (int u = 0; u < ACT_U; ++u) x.a[u] = ap[k0 + 4 * u];
 }
+// FINAL (the second hidden layer): the activations are not written back -- linear3 (TD3:101) is folded into the epilogue: every
+// lane multiplies its 4 rows x 2 columns of relu(h2) by linear3's weights of those columns, a DPP scan sums the 16 lanes
+// (= 32 columns) of each row group, and lane 15 of the group leaves the wave's partial logits in out[(wave 16 + row) 2 + o];
+// the caller adds the eight waves in wave order.  (Before: 16 x 256 activations through LDS, a barrier, 8 k LDS reads.)
+__device__ __forceinline__ float actor_row_sum(float v)      // inclusive scan over the 16 lanes of a DPP row: lane 15 = the sum
+{
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, false));   // row_shr:1
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x112, 0xf, 0xf, false));   // row_shr:2
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x114, 0xf, 0xf, false));   // row_shr:4
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x118, 0xf, 0xf, false));   // row_shr:8
+    return v;
+}
+template <bool FINAL = false>
 __device__ __forceinline__ void actor_layer(const float* __restrict__ A, int lda, int K, const float* __restrict__ WP,
                                             const float* __restrict__ bias, float* __restrict__ out, int ldo, int wave, int lane,
-                                            const ActW& first)
+                                            const ActW& first, const float* __restrict__ W3 = nullptr)
 {
     const int ai = lane & 15, ak = lane >> 4;
     const int colb = 32 * wave + 2 * ai;
+    float w3[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (FINAL) { w3[0] = W3[colb]; w3[1] = W3[colb + 1]; w3[2] = W3[ACT_H + colb]; w3[3] = W3[ACT_H + colb + 1]; }
     f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
     const float* ap = A + ai * lda + ak;
-    const float4* bp = actor_wptr(WP, wave, lane);
+    const ActWPtr bp = actor_wptr(WP, wave, lane);
     // two register blocks, ping-pong: block b's MFMAs run on one while the other receives block b + 1 (a copy `cur = nxt` at the
     // end of an iteration would wait for the loads it is supposed to hide).  The scheduling barriers keep the compiler from
-    // sinking the loads below the MFMAs.
+    // sinking the loads below the MFMAs.  (A ring of four blocks, three requests ahead, measured the same 17.5 us: layer 1 7 %
+    // faster, layer 2 10 % slower for its longer ramp -- the loads are not latency-bound any more.)
     ActW w0 = first, w1;
     ActA a0, a1;
     const int nblk = K / (4 * ACT_U);
@@ -2728,10 +2747,20 @@ __device__ __forceinline__ void actor_layer(const float* __restrict__ A, int lda
     if (blk < nblk) mma(w0, a0);                        // odd block count: the last pair left block nblk - 1 in w0 / a0
     const int rowb = ak * 4;                            // C/D: col = lane & 15, row = (lane >> 4) * 4 + reg
     const float bv0 = bias[colb], bv1 = bias[colb + 1];
+    if constexpr (!FINAL) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        out[(rowb + r) * ldo + colb] = fmaxf(acc0[r] + bv0, 0.f);
-        out[(rowb + r) * ldo + colb + 1] = fmaxf(acc1[r] + bv1, 0.f);
+        for (int r = 0; r < 4; ++r) {
+            out[(rowb + r) * ldo + colb] = fmaxf(acc0[r] + bv0, 0.f);
+            out[(rowb + r) * ldo + colb + 1] = fmaxf(acc1[r] + bv1, 0.f);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float h0 = fmaxf(acc0[r] + bv0, 0.f), h1 = fmaxf(acc1[r] + bv1, 0.f);
+            const float l0 = actor_row_sum(fmaf(h1, w3[1], h0 * w3[0]));
+            const float l1 = actor_row_sum(fmaf(h1, w3[3], h0 * w3[2]));
+            if (ai == 15) { out[(wave * ACT_M + rowb + r) * 2] = l0; out[(wave * ACT_M + rowb + r) * 2 + 1] = l1; }
+        }
     }
 }
 
@@ -2798,31 +2827,17 @@ __device__ __forceinline__ void actor_tile(const float* __restrict__ obs, int n_
     ACT_T(3);
     __syncthreads();
     ACT_T(4);
-    float* H2 = X;
-    // linear3's weights for the last stage (thread = (env i, output o, eighth of K)): requested now, used after layer 2
-    float w3r[32];
-    float b3r = 0.f;
-    if (tid < 256) {
-        const float* w = W3 + ((tid >> 3) & 1) * ACT_H + (tid & 7) * 32;
-#pragma unroll
-        for (int k = 0; k < 32; ++k) w3r[k] = w[k];
-        b3r = b3[(tid >> 3) & 1];
-    }
-    actor_layer(H, ldh, ACT_H, W2T, b2, H2, ldh, wave, lane, w2);
+    float* PL = X;                     // [8 waves][16 rows][2]: the waves' partial logits (the observations are dead by now)
+    actor_layer<true>(H, ldh, ACT_H, W2T, b2, PL, 0, wave, lane, w2, W3);
     ACT_T(5);
     __syncthreads();
     ACT_T(6);
-    if (tid < 256)
-    {   // linear3 (TD3:101) + heads, exploration noise, clip: thread = (env i, output o, eighth of K), 32-term partial dots
-        const int i = tid >> 4, o = (tid >> 3) & 1, part = tid & 7;
-        const float* h = H2 + i * ldh + part * 32;
-        float acc = 0.f;
+    if (tid < 2 * ACT_M)
+    {   // heads, exploration noise, clip: thread = (env i, output o)
+        const int i = tid >> 1, o = tid & 1, part = 0;
+        float logit = b3[o];
 #pragma unroll
-        for (int k = 0; k < 32; ++k) acc = fmaf(h[k], w3r[k], acc);
-        acc += __shfl_xor(acc, 1, 64);
-        acc += __shfl_xor(acc, 2, 64);
-        acc += __shfl_xor(acc, 4, 64);
-        const float logit = acc + b3r;
+        for (int w = 0; w < NW; ++w) logit += PL[(w * ACT_M + i) * 2 + o];
         const int e = row0 + i;
         float val = (o == 0) ? max_v / (1.0f + __expf(-logit)) : max_w * tanhf(logit);
         if (sigma > 0.0f) {   // same generator as cn_policy_tail_kernel: keyed by (seed, counter, env row)
