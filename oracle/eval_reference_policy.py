@@ -100,6 +100,12 @@ def main():
         for sigma in (1.0, 0.0):
             cfg, init = world(k)
             show("top_%d_obstacle ep2500, sigma %.0f / training world, walkers U(-0.2, 0.2) m/s" % (k, sigma), run(m, cfg, init, None, a.episodes, sigma=sigma))
+    # how many of the 14 walkers are really in the room?  (obstacles 7-14 are created at one point: presets.training's docstring)
+    for npeds in (10, 8, 7, 6, 4):
+        cfg, init = world(8)
+        cfg.n_peds = npeds
+        show("top_8_obstacle ep2500, sigma 1 / training world, only obstacles 1-%d in the room (round still 1.4 s)" % npeds,
+             run(actors[8], cfg, init[:, :npeds].copy(), None, a.episodes, sigma=1.0))
     for vmax in (0.1, 0.03, 0.0):
         for k in (1, 8):
             cfg, init = world(k, vmax)

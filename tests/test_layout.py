@@ -98,3 +98,15 @@ def test_lds_budget_of_benchmark_configs():
     L.cn_lds_bytes.argtypes = [C.c_int] * 5
     assert L.cn_lds_bytes(360, 20, 8, 359 // 4 + 2, 32) <= 10 * 1024      # 16 wavefronts per CU
     assert L.cn_lds_bytes(720, 100, 8, 719 // 4 + 2, 64) <= 160 * 1024
+
+
+def test_training_preset_and_the_cospawned_obstacles():
+    """presets.training: the world file's 14 obstacles, or (drop_cospawned) the six that have a spawn pose of their own --
+    obstacles 7-14 are all created at (0.22, 0.54) (turtlebot3_crowd_dense.world:447-867); the crowd node's round stays 1.4 s."""
+    from crowdnav import presets
+    cfg, init = presets.training(n_envs=3)
+    assert cfg.n_peds == 14 and cfg.ped_cycle_ms == 1400 and init.shape == (3, 14, 2)
+    assert len({tuple(p) for p in init[0]}) == 7 and (init[0, 6:] == init[0, 6]).all()
+    cfg6, init6 = presets.training(n_envs=3, drop_cospawned=True)
+    assert cfg6.n_peds == 6 and cfg6.ped_cycle_ms == 1400 and init6.shape == (3, 6, 2)
+    assert (init6[0] == init[0, :6]).all() and cfg6.ped_vmax == cfg.ped_vmax == 0.2
