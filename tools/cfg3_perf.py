@@ -5,6 +5,9 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "drl-based-mapless-crowd-navigation-with-perceived-risk_amd"))
 import torch
+from crowdnav import _abi
+if os.environ.get("CN_LIB"):
+    _abi.LIB_PATH = os.path.abspath(os.environ["CN_LIB"]); _abi.build = lambda force=False: _abi.LIB_PATH
 from crowdnav import Config
 from crowdnav.env import VecEnvGroups
 from crowdnav.rollout import rollout_groups
@@ -21,7 +24,7 @@ def marker(envs):
     return tot
 
 for G in (1, 2, 4):
-    g = VecEnvGroups(cfg, groups=G); g.reset()
+    g = VecEnvGroups(cfg, groups=G, arbitration=os.environ.get("CN_GROUP_ARB") or None); g.reset()
     agent = Agent(obs_dim=g.D, device="cuda", seed=0, memory_size=16)
     rollout_groups(g, agent, 200); torch.cuda.synchronize()
     for rep in range(2):
