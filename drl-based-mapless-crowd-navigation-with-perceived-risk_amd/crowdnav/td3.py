@@ -165,7 +165,8 @@ class Agent:
             # K-major -> the order the kernel's wavefronts consume (16-byte loads, 4 KB contiguous per wavefront and block)
             _abi.check(L.cn_actor_pack_weights(C.c_void_p(w1t.data_ptr()), Dp, C.c_void_p(w1p.data_ptr()), self._dev_index, st))
             _abi.check(L.cn_actor_pack_weights(C.c_void_p(w2t.data_ptr()), 256, C.c_void_p(w2p.data_ptr()), self._dev_index, st))
-            torch.cuda.current_stream(self.device).synchronize()       # w1t / w2t die with this scope
+            # no host synchronise: the pack kernels were enqueued on torch's current stream, so the caching allocator's
+            # stream-ordered reuse of w1t / w2t (freed with this scope) cannot overtake them
             self._fw = dict(w1p=w1p, b1=a.linear1.bias.detach().float().contiguous(),
                             w2p=w2p, b2=a.linear2.bias.detach().float().contiguous(),
                             w3=a.linear3.weight.detach().float().contiguous(), b3=a.linear3.bias.detach().float().contiguous())
