@@ -7,7 +7,9 @@ cd /tmp
 i=0
 for C in "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH SQ_INSTS_BRANCH SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \
          "SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES SQ_INSTS_SMEM SQ_INST_LEVEL_SMEM SQ_INST_CYCLES_SMEM SQ_INST_CYCLES_SALU SQ_INSTS_SALU" \
-         "SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INST_LEVEL_LDS SQ_INSTS_LDS SQ_IFETCH_LEVEL SQ_LEVEL_WAVES SQ_WAVES"; do
+         "SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INST_LEVEL_LDS SQ_INSTS_LDS SQ_IFETCH_LEVEL SQ_LEVEL_WAVES SQ_WAVES" \
+         "SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT" \
+         "SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_MISC"; do
   i=$((i+1))
   rocprofv3 --output-format csv --pmc $C -d "$OUT/pmcx$i" -o pmc -- $BENCH > "$OUT/pmcx$i.log" 2>&1
 done
@@ -15,7 +17,7 @@ cd "$REPO"
 python - "$OUT" <<'PY' | tee "$OUT/pmc_extra.txt"
 import csv, glob, os, sys
 d = sys.argv[1]
-for k in ("cn_env_kernel", "cn_env_kernel_seq"):
+for k in ("cn_env_kernel", "cn_env_kernel_fair", "cn_env_kernel_seq"):
     print("==", k, "(per env-step, full 4096-env grid)")
     for f in sorted(glob.glob(os.path.join(d, "pmcx*", "**", "*counter_collection.csv"), recursive=True)):
         rows = [r for r in csv.DictReader(open(f)) if r.get("Kernel_Name", "").split("(")[0].strip() == k]
