@@ -210,8 +210,9 @@ def main():
         """One decomposition of a config: its envs as G stream groups (G = 1: one launch per step), open loop or with the TD3
         actor in the loop (each group's act -> step chain on its own stream, crowdnav.rollout.rollout_groups)."""
 
-        def __init__(self, lcfg, G, mode="next", lacts=None, agent=None, sequence=False, arbitration=None):
+        def __init__(self, lcfg, G, mode="next", lacts=None, agent=None, sequence=False, arbitration=None, python_loop=False):
             self.cfg, self.G, self.mode, self.agent, self.sequence = lcfg, G, mode, agent, sequence
+            self.python_loop = python_loop             # the timed K steps enqueued one foreign call per step from Python (as a trainer would)
             # arbitration None: the library's defaults (cn_set_arbitration) -- one launch per step picks the fair kernel when it
             # fills the device on its own, overlapping stream groups stay on the hardware's oldest-first order
             self.grp = VecEnvGroups(lcfg, groups=G, device=dev_index, streams=streams[:G] if G <= len(streams) else None,
@@ -274,7 +275,7 @@ def main():
             t0 = time.perf_counter()
             for g in range(G):
                 ev0[g].record(grp.streams[g])
-            if self.agent is None and steps == K:
+            if self.agent is None and steps == K and not self.python_loop:
                 self.timed_call()
             else:
                 self.run(steps)
@@ -314,10 +315,14 @@ def main():
         legs = {}
         if sequence_leg:
             # + the A/B of cn_set_arbitration on one launch per step (only where the library's default is the fair kernel)
-            candidates = list(candidates) + (["1_groups_oldest_first"] if 1 in candidates and lcfg.n_envs >= 2048 else []) + ["sequence"]
+            # + one launch per step enqueued from a Python loop, one foreign call per step (what a Python trainer pays; the other
+            #   legs pre-marshal their K steps into ONE cn_step_multi / cn_step_sequence call)
+            candidates = (list(candidates) + (["1_groups_oldest_first"] if 1 in candidates and lcfg.n_envs >= 2048 else [])
+                          + (["1_groups_python_enqueue"] if 1 in candidates else []) + ["sequence"])
         for G in candidates:
             lg = (Leg(lcfg, 1, lacts=lacts, sequence=True) if G == "sequence" else
                   Leg(lcfg, 1, mode=mode, lacts=lacts, agent=agent, arbitration="oldest_first") if G == "1_groups_oldest_first" else
+                  Leg(lcfg, 1, mode=mode, lacts=lacts, agent=agent, python_loop=True) if G == "1_groups_python_enqueue" else
                   Leg(lcfg, G, mode=mode, lacts=lacts, agent=agent))
             lg.run(a.preroll + a.warmup - warm_tail)
             legs[G] = lg
