@@ -25,8 +25,9 @@ from .td3 import Agent
 
 
 def make_env(scenario, n_envs, max_steps, seed, device, ped_vmax=None):
-    if scenario == "training":
-        cfg, init = presets.training(n_envs=n_envs, max_steps=max_steps, seed=seed)
+    if scenario in ("training", "training_as_logged"):
+        # training_as_logged: without obstacles 7-14, which the world file creates at one point (presets.training's docstring)
+        cfg, init = presets.training(n_envs=n_envs, max_steps=max_steps, seed=seed, drop_cospawned=scenario == "training_as_logged")
         if ped_vmax is not None:
             cfg.ped_vmax = ped_vmax
         vel = None
@@ -117,7 +118,7 @@ def run_evaluation(a):
 
 def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
-    ap.add_argument("--scenario", default="training", help="training | bench | {crossing,towards,ahead,random}_{4,8,12,20}")
+    ap.add_argument("--scenario", default="training", help="training | training_as_logged | bench | {crossing,towards,ahead,random}_{4,8,12,20}")
     ap.add_argument("--envs", type=int, default=1024)
     ap.add_argument("--launches", type=int, default=3000)
     ap.add_argument("--max-steps", type=int, default=1000, help="nsteps (configs/td3.yaml)")
