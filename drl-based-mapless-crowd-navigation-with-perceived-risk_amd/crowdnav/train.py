@@ -54,6 +54,8 @@ def train(a):
         ns = os.path.join(a.load, "noise_state_ep%d.txt" % a.load_episode)
         if os.path.exists(ns):           # continue the exploration-noise stream instead of replaying it
             agent.set_noise_state(*[int(x) for x in open(ns).read().split()])
+    if a.graphs:
+        agent.enable_graphs()         # a TD3 update as one hipGraph launch (the eager update is launch-bound at batch 128)
     stats = EpisodeStats()
     os.makedirs(a.out, exist_ok=True)
     obs = env.reset()
@@ -128,6 +130,7 @@ def main(argv=None):
     ap.add_argument("--checkpoint-every", type=int, default=100000, help="episodes between checkpoints (TRAIN:150: 100)")
     ap.add_argument("--log-every", type=int, default=100)
     ap.add_argument("--ped-vmax", type=float, default=None, help="training world only: walker speed bound (CROWD:101 -> 0.2)")
+    ap.add_argument("--graphs", type=int, default=1, help="1: capture the TD3 update into hipGraphs (Agent.enable_graphs)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--out", default="runs/td3")

@@ -139,7 +139,7 @@ def test_batched_trainer_runs_on_the_next_step_reset_kernel(tmp_path):
     a = T.main.__globals__["argparse"].Namespace(scenario="bench", envs=64, launches=120, max_steps=25, updates=1, batch=64, memory=20000,
                                                  checkpoint_every=10 ** 9, log_every=10 ** 9, ped_vmax=None, seed=3, device=0,
                                                  out=str(tmp_path / "run"), csv=True, load=None, load_episode=0, evaluate=False,
-                                                 episodes_per_env=1)
+                                                 episodes_per_env=1, graphs=1)
     agent, episodes = T.train(a)
     m = agent.memory
     assert episodes > 64 and len(m) == m.size
@@ -159,6 +159,62 @@ def test_batched_trainer_runs_on_the_next_step_reset_kernel(tmp_path):
     from crowdnav.rollout import evaluate
     st = evaluate(VecEnv(Config(n_envs=32, max_steps=20, seed=4)), agent)
     assert len(st.rows) == 32 and all(abs(r[7] - r[4] * 0.16) < 1e-9 and r[7] > 0 for r in st.rows)
+
+
+def test_graphed_td3_update_equals_the_eager_update():
+    """Agent.enable_graphs: the TD3 update captured into two hipGraphs (critics only / critics + actor + soft updates).
+    (a) enable_graphs leaves parameters and optimizer state untouched (its warm-up runs on a copy);
+    (b) the graphs compute _update's arithmetic: fed the same replay rows and target noise through the eager path of an
+        identically built agent (capturable Adam on both sides), six updates give the same parameters bit for bit;
+    (c) the golden vectors of the REFERENCE's learn() still hold after enable_graphs (explicit batches take the eager path
+        with the capturable optimizers)."""
+    import torch
+    from crowdnav.td3 import Agent
+
+    def build():
+        ag = Agent(device="cuda", memory_size=4096, obs_dim=46, hidden=32, batch_size=16, seed=5)
+        g = torch.Generator(device="cuda").manual_seed(11)
+        n = 600
+        ag.memory.add(torch.randn((n, 46), generator=g, device="cuda"), torch.rand((n, 2), generator=g, device="cuda"),
+                      torch.randn(n, generator=g, device="cuda"), torch.randn((n, 46), generator=g, device="cuda"),
+                      (torch.rand(n, generator=g, device="cuda") < 0.1))
+        return ag
+    a, b = build(), build()
+    before = [p.detach().clone() for m in (a.actor, a.q1, a.q2, a.actor_t, a.q1_t, a.q2_t) for p in m.parameters()]
+    a.enable_graphs(); b.enable_graphs()
+    after = [p for m in (a.actor, a.q1, a.q2, a.actor_t, a.q1_t, a.q2_t) for p in m.parameters()]
+    assert all(torch.equal(x, y) for x, y in zip(before, after))                       # (a)
+    assert all(float(st["step"]) == 0.0 and not st["exp_avg"].any() for o in (a.opt_a, a.opt_q1, a.opt_q2) for st in o.state.values())
+    # (b) a: graph replays; b: the eager path on exactly the rows / noise a's graph drew (re-drawn from the same generator state)
+    for step in range(6):
+        st = torch.cuda.get_rng_state("cuda")
+        a.learn(step)
+        torch.cuda.synchronize()
+        torch.cuda.set_rng_state(st, "cuda")
+        u = torch.rand(16, device="cuda")
+        idx = (u * float(len(b.memory))).long().clamp_(max=b.memory.cap - 1)
+        noise = torch.randn((16, 2), device="cuda")
+        m = b.memory
+        b.learn(step, batch=(m.s[idx], m.a[idx], m.r[idx], m.s2[idx], m.d[idx]), target_noise=noise)
+    for ma, mb in ((a.actor, b.actor), (a.q1, b.q1), (a.q2, b.q2), (a.actor_t, b.actor_t), (a.q1_t, b.q1_t), (a.q2_t, b.q2_t)):
+        for pa, pb in zip(ma.parameters(), mb.parameters()):
+            assert torch.equal(pa, pb)
+    # (c) the reference's learn() goldens through an agent that has graphs enabled
+    G = np.load(os.path.join(ROOT, "tests", "golden", "td3.npz"))
+    ag = Agent(device="cuda", memory_size=64, obs_dim=46, hidden=32, batch_size=16)
+    nets = dict(actor=ag.actor, actor_t=ag.actor_t, q1=ag.q1, q1_t=ag.q1_t, q2=ag.q2, q2_t=ag.q2_t)
+    for k, m_ in nets.items():
+        m_.load_state_dict({n: torch.from_numpy(G["init.%s.%s" % (k, n)]).cuda() for n in m_.state_dict()})
+    ag.memory.add(torch.zeros((32, 46), device="cuda"), torch.zeros((32, 2), device="cuda"), torch.zeros(32, device="cuda"),
+                  torch.zeros((32, 46), device="cuda"), torch.zeros(32, device="cuda", dtype=torch.bool))
+    ag.enable_graphs()
+    dev = lambda x: torch.from_numpy(x).cuda()
+    batch = (dev(G["upd_s"]), dev(G["upd_a"]), dev(G["upd_r"])[:, None], dev(G["upd_s2"]), dev(G["upd_d"])[:, None])
+    for step in range(4):
+        ag.learn(step, batch=batch, target_noise=dev(G["upd_noise"][step]))
+        for k, m_ in nets.items():
+            for n, v in m_.state_dict().items():
+                np.testing.assert_allclose(v.cpu().numpy(), G["step%d.%s.%s" % (step, k, n)], rtol=5e-4, atol=2e-6, err_msg="step %d %s.%s" % (step, k, n))
 
 
 def test_episode_stats_rows_match_the_reference_run():

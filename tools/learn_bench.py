@@ -1,0 +1,23 @@
+#!/usr/bin/env python
+"""TD3 updates per second: the eager torch path against Agent.enable_graphs (one hipGraph launch per update)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "drl-based-mapless-crowd-navigation-with-perceived-risk_amd"))
+import torch
+from crowdnav.td3 import Agent
+for B in (128, 1024):
+    row = []
+    for graphs in (False, True):
+        ag = Agent(obs_dim=398, device="cuda", seed=0, batch_size=B, memory_size=200000)
+        n = 100000
+        ag.memory.add(torch.randn((n, 398), device="cuda"), torch.rand((n, 2), device="cuda"), torch.randn(n, device="cuda"),
+                      torch.randn((n, 398), device="cuda"), torch.rand(n, device="cuda") < 0.05)
+        if graphs:
+            ag.enable_graphs()
+        for i in range(50): ag.learn(i)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        K = 400
+        for i in range(K): ag.learn(i)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        row.append(dt / K * 1e3)
+    print("batch %5d: eager %.3f ms per update, graphed %.3f ms (%.1fx)" % (B, row[0], row[1], row[0] / row[1]))
