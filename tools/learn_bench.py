@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "drl-based-mapless-crowd-navigation-with-perceived-risk_amd"))
 import torch
 from crowdnav.td3 import Agent
-for B in (128, 1024):
+for B in [int(x) for x in os.environ.get("CN_BATCHES", "128,1024").split(",")]:
     row = []
     for graphs in (False, True):
         ag = Agent(obs_dim=398, device="cuda", seed=0, batch_size=B, memory_size=200000)
