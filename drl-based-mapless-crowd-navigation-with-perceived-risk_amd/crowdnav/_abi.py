@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_PKG, "lib", "libcrowdnav.so")
 BUILD_SH = os.path.join(_PKG, "csrc", "build.sh")
 
 CN_MAX_TRACKS = 64
-EXPECTED_ABI = 4       # the version the ctypes structs below were written against (include/crowdnav.h CN_ABI_VERSION)
+EXPECTED_ABI = 5       # the version the ctypes structs below were written against (include/crowdnav.h CN_ABI_VERSION)
 CN_PHASE_ALL, CN_PHASE_PRE, CN_PHASE_GET_STATE, CN_PHASE_REWARD = 0, 1, 2, 4
 CN_SD_COUNT = 24
 CN_SI_COUNT = 16

@@ -12,7 +12,7 @@ class CnConfig(C.Structure):
         ("max_steps", C.c_int32), ("ped_mode", C.c_int32), ("dt_ms", C.c_int32), ("scan_latency_ms", C.c_int32),
         ("settle_ms", C.c_int32), ("ped_cycle_ms", C.c_int32), ("ped_stagger_ms", C.c_int32), ("track_capacity", C.c_int32),
         ("obs_layout", C.c_int32), ("geos_untyped_empty", C.c_int32), ("ped_contact", C.c_int32), ("risk_mode", C.c_int32),
-        ("py2_round", C.c_int32), ("sf_tick_ms", C.c_int32),
+        ("py2_round", C.c_int32), ("sf_tick_ms", C.c_int32), ("scan_f32", C.c_int32), ("waypoint_reward", C.c_int32),
         ("env_index_base", C.c_int64), ("seed", C.c_uint64),
         ("room_half", C.c_double), ("ped_radius", C.c_double), ("ped_vmax", C.c_double),
         ("robot_clearance", C.c_double), ("lidar_min", C.c_double), ("lidar_max", C.c_double),
@@ -21,7 +21,7 @@ class CnConfig(C.Structure):
         ("start_x", C.c_double), ("start_y", C.c_double), ("spawn_x", C.c_double), ("spawn_y", C.c_double),
         ("spawn_yaw", C.c_double), ("waypoint_radius", C.c_double), ("goal_eps", C.c_double),
         ("sf_tau", C.c_double), ("sf_A", C.c_double), ("sf_B", C.c_double), ("sf_wall_A", C.c_double),
-        ("sf_wall_B", C.c_double), ("sf_goal_eps", C.c_double),
+        ("sf_wall_B", C.c_double), ("sf_goal_eps", C.c_double), ("wheel_accel", C.c_double), ("wheel_separation", C.c_double),
     ]
 
 
@@ -46,6 +46,8 @@ class Config:
     risk_mode: int = 0             # 0: lidar segmentation + tracker (the reference); 1: "gt" -- simulator pedestrians
     py2_round: int = 0             # 1: Python-2.7 round() -- exact ties away from zero, round(np.float64) = the builtin (the reference's platform)
     sf_tick_ms: int = 0            # ped_mode 2: physics tick of the social-force integrator in ms (0 -> 10)
+    scan_f32: int = 0              # 1: simulated ranges rounded to float32 before get_state (LaserScan.ranges is float32[])
+    waypoint_reward: int = 200     # ENV:1116; 0 = the reward the published training log was recorded under (max return 173 < 200)
     env_index_base: int = 0
     seed: int = 1234
     room_half: float = 1.40        # WORLD:926-1108
@@ -73,6 +75,8 @@ class Config:
     sf_wall_A: float = 1.0         # wall repulsion strength, m/s^2
     sf_wall_B: float = 0.05        # ... and range, m
     sf_goal_eps: float = 0.10      # goal reached within this distance -> next goal
+    wheel_accel: float = 0.0       # XACRO:70 wheelAcceleration (m/s^2): 1.0 = the diff-drive plugin's wheel-speed ramp; 0 = kinematic robot
+    wheel_separation: float = 0.160  # XACRO:68
 
     def resolved(self):
         d = asdict(self)

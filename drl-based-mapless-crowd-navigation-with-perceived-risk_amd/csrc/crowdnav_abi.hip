@@ -34,6 +34,10 @@ extern "C" __global__ void cn_env_kernel_rw_ext(CnKParams p);
 extern "C" __global__ void cn_env_kernel_orig(CnKParams p);
 extern "C" __global__ void cn_env_kernel_orig_ext(CnKParams p);
 extern "C" __global__ void cn_env_kernel_orig_same(CnKParams p);
+extern "C" __global__ void cn_env_kernel_wa(CnKParams p);
+extern "C" __global__ void cn_env_kernel_wa_same(CnKParams p);
+extern "C" __global__ void cn_env_kernel_gt_wa(CnKParams p);
+extern "C" __global__ void cn_env_kernel_gt_wa_same(CnKParams p);
 extern "C" __global__ void cn_env_kernel_seq(CnKParams p);
 extern "C" __global__ void cn_env_kernel_gt_seq(CnKParams p);
 extern "C" __global__ void cn_bbox_kernel(CnKParams p, double* out);
@@ -232,8 +236,11 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
         !(c.obs_layout == CN_LAYOUT_RISK || c.obs_layout == CN_LAYOUT_ORIGINAL || c.obs_layout == CN_LAYOUT_REALWORLD) ||
         !(c.geos_untyped_empty == 0 || c.geos_untyped_empty == 1) || !(c.ped_contact == 0 || c.ped_contact == 1) ||
         !(c.risk_mode == CN_RISK_LIDAR_TRACKER || c.risk_mode == CN_RISK_GT) || !(c.py2_round == 0 || c.py2_round == 1) ||
-        c.ped_mode < 0 || c.ped_mode > 2)
+        c.ped_mode < 0 || c.ped_mode > 2 || !(c.scan_f32 == 0 || c.scan_f32 == 1))
         return fail(CN_ERR_CONFIG, "cn_create: config out of range");
+    if (!(c.wheel_accel >= 0.0) || (c.wheel_accel > 0.0 && (c.ped_contact || c.ped_mode == 2 || c.obs_layout != CN_LAYOUT_RISK || !(c.wheel_separation > 0.0))))
+        return fail(CN_ERR_CONFIG, "cn_create: wheel_accel must be >= 0 and needs obs_layout 0, the plain simulator (ped_contact 0, ped_mode 0 / 1) "
+                                   "and a positive wheel_separation");
     if (c.ped_mode == 2 && (c.ped_contact || c.obs_layout != CN_LAYOUT_RISK || !(c.sf_tau > 0.0) || !(c.sf_B > 0.0) ||
                             !(c.sf_wall_B > 0.0) || !(c.sf_goal_eps >= 0.0) || c.sf_tick_ms < 0 || 64 * (size_t)c.n_peds > 16 * (size_t)(c.n_rays - 1)))
         return fail(CN_ERR_CONFIG, "cn_create: ped_mode 2 (social force) needs obs_layout 0, ped_contact 0, positive sf_tau / sf_B / "
@@ -301,6 +308,7 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
     k.max_steps = c.max_steps; k.ped_mode = c.ped_mode; k.dt_ms = c.dt_ms; k.scan_latency_ms = c.scan_latency_ms;
     k.settle_ms = c.settle_ms; k.ped_cycle_ms = c.ped_cycle_ms; k.ped_stagger_ms = c.ped_stagger_ms;
     k.geos_untyped_empty = c.geos_untyped_empty; k.ped_contact = c.ped_contact; k.risk_mode = c.risk_mode; k.py2_round = c.py2_round;
+    k.scan_f32 = c.scan_f32; k.waypoint_reward = c.waypoint_reward; k.wheel_accel = c.wheel_accel; k.wheel_sep = c.wheel_separation;
     k.sf_tau = c.sf_tau; k.sf_A = c.sf_A; k.sf_B = c.sf_B; k.sf_wall_A = c.sf_wall_A; k.sf_wall_B = c.sf_wall_B;
     k.sf_goal_eps2 = c.sf_goal_eps * c.sf_goal_eps; k.sf_tick_ms = c.sf_tick_ms > 0 ? c.sf_tick_ms : 10;
     // pair matrix G [P][P] + next state + goal records in the simulator's LDS scratch (regions A + B, 16 (R - 1) bytes)?
@@ -345,6 +353,12 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
         HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_sf_same, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
         HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_gt_sf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
         HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_gt_sf_same, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
+        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_wa, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
+        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_wa_same, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
+        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_gt_wa, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
+        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_gt_wa_same, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
+        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_seq, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
+        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_gt_seq, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
         HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_gt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
         HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_gt_same, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
         HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_rw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
@@ -437,8 +451,8 @@ static int launch(cn_handle h, const CnKParams& kp, hipStream_t st, bool overlap
     } else {
         // simulated sensors: {lidar tracker, gt} x {no contact, contact} x {one observation per launch, step + same-call reset}
         const bool same = kp.mode == CN_MODE_STEP && kp.auto_reset == 1;
-        const bool gt = h->cfg.risk_mode == CN_RISK_GT, ct = h->cfg.ped_contact != 0, sf = h->cfg.ped_mode == 2;
-        void (*fn)(CnKParams) = gt ? (sf ? (same ? cn_env_kernel_gt_sf_same : cn_env_kernel_gt_sf)
+        const bool gt = h->cfg.risk_mode == CN_RISK_GT, ct = h->cfg.ped_contact != 0, sf = h->cfg.ped_mode == 2, wa = h->cfg.wheel_accel > 0.0;
+        void (*fn)(CnKParams) = wa ? (gt ? (same ? cn_env_kernel_gt_wa_same : cn_env_kernel_gt_wa) : (same ? cn_env_kernel_wa_same : cn_env_kernel_wa)) : gt ? (sf ? (same ? cn_env_kernel_gt_sf_same : cn_env_kernel_gt_sf)
                                          : ct ? (same ? cn_env_kernel_gt_ct_same : cn_env_kernel_gt_ct) : (same ? cn_env_kernel_gt_same : cn_env_kernel_gt))
                                    : (sf ? (same ? cn_env_kernel_sf_same : cn_env_kernel_sf)
                                          : ct ? (same ? cn_env_kernel_ct_same : cn_env_kernel_ct) : (same ? cn_env_kernel_same : cn_env_kernel));
@@ -580,22 +594,19 @@ extern "C" int cn_actor_forward(const cn_actor_weights* w, const float* obs, flo
 extern "C" int cn_step_sequence(cn_handle h, const cn_sequence_io* io, void* stream)
 {
     if (!h || !io || !io->action || !io->obs || !io->reward || !io->done) return fail(CN_ERR_ARG, "cn_step_sequence: null argument");
-    if (h->cfg.obs_layout != CN_LAYOUT_RISK || h->cfg.ped_contact || h->cfg.ped_mode == 2)
-        return fail(CN_ERR_CONFIG, "cn_step_sequence: built for obs_layout 0 with the plain simulator (no contact / social-force ticks)");
+    if (h->cfg.obs_layout != CN_LAYOUT_RISK || h->cfg.ped_contact || h->cfg.ped_mode == 2 || h->cfg.wheel_accel > 0.0)
+        return fail(CN_ERR_CONFIG, "cn_step_sequence: built for obs_layout 0 with the plain simulator (no contact / social-force / wheel-ramp ticks)");
     if (io->n_steps < 0 || io->action_stride < 0 || io->obs_stride < 0 || io->reward_stride < 0 || io->done_stride < 0 || io->topk_stride < 0)
         return fail(CN_ERR_ARG, "cn_step_sequence: negative step count or stride");
     if (io->n_steps == 0) return CN_OK;
     CnKParams kp = h->kp;
     kp.mode = CN_MODE_STEP; kp.auto_reset = 2;
     kp.action = io->action; kp.step_counter = nullptr; kp.final_obs = nullptr; kp.obs_f64 = nullptr;
-    // the step body writes observation slot t + 1 (cn_rollout's convention: slot 0 = the observation before the first step);
-    // here slot t is step t's, so the base moves back by one stride
-    kp.obs = io->obs - io->obs_stride; kp.reward = io->reward; kp.done = io->done; kp.topk_idx = io->topk_idx;
+    kp.obs = io->obs; kp.reward = io->reward; kp.done = io->done; kp.topk_idx = io->topk_idx;
     kp.roll_steps = io->n_steps; kp.roll_action_in_stride = io->action_stride; kp.roll_obs_stride = io->obs_stride;
     kp.roll_reward_stride = io->reward_stride; kp.roll_done_stride = io->done_stride; kp.roll_topk_stride = io->topk_stride;
     DeviceScope scope(h->device);
     void (*fn)(CnKParams) = h->cfg.risk_mode == CN_RISK_GT ? cn_env_kernel_gt_seq : cn_env_kernel_seq;
-    if (h->lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
     hipLaunchKernelGGL(fn, dim3(h->cfg.n_envs), dim3(64), h->lds, (hipStream_t)stream, kp);
     HIPCHK(hipGetLastError());
     return CN_OK;
@@ -699,11 +710,12 @@ static const char* config_mismatch(const cn_config& a, const cn_config& b)
 #define CN_CMP(f) if (memcmp(&a.f, &b.f, sizeof(a.f)) != 0) return #f;
     CN_CMP(n_envs) CN_CMP(n_peds) CN_CMP(n_rays) CN_CMP(k_obstacles) CN_CMP(max_steps) CN_CMP(ped_mode) CN_CMP(dt_ms)
     CN_CMP(scan_latency_ms) CN_CMP(settle_ms) CN_CMP(ped_cycle_ms) CN_CMP(ped_stagger_ms) CN_CMP(track_capacity) CN_CMP(obs_layout)
-    CN_CMP(geos_untyped_empty) CN_CMP(ped_contact) CN_CMP(risk_mode) CN_CMP(py2_round) CN_CMP(sf_tick_ms) CN_CMP(env_index_base) CN_CMP(seed)
+    CN_CMP(geos_untyped_empty) CN_CMP(ped_contact) CN_CMP(risk_mode) CN_CMP(py2_round) CN_CMP(sf_tick_ms) CN_CMP(scan_f32) CN_CMP(waypoint_reward)
+    CN_CMP(env_index_base) CN_CMP(seed)
     CN_CMP(room_half) CN_CMP(ped_radius) CN_CMP(ped_vmax) CN_CMP(robot_clearance) CN_CMP(lidar_min) CN_CMP(lidar_max) CN_CMP(lidar_span)
     CN_CMP(lidar_offset_x) CN_CMP(max_scan_range) CN_CMP(min_scan_range) CN_CMP(goal_x) CN_CMP(goal_y) CN_CMP(start_x) CN_CMP(start_y)
     CN_CMP(spawn_x) CN_CMP(spawn_y) CN_CMP(spawn_yaw) CN_CMP(waypoint_radius) CN_CMP(goal_eps)
-    CN_CMP(sf_tau) CN_CMP(sf_A) CN_CMP(sf_B) CN_CMP(sf_wall_A) CN_CMP(sf_wall_B) CN_CMP(sf_goal_eps)
+    CN_CMP(sf_tau) CN_CMP(sf_A) CN_CMP(sf_B) CN_CMP(sf_wall_A) CN_CMP(sf_wall_B) CN_CMP(sf_goal_eps) CN_CMP(wheel_accel) CN_CMP(wheel_separation)
 #undef CN_CMP
     return nullptr;
 }

@@ -17,6 +17,7 @@ struct CnKParams {
     int32_t ext_phase;       // cn_external_io.phase (CN_PHASE_* mask, 0 = whole flow); CN_MODE_EXT_STEP only
     int32_t geos_untyped_empty, ped_contact, risk_mode, py2_round;   // cn_config switches
     int32_t sf_tick_ms, sf_pair_matrix;   // ped_mode 2: physics tick; 1 = the pair matrix fits in the simulator's LDS scratch
+    int32_t scan_f32, waypoint_reward;    // cn_config: float32 LaserScan.ranges; ENV:1116's way-point reward (200, or 0 = as logged)
     int64_t env_index_base;
     uint64_t seed;
     // constants (cn_config)
@@ -25,6 +26,7 @@ struct CnKParams {
     double waypoint_radius, goal_eps, angle_inc_deg, lidar_step;
     double ped_inv_cycle;    // 1.0 / ped_cycle_ms
     double sf_tau, sf_A, sf_B, sf_wall_A, sf_wall_B, sf_goal_eps2;   // ped_mode 2 (social force): cn_config.sf_*, goal radius squared
+    double wheel_accel, wheel_sep;   // cn_config.wheel_accel (0 = kinematic robot), wheel_separation
     double blk_cb, blk_sb;   // cos / sin of the half-width (32.5 lidar steps) of a 64-ray block (near-pedestrian block bits)
     const double* blk_dir;   // [ceil(R/64)][2] robot-frame direction of ray 64 q + 32 (clamped to R - 1)
     double trig[34];         // constants of cn_det_sincos_t / cn_atan2_t (CN_TRIG_TABLE): scalar loads next to the polynomials

@@ -70,6 +70,7 @@ typedef const __attribute__((address_space(4))) CnKParams* KP;
 struct EnvRegs {  // per-env scalars, uniform across the wave
     double rx, ry, ryaw, rv, rw, clock, wpx, wpy, prev_dist, prev_head;
     double dq0x, dq0y, dq1x, dq1y, ts, bb, ego, cprob, ep_ret, last_ret;
+    double cv, cw;        // SIM 3 (cn_config.wheel_accel): the twist /cmd_vel last carried; (rv, rw) is then the wheels' real twist
     long long crowd_ms;
     int done, dq_len, ntracks, ego_viol, social_viol, obst_steps, succ, fail, ep_step, status, nconf, nent, pending, episodes;
 };
@@ -318,6 +319,30 @@ __device__ __forceinline__ void robot_advance(KP p, EnvRegs& e, int ms)
     e.ryaw = th;
 }
 
+// cn_config.wheel_accel > 0 (SIM 3; XACRO:57-72 libgazebo_ros_diff_drive.so, restated in include/crowdnav.h): plugin ticks of at most
+// 10 ms; the wheel speeds move towards the commanded ones by at most wheel_accel * h per tick -- either wheel within 0.01 m/s of
+// its target releases both -- and the tick's twist moves the robot by the mid-point rule.  Wave-uniform; the same operations in
+// the same order as the oracle's robot_advance_wheels.
+__device__ __forceinline__ void robot_advance_wheels(KP p, EnvRegs& e, int ms)
+{
+    const double a = p->wheel_accel, sep = p->wheel_sep, half = 0.5 * sep;
+    const double tl = e.cv - e.cw * half, tr = e.cv + e.cw * half;
+    double cl = e.rv - e.rw * half, cr = e.rv + e.rw * half;
+    for (int tt = 0; tt < ms; ) {
+        const int h = (ms - tt < 10) ? (ms - tt) : 10;
+        const double ah = a * ((double)h / 1000.0);
+        if (fabs(tl - cl) < 0.01 || fabs(tr - cr) < 0.01) { cl = tl; cr = tr; }
+        else {
+            cl += (tl >= cl) ? fmin(tl - cl, ah) : fmax(tl - cl, -ah);
+            cr += (tr >= cr) ? fmin(tr - cr, ah) : fmax(tr - cr, -ah);
+        }
+        e.rv = (cl + cr) * 0.5;
+        e.rw = (cr - cl) / sep;
+        robot_advance(p, e, h);
+        tt += h;
+    }
+}
+
 // cn_config.ped_contact = 1 (row A2; WORLD:86-145: rigid frictionless cylinders): the world advances in physics ticks of at
 // most 10 ms -- crowd velocity assignments falling inside a tick take effect at its start, the (kinematic) robot moves by the
 // mid-point rule, every pedestrian integrates into the room, then contacts are resolved Jacobi style from that state:
@@ -555,6 +580,12 @@ template <int SIM>
 __device__ __forceinline__ void sim_advance_ticks(KP p, EnvRegs& e, int env, int lane, double* ped_p, double* ped_v, double* scr, int ms)
 {
     if constexpr (SIM == 2) sim_advance_sf(p, e, env, lane, ped_p, ped_v, scr, ms);
+    else if constexpr (SIM == 3) {        // plain pedestrians (they do not see the robot), wheel-ramp robot
+        if (ms <= 0) return;
+        ped_advance(p, env, lane, ped_p, ped_v, e.crowd_ms, e.crowd_ms + ms);
+        e.crowd_ms += ms;
+        robot_advance_wheels(p, e, ms);
+    }
     else sim_advance_contact(p, e, env, lane, ped_p, ped_v, scr, ms);
 }
 
@@ -673,7 +704,10 @@ __device__ __forceinline__ double cast_ray(KP p, const Lds& L, int env, int k, d
         }
         for (int c = 64; c < nnear; ++c)                       // beyond 64 near pedestrians: per-slot bits
             if ((((const u64*)L.nearp)[4 * c + 3] >> q) & 1ull) test(c);
-        return (t > p->lidar_max) ? INFINITY : t;       // the simulated sensor reports no return beyond its range
+        t = (t > p->lidar_max) ? INFINITY : t;          // the simulated sensor reports no return beyond its range
+        // cn_config.scan_f32: sensor_msgs/LaserScan.ranges is float32[] (XACRO:172-175) -- what Gazebo hands ENV:1218
+        if (__builtin_expect(p->scan_f32 != 0, 0)) t = (double)(float)t;
+        return t;
     }
 }
 
@@ -2102,7 +2136,7 @@ __device__ __forceinline__ double compute_reward(KP p, const Poly& pg, EnvRegs& 
     }
     if (in_box(e.rx, e.ry, e.wpx, e.wpy, p->goal_eps)) {  // ENV:1109-1125
         waypoint_refresh(p, pg, e, lane, e.rx, e.ry);
-        wp = 200;
+        wp = p->waypoint_reward;                           // ENV:1116: 200 (cn_config.waypoint_reward; 0 = the published log's reward)
         if (in_box(e.wpx, e.wpy, p->goal_x, p->goal_y, p->goal_eps)) { e.wpx = p->goal_x; e.wpy = p->goal_y; }
     }
     double reward = (double)(-2 + dtg + htg + wp);
@@ -2138,7 +2172,7 @@ __device__ __forceinline__ void env_kernel_body(const int env, const int lane, c
     }
     const int R = p->R, n = R - 1, P = p->P, K = p->K;
     // where this step's outputs go: the caller's buffers, or (FUSED) slot t of its trajectory buffers (stride 0 = in place)
-    auto io_obs = [&]() -> float* { if constexpr (FUSED) return p->obs + (size_t)((t + 1) * p->roll_obs_stride); else return p->obs; };
+    auto io_obs = [&]() -> float* { if constexpr (FUSED) return p->obs + (size_t)(t * p->roll_obs_stride); else return p->obs; };
     auto io_reward = [&]() -> float* { if constexpr (FUSED) return p->reward + (size_t)(t * p->roll_reward_stride); else return p->reward; };
     auto io_done = [&]() -> uint8_t* { if constexpr (FUSED) return p->done + (size_t)(t * p->roll_done_stride); else return p->done; };
     auto io_action = [&]() -> const float* { if constexpr (FUSED) return p->action + (size_t)(t * p->roll_action_in_stride); else return p->action; };
@@ -2217,6 +2251,7 @@ __device__ __forceinline__ void env_kernel_body(const int env, const int lane, c
     e.succ = si[CN_SI_SUCCESS]; e.fail = si[CN_SI_FAILURE]; e.ep_step = si[CN_SI_EP_STEP]; e.status = si[CN_SI_STATUS];
     e.nconf = si[CN_SI_NCONF]; e.nent = si[CN_SI_NENTRIES]; e.pending = si[CN_SI_PENDING_RESET]; e.episodes = si[CN_SI_EPISODES];
     e.crowd_ms = (long long)(((unsigned long long)(unsigned)si[CN_SI_CROWD_HI] << 32) | (unsigned)si[CN_SI_CROWD_LO]);
+    e.cv = 0.0; e.cw = 0.0;       // the command lives inside one call: a step publishes its action first, a reset leaves it zero
 
     // The tracker table is read from HBM in the middle of the observation (its LDS space holds the end points until then),
     // which would put a full memory round trip on the wavefront's critical path.  Touch its lines now -- one dword per
@@ -2266,7 +2301,7 @@ __device__ __forceinline__ void env_kernel_body(const int env, const int lane, c
             if (!ext) {
                 const double v = (double)io_action()[2 * env], w = (double)io_action()[2 * env + 1];
                 const double t0 = e.clock;
-                e.rv = v; e.rw = w;                               // pub_cmd_vel.publish (ENV:1200)
+                if constexpr (SIM == 3) { e.cv = v; e.cw = w; } else { e.rv = v; e.rw = w; }   // pub_cmd_vel.publish (ENV:1200)
                 e.clock += cn_div1000((double)p->dt_ms);              // time.sleep(0.15) (ENV:1201)
                 if constexpr (SIM != 0) sim_advance_ticks<SIM>(p, e, env, lane, L.ped, pedv, (double*)smem, p->dt_ms);
                 else {
@@ -2301,7 +2336,7 @@ __device__ __forceinline__ void env_kernel_body(const int env, const int lane, c
         } else {
             // Env.reset (ENV:1227-1263): gazebo/reset_simulation puts poses back and zeroes twists (the crowd clock keeps running)
             if (!ext) {
-                e.rx = p->spawn_x; e.ry = p->spawn_y; e.ryaw = p->spawn_yaw; e.rv = 0.0; e.rw = 0.0;
+                e.rx = p->spawn_x; e.ry = p->spawn_y; e.ryaw = p->spawn_yaw; e.rv = 0.0; e.rw = 0.0; e.cv = 0.0; e.cw = 0.0;
                 for (int i = lane; i < 2 * P; i += 64) { L.ped[i] = gped_init[i]; pedv[i] = 0.0; }
                 CN_SYNC();
                 e.clock += cn_div1000((double)p->scan_latency_ms);    // wait_for_message('scan') (ENV:1238)
@@ -2351,7 +2386,7 @@ __device__ __forceinline__ void env_kernel_body(const int env, const int lane, c
             }
             if (ph_obs && io_topk() && lane < K) io_topk()[(size_t)env * K + lane] = LAYOUT != 0 ? -1 : L.kidx[lane];
             if (done) {
-                if (!ext) { e.rv = 0.0; e.rw = 0.0; }             // pub_cmd_vel.publish(Twist()) (ENV:1160)
+                if (!ext) { if constexpr (SIM == 3) { e.cv = 0.0; e.cw = 0.0; } else { e.rv = 0.0; e.rw = 0.0; } }   // pub_cmd_vel.publish(Twist()) (ENV:1160)
                 e.last_ret = e.ep_ret;
                 e.episodes += 1;
                 e.pending = !ext && (p->auto_reset == 2);
@@ -2390,7 +2425,7 @@ __device__ __forceinline__ void env_kernel_body(const int env, const int lane, c
         if (!ext) {
             const double v = (double)io_action()[2 * env], w = (double)io_action()[2 * env + 1];
             const double t0 = e.clock;
-            e.rv = v; e.rw = w;                               // pub_cmd_vel.publish (ENV:1200)
+            if constexpr (SIM == 3) { e.cv = v; e.cw = w; } else { e.rv = v; e.rw = w; }   // pub_cmd_vel.publish (ENV:1200)
             e.clock += cn_div1000((double)p->dt_ms);              // time.sleep(0.15) (ENV:1201)
             if constexpr (SIM != 0) sim_advance_ticks<SIM>(p, e, env, lane, L.ped, pedv, (double*)smem, p->dt_ms);
             else {
@@ -2436,7 +2471,7 @@ __device__ __forceinline__ void env_kernel_body(const int env, const int lane, c
         }
         if (io_topk() && lane < K) io_topk()[(size_t)env * K + lane] = LAYOUT != 0 ? -1 : L.kidx[lane];
         if (done) {
-            if (!ext) { e.rv = 0.0; e.rw = 0.0; }             // pub_cmd_vel.publish(Twist()) (ENV:1160)
+            if (!ext) { if constexpr (SIM == 3) { e.cv = 0.0; e.cw = 0.0; } else { e.rv = 0.0; e.rw = 0.0; } }   // pub_cmd_vel.publish(Twist()) (ENV:1160)
             e.last_ret = e.ep_ret;
             e.episodes += 1;
             need_reset = !ext && (p->auto_reset == 1);
@@ -2453,7 +2488,7 @@ __device__ __forceinline__ void env_kernel_body(const int env, const int lane, c
         // ---- Env.reset (ENV:1227-1263) + TRAIN:114-116 -----------------------------------------------
         // gazebo/reset_simulation: poses back to their initial values, twists zeroed (crowd clock keeps running)
         if (!ext) {
-        e.rx = p->spawn_x; e.ry = p->spawn_y; e.ryaw = p->spawn_yaw; e.rv = 0.0; e.rw = 0.0;
+        e.rx = p->spawn_x; e.ry = p->spawn_y; e.ryaw = p->spawn_yaw; e.rv = 0.0; e.rw = 0.0; e.cv = 0.0; e.cw = 0.0;
         for (int i = lane; i < 2 * P; i += 64) { L.ped[i] = gped_init[i]; pedv[i] = 0.0; }
         CN_SYNC();
         e.clock += cn_div1000((double)p->scan_latency_ms);        // wait_for_message('scan') (ENV:1238)
@@ -2560,6 +2595,11 @@ extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_sf(CnKParams p) {
 extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_sf_same(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, true, 0, false, 2>(blockIdx.x, threadIdx.x, cn_smem); }
 extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_gt_sf(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, false, 0, true, 2>(blockIdx.x, threadIdx.x, cn_smem); }
 extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_gt_sf_same(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, true, 0, true, 2>(blockIdx.x, threadIdx.x, cn_smem); }
+// wheel_accel > 0: the diff-drive plugin's wheel-speed ramp (10 ms plugin ticks for the robot), for both risk modes
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_wa(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, false, 0, false, 3>(blockIdx.x, threadIdx.x, cn_smem); }
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_wa_same(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, true, 0, false, 3>(blockIdx.x, threadIdx.x, cn_smem); }
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_gt_wa(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, false, 0, true, 3>(blockIdx.x, threadIdx.x, cn_smem); }
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_gt_wa_same(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, true, 0, true, 3>(blockIdx.x, threadIdx.x, cn_smem); }
 // obs_layout 2 (environment_stage_1_nobonus_realworld.py): the 370-input physical-robot variant
 extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_rw(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, false, 2>(blockIdx.x, threadIdx.x, cn_smem); }
 extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_rw_same(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, true, 2>(blockIdx.x, threadIdx.x, cn_smem); }

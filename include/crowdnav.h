@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CN_ABI_VERSION 4
+#define CN_ABI_VERSION 5
 #define CN_MAX_TRACKS 64      /* largest per-env capacity of the obstacle tracker (ENV:656-743): one lane per track */
 #define CN_MAX_K 16
 
@@ -90,6 +90,16 @@ typedef struct cn_config {
     int32_t sf_tick_ms;      /* ped_mode 2: physics tick of the social-force integrator, ms; 0 -> 10 (the contact model's tick).  The model is
                               * an explicit scheme, so the tick is part of its definition: 10 ms resolves a 0.2 m/s crowd to 2 mm per tick,
                               * 50 ms (the usual choice for social-force crowds, tau = 0.5 s) costs a fifth */
+    int32_t scan_f32;        /* 0: the simulated lidar hands Env.get_state float64 ranges (rounds 1-3);
+                              * 1: every range is rounded to float32 first -- what sensor_msgs/LaserScan.ranges (float32[]) carries from
+                              *    gazebo_ros_laser (XACRO:172-175) to ENV:1218's wait_for_message.  Simulator side only: the reference code
+                              *    behind it is unchanged, but its exact-equality tests (`round(scan, 3) == 0.6`, ENV:324-346) then see
+                              *    float32-representable inputs.  Externally supplied scans (cn_observe_external) are taken as they are */
+    int32_t waypoint_reward; /* ENV:1116 `waypoint_reward = 200` -> 200.  The published training log (results/td3/revamped/
+                              * new_tracking_cp_gcp_nobonus_corrected_3/td3_training.csv, 3021 episodes) never contains it -- its largest
+                              * episode return is 173 < 200 -- while the committed reward pays it whenever the robot comes within
+                              * goal_eps of a way-point 0.3 m ahead, i.e. on most steps of a diagonal run:
+                              * 0 reproduces the reward the log was recorded under ("nobonus") */
     int64_t env_index_base;  /* global index of env 0: RNG streams are keyed by global index */
     uint64_t seed;
     double room_half;        /* WORLD:926-1108 -> 1.40 */
@@ -119,6 +129,19 @@ typedef struct cn_config {
     double sf_wall_A;        /* wall repulsion strength, m/s^2 -> 1.0 */
     double sf_wall_B;        /* ... and range, m -> 0.05 */
     double sf_goal_eps;      /* a goal counts as reached within this distance -> 0.10 */
+    /* Wheel dynamics of the diff-drive plugin (XACRO:57-72: libgazebo_ros_diff_drive.so, updateRate 100, wheelSeparation 0.160,
+     * wheelAcceleration 1, wheelTorque 10).  wheel_accel = 0: kinematic robot, the commanded twist is the twist (rounds 1-3).
+     * wheel_accel > 0 (XACRO:70 -> 1.0 m/s^2): the plugin's wheel-speed ramp, restated from gazebo_ros_pkgs'
+     * gazebo_ros_diff_drive.cpp (UpdateChild / getWheelVelocities / UpdateOdometryEncoder; third-party, not vendored by the
+     * reference, so this is its published algorithm and not a pinned parity): on plugin ticks of 10 ms
+     *   target wheel speeds  tl = v_cmd - w_cmd * sep / 2,  tr = v_cmd + w_cmd * sep / 2
+     *   if |tl - cl| < 0.01 or |tr - cr| < 0.01:  cl = tl, cr = tr          (either wheel within tolerance releases both)
+     *   else  cl += clamp(tl - cl, -a h, +a h),  cr += clamp(tr - cr, -a h, +a h)
+     *   the tick's twist v = (cl + cr) / 2, w = (cr - cl) / sep moves the robot by the mid-point rule; /odom reports that twist.
+     * A commanded 0 <-> 0.22 m/s then takes 0.22 s (1.5 control periods), a full turn command w = 2 rad/s 0.16 s.
+     * Requires obs_layout 0 and the plain simulator (ped_contact 0, ped_mode 0 / 1); cn_step_sequence refuses it. */
+    double wheel_accel;      /* m/s^2 at the wheel rim; 0 = off */
+    double wheel_separation; /* XACRO:68 -> 0.160 */
 } cn_config;
 
 typedef struct cn_env_s* cn_handle;

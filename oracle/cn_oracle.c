@@ -50,6 +50,7 @@ typedef struct {
 typedef struct {
     /* simulator (no reference source; DESIGN.md "physics") */
     double rx, ry, ryaw, rv, rw;
+    double cmd_v, cmd_w;   /* wheel_accel > 0: the twist /cmd_vel last carried ((rv, rw) is then the wheels' real twist) */
     double* ped_p;
     double* ped_v;
     double* ped_init;
@@ -258,6 +259,31 @@ static void robot_advance(const cno_sim* s, env_t* e, int64_t ms)
     if (th > M_PI) th -= 2.0 * M_PI;
     else if (th <= -M_PI) th += 2.0 * M_PI;
     e->ryaw = th;
+}
+
+/* cn_config.wheel_accel > 0 (XACRO:57-72): the wheel-speed ramp of libgazebo_ros_diff_drive.so, as include/crowdnav.h states it
+ * (third-party plugin, restated from its published source: UpdateChild's branch on wheel_accel).  The command (cmd_v, cmd_w) is
+ * what /cmd_vel last carried; (rv, rw) is the twist the wheels really have -- what /odom reports (ENV:239-243).  Plugin ticks of
+ * at most 10 ms (updateRate 100); the tick's new wheel speeds move the robot over that tick by the mid-point rule. */
+static void robot_advance_wheels(const cno_sim* s, env_t* e, int64_t ms)
+{
+    const cno_config* c = &s->cfg;
+    const double a = c->wheel_accel, half = 0.5 * c->wheel_separation;
+    const double tl = e->cmd_v - e->cmd_w * half, tr = e->cmd_v + e->cmd_w * half;
+    double cl = e->rv - e->rw * half, cr = e->rv + e->rw * half;
+    for (int64_t tt = 0; tt < ms; ) {
+        const int64_t h = (ms - tt < 10) ? (ms - tt) : 10;
+        const double ah = a * ((double)h / 1000.0);
+        if (fabs(tl - cl) < 0.01 || fabs(tr - cr) < 0.01) { cl = tl; cr = tr; }
+        else {
+            cl += (tl >= cl) ? fmin(tl - cl, ah) : fmax(tl - cl, -ah);
+            cr += (tr >= cr) ? fmin(tr - cr, ah) : fmax(tr - cr, -ah);
+        }
+        e->rv = (cl + cr) * 0.5;
+        e->rw = (cr - cl) / c->wheel_separation;
+        robot_advance(s, e, h);
+        tt += h;
+    }
 }
 
 /* cn_config.ped_contact = 1 (row A2; WORLD:86-145: rigid mu = 0 cylinders, r = 0.0505, 1 kg): the world advances in physics
@@ -480,7 +506,8 @@ static void sim_advance(const cno_sim* s, env_t* e, int64_t gid, int64_t ms)
     if (s->cfg.ped_contact) { sim_advance_contact(s, e, gid, ms); return; }
     ped_advance(s, e, gid, e->crowd_ms, e->crowd_ms + ms);
     e->crowd_ms += ms;
-    robot_advance(s, e, ms);
+    if (s->cfg.wheel_accel > 0.0) robot_advance_wheels(s, e, ms);
+    else robot_advance(s, e, ms);
 }
 
 /* gazebo/reset_simulation (ENV:1228-1231): poses back to their initial values, twists zeroed.
@@ -489,7 +516,7 @@ static void sim_reset(const cno_sim* s, env_t* e)
 {
     const cno_config* c = &s->cfg;
     e->rx = c->spawn_x; e->ry = c->spawn_y; e->ryaw = c->spawn_yaw;
-    e->rv = 0.0; e->rw = 0.0;
+    e->rv = 0.0; e->rw = 0.0; e->cmd_v = 0.0; e->cmd_w = 0.0;
     memcpy(e->ped_p, e->ped_init, sizeof(double) * 2 * c->n_peds);
     memset(e->ped_v, 0, sizeof(double) * 2 * c->n_peds);
 }
@@ -525,6 +552,7 @@ static void raycast_impl(const cno_config* c, const double* lc, const double* ls
             }
         }
         ranges[k] = (t > c->lidar_max) ? INFINITY : t;
+        if (c->scan_f32) ranges[k] = (double)(float)ranges[k];    /* sensor_msgs/LaserScan.ranges is float32[] (XACRO:172-175) */
     }
 }
 
@@ -1231,7 +1259,7 @@ static double env_compute_reward(const cno_sim* s, env_t* e, const double* state
     }
     if (in_box(px, py, e->wpx, e->wpy, c->goal_eps)) { /* ENV:1109-1125 */
         waypoint_refresh(s, e, px, py);
-        wp = 200;
+        wp = c->waypoint_reward;                                   /* ENV:1116: 200 */
         if (in_box(e->wpx, e->wpy, c->goal_x, c->goal_y, c->goal_eps)) { e->wpx = c->goal_x; e->wpy = c->goal_y; }
     }
     double reward = (double)(step_reward + dtg + htg + wp);
@@ -1641,7 +1669,8 @@ static void env_step_flow(const cno_sim* s, env_t* e, int64_t gid, double v, dou
 {
     const cno_config* c = &s->cfg;
     double t0 = e->clock;
-    e->rv = v; e->rw = w;                                          /* pub_cmd_vel.publish (ENV:1200) */
+    if (c->wheel_accel > 0.0) { e->cmd_v = v; e->cmd_w = w; }     /* pub_cmd_vel.publish (ENV:1200): the wheels ramp towards it */
+    else { e->rv = v; e->rw = w; }                                 /* kinematic robot: the command is the twist */
     e->clock += (double)c->dt_ms / 1000.0;                         /* time.sleep(0.15) (ENV:1201) */
     sim_advance(s, e, gid, c->dt_ms);
     double end_timestep = e->clock - t0;                           /* ENV:1202 */
@@ -1670,7 +1699,9 @@ static void env_step_flow(const cno_sim* s, env_t* e, int64_t gid, double v, dou
     env_get_state(s, e, e->ranges, e->rx, e->ry, e->ryaw, e->rv, e->rw, step_counter, e->clock, obs, done, topk_idx);
     *reward = env_compute_reward(s, e, obs, e->rx, e->ry, *done);
     }
-    if (*done) { e->rv = 0.0; e->rw = 0.0; }                      /* pub_cmd_vel.publish(Twist()) (ENV:1160) */
+    if (*done) {                                                   /* pub_cmd_vel.publish(Twist()) (ENV:1160) */
+        if (c->wheel_accel > 0.0) { e->cmd_v = 0.0; e->cmd_w = 0.0; } else { e->rv = 0.0; e->rw = 0.0; }
+    }
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -1702,6 +1733,9 @@ int cno_create(const cno_config* cfg, cno_sim** out)
     if (cfg->ped_cycle_ms < 1 || cfg->dt_ms < 1) return -2;
     if (cfg->ped_mode < 0 || cfg->ped_mode > 2) return -2;
     if (cfg->ped_mode == 2 && (cfg->ped_contact || !(cfg->sf_tau > 0.0) || !(cfg->sf_B > 0.0) || !(cfg->sf_wall_B > 0.0) || cfg->sf_tick_ms < 0)) return -2;
+    if (!(cfg->wheel_accel >= 0.0) || (cfg->wheel_accel > 0.0 && (cfg->ped_contact || cfg->ped_mode == 2 || cfg->obs_layout != 0 ||
+                                                                    !(cfg->wheel_separation > 0.0)))) return -2;
+    if (cfg->scan_f32 < 0 || cfg->scan_f32 > 1) return -2;
     cno_sim* s = (cno_sim*)calloc(1, sizeof(cno_sim));
     s->cfg = *cfg;
     s->n = cfg->n_rays - 1;
@@ -1970,7 +2004,7 @@ int cno_hsim_reset(cno_sim* s, int env) { sim_reset(s, &s->envs[env]); return 0;
 int cno_hsim_advance(cno_sim* s, int env, int32_t ms, double v, double w)
 {
     env_t* e = &s->envs[env];
-    e->rv = v; e->rw = w;
+    if (s->cfg.wheel_accel > 0.0) { e->cmd_v = v; e->cmd_w = w; } else { e->rv = v; e->rw = w; }
     sim_advance(s, e, s->cfg.env_index_base + env, ms);
     return 0;
 }

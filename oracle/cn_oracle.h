@@ -44,6 +44,8 @@ typedef struct cno_config {
     int32_t risk_mode;       /* 0: lidar tracker (reference); 1: gt (simulator pedestrians feed A21-A24) */
     int32_t py2_round;       /* 1: Python-2.7 round(): exact ties away from zero, round(np.float64, n) = the builtin (include/crowdnav.h) */
     int32_t sf_tick_ms;      /* ped_mode 2: physics tick in ms (0 -> 10) */
+    int32_t scan_f32;        /* 1: simulated ranges rounded to float32 before get_state (sensor_msgs/LaserScan.ranges is float32[]) */
+    int32_t waypoint_reward; /* ENV:1116 -> 200; 0 = the reward the published log was recorded under (include/crowdnav.h) */
     int64_t env_index_base;  /* global index of env 0 (multi-GPU sharding) */
     uint64_t seed;
     double room_half;        /* inner half extent of the square room (WORLD:926-1108 -> 1.40) */
@@ -63,6 +65,8 @@ typedef struct cno_config {
     double goal_eps;         /* 0.20 (ENV:1285,1303) */
     /* ped_mode 2: social-force pedestrians (defined in include/crowdnav.h; no reference source) */
     double sf_tau, sf_A, sf_B, sf_wall_A, sf_wall_B, sf_goal_eps;
+    double wheel_accel;      /* XACRO:70 wheelAcceleration, m/s^2; 0 = kinematic robot (include/crowdnav.h states the model) */
+    double wheel_separation; /* XACRO:68 -> 0.160 */
 } cno_config;
 
 typedef struct cno_sim cno_sim;

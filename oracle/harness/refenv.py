@@ -319,8 +319,12 @@ class Harness(object):
         od.pose.pose.position = Point(float(robot[0]), float(robot[1]), 0.0)
         yaw = float(robot[2])
         od.pose.pose.orientation = Quaternion(0.0, 0.0, math.sin(yaw / 2.0), math.cos(yaw / 2.0))
-        od.twist.twist.linear = Vector3(self.cmd[0], 0.0, 0.0)
-        od.twist.twist.angular = Vector3(0.0, 0.0, self.cmd[1])
+        if getattr(self.sim.cfg, "wheel_accel", 0.0) > 0.0:   # /odom reports the twist the wheels have, not the command (cn_config.wheel_accel)
+            od.twist.twist.linear = Vector3(float(robot[3]), 0.0, 0.0)
+            od.twist.twist.angular = Vector3(0.0, 0.0, float(robot[4]))
+        else:
+            od.twist.twist.linear = Vector3(self.cmd[0], 0.0, 0.0)
+            od.twist.twist.angular = Vector3(0.0, 0.0, self.cmd[1])
         if self.odom_cb is not None:
             self.odom_cb(od)
 

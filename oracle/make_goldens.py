@@ -33,6 +33,9 @@ SEQ_CONFIGS = {
     # the reference under GEOS <= 3.8 empty-result semantics (cn_config.geos_untyped_empty; shapely_shim.UNTYPED_EMPTY):
     # get_collision_point gives up at the first candidate segment that misses (UTL:279-289)
     "geos38": (dict(n_peds=60, max_steps=120, seed=15, geos_untyped_empty=1), 3, (0.0, 0.22, -2.0, 2.0)),
+    # the reference fed by the simulator's "as Gazebo delivers it" switches: float32 LaserScan.ranges (cn_config.scan_f32) and the
+    # diff-drive plugin's wheel-speed ramp (cn_config.wheel_accel; /odom then reports the wheels' twist, not the command)
+    "gazebo20": (dict(n_peds=20, max_steps=150, seed=17, scan_f32=1, wheel_accel=1.0), 4, (0.0, 0.22, -2.0, 2.0)),
 }
 # the reference under Python-2.7 round() (cn_config.py2_round; harness refenv.py2_round), fed by TieSim: sensor data on exact ties
 TIE_CONFIGS = {

@@ -20,7 +20,7 @@ class CnoConfig(C.Structure):
         ("max_steps", C.c_int32), ("ped_mode", C.c_int32), ("dt_ms", C.c_int32), ("scan_latency_ms", C.c_int32),
         ("settle_ms", C.c_int32), ("ped_cycle_ms", C.c_int32), ("ped_stagger_ms", C.c_int32), ("reserved0", C.c_int32),
         ("obs_layout", C.c_int32), ("geos_untyped_empty", C.c_int32), ("ped_contact", C.c_int32), ("risk_mode", C.c_int32),
-        ("py2_round", C.c_int32), ("sf_tick_ms", C.c_int32),
+        ("py2_round", C.c_int32), ("sf_tick_ms", C.c_int32), ("scan_f32", C.c_int32), ("waypoint_reward", C.c_int32),
         ("env_index_base", C.c_int64), ("seed", C.c_uint64),
         ("room_half", C.c_double), ("ped_radius", C.c_double), ("ped_vmax", C.c_double),
         ("robot_clearance", C.c_double), ("lidar_min", C.c_double), ("lidar_max", C.c_double),
@@ -29,7 +29,7 @@ class CnoConfig(C.Structure):
         ("start_x", C.c_double), ("start_y", C.c_double), ("spawn_x", C.c_double), ("spawn_y", C.c_double),
         ("spawn_yaw", C.c_double), ("waypoint_radius", C.c_double), ("goal_eps", C.c_double),
         ("sf_tau", C.c_double), ("sf_A", C.c_double), ("sf_B", C.c_double), ("sf_wall_A", C.c_double),
-        ("sf_wall_B", C.c_double), ("sf_goal_eps", C.c_double),
+        ("sf_wall_B", C.c_double), ("sf_goal_eps", C.c_double), ("wheel_accel", C.c_double), ("wheel_separation", C.c_double),
     ]
 
 
@@ -56,11 +56,11 @@ class CnoDebug(C.Structure):
 # Reference defaults (SURVEY.md appendix B cites every value).
 DEFAULTS = dict(
     n_envs=1, n_peds=20, n_rays=360, k_obstacles=8, max_steps=1000, ped_mode=0, dt_ms=150, scan_latency_ms=10,
-    settle_ms=100, ped_cycle_ms=0, ped_stagger_ms=100, reserved0=0, obs_layout=0, geos_untyped_empty=0, ped_contact=0, risk_mode=0, py2_round=0, sf_tick_ms=0, env_index_base=0, seed=1234,
+    settle_ms=100, ped_cycle_ms=0, ped_stagger_ms=100, reserved0=0, obs_layout=0, geos_untyped_empty=0, ped_contact=0, risk_mode=0, py2_round=0, sf_tick_ms=0, scan_f32=0, waypoint_reward=200, env_index_base=0, seed=1234,
     room_half=1.40, ped_radius=0.0505, ped_vmax=0.2, robot_clearance=0.09, lidar_min=0.08, lidar_max=0.60,
     lidar_span=6.28, lidar_offset_x=-0.032, max_scan_range=0.6, min_scan_range=0.12, goal_x=-1.0, goal_y=1.0,
     start_x=0.75, start_y=-0.75, spawn_x=1.0, spawn_y=-1.0, spawn_yaw=3.14, waypoint_radius=0.3, goal_eps=0.20,
-    sf_tau=0.5, sf_A=0.8, sf_B=0.10, sf_wall_A=1.0, sf_wall_B=0.05, sf_goal_eps=0.10,
+    sf_tau=0.5, sf_A=0.8, sf_B=0.10, sf_wall_A=1.0, sf_wall_B=0.05, sf_goal_eps=0.10, wheel_accel=0.0, wheel_separation=0.160,
 )
 
 

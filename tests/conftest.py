@@ -27,7 +27,7 @@ def load_seq(name):
     import numpy as np
     z = np.load(os.path.join(GOLDEN, "seq_%s.npz" % name))
     kw = {str(k): float(v) for k, v in zip(z["config_keys"], z["config_vals"])}
-    for k in ("n_peds", "max_steps", "seed", "k_obstacles", "obs_layout", "geos_untyped_empty", "ped_contact", "risk_mode", "dt_ms", "py2_round", "ped_mode"):
+    for k in ("n_peds", "max_steps", "seed", "k_obstacles", "obs_layout", "geos_untyped_empty", "ped_contact", "risk_mode", "dt_ms", "py2_round", "ped_mode", "scan_f32", "waypoint_reward"):
         if k in kw:
             kw[k] = int(kw[k])
     return z, kw

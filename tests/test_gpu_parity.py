@@ -114,6 +114,47 @@ def test_arbitration_switch_rule_and_identical_results():
     assert bytes(big.snapshot()[_abi.C.sizeof(_abi.CnSnapshotHeader):]) == bytes(other.snapshot()[_abi.C.sizeof(_abi.CnSnapshotHeader):])
 
 
+@pytest.mark.parametrize("mode", [True, "next"])
+@pytest.mark.parametrize("risk", [0, 1])
+def test_rollout_parity_as_gazebo_delivers_it(oracle_mod, mode, risk):
+    """The three round-4 switches together (include/crowdnav.h): float32 LaserScan.ranges (scan_f32), the diff-drive plugin's
+    wheel-speed ramp (wheel_accel = XACRO:70's 1 m/s^2: cn_env_kernel_wa*, the robot on 10 ms plugin ticks, /odom = the wheels'
+    twist) and the reward without ENV:1116's way-point bonus (waypoint_reward = 0, the published log's reward).  GPU = oracle
+    bit for bit, both reset conventions, both risk modes; the robot's pose AND twist equal the oracle's."""
+    n_done, frac = _compare_rollout(oracle_mod, steps=120, seed=23 + risk, reset_mode=mode, n_envs=48, n_peds=20, max_steps=45,
+                                    scan_f32=1, wheel_accel=1.0, waypoint_reward=0, risk_mode=risk)
+    assert n_done > 20 and frac > 0.999
+
+
+def test_each_round4_switch_changes_the_run_and_defaults_do_not():
+    """scan_f32 / wheel_accel / waypoint_reward are off by default (the kernels rounds 1-3 measured); each one alone changes what a
+    seeded run returns: float32 ranges move observation values in the 8th digit, the wheel ramp moves the robot, and without the
+    way-point bonus no step is rewarded with more than 0 before the goal."""
+    import torch
+    from crowdnav import Config
+    from crowdnav.env import VecEnv
+    g = torch.Generator(device="cpu").manual_seed(3)
+    acts = [torch.stack([torch.rand(64, generator=g) * 0.22, torch.rand(64, generator=g) * 4 - 2], 1).cuda() for _ in range(60)]
+
+    def run(**kw):
+        env = VecEnv(Config(n_envs=64, n_peds=20, seed=31, max_steps=200, **kw)); env.enable_f64_obs(); env.reset()
+        obs, rew = [], []
+        for a in acts:
+            env.step(a, auto_reset="next"); obs.append(env.obs_f64.clone()); rew.append(env.reward.clone())
+        env.close()
+        return torch.stack(obs), torch.stack(rew)
+    o0, r0 = run()
+    o1, r1 = run(scan_f32=0, wheel_accel=0.0, waypoint_reward=200)
+    assert torch.equal(o0, o1) and torch.equal(r0, r1)
+    of, rf = run(scan_f32=1)
+    assert not torch.equal(of, o0) and float((of[0, :, :359] - o0[0, :, :359]).abs().max()) < 1e-3
+    ow, rw_ = run(wheel_accel=1.0)
+    assert not torch.equal(ow[5, :, 361:363], o0[5, :, 361:363])                   # the pose features differ once the robot lags
+    on, rn = run(waypoint_reward=0)
+    assert bool(((r0 >= 196.0) & (r0 <= 200.0)).any())            # -2 + dtg + htg + 200 on a non-terminal step ...
+    assert float(rn[rn < 100.0].max()) <= 0.0                      # ... never without the bonus (terminal success: 200 + ...)
+
+
 def test_rollout_parity_dense_crowd(oracle_mod):
     # 100 pedestrians in the small room: > K tracks on most steps ("keep the K lowest", ENV:882-883)
     n_done, frac = _compare_rollout(oracle_mod, steps=60, seed=5, n_envs=32, n_peds=100, max_steps=40)
@@ -301,7 +342,7 @@ def test_rollout_parity_720_rays(oracle_mod):
     _compare_rollout(oracle_mod, steps=30, seed=11, n_envs=8, n_peds=100, n_rays=720, room_half=2.4, max_steps=25)
 
 
-@pytest.mark.parametrize("name", ["train20", "dense100", "eval60", "k4", "geos38"])
+@pytest.mark.parametrize("name", ["train20", "dense100", "eval60", "k4", "geos38", "gazebo20"])
 def test_reproduces_reference_golden_run(name):
     """N=1, driven only by the recorded actions: the HIP path reproduces what the REFERENCE's Python
     returned in the golden run (observations, rewards, done flags)."""
@@ -660,7 +701,7 @@ def test_reference_scenarios_presets(oracle_mod):
     assert open(path).readline().strip().split(",") == st.HEADERS
 
 
-@pytest.mark.parametrize("name", ["train20", "dense100", "eval60", "k4", "geos38", "py2tie"])
+@pytest.mark.parametrize("name", ["train20", "dense100", "eval60", "k4", "geos38", "py2tie", "gazebo20"])
 def test_golden_replay_through_the_kernel(name):
     """The kernel fed with EXACTLY what Gazebo/ROS handed the reference in the golden runs (lidar ranges, odom,
     clock, step counter; cn_observe_external) returns what the REFERENCE's own Python returned: observations,

@@ -24,13 +24,13 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(L, s), "libcrowdnav.so does not export %s" % s
     assert set(syms) == set(crowdnav._abi.EXPORTS)
-    assert L.cn_abi_version() == crowdnav._abi.EXPECTED_ABI == 4
+    assert L.cn_abi_version() == crowdnav._abi.EXPECTED_ABI == 5
 
 
 def test_config_struct_matches_header_and_oracle():
     from crowdnav.config import CnConfig, Config
     from oracle import oracle
-    assert C.sizeof(CnConfig) == C.sizeof(oracle.CnoConfig) == 18 * 4 + 8 + 8 + 25 * 8
+    assert C.sizeof(CnConfig) == C.sizeof(oracle.CnoConfig) == 20 * 4 + 8 + 8 + 27 * 8
     from crowdnav._abi import CnSnapshotHeader
     assert C.sizeof(CnSnapshotHeader) == 8 + 6 * 4 + 8 + C.sizeof(CnConfig)      # cn_snapshot_header (include/crowdnav.h)
     assert [f[0].replace("track_capacity", "reserved0") for f in CnConfig._fields_] == [f[0] for f in oracle.CnoConfig._fields_]
@@ -70,7 +70,9 @@ def test_cn_create_rejects_configs_the_reference_cannot_run():
                      (dict(n_rays=4), b"out of range"), (dict(k_obstacles=0), b"out of range"),
                      (dict(risk_mode=1, obs_layout=1), b"risk_mode gt"), (dict(py2_round=3), b"out of range"),
                      (dict(ped_mode=2, sf_B=0.0), b"social force"), (dict(ped_mode=2, obs_layout=1), b"social force"),
-                     (dict(ped_mode=2, n_peds=100, n_rays=360), b"social force")):
+                     (dict(ped_mode=2, n_peds=100, n_rays=360), b"social force"), (dict(scan_f32=2), b"out of range"),
+                     (dict(wheel_accel=-1.0), b"wheel_accel"), (dict(wheel_accel=1.0, ped_contact=1), b"wheel_accel"),
+                     (dict(wheel_accel=1.0, obs_layout=1), b"wheel_accel"), (dict(wheel_accel=1.0, wheel_separation=0.0), b"wheel_accel")):
         h = C.c_void_p()
         cfg = Config(**bad).to_c()
         rc = L.cn_create(C.byref(cfg), 0, C.byref(h))

@@ -6,7 +6,8 @@ import pytest
 
 from conftest import load_seq
 
-SEQS = ["train20", "dense100", "eval60", "k4", "geos38"]   # geos38: the reference under GEOS <= 3.8 empty-result semantics
+SEQS = ["train20", "dense100", "eval60", "k4", "geos38",  # geos38: the reference under GEOS <= 3.8 empty-result semantics
+        "gazebo20"]   # float32 LaserScan.ranges + the diff-drive plugin's wheel-speed ramp (cn_config.scan_f32, wheel_accel)
 # py2tie: the reference under Python-2.7 round() (cn_config.py2_round), its sensor data placed on exact decimal ties by
 # oracle/make_goldens.py's TieSim -- replay only (the poses it was fed are not the simulator's)
 REPLAY_SEQS = SEQS + ["py2tie"]

@@ -358,3 +358,87 @@ def test_social_force_crowd_keeps_moving_and_mostly_apart(oracle_mod):
         assert (np.hypot(pv[:, 0], pv[:, 1]) <= 1.3 * v0 + 1e-12).all()
         assert o.get_state(e)["ped_aux"][:, 2].sum() >= 20        # on average every pedestrian reached a goal
     assert overlap < 0.02 * 375 * 4 * 190 and deep == 0
+
+
+# ---- cn_config.wheel_accel: the diff-drive plugin's wheel-speed ramp (XACRO:57-72; include/crowdnav.h states the model) ----------
+def _wheel_sim(oracle_mod, **kw):
+    o = oracle_mod.Oracle(n_envs=1, n_peds=0, wheel_accel=1.0, spawn_x=0.0, spawn_y=0.0, spawn_yaw=0.0, room_half=5.0, **kw)
+    o.hsim_reset()
+    return o
+
+
+def test_wheel_ramp_reaches_a_forward_command_in_22_ticks(oracle_mod):
+    """From rest to v = 0.22 m/s at 1 m/s^2 on 10 ms ticks: the wheel speed is 0.01 k after tick k, the tick's speed moves the robot
+    over that tick, so 150 ms cover 0.01 * 0.01 * (1 + ... + 15) = 0.012 m (the kinematic robot: 0.033 m) and /odom reports 0.15 m/s;
+    the command is reached on tick 22 and held."""
+    o = _wheel_sim(oracle_mod)
+    o.hsim_advance(150, 0.22, 0.0)
+    r = o.sim_state()[0]
+    assert abs(r[3] - 0.15) < 1e-12 and r[4] == 0.0
+    assert abs(r[0] - 0.012) < 1e-12 and r[1] == 0.0 and r[2] == 0.0
+    o.hsim_advance(70, 0.22, 0.0)            # ticks 16 .. 22
+    r = o.sim_state()[0]
+    assert abs(r[3] - 0.22) < 1e-12
+    x22 = 0.01 * 0.01 * sum(range(1, 23))
+    assert abs(r[0] - x22) < 1e-12
+    o.hsim_advance(100, 0.22, 0.0)
+    assert abs(o.sim_state()[0][0] - (x22 + 0.022)) < 1e-12 and o.sim_state()[0][3] == 0.22
+    # and back down: a stop command takes the same 0.22 s
+    o.hsim_advance(100, 0.0, 0.0)
+    assert abs(o.sim_state()[0][3] - 0.12) < 1e-12
+    o.hsim_advance(120, 0.0, 0.0)
+    assert o.sim_state()[0][3] == 0.0
+    k = oracle_mod.Oracle(n_envs=1, n_peds=0, spawn_x=0.0, spawn_y=0.0, spawn_yaw=0.0, room_half=5.0)   # wheel_accel 0: kinematic
+    k.hsim_reset(); k.hsim_advance(150, 0.22, 0.0)
+    assert abs(k.sim_state()[0][0] - 0.033) < 1e-12 and k.sim_state()[0][3] == 0.22
+
+
+def test_wheel_ramp_either_wheel_within_tolerance_releases_both(oracle_mod):
+    """gazebo_ros_diff_drive's condition is an OR: when ONE wheel is within 0.01 m/s of its target both are set to their targets.
+    v = 0.1, w = 0.9375 -> targets 0.025 / 0.175 m/s: two ticks of +0.01 on both wheels (pure translation), then the left wheel is
+    0.005 from its target and the right one jumps from 0.02 to 0.175."""
+    o = _wheel_sim(oracle_mod)
+    o.hsim_advance(20, 0.1, 0.9375)
+    r = o.sim_state()[0]
+    assert abs(r[3] - 0.02) < 1e-15 and abs(r[4]) < 1e-15 and abs(r[0] - 0.0003) < 1e-15 and r[2] == 0.0
+    o.hsim_advance(10, 0.1, 0.9375)
+    r = o.sim_state()[0]
+    assert abs(r[3] - 0.1) < 1e-15 and abs(r[4] - 0.9375) < 1e-13
+    assert abs(r[2] - 0.009375) < 1e-15                      # that tick already turns at the full rate
+
+
+def test_wheel_ramp_turn_command_and_odom_twist_in_the_observation(oracle_mod):
+    """A pure turn command w = 2 rad/s (wheel targets -0.16 / +0.16 m/s) takes 16 ticks; the observation's twist features
+    (ENV:267-268: -v cos(w), v sin(w) with the ANGULAR velocity used as the angle) are built from the wheels' twist, not the command."""
+    o = _wheel_sim(oracle_mod)
+    o.hsim_advance(100, 0.0, 2.0)
+    r = o.sim_state()[0]
+    assert abs(r[4] - 0.1 * 2 / 0.16) < 1e-12 and abs(r[3]) < 1e-15     # 10 ticks: wheels at -/+0.10 -> w = 1.25 rad/s
+    yaw = sum(0.01 * k * 2 / 0.16 * 0.01 for k in range(1, 11))
+    assert abs(r[2] - yaw) < 1e-12
+    o2 = oracle_mod.Oracle(n_envs=1, n_peds=0, wheel_accel=1.0, max_steps=50)
+    o2.reset()
+    obs, _, _, _ = o2.step(np.array([[0.22, 0.0]]))
+    v = 0.16                                                            # 150 + 10 ms after the command: 16 ticks of +0.01
+    assert abs(obs[0, 364] - (-v)) < 1e-3 and abs(obs[0, 365]) < 1e-12  # state[364] = -v cos(0), state[365] = v sin(0)
+
+
+def test_scan_f32_rounds_every_range_to_float32(oracle_mod):
+    cfg = oracle_mod.make_config(n_peds=1, room_half=1.40, scan_f32=1)
+    cfg0 = oracle_mod.make_config(n_peds=1, room_half=1.40)
+    rg, rg0 = (_raycast(oracle_mod, c, 1.0, -1.0, 0.3, [[0.7, -0.8]]) for c in (cfg, cfg0))
+    fin = np.isfinite(rg0)
+    assert fin.sum() > 50 and np.array_equal(np.isfinite(rg), fin)
+    assert np.array_equal(rg[fin], rg0[fin].astype(np.float32).astype(np.float64)) and not np.array_equal(rg[fin], rg0[fin])
+
+
+def test_waypoint_reward_switch(oracle_mod):
+    """ENV:1109-1116 pays `waypoint_reward` when the robot is within goal_eps of the way-point; 0 = the published log's reward
+    (its largest episode return in 3021 episodes is 173 < 200, while here the bonus is paid several times per episode)."""
+    L = oracle_mod.lib()
+    for bonus in (200, 0):
+        o = oracle_mod.Oracle(n_envs=1, n_peds=0, waypoint_reward=bonus)
+        o.reset()
+        # cno_compute_reward(handle, env, cur_head, cur_dist, prev_head, prev_dist, px, py, wpx, wpy, done)
+        r = L.cno_compute_reward(o.h, 0, 0.1, 0.25, 0.2, 0.3, 0.5, -0.5, 0.4, -0.4, 0)
+        assert r == -2 + 1 + 1 + bonus
