@@ -159,7 +159,12 @@ def main():
         raise SystemExit("bench.py: rank %d has no GPU (%d visible); CN_BENCH_DRYRUN_GLOO=1 shares cuda:0 for a dry run"
                          % (rank, torch.cuda.device_count()))
     dev_index = 0 if dry else local_rank
-    if world > 1:
+    # Under a launcher (torch.distributed.run sets RANK / WORLD_SIZE) the process group is created and every collective of the
+    # N > 1 path runs even at world size 1 -- communicator init, the barrier, the sample all-reduces, the RCCL all-gather of
+    # returns -- so that branch has executed on real hardware before an 8-GPU run meets it.  The driver's N = 1 run (plain
+    # `python bench.py`, no launcher environment) takes no collective at all.
+    use_dist = world > 1 or ("RANK" in os.environ and "WORLD_SIZE" in os.environ and os.environ.get("CN_BENCH_NO_DIST") != "1")
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if dry:
             dist.init_process_group("gloo")
@@ -193,7 +198,7 @@ def main():
     warm_tail = min(a.warmup, 3)
 
     def rank_barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     def bracket(strs):
@@ -218,6 +223,9 @@ def main():
             self.grp = VecEnvGroups(lcfg, groups=G, device=dev_index, streams=streams[:G] if G <= len(streams) else None,
                                     arbitration=arbitration)
             self.arbitration = "rotating per step (sequence kernel)" if sequence else self.grp.envs[0].arbitration
+            # the device kernel this leg's launches run (cn_kernel_name): the key of profiles/rNN/{counters,traffic}.json
+            e0 = self.grp.envs[0]
+            self.kernel = e0.kernel_name("sequence" if sequence else "same" if mode == "same" else "multi" if G > 1 else "step")
             self.grp.reset()
             self.enq_ms = None
             if sequence:
@@ -299,7 +307,7 @@ def main():
 
     def reduce_samples(samples):
         """per-sample (wall, kernel ms, taken) over the ranks: max wall, mean kernel ms, summed env-steps"""
-        if world == 1:
+        if not use_dist:
             return samples, None
         t = torch.tensor(samples, dtype=torch.float64, device=cdev)          # [n, 3]
         mx = t.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
@@ -342,7 +350,7 @@ def main():
             vals = [s[2] / s[0] for s in red]
             mi = median_index(vals)
             out["legs"][G] = {"median": vals[mi], "samples": vals, "wall": red[mi][0], "kernel_ms": red[mi][1],
-                              "taken": red[mi][2], "enq_ms": legs[G].enq_ms, "arbitration": legs[G].arbitration,
+                              "taken": red[mi][2], "enq_ms": legs[G].enq_ms, "arbitration": legs[G].arbitration, "kernel": legs[G].kernel,
                               "per_rank": [pr[mi] for pr in per_rank] if per_rank else None}
             legs[G].close()
         return out
@@ -393,7 +401,7 @@ def main():
                                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": l_["median"] * d4 / 1e9 / HBM_PEAK_GBS}}
 
     gather = None
-    if world > 1:
+    if use_dist:
         # the path's one exchange: all-gather of per-env episode returns over xGMI.  A fresh handle stepped a few
         # hundred launches so that every env has finished episodes to report.
         lg = Leg(cfg, 1, lacts=acts)
@@ -434,9 +442,21 @@ def main():
     # every launch moves its envs' state, reset or step; G launches are in flight at once, one per stream
     achieved = G * B * n_launch / (kernel_ms * 1e-3) / 1e9
     achieved_d4 = G * D4 * n_launch / (kernel_ms * 1e-3) / 1e9
-    counters, counters_src = profiled_json("counters.json") if (a.peds, a.rays) == (20, 360) else (None, "other workload")
-    traffic, traffic_src = profiled_json("traffic.json") if (N, a.peds, a.rays) == (4096, 20, 360) else (None, "other workload")
-    traffic_b = float(traffic["bytes_per_launch"]) * n_launch / 4096.0 if traffic else None
+    # PMC figures of the HEADLINE kernel (and of no other): profiles/rNN/{counters,traffic}.json are keyed by kernel name
+    hk = hl["kernel"]
+    counters_all, counters_src = profiled_json("counters.json") if (a.peds, a.rays) == (20, 360) else (None, "other workload")
+    traffic_all, traffic_src = profiled_json("traffic.json") if (N, a.peds, a.rays) == (4096, 20, 360) else (None, "other workload")
+    counters = (counters_all or {}).get("kernels", {}).get(hk)
+    traffic = (traffic_all or {}).get("kernels", {}).get(hk)
+    if counters_all and not counters:
+        counters_src = "%s has no entry for %s" % (counters_src, hk)
+    if traffic_all and not traffic:
+        traffic_src = "%s has no entry for %s" % (traffic_src, hk)
+    steps_per_launch = K if Gc == "sequence" else 1
+    # HBM bytes the counters saw per launch of the headline kernel, scaled to this run's launch (envs per launch x steps per launch)
+    traffic_b = float(traffic["bytes_per_env_step"]) * n_launch * steps_per_launch if traffic else None
+    flops_d5 = 79e3 if (a.peds, a.rays) == (20, 360) else 623e3 if (a.peds, a.rays) == (100, 720) else None
+    VALU_PEAK_F64 = 157.3e12                                                     # MI355X_MICROARCH.md: vector peak the survey's D3 prices against
     out = {
         "metric": baseline_metric(),
         "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -446,11 +466,13 @@ def main():
         "config": {"workload": "%s: %d envs/GPU x %d pedestrians x %d rays, K=%d, lidar-tracker risk features, "
                                "next-step auto-reset (reset launches not counted as env-steps), open-loop "
                                "U(0,0.22)xU(-2,2) actions, %d untimed pre-roll steps; one step = every env stepped once, "
-                               "%s; median of %d samples of %d steps" % (
+                               "%s; median of %d samples of %d steps; the closed-loop comparables are "
+                               "config.one_launch_per_step_value and config.legs_env_steps_s" % (
                                    ("BASELINE configs[3] shape, %d envs total over %d GPU(s) (strong scaling)" % (a.envs_total, world))
                                    if a.envs_total else ("BASELINE configs[1] per GPU (weak scaling over %d GPU(s))" % world),
                                    N, a.peds, a.rays, a.k, a.preroll,
-                                   ("the K steps enqueued as ONE cn_step_sequence launch (persistent wavefronts, actions [K, N, 2] in HBM)"
+                                   ("the K steps enqueued as ONE cn_step_sequence launch (persistent wavefronts, actions [K, N, 2] in HBM: an "
+                                    "OPEN-LOOP-ONLY decomposition -- it cannot serve a policy in the loop)"
                                     if Gc == "sequence" else "the envs running as %d independent stream group(s) of %d" % (G, n_launch)), R, K),
                    "envs_per_gpu": N, "envs_total": N * world, "stream_groups": G, "stream_groups_requested": Gmax,
                    "decomposition": leg_name(Gc),
@@ -480,10 +502,18 @@ def main():
                      "traffic": traffic_b,
                      "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE+WRITE_SIZE, calibrated; profiles/)",
                      "traffic_source": traffic_src,
-                     "algorithmic_bytes_per_launch": D4 * n_launch, "envs_per_launch": n_launch,
+                     "algorithmic_bytes_per_launch": D4 * n_launch * steps_per_launch, "envs_per_launch": n_launch,
                      "concurrent_launches": G,
-                     "kernel": ("cn_env_kernel_seq (kernel_ms = launch duration / K)" if Gc == "sequence" else
-                                "cn_env_kernel_fair" if hl["arbitration"] == "fair" else "cn_env_kernel"), "kernel_ms": kernel_ms,
+                     # the kernel every figure of this block belongs to (cn_kernel_name of the headline leg's handle); for the sequence
+                     # kernel kernel_ms = launch duration / K and the counters are per control period
+                     "kernel": hk, "kernel_ms": kernel_ms, "steps_per_launch": steps_per_launch,
+                     "wasted_traffic_ratio": (traffic_b / (D4 * n_launch * steps_per_launch)) if traffic_b else None,
+                     "wasted_traffic_ratio_f64_layout": (traffic_b / (B * n_launch * steps_per_launch)) if traffic_b else None,
+                     # the same speed priced in flops: SURVEY 8(d) D5 x env-steps/s over the vector peak D3 names
+                     "flops_per_env_step_d5": flops_d5,
+                     "frac_valu": (value / world * flops_d5 / VALU_PEAK_F64) if flops_d5 else None,
+                     "valu_peak_tflops": VALU_PEAK_F64 / 1e12,
+                     "legs_kernels": {leg_name(g): v["kernel"] for g, v in main_m["legs"].items()},
                      # what actually binds: instruction issue (float64 VALU) and one wavefront's critical path, not HBM
                      "binding": "instruction issue (f64 VALU) above ~8k resident envs; one wavefront's critical path at 4096",
                      "issue_bound_env_steps_s": plateau,
@@ -493,7 +523,11 @@ def main():
                      "counters_source": counters_src,
                      "note": "achieved = concurrent_launches x algorithmic bytes per launch / mean launch duration on "
                              "its own stream (HIP events per group stream, the headline's median sample)",
-                     "one_launch_per_step": ({"envs_per_launch": N, "kernel_ms": one["kernel_ms"],
+                     "one_launch_per_step": ({"envs_per_launch": N, "kernel": one["kernel"], "kernel_ms": one["kernel_ms"],
+                                              "traffic": (float(traffic_all["kernels"][one["kernel"]]["bytes_per_launch"])
+                                                          if traffic_all and one["kernel"] in traffic_all.get("kernels", {}) else None),
+                                              "valu_busy": ((counters_all or {}).get("kernels", {}).get(one["kernel"]) or {}).get("valu_busy"),
+                                              "wave_instr_per_env_step": ((counters_all or {}).get("kernels", {}).get(one["kernel"]) or {}).get("wave_instr_per_env_step"),
                                               "achieved": D4 * N / (one["kernel_ms"] * 1e-3) / 1e9,
                                               "frac": D4 * N / (one["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS} if one else None)},
     }
@@ -530,7 +564,7 @@ def main():
                                                     "source": "BASELINE.md"}}
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

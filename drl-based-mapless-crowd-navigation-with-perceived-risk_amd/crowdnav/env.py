@@ -75,6 +75,17 @@ class VecEnv:
             _abi.check(rc)
         return {_abi.CN_ARB_OLDEST_FIRST: "oldest_first", _abi.CN_ARB_FAIR: "fair"}[rc]
 
+    KERNEL_OF = {"step": 0, "reset": 0, "same": 1, "sequence": 2, "external": 3, "multi": 4}
+
+    def kernel_name(self, what="step"):
+        """cn_kernel_name: the device kernel a call on this handle launches right now -- "step" (cn_step with auto_reset
+        "next" / none, cn_reset), "same" (same-call reset), "sequence", "external", "multi" (inside a cn_step_multi over
+        several handles).  A handle of the headline shape gets the `_s360` kernels."""
+        n = self.L.cn_kernel_name(self.h, self.KERNEL_OF[what])
+        if n is None:
+            _abi.check(-1)
+        return n.decode()
+
     def close(self):
         if getattr(self, "h", None):
             self.L.cn_destroy(self.h)
@@ -137,10 +148,13 @@ class VecEnv:
         self._keep_reset = m      # alive until the next call: the launch is asynchronous
         return self.obs
 
-    def step(self, action, step_counter=None, auto_reset=True, want_final=False):
+    def step(self, action, step_counter=None, auto_reset="next", want_final=False):
         """Env.step for every env.  action: [N,2] float32 device tensor (v, w).
-        auto_reset: False | True/"same" (finished envs reset inside this call) | "next" (a finished env
-        spends the next call on its reset: action ignored, reward 0, done 0 -- shortest launches).
+        auto_reset: "next" (the default since round 4: a finished env returns its TERMINAL observation with done = 1 and spends
+        the next call on Env.reset -- that call ignores its action and returns the new episode's first observation with
+        reward 0, done 0; one observation per wavefront, the fast kernel) | True / "same" (finished envs run Env.reset inside
+        the same call: obs = the new episode's first observation, the terminal one in final_obs when want_final; a launch then
+        lasts two observations for any env that finishes -- ~55 % of the speed) | False (no reset: the caller resets).
         Returns (obs, reward, done) device tensors (views of internal buffers)."""
         a = action
         if not (isinstance(a, torch.Tensor) and a.device == self.device and a.dtype == torch.float32 and a.is_contiguous()):

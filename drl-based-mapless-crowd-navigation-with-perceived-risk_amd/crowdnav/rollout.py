@@ -2,8 +2,8 @@
 
 The reference drives ONE env: reset() -> done=False -> for step: act -> env.step(a, step+1, "continuous")
 -> accumulate reward -> on done: scores, CSV row.  Here N envs advance per launch; each env keeps its own
-1-based step counter and return on the device, finished envs are reset inside the same launch
-(cn_step auto_reset), and episode statistics come back as tensors.  Across GPUs the envs shard by global
+1-based step counter and return on the device, a finished env spends its next launch on Env.reset
+(cn_step auto_reset 2, the fast kernel), and episode statistics come back as tensors.  Across GPUs the envs shard by global
 index with no data-path collective; the one exchange is the all-gather of per-env episode returns."""
 import csv
 import os
@@ -80,22 +80,30 @@ def rollout(env, agent, n_steps, learn=False, add_noise=True, stats=None, policy
         agent.sync_fused_weights()
     obs = env.obs if getattr(env, "_started", False) else env.reset()
     env._started = True
+    # next-step reset convention (the fast kernel): a finished env's next launch is its Env.reset -- not a transition, not an
+    # episode row; the observation it returned with done = 1 is the terminal one
+    resetting = getattr(env, "_resetting", None)
+    if resetting is None:
+        resetting = torch.zeros(env.N, dtype=torch.bool, device=obs.device)
     for t in range(n_steps):
         act = policy(obs, t) if act_fn is None else act_fn(obs, add_noise=add_noise)
         if learn:
             prev = obs.clone()
-        obs, reward, done = env.step(act, auto_reset=True, want_final=learn or stats is not None)
+        obs, reward, done = env.step(act, auto_reset="next")
         if learn:
-            agent.memory.add(prev, act, reward, env.final_obs, done)
+            agent.memory.add_masked(prev, act, reward, obs, done, ~resetting)
+            agent.memory.sync_len()
             agent.learn(t)
+        resetting = done.bool()
         if stats is not None and bool(done.any()):
-            # the live counters are zeroed by the reset inside the launch; columns 10..13 keep the finished episode's
-            # values as they stood when Env.step returned done (what TRAIN:142-147 reads), terminal step included
+            # columns 10..13 keep the finished episode's counters as they stood when Env.step returned done (what TRAIN:142-147
+            # reads), terminal step included
             c = env.counters().cpu()
             ret, _ = env.returns()
             ret = ret.cpu()
             for e in torch.nonzero(done.cpu()).flatten().tolist():
                 stats.add_from_counters(c[e], ret[e].item())
+    env._resetting = resetting
     return n_steps * env.N
 
 
@@ -140,7 +148,7 @@ def evaluate(env, agent, episodes_per_env=1, max_launches=100000):
     launches = 0
     while int(finished.min().item()) < episodes_per_env and launches < max_launches:
         act = agent.act(obs, add_noise=False)
-        obs, reward, done = env.step(act, auto_reset=True)
+        obs, reward, done = env.step(act, auto_reset="next")        # (a finished env's next launch is its reset: done = 0 there)
         launches += 1
         take = done.bool() & (finished < episodes_per_env)
         if bool(take.any()):

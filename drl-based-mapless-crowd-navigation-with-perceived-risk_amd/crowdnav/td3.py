@@ -43,15 +43,22 @@ class Critic(nn.Module):
 
 
 class DeviceReplay:
-    """Ring buffer on the device (ReplayBuffer, TD3:19-37, without the Python list)."""
+    """Ring buffer on the device (ReplayBuffer, TD3:19-37, without the Python list).  Write position and fill level live on the
+    device too (`pos_dev`, `size_dev`), so a masked add needs no host read: rows that are not transitions are written to a
+    spare row past the end of the ring.  `len()` is the host's count: exact after add(), a lower-bound estimate refreshed by
+    sync_len() after add_masked()."""
 
     def __init__(self, capacity, obs_dim, device):
         self.cap, self.pos, self.size = int(capacity), 0, 0
-        self.s = torch.empty((capacity, obs_dim), dtype=torch.float32, device=device)
-        self.s2 = torch.empty((capacity, obs_dim), dtype=torch.float32, device=device)
-        self.a = torch.empty((capacity, 2), dtype=torch.float32, device=device)
-        self.r = torch.empty((capacity, 1), dtype=torch.float32, device=device)
-        self.d = torch.empty((capacity, 1), dtype=torch.float32, device=device)
+        cap1 = self.cap + 1                       # row `cap`: where add_masked() drops the rows it does not keep
+        self.s = torch.zeros((cap1, obs_dim), dtype=torch.float32, device=device)
+        self.s2 = torch.zeros((cap1, obs_dim), dtype=torch.float32, device=device)
+        self.a = torch.zeros((cap1, 2), dtype=torch.float32, device=device)
+        self.r = torch.zeros((cap1, 1), dtype=torch.float32, device=device)
+        self.d = torch.zeros((cap1, 1), dtype=torch.float32, device=device)
+        self.pos_dev = torch.zeros((), dtype=torch.int64, device=device)
+        self.size_dev = torch.zeros((), dtype=torch.int64, device=device)
+        self._ar = None
 
     def add(self, s, a, r, s2, d):
         n = s.shape[0]
@@ -60,18 +67,32 @@ class DeviceReplay:
         self.r[idx, 0], self.d[idx, 0] = r, d.float()
         self.pos = (self.pos + n) % self.cap
         self.size = min(self.cap, self.size + n)
+        self.pos_dev.fill_(self.pos); self.size_dev.fill_(self.size)
 
     def add_masked(self, s, a, r, s2, d, keep):
         """add() for the rows where `keep` (bool [n]) is set -- the others are not transitions (an env's reset launch under the
-        next-step reset convention).  One host read of the count per call."""
-        k = int(keep.sum().item())
-        if k == s.shape[0]:
-            return self.add(s, a, r, s2, d)
-        if k:
-            self.add(s[keep], a[keep], r[keep], s2[keep], d[keep])
+        next-step reset convention).  No host synchronisation: kept rows go to consecutive ring slots after `pos_dev`, the
+        rest to the spare row; the host-side len() only advances at sync_len()."""
+        n = s.shape[0]
+        k = keep.to(torch.int64)
+        c = torch.cumsum(k, 0)
+        idx = torch.where(keep, (self.pos_dev + c - 1) % self.cap, torch.full_like(c, self.cap))
+        self.s.index_copy_(0, idx, s); self.a.index_copy_(0, idx, a); self.s2.index_copy_(0, idx, s2)
+        self.r.index_copy_(0, idx, r.reshape(n, 1)); self.d.index_copy_(0, idx, d.reshape(n, 1).float())
+        tot = c[-1]
+        self.pos_dev.copy_((self.pos_dev + tot) % self.cap)
+        self.size_dev.copy_(torch.clamp(self.size_dev + tot, max=self.cap))
+
+    def sync_len(self):
+        """Bring the host-side position / fill level up to date with the device's (one host read)."""
+        self.pos, self.size = int(self.pos_dev.item()), int(self.size_dev.item())
+        return self.size
 
     def sample(self, batch):
-        idx = torch.randint(0, self.size, (batch,), device=self.s.device)
+        """Uniform sample of the filled part; the indices are drawn on the device from the device-side fill level."""
+        u = torch.rand(batch, device=self.s.device)
+        idx = (u * self.size_dev.clamp(min=1).to(torch.float32)).long().clamp_(max=self.cap - 1)
+        idx = torch.minimum(idx, (self.size_dev - 1).clamp(min=0))
         return self.s[idx], self.a[idx], self.r[idx], self.s2[idx], self.d[idx]
 
     def __len__(self):
@@ -267,12 +288,13 @@ class Agent:
         self.opt_a = torch.optim.Adam(self.actor.parameters(), lr=lr[0], fused=True, capturable=True)
         self.opt_q1 = torch.optim.Adam(self.q1.parameters(), lr=lr[1], fused=True, capturable=True)
         self.opt_q2 = torch.optim.Adam(self.q2.parameters(), lr=lr[2], fused=True, capturable=True)
-        self._g_size = torch.ones((), dtype=torch.float32, device=dev)          # live replay size, refreshed before a replay
         mem = self.memory
 
         def one(do_actor):
+            # indices from the DEVICE-side fill level (DeviceReplay.size_dev): no host value is frozen into the graph, and an
+            # index can never reach a row that was not written (float32 rounding of u * size is clamped to size - 1)
             u = torch.rand(B, device=dev)
-            idx = (u * self._g_size).long().clamp_(max=mem.cap - 1)
+            idx = torch.minimum((u * mem.size_dev.to(torch.float32)).long(), (mem.size_dev - 1).clamp(min=0))
             noise = torch.randn((B, 2), device=dev)
             return self._update(mem.s[idx], mem.a[idx], mem.r[idx], mem.s2[idx], mem.d[idx], noise, do_actor)
 
@@ -316,7 +338,6 @@ class Agent:
                 return None
             if getattr(self, "_graphs", None) and target_noise is None:
                 do_actor = step % self.policy_delay == 0
-                self._g_size.fill_(float(len(self.memory)))
                 self._graphs[do_actor].replay()
                 return self._g_loss[do_actor]
             batch = self.memory.sample(self.batch_size)

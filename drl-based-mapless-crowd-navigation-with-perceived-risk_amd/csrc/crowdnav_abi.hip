@@ -39,6 +39,9 @@ extern "C" __global__ void cn_env_kernel_wa_same(CnKParams p);
 extern "C" __global__ void cn_env_kernel_gt_wa(CnKParams p);
 extern "C" __global__ void cn_env_kernel_gt_wa_same(CnKParams p);
 extern "C" __global__ void cn_env_kernel_seq(CnKParams p);
+extern "C" __global__ void cn_env_kernel_s360(CnKParams p);
+extern "C" __global__ void cn_env_kernel_fair_s360(CnKParams p);
+extern "C" __global__ void cn_env_kernel_seq_s360(CnKParams p);
 extern "C" __global__ void cn_env_kernel_gt_seq(CnKParams p);
 extern "C" __global__ void cn_bbox_kernel(CnKParams p, double* out);
 extern "C" __global__ void cn_gather_kernel(CnKParams p, float* last_ret, float* run_ret, int32_t* counters);
@@ -62,6 +65,7 @@ struct cn_env_s {
     std::vector<double> ped_init;
     int arbitration = CN_ARB_AUTO;    // cn_set_arbitration
     int n_cus = 0;                    // compute units of `device` (CN_ARB_AUTO: fair from 2 wavefronts per SIMD = 8 x n_cus envs)
+    bool shape360 = false;            // the headline shape (360 rays, 20 pedestrians, K = 8 and cn_create's sizes for it): the _s360 kernels
 };
 
 // RAII: run on the handle's device even if the calling thread's current device is another one
@@ -308,12 +312,15 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
     k.max_steps = c.max_steps; k.ped_mode = c.ped_mode; k.dt_ms = c.dt_ms; k.scan_latency_ms = c.scan_latency_ms;
     k.settle_ms = c.settle_ms; k.ped_cycle_ms = c.ped_cycle_ms; k.ped_stagger_ms = c.ped_stagger_ms;
     k.geos_untyped_empty = c.geos_untyped_empty; k.ped_contact = c.ped_contact; k.risk_mode = c.risk_mode; k.py2_round = c.py2_round;
+    k.lidar_min_positive = c.lidar_min > 0.0 ? 1 : 0;
     k.scan_f32 = c.scan_f32; k.waypoint_reward = c.waypoint_reward; k.wheel_accel = c.wheel_accel; k.wheel_sep = c.wheel_separation;
     k.sf_tau = c.sf_tau; k.sf_A = c.sf_A; k.sf_B = c.sf_B; k.sf_wall_A = c.sf_wall_A; k.sf_wall_B = c.sf_wall_B;
     k.sf_goal_eps2 = c.sf_goal_eps * c.sf_goal_eps; k.sf_tick_ms = c.sf_tick_ms > 0 ? c.sf_tick_ms : 10;
     // pair matrix G [P][P] + next state + goal records in the simulator's LDS scratch (regions A + B, 16 (R - 1) bytes)?
     k.sf_pair_matrix = (c.ped_mode == 2 && P >= 2 && P < 256 && 8 * (size_t)P * P + 64 * (size_t)P + (size_t)P * (P - 1) + 16 <= 16 * (size_t)(R - 1)) ? 1 : 0;
     k.near_sep = cn_near_separate(R, P, K, h->max_conf, h->trk_cap);
+    // the kernels compiled for the headline shape assume exactly these six values (crowdnav_kernel.hip, SHAPE == 360)
+    h->shape360 = R == 360 && P == 20 && K == 8 && h->max_conf == 91 && h->trk_cap == 32 && k.near_sep == 1 && !getenv("CN_NO_SHAPE_KERNELS");
     k.max_conf = h->max_conf; k.trk_cap = h->trk_cap; k.env_index_base = c.env_index_base; k.seed = c.seed;
     k.room_half = c.room_half; k.ped_radius = c.ped_radius; k.ped_vmax = c.ped_vmax; k.robot_clearance = c.robot_clearance;
     k.lidar_min = c.lidar_min; k.lidar_max = c.lidar_max; k.lidar_offset_x = c.lidar_offset_x;
@@ -426,39 +433,50 @@ static bool fair_launch(const cn_env_s* h, bool overlapped)
     return h->n_cus > 0 && h->cfg.n_envs >= 8 * h->n_cus;
 }
 
+typedef void (*cn_kernel_fn)(CnKParams);
+struct KernelChoice { cn_kernel_fn fn; const char* name; };
+#define CN_KC(f) KernelChoice{f, #f}
+
+// Which kernel a launch of this handle runs.  ext: externally supplied /scan + /odom; same: Env.step + same-call reset.
+static KernelChoice choose_kernel(const cn_env_s* h, bool ext, bool same, bool overlapped)
+{
+    const cn_config& c = h->cfg;
+    if (c.obs_layout == CN_LAYOUT_REALWORLD) return ext ? CN_KC(cn_env_kernel_rw_ext) : same ? CN_KC(cn_env_kernel_rw_same) : CN_KC(cn_env_kernel_rw);
+    if (c.obs_layout == CN_LAYOUT_ORIGINAL) return ext ? CN_KC(cn_env_kernel_orig_ext) : same ? CN_KC(cn_env_kernel_orig_same) : CN_KC(cn_env_kernel_orig);
+    if (ext) return c.risk_mode == CN_RISK_GT ? KernelChoice{nullptr, nullptr} : CN_KC(cn_env_kernel_ext);
+    // simulated sensors: {lidar tracker, gt} x {plain, contact, social force, wheel ramp} x {one observation per launch, step + same-call reset}
+    const bool gt = c.risk_mode == CN_RISK_GT, ct = c.ped_contact != 0, sf = c.ped_mode == 2, wa = c.wheel_accel > 0.0;
+    if (wa) return gt ? (same ? CN_KC(cn_env_kernel_gt_wa_same) : CN_KC(cn_env_kernel_gt_wa)) : (same ? CN_KC(cn_env_kernel_wa_same) : CN_KC(cn_env_kernel_wa));
+    if (gt) return sf ? (same ? CN_KC(cn_env_kernel_gt_sf_same) : CN_KC(cn_env_kernel_gt_sf))
+                      : ct ? (same ? CN_KC(cn_env_kernel_gt_ct_same) : CN_KC(cn_env_kernel_gt_ct)) : (same ? CN_KC(cn_env_kernel_gt_same) : CN_KC(cn_env_kernel_gt));
+    if (sf) return same ? CN_KC(cn_env_kernel_sf_same) : CN_KC(cn_env_kernel_sf);
+    if (ct) return same ? CN_KC(cn_env_kernel_ct_same) : CN_KC(cn_env_kernel_ct);
+    if (same) return CN_KC(cn_env_kernel_same);
+    const bool fair = fair_launch(h, overlapped);
+    if (h->shape360) return fair ? CN_KC(cn_env_kernel_fair_s360) : CN_KC(cn_env_kernel_s360);
+    return fair ? CN_KC(cn_env_kernel_fair) : CN_KC(cn_env_kernel);
+}
+static KernelChoice choose_sequence_kernel(const cn_env_s* h)
+{
+    return h->cfg.risk_mode == CN_RISK_GT ? CN_KC(cn_env_kernel_gt_seq) : (h->shape360 ? CN_KC(cn_env_kernel_seq_s360) : CN_KC(cn_env_kernel_seq));
+}
+
+extern "C" const char* cn_kernel_name(cn_handle h, int what)
+{
+    if (!h || what < 0 || what > 4) { fail(CN_ERR_ARG, "cn_kernel_name: bad argument"); return nullptr; }
+    if (what == 2) return choose_sequence_kernel(h).name;
+    return choose_kernel(h, what == 3, what == 1, what == 4).name;
+}
+
 static int launch(cn_handle h, const CnKParams& kp, hipStream_t st, bool overlapped = false)
 {
     DeviceScope scope(h->device);
-    if (h->cfg.obs_layout == CN_LAYOUT_REALWORLD) {
-        if (kp.mode == CN_MODE_EXT_STEP || kp.mode == CN_MODE_EXT_RESET)
-            hipLaunchKernelGGL(cn_env_kernel_rw_ext, dim3(kp.N), dim3(64), h->lds, st, kp);
-        else if (kp.mode == CN_MODE_STEP && kp.auto_reset == 1)
-            hipLaunchKernelGGL(cn_env_kernel_rw_same, dim3(kp.N), dim3(64), h->lds, st, kp);
-        else
-            hipLaunchKernelGGL(cn_env_kernel_rw, dim3(kp.N), dim3(64), h->lds, st, kp);
-    } else if (h->cfg.obs_layout == CN_LAYOUT_ORIGINAL) {
-        if (kp.mode == CN_MODE_EXT_STEP || kp.mode == CN_MODE_EXT_RESET)
-            hipLaunchKernelGGL(cn_env_kernel_orig_ext, dim3(kp.N), dim3(64), h->lds, st, kp);
-        else if (kp.mode == CN_MODE_STEP && kp.auto_reset == 1)
-            hipLaunchKernelGGL(cn_env_kernel_orig_same, dim3(kp.N), dim3(64), h->lds, st, kp);
-        else
-            hipLaunchKernelGGL(cn_env_kernel_orig, dim3(kp.N), dim3(64), h->lds, st, kp);
-    } else if (kp.mode == CN_MODE_EXT_STEP || kp.mode == CN_MODE_EXT_RESET) {
-        if (h->cfg.risk_mode == CN_RISK_GT)
-            return fail(CN_ERR_CONFIG, "cn_observe_external: risk_mode gt reads the library simulator's pedestrians; "
-                                       "external /scan + /odom only exist in lidar_tracker mode");
-        hipLaunchKernelGGL(cn_env_kernel_ext, dim3(kp.N), dim3(64), h->lds, st, kp);
-    } else {
-        // simulated sensors: {lidar tracker, gt} x {no contact, contact} x {one observation per launch, step + same-call reset}
-        const bool same = kp.mode == CN_MODE_STEP && kp.auto_reset == 1;
-        const bool gt = h->cfg.risk_mode == CN_RISK_GT, ct = h->cfg.ped_contact != 0, sf = h->cfg.ped_mode == 2, wa = h->cfg.wheel_accel > 0.0;
-        void (*fn)(CnKParams) = wa ? (gt ? (same ? cn_env_kernel_gt_wa_same : cn_env_kernel_gt_wa) : (same ? cn_env_kernel_wa_same : cn_env_kernel_wa)) : gt ? (sf ? (same ? cn_env_kernel_gt_sf_same : cn_env_kernel_gt_sf)
-                                         : ct ? (same ? cn_env_kernel_gt_ct_same : cn_env_kernel_gt_ct) : (same ? cn_env_kernel_gt_same : cn_env_kernel_gt))
-                                   : (sf ? (same ? cn_env_kernel_sf_same : cn_env_kernel_sf)
-                                         : ct ? (same ? cn_env_kernel_ct_same : cn_env_kernel_ct) : (same ? cn_env_kernel_same : cn_env_kernel));
-        if (fn == cn_env_kernel && fair_launch(h, overlapped)) fn = cn_env_kernel_fair;
-        hipLaunchKernelGGL(fn, dim3(kp.N), dim3(64), h->lds, st, kp);
-    }
+    const bool ext = kp.mode == CN_MODE_EXT_STEP || kp.mode == CN_MODE_EXT_RESET;
+    const KernelChoice kc = choose_kernel(h, ext, kp.mode == CN_MODE_STEP && kp.auto_reset == 1, overlapped);
+    if (!kc.fn)
+        return fail(CN_ERR_CONFIG, "cn_observe_external: risk_mode gt reads the library simulator's pedestrians; "
+                                   "external /scan + /odom only exist in lidar_tracker mode");
+    hipLaunchKernelGGL(kc.fn, dim3(kp.N), dim3(64), h->lds, st, kp);
     HIPCHK(hipGetLastError());
     return CN_OK;
 }
@@ -495,7 +513,7 @@ extern "C" int cn_set_arbitration(cn_handle h, int mode)
 extern "C" int cn_get_arbitration(cn_handle h)
 {
     if (!h) return fail(CN_ERR_ARG, "cn_get_arbitration: null handle");
-    const bool has_variant = h->cfg.obs_layout == CN_LAYOUT_RISK && h->cfg.risk_mode != CN_RISK_GT && !h->cfg.ped_contact && h->cfg.ped_mode != 2;
+    const bool has_variant = h->cfg.obs_layout == CN_LAYOUT_RISK && h->cfg.risk_mode != CN_RISK_GT && !h->cfg.ped_contact && h->cfg.ped_mode != 2 && !(h->cfg.wheel_accel > 0.0);
     return has_variant && fair_launch(h, false) ? CN_ARB_FAIR : CN_ARB_OLDEST_FIRST;
 }
 
@@ -606,7 +624,7 @@ extern "C" int cn_step_sequence(cn_handle h, const cn_sequence_io* io, void* str
     kp.roll_steps = io->n_steps; kp.roll_action_in_stride = io->action_stride; kp.roll_obs_stride = io->obs_stride;
     kp.roll_reward_stride = io->reward_stride; kp.roll_done_stride = io->done_stride; kp.roll_topk_stride = io->topk_stride;
     DeviceScope scope(h->device);
-    void (*fn)(CnKParams) = h->cfg.risk_mode == CN_RISK_GT ? cn_env_kernel_gt_seq : cn_env_kernel_seq;
+    cn_kernel_fn fn = choose_sequence_kernel(h).fn;
     hipLaunchKernelGGL(fn, dim3(h->cfg.n_envs), dim3(64), h->lds, (hipStream_t)stream, kp);
     HIPCHK(hipGetLastError());
     return CN_OK;

@@ -681,7 +681,7 @@ __device__ __forceinline__ double cast_ray(KP p, const Lds& L, int env, int k, d
         const double reach = p->lidar_max * (1.0 + 1e-9);
         if (wall_x && dx != 0.0 && h - cn_xorsign(ox, dx) <= fma(reach, fabs(dx), 1e-12)) t = cn_vmin(t, cn_div(copysign(h, dx) - ox, dx));
         if (wall_y && dy != 0.0 && h - cn_xorsign(oy, dy) <= fma(reach, fabs(dy), 1e-12)) t = cn_vmin(t, cn_div(copysign(h, dy) - oy, dy));
-        if (t < p->lidar_min) t = p->lidar_min;
+        t = cn_vmax_s(t, p->lidar_min);                        // (one v_max_f64: t is +inf or a finite quotient here, never a NaN)
         const int q = k >> 6;                                  // this block of 64 rays (wave-uniform)
         auto test = [&](int c) {
             const double ocx = L.nearp[4 * c], ocy = L.nearp[4 * c + 1], cc = L.nearp[4 * c + 2];
@@ -817,7 +817,8 @@ __device__ __forceinline__ double bbox_size(KP p, double* stage, int lane, int n
 {
     const double MAXR = p->max_scan_range, deg2rad = CN_PI / 180.0;
     double sum = 0.0;
-    for (int i0 = 0; i0 < n; i0 += 64) {
+#pragma unroll 1
+    for (int i0 = 0; i0 < n; i0 += 64) {      // (cold: resets away from the spawn pose only -- never unrolled, whatever n is known to be)
         int i = i0 + lane;
         if (i < n) {
             int j = (i == n - 1) ? 0 : i + 1;
@@ -1017,8 +1018,10 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
                 else if (r > MAXR) sc = MAXR;
                 else sc = r;
             } else {
-                // the simulated sensor returns +inf or a finite range >= lidar_min >= 0, never a NaN: the same chain, shorter
-                sc = (r == 0.0) ? MAXR : cn_vmin(r, MAXR);
+                // the simulated sensor returns +inf or a finite range >= lidar_min >= 0, never a NaN: the same chain, shorter.
+                // With lidar_min > 0 (cn_create records it) a zero range cannot occur either, and +inf falls out of the min.
+                sc = cn_vmin(r, MAXR);
+                if (__builtin_expect(!p->lidar_min_positive, 0)) sc = (r == 0.0) ? MAXR : sc;
             }
             smin = cn_vmin(smin, sc);
             // sin/cos(radians(j * inc) - yaw) by angle addition from a host table of sin/cos(radians(j * inc))
@@ -2154,7 +2157,7 @@ __device__ __forceinline__ double compute_reward(KP p, const Poly& pg, EnvRegs& 
 // `env`, `lane`: this wavefront's environment and lane; `smem`: its LDS working set (cn_lds_bytes).  The per-launch kernels pass
 // blockIdx.x / threadIdx.x / the block's dynamic LDS; the multi-step kernel (FUSED, cn_env_kernel_seq below) calls this once per
 // step, `t` steps into its launch, with the step's actions / outputs at slot t of the caller's buffers.
-template <bool EXT, bool TWO, int LAYOUT, bool GT = false, int SIM = 0, bool FUSED = false, bool FAIR = false>
+template <bool EXT, bool TWO, int LAYOUT, bool GT = false, int SIM = 0, bool FUSED = false, bool FAIR = false, int SHAPE = 0>
 __device__ __forceinline__ void env_kernel_body(const int env, const int lane, char* const smem, const long long t = 0)
 {
     KP p = (KP)__builtin_amdgcn_kernarg_segment_ptr();
@@ -2165,6 +2168,15 @@ __device__ __forceinline__ void env_kernel_body(const int env, const int lane, c
         unsigned long long pp = (unsigned long long)p;
         asm volatile("" : "+s"(pp));
         p = (KP)pp;
+    }
+    if constexpr (SHAPE == 360) {
+        // The headline shape (BASELINE configs[1]: 360 rays, 20 pedestrians, K = 8; cn_create's max_conf / tracker slots / LDS
+        // map for it) as COMPILE-TIME facts: the kernarg loads of these six fields fold to constants everywhere below (the
+        // loads are invariant, so one assumption covers every use), which turns the LDS map into immediates, the word loops
+        // (W = 6) into straight-line code and frees the scalar registers that held the map.  launch() only picks an _s360
+        // kernel for a handle whose configuration IS this shape.
+        __builtin_assume(p->R == 360); __builtin_assume(p->P == 20); __builtin_assume(p->K == 8);
+        __builtin_assume(p->max_conf == 91); __builtin_assume(p->trk_cap == 32); __builtin_assume(p->near_sep == 1);
     }
     if constexpr (!FUSED) {
         if (env >= p->N) return;
@@ -2247,9 +2259,23 @@ __device__ __forceinline__ void env_kernel_body(const int env, const int lane, c
     e.ts = sd[CN_SD_TS]; e.bb = sd[CN_SD_BB]; e.ego = sd[CN_SD_EGO]; e.cprob = sd[CN_SD_CPROB];
     e.ep_ret = sd[CN_SD_EP_RETURN]; e.last_ret = sd[CN_SD_LAST_RETURN];
     e.done = si[CN_SI_DONE]; e.dq_len = si[CN_SI_DQ_LEN]; e.ntracks = si[CN_SI_NTRACKS];
-    e.ego_viol = si[CN_SI_EGO_VIOL]; e.social_viol = si[CN_SI_SOCIAL_VIOL]; e.obst_steps = si[CN_SI_OBST_STEPS];
-    e.succ = si[CN_SI_SUCCESS]; e.fail = si[CN_SI_FAILURE]; e.ep_step = si[CN_SI_EP_STEP]; e.status = si[CN_SI_STATUS];
-    e.nconf = si[CN_SI_NCONF]; e.nent = si[CN_SI_NENTRIES]; e.pending = si[CN_SI_PENDING_RESET]; e.episodes = si[CN_SI_EPISODES];
+    e.ep_step = si[CN_SI_EP_STEP]; e.pending = si[CN_SI_PENDING_RESET];
+    // The counters nothing reads before the observation is over (safety violations, obstacle-present steps, success / failure,
+    // status bits, episode count) stay in ONE vector register for most of the call -- lane k holds si[k], one coalesced load --
+    // instead of nine scalar values that live from the first instruction to the last (the kernel sits at its register caps).
+    // Until cold_settle() the fields of `e` are this call's increments; cold_settle() folds the stored values in.
+    const int cold_i = si[lane & (CN_SI_COUNT - 1)];
+    static_assert((CN_SI_COUNT & (CN_SI_COUNT - 1)) == 0, "CN_SI_COUNT is a power of two");
+    e.ego_viol = 0; e.social_viol = 0; e.obst_steps = 0; e.status = 0; e.succ = 0; e.fail = 0; e.episodes = 0; e.nconf = 0; e.nent = 0;
+    bool cold_settled = false;
+    auto cold_settle = [&]() {
+        if (cold_settled) return;
+        cold_settled = true;
+        e.ego_viol += __builtin_amdgcn_readlane(cold_i, CN_SI_EGO_VIOL); e.social_viol += __builtin_amdgcn_readlane(cold_i, CN_SI_SOCIAL_VIOL);
+        e.obst_steps += __builtin_amdgcn_readlane(cold_i, CN_SI_OBST_STEPS); e.status |= __builtin_amdgcn_readlane(cold_i, CN_SI_STATUS);
+        e.succ = __builtin_amdgcn_readlane(cold_i, CN_SI_SUCCESS); e.fail = __builtin_amdgcn_readlane(cold_i, CN_SI_FAILURE);
+        e.episodes = __builtin_amdgcn_readlane(cold_i, CN_SI_EPISODES);
+    };
     e.crowd_ms = (long long)(((unsigned long long)(unsigned)si[CN_SI_CROWD_HI] << 32) | (unsigned)si[CN_SI_CROWD_LO]);
     e.cv = 0.0; e.cw = 0.0;       // the command lives inside one call: a step publishes its action first, a reset leaves it zero
 
@@ -2368,8 +2394,10 @@ __device__ __forceinline__ void env_kernel_body(const int env, const int lane, c
                 L.tail[lane] = p->obs_f64 ? p->obs_f64[(size_t)env * D_ + src] : (double)p->obs[(size_t)env * D_ + src];
             }
             done = io_done()[env] ? 1 : 0;
+            e.nconf = __builtin_amdgcn_readlane(cold_i, CN_SI_NCONF); e.nent = __builtin_amdgcn_readlane(cold_i, CN_SI_NENTRIES);   // no observation ran
             CN_SYNC();
         }
+        cold_settle();
         if (!do_reset && !ph_rew) {
             if (lane == 0) io_done()[env] = (uint8_t)done;           // get_state returns (state, self.done) (ENV:1044)
             if (ph_obs && io_topk() && lane < K) io_topk()[(size_t)env * K + lane] = LAYOUT != 0 ? -1 : L.kidx[lane];
@@ -2456,12 +2484,15 @@ __device__ __forceinline__ void env_kernel_body(const int env, const int lane, c
         double r;
         if constexpr (LAYOUT == 1) {
             observe_original<EXT>(p, e, L, env, lane, sc, p->obs, ext ? nullptr : p->final_obs, p->obs_f64, &done);
+            cold_settle();
             r = compute_reward_original(p, e, L, done);
         } else if constexpr (LAYOUT == 2) {
             observe_realworld<EXT>(p, pg, e, L, RQ, env, lane, sc, p->obs, ext ? nullptr : p->final_obs, p->obs_f64, &done);
+            cold_settle();
             r = compute_reward_realworld(p, e, L, done);
         } else {
             observe<EXT, GT, FAIR>(p, pg, e, L, env, lane, sc, p->obs, ext ? nullptr : p->final_obs, p->obs_f64, &done);
+            cold_settle();
             r = compute_reward(p, pg, e, L, lane, done);
         }
         e.ep_ret += r;
@@ -2513,6 +2544,7 @@ __device__ __forceinline__ void env_kernel_body(const int env, const int lane, c
         CN_SYNC();
         observe<EXT, GT, FAIR>(p, pg, e, L, env, lane, 0, p->obs, nullptr, p->obs_f64, &d2);
         }
+        cold_settle();
         e.social_viol = 0; e.ego_viol = 0; e.obst_steps = 0;  // ENV:1260-1262
         if (!ext) {
         e.clock += cn_div1000((double)p->settle_ms);              // TRAIN:114 time.sleep(0.1)
@@ -2525,6 +2557,7 @@ __device__ __forceinline__ void env_kernel_body(const int env, const int lane, c
     }
 
     }
+    cold_settle();
     asm volatile("" :: "v"(trk_warm));   // keeps the warming load (its value is irrelevant)
     CN_T(18);
     // ---- write env state back ---------------------------------------------------------------------
@@ -2557,6 +2590,8 @@ __device__ __forceinline__ void env_kernel_body(const int env, const int lane, c
 #endif
 extern "C" __global__ void CN_HOT_BOUNDS cn_env_kernel(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, false, 0>(blockIdx.x, threadIdx.x, cn_smem); }
 extern "C" __global__ void CN_HOT_BOUNDS cn_env_kernel_fair(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, false, 0, false, 0, false, true>(blockIdx.x, threadIdx.x, cn_smem); }
+extern "C" __global__ void CN_HOT_BOUNDS cn_env_kernel_s360(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, false, 0, false, 0, false, false, 360>(blockIdx.x, threadIdx.x, cn_smem); }
+extern "C" __global__ void CN_HOT_BOUNDS cn_env_kernel_fair_s360(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, false, 0, false, 0, false, true, 360>(blockIdx.x, threadIdx.x, cn_smem); }
 extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_same(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, true, 0>(blockIdx.x, threadIdx.x, cn_smem); }
 extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_ext(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<true, false, 0>(blockIdx.x, threadIdx.x, cn_smem); }
 // cn_step_sequence: T control periods per launch with OPEN-LOOP actions (resident in HBM: [T][N][2], or one [N][2] held for T
@@ -2565,7 +2600,7 @@ extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_ext(CnKParams p) 
 // step -- and after a few steps the wavefronts of a SIMD are out of phase (they stop contending for the same unit at the same
 // time), which is what one launch per step can never be.  Each step is exactly cn_env_kernel's (next-step reset convention) and
 // writes its observation / reward / done / indices to slot t of the caller's buffers (stride 0: in place).
-template <bool GT>
+template <bool GT, int SHAPE = 0>
 __device__ __forceinline__ void sequence_body()
 {
     extern __shared__ __attribute__((aligned(16))) char cn_smem[];
@@ -2577,10 +2612,11 @@ __device__ __forceinline__ void sequence_body()
         asm volatile("" : "+v"(lane_));          // per-step laundering (see env_kernel_body): nothing is hoisted out of the step loop
         lane_ &= 63;
         cn_setprio_uniform((int)(t + wslot) & 3);      // see "issue arbitration" at the top: every slot gets every level in turn
-        env_kernel_body<false, false, 0, GT, 0, true>(blockIdx.x, lane_, cn_smem, t);
+        env_kernel_body<false, false, 0, GT, 0, true, false, SHAPE>(blockIdx.x, lane_, cn_smem, t);
     }
 }
 extern "C" __global__ void CN_HOT_BOUNDS cn_env_kernel_seq(CnKParams p) { sequence_body<false>(); }
+extern "C" __global__ void CN_HOT_BOUNDS cn_env_kernel_seq_s360(CnKParams p) { sequence_body<false, 360>(); }
 extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_gt_seq(CnKParams p) { sequence_body<true>(); }
 // risk_mode gt: the perceived-risk features from the simulator's own pedestrians (no segmentation, no tracker)
 extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_gt(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, false, 0, true>(blockIdx.x, threadIdx.x, cn_smem); }

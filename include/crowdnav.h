@@ -223,6 +223,12 @@ int cn_step(cn_handle h, const cn_step_io* io, void* stream);
 #define CN_ARB_FAIR 2
 int cn_set_arbitration(cn_handle h, int mode);
 int cn_get_arbitration(cn_handle h);
+/* Name of the device kernel a call on this handle launches right now (diagnostics: bench.py and the profile summaries key the
+ * PMC counters of a run by it).  what: 0 = cn_step with auto_reset 0 / 2 and cn_reset, 1 = cn_step with auto_reset 1 (same-call
+ * reset), 2 = cn_step_sequence, 3 = cn_observe_external, 4 = cn_step inside a cn_step_multi over several handles.  Handles whose
+ * shape is the headline one (360 rays, 20 pedestrians, K = 8, default tracker slots) get kernels compiled for exactly that
+ * shape (`..._s360`: the LDS map, word counts and loop bounds are constants there); results are identical.  NULL on error. */
+const char* cn_kernel_name(cn_handle h, int what);
 /* n calls of cn_step in one crossing of the boundary: handle i steps with ios[i] on streams[i] (env batches run as
  * independent stream groups, DESIGN.md section 6: the launches are the same, the host thread pays the foreign-call
  * overhead once per step instead of once per group).  Stops at the first error and returns it. */

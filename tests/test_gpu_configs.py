@@ -129,36 +129,70 @@ def test_config3_actor_in_the_loop_4096_envs(oracle_mod, sigma):
     envs.close()
 
 
-def test_batched_trainer_runs_on_the_next_step_reset_kernel(tmp_path):
-    """crowdnav.train (TRAIN:40-168 batched) on the fast one-observation kernel: a finished env's next launch is its reset and
-    is masked out of the replay, so the buffer holds exactly the env-steps taken; terminal transitions carry done = 1 and the
-    terminal observation; evaluation rows carry the episode's duration (TRAIN:141 timelapse)."""
-    import argparse
+@pytest.mark.parametrize("reset_mode", ["next", "same"])
+def test_batched_trainer_runs_on_the_next_step_reset_kernel(tmp_path, reset_mode):
+    """crowdnav.train (TRAIN:40-168 batched) without a host synchronisation per launch: the actor as one kernel
+    (cn_actor_forward), the replay's masked add and the episode log on the device.  reset_mode "next" (the fast
+    one-observation kernel): a finished env's next launch is its reset and is masked out of the replay, so the buffer holds
+    exactly the env-steps taken; "same" (the older path, kept for A/B runs): every launch is a transition and s' of a finished
+    env is final_obs.  Terminal transitions carry done = 1 and the terminal observation; the CSV has one row per episode in the
+    reference's 8-column schema; evaluation rows carry the episode's duration (TRAIN:141 timelapse)."""
     import torch
     from crowdnav import train as T
     a = T.main.__globals__["argparse"].Namespace(scenario="bench", envs=64, launches=120, max_steps=25, updates=1, batch=64, memory=20000,
-                                                 checkpoint_every=10 ** 9, log_every=10 ** 9, ped_vmax=None, seed=3, device=0,
+                                                 checkpoint_every=10 ** 9, log_every=50, ped_vmax=None, seed=3, device=0,
                                                  out=str(tmp_path / "run"), csv=True, load=None, load_episode=0, evaluate=False,
-                                                 episodes_per_env=1, graphs=1)
+                                                 episodes_per_env=1, graphs=1, waypoint_reward=0, scan_f32=None, wheel_accel=None,
+                                                 reset_mode=reset_mode, max_csv_rows=100000, time_limit=0.0)
     agent, episodes = T.train(a)
     m = agent.memory
-    assert episodes > 64 and len(m) == m.size
-    # 120 launches x 64 envs, minus one launch per finished episode (except episodes that finished in the very last launch)
-    assert 120 * 64 - episodes <= len(m) <= 120 * 64 - episodes + 64
+    assert episodes > 64 and len(m) == m.size == int(m.size_dev.item())
+    if reset_mode == "next":
+        # 120 launches x 64 envs, minus one launch per finished episode (except episodes that finished in the very last launch)
+        assert 120 * 64 - episodes <= len(m) <= 120 * 64 - episodes + 64
+    else:
+        assert len(m) == 120 * 64
     d = m.d[:m.size, 0]
     assert 0 < int(d.sum().item()) <= episodes
     # a terminal transition's s' is the terminal observation, not a fresh episode's first one: the robot is where the episode
     # ended, i.e. either inside the goal box, at max_steps, or with a scan below min_scan_range (0.12)
     term = torch.nonzero(d > 0).flatten()[:50]
     assert (m.s2[term, :359].min(1).values < 0.6).any()
+    assert float(m.r[:m.size].max()) <= 200.0            # waypoint_reward = 0: nothing above the goal reward
     import csv
     rows = list(csv.reader(open(os.path.join(a.out, "td3_training.csv"))))
-    assert rows[0][-1] == "timelapse" and len(rows) - 1 == episodes
+    assert rows[0] == ["episode_number", "success_episode", "failure_episode", "episode_reward", "episode_step", "ego_safety_score",
+                       "social_safety_score", "timelapse"] and len(rows) - 1 == episodes
+    assert all(1 <= int(r[4]) <= 25 for r in rows[1:]) and any(int(r[4]) == 25 for r in rows[1:])
     from crowdnav.env import VecEnv
     from crowdnav import Config
     from crowdnav.rollout import evaluate
     st = evaluate(VecEnv(Config(n_envs=32, max_steps=20, seed=4)), agent)
     assert len(st.rows) == 32 and all(abs(r[7] - r[4] * 0.16) < 1e-9 and r[7] > 0 for r in st.rows)
+
+
+def test_device_replay_masked_add_without_a_host_read():
+    """DeviceReplay.add_masked: kept rows land in consecutive ring slots after the device-side position (wrapping), the others in
+    the spare row; sample() never returns an unwritten row."""
+    import torch
+    from crowdnav.td3 import DeviceReplay
+    m = DeviceReplay(10, 3, "cuda")
+    g = torch.Generator(device="cuda").manual_seed(1)
+    want = []
+    for it in range(7):
+        s = torch.rand((4, 3), generator=g, device="cuda") + it
+        keep = torch.tensor([it % 2 == 0, True, it % 3 != 0, False], device="cuda")
+        m.add_masked(s, s[:, :2], s[:, 0], s + 100, keep, keep)
+        want += [s[i] for i in range(4) if bool(keep[i])]
+    n = m.sync_len()
+    assert n == 10 and len(want) > 10 and m.pos == len(want) % 10
+    for j, row in enumerate(want[-10:]):
+        slot = (len(want) - 10 + j) % 10
+        assert torch.equal(m.s[slot], row) and torch.equal(m.s2[slot], row + 100) and float(m.r[slot]) == float(row[0])
+    m2 = DeviceReplay(100, 3, "cuda")
+    m2.add_masked(torch.ones((4, 3), device="cuda"), torch.ones((4, 2), device="cuda"), torch.ones(4, device="cuda"),
+                  torch.ones((4, 3), device="cuda"), torch.zeros(4, device="cuda"), torch.tensor([True, False, True, True], device="cuda"))
+    assert m2.sync_len() == 3 and bool((m2.sample(64)[0] == 1).all())
 
 
 def test_graphed_td3_update_equals_the_eager_update():
@@ -192,7 +226,7 @@ def test_graphed_td3_update_equals_the_eager_update():
         torch.cuda.synchronize()
         torch.cuda.set_rng_state(st, "cuda")
         u = torch.rand(16, device="cuda")
-        idx = (u * float(len(b.memory))).long().clamp_(max=b.memory.cap - 1)
+        idx = (u * float(len(b.memory))).long().clamp_(max=len(b.memory) - 1)
         noise = torch.randn((16, 2), device="cuda")
         m = b.memory
         b.learn(step, batch=(m.s[idx], m.a[idx], m.r[idx], m.s2[idx], m.d[idx]), target_noise=noise)
@@ -475,6 +509,37 @@ def test_bench_self_launches_two_ranks():
         assert ga["ms"] is not None and ga["ranks_seen"] == 2 and ga["all_ranks_agree"] and out["value"] > 0
         pr = out["config"]["per_rank"]
         assert [p_["rank"] for p_ in pr] == [0, 1] and all(p_["value"] > 0 for p_ in pr)
+
+
+def test_bench_under_the_launcher_runs_the_rccl_path_at_world_size_one():
+    """The driver launches `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` on an 8-GPU node; with the
+    one GPU a round can lease, the same command at N = 1 still takes the NON-gloo branch of bench.py: process group "nccl"
+    (= RCCL) bound to the device, communicator init, barrier, the sample all-reduces / all-gathers on device buffers and the
+    all_gather_into_tensor of the per-env episode returns -- every collective call an 8-rank run makes, executed on real
+    hardware here.  (Scaling itself is the driver's 8-GPU tier; DESIGN.md section 7 holds the expected curve.)"""
+    import json
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "CN_BENCH_DRYRUN_GLOO", "CN_BENCH_NO_DIST"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2",
+                        "--preroll", "20", "--repeats", "2", "--no-cpu-baseline", "--no-plateau", "--no-other-configs"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["scaling"] == "weak"
+    ga = out["config"]["returns_allgather"]
+    assert ga is not None and ga["collective"] == "rccl" and ga["rccl_version"] and ga["ranks_seen"] == 1 and ga["all_ranks_agree"]
+    assert ga["bytes_per_rank"] == 4 * 4096 and ga["ms"] > 0 and ga["nonzero_returns"] > 0
+    pr = out["config"]["per_rank"]
+    assert [p_["rank"] for p_ in pr] == [0] and abs(pr[0]["value"] - out["value"]) <= 1e-6 * out["value"]
+    assert out["roofline"]["kernel"].startswith("cn_env_kernel") and out["roofline"]["kernel"] == out["roofline"]["legs_kernels"][out["config"]["decomposition"]]
 
 
 def test_td3_update_on_the_gpu_matches_reference_learn():

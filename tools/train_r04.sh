@@ -1,0 +1,20 @@
+#!/bin/bash
+# Round-4 training runs on the GPU box: TD3 with the reference's hyper-parameters (TRAIN:62-72) in
+# presets.training(drop_cospawned=True) -- tools/train_r04.sh <set> <seconds per run>  -> gpurun_out/train_<set>/<run>.txt (+ CSV)
+SET="${1:-probe}"; LIM="${2:-420}"
+cd "$(dirname "$0")/.."; OUT="gpurun_out/train_$SET"; mkdir -p "$OUT"
+export PYTHONPATH="$PWD/drl-based-mapless-crowd-navigation-with-perceived-risk_amd:${PYTHONPATH:-}"
+run() { name="$1"; shift
+  python -m crowdnav.train --scenario training_as_logged --csv --log-every 250 --launches 100000000 --time-limit "$LIM" --out "$OUT/$name" "$@" 2>&1 | grep -v amdgpu.ids > "$OUT/$name.txt"
+  echo "== $name: $*"; tail -3 "$OUT/$name.txt"; rm -f "$OUT/$name"/*.pt; }
+case "$SET" in
+  probe)   # the published log's reward (no way-point bonus) at the reference's update-to-data ratio of 1, and the committed reward beside it
+    run e16_u16_wp0   --envs 16 --updates 16 --waypoint-reward 0
+    run e16_u16_wp200 --envs 16 --updates 16 --waypoint-reward 200
+    run e64_u16_b512_wp0 --envs 64 --updates 16 --batch 512 --waypoint-reward 0 ;;
+  same)    # the reset convention isolated -- same seed, scenario, env count, both conventions
+    run next_e16 --envs 16 --updates 16 --waypoint-reward 0 --reset-mode next
+    run same_e16 --envs 16 --updates 16 --waypoint-reward 0 --reset-mode same ;;
+  long)
+    run e16_u16_wp0 --envs 16 --updates 16 --waypoint-reward 0 ;;
+esac
