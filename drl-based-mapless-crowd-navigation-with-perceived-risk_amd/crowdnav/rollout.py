@@ -63,13 +63,15 @@ class EpisodeStats:
         return path
 
 
-def rollout(env, agent, n_steps, learn=False, add_noise=True, stats=None, policy=None):
+def rollout(env, agent, n_steps, learn=False, add_noise=True, stats=None, policy=None, auto_reset="next"):
     """Actor-in-the-loop rollout (BASELINE config 3).  Returns total env-steps taken.
     `env` is a crowdnav.env.VecEnv; `agent` a crowdnav.td3.Agent on the same device.
     policy: "mfma" = the whole actor as one libcrowdnav kernel (cn_actor_forward; default when the weights are
     static), "tail" = PyTorch GEMMs + fused output stage (cn_policy_tail; default while learning, since the
     weights change every update), "torch" = plain PyTorch; or a callable `policy(obs, t) -> [N, 2] float32 device
-    tensor` (scripted / replayed actions; `agent` may then be None)."""
+    tensor` (scripted / replayed actions; `agent` may then be None).
+    auto_reset: "next" (default; the fast kernel: a finished env's next launch is its Env.reset, its action is ignored and the
+    launch is neither a transition nor an episode row) or "same" (the reset inside the finishing launch, s' from final_obs)."""
     if policy is None:
         policy = "tail" if learn else "mfma"
     if callable(policy):
@@ -89,12 +91,18 @@ def rollout(env, agent, n_steps, learn=False, add_noise=True, stats=None, policy
         act = policy(obs, t) if act_fn is None else act_fn(obs, add_noise=add_noise)
         if learn:
             prev = obs.clone()
-        obs, reward, done = env.step(act, auto_reset="next")
+        if auto_reset == "next":
+            obs, reward, done = env.step(act, auto_reset="next")
+            if learn:
+                agent.memory.add_masked(prev, act, reward, obs, done, ~resetting)
+            resetting = done.bool()
+        else:
+            obs, reward, done = env.step(act, auto_reset="same", want_final=learn)
+            if learn:
+                agent.memory.add_masked(prev, act, reward, env.final_obs, done, torch.ones_like(resetting))
         if learn:
-            agent.memory.add_masked(prev, act, reward, obs, done, ~resetting)
             agent.memory.sync_len()
             agent.learn(t)
-        resetting = done.bool()
         if stats is not None and bool(done.any()):
             # columns 10..13 keep the finished episode's counters as they stood when Env.step returned done (what TRAIN:142-147
             # reads), terminal step included

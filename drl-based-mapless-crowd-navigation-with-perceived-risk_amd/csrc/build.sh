@@ -6,6 +6,8 @@
 #   build.sh all        both
 #   -ffp-contract=off : no implicit FMA contraction; every fma() in the sources is explicit, which is
 #                       what makes the simulator bit-reproducible against the CPU oracle
+# crowdnav_kernel.hip is compiled as two units: CN_TU=1 (every kernel but the sequence kernels) and CN_TU=2 (the sequence
+# kernels, with -mllvm -disable-machine-licm: see the note above the kernel definitions).
 set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 OUT="$HERE/../lib"
@@ -13,14 +15,23 @@ mkdir -p "$OUT"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-builtin-pow -Wall -Wno-unused-function"
 WHAT="${1:-product}"
+build_lib() {   # $1 = output name, $2.. = extra flags
+  local name="$1"; shift
+  local T; T="$(mktemp -d)"
+  "$HIPCC" $FLAGS ${CN_EXTRA_FLAGS:-} "$@" -DCN_TU=1 -c -o "$T/k1.o" "$HERE/crowdnav_kernel.hip" &
+  "$HIPCC" $FLAGS ${CN_EXTRA_FLAGS:-} "$@" -DCN_TU=2 -mllvm -disable-machine-licm -c -o "$T/k2.o" "$HERE/crowdnav_kernel.hip" &
+  "$HIPCC" $FLAGS ${CN_EXTRA_FLAGS:-} "$@" -c -o "$T/abi.o" "$HERE/crowdnav_abi.hip" &
+  wait
+  # link next to the target and rename: a process that already mapped the old file keeps it, nobody maps a partial one
+  "$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT/.$name.$$" "$T/k1.o" "$T/k2.o" "$T/abi.o"
+  mv -f "$OUT/.$name.$$" "$OUT/$name"
+  rm -rf "$T"
+}
 if [ "$WHAT" = "product" ] || [ "$WHAT" = "all" ]; then
-  # build next to the target and rename: a process that already mapped the old file keeps it, nobody maps a partial one
-  "$HIPCC" $FLAGS ${CN_EXTRA_FLAGS:-} -shared -o "$OUT/.libcrowdnav.so.$$" "$HERE/crowdnav_kernel.hip" "$HERE/crowdnav_abi.hip"
-  mv -f "$OUT/.libcrowdnav.so.$$" "$OUT/libcrowdnav.so"
+  build_lib libcrowdnav.so
   echo "built $OUT/libcrowdnav.so"
 fi
 if [ "$WHAT" = "timing" ] || [ "$WHAT" = "all" ]; then
-  "$HIPCC" $FLAGS -DCN_TIMING -shared -o "$OUT/.libcrowdnav_timing.so.$$" "$HERE/crowdnav_kernel.hip" "$HERE/crowdnav_abi.hip"
-  mv -f "$OUT/.libcrowdnav_timing.so.$$" "$OUT/libcrowdnav_timing.so"
+  build_lib libcrowdnav_timing.so -DCN_TIMING
   echo "built $OUT/libcrowdnav_timing.so (stage time stamps; profiling only)"
 fi

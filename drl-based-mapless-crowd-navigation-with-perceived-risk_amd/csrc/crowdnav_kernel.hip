@@ -2588,12 +2588,19 @@ __device__ __forceinline__ void env_kernel_body(const int env, const int lane, c
 #else
 #define CN_HOT_BOUNDS __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
 #endif
+// Two translation units (csrc/build.sh): CN_TU 1 = every kernel except the sequence kernels, CN_TU 2 = the sequence kernels alone,
+// compiled with -mllvm -disable-machine-licm.  Their step loop wraps the whole step body; MachineLICM hoists every constant and
+// address the body materialises out of that loop and the register allocator then spills them (cn_env_kernel_seq: 155 SGPR + 6
+// VGPR spills, 28 bytes of scratch; without the pass 6 / 0 / 0 and 3 % faster).  Unset = one unit with everything.
+#if !defined(CN_TU) || CN_TU == 1
 extern "C" __global__ void CN_HOT_BOUNDS cn_env_kernel(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, false, 0>(blockIdx.x, threadIdx.x, cn_smem); }
 extern "C" __global__ void CN_HOT_BOUNDS cn_env_kernel_fair(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, false, 0, false, 0, false, true>(blockIdx.x, threadIdx.x, cn_smem); }
 extern "C" __global__ void CN_HOT_BOUNDS cn_env_kernel_s360(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, false, 0, false, 0, false, false, 360>(blockIdx.x, threadIdx.x, cn_smem); }
 extern "C" __global__ void CN_HOT_BOUNDS cn_env_kernel_fair_s360(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, false, 0, false, 0, false, true, 360>(blockIdx.x, threadIdx.x, cn_smem); }
 extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_same(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, true, 0>(blockIdx.x, threadIdx.x, cn_smem); }
 extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_ext(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<true, false, 0>(blockIdx.x, threadIdx.x, cn_smem); }
+#endif
+#if !defined(CN_TU) || CN_TU == 2
 // cn_step_sequence: T control periods per launch with OPEN-LOOP actions (resident in HBM: [T][N][2], or one [N][2] held for T
 // periods).  One wavefront keeps its environment for the whole launch and walks its T steps at its own pace: no launch boundary,
 // no device-wide join between steps -- the launch ends with its slowest wavefront's T steps, not with T x the slowest single
@@ -2618,6 +2625,8 @@ __device__ __forceinline__ void sequence_body()
 extern "C" __global__ void CN_HOT_BOUNDS cn_env_kernel_seq(CnKParams p) { sequence_body<false>(); }
 extern "C" __global__ void CN_HOT_BOUNDS cn_env_kernel_seq_s360(CnKParams p) { sequence_body<false, 360>(); }
 extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_gt_seq(CnKParams p) { sequence_body<true>(); }
+#endif
+#if !defined(CN_TU) || CN_TU == 1
 // risk_mode gt: the perceived-risk features from the simulator's own pedestrians (no segmentation, no tracker)
 extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_gt(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, false, 0, true>(blockIdx.x, threadIdx.x, cn_smem); }
 extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_gt_same(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, true, 0, true>(blockIdx.x, threadIdx.x, cn_smem); }
@@ -3006,4 +3015,5 @@ extern "C" void cn_calib_launch(void* buf, size_t bytes, int width, int write, v
         else hipLaunchKernelGGL(cn_calib_write_kernel<double>, g, b, 0, st, (double*)buf, bytes / 8);
     }
 }
+#endif
 #endif

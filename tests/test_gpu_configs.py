@@ -251,10 +251,11 @@ def test_graphed_td3_update_equals_the_eager_update():
                 np.testing.assert_allclose(v.cpu().numpy(), G["step%d.%s.%s" % (step, k, n)], rtol=5e-4, atol=2e-6, err_msg="step %d %s.%s" % (step, k, n))
 
 
-def test_episode_stats_rows_match_the_reference_run():
+@pytest.mark.parametrize("reset_mode", ["next", "same"])
+def test_episode_stats_rows_match_the_reference_run(reset_mode):
     """SURVEY 8a A33 "pinned by": the batched loop's per-episode rows (EpisodeStats: success, failure, return, steps,
     ego / social safety scores) equal the tuples of the golden run the REFERENCE's Python produced (`train20`: five
-    episodes), the recorded actions replayed through crowdnav.rollout.rollout with same-call auto-reset."""
+    episodes), the recorded actions replayed through crowdnav.rollout.rollout under both reset conventions."""
     import torch
     from crowdnav import Config
     from crowdnav.env import VecEnv
@@ -265,7 +266,21 @@ def test_episode_stats_rows_match_the_reference_run():
     env = VecEnv(Config(n_envs=1, **kw))
     env.set_ped_init(z["ped_init"])
     stats = EpisodeStats()
-    rollout(env, None, len(steps), stats=stats, policy=lambda obs, t: acts[t:t + 1].contiguous())
+    if reset_mode == "same":
+        rollout(env, None, len(steps), stats=stats, policy=lambda obs, t: acts[t:t + 1].contiguous(), auto_reset="same")
+    else:
+        # next-step reset (rollout's default): the launch after a finished episode is the env's Env.reset and ignores its action,
+        # so the recorded action stream pauses for that launch
+        used = [0]
+
+        def policy(obs, t):
+            if t > 0 and bool(env.done[0].item()):
+                return torch.zeros((1, 2), device="cuda")
+            used[0] += 1
+            return acts[used[0] - 1:used[0]].contiguous()
+        n_eps = int(sum(bool(z["done"][i]) for i in steps))
+        rollout(env, None, len(steps) + n_eps - 1, stats=stats, policy=policy)
+        assert used[0] == len(steps)
     # the reference's tuples, episode by episode (TRAIN:142-161)
     want, ret, n = [], 0.0, 0
     for i in steps:
