@@ -29,7 +29,8 @@ EXPORTS = ["cn_abi_version", "cn_last_error", "cn_create", "cn_destroy", "cn_obs
            "cn_set_ped_init", "cn_get_ped_init", "cn_set_ped_preset_vel", "cn_reset", "cn_step", "cn_step_multi", "cn_set_arbitration", "cn_get_arbitration", "cn_kernel_name",
            "cn_observe_external",
            "cn_policy_tail", "cn_actor_pack_weights", "cn_actor_forward", "cn_step_sequence", "cn_get_counters",
-           "cn_get_returns", "cn_debug_env", "cn_lds_bytes", "cn_near_separate", "cn_snapshot_size", "cn_snapshot", "cn_restore"]
+           "cn_get_returns", "cn_debug_env", "cn_lds_bytes", "cn_near_separate", "cn_snapshot_size", "cn_snapshot", "cn_restore",
+           "cn_td3_create", "cn_td3_destroy", "cn_td3_update", "cn_td3_loss_dev", "cn_td3_last_error"]
 
 
 class CnStepIO(C.Structure):
@@ -96,6 +97,26 @@ class CnActorWeights(C.Structure):
     _fields_ = [("w1p", C.c_void_p), ("b1", C.c_void_p), ("w2p", C.c_void_p), ("b2", C.c_void_p), ("w3", C.c_void_p),
                 ("b3", C.c_void_p), ("obs_dim", C.c_int32), ("obs_dim_padded", C.c_int32), ("hidden", C.c_int32),
                 ("reserved", C.c_int32)]
+
+
+class CnTd3Mlp(C.Structure):
+    """Mirror of `cn_td3_mlp`: device pointers to one network's nn.Linear storages."""
+    _fields_ = [(n, C.c_void_p) for n in ("w1", "b1", "w2", "b2", "w3", "b3")]
+
+
+class CnTd3Config(C.Structure):
+    """Mirror of `cn_td3_config` (include/crowdnav.h)."""
+    _fields_ = [("obs_dim", C.c_int32), ("hidden", C.c_int32), ("batch", C.c_int32), ("policy_delay", C.c_int32),
+                ("gamma", C.c_float), ("tau", C.c_float), ("lr_actor", C.c_float), ("lr_critic", C.c_float), ("beta1", C.c_float),
+                ("beta2", C.c_float), ("eps", C.c_float), ("noise_std", C.c_float), ("noise_clip", C.c_float), ("max_v", C.c_float),
+                ("max_w", C.c_float), ("reserved", C.c_float),
+                ("actor", CnTd3Mlp), ("actor_t", CnTd3Mlp), ("q1", CnTd3Mlp), ("q1_t", CnTd3Mlp), ("q2", CnTd3Mlp), ("q2_t", CnTd3Mlp),
+                ("replay_s", C.c_void_p), ("replay_a", C.c_void_p), ("replay_r", C.c_void_p), ("replay_s2", C.c_void_p), ("replay_d", C.c_void_p),
+                ("replay_size_dev", C.c_void_p), ("seed", C.c_uint64)]
+
+
+class CnTd3Batch(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("s", "a", "r", "s2", "d", "target_noise")]
 
 
 class CnSequenceIO(C.Structure):
@@ -193,6 +214,11 @@ def lib():
         L.cn_snapshot_size.argtypes = [vp]; L.cn_snapshot_size.restype = C.c_size_t
         L.cn_snapshot.argtypes = [vp, vp, C.c_size_t]
         L.cn_restore.argtypes = [vp, vp, C.c_size_t]
+        L.cn_td3_create.argtypes = [C.POINTER(CnTd3Config), C.c_int, C.POINTER(vp)]
+        L.cn_td3_destroy.argtypes = [vp]; L.cn_td3_destroy.restype = None
+        L.cn_td3_update.argtypes = [vp, C.c_int, C.POINTER(CnTd3Batch), vp]
+        L.cn_td3_loss_dev.argtypes = [vp]; L.cn_td3_loss_dev.restype = vp
+        L.cn_td3_last_error.restype = C.c_char_p
         _lib = L
     return _lib
 

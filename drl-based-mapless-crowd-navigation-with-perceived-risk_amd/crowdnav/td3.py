@@ -326,6 +326,69 @@ class Agent:
                         cur["step"].fill_(float(prev["step"]))
         torch.cuda.synchronize(dev)
 
+    # ---- the same update as 10 (+ 11) hand-written launches: libcrowdnav's cn_td3_update (csrc/crowdnav_td3.hip) ----------------------
+    def enable_fused_update(self):
+        """Hand the update to cn_td3_update: forward / backward GEMMs of the six networks on the f32 matrix cores, weight gradients
+        folded into the Adam step, TD target / heads / soft updates as small kernels, replay indices and target noise drawn on the
+        device -- 10 launches for the critic step, 11 more with the actor and the targets, against ~150 through PyTorch.  The
+        networks stay these nn.Modules (the kernels step their parameter storages in place); Adam's moments restart from zero
+        inside the library (torch.optim state is not carried over), so call this before training, not in the middle of it."""
+        import ctypes as C
+        from . import _abi
+        if self.device.type != "cuda":
+            raise RuntimeError("enable_fused_update needs a HIP device")
+        if getattr(self, "_td3_h", None):
+            return
+        L = _abi.lib()
+
+        def mlp(m):
+            ps = [m.linear1.weight, m.linear1.bias, m.linear2.weight, m.linear2.bias, m.linear3.weight, m.linear3.bias]
+            assert all(p.is_contiguous() and p.dtype == torch.float32 and p.device == self.device for p in ps)
+            return _abi.CnTd3Mlp(*[p.data_ptr() for p in ps])
+        mem = self.memory
+        og = self.opt_a.param_groups[0]
+        cfg = _abi.CnTd3Config(obs_dim=self.actor.linear1.in_features, hidden=self.actor.linear1.out_features, batch=self.batch_size,
+                               policy_delay=self.policy_delay, gamma=self.gamma, tau=self.tau, lr_actor=og["lr"],
+                               lr_critic=self.opt_q1.param_groups[0]["lr"], beta1=og["betas"][0], beta2=og["betas"][1], eps=og["eps"],
+                               noise_std=self.noise_std, noise_clip=self.noise_clip, max_v=self.max_v, max_w=self.max_w, reserved=0.0,
+                               actor=mlp(self.actor), actor_t=mlp(self.actor_t), q1=mlp(self.q1), q1_t=mlp(self.q1_t), q2=mlp(self.q2),
+                               q2_t=mlp(self.q2_t), replay_s=mem.s.data_ptr(), replay_a=mem.a.data_ptr(), replay_r=mem.r.data_ptr(),
+                               replay_s2=mem.s2.data_ptr(), replay_d=mem.d.data_ptr(), replay_size_dev=mem.size_dev.data_ptr(),
+                               seed=self._noise_seed)
+        h = C.c_void_p()
+        rc = L.cn_td3_create(C.byref(cfg), self._dev_index, C.byref(h))
+        if rc != 0:
+            raise _abi.CrowdNavError("cn_td3_create: %s" % L.cn_td3_last_error().decode())
+        self._td3_h, self._td3_cfg = h, cfg
+        import numpy as np  # noqa: F401
+        self._td3_loss = None
+
+    def _fused_learn(self, step, batch=None, target_noise=None):
+        import ctypes as C
+        from . import _abi
+        L = _abi.lib()
+        st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        bp = None
+        if batch is not None:
+            s, a, r, s2, d = [t.contiguous().float() for t in batch]
+            tn = target_noise.contiguous().float() if target_noise is not None else None
+            self._td3_keep = (s, a, r, s2, d, tn)            # alive until the next call: the launches are asynchronous
+            bp = C.byref(_abi.CnTd3Batch(s.data_ptr(), a.data_ptr(), r.data_ptr(), s2.data_ptr(), d.data_ptr(),
+                                         tn.data_ptr() if tn is not None else None))
+        rc = L.cn_td3_update(self._td3_h, int(step % self.policy_delay == 0), bp, st)
+        if rc != 0:
+            raise _abi.CrowdNavError("cn_td3_update: %s" % L.cn_td3_last_error().decode())
+        return None
+
+    def __del__(self):
+        try:
+            if getattr(self, "_td3_h", None):
+                from . import _abi
+                _abi.lib().cn_td3_destroy(self._td3_h)
+                self._td3_h = None
+        except Exception:
+            pass
+
     def learn(self, step, batch=None, target_noise=None):
         """One TD3 update (TD3:225-285): clipped target-policy noise added to the target actor's action (the
         reference does not re-clip the noisy action to the action bounds, TD3:244-247), min of the two target
@@ -333,6 +396,10 @@ class Agent:
         the three soft updates.  `batch` = (s, a, r[B,1], s2, d[B,1]) and `target_noise` [B,2] (before the clip)
         override the replay sample / the generator -- used by the parity test against the reference's update.
         Returns the first critic's loss as a 0-d tensor (no host synchronisation)."""
+        if getattr(self, "_td3_h", None):
+            if batch is None and len(self.memory) <= self.batch_size:
+                return None
+            return self._fused_learn(step, batch, target_noise)
         if batch is None:
             if len(self.memory) <= self.batch_size:
                 return None

@@ -97,7 +97,9 @@ def train(a):
         ns = os.path.join(a.load, "noise_state_ep%d.txt" % a.load_episode)
         if os.path.exists(ns):           # continue the exploration-noise stream instead of replaying it
             agent.set_noise_state(*[int(x) for x in open(ns).read().split()])
-    if a.graphs:
+    if a.learner == "fused":
+        agent.enable_fused_update()   # cn_td3_update: the update as 10 (+ 11) hand-written launches
+    elif a.graphs:
         agent.enable_graphs()         # a TD3 update as one hipGraph launch (the eager update is launch-bound at batch 128)
     stats = EpisodeStats()
     os.makedirs(a.out, exist_ok=True)
@@ -210,6 +212,7 @@ def main(argv=None):
     ap.add_argument("--wheel-accel", type=float, default=None, help="cn_config.wheel_accel (XACRO:70: 1.0)")
     ap.add_argument("--reset-mode", default="next", choices=["next", "same"], help="next: the fast kernel, reset launches masked out of the replay; same: same-call reset + final_obs")
     ap.add_argument("--graphs", type=int, default=1, help="1: capture the TD3 update into hipGraphs (Agent.enable_graphs)")
+    ap.add_argument("--learner", default="torch", choices=["torch", "fused"], help="torch: the PyTorch update (eager / hipGraph); fused: cn_td3_update (csrc/crowdnav_td3.hip)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--out", default="runs/td3")

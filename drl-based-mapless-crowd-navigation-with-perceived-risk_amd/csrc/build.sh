@@ -21,9 +21,10 @@ build_lib() {   # $1 = output name, $2.. = extra flags
   "$HIPCC" $FLAGS ${CN_EXTRA_FLAGS:-} "$@" -DCN_TU=1 -c -o "$T/k1.o" "$HERE/crowdnav_kernel.hip" &
   "$HIPCC" $FLAGS ${CN_EXTRA_FLAGS:-} "$@" -DCN_TU=2 -mllvm -disable-machine-licm -c -o "$T/k2.o" "$HERE/crowdnav_kernel.hip" &
   "$HIPCC" $FLAGS ${CN_EXTRA_FLAGS:-} "$@" -c -o "$T/abi.o" "$HERE/crowdnav_abi.hip" &
+  "$HIPCC" $FLAGS ${CN_EXTRA_FLAGS:-} "$@" -c -o "$T/td3.o" "$HERE/crowdnav_td3.hip" &
   wait
   # link next to the target and rename: a process that already mapped the old file keeps it, nobody maps a partial one
-  "$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT/.$name.$$" "$T/k1.o" "$T/k2.o" "$T/abi.o"
+  "$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT/.$name.$$" "$T/k1.o" "$T/k2.o" "$T/abi.o" "$T/td3.o"
   mv -f "$OUT/.$name.$$" "$OUT/$name"
   rm -rf "$T"
 }

@@ -1,0 +1,544 @@
+// crowdnav_td3.hip -- the TD3 update (td3.py:225-285 of the reference: Agent.learn) as a short chain of HIP kernels (gfx950).
+//
+// The caller of the hot path.  A vectorised environment makes the learner the bottleneck: through PyTorch one
+// update is ~150 small kernels (1.2 ms as a hipGraph at batch 128).  Here the same arithmetic is 10 launches for the critic
+// step and 11 more when the actor and the targets move, all float32 like the reference:
+//   prep        sample the replay on the device (counter-based indices and target-policy noise), gather [s|a], [s2|.], r, d
+//   gemm F      Y = act(X W^T + b) on the f32 matrix cores (v_mfma_f32_16x16x4_f32), up to four networks per launch
+//   gemm G      dX = (dY W) (.) [H > 0]            (back-propagation through a ReLU layer)
+//   gemm H      dW = dY^T X folded into the Adam step of W (and of b): the gradient never exists in memory
+//   head kernels (linear3 + sigmoid / tanh heads forward, TD target + MSE gradient + linear3 backward, actor-loss chain)
+//   soft        target <- (1 - tau) target + tau local
+// The parameters are the caller's (PyTorch nn.Linear storages, weight [out][in]); Adam's moments and step counters live here.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+#include <new>
+#include <string>
+
+#include "../../include/crowdnav.h"
+#include "crowdnav_device.h"
+
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+namespace {
+
+thread_local std::string g_td3_err;
+int td3_fail(int code, const std::string& msg) { g_td3_err = msg; return code; }
+#define TD3CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return td3_fail(CN_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+
+// ---- the one GEMM kernel ------------------------------------------------------------------------------------------------
+// C[i][j] = sum_r A(i, r) B(r, j), a 32 x 32 tile of C per workgroup of four wavefronts (2 x 2 MFMA tiles of 16 x 16), r in
+// chunks of 32 staged through LDS with the next chunk's global loads in flight.  MODE decides what A, B and the epilogue are:
+//   F  forward          i = row m, j = unit n, r = input k :  A = X[m][k],  B = W[n][k],   C = act(acc + bias[n])
+//   G  backward (data)  i = row m, j = input k, r = unit n :  A = dY[m][n], B = W[n][k],   C = acc * [mask[m][k] > 0]
+//   H  backward (weights) + Adam   i = unit n, j = input k, r = row m :  A = dY[m][n], B = X[m][k],  W[n][k] <- Adam(acc);
+//      the workgroups of the first j-tile also reduce dY over the rows and step the bias
+enum { GEMM_F = 0, GEMM_G = 1, GEMM_H = 2 };
+struct GemmJob {
+    const float* A; const float* B; float* C;      // H: C = the weight being stepped
+    const float* bias;                             // F: bias[n]
+    const float* mask;                             // G: activation the ReLU mask is taken from (same shape / ld as C)
+    float* m; float* v;                            // H: Adam moments of the weight
+    float* bparam; float* bm; float* bv;           // H: bias and its moments
+    const float* adam;                             // H: {lr / (1 - beta1^t), sqrt(1 - beta2^t)} of this optimizer (device)
+    int I, J, R;                                   // extents of i, j, r
+    int lda, ldb, ldc;
+    int relu;
+};
+struct GemmArgs { GemmJob job[4]; float beta1, beta2, eps; };
+
+template <int MODE>
+__global__ void __launch_bounds__(256) td3_gemm_kernel(GemmArgs args)
+{
+    const GemmJob& jb = args.job[blockIdx.z];
+    const int I = jb.I, J = jb.J, R = jb.R;
+    const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+    if (i0 >= I || j0 >= J) return;
+    __shared__ float As[32][33];       // [r][i]
+    __shared__ float Bs[32][33];       // [r][j]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lo = tid & 31, hi = tid >> 5;          // hi: 0..7
+    const float* __restrict__ A = jb.A;
+    const float* __restrict__ B = jb.B;
+    // this thread's four elements of a chunk: along the contiguous direction of the operand in memory
+    //   A: F, G -> A[i * lda + r] (r contiguous): r = lo, i = hi + 8 q;   H -> A[r * lda + i] (i contiguous): i = lo, r = hi + 8 q
+    //   B: F    -> B[j * ldb + r] (r contiguous): r = lo, j = hi + 8 q;   G, H -> B[r * ldb + j] (j contiguous): j = lo, r = hi + 8 q
+    float ra[4], rb[4];
+    auto fetch = [&](int r0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (MODE != GEMM_H) { const int r = r0 + lo, i = i0 + hi + 8 * q; ra[q] = (r < R && i < I) ? A[(size_t)i * jb.lda + r] : 0.f; }
+            else { const int i = i0 + lo, r = r0 + hi + 8 * q; ra[q] = (r < R && i < I) ? A[(size_t)r * jb.lda + i] : 0.f; }
+            if (MODE == GEMM_F) { const int r = r0 + lo, j = j0 + hi + 8 * q; rb[q] = (r < R && j < J) ? B[(size_t)j * jb.ldb + r] : 0.f; }
+            else { const int j = j0 + lo, r = r0 + hi + 8 * q; rb[q] = (r < R && j < J) ? B[(size_t)r * jb.ldb + j] : 0.f; }
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (MODE != GEMM_H) As[lo][hi + 8 * q] = ra[q]; else As[hi + 8 * q][lo] = ra[q];
+            if (MODE == GEMM_F) Bs[lo][hi + 8 * q] = rb[q]; else Bs[hi + 8 * q][lo] = rb[q];
+        }
+    };
+    const int wi = (wave & 1) * 16, wj = (wave >> 1) * 16;
+    const int li = lane & 15, lk = lane >> 4;
+    f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;                                // H: sum over the rows of dY[.][i0 + tid] (threads 0..31 of the first j-tile)
+    fetch(0);
+    for (int r0 = 0; r0 < R; r0 += 32) {
+        stage();
+        __syncthreads();
+        if (r0 + 32 < R) fetch(r0 + 32);
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(As[4 * s + lk][wi + li], Bs[4 * s + lk][wj + li], acc, 0, 0, 0);
+        if (MODE == GEMM_H && blockIdx.x == 0 && tid < 32) {
+#pragma unroll
+            for (int r = 0; r < 32; ++r) bsum += As[r][tid];
+        }
+        __syncthreads();
+    }
+    // epilogue: acc[q] = C[i0 + wi + 4 lk + q][j0 + wj + li]
+    const int j = j0 + wj + li;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int i = i0 + wi + 4 * lk + q;
+        if (i >= I || j >= J) continue;
+        const size_t o = (size_t)i * jb.ldc + j;
+        if (MODE == GEMM_F) {
+            float y = acc[q] + jb.bias[j];
+            if (jb.relu) y = fmaxf(y, 0.f);
+            jb.C[o] = y;
+        } else if (MODE == GEMM_G) {
+            jb.C[o] = jb.mask[o] > 0.f ? acc[q] : 0.f;
+        } else {
+            const float g = acc[q];
+            const float m = args.beta1 * jb.m[o] + (1.f - args.beta1) * g;
+            const float v = args.beta2 * jb.v[o] + (1.f - args.beta2) * g * g;
+            jb.m[o] = m; jb.v[o] = v;
+            jb.C[o] -= jb.adam[0] * m / (sqrtf(v) / jb.adam[1] + args.eps);
+        }
+    }
+    if (MODE == GEMM_H && blockIdx.x == 0 && tid < 32 && i0 + tid < I && jb.bparam) {
+        const int i = i0 + tid;
+        const float g = bsum;
+        const float m = args.beta1 * jb.bm[i] + (1.f - args.beta1) * g;
+        const float v = args.beta2 * jb.bv[i] + (1.f - args.beta2) * g * g;
+        jb.bm[i] = m; jb.bv[i] = v;
+        jb.bparam[i] -= jb.adam[0] * m / (sqrtf(v) / jb.adam[1] + args.eps);
+    }
+}
+
+// ---- small kernels ------------------------------------------------------------------------------------------------------
+struct PrepArgs {
+    const float *rs, *ra, *rr, *rs2, *rd;          // replay ring (rows `obs_dim` / 2 / 1 wide) or the explicit batch
+    const float* noise_in;                         // explicit target-policy noise [B][2] (unit variance, before the clip) or null
+    const int64_t* size_dev;                       // live replay size (device) or null = the rows ARE the batch
+    float *xs, *x2, *r, *d, *noise;                // outputs: [B][D + 2] x 2, [B], [B], [B][2]
+    float* adam;                                   // [2 optimizers][2]: lr / (1 - beta1^t), sqrt(1 - beta2^t)
+    float* steps;                                  // [2] step counters (critics, actor), advanced here
+    unsigned long long* counter;                   // update counter (keys the sampling)
+    uint64_t seed;
+    int B, D, do_actor;
+    float lr_critic, lr_actor, beta1, beta2, noise_std, noise_clip;
+};
+__global__ void __launch_bounds__(256) td3_prep_kernel(PrepArgs p)
+{
+    const int m = blockIdx.x, tid = threadIdx.x, Dc = p.D + 2;
+    const unsigned long long cnt = *p.counter;       // (advanced by td3_tick_kernel, the next launch on the stream)
+    size_t row = (size_t)m;
+    if (p.size_dev) {
+        const unsigned long long size = (unsigned long long)(*p.size_dev > 0 ? *p.size_dev : 1);
+        const uint64_t h = cn_mix64(cn_mix64(p.seed ^ cn_mix64(cnt)) ^ (uint64_t)(uint32_t)m);
+        row = (size_t)(h % size);
+    }
+    const float* s = p.rs + row * (size_t)p.D;
+    const float* s2 = p.rs2 + row * (size_t)p.D;
+    for (int c = tid; c < p.D; c += blockDim.x) {
+        p.xs[(size_t)m * Dc + c] = s[c];
+        p.x2[(size_t)m * Dc + c] = s2[c];
+    }
+    if (tid < 2) {
+        p.xs[(size_t)m * Dc + p.D + tid] = p.ra[row * 2 + tid];
+        float z;
+        if (p.noise_in) z = p.noise_in[(size_t)m * 2 + tid];
+        else {   // Box-Muller on a counter-based pair, keyed by (seed, update counter, row)
+            const uint64_t h = cn_mix64(cn_mix64(p.seed ^ cn_mix64(cnt ^ 0x5bd1e995u)) ^ (uint64_t)(uint32_t)m);
+            const float u1 = ((float)(uint32_t)(h >> 40) + 1.0f) * (1.0f / 16777217.0f);
+            const float u2 = (float)(uint32_t)((h >> 8) & 0xffffffu) * (1.0f / 16777216.0f);
+            const float rr = sqrtf(-2.0f * logf(u1));
+            z = tid == 0 ? rr * cosf(6.28318530718f * u2) : rr * sinf(6.28318530718f * u2);
+        }
+        p.noise[(size_t)m * 2 + tid] = fminf(fmaxf(z * p.noise_std, -p.noise_clip), p.noise_clip);     // TD3:241-242
+    }
+    if (tid == 2) p.r[m] = p.rr[row];
+    if (tid == 3) p.d[m] = p.rd[row];
+}
+// one thread: advance the update counter and the Adam step counters, publish this update's bias corrections
+__global__ void td3_tick_kernel(PrepArgs p)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    *p.counter += 1ull;
+    p.steps[0] += 1.f;
+    p.adam[0] = p.lr_critic / (1.f - powf(p.beta1, p.steps[0]));
+    p.adam[1] = sqrtf(1.f - powf(p.beta2, p.steps[0]));
+    if (p.do_actor) {
+        p.steps[1] += 1.f;
+        p.adam[2] = p.lr_actor / (1.f - powf(p.beta1, p.steps[1]));
+        p.adam[3] = sqrtf(1.f - powf(p.beta2, p.steps[1]));
+    }
+}
+
+// Actor.forward's last layer and heads (TD3:101-105) for a batch: logits = h2 W3^T + b3, action = (sigmoid max_v, tanh max_w)
+// (+ the clipped target-policy noise, not re-clipped to the action bounds: TD3:244-247) written into columns D, D + 1 of x.
+__global__ void __launch_bounds__(256) td3_actor_head_kernel(const float* __restrict__ h2, const float* __restrict__ W3, const float* __restrict__ b3,
+                                                             const float* __restrict__ noise, float* __restrict__ x, float* __restrict__ logits,
+                                                             int B, int H, int Dc, float max_v, float max_w)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 2 * B) return;
+    const int m = t >> 1, o = t & 1;
+    float acc = b3[o];
+    const float* hr = h2 + (size_t)m * H;
+    const float* w = W3 + (size_t)o * H;
+    for (int n = 0; n < H; ++n) acc = fmaf(hr[n], w[n], acc);
+    if (logits) logits[t] = acc;
+    float a = o == 0 ? max_v / (1.f + expf(-acc)) : max_w * tanhf(acc);
+    if (noise) a += noise[t];
+    x[(size_t)m * Dc + (Dc - 2) + o] = a;
+}
+// Critic.forward's last layer for up to four critics: q[z][m] = h2[z][m] . W3[z] + b3[z]
+struct QHeadArgs { const float* h2[4]; const float* W3[4]; const float* b3[4]; float* q[4]; int B, H, nz; };
+__global__ void __launch_bounds__(256) td3_q_head_kernel(QHeadArgs a)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= a.nz * a.B) return;
+    const int z = t / a.B, m = t - z * a.B;
+    float acc = a.b3[z][0];
+    const float* hr = a.h2[z] + (size_t)m * a.H;
+    for (int n = 0; n < a.H; ++n) acc = fmaf(hr[n], a.W3[z][n], acc);
+    a.q[z][m] = acc;
+}
+// TD target, MSE gradient and linear3's backward + Adam step for the two critics (one workgroup per critic):
+//   y = r + (1 - d) gamma min(q1_t, q2_t)  (TD3:249-252);  loss_z = mean (q_z - y)^2;  dq_z = 2 (q_z - y) / B
+//   dz2_z[m][n] = dq_z[m] W3_z[n] [h2_z[m][n] > 0];  dW3_z[n] = sum_m dq_z[m] h2_z[m][n];  db3_z = sum_m dq_z[m]
+struct CriticHeadBwdArgs {
+    const float *r, *d, *qt1, *qt2;
+    const float* q[2]; const float* h2[2]; float* dz2[2];
+    float* W3[2]; float* b3[2]; float* m3[2]; float* v3[2]; float* mb3[2]; float* vb3[2];
+    const float* adam; float* loss;
+    int B, H; float gamma, beta1, beta2, eps;
+};
+__global__ void __launch_bounds__(256) td3_critic_head_bwd_kernel(CriticHeadBwdArgs a)
+{
+    extern __shared__ float dq[];                   // [B]
+    const int z = blockIdx.x, tid = threadIdx.x;
+    float part = 0.f;
+    for (int m = tid; m < a.B; m += blockDim.x) {
+        const float y = a.r[m] + (1.f - a.d[m]) * a.gamma * fminf(a.qt1[m], a.qt2[m]);
+        const float e = a.q[z][m] - y;
+        dq[m] = 2.f * e / (float)a.B;
+        part += e * e;
+    }
+    __syncthreads();
+    if (z == 0) {                                    // the first critic's loss (what Agent.learn returns), by one thread
+        __shared__ float red[256];
+        red[tid] = part;
+        __syncthreads();
+        if (tid == 0) { float s = 0.f; for (int i = 0; i < (int)blockDim.x; ++i) s += red[i]; a.loss[0] = s / (float)a.B; }
+    }
+    for (int n = tid; n < a.H; n += blockDim.x) {
+        const float w = a.W3[z][n];
+        float g = 0.f;
+        for (int m = 0; m < a.B; ++m) {
+            const float h = a.h2[z][(size_t)m * a.H + n];
+            a.dz2[z][(size_t)m * a.H + n] = h > 0.f ? dq[m] * w : 0.f;
+            g = fmaf(dq[m], h, g);
+        }
+        const float mm = a.beta1 * a.m3[z][n] + (1.f - a.beta1) * g;
+        const float vv = a.beta2 * a.v3[z][n] + (1.f - a.beta2) * g * g;
+        a.m3[z][n] = mm; a.v3[z][n] = vv;
+        a.W3[z][n] = w - a.adam[0] * mm / (sqrtf(vv) / a.adam[1] + a.eps);
+    }
+    if (tid == 0) {
+        float g = 0.f;
+        for (int m = 0; m < a.B; ++m) g += dq[m];
+        const float mm = a.beta1 * a.mb3[z][0] + (1.f - a.beta1) * g;
+        const float vv = a.beta2 * a.vb3[z][0] + (1.f - a.beta2) * g * g;
+        a.mb3[z][0] = mm; a.vb3[z][0] = vv;
+        a.b3[z][0] -= a.adam[0] * mm / (sqrtf(vv) / a.adam[1] + a.eps);
+    }
+}
+// actor loss -mean Q1(s, pi(s)) (TD3:268-269), first link of the chain: d/dh2 of the critic, dz2[m][n] = -(1 / B) W3[n] [h2[m][n] > 0]
+__global__ void __launch_bounds__(256) td3_policy_dz2_kernel(const float* __restrict__ h2, const float* __restrict__ W3, float* __restrict__ dz2, int B, int H)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * H) return;
+    const int n = t % H;
+    dz2[t] = h2[t] > 0.f ? -W3[n] / (float)B : 0.f;
+}
+// ... through the critic's first layer to the action (the two action columns of W1), through the heads' derivatives to the
+// logits, then linear3 of the ACTOR backward + its Adam step (one workgroup):
+//   da[m][o] = sum_n dz1q[m][n] W1q[n][D + o];  dlogit = da (.) (max_v s (1 - s), max_w (1 - t^2))
+//   dz2a[m][n] = sum_o dlogit[m][o] W3a[o][n] [h2a[m][n] > 0];  dW3a[o][n] = sum_m dlogit[m][o] h2a[m][n];  db3a[o] = sum_m dlogit[m][o]
+struct ActorHeadBwdArgs {
+    const float *dz1q, *W1q, *logits, *h2a; float* dz2a;
+    float *W3, *b3, *m3, *v3, *mb3, *vb3;
+    const float* adam;
+    int B, H, Dc; float max_v, max_w, beta1, beta2, eps;
+};
+__global__ void __launch_bounds__(256) td3_actor_head_bwd_kernel(ActorHeadBwdArgs a)
+{
+    extern __shared__ float dl[];                   // [B][2]
+    const int tid = threadIdx.x;
+    for (int t = tid; t < 2 * a.B; t += blockDim.x) {
+        const int m = t >> 1, o = t & 1;
+        float da = 0.f;
+        for (int n = 0; n < a.H; ++n) da = fmaf(a.dz1q[(size_t)m * a.H + n], a.W1q[(size_t)n * a.Dc + (a.Dc - 2) + o], da);
+        const float lg = a.logits[t];
+        float dh;
+        if (o == 0) { const float s = 1.f / (1.f + expf(-lg)); dh = a.max_v * s * (1.f - s); }
+        else { const float th = tanhf(lg); dh = a.max_w * (1.f - th * th); }
+        dl[t] = da * dh;
+    }
+    __syncthreads();
+    for (int n = tid; n < a.H; n += blockDim.x) {
+        const float w0 = a.W3[n], w1 = a.W3[a.H + n];
+        float g0 = 0.f, g1 = 0.f;
+        for (int m = 0; m < a.B; ++m) {
+            const float h = a.h2a[(size_t)m * a.H + n];
+            a.dz2a[(size_t)m * a.H + n] = h > 0.f ? fmaf(dl[2 * m + 1], w1, dl[2 * m] * w0) : 0.f;
+            g0 = fmaf(dl[2 * m], h, g0); g1 = fmaf(dl[2 * m + 1], h, g1);
+        }
+        const float g[2] = {g0, g1};
+        for (int o = 0; o < 2; ++o) {
+            const size_t ix = (size_t)o * a.H + n;
+            const float mm = a.beta1 * a.m3[ix] + (1.f - a.beta1) * g[o];
+            const float vv = a.beta2 * a.v3[ix] + (1.f - a.beta2) * g[o] * g[o];
+            a.m3[ix] = mm; a.v3[ix] = vv;
+            a.W3[ix] -= a.adam[2] * mm / (sqrtf(vv) / a.adam[3] + a.eps);
+        }
+    }
+    if (tid < 2) {
+        float g = 0.f;
+        for (int m = 0; m < a.B; ++m) g += dl[2 * m + tid];
+        const float mm = a.beta1 * a.mb3[tid] + (1.f - a.beta1) * g;
+        const float vv = a.beta2 * a.vb3[tid] + (1.f - a.beta2) * g * g;
+        a.mb3[tid] = mm; a.vb3[tid] = vv;
+        a.b3[tid] -= a.adam[2] * mm / (sqrtf(vv) / a.adam[3] + a.eps);
+    }
+}
+// soft updates (TD3:287-299): target <- target (1 - tau) + local tau, 18 tensors in one launch
+struct SoftArgs { float* dst[18]; const float* src[18]; int n[18]; float tau; };
+__global__ void __launch_bounds__(256) td3_soft_kernel(SoftArgs a)
+{
+    const int k = blockIdx.y;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n[k]; i += gridDim.x * blockDim.x)
+        a.dst[k][i] = a.dst[k][i] * (1.f - a.tau) + a.src[k][i] * a.tau;
+}
+
+}  // namespace
+
+// ---- host side ------------------------------------------------------------------------------------------------------------
+struct cn_td3_s {
+    cn_td3_config cfg;
+    int device;
+    int B, D, Dc, H;
+    float* pool = nullptr;         // one allocation for the whole workspace
+    // batch
+    float *xs, *x2, *r, *d, *noise, *logits;
+    float *t_h1, *t_h2;            // target actor
+    float *c_h1[4], *c_h2[4], *c_q[4];      // q1, q2, q1_t, q2_t
+    float *a_h1, *a_h2;            // actor
+    float *dz2[2], *dz1[2];
+    float* loss;
+    float* adam;                   // [4]
+    float* steps;                  // [2]
+    unsigned long long* counter;
+    // Adam moments: actor, q1, q2 x {w1, b1, w2, b2, w3, b3} x {m, v}
+    float* mom[3][6][2];
+};
+
+namespace {
+struct DevScope {
+    int prev = -1, want;
+    explicit DevScope(int dev) : want(dev) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; if (prev != want) (void)hipSetDevice(want); }
+    ~DevScope() { if (prev >= 0 && prev != want) (void)hipSetDevice(prev); }
+};
+const cn_td3_mlp& net_of(const cn_td3_config& c, int k) { return k == 0 ? c.actor : k == 1 ? c.q1 : c.q2; }
+float* param_of(const cn_td3_mlp& n, int j) { return j == 0 ? n.w1 : j == 1 ? n.b1 : j == 2 ? n.w2 : j == 3 ? n.b2 : j == 4 ? n.w3 : n.b3; }
+size_t param_count(const cn_td3_s* h, int net, int j)
+{
+    const size_t in1 = net == 0 ? (size_t)h->D : (size_t)h->Dc, out3 = net == 0 ? 2 : 1, H = (size_t)h->H;
+    switch (j) { case 0: return H * in1; case 1: return H; case 2: return H * H; case 3: return H; case 4: return out3 * H; default: return out3; }
+}
+template <int MODE>
+void launch_gemm(const GemmArgs& ga, int njobs, hipStream_t st)
+{
+    int gx = 0, gy = 0;
+    for (int z = 0; z < njobs; ++z) { const int x_ = (ga.job[z].J + 31) / 32, y_ = (ga.job[z].I + 31) / 32; gx = x_ > gx ? x_ : gx; gy = y_ > gy ? y_ : gy; }
+    hipLaunchKernelGGL(td3_gemm_kernel<MODE>, dim3(gx, gy, njobs), dim3(256), 0, st, ga);
+}
+}  // namespace
+
+extern "C" const char* cn_td3_last_error(void) { return g_td3_err.c_str(); }
+
+extern "C" int cn_td3_create(const cn_td3_config* cfg, int device, cn_td3_handle* out)
+{
+    if (!cfg || !out) return td3_fail(CN_ERR_ARG, "cn_td3_create: null argument");
+    const cn_td3_config& c = *cfg;
+    if (c.obs_dim < 1 || c.hidden < 1 || c.batch < 1 || c.batch > 4096 || c.hidden > 4096 || c.policy_delay < 1)
+        return td3_fail(CN_ERR_CONFIG, "cn_td3_create: obs_dim / hidden / batch / policy_delay out of range");
+    const cn_td3_mlp* nets[6] = {&c.actor, &c.actor_t, &c.q1, &c.q1_t, &c.q2, &c.q2_t};
+    for (const cn_td3_mlp* n : nets)
+        if (!n->w1 || !n->b1 || !n->w2 || !n->b2 || !n->w3 || !n->b3) return td3_fail(CN_ERR_ARG, "cn_td3_create: null parameter pointer");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return td3_fail(CN_ERR_NO_DEVICE, "cn_td3_create: no HIP device (libcrowdnav has no CPU fallback)");
+    if (device < 0 || device >= ndev) return td3_fail(CN_ERR_ARG, "cn_td3_create: bad device ordinal");
+    DevScope scope(device);
+    cn_td3_s* h = new (std::nothrow) cn_td3_s();
+    if (!h) return td3_fail(CN_ERR_ARG, "cn_td3_create: out of memory");
+    h->cfg = c; h->device = device; h->B = c.batch; h->D = c.obs_dim; h->Dc = c.obs_dim + 2; h->H = c.hidden;
+    const size_t B = h->B, Dc = h->Dc, H = h->H;
+    size_t words = 2 * B * Dc + 2 * B + 2 * B + 2 * B          // xs, x2, r, d, noise, logits
+                   + 2 * B * H + 4 * (2 * B * H + B) + 2 * B * H + 4 * B * H + 1 + 4 + 2 + 2;   // t_h, c_h / c_q, a_h, dz, loss, adam, steps, counter
+    size_t mom_words = 0;
+    for (int net = 0; net < 3; ++net) for (int j = 0; j < 6; ++j) mom_words += 2 * param_count(h, net, j);
+    hipError_t e = hipMalloc(&h->pool, (words + mom_words) * sizeof(float));
+    if (e != hipSuccess) { delete h; return td3_fail(CN_ERR_HIP, std::string("cn_td3_create: hipMalloc: ") + hipGetErrorString(e)); }
+    e = hipMemset(h->pool, 0, (words + mom_words) * sizeof(float));
+    if (e != hipSuccess) { (void)hipFree(h->pool); delete h; return td3_fail(CN_ERR_HIP, std::string("cn_td3_create: hipMemset: ") + hipGetErrorString(e)); }
+    float* q = h->pool;
+    auto take = [&](size_t n) { float* r_ = q; q += n; return r_; };
+    h->counter = (unsigned long long*)take(2);       // first: 8-byte aligned
+    h->xs = take(B * Dc); h->x2 = take(B * Dc); h->r = take(B); h->d = take(B); h->noise = take(2 * B); h->logits = take(2 * B);
+    h->t_h1 = take(B * H); h->t_h2 = take(B * H);
+    for (int z = 0; z < 4; ++z) { h->c_h1[z] = take(B * H); h->c_h2[z] = take(B * H); h->c_q[z] = take(B); }
+    h->a_h1 = take(B * H); h->a_h2 = take(B * H);
+    for (int z = 0; z < 2; ++z) { h->dz2[z] = take(B * H); h->dz1[z] = take(B * H); }
+    h->loss = take(1); h->adam = take(4); h->steps = take(2);
+    for (int net = 0; net < 3; ++net) for (int j = 0; j < 6; ++j) for (int k = 0; k < 2; ++k) h->mom[net][j][k] = take(param_count(h, net, j));
+    *out = h;
+    return CN_OK;
+}
+
+extern "C" void cn_td3_destroy(cn_td3_handle h)
+{
+    if (!h) return;
+    DevScope scope(h->device);
+    (void)hipFree(h->pool);
+    delete h;
+}
+
+extern "C" const float* cn_td3_loss_dev(cn_td3_handle h) { return h ? h->loss : nullptr; }
+
+extern "C" int cn_td3_update(cn_td3_handle h, int do_actor, const cn_td3_batch* batch, void* stream)
+{
+    if (!h) return td3_fail(CN_ERR_ARG, "cn_td3_update: null handle");
+    const cn_td3_config& c = h->cfg;
+    if (!batch && (!c.replay_s || !c.replay_a || !c.replay_r || !c.replay_s2 || !c.replay_d || !c.replay_size_dev))
+        return td3_fail(CN_ERR_ARG, "cn_td3_update: no explicit batch and no replay ring in the configuration");
+    if (batch && (!batch->s || !batch->a || !batch->r || !batch->s2 || !batch->d)) return td3_fail(CN_ERR_ARG, "cn_td3_update: null batch pointer");
+    DevScope scope(h->device);
+    hipStream_t st = (hipStream_t)stream;
+    const int B = h->B, D = h->D, Dc = h->Dc, H = h->H;
+    // 0. sample / gather, noise, Adam constants
+    PrepArgs pa;
+    memset(&pa, 0, sizeof(pa));
+    if (batch) { pa.rs = batch->s; pa.ra = batch->a; pa.rr = batch->r; pa.rs2 = batch->s2; pa.rd = batch->d; pa.noise_in = batch->target_noise; pa.size_dev = nullptr; }
+    else { pa.rs = c.replay_s; pa.ra = c.replay_a; pa.rr = c.replay_r; pa.rs2 = c.replay_s2; pa.rd = c.replay_d; pa.noise_in = nullptr; pa.size_dev = c.replay_size_dev; }
+    pa.xs = h->xs; pa.x2 = h->x2; pa.r = h->r; pa.d = h->d; pa.noise = h->noise; pa.adam = h->adam; pa.steps = h->steps; pa.counter = h->counter;
+    pa.seed = c.seed; pa.B = B; pa.D = D; pa.do_actor = do_actor ? 1 : 0;
+    pa.lr_critic = c.lr_critic; pa.lr_actor = c.lr_actor; pa.beta1 = c.beta1; pa.beta2 = c.beta2; pa.noise_std = c.noise_std; pa.noise_clip = c.noise_clip;
+    hipLaunchKernelGGL(td3_prep_kernel, dim3(B), dim3(256), 0, st, pa);
+    hipLaunchKernelGGL(td3_tick_kernel, dim3(1), dim3(64), 0, st, pa);
+
+    auto fwd_job = [&](GemmJob& j, const float* X, int ldx, int K, const float* W, const float* b, float* Y) {
+        memset(&j, 0, sizeof(j));
+        j.A = X; j.B = W; j.C = Y; j.bias = b; j.I = B; j.J = H; j.R = K; j.lda = ldx; j.ldb = K; j.ldc = H; j.relu = 1;
+    };
+    auto bwd_data_job = [&](GemmJob& j, const float* dY, const float* W, const float* mask, float* dX) {   // through a hidden layer (H x H)
+        memset(&j, 0, sizeof(j));
+        j.A = dY; j.B = W; j.C = dX; j.mask = mask; j.I = B; j.J = H; j.R = H; j.lda = H; j.ldb = H; j.ldc = H;
+    };
+    auto wgrad_job = [&](GemmJob& j, const float* dY, const float* X, int ldx, int K, float* W, float* bparam, int net, int wj, const float* adam) {
+        memset(&j, 0, sizeof(j));
+        j.A = dY; j.B = X; j.C = W; j.I = H; j.J = K; j.R = B; j.lda = H; j.ldb = ldx; j.ldc = K;
+        j.m = h->mom[net][wj][0]; j.v = h->mom[net][wj][1]; j.bparam = bparam; j.bm = h->mom[net][wj + 1][0]; j.bv = h->mom[net][wj + 1][1]; j.adam = adam;
+    };
+    GemmArgs ga;
+    ga.beta1 = c.beta1; ga.beta2 = c.beta2; ga.eps = c.eps;
+    // 1-3. target actor on s2 -> a2 = pi_t(s2) + clipped noise, into x2's action columns (TD3:238-247)
+    fwd_job(ga.job[0], h->x2, Dc, D, c.actor_t.w1, c.actor_t.b1, h->t_h1); launch_gemm<GEMM_F>(ga, 1, st);
+    fwd_job(ga.job[0], h->t_h1, H, H, c.actor_t.w2, c.actor_t.b2, h->t_h2); launch_gemm<GEMM_F>(ga, 1, st);
+    hipLaunchKernelGGL(td3_actor_head_kernel, dim3((2 * B + 255) / 256), dim3(256), 0, st, h->t_h2, c.actor_t.w3, c.actor_t.b3, h->noise, h->x2,
+                       (float*)nullptr, B, H, Dc, c.max_v, c.max_w);
+    // 4-6. the four critics forward: q1, q2 on (s, a); q1_t, q2_t on (s2, a2)
+    const cn_td3_mlp* crit[4] = {&c.q1, &c.q2, &c.q1_t, &c.q2_t};
+    for (int z = 0; z < 4; ++z) fwd_job(ga.job[z], z < 2 ? h->xs : h->x2, Dc, Dc, crit[z]->w1, crit[z]->b1, h->c_h1[z]);
+    launch_gemm<GEMM_F>(ga, 4, st);
+    for (int z = 0; z < 4; ++z) fwd_job(ga.job[z], h->c_h1[z], H, H, crit[z]->w2, crit[z]->b2, h->c_h2[z]);
+    launch_gemm<GEMM_F>(ga, 4, st);
+    QHeadArgs qa;
+    for (int z = 0; z < 4; ++z) { qa.h2[z] = h->c_h2[z]; qa.W3[z] = crit[z]->w3; qa.b3[z] = crit[z]->b3; qa.q[z] = h->c_q[z]; }
+    qa.B = B; qa.H = H; qa.nz = 4;
+    hipLaunchKernelGGL(td3_q_head_kernel, dim3((4 * B + 255) / 256), dim3(256), 0, st, qa);
+    // 7. TD target, MSE gradients, linear3 backward + Adam (both critics)
+    CriticHeadBwdArgs ca;
+    ca.r = h->r; ca.d = h->d; ca.qt1 = h->c_q[2]; ca.qt2 = h->c_q[3];
+    for (int z = 0; z < 2; ++z) {
+        ca.q[z] = h->c_q[z]; ca.h2[z] = h->c_h2[z]; ca.dz2[z] = h->dz2[z]; ca.W3[z] = crit[z]->w3; ca.b3[z] = crit[z]->b3;
+        ca.m3[z] = h->mom[1 + z][4][0]; ca.v3[z] = h->mom[1 + z][4][1]; ca.mb3[z] = h->mom[1 + z][5][0]; ca.vb3[z] = h->mom[1 + z][5][1];
+    }
+    ca.adam = h->adam; ca.loss = h->loss; ca.B = B; ca.H = H; ca.gamma = c.gamma; ca.beta1 = c.beta1; ca.beta2 = c.beta2; ca.eps = c.eps;
+    hipLaunchKernelGGL(td3_critic_head_bwd_kernel, dim3(2), dim3(256), B * sizeof(float), st, ca);
+    // 8. through the second hidden layer: dz1 = (dz2 W2) (.) [h1 > 0]   (W2 is read here, stepped in 9)
+    for (int z = 0; z < 2; ++z) bwd_data_job(ga.job[z], h->dz2[z], crit[z]->w2, h->c_h1[z], h->dz1[z]);
+    launch_gemm<GEMM_G>(ga, 2, st);
+    // 9. weight gradients folded into Adam: W2, b2, W1, b1 of both critics
+    for (int z = 0; z < 2; ++z) {
+        wgrad_job(ga.job[z], h->dz2[z], h->c_h1[z], H, H, crit[z]->w2, crit[z]->b2, 1 + z, 2, h->adam);
+        wgrad_job(ga.job[2 + z], h->dz1[z], h->xs, Dc, Dc, crit[z]->w1, crit[z]->b1, 1 + z, 0, h->adam);
+    }
+    launch_gemm<GEMM_H>(ga, 4, st);
+    if (do_actor) {
+        // 10-12. pi(s) into xs's action columns (the batch's own actions are not needed any more)
+        fwd_job(ga.job[0], h->xs, Dc, D, c.actor.w1, c.actor.b1, h->a_h1); launch_gemm<GEMM_F>(ga, 1, st);
+        fwd_job(ga.job[0], h->a_h1, H, H, c.actor.w2, c.actor.b2, h->a_h2); launch_gemm<GEMM_F>(ga, 1, st);
+        hipLaunchKernelGGL(td3_actor_head_kernel, dim3((2 * B + 255) / 256), dim3(256), 0, st, h->a_h2, c.actor.w3, c.actor.b3, (const float*)nullptr,
+                           h->xs, h->logits, B, H, Dc, c.max_v, c.max_w);
+        // 13-14. the UPDATED first critic on (s, pi(s)) (TD3:268)
+        fwd_job(ga.job[0], h->xs, Dc, Dc, c.q1.w1, c.q1.b1, h->c_h1[0]); launch_gemm<GEMM_F>(ga, 1, st);
+        fwd_job(ga.job[0], h->c_h1[0], H, H, c.q1.w2, c.q1.b2, h->c_h2[0]); launch_gemm<GEMM_F>(ga, 1, st);
+        // 15-17. -mean Q back to the action, through the heads, linear3 of the actor + Adam
+        hipLaunchKernelGGL(td3_policy_dz2_kernel, dim3((B * H + 255) / 256), dim3(256), 0, st, h->c_h2[0], c.q1.w3, h->dz2[0], B, H);
+        bwd_data_job(ga.job[0], h->dz2[0], c.q1.w2, h->c_h1[0], h->dz1[0]); launch_gemm<GEMM_G>(ga, 1, st);
+        ActorHeadBwdArgs aa;
+        aa.dz1q = h->dz1[0]; aa.W1q = c.q1.w1; aa.logits = h->logits; aa.h2a = h->a_h2; aa.dz2a = h->dz2[1];
+        aa.W3 = c.actor.w3; aa.b3 = c.actor.b3; aa.m3 = h->mom[0][4][0]; aa.v3 = h->mom[0][4][1]; aa.mb3 = h->mom[0][5][0]; aa.vb3 = h->mom[0][5][1];
+        aa.adam = h->adam; aa.B = B; aa.H = H; aa.Dc = Dc; aa.max_v = c.max_v; aa.max_w = c.max_w; aa.beta1 = c.beta1; aa.beta2 = c.beta2; aa.eps = c.eps;
+        hipLaunchKernelGGL(td3_actor_head_bwd_kernel, dim3(1), dim3(256), 2 * B * sizeof(float), st, aa);
+        // 18-19. the actor's hidden layers
+        bwd_data_job(ga.job[0], h->dz2[1], c.actor.w2, h->a_h1, h->dz1[1]); launch_gemm<GEMM_G>(ga, 1, st);
+        wgrad_job(ga.job[0], h->dz2[1], h->a_h1, H, H, c.actor.w2, c.actor.b2, 0, 2, h->adam + 2);
+        wgrad_job(ga.job[1], h->dz1[1], h->xs, Dc, D, c.actor.w1, c.actor.b1, 0, 0, h->adam + 2);
+        launch_gemm<GEMM_H>(ga, 2, st);
+        // 20. soft updates of the three targets
+        SoftArgs sa;
+        const cn_td3_mlp* loc[3] = {&c.q1, &c.q2, &c.actor};
+        const cn_td3_mlp* tgt[3] = {&c.q1_t, &c.q2_t, &c.actor_t};
+        const int netid[3] = {1, 2, 0};
+        int k = 0, nmax = 0;
+        for (int t = 0; t < 3; ++t)
+            for (int j = 0; j < 6; ++j, ++k) {
+                sa.dst[k] = param_of(*tgt[t], j); sa.src[k] = param_of(*loc[t], j); sa.n[k] = (int)param_count(h, netid[t], j);
+                nmax = sa.n[k] > nmax ? sa.n[k] : nmax;
+            }
+        sa.tau = c.tau;
+        hipLaunchKernelGGL(td3_soft_kernel, dim3((nmax + 255) / 256 < 64 ? (nmax + 255) / 256 : 64, 18), dim3(256), 0, st, sa);
+    }
+    TD3CHK(hipGetLastError());
+    return CN_OK;
+}

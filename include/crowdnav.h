@@ -259,6 +259,47 @@ int cn_actor_pack_weights(const float* wt_dev, int k_rows, float* packed_dev, in
 int cn_actor_forward(const cn_actor_weights* w, const float* obs, float* action, int n, float max_v, float max_w,
                      float sigma, uint64_t seed, uint64_t counter, int device, void* stream);
 
+/* The TD3 update -- Agent.learn (td3.py:225-285) with the hyper-parameters of start_td3_training.py:62-72 -- as a short chain
+ * of launches on the caller's stream (crowdnav_td3.hip): the forward and backward GEMMs of the six 3-layer networks on the f32
+ * matrix cores, weight gradients folded into the Adam step (a gradient never exists in memory), the TD target / MSE gradient /
+ * heads as small kernels, replay sampling and target-policy noise drawn on the device.  10 launches for the critic step, 11
+ * more when the actor and the targets move (every policy_delay-th update); through PyTorch the same update is ~150 kernels.
+ * The parameters stay the caller's: device pointers to the nn.Linear storages (weight [out][in] row-major float32, bias
+ * [out]) of actor / critics and their targets, stepped in place.  Adam's moments and step counters are the handle's (zero at
+ * cn_td3_create, like a fresh torch.optim.Adam).  Arithmetic: float32 throughout like the reference; same formulas as
+ * torch.optim.Adam (no weight decay, no amsgrad) and F.mse_loss; results agree with the PyTorch update up to summation order. */
+typedef struct cn_td3_mlp { float *w1, *b1, *w2, *b2, *w3, *b3; } cn_td3_mlp;   /* Linear(in, H) - ReLU - Linear(H, H) - ReLU - Linear(H, out) */
+typedef struct cn_td3_config {
+    int32_t obs_dim;         /* actor input width (TRAIN:88 -> 398); the critics take obs_dim + 2 (TD3:114) */
+    int32_t hidden;          /* TRAIN:65 -> 256 */
+    int32_t batch;           /* TRAIN:62 -> 128 */
+    int32_t policy_delay;    /* TRAIN:72 -> 2 (the caller passes do_actor itself; kept for the record) */
+    float gamma, tau;        /* td3.yaml -> 0.99, 0.005 */
+    float lr_actor, lr_critic, beta1, beta2, eps;   /* 3e-4, 3e-4, torch.optim.Adam's 0.9, 0.999, 1e-8 */
+    float noise_std, noise_clip;                    /* TRAIN:70-71 -> 0.2, 0.5 (target-policy smoothing, TD3:240-243) */
+    float max_v, max_w;                             /* TRAIN:67-68 -> 0.22, 2.0 (the actor's heads, TD3:103-104) */
+    float reserved;
+    cn_td3_mlp actor, actor_t, q1, q1_t, q2, q2_t;
+    /* the replay ring on the device (rows obs_dim / 2 / 1 / obs_dim / 1 floats wide; done as 0 / 1) and its live size (an int64
+     * on the device, read at update time: indices are drawn uniformly below it).  May all be NULL when every update passes
+     * an explicit batch. */
+    const float *replay_s, *replay_a, *replay_r, *replay_s2, *replay_d;
+    const int64_t* replay_size_dev;
+    uint64_t seed;           /* keys the replay indices and the target-policy noise with the handle's update counter */
+} cn_td3_config;
+typedef struct cn_td3_batch {   /* an explicit batch instead of a replay sample (parity tests): [B, obs_dim], [B, 2], [B], [B, obs_dim], [B] */
+    const float *s, *a, *r, *s2, *d;
+    const float* target_noise;   /* [B, 2] unit-variance noise BEFORE the scale and clip (TD3:240-242), or NULL = drawn on the device */
+} cn_td3_batch;
+typedef struct cn_td3_s* cn_td3_handle;
+int cn_td3_create(const cn_td3_config* cfg, int device, cn_td3_handle* out);
+void cn_td3_destroy(cn_td3_handle h);
+/* One update.  do_actor != 0: also the actor step and the three soft updates (TD3:264-285).  batch NULL = sample the replay.
+ * Enqueues only (capturable into a hipGraph). */
+int cn_td3_update(cn_td3_handle h, int do_actor, const cn_td3_batch* batch, void* stream);
+const float* cn_td3_loss_dev(cn_td3_handle h);      /* device pointer: the first critic's MSE loss of the last update */
+const char* cn_td3_last_error(void);
+
 /* n_steps calls of cn_step (auto_reset = 2, the next-step reset convention) with OPEN-LOOP actions -- scripted or recorded
  * actions, action repeat, the uniform-random warm-up phase of an off-policy learner -- as ONE launch: a wavefront keeps its
  * environment for the whole launch and walks its steps at its own pace (no launch boundary and no device-wide join between

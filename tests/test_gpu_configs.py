@@ -252,6 +252,76 @@ def test_graphed_td3_update_equals_the_eager_update():
 
 
 @pytest.mark.parametrize("reset_mode", ["next", "same"])
+@pytest.mark.parametrize("shape", [(398, 256, 128), (46, 32, 16), (370, 64, 48)])
+def test_fused_td3_update_matches_the_pytorch_update(shape):
+    """cn_td3_update (csrc/crowdnav_td3.hip: the TD3 update as 10 + 11 hand-written launches -- MFMA GEMMs forward and backward,
+    weight gradients folded into Adam, TD target / heads / soft updates as small kernels) against crowdnav.td3.Agent._update (the
+    PyTorch restatement of td3.py:225-285, itself pinned on the reference's learn() goldens): two identically initialised agents,
+    the same explicit batches and target-policy noise, six updates (three with the actor step and the soft updates) -- every
+    parameter of the six networks agrees up to float32 summation order.  Shapes: the product's (398 -> 256 -> 256, batch 128), the
+    goldens' (46 -> 32, batch 16: tiles smaller than the kernel's 32 x 32), and one with ragged tile edges."""
+    import torch
+    from crowdnav.td3 import Agent
+    obs_dim, hidden, B = shape
+    a = Agent(obs_dim=obs_dim, hidden=hidden, batch_size=B, seed=3, memory_size=64, device="cuda")
+    b = Agent(obs_dim=obs_dim, hidden=hidden, batch_size=B, seed=3, memory_size=64, device="cuda")
+    nets = lambda ag: (ag.actor, ag.actor_t, ag.q1, ag.q1_t, ag.q2, ag.q2_t)
+    for ma, mb in zip(nets(a), nets(b)):
+        for pa, pb in zip(ma.parameters(), mb.parameters()):
+            assert torch.equal(pa, pb)
+    a.enable_fused_update()
+    g = torch.Generator(device="cuda").manual_seed(17)
+    for step in range(6):
+        batch = (torch.randn((B, obs_dim), generator=g, device="cuda") * 0.5,
+                 torch.rand((B, 2), generator=g, device="cuda") * torch.tensor([0.22, 4.0], device="cuda") - torch.tensor([0.0, 2.0], device="cuda"),
+                 torch.randn((B, 1), generator=g, device="cuda") * 3.0, torch.randn((B, obs_dim), generator=g, device="cuda") * 0.5,
+                 (torch.rand((B, 1), generator=g, device="cuda") < 0.2).float())
+        noise = torch.randn((B, 2), generator=g, device="cuda")
+        a.learn(step, batch=batch, target_noise=noise)
+        b.learn(step, batch=batch, target_noise=noise)
+        torch.cuda.synchronize()
+        worst = 0.0
+        for ma, mb in zip(nets(a), nets(b)):
+            for (n_, pa), pb in zip(ma.named_parameters(), mb.parameters()):
+                diff = (pa - pb).abs()
+                # Adam's first steps move every weight by ~lr whatever the gradient's size, so a gradient that cancels to ~0 can
+                # land on the other side of zero in another summation order: allow a handful of such weights (<= 2 lr apart)
+                bad = diff > (2e-6 + 2e-4 * pb.abs())
+                assert int(bad.sum()) <= max(2, pa.numel() // 2000), (step, n_, int(bad.sum()), float(diff.max()))
+                assert float(diff.max()) <= 2.5 * 3e-4 * (step + 1), (step, n_, float(diff.max()))
+                worst = max(worst, float(diff.max()))
+    # the fused path also samples the replay and draws the target noise on the device: it runs and changes the networks
+    a.memory.add(batch[0], batch[1], batch[2][:, 0], batch[3], batch[4][:, 0] > 0)
+    a.memory.add(batch[0], batch[1], batch[2][:, 0], batch[3], batch[4][:, 0] > 0)
+    before = [p.detach().clone() for p in a.q1.parameters()]
+    for step in range(4):
+        a.learn(step)
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(p).all() for m in nets(a) for p in m.parameters())
+    assert any(not torch.equal(x, y) for x, y in zip(before, a.q1.parameters()))
+
+
+def test_fused_td3_update_on_the_reference_learn_goldens():
+    """The golden vectors of the REFERENCE's own td3.Agent.learn() (tests/golden/td3.npz, oracle/make_goldens_td3.py) through
+    cn_td3_update: four updates with the pinned batch and target-policy noise."""
+    import torch
+    from crowdnav.td3 import Agent
+    G = np.load(os.path.join(ROOT, "tests", "golden", "td3.npz"))
+    ag = Agent(device="cuda", memory_size=64, obs_dim=46, hidden=32, batch_size=16)
+    nets = dict(actor=ag.actor, actor_t=ag.actor_t, q1=ag.q1, q1_t=ag.q1_t, q2=ag.q2, q2_t=ag.q2_t)
+    for k, m in nets.items():
+        m.load_state_dict({n: torch.from_numpy(G["init.%s.%s" % (k, n)]).cuda() for n in m.state_dict()})
+    ag.enable_fused_update()
+    dev = lambda x: torch.from_numpy(x).cuda()
+    batch = (dev(G["upd_s"]), dev(G["upd_a"]), dev(G["upd_r"])[:, None], dev(G["upd_s2"]), dev(G["upd_d"])[:, None])
+    for step in range(4):
+        ag.learn(step, batch=batch, target_noise=dev(G["upd_noise"][step]))
+        torch.cuda.synchronize()
+        for k, m_ in nets.items():
+            for n, v in m_.state_dict().items():
+                np.testing.assert_allclose(v.cpu().numpy(), G["step%d.%s.%s" % (step, k, n)], rtol=5e-4, atol=2e-6, err_msg="step %d %s.%s" % (step, k, n))
+
+
 def test_episode_stats_rows_match_the_reference_run(reset_mode):
     """SURVEY 8a A33 "pinned by": the batched loop's per-episode rows (EpisodeStats: success, failure, return, steps,
     ego / social safety scores) equal the tuples of the golden run the REFERENCE's Python produced (`train20`: five
