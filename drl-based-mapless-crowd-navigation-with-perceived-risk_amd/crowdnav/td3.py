@@ -343,7 +343,7 @@ class Agent:
 
         def mlp(m):
             ps = [m.linear1.weight, m.linear1.bias, m.linear2.weight, m.linear2.bias, m.linear3.weight, m.linear3.bias]
-            assert all(p.is_contiguous() and p.dtype == torch.float32 and p.device == self.device for p in ps)
+            assert all(p.is_contiguous() and p.dtype == torch.float32 and p.is_cuda for p in ps)
             return _abi.CnTd3Mlp(*[p.data_ptr() for p in ps])
         mem = self.memory
         og = self.opt_a.param_groups[0]

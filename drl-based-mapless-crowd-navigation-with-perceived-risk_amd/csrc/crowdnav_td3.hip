@@ -1,8 +1,8 @@
 // crowdnav_td3.hip -- the TD3 update (td3.py:225-285 of the reference: Agent.learn) as a short chain of HIP kernels (gfx950).
 //
 // The caller of the hot path.  A vectorised environment makes the learner the bottleneck: through PyTorch one
-// update is ~150 small kernels (1.2 ms as a hipGraph at batch 128).  Here the same arithmetic is 10 launches for the critic
-// step and 11 more when the actor and the targets move, all float32 like the reference:
+// update is ~150 small kernels (1.2 ms as a hipGraph at batch 128).  Here the same arithmetic is 11 launches for the critic
+// step and 12 more when the actor and the targets move, all float32 like the reference:
 //   prep        sample the replay on the device (counter-based indices and target-policy noise), gather [s|a], [s2|.], r, d
 //   gemm F      Y = act(X W^T + b) on the f32 matrix cores (v_mfma_f32_16x16x4_f32), up to four networks per launch
 //   gemm G      dX = (dY W) (.) [H > 0]            (back-propagation through a ReLU layer)
@@ -49,6 +49,8 @@ struct GemmJob {
 };
 struct GemmArgs { GemmJob job[4]; float beta1, beta2, eps; };
 
+#define TD3_RC 128                 /* depth of a staged chunk: the loads of a whole chunk (16 + 16 per thread) are in flight together, so a
+                                      layer's K = 398 pays four memory round trips, not thirteen (the tiles are latency-bound: 32 workgroups) */
 template <int MODE>
 __global__ void __launch_bounds__(256) td3_gemm_kernel(GemmArgs args)
 {
@@ -56,30 +58,31 @@ __global__ void __launch_bounds__(256) td3_gemm_kernel(GemmArgs args)
     const int I = jb.I, J = jb.J, R = jb.R;
     const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
     if (i0 >= I || j0 >= J) return;
-    __shared__ float As[32][33];       // [r][i]
-    __shared__ float Bs[32][33];       // [r][j]
+    __shared__ float As[TD3_RC][33];       // [r][i]
+    __shared__ float Bs[TD3_RC][33];       // [r][j]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lo = tid & 31, hi = tid >> 5;          // hi: 0..7
     const float* __restrict__ A = jb.A;
     const float* __restrict__ B = jb.B;
-    // this thread's four elements of a chunk: along the contiguous direction of the operand in memory
-    //   A: F, G -> A[i * lda + r] (r contiguous): r = lo, i = hi + 8 q;   H -> A[r * lda + i] (i contiguous): i = lo, r = hi + 8 q
-    //   B: F    -> B[j * ldb + r] (r contiguous): r = lo, j = hi + 8 q;   G, H -> B[r * ldb + j] (j contiguous): j = lo, r = hi + 8 q
-    float ra[4], rb[4];
+    constexpr int NQ = TD3_RC / 8;                   // elements per thread, operand and chunk
+    // this thread's elements of a chunk, along the contiguous direction of the operand in memory:
+    //   A: F, G -> A[i * lda + r] (r contiguous): r = lo + 32 (q & 3), i = hi + 8 (q >> 2);   H -> A[r * lda + i] (i contiguous): i = lo, r = hi + 8 q
+    //   B: F    -> B[j * ldb + r] (r contiguous): r = lo + 32 (q & 3), j = hi + 8 (q >> 2);   G, H -> B[r * ldb + j] (j contiguous): j = lo, r = hi + 8 q
+    float ra[NQ], rb[NQ];
     auto fetch = [&](int r0) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (MODE != GEMM_H) { const int r = r0 + lo, i = i0 + hi + 8 * q; ra[q] = (r < R && i < I) ? A[(size_t)i * jb.lda + r] : 0.f; }
+        for (int q = 0; q < NQ; ++q) {
+            if (MODE != GEMM_H) { const int r = r0 + lo + 32 * (q & 3), i = i0 + hi + 8 * (q >> 2); ra[q] = (r < R && i < I) ? A[(size_t)i * jb.lda + r] : 0.f; }
             else { const int i = i0 + lo, r = r0 + hi + 8 * q; ra[q] = (r < R && i < I) ? A[(size_t)r * jb.lda + i] : 0.f; }
-            if (MODE == GEMM_F) { const int r = r0 + lo, j = j0 + hi + 8 * q; rb[q] = (r < R && j < J) ? B[(size_t)j * jb.ldb + r] : 0.f; }
+            if (MODE == GEMM_F) { const int r = r0 + lo + 32 * (q & 3), j = j0 + hi + 8 * (q >> 2); rb[q] = (r < R && j < J) ? B[(size_t)j * jb.ldb + r] : 0.f; }
             else { const int j = j0 + lo, r = r0 + hi + 8 * q; rb[q] = (r < R && j < J) ? B[(size_t)r * jb.ldb + j] : 0.f; }
         }
     };
     auto stage = [&]() {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (MODE != GEMM_H) As[lo][hi + 8 * q] = ra[q]; else As[hi + 8 * q][lo] = ra[q];
-            if (MODE == GEMM_F) Bs[lo][hi + 8 * q] = rb[q]; else Bs[hi + 8 * q][lo] = rb[q];
+        for (int q = 0; q < NQ; ++q) {
+            if (MODE != GEMM_H) As[lo + 32 * (q & 3)][hi + 8 * (q >> 2)] = ra[q]; else As[hi + 8 * q][lo] = ra[q];
+            if (MODE == GEMM_F) Bs[lo + 32 * (q & 3)][hi + 8 * (q >> 2)] = rb[q]; else Bs[hi + 8 * q][lo] = rb[q];
         }
     };
     const int wi = (wave & 1) * 16, wj = (wave >> 1) * 16;
@@ -87,16 +90,15 @@ __global__ void __launch_bounds__(256) td3_gemm_kernel(GemmArgs args)
     f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
     float bsum = 0.f;                                // H: sum over the rows of dY[.][i0 + tid] (threads 0..31 of the first j-tile)
     fetch(0);
-    for (int r0 = 0; r0 < R; r0 += 32) {
+    for (int r0 = 0; r0 < R; r0 += TD3_RC) {
         stage();
         __syncthreads();
-        if (r0 + 32 < R) fetch(r0 + 32);
-#pragma unroll
-        for (int s = 0; s < 8; ++s)
+        if (r0 + TD3_RC < R) fetch(r0 + TD3_RC);
+        const int steps = (min(TD3_RC, R - r0) + 3) >> 2;      // k-steps of 4 that hold data (the rest of the chunk is zero)
+        for (int s = 0; s < steps; ++s)
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(As[4 * s + lk][wi + li], Bs[4 * s + lk][wj + li], acc, 0, 0, 0);
         if (MODE == GEMM_H && blockIdx.x == 0 && tid < 32) {
-#pragma unroll
-            for (int r = 0; r < 32; ++r) bsum += As[r][tid];
+            for (int r = 0; r < 4 * steps; ++r) bsum += As[r][tid];
         }
         __syncthreads();
     }
@@ -191,37 +193,48 @@ __global__ void td3_tick_kernel(PrepArgs p)
     }
 }
 
-// Actor.forward's last layer and heads (TD3:101-105) for a batch: logits = h2 W3^T + b3, action = (sigmoid max_v, tanh max_w)
-// (+ the clipped target-policy noise, not re-clipped to the action bounds: TD3:244-247) written into columns D, D + 1 of x.
+__device__ __forceinline__ float td3_wave_sum(float v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+// Actor.forward's last layer and heads (TD3:101-105) for a batch, one WAVEFRONT per row (lanes over the hidden units): logits =
+// h2 W3^T + b3, action = (sigmoid max_v, tanh max_w) (+ the clipped target-policy noise, not re-clipped to the action bounds:
+// TD3:244-247) written into columns D, D + 1 of x.
 __global__ void __launch_bounds__(256) td3_actor_head_kernel(const float* __restrict__ h2, const float* __restrict__ W3, const float* __restrict__ b3,
                                                              const float* __restrict__ noise, float* __restrict__ x, float* __restrict__ logits,
                                                              int B, int H, int Dc, float max_v, float max_w)
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= 2 * B) return;
-    const int m = t >> 1, o = t & 1;
-    float acc = b3[o];
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (m >= B) return;
     const float* hr = h2 + (size_t)m * H;
-    const float* w = W3 + (size_t)o * H;
-    for (int n = 0; n < H; ++n) acc = fmaf(hr[n], w[n], acc);
-    if (logits) logits[t] = acc;
-    float a = o == 0 ? max_v / (1.f + expf(-acc)) : max_w * tanhf(acc);
-    if (noise) a += noise[t];
-    x[(size_t)m * Dc + (Dc - 2) + o] = a;
+    float a0 = 0.f, a1 = 0.f;
+    for (int n = lane; n < H; n += 64) { const float h = hr[n]; a0 = fmaf(h, W3[n], a0); a1 = fmaf(h, W3[H + n], a1); }
+    a0 = td3_wave_sum(a0) + b3[0]; a1 = td3_wave_sum(a1) + b3[1];
+    if (lane < 2) {
+        const float lg = lane == 0 ? a0 : a1;
+        if (logits) logits[2 * m + lane] = lg;
+        float a = lane == 0 ? max_v / (1.f + expf(-lg)) : max_w * tanhf(lg);
+        if (noise) a += noise[2 * m + lane];
+        x[(size_t)m * Dc + (Dc - 2) + lane] = a;
+    }
 }
-// Critic.forward's last layer for up to four critics: q[z][m] = h2[z][m] . W3[z] + b3[z]
+// Critic.forward's last layer for up to four critics, one wavefront per (critic, row): q[z][m] = h2[z][m] . W3[z] + b3[z]
 struct QHeadArgs { const float* h2[4]; const float* W3[4]; const float* b3[4]; float* q[4]; int B, H, nz; };
 __global__ void __launch_bounds__(256) td3_q_head_kernel(QHeadArgs a)
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (t >= a.nz * a.B) return;
     const int z = t / a.B, m = t - z * a.B;
-    float acc = a.b3[z][0];
     const float* hr = a.h2[z] + (size_t)m * a.H;
-    for (int n = 0; n < a.H; ++n) acc = fmaf(hr[n], a.W3[z][n], acc);
-    a.q[z][m] = acc;
+    float acc = 0.f;
+    for (int n = lane; n < a.H; n += 64) acc = fmaf(hr[n], a.W3[z][n], acc);
+    acc = td3_wave_sum(acc);
+    if (lane == 0) a.q[z][m] = acc + a.b3[z][0];
 }
-// TD target, MSE gradient and linear3's backward + Adam step for the two critics (one workgroup per critic):
+// TD target, MSE gradient and linear3's backward + Adam step for the two critics; workgroup (x, z) = 64 hidden units of critic z,
+// its 256 threads = 4 row groups x 64 units:
 //   y = r + (1 - d) gamma min(q1_t, q2_t)  (TD3:249-252);  loss_z = mean (q_z - y)^2;  dq_z = 2 (q_z - y) / B
 //   dz2_z[m][n] = dq_z[m] W3_z[n] [h2_z[m][n] > 0];  dW3_z[n] = sum_m dq_z[m] h2_z[m][n];  db3_z = sum_m dq_z[m]
 struct CriticHeadBwdArgs {
@@ -233,42 +246,51 @@ struct CriticHeadBwdArgs {
 };
 __global__ void __launch_bounds__(256) td3_critic_head_bwd_kernel(CriticHeadBwdArgs a)
 {
-    extern __shared__ float dq[];                   // [B]
-    const int z = blockIdx.x, tid = threadIdx.x;
-    float part = 0.f;
-    for (int m = tid; m < a.B; m += blockDim.x) {
+    extern __shared__ float sm[];                   // dq [B] | partial [4][64] | red [256]
+    float* dq = sm; float* part = sm + a.B; float* red = part + 256;
+    const int z = blockIdx.y, tid = threadIdx.x;
+    float e2 = 0.f, sdq = 0.f;
+    for (int m = tid; m < a.B; m += 256) {
         const float y = a.r[m] + (1.f - a.d[m]) * a.gamma * fminf(a.qt1[m], a.qt2[m]);
         const float e = a.q[z][m] - y;
-        dq[m] = 2.f * e / (float)a.B;
-        part += e * e;
+        const float g = 2.f * e / (float)a.B;
+        dq[m] = g; e2 += e * e; sdq += g;
     }
     __syncthreads();
-    if (z == 0) {                                    // the first critic's loss (what Agent.learn returns), by one thread
-        __shared__ float red[256];
-        red[tid] = part;
+    if (blockIdx.x == 0) {                           // the loss (critic 1: what Agent.learn returns) and the bias of linear3
+        red[tid] = z == 0 ? e2 : 0.f;
         __syncthreads();
-        if (tid == 0) { float s = 0.f; for (int i = 0; i < (int)blockDim.x; ++i) s += red[i]; a.loss[0] = s / (float)a.B; }
+        if (tid == 0 && z == 0) { float s_ = 0.f; for (int i = 0; i < 256; ++i) s_ += red[i]; a.loss[0] = s_ / (float)a.B; }
+        __syncthreads();
+        red[tid] = sdq;
+        __syncthreads();
+        if (tid == 0) {
+            float g = 0.f;
+            for (int i = 0; i < 256; ++i) g += red[i];
+            const float mm = a.beta1 * a.mb3[z][0] + (1.f - a.beta1) * g;
+            const float vv = a.beta2 * a.vb3[z][0] + (1.f - a.beta2) * g * g;
+            a.mb3[z][0] = mm; a.vb3[z][0] = vv;
+            a.b3[z][0] -= a.adam[0] * mm / (sqrtf(vv) / a.adam[1] + a.eps);
+        }
     }
-    for (int n = tid; n < a.H; n += blockDim.x) {
-        const float w = a.W3[z][n];
-        float g = 0.f;
-        for (int m = 0; m < a.B; ++m) {
+    const int rg = tid >> 6, c = tid & 63, n = blockIdx.x * 64 + c;
+    float g = 0.f, w = 0.f;
+    if (n < a.H) {
+        w = a.W3[z][n];
+        for (int m = rg; m < a.B; m += 4) {
             const float h = a.h2[z][(size_t)m * a.H + n];
             a.dz2[z][(size_t)m * a.H + n] = h > 0.f ? dq[m] * w : 0.f;
             g = fmaf(dq[m], h, g);
         }
+    }
+    part[rg * 64 + c] = g;
+    __syncthreads();
+    if (rg == 0 && n < a.H) {
+        g = (part[c] + part[64 + c]) + (part[128 + c] + part[192 + c]);
         const float mm = a.beta1 * a.m3[z][n] + (1.f - a.beta1) * g;
         const float vv = a.beta2 * a.v3[z][n] + (1.f - a.beta2) * g * g;
         a.m3[z][n] = mm; a.v3[z][n] = vv;
         a.W3[z][n] = w - a.adam[0] * mm / (sqrtf(vv) / a.adam[1] + a.eps);
-    }
-    if (tid == 0) {
-        float g = 0.f;
-        for (int m = 0; m < a.B; ++m) g += dq[m];
-        const float mm = a.beta1 * a.mb3[z][0] + (1.f - a.beta1) * g;
-        const float vv = a.beta2 * a.vb3[z][0] + (1.f - a.beta2) * g * g;
-        a.mb3[z][0] = mm; a.vb3[z][0] = vv;
-        a.b3[z][0] -= a.adam[0] * mm / (sqrtf(vv) / a.adam[1] + a.eps);
     }
 }
 // actor loss -mean Q1(s, pi(s)) (TD3:268-269), first link of the chain: d/dh2 of the critic, dz2[m][n] = -(1 / B) W3[n] [h2[m][n] > 0]
@@ -279,55 +301,73 @@ __global__ void __launch_bounds__(256) td3_policy_dz2_kernel(const float* __rest
     const int n = t % H;
     dz2[t] = h2[t] > 0.f ? -W3[n] / (float)B : 0.f;
 }
-// ... through the critic's first layer to the action (the two action columns of W1), through the heads' derivatives to the
-// logits, then linear3 of the ACTOR backward + its Adam step (one workgroup):
-//   da[m][o] = sum_n dz1q[m][n] W1q[n][D + o];  dlogit = da (.) (max_v s (1 - s), max_w (1 - t^2))
+// ... through the critic's first layer to the action (the two action columns of W1) and through the heads' derivatives to the
+// logits, one wavefront per row:  da[m][o] = sum_n dz1q[m][n] W1q[n][D + o];  dlogit = da (.) (max_v s (1 - s), max_w (1 - t^2))
+__global__ void __launch_bounds__(256) td3_dlogit_kernel(const float* __restrict__ dz1q, const float* __restrict__ W1q, const float* __restrict__ logits,
+                                                         float* __restrict__ dl, int B, int H, int Dc, float max_v, float max_w)
+{
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (m >= B) return;
+    float a0 = 0.f, a1 = 0.f;
+    for (int n = lane; n < H; n += 64) {
+        const float g = dz1q[(size_t)m * H + n];
+        a0 = fmaf(g, W1q[(size_t)n * Dc + (Dc - 2)], a0); a1 = fmaf(g, W1q[(size_t)n * Dc + (Dc - 1)], a1);
+    }
+    a0 = td3_wave_sum(a0); a1 = td3_wave_sum(a1);
+    if (lane < 2) {
+        const float lg = logits[2 * m + lane];
+        float dh;
+        if (lane == 0) { const float s_ = 1.f / (1.f + expf(-lg)); dh = max_v * s_ * (1.f - s_); }
+        else { const float th = tanhf(lg); dh = max_w * (1.f - th * th); }
+        dl[2 * m + lane] = (lane == 0 ? a0 : a1) * dh;
+    }
+}
+// ... then linear3 of the ACTOR backward + its Adam step; workgroup x = 64 hidden units, 4 row groups x 64 units:
 //   dz2a[m][n] = sum_o dlogit[m][o] W3a[o][n] [h2a[m][n] > 0];  dW3a[o][n] = sum_m dlogit[m][o] h2a[m][n];  db3a[o] = sum_m dlogit[m][o]
 struct ActorHeadBwdArgs {
-    const float *dz1q, *W1q, *logits, *h2a; float* dz2a;
+    const float *dl, *h2a; float* dz2a;
     float *W3, *b3, *m3, *v3, *mb3, *vb3;
     const float* adam;
-    int B, H, Dc; float max_v, max_w, beta1, beta2, eps;
+    int B, H; float beta1, beta2, eps;
 };
 __global__ void __launch_bounds__(256) td3_actor_head_bwd_kernel(ActorHeadBwdArgs a)
 {
-    extern __shared__ float dl[];                   // [B][2]
+    extern __shared__ float sm[];                   // dl [2 B] | partial [2][4][64]
+    float* dl = sm; float* part = sm + 2 * a.B;
     const int tid = threadIdx.x;
-    for (int t = tid; t < 2 * a.B; t += blockDim.x) {
-        const int m = t >> 1, o = t & 1;
-        float da = 0.f;
-        for (int n = 0; n < a.H; ++n) da = fmaf(a.dz1q[(size_t)m * a.H + n], a.W1q[(size_t)n * a.Dc + (a.Dc - 2) + o], da);
-        const float lg = a.logits[t];
-        float dh;
-        if (o == 0) { const float s = 1.f / (1.f + expf(-lg)); dh = a.max_v * s * (1.f - s); }
-        else { const float th = tanhf(lg); dh = a.max_w * (1.f - th * th); }
-        dl[t] = da * dh;
-    }
+    for (int t = tid; t < 2 * a.B; t += 256) dl[t] = a.dl[t];
     __syncthreads();
-    for (int n = tid; n < a.H; n += blockDim.x) {
-        const float w0 = a.W3[n], w1 = a.W3[a.H + n];
-        float g0 = 0.f, g1 = 0.f;
-        for (int m = 0; m < a.B; ++m) {
-            const float h = a.h2a[(size_t)m * a.H + n];
-            a.dz2a[(size_t)m * a.H + n] = h > 0.f ? fmaf(dl[2 * m + 1], w1, dl[2 * m] * w0) : 0.f;
-            g0 = fmaf(dl[2 * m], h, g0); g1 = fmaf(dl[2 * m + 1], h, g1);
-        }
-        const float g[2] = {g0, g1};
-        for (int o = 0; o < 2; ++o) {
-            const size_t ix = (size_t)o * a.H + n;
-            const float mm = a.beta1 * a.m3[ix] + (1.f - a.beta1) * g[o];
-            const float vv = a.beta2 * a.v3[ix] + (1.f - a.beta2) * g[o] * g[o];
-            a.m3[ix] = mm; a.v3[ix] = vv;
-            a.W3[ix] -= a.adam[2] * mm / (sqrtf(vv) / a.adam[3] + a.eps);
-        }
-    }
-    if (tid < 2) {
+    if (blockIdx.x == 0 && tid < 2) {
         float g = 0.f;
         for (int m = 0; m < a.B; ++m) g += dl[2 * m + tid];
         const float mm = a.beta1 * a.mb3[tid] + (1.f - a.beta1) * g;
         const float vv = a.beta2 * a.vb3[tid] + (1.f - a.beta2) * g * g;
         a.mb3[tid] = mm; a.vb3[tid] = vv;
         a.b3[tid] -= a.adam[2] * mm / (sqrtf(vv) / a.adam[3] + a.eps);
+    }
+    const int rg = tid >> 6, c = tid & 63, n = blockIdx.x * 64 + c;
+    float g0 = 0.f, g1 = 0.f, w0 = 0.f, w1 = 0.f;
+    if (n < a.H) {
+        w0 = a.W3[n]; w1 = a.W3[a.H + n];
+        for (int m = rg; m < a.B; m += 4) {
+            const float h = a.h2a[(size_t)m * a.H + n];
+            a.dz2a[(size_t)m * a.H + n] = h > 0.f ? fmaf(dl[2 * m + 1], w1, dl[2 * m] * w0) : 0.f;
+            g0 = fmaf(dl[2 * m], h, g0); g1 = fmaf(dl[2 * m + 1], h, g1);
+        }
+    }
+    part[rg * 64 + c] = g0; part[256 + rg * 64 + c] = g1;
+    __syncthreads();
+    if (rg == 0 && n < a.H) {
+        const float w[2] = {w0, w1};
+        for (int o = 0; o < 2; ++o) {
+            const float* pp = part + 256 * o;
+            const float g = (pp[c] + pp[64 + c]) + (pp[128 + c] + pp[192 + c]);
+            const size_t ix = (size_t)o * a.H + n;
+            const float mm = a.beta1 * a.m3[ix] + (1.f - a.beta1) * g;
+            const float vv = a.beta2 * a.v3[ix] + (1.f - a.beta2) * g * g;
+            a.m3[ix] = mm; a.v3[ix] = vv;
+            a.W3[ix] = w[o] - a.adam[2] * mm / (sqrtf(vv) / a.adam[3] + a.eps);
+        }
     }
 }
 // soft updates (TD3:287-299): target <- target (1 - tau) + local tau, 18 tensors in one launch
@@ -473,7 +513,7 @@ extern "C" int cn_td3_update(cn_td3_handle h, int do_actor, const cn_td3_batch* 
     // 1-3. target actor on s2 -> a2 = pi_t(s2) + clipped noise, into x2's action columns (TD3:238-247)
     fwd_job(ga.job[0], h->x2, Dc, D, c.actor_t.w1, c.actor_t.b1, h->t_h1); launch_gemm<GEMM_F>(ga, 1, st);
     fwd_job(ga.job[0], h->t_h1, H, H, c.actor_t.w2, c.actor_t.b2, h->t_h2); launch_gemm<GEMM_F>(ga, 1, st);
-    hipLaunchKernelGGL(td3_actor_head_kernel, dim3((2 * B + 255) / 256), dim3(256), 0, st, h->t_h2, c.actor_t.w3, c.actor_t.b3, h->noise, h->x2,
+    hipLaunchKernelGGL(td3_actor_head_kernel, dim3((B + 3) / 4), dim3(256), 0, st, h->t_h2, c.actor_t.w3, c.actor_t.b3, h->noise, h->x2,
                        (float*)nullptr, B, H, Dc, c.max_v, c.max_w);
     // 4-6. the four critics forward: q1, q2 on (s, a); q1_t, q2_t on (s2, a2)
     const cn_td3_mlp* crit[4] = {&c.q1, &c.q2, &c.q1_t, &c.q2_t};
@@ -484,7 +524,7 @@ extern "C" int cn_td3_update(cn_td3_handle h, int do_actor, const cn_td3_batch* 
     QHeadArgs qa;
     for (int z = 0; z < 4; ++z) { qa.h2[z] = h->c_h2[z]; qa.W3[z] = crit[z]->w3; qa.b3[z] = crit[z]->b3; qa.q[z] = h->c_q[z]; }
     qa.B = B; qa.H = H; qa.nz = 4;
-    hipLaunchKernelGGL(td3_q_head_kernel, dim3((4 * B + 255) / 256), dim3(256), 0, st, qa);
+    hipLaunchKernelGGL(td3_q_head_kernel, dim3((4 * B + 3) / 4), dim3(256), 0, st, qa);
     // 7. TD target, MSE gradients, linear3 backward + Adam (both critics)
     CriticHeadBwdArgs ca;
     ca.r = h->r; ca.d = h->d; ca.qt1 = h->c_q[2]; ca.qt2 = h->c_q[3];
@@ -493,7 +533,7 @@ extern "C" int cn_td3_update(cn_td3_handle h, int do_actor, const cn_td3_batch* 
         ca.m3[z] = h->mom[1 + z][4][0]; ca.v3[z] = h->mom[1 + z][4][1]; ca.mb3[z] = h->mom[1 + z][5][0]; ca.vb3[z] = h->mom[1 + z][5][1];
     }
     ca.adam = h->adam; ca.loss = h->loss; ca.B = B; ca.H = H; ca.gamma = c.gamma; ca.beta1 = c.beta1; ca.beta2 = c.beta2; ca.eps = c.eps;
-    hipLaunchKernelGGL(td3_critic_head_bwd_kernel, dim3(2), dim3(256), B * sizeof(float), st, ca);
+    hipLaunchKernelGGL(td3_critic_head_bwd_kernel, dim3((H + 63) / 64, 2), dim3(256), (B + 512) * sizeof(float), st, ca);
     // 8. through the second hidden layer: dz1 = (dz2 W2) (.) [h1 > 0]   (W2 is read here, stepped in 9)
     for (int z = 0; z < 2; ++z) bwd_data_job(ga.job[z], h->dz2[z], crit[z]->w2, h->c_h1[z], h->dz1[z]);
     launch_gemm<GEMM_G>(ga, 2, st);
@@ -507,7 +547,7 @@ extern "C" int cn_td3_update(cn_td3_handle h, int do_actor, const cn_td3_batch* 
         // 10-12. pi(s) into xs's action columns (the batch's own actions are not needed any more)
         fwd_job(ga.job[0], h->xs, Dc, D, c.actor.w1, c.actor.b1, h->a_h1); launch_gemm<GEMM_F>(ga, 1, st);
         fwd_job(ga.job[0], h->a_h1, H, H, c.actor.w2, c.actor.b2, h->a_h2); launch_gemm<GEMM_F>(ga, 1, st);
-        hipLaunchKernelGGL(td3_actor_head_kernel, dim3((2 * B + 255) / 256), dim3(256), 0, st, h->a_h2, c.actor.w3, c.actor.b3, (const float*)nullptr,
+        hipLaunchKernelGGL(td3_actor_head_kernel, dim3((B + 3) / 4), dim3(256), 0, st, h->a_h2, c.actor.w3, c.actor.b3, (const float*)nullptr,
                            h->xs, h->logits, B, H, Dc, c.max_v, c.max_w);
         // 13-14. the UPDATED first critic on (s, pi(s)) (TD3:268)
         fwd_job(ga.job[0], h->xs, Dc, Dc, c.q1.w1, c.q1.b1, h->c_h1[0]); launch_gemm<GEMM_F>(ga, 1, st);
@@ -515,11 +555,12 @@ extern "C" int cn_td3_update(cn_td3_handle h, int do_actor, const cn_td3_batch* 
         // 15-17. -mean Q back to the action, through the heads, linear3 of the actor + Adam
         hipLaunchKernelGGL(td3_policy_dz2_kernel, dim3((B * H + 255) / 256), dim3(256), 0, st, h->c_h2[0], c.q1.w3, h->dz2[0], B, H);
         bwd_data_job(ga.job[0], h->dz2[0], c.q1.w2, h->c_h1[0], h->dz1[0]); launch_gemm<GEMM_G>(ga, 1, st);
+        hipLaunchKernelGGL(td3_dlogit_kernel, dim3((B + 3) / 4), dim3(256), 0, st, h->dz1[0], c.q1.w1, h->logits, h->noise, B, H, Dc, c.max_v, c.max_w);
         ActorHeadBwdArgs aa;
-        aa.dz1q = h->dz1[0]; aa.W1q = c.q1.w1; aa.logits = h->logits; aa.h2a = h->a_h2; aa.dz2a = h->dz2[1];
+        aa.dl = h->noise; aa.h2a = h->a_h2; aa.dz2a = h->dz2[1];       // (the noise buffer is free by now: it holds dlogit [B][2])
         aa.W3 = c.actor.w3; aa.b3 = c.actor.b3; aa.m3 = h->mom[0][4][0]; aa.v3 = h->mom[0][4][1]; aa.mb3 = h->mom[0][5][0]; aa.vb3 = h->mom[0][5][1];
-        aa.adam = h->adam; aa.B = B; aa.H = H; aa.Dc = Dc; aa.max_v = c.max_v; aa.max_w = c.max_w; aa.beta1 = c.beta1; aa.beta2 = c.beta2; aa.eps = c.eps;
-        hipLaunchKernelGGL(td3_actor_head_bwd_kernel, dim3(1), dim3(256), 2 * B * sizeof(float), st, aa);
+        aa.adam = h->adam; aa.B = B; aa.H = H; aa.beta1 = c.beta1; aa.beta2 = c.beta2; aa.eps = c.eps;
+        hipLaunchKernelGGL(td3_actor_head_bwd_kernel, dim3((H + 63) / 64), dim3(256), (2 * B + 512) * sizeof(float), st, aa);
         // 18-19. the actor's hidden layers
         bwd_data_job(ga.job[0], h->dz2[1], c.actor.w2, h->a_h1, h->dz1[1]); launch_gemm<GEMM_G>(ga, 1, st);
         wgrad_job(ga.job[0], h->dz2[1], h->a_h1, H, H, c.actor.w2, c.actor.b2, 0, 2, h->adam + 2);

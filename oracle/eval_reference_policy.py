@@ -101,6 +101,17 @@ def main():
         print("%-98s %5d | %7.3f %8.1f %6.1f %6.3f %6.3f | %7.0f %7.2f" % (name, r["n"], r["success"], r["ret"], r["steps"], r["ego"], r["social"],
                                                                        r["ret_max"], r["bonuses"]), flush=True)
 
+    # the five columns of the published log against this simulator, switch by switch (cn_config.waypoint_reward / scan_f32 / wheel_accel)
+    if a.switches:
+        for drop, label in ((True, "obstacles 1-6"), (False, "all 14 obstacles")):
+            for sw, sname in ((dict(), "as committed (bonus 200, float64 scan, kinematic)"),
+                              (dict(waypoint_reward=0), "waypoint_reward 0"),
+                              (dict(waypoint_reward=0, scan_f32=1), "waypoint_reward 0 + scan_f32"),
+                              (dict(waypoint_reward=0, wheel_accel=1.0), "waypoint_reward 0 + wheel_accel 1"),
+                              (dict(waypoint_reward=0, scan_f32=1, wheel_accel=1.0), "waypoint_reward 0 + scan_f32 + wheel_accel 1")):
+                cfg, init = presets.training(n_envs=a.envs, max_steps=a.max_steps, seed=77, k_obstacles=8, drop_cospawned=drop, **sw)
+                show("top_8 ep2500, sigma 1 / training world, %s: %s" % (label, sname), run(actors[8], cfg, init, None, a.episodes, sigma=1.0))
+        return
     def world(k, vmax=None):
         cfg, init = presets.training(n_envs=a.envs, max_steps=a.max_steps, seed=77, k_obstacles=k)
         if vmax is not None:
@@ -113,17 +124,6 @@ def main():
         for sigma in (1.0, 0.0):
             cfg, init = world(k)
             show("top_%d_obstacle ep2500, sigma %.0f / training world, walkers U(-0.2, 0.2) m/s" % (k, sigma), run(m, cfg, init, None, a.episodes, sigma=sigma))
-    # the five columns of the published log against this simulator, switch by switch (cn_config.waypoint_reward / scan_f32 / wheel_accel)
-    if a.switches:
-        for drop, label in ((True, "obstacles 1-6"), (False, "all 14 obstacles")):
-            for sw, sname in ((dict(), "as committed (bonus 200, float64 scan, kinematic)"),
-                              (dict(waypoint_reward=0), "waypoint_reward 0"),
-                              (dict(waypoint_reward=0, scan_f32=1), "waypoint_reward 0 + scan_f32"),
-                              (dict(waypoint_reward=0, wheel_accel=1.0), "waypoint_reward 0 + wheel_accel 1"),
-                              (dict(waypoint_reward=0, scan_f32=1, wheel_accel=1.0), "waypoint_reward 0 + scan_f32 + wheel_accel 1")):
-                cfg, init = presets.training(n_envs=a.envs, max_steps=a.max_steps, seed=77, k_obstacles=8, drop_cospawned=drop, **sw)
-                show("top_8 ep2500, sigma 1 / training world, %s: %s" % (label, sname), run(actors[8], cfg, init, None, a.episodes, sigma=1.0))
-        return
     # how many of the 14 walkers are really in the room?  (obstacles 7-14 are created at one point: presets.training's docstring)
     for npeds in (10, 8, 7, 6, 4):
         cfg, init = world(8)

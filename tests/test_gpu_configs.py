@@ -251,7 +251,6 @@ def test_graphed_td3_update_equals_the_eager_update():
                 np.testing.assert_allclose(v.cpu().numpy(), G["step%d.%s.%s" % (step, k, n)], rtol=5e-4, atol=2e-6, err_msg="step %d %s.%s" % (step, k, n))
 
 
-@pytest.mark.parametrize("reset_mode", ["next", "same"])
 @pytest.mark.parametrize("shape", [(398, 256, 128), (46, 32, 16), (370, 64, 48)])
 def test_fused_td3_update_matches_the_pytorch_update(shape):
     """cn_td3_update (csrc/crowdnav_td3.hip: the TD3 update as 10 + 11 hand-written launches -- MFMA GEMMs forward and backward,
@@ -263,8 +262,8 @@ def test_fused_td3_update_matches_the_pytorch_update(shape):
     import torch
     from crowdnav.td3 import Agent
     obs_dim, hidden, B = shape
-    a = Agent(obs_dim=obs_dim, hidden=hidden, batch_size=B, seed=3, memory_size=64, device="cuda")
-    b = Agent(obs_dim=obs_dim, hidden=hidden, batch_size=B, seed=3, memory_size=64, device="cuda")
+    a = Agent(obs_dim=obs_dim, hidden=hidden, batch_size=B, seed=3, memory_size=4 * B, device="cuda")
+    b = Agent(obs_dim=obs_dim, hidden=hidden, batch_size=B, seed=3, memory_size=4 * B, device="cuda")
     nets = lambda ag: (ag.actor, ag.actor_t, ag.q1, ag.q1_t, ag.q2, ag.q2_t)
     for ma, mb in zip(nets(a), nets(b)):
         for pa, pb in zip(ma.parameters(), mb.parameters()):
@@ -288,8 +287,8 @@ def test_fused_td3_update_matches_the_pytorch_update(shape):
                 # land on the other side of zero in another summation order: allow a handful of such weights (<= 2 lr apart)
                 bad = diff > (2e-6 + 2e-4 * pb.abs())
                 assert int(bad.sum()) <= max(2, pa.numel() // 2000), (step, n_, int(bad.sum()), float(diff.max()))
-                assert float(diff.max()) <= 2.5 * 3e-4 * (step + 1), (step, n_, float(diff.max()))
-                worst = max(worst, float(diff.max()))
+                assert float(diff.detach().max()) <= 2.5 * 3e-4 * (step + 1), (step, n_, float(diff.detach().max()))
+                worst = max(worst, float(diff.detach().max()))
     # the fused path also samples the replay and draws the target noise on the device: it runs and changes the networks
     a.memory.add(batch[0], batch[1], batch[2][:, 0], batch[3], batch[4][:, 0] > 0)
     a.memory.add(batch[0], batch[1], batch[2][:, 0], batch[3], batch[4][:, 0] > 0)
@@ -322,6 +321,7 @@ def test_fused_td3_update_on_the_reference_learn_goldens():
                 np.testing.assert_allclose(v.cpu().numpy(), G["step%d.%s.%s" % (step, k, n)], rtol=5e-4, atol=2e-6, err_msg="step %d %s.%s" % (step, k, n))
 
 
+@pytest.mark.parametrize("reset_mode", ["next", "same"])
 def test_episode_stats_rows_match_the_reference_run(reset_mode):
     """SURVEY 8a A33 "pinned by": the batched loop's per-episode rows (EpisodeStats: success, failure, return, steps,
     ego / social safety scores) equal the tuples of the golden run the REFERENCE's Python produced (`train20`: five

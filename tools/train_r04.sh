@@ -17,4 +17,7 @@ case "$SET" in
     run same_e16 --envs 16 --updates 16 --waypoint-reward 0 --reset-mode same ;;
   long)
     run e16_u16_wp0 --envs 16 --updates 16 --waypoint-reward 0 ;;
+  fused)   # the same runs on cn_td3_update (csrc/crowdnav_td3.hip): the reference's ratio of one update per env-step, and 4x the envs
+    run fused_e16_u16_wp0 --envs 16 --updates 16 --waypoint-reward 0 --learner fused
+    run fused_e64_u64_wp0 --envs 64 --updates 64 --waypoint-reward 0 --learner fused ;;
 esac
