@@ -980,7 +980,6 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
     if (have_tg) { sy = tg.sy; cy = tg.cy; } else cn_det_sincos_t(p->trig, yaw, &sy, &cy);
     const double ox = fma(p->lidar_offset_x, cy, px), oy = fma(p->lidar_offset_x, sy, py);
     const double h = p->room_half;
-    const double deg2rad = CN_PI / 180.0;
     const int nnear = near_peds(p, L, lane, ox, oy, sy, cy);
     const bool wall_x = !(h - fabs(ox) > p->lidar_max + 1e-6);
     const bool wall_y = !(h - fabs(oy) > p->lidar_max + 1e-6);
@@ -2177,6 +2176,12 @@ __device__ __forceinline__ void env_kernel_body(const int env, const int lane, c
         // kernel for a handle whose configuration IS this shape.
         __builtin_assume(p->R == 360); __builtin_assume(p->P == 20); __builtin_assume(p->K == 8);
         __builtin_assume(p->max_conf == 91); __builtin_assume(p->trk_cap == 32); __builtin_assume(p->near_sep == 1);
+#ifdef CN_S360_MORE
+        // ... and the switches of the default world (cn_create checks every one of them before it picks an _s360 kernel)
+        __builtin_assume(p->dt_ms == 150); __builtin_assume(p->scan_latency_ms == 10); __builtin_assume(p->settle_ms == 100); __builtin_assume(p->ped_stagger_ms == 100);
+        __builtin_assume(p->ped_mode == 0); __builtin_assume(p->geos_untyped_empty == 0); __builtin_assume(p->scan_f32 == 0); __builtin_assume(p->lidar_min_positive == 1);
+        __builtin_assume(p->assoc_fast == 1); __builtin_assume(p->bb_spawn_valid == 1); __builtin_assume(p->py2_round == 0);
+#endif
     }
     if constexpr (!FUSED) {
         if (env >= p->N) return;

@@ -17,6 +17,13 @@ case "$SET" in
     run same_e16 --envs 16 --updates 16 --waypoint-reward 0 --reset-mode same ;;
   long)
     run e16_u16_wp0 --envs 16 --updates 16 --waypoint-reward 0 ;;
+  seeds)   # robustness: the 16-env recipe under other seeds, and the env count in between (fused learner)
+    for S in 1 2 3; do run fused_e16_u16_wp0_seed$S --envs 16 --updates 16 --waypoint-reward 0 --learner fused --seed $S; done
+    run fused_e32_u32_wp0 --envs 32 --updates 32 --waypoint-reward 0 --learner fused
+    for S in 1 2; do run fused_e64_u64_wp0_seed$S --envs 64 --updates 64 --waypoint-reward 0 --learner fused --seed $S; done ;;
+  resetab) # the reset convention isolated -- same seed, scenario, env count, learner; only --reset-mode differs
+    run fused_next_e16 --envs 16 --updates 16 --waypoint-reward 0 --learner fused --reset-mode next
+    run fused_same_e16 --envs 16 --updates 16 --waypoint-reward 0 --learner fused --reset-mode same ;;
   fused)   # the same runs on cn_td3_update (csrc/crowdnav_td3.hip): the reference's ratio of one update per env-step, and 4x the envs
     run fused_e16_u16_wp0 --envs 16 --updates 16 --waypoint-reward 0 --learner fused
     run fused_e64_u64_wp0 --envs 64 --updates 64 --waypoint-reward 0 --learner fused ;;
