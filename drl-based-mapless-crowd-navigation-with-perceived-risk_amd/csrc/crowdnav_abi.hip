@@ -42,6 +42,8 @@ extern "C" __global__ void cn_env_kernel_seq(CnKParams p);
 extern "C" __global__ void cn_env_kernel_s360(CnKParams p);
 extern "C" __global__ void cn_env_kernel_fair_s360(CnKParams p);
 extern "C" __global__ void cn_env_kernel_seq_s360(CnKParams p);
+extern "C" __global__ void cn_env_kernel_s720(CnKParams p);
+extern "C" __global__ void cn_env_kernel_fair_s720(CnKParams p);
 extern "C" __global__ void cn_env_kernel_gt_seq(CnKParams p);
 extern "C" __global__ void cn_bbox_kernel(CnKParams p, double* out);
 extern "C" __global__ void cn_gather_kernel(CnKParams p, float* last_ret, float* run_ret, int32_t* counters);
@@ -67,6 +69,7 @@ struct cn_env_s {
     int n_cus = 0;                    // compute units of `device` (CN_ARB_AUTO: fair from 2 wavefronts per SIMD = 8 x n_cus envs)
     bool shape360_more_pending = false;
     bool shape360 = false;            // the headline shape (360 rays, 20 pedestrians, K = 8 and cn_create's sizes for it): the _s360 kernels
+    bool shape720 = false;            // BASELINE configs[4] (720 rays, 100 pedestrians, K = 8): the _s720 kernels
 };
 
 // RAII: run on the handle's device even if the calling thread's current device is another one
@@ -322,6 +325,7 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
     k.near_sep = cn_near_separate(R, P, K, h->max_conf, h->trk_cap);
     // the kernels compiled for the headline shape assume exactly these six values (crowdnav_kernel.hip, SHAPE == 360)
     h->shape360 = R == 360 && P == 20 && K == 8 && h->max_conf == 91 && h->trk_cap == 32 && k.near_sep == 1 && !getenv("CN_NO_SHAPE_KERNELS");
+    h->shape720 = R == 720 && P == 100 && K == 8 && h->max_conf == 181 && h->trk_cap == 64 && k.near_sep == 0 && !getenv("CN_NO_SHAPE_KERNELS");
 #ifdef CN_S360_MORE
     h->shape360_more_pending = true;      // the remaining assumptions depend on fields filled in below (assoc_fast, bb_spawn_valid)
 #endif
@@ -367,6 +371,11 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
         HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_sf_same, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
         HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_gt_sf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
         HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_gt_sf_same, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
+        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_s360, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
+        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_fair_s360, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
+        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_seq_s360, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
+        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_s720, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
+        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_fair_s720, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
         HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_wa, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
         HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_wa_same, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
         HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_gt_wa, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
@@ -461,6 +470,7 @@ static KernelChoice choose_kernel(const cn_env_s* h, bool ext, bool same, bool o
     if (same) return CN_KC(cn_env_kernel_same);
     const bool fair = fair_launch(h, overlapped);
     if (h->shape360) return fair ? CN_KC(cn_env_kernel_fair_s360) : CN_KC(cn_env_kernel_s360);
+    if (h->shape720) return fair ? CN_KC(cn_env_kernel_fair_s720) : CN_KC(cn_env_kernel_s720);
     return fair ? CN_KC(cn_env_kernel_fair) : CN_KC(cn_env_kernel);
 }
 static KernelChoice choose_sequence_kernel(const cn_env_s* h)

@@ -46,7 +46,10 @@ __device__ __forceinline__ void cn_setprio_uniform(int v)      // v: wave-unifor
                            else if ((k) == 11) __builtin_amdgcn_s_setprio(1); else if ((k) == 15) __builtin_amdgcn_s_setprio(0); } } while (0)
 #ifdef CN_TIMING
 #define CN_ABLATE(bit) (p->ablate & (bit))   /* stage-skipping mask of tools/ablate.py: timing build only */
-#define CN_T(k) do { CN_FAIR_AT(k); if (p->timing && lane == 0) p->timing[(size_t)env * 32 + (k)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+/* bits 8..15 of the mask: stamp number + 1 at which every wavefront ENDS (tools/stage_instr.py: the PMC counters of a launch cut
+   at stamp k are the instructions issued up to k, and the differences between consecutive cuts the dynamic ledger of the stages) */
+#define CN_T(k) do { CN_FAIR_AT(k); if (p->timing && lane == 0) p->timing[(size_t)env * 32 + (k)] = (long long)__builtin_amdgcn_s_memtime(); \
+                     if (((p->ablate >> 8) & 0xff) == (k) + 1) __builtin_amdgcn_endpgm(); } while (0)
 #else
 #define CN_ABLATE(bit) 0
 #define CN_T(k) CN_FAIR_AT(k)
@@ -520,6 +523,33 @@ __device__ __forceinline__ void sim_advance_sf(KP p, EnvRegs& e, int env, int la
                     const double g = act ? G[i * P + j] : CN_NAN;
                     const double ddx = xi - ped_p[2 * j], ddy = yi - ped_p[2 * j + 1];
                     if (j != i && g == g) { ax = fma(g, ddx, ax); ay = fma(g, ddy, ay); }     // NaN = no contribution (skipped pair)
+                }
+            } else if (P <= 128) {
+                // Dense crowds (no room for the pair matrix): the expensive part of a pair term -- sqrt, two divides, the exponential,
+                // ~80 float64 instructions -- is only owed for pedestrians within the cut-off, a quarter of a 100-pedestrian room.
+                // Written as one loop over j the wavefront pays it for EVERY j (some lane always has a near pair).  So: a cheap pass
+                // marks each lane's near pedestrians in a 128-bit mask (broadcast reads, a dozen instructions per j), then every lane
+                // walks ITS OWN mask in ascending j -- the loop runs as long as the busiest lane's neighbour count (~35-40 of 100),
+                // and each lane's sum keeps the oracle's order and arithmetic.
+                u64 m0 = 0ull, m1 = 0ull;
+                for (int j = 0; j < P; ++j) {
+                    const double ddx = xi - ped_p[2 * j], ddy = yi - ped_p[2 * j + 1];
+                    const double d2 = fma(ddx, ddx, ddy * ddy);
+                    const u64 nr = (act && j != i && d2 > 0.0 && !(d2 > cut2)) ? 1ull : 0ull;
+                    if (j < 64) m0 |= nr << j; else m1 |= nr << (j - 64);
+                }
+                while (__ballot((m0 | m1) != 0ull) != 0ull) {
+                    if ((m0 | m1) != 0ull) {
+                        int j;
+                        if (m0) { j = __builtin_ctzll(m0); m0 &= m0 - 1ull; } else { j = 64 + __builtin_ctzll(m1); m1 &= m1 - 1ull; }
+                        const double ddx = xi - ped_p[2 * j], ddy = yi - ped_p[2 * j + 1];
+                        const double d2 = fma(ddx, ddx, ddy * ddy);
+                        const double d = sqrt(d2), arg = (2.0 * r - d) / B;
+                        if (!(arg < -12.0)) {
+                            const double f = (A * cn_det_exp(arg)) * (1.0 / d);
+                            ax = fma(f, ddx, ax); ay = fma(f, ddy, ay);
+                        }
+                    }
                 }
             } else
             for (int j = 0; j < P; ++j) {
@@ -2168,14 +2198,17 @@ __device__ __forceinline__ void env_kernel_body(const int env, const int lane, c
         asm volatile("" : "+s"(pp));
         p = (KP)pp;
     }
-    if constexpr (SHAPE == 360) {
-        // The headline shape (BASELINE configs[1]: 360 rays, 20 pedestrians, K = 8; cn_create's max_conf / tracker slots / LDS
-        // map for it) as COMPILE-TIME facts: the kernarg loads of these six fields fold to constants everywhere below (the
-        // loads are invariant, so one assumption covers every use), which turns the LDS map into immediates, the word loops
-        // (W = 6) into straight-line code and frees the scalar registers that held the map.  launch() only picks an _s360
-        // kernel for a handle whose configuration IS this shape.
-        __builtin_assume(p->R == 360); __builtin_assume(p->P == 20); __builtin_assume(p->K == 8);
-        __builtin_assume(p->max_conf == 91); __builtin_assume(p->trk_cap == 32); __builtin_assume(p->near_sep == 1);
+    if constexpr (SHAPE != 0) {
+        // A benchmark shape as COMPILE-TIME facts -- SHAPE 360: BASELINE configs[1] (360 rays, 20 pedestrians, K = 8), SHAPE 720:
+        // configs[4] (720 rays, 100 pedestrians, K = 8) -- with cn_create's max_conf / tracker slots / LDS map for it: the kernarg
+        // loads of these six fields fold to constants everywhere below (the loads are invariant, so one assumption covers every
+        // use), which turns the LDS map into immediates, the word loops (W = 6 / 12) into straight-line code and frees the scalar
+        // registers that held the map.  launch() only picks an _s360 / _s720 kernel for a handle whose configuration IS that shape.
+        constexpr int SR = SHAPE == 360 ? 360 : 720, SP = SHAPE == 360 ? 20 : 100, SMC = SHAPE == 360 ? 91 : 181, STC = SHAPE == 360 ? 32 : 64,
+                      SNS = SHAPE == 360 ? 1 : 0;
+        static_assert(SHAPE == 360 || SHAPE == 720, "compiled shapes");
+        __builtin_assume(p->R == SR); __builtin_assume(p->P == SP); __builtin_assume(p->K == 8);
+        __builtin_assume(p->max_conf == SMC); __builtin_assume(p->trk_cap == STC); __builtin_assume(p->near_sep == SNS);
 #ifdef CN_S360_MORE
         // ... and the switches of the default world (cn_create checks every one of them before it picks an _s360 kernel)
         __builtin_assume(p->dt_ms == 150); __builtin_assume(p->scan_latency_ms == 10); __builtin_assume(p->settle_ms == 100); __builtin_assume(p->ped_stagger_ms == 100);
@@ -2602,6 +2635,8 @@ extern "C" __global__ void CN_HOT_BOUNDS cn_env_kernel(CnKParams p) { extern __s
 extern "C" __global__ void CN_HOT_BOUNDS cn_env_kernel_fair(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, false, 0, false, 0, false, true>(blockIdx.x, threadIdx.x, cn_smem); }
 extern "C" __global__ void CN_HOT_BOUNDS cn_env_kernel_s360(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, false, 0, false, 0, false, false, 360>(blockIdx.x, threadIdx.x, cn_smem); }
 extern "C" __global__ void CN_HOT_BOUNDS cn_env_kernel_fair_s360(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, false, 0, false, 0, false, true, 360>(blockIdx.x, threadIdx.x, cn_smem); }
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_s720(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, false, 0, false, 0, false, false, 720>(blockIdx.x, threadIdx.x, cn_smem); }
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_fair_s720(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, false, 0, false, 0, false, true, 720>(blockIdx.x, threadIdx.x, cn_smem); }
 extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_same(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, true, 0>(blockIdx.x, threadIdx.x, cn_smem); }
 extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_ext(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<true, false, 0>(blockIdx.x, threadIdx.x, cn_smem); }
 #endif

@@ -105,9 +105,17 @@ def test_device_replay_ring():
     for i in range(3):
         s = torch.full((4, 3), float(i)); m.add(s, torch.zeros(4, 2), torch.full((4,), float(i)), s + 1, torch.zeros(4, dtype=torch.uint8))
     assert len(m) == 8 and m.pos == 4
-    assert m.s[:4, 0].tolist() == [2.0] * 4 and m.s[4:, 0].tolist() == [1.0] * 4      # oldest rows overwritten
+    assert m.s[:4, 0].tolist() == [2.0] * 4 and m.s[4:8, 0].tolist() == [1.0] * 4     # oldest rows overwritten (row 8 = the spare row)
     s, a, r, s2, d = m.sample(5)
     assert s.shape == (5, 3) and r.shape == (5, 1) and torch.equal(s2, s + 1)
+    # masked add without a host read: kept rows go to consecutive slots after the device-side position, the others to the spare row
+    m2 = DeviceReplay(8, 3, "cpu")
+    for i in range(3):
+        s = torch.full((4, 3), float(10 + i))
+        m2.add_masked(s, torch.zeros(4, 2), torch.zeros(4), s + 1, torch.zeros(4), torch.tensor([True, False, True, True]))
+    assert m2.sync_len() == 8 and m2.pos == 1                                           # 9 kept rows wrapped once
+    assert m2.s[:8, 0].tolist() == [12.0, 10.0, 10.0, 11.0, 11.0, 11.0, 12.0, 12.0]
+    assert bool((m2.sample(64)[0][:, 0] >= 10.0).all())
 
 
 def test_episode_csv_schema(tmp_path):
