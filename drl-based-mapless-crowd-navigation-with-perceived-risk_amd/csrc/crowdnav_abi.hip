@@ -67,7 +67,6 @@ struct cn_env_s {
     std::vector<double> ped_init;
     int arbitration = CN_ARB_AUTO;    // cn_set_arbitration
     int n_cus = 0;                    // compute units of `device` (CN_ARB_AUTO: fair from 2 wavefronts per SIMD = 8 x n_cus envs)
-    bool shape360_more_pending = false;
     bool shape360 = false;            // the headline shape (360 rays, 20 pedestrians, K = 8 and cn_create's sizes for it): the _s360 kernels
     bool shape720 = false;            // BASELINE configs[4] (720 rays, 100 pedestrians, K = 8): the _s720 kernels
 };
@@ -326,9 +325,6 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
     // the kernels compiled for the headline shape assume exactly these six values (crowdnav_kernel.hip, SHAPE == 360)
     h->shape360 = R == 360 && P == 20 && K == 8 && h->max_conf == 91 && h->trk_cap == 32 && k.near_sep == 1 && !getenv("CN_NO_SHAPE_KERNELS");
     h->shape720 = R == 720 && P == 100 && K == 8 && h->max_conf == 181 && h->trk_cap == 64 && k.near_sep == 0 && !getenv("CN_NO_SHAPE_KERNELS");
-#ifdef CN_S360_MORE
-    h->shape360_more_pending = true;      // the remaining assumptions depend on fields filled in below (assoc_fast, bb_spawn_valid)
-#endif
     k.max_conf = h->max_conf; k.trk_cap = h->trk_cap; k.env_index_base = c.env_index_base; k.seed = c.seed;
     k.room_half = c.room_half; k.ped_radius = c.ped_radius; k.ped_vmax = c.ped_vmax; k.robot_clearance = c.robot_clearance;
     k.lidar_min = c.lidar_min; k.lidar_max = c.lidar_max; k.lidar_offset_x = c.lidar_offset_x;
@@ -354,9 +350,6 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
         k.assoc_tab = (const int16_t*)(h->d_poly + 128);
         HIPCHK(hipMemcpy((void*)k.assoc_tab, tab, sizeof(tab), hipMemcpyHostToDevice));
     }
-    if (h->shape360_more_pending)
-        h->shape360 = h->shape360 && c.dt_ms == 150 && c.scan_latency_ms == 10 && c.settle_ms == 100 && c.ped_stagger_ms == 100 && c.ped_mode == 0 &&
-                      c.geos_untyped_empty == 0 && c.scan_f32 == 0 && k.lidar_min_positive == 1 && k.assoc_fast == 1 && k.bb_spawn_valid == 1 && c.py2_round == 0;
     if (h->lds > 64 * 1024)
     {
         HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));

@@ -2209,12 +2209,6 @@ __device__ __forceinline__ void env_kernel_body(const int env, const int lane, c
         static_assert(SHAPE == 360 || SHAPE == 720, "compiled shapes");
         __builtin_assume(p->R == SR); __builtin_assume(p->P == SP); __builtin_assume(p->K == 8);
         __builtin_assume(p->max_conf == SMC); __builtin_assume(p->trk_cap == STC); __builtin_assume(p->near_sep == SNS);
-#ifdef CN_S360_MORE
-        // ... and the switches of the default world (cn_create checks every one of them before it picks an _s360 kernel)
-        __builtin_assume(p->dt_ms == 150); __builtin_assume(p->scan_latency_ms == 10); __builtin_assume(p->settle_ms == 100); __builtin_assume(p->ped_stagger_ms == 100);
-        __builtin_assume(p->ped_mode == 0); __builtin_assume(p->geos_untyped_empty == 0); __builtin_assume(p->scan_f32 == 0); __builtin_assume(p->lidar_min_positive == 1);
-        __builtin_assume(p->assoc_fast == 1); __builtin_assume(p->bb_spawn_valid == 1); __builtin_assume(p->py2_round == 0);
-#endif
     }
     if constexpr (!FUSED) {
         if (env >= p->N) return;
