@@ -34,6 +34,10 @@ extern "C" __global__ void cn_env_kernel_rw_ext(CnKParams p);
 extern "C" __global__ void cn_env_kernel_orig(CnKParams p);
 extern "C" __global__ void cn_env_kernel_orig_ext(CnKParams p);
 extern "C" __global__ void cn_env_kernel_orig_same(CnKParams p);
+extern "C" __global__ void cn_env_kernel_sfd(CnKParams p);
+extern "C" __global__ void cn_env_kernel_sfd_same(CnKParams p);
+extern "C" __global__ void cn_env_kernel_gt_sfd(CnKParams p);
+extern "C" __global__ void cn_env_kernel_gt_sfd_same(CnKParams p);
 extern "C" __global__ void cn_env_kernel_wa(CnKParams p);
 extern "C" __global__ void cn_env_kernel_wa_same(CnKParams p);
 extern "C" __global__ void cn_env_kernel_gt_wa(CnKParams p);
@@ -375,6 +379,10 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
         HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_gt_wa_same, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
         HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_seq, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
         HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_gt_seq, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
+        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_sfd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
+        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_sfd_same, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
+        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_gt_sfd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
+        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_gt_sfd_same, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
         HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_gt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
         HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_gt_same, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
         HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_rw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
@@ -456,6 +464,8 @@ static KernelChoice choose_kernel(const cn_env_s* h, bool ext, bool same, bool o
     // simulated sensors: {lidar tracker, gt} x {plain, contact, social force, wheel ramp} x {one observation per launch, step + same-call reset}
     const bool gt = c.risk_mode == CN_RISK_GT, ct = c.ped_contact != 0, sf = c.ped_mode == 2, wa = c.wheel_accel > 0.0;
     if (wa) return gt ? (same ? CN_KC(cn_env_kernel_gt_wa_same) : CN_KC(cn_env_kernel_gt_wa)) : (same ? CN_KC(cn_env_kernel_wa_same) : CN_KC(cn_env_kernel_wa));
+    const bool sfd = sf && !h->kp.sf_pair_matrix && c.n_peds <= 128;      // dense social-force crowd: per-lane near masks
+    if (sfd) return gt ? (same ? CN_KC(cn_env_kernel_gt_sfd_same) : CN_KC(cn_env_kernel_gt_sfd)) : (same ? CN_KC(cn_env_kernel_sfd_same) : CN_KC(cn_env_kernel_sfd));
     if (gt) return sf ? (same ? CN_KC(cn_env_kernel_gt_sf_same) : CN_KC(cn_env_kernel_gt_sf))
                       : ct ? (same ? CN_KC(cn_env_kernel_gt_ct_same) : CN_KC(cn_env_kernel_gt_ct)) : (same ? CN_KC(cn_env_kernel_gt_same) : CN_KC(cn_env_kernel_gt));
     if (sf) return same ? CN_KC(cn_env_kernel_sf_same) : CN_KC(cn_env_kernel_sf);

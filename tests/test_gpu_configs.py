@@ -143,7 +143,8 @@ def test_batched_trainer_runs_on_the_next_step_reset_kernel(tmp_path, reset_mode
                                                  checkpoint_every=10 ** 9, log_every=50, ped_vmax=None, seed=3, device=0,
                                                  out=str(tmp_path / "run"), csv=True, load=None, load_episode=0, evaluate=False,
                                                  episodes_per_env=1, graphs=1, waypoint_reward=0, scan_f32=None, wheel_accel=None,
-                                                 reset_mode=reset_mode, max_csv_rows=100000, time_limit=0.0)
+                                                 reset_mode=reset_mode, max_csv_rows=100000, time_limit=0.0,
+                                                 learner="fused" if reset_mode == "next" else "torch")
     agent, episodes = T.train(a)
     m = agent.memory
     assert episodes > 64 and len(m) == m.size == int(m.size_dev.item())
