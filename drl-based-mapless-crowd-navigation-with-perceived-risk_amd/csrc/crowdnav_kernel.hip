@@ -1188,81 +1188,85 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
     // flips is a handful of 64-bit mask operations.
     CN_T(7);
     {
-        // On the SCALAR unit, one 64-ray word after the other (round 4; rounds 1-3 ran lane = word with shuffle scans across the
-        // words: ~280 vector instructions per observation with 6 of 64 lanes doing anything -- the dynamic ledger's largest block
-        // of "other" VALU work, profiles/r04/stage_instr.txt).  Inside a word, du before each ray is a prefix parity of the
-        // class-A rays (they swap du) combined with a fill-forward from the class-D rays (they set it to 1); across words the
-        // two carried values are du itself and the last ray that set last_type.  Every operand is wave-uniform, so the 64-bit
-        // mask algebra compiles to s_and_b64 / s_lshl_b64 / s_flbit / s_ff1: it issues beside the vector pipe the kernel is
-        // bound by.  The five flag words of every 64-ray block reach the scalar registers through two LDS reads (lane = 16 m + q
-        // holds word q of mask m) and a v_readlane pair each.
-        u64 mine = 0ull, mine4 = 0ull;               // lane 16 m + q: word q of mask m (m = 0..3: none, zero, nzero, nnone); mine4: lane q = eq
-        {
-            const int m = lane >> 4, q = lane & 15;
-            const int id = m == 0 ? M_NONE : (m == 1 ? M_ZERO : (m == 2 ? M_NZERO : M_NNONE));
-            if (q < W && !(CN_ABLATE(2))) { mine = WORD(id, q); if (m == 0) mine4 = WORD(M_EQ, q); }
-            else if (m == 0) mine = ~0ull;                                   // (beyond the scan / ablated: no occupied ray)
-        }
-        const int mlo = (int)(unsigned)mine, mhi = (int)(unsigned)(mine >> 32), elo = (int)(unsigned)mine4, ehi = (int)(unsigned)(mine4 >> 32);
-        auto word = [&](int m, int q) -> u64 {
-            const int src = m < 4 ? 16 * m + q : q;
-            const unsigned lo = (unsigned)__builtin_amdgcn_readlane(m < 4 ? mlo : elo, src), hi = (unsigned)__builtin_amdgcn_readlane(m < 4 ? mhi : ehi, src);
-            return ((u64)hi << 32) | lo;
-        };
-        int du = 0, below = 0;                         // du entering the word; packed (valid, type, index) of the last ray that set last_type
-        for (int q = 0; q < W; ++q) {
-            const u64 occ = ~word(0, q);
-            const u64 Z = word(1, q) & occ;
-            const u64 NZ = word(2, q), NN = word(3, q), E = word(4, q);
+        // lane = word (W <= 16).  (Round 4 also ran this stage on the SCALAR unit, one word after the other with every mask in SGPRs:
+        // 283 -> 164 vector instructions but + 670 scalar ones per observation, and 4-8 % SLOWER in every leg -- the scalar unit
+        // is shared by the CU's wavefronts and its dependent 64-bit chains do not overlap; profiles/r04/stage_instr_scalar_type_machine.txt.)
+        // Inside a word, du before each ray is a prefix parity of the class-A rays (they swap du)
+        // combined with a fill-forward from the class-D rays (they set it to 1); ACROSS words the same two maps
+        // compose (a word with a D ray outputs a constant, one without XORs its parity in), so the words' incoming du
+        // -- and the last ray that set last_type below each word -- come from two 4-step shuffle scans.
+        const int q = lane;
+        u64 occ = 0, Z = 0, cA = 0, cB = 0, cC = 0, cD = 0;
+        if (q < W && !(CN_ABLATE(2))) {
+            occ = ~WORD(M_NONE, q);
+            Z = WORD(M_ZERO, q) & occ;
+            const u64 NZ = WORD(M_NZERO, q), NN = WORD(M_NNONE, q), E = WORD(M_EQ, q);
             const u64 nonz = occ & ~Z;
-            const u64 cA = nonz & NZ;                  // 'w' fresh, du -> 1
-            const u64 cB = nonz & ~NZ & NN;            // 'o' fresh, state untouched
-            const u64 cC = nonz & ~NZ & ~NN & E;       // 'w' fresh
-            const u64 cD = nonz & ~NZ & ~NN & ~E;      // alias, du -> 1
-            u64 PI = cA;                               // inclusive prefix parity of the A rays
-            PI ^= PI << 1; PI ^= PI << 2; PI ^= PI << 4; PI ^= PI << 8; PI ^= PI << 16; PI ^= PI << 32;
-            const u64 PE = PI << 1;                    // exclusive
-            u64 have = cD, F = PI & cD;                // F: PI at the last D ray at or below each position
-            F |= (F << 1) & ~have;  have |= have << 1;
-            F |= (F << 2) & ~have;  have |= have << 2;
-            F |= (F << 4) & ~have;  have |= have << 4;
-            F |= (F << 8) & ~have;  have |= have << 8;
-            F |= (F << 16) & ~have; have |= have << 16;
-            F |= (F << 32) & ~have; have |= have << 32;
-            const u64 haveE = have << 1, FE = F << 1;  // ... strictly below
-            const u64 DU = (haveE & ~(PE ^ FE)) | (~haveE & (du ? ~PE : PE));   // du before each ray
-            const u64 du1 = DU & occ, du0 = ~DU & occ;
-            const u64 setW = (du1 & Z) | (du0 & (Z | cA | cC));   // fresh 'w'; these rays also become last_type
-            const u64 setO = du1 & ~Z;                             // fresh 'o' that becomes last_type (du == 1 only)
-            u64 isw = setW, iso = setO | (du0 & cB);
-            const u64 S = setW | setO;
-            u64 alias = du0 & cD;                      // T[i] = last_type: carries that ray's range and pose
-            while (alias) {
-                const int t = __builtin_ctzll(alias);
-                const u64 bit = 1ull << t;
-                alias &= ~bit;
-                const u64 prev = S & (bit - 1ull);
-                int ty = below ? ((below >> 16) & 3) : TY_NONE, src = below & 0xffff;
-                if (prev) { const int hb = 63 - __builtin_clzll(prev); ty = ((setW >> hb) & 1ull) ? TY_W : TY_O; src = 64 * q + hb; }
-                if (ty == TY_W) isw |= bit;
-                else if (ty == TY_O) iso |= bit;
-                if (ty != TY_NONE && lane == 0) {
-                    // ENV:433-445: the aliased ray carries the range and pose of the ray its list was created at.  Copied right
-                    // here: sources are never aliased themselves, and both ends are occupied rays, so the occupancy words
-                    // (range != 0.6) gathered before the gradients stay valid -- no separate pass over all rays.
-                    const int i_ = 64 * q + t;
-                    L.dmil[i_] = L.dmil[src]; L.ptx[i_] = L.ptx[src]; L.pty[i_] = L.pty[src];
-                }
-            }
-            if (lane == 0) { WORD(M_ISW, q) = isw; WORD(M_ISO, q) = iso; }
-            // what this word hands to the next: du after its last ray, and its last ray that set last_type
-            if (cD) du = 1 ^ (int)((PI >> 63) & 1ull) ^ (int)((PI >> (63 - __builtin_clzll(cD))) & 1ull);
-            else du ^= (int)((PI >> 63) & 1ull);
-            if (S) { const int hb = 63 - __builtin_clzll(S); below = (1 << 30) | ((((setW >> hb) & 1ull) ? TY_W : TY_O) << 16) | (64 * q + hb); }
+            cA = nonz & NZ;                    // 'w' fresh, du -> 1
+            cB = nonz & ~NZ & NN;              // 'o' fresh, state untouched
+            cC = nonz & ~NZ & ~NN & E;         // 'w' fresh
+            cD = nonz & ~NZ & ~NN & ~E;        // alias, du -> 1
         }
-        CN_SYNC();      // (the flag words were read into `mine` before any of them is overwritten)
+        u64 PI = cA;                                  // inclusive prefix parity of the A rays
+        PI ^= PI << 1; PI ^= PI << 2; PI ^= PI << 4; PI ^= PI << 8; PI ^= PI << 16; PI ^= PI << 32;
+        const u64 PE = PI << 1;                       // exclusive
+        u64 have = cD, F = PI & cD;                   // F: PI at the last D ray at or below each position
+        F |= (F << 1) & ~have;  have |= have << 1;
+        F |= (F << 2) & ~have;  have |= have << 2;
+        F |= (F << 4) & ~have;  have |= have << 4;
+        F |= (F << 8) & ~have;  have |= have << 8;
+        F |= (F << 16) & ~have; have |= have << 16;
+        F |= (F << 32) & ~have; have |= have << 32;
+        // this word as a map of du: constant (fc = 1, fv) if it has a D ray, else du ^ fv
+        int fc = cD != 0ull;
+        int fv = (int)((PI >> 63) & 1ull);
+        if (fc) fv = 1 ^ fv ^ (int)((PI >> (63 - __builtin_clzll(cD))) & 1ull);
+        int sc_ = fc, sv_ = fv;                       // inclusive scan of the composition over the words below
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) {
+            const int lc = __shfl_up(sc_, d, 64), lv = __shfl_up(sv_, d, 64);
+            if (lane >= d && !sc_) { sc_ = lc; sv_ ^= lv; }   // (this o lower): a constant map absorbs what is below it
+        }
+        int du = __shfl_up(sv_, 1, 64);               // du entering this word: the maps below applied to du = 0
+        if (lane == 0) du = 0;
+        const u64 haveE = have << 1, FE = F << 1;     // ... strictly below
+        const u64 DU = (haveE & ~(PE ^ FE)) | (~haveE & (du ? ~PE : PE));   // du before each ray
+        const u64 du1 = DU & occ, du0 = ~DU & occ;
+        const u64 setW = (du1 & Z) | (du0 & (Z | cA | cC));   // fresh 'w'; these rays also become last_type
+        const u64 setO = du1 & ~Z;                             // fresh 'o' that becomes last_type (du == 1 only)
+        u64 isw = setW, iso = setO | (du0 & cB), al = 0;
+        const u64 S = setW | setO;
+        // last ray that set last_type at or below each word: packed (valid, type, index), fill-forward over the lanes
+        int pk = 0;
+        if (S) { const int hb = 63 - __builtin_clzll(S); pk = (1 << 30) | ((((setW >> hb) & 1ull) ? TY_W : TY_O) << 16) | (64 * q + hb); }
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) {
+            const int lo_ = __shfl_up(pk, d, 64);
+            if (lane >= d && !pk) pk = lo_;
+        }
+        int below = __shfl_up(pk, 1, 64);             // ... strictly below this word
+        if (lane == 0) below = 0;
+        u64 alias = du0 & cD;                          // T[i] = last_type: carries that ray's range and pose
+        while (alias) {
+            const int t = __builtin_ctzll(alias);
+            const u64 bit = 1ull << t;
+            alias &= ~bit;
+            const u64 prev = S & (bit - 1ull);
+            int ty = below ? ((below >> 16) & 3) : TY_NONE, src = below & 0xffff;
+            if (prev) { const int hb = 63 - __builtin_clzll(prev); ty = ((setW >> hb) & 1ull) ? TY_W : TY_O; src = 64 * q + hb; }
+            if (ty == TY_W) isw |= bit;
+            else if (ty == TY_O) iso |= bit;
+            if (ty != TY_NONE) {
+                // ENV:433-445: the aliased ray carries the range and pose of the ray its list was created at.  Copied right
+                // here: sources are never aliased themselves, and both ends are occupied rays, so the occupancy words
+                // (range != 0.6) gathered before the gradients stay valid -- no separate pass over all rays.
+                const int i_ = 64 * q + t;
+                L.dmil[i_] = L.dmil[src]; L.ptx[i_] = L.ptx[src]; L.pty[i_] = L.pty[src];
+            }
+        }
+        (void)al;
         // (the flag-word slot M_NNONE is dead now: it takes the ray-space occupancy for the order/split words)
-        if (lane < W) WORD(M_NNONE, lane) = occraw;
+        if (q < W) { WORD(M_ISW, q) = isw; WORD(M_ISO, q) = iso; WORD(M_NNONE, q) = occraw; }
     }
     CN_SYNC();
     CN_T(8);
