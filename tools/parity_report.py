@@ -34,6 +34,9 @@ def main():
     ap.add_argument("--py2", type=int, default=0, help="cn_config.py2_round")
     ap.add_argument("--ped-mode", type=int, default=0, help="2 = social-force pedestrians")
     ap.add_argument("--sf-tick", type=int, default=0, help="cn_config.sf_tick_ms")
+    ap.add_argument("--scan-f32", type=int, default=0, help="cn_config.scan_f32")
+    ap.add_argument("--wheel-accel", type=float, default=0.0, help="cn_config.wheel_accel")
+    ap.add_argument("--waypoint-reward", type=int, default=200, help="cn_config.waypoint_reward")
     a = ap.parse_args()
     import torch
     from crowdnav import Config
@@ -42,10 +45,12 @@ def main():
 
     cfg = Config(n_envs=a.envs, n_peds=a.peds, n_rays=a.rays, room_half=a.room, seed=a.seed, max_steps=a.max_steps,
                  min_scan_range=a.min_scan, k_obstacles=a.k, risk_mode=a.risk_mode, ped_contact=a.contact,
-                 geos_untyped_empty=a.geos, obs_layout=a.layout, ped_vmax=a.vmax, dt_ms=a.dt_ms, py2_round=a.py2, ped_mode=a.ped_mode, sf_tick_ms=a.sf_tick)
+                 geos_untyped_empty=a.geos, obs_layout=a.layout, ped_vmax=a.vmax, dt_ms=a.dt_ms, py2_round=a.py2, ped_mode=a.ped_mode, sf_tick_ms=a.sf_tick,
+                 scan_f32=a.scan_f32, wheel_accel=a.wheel_accel, waypoint_reward=a.waypoint_reward)
     print("== parity_report", " ".join(sys.argv[1:]))
     env = VecEnv(cfg)
     env.enable_f64_obs()
+    print("kernels: step %s, same-call %s" % (env.kernel_name("step"), env.kernel_name("same")))
     orc = oracle.Oracle(cfg.as_dict())
     oracle.set_num_threads()
     n = a.rays - 1

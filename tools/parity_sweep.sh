@@ -2,7 +2,7 @@
 # The GPU-vs-oracle sweeps DESIGN.md quotes (every observation / reward / done flag / index / counter compared, zero
 # differences expected).  Writes gpurun_out/<tag>/parity_sweep.txt; copy it to profiles/<tag>/.
 #   tools/parity_sweep.sh r02 [scale]      scale multiplies every --steps (10 -> 36 M env-steps, ~10 min; output parity_sweep_x10.txt)
-TAG="${1:-r03}"; S="${2:-1}"; cd "$(dirname "$0")/.."; OUT="gpurun_out/$TAG"; mkdir -p "$OUT"
+TAG="${1:-r04}"; S="${2:-1}"; cd "$(dirname "$0")/.."; OUT="gpurun_out/$TAG"; mkdir -p "$OUT"
 R="python tools/parity_report.py --verbose 2"
 NAME=parity_sweep; [ "$S" != 1 ] && NAME="parity_sweep_x$S"
 {
@@ -29,4 +29,9 @@ $R --envs 512 --steps $((200 * S)) --layout 2 --dt-ms 50 --py2 1
 $R --envs 1024 --steps $((200 * S)) --ped-mode 2 --reset-mode next
 $R --envs 512 --steps $((150 * S)) --ped-mode 2 --peds 60 --risk-mode 1 --min-scan 0.0
 $R --envs 1024 --steps $((200 * S)) --ped-mode 2 --sf-tick 50 --reset-mode next
+# round 4: "as Gazebo delivers it" (float32 scans, the diff-drive plugin's wheel ramp), the published log's reward, the dense social-force kernels
+$R --envs 2048 --steps $((200 * S)) --scan-f32 1 --wheel-accel 1.0 --waypoint-reward 0 --reset-mode next
+$R --envs 1024 --steps $((200 * S)) --peds 60 --scan-f32 1 --wheel-accel 1.0 --risk-mode 1
+$R --envs 1024 --steps $((200 * S)) --peds 6 --waypoint-reward 0 --max-steps 300 --reset-mode next
+$R --envs 256 --steps $((100 * S)) --ped-mode 2 --peds 100 --rays 720 --room 2.4 --reset-mode next
 } 2>&1 | grep -v amdgpu.ids | tee "$OUT/$NAME.txt"

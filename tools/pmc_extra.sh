@@ -1,7 +1,7 @@
 #!/bin/bash
 # Extra SQ / SQC counter passes of the one-launch-per-step leg (instruction cache, scalar data cache, memory latency levels):
 #   tools/pmc_extra.sh <tag>   -> gpurun_out/<tag>/pmc_extra.txt
-TAG="${1:-r03}"; cd "$(dirname "$0")/.."; REPO="$PWD"; OUT="$REPO/gpurun_out/$TAG"; mkdir -p "$OUT"; export TMPDIR=/tmp
+TAG="${1:-r04}"; cd "$(dirname "$0")/.."; REPO="$PWD"; OUT="$REPO/gpurun_out/$TAG"; mkdir -p "$OUT"; export TMPDIR=/tmp
 BENCH="python $REPO/bench.py --steps 100 --warmup 10 --repeats 2 --groups 1 --no-cpu-baseline --no-plateau --no-other-configs"
 cd /tmp
 i=0
@@ -17,7 +17,10 @@ cd "$REPO"
 python - "$OUT" <<'PY' | tee "$OUT/pmc_extra.txt"
 import csv, glob, os, sys
 d = sys.argv[1]
-for k in ("cn_env_kernel", "cn_env_kernel_fair", "cn_env_kernel_seq"):
+names = set()
+for f in glob.glob(os.path.join(d, "pmcx*", "**", "*counter_collection.csv"), recursive=True):
+    names |= {r.get("Kernel_Name", "").split("(")[0].strip() for r in csv.DictReader(open(f)) if r.get("Kernel_Name", "").startswith("cn_env_kernel")}
+for k in sorted(names):
     print("==", k, "(per env-step, full 4096-env grid)")
     for f in sorted(glob.glob(os.path.join(d, "pmcx*", "**", "*counter_collection.csv"), recursive=True)):
         rows = [r for r in csv.DictReader(open(f)) if r.get("Kernel_Name", "").split("(")[0].strip() == k]

@@ -2,7 +2,7 @@
 # rocprofv3 recipe (run on the GPU box via gpurun): kernel-trace stats + separate PMC passes.
 #   tools/profile.sh <tag> [bench args...]
 set -u
-TAG="${1:-r01}"; shift || true
+TAG="${1:-r04}"; shift || true
 cd "$(dirname "$0")/.."
 REPO="$PWD"
 export TMPDIR=/tmp
@@ -22,5 +22,5 @@ rocprofv3 --output-format csv --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_IN
 rocprofv3 --output-format csv --pmc FETCH_SIZE -d "$OUT/calib_fetch" -o pmc -- python $REPO/tools/calib_pmc.py > "$OUT/calib_fetch.log" 2>&1
 rocprofv3 --output-format csv --pmc WRITE_SIZE -d "$OUT/calib_write" -o pmc -- python $REPO/tools/calib_pmc.py > "$OUT/calib_write.log" 2>&1
 cd "$REPO"
-python tools/summarize_prof.py "$OUT" > "$OUT/summary.txt" 2>&1
+CN_PROFILE_SEQ_STEPS=300 python tools/summarize_prof.py "$OUT" > "$OUT/summary.txt" 2>&1
 cat "$OUT/summary.txt"
