@@ -36,3 +36,4 @@ for k in sorted(names):
         for c in sorted(acc):
             print("  %-30s %14.1f" % (c, acc[c] / cnt[c] / (gmax / 64) / steps))
 PY
+rm -rf "$OUT"/pmcx[0-9]*/

@@ -24,3 +24,7 @@ rocprofv3 --output-format csv --pmc WRITE_SIZE -d "$OUT/calib_write" -o pmc -- p
 cd "$REPO"
 CN_PROFILE_SEQ_STEPS=300 python tools/summarize_prof.py "$OUT" > "$OUT/summary.txt" 2>&1
 cat "$OUT/summary.txt"
+# gpurun merges at most 64 MiB back: keep the summaries and the kernel statistics, drop the raw traces / counter dumps
+mkdir -p "$OUT/keep"
+for d in trace trace_driver; do f=$(find "$OUT/$d" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/keep/kernel_stats_$d.csv"; done
+find "$OUT" -mindepth 1 -maxdepth 1 -type d ! -name keep -exec rm -rf {} +

@@ -10,3 +10,4 @@ for C in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_R
 done
 cd "$REPO"
 python tools/stage_instr_report.py "$OUT" | tee "$REPO/gpurun_out/$TAG/stage_instr.txt"
+cp "$OUT/order.txt" "$REPO/gpurun_out/$TAG/stage_instr_order.txt"; rm -rf "$OUT"
