@@ -230,6 +230,10 @@ class VecEnv:
         if traj is not None:
             with self._on_stream():
                 self.obs.copy_(traj["obs"][T - 1]); self.reward.copy_(traj["reward"][T - 1]); self.done.copy_(traj["done"][T - 1])
+                if traj.get("topk_idx") is not None:
+                    self.topk_idx.copy_(traj["topk_idx"][T - 1])
+                else:
+                    self.topk_idx.fill_(-1)      # not produced by this call: never left stale next to the new observation
         return T * self.N
 
     def bind_step_sequence(self, actions):

@@ -103,6 +103,8 @@ static int g_threads = 1;
 /* cn_config.py2_round of the handle whose call is running (set on entry of every public function that takes a handle;
  * read-only inside the OpenMP region).  0: Python-3 round(), 1: Python-2.7 round() (floatobject.c _Py_double_round: correctly
  * rounded, an EXACT tie -- 2-valuation of x equal to -(nd + 1) -- goes away from zero). */
+/* (A process-global on purpose: the oracle is test infrastructure, driven from one thread; handles with different py2_round
+ * values may coexist because every public call sets it on entry, but they must not be stepped concurrently.) */
 static int g_py2 = 0;
 void cno_set_py2_round(int on) { g_py2 = on ? 1 : 0; }
 

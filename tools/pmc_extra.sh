@@ -32,7 +32,7 @@ for k in sorted(names):
             if int(r.get("Grid_Size", 0) or 0) != gmax:
                 continue
             acc[r["Counter_Name"]] = acc.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"]); cnt[r["Counter_Name"]] = cnt.get(r["Counter_Name"], 0) + 1
-        steps = 100.0 if k.endswith("_seq") else 1.0
+        steps = 100.0 if "_seq" in k else 1.0
         for c in sorted(acc):
             print("  %-30s %14.1f" % (c, acc[c] / cnt[c] / (gmax / 64) / steps))
 PY
