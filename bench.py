@@ -215,8 +215,10 @@ def main():
         """One decomposition of a config: its envs as G stream groups (G = 1: one launch per step), open loop or with the TD3
         actor in the loop (each group's act -> step chain on its own stream, crowdnav.rollout.rollout_groups)."""
 
-        def __init__(self, lcfg, G, mode="next", lacts=None, agent=None, sequence=False, arbitration=None, python_loop=False):
+        def __init__(self, lcfg, G, mode="next", lacts=None, agent=None, sequence=False, arbitration=None, python_loop=False,
+                     policy_sequence=False):
             self.cfg, self.G, self.mode, self.agent, self.sequence = lcfg, G, mode, agent, sequence
+            self.timed_call = None
             self.python_loop = python_loop             # the timed K steps enqueued one foreign call per step from Python (as a trainer would)
             # arbitration None: the library's defaults (cn_set_arbitration) -- one launch per step picks the fair kernel when it
             # fills the device on its own, overlapping stream groups stay on the hardware's oldest-first order
@@ -225,7 +227,8 @@ def main():
             self.arbitration = "rotating per step (sequence kernel)" if sequence else self.grp.envs[0].arbitration
             # the device kernel this leg's launches run (cn_kernel_name): the key of profiles/rNN/{counters,traffic}.json
             e0 = self.grp.envs[0]
-            self.kernel = e0.kernel_name("sequence" if sequence else "same" if mode == "same" else "multi" if G > 1 else "step")
+            self.kernel = e0.kernel_name("policy" if policy_sequence else "sequence" if sequence else "same" if mode == "same" else
+                                         "multi" if G > 1 else "step")
             self.grp.reset()
             self.enq_ms = None
             if sequence:
@@ -237,6 +240,11 @@ def main():
                 self.calls = [self.grp.bind_step_all(lacts[i], auto_reset=mode) for i in range(N_ACT)]
                 # the K timed steps as ONE pre-marshalled cn_step_multi (K x G entries): the host side of a sample is a C loop
                 self.timed_call = self.grp.bind_step_sequence([lacts[i % N_ACT] for i in range(K)], auto_reset=mode)
+            elif policy_sequence:
+                # cn_rollout_policy: the K timed periods (actor -> Env.step, closed loop) as ONE launch; warm-up = one-period launches
+                agent.sync_fused_weights()
+                self.chain = [e0.bind_rollout_policy(agent, 1, add_noise=True)]
+                self.timed_call = e0.bind_rollout_policy(agent, K, add_noise=True)
             else:
                 agent.sync_fused_weights()
                 self.act = torch.zeros((lcfg.n_envs, 2), dtype=torch.float32, device=dev)
@@ -283,7 +291,7 @@ def main():
             t0 = time.perf_counter()
             for g in range(G):
                 ev0[g].record(grp.streams[g])
-            if self.agent is None and steps == K and not self.python_loop:
+            if self.timed_call is not None and steps == K and not self.python_loop:
                 self.timed_call()
             else:
                 self.run(steps)
@@ -331,6 +339,7 @@ def main():
             lg = (Leg(lcfg, 1, lacts=lacts, sequence=True) if G == "sequence" else
                   Leg(lcfg, 1, mode=mode, lacts=lacts, agent=agent, arbitration="oldest_first") if G == "1_groups_oldest_first" else
                   Leg(lcfg, 1, mode=mode, lacts=lacts, agent=agent, python_loop=True) if G == "1_groups_python_enqueue" else
+                  Leg(lcfg, 1, agent=agent, policy_sequence=True) if G == "policy_sequence" else
                   Leg(lcfg, G, mode=mode, lacts=lacts, agent=agent))
             lg.run(a.preroll + a.warmup - warm_tail)
             legs[G] = lg
@@ -384,16 +393,18 @@ def main():
         from crowdnav.td3 import Agent
         other = {}
         agent = Agent(obs_dim=cfg.obs_dim, device="cuda:%d" % dev_index, seed=0, memory_size=16)
-        m3 = measure(cfg, cands, agent=agent, repeats=min(R, 3))
+        m3 = measure(cfg, list(cands) + ["policy_sequence"], agent=agent, repeats=min(R, 3))
         c5 = Config(n_envs=N, n_peds=100, n_rays=720, k_obstacles=a.k, max_steps=1000, seed=1234, ped_cycle_ms=1400, room_half=2.40)
         m5 = measure(c5, [Gmax, 1] if Gmax > 1 else [1], lacts=acts, repeats=min(R, 3))
         for key, m, P_, R_, what in (("configs[2]", m3, 20, 360, "4096 envs x 20 pedestrians x 360 rays, K=8, TD3 actor in the loop "
-                                      "(f32-MFMA actor + exploration noise -> Env.step: a cn_actor_forward -> cn_step chain per stream group)"),
+                                      "(f32-MFMA actor + exploration noise -> Env.step, closed loop: policy_sequence = the K periods as ONE "
+                                      "cn_rollout_policy launch, the actor inside the step kernel; N_groups = a cn_actor_forward -> cn_step chain per stream group)"),
                                      ("configs[4]", m5, 100, 720, "4096 envs x 100 pedestrians x 720 rays, K=8, room 4.8 m, open loop")):
             l_ = m["legs"][m["chosen"]]
             d4 = d4_bytes(P_, R_, a.k)
             other[key] = {"workload": what, "value": l_["median"], "unit": "env-steps/s", "ms_per_step": l_["wall"] / K * 1e3,
-                          "decomposition": "%d stream group(s)" % m["chosen"],
+                          "decomposition": ("%d stream group(s)" % m["chosen"]) if isinstance(m["chosen"], int) else m["chosen"],
+                          "kernel": l_["kernel"],
                           "samples_env_steps_s": l_["samples"],
                           "legs_env_steps_s": {leg_name(g): v["median"] for g, v in m["legs"].items()},
                           "probe_env_steps_s": m["probe_env_steps_s"],

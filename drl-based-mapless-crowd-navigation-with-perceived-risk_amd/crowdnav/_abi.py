@@ -28,7 +28,7 @@ TF = dict(PX=0, PY=1, DIST=2, D0X=3, D0Y=4, D1X=5, D1Y=6, T=7, SPEED=8, VX=9, VY
 EXPORTS = ["cn_abi_version", "cn_last_error", "cn_create", "cn_destroy", "cn_obs_dim", "cn_config_of",
            "cn_set_ped_init", "cn_get_ped_init", "cn_set_ped_preset_vel", "cn_reset", "cn_step", "cn_step_multi", "cn_set_arbitration", "cn_get_arbitration", "cn_kernel_name",
            "cn_observe_external",
-           "cn_policy_tail", "cn_actor_pack_weights", "cn_actor_forward", "cn_step_sequence", "cn_get_counters",
+           "cn_policy_tail", "cn_actor_pack_weights", "cn_actor_forward", "cn_step_sequence", "cn_rollout_policy", "cn_get_counters",
            "cn_get_returns", "cn_debug_env", "cn_lds_bytes", "cn_near_separate", "cn_snapshot_size", "cn_snapshot", "cn_restore",
            "cn_td3_create", "cn_td3_destroy", "cn_td3_update", "cn_td3_loss_dev", "cn_td3_last_error"]
 
@@ -126,6 +126,16 @@ class CnSequenceIO(C.Structure):
                 ("topk_stride", C.c_int64), ("n_steps", C.c_int32), ("reserved", C.c_int32)]
 
 
+class CnPolicyIO(C.Structure):
+    """Mirror of `cn_policy_io` (include/crowdnav.h)."""
+    _fields_ = [("obs0", C.c_void_p), ("action", C.c_void_p), ("obs", C.c_void_p), ("reward", C.c_void_p), ("done", C.c_void_p),
+                ("topk_idx", C.c_void_p),
+                ("action_stride", C.c_int64), ("obs_stride", C.c_int64), ("reward_stride", C.c_int64), ("done_stride", C.c_int64),
+                ("topk_stride", C.c_int64), ("n_steps", C.c_int32), ("reserved", C.c_int32),
+                ("max_v", C.c_float), ("max_w", C.c_float), ("sigma", C.c_float), ("reserved_f", C.c_float),
+                ("seed", C.c_uint64), ("counter", C.c_uint64)]
+
+
 class CrowdNavError(RuntimeError):
     pass
 
@@ -208,6 +218,7 @@ def lib():
         L.cn_actor_forward.argtypes = [C.POINTER(CnActorWeights), vp, vp, C.c_int, C.c_float, C.c_float, C.c_float,
                                        C.c_uint64, C.c_uint64, C.c_int, vp]
         L.cn_step_sequence.argtypes = [vp, C.POINTER(CnSequenceIO), vp]
+        L.cn_rollout_policy.argtypes = [vp, C.POINTER(CnActorWeights), C.POINTER(CnPolicyIO), vp]
         L.cn_get_counters.argtypes = [vp, vp, vp]
         L.cn_get_returns.argtypes = [vp, vp, vp, vp]
         L.cn_debug_env.argtypes = [vp, C.c_int, vp, vp, vp, vp]

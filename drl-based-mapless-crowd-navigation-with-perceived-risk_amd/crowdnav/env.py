@@ -75,12 +75,12 @@ class VecEnv:
             _abi.check(rc)
         return {_abi.CN_ARB_OLDEST_FIRST: "oldest_first", _abi.CN_ARB_FAIR: "fair"}[rc]
 
-    KERNEL_OF = {"step": 0, "reset": 0, "same": 1, "sequence": 2, "external": 3, "multi": 4}
+    KERNEL_OF = {"step": 0, "reset": 0, "same": 1, "sequence": 2, "external": 3, "multi": 4, "policy": 5}
 
     def kernel_name(self, what="step"):
         """cn_kernel_name: the device kernel a call on this handle launches right now -- "step" (cn_step with auto_reset
         "next" / none, cn_reset), "same" (same-call reset), "sequence", "external", "multi" (inside a cn_step_multi over
-        several handles).  A handle of the headline shape gets the `_s360` kernels."""
+        several handles), "policy" (cn_rollout_policy).  A handle of the headline shape gets the `_s360` kernels."""
         n = self.L.cn_kernel_name(self.h, self.KERNEL_OF[what])
         if n is None:
             _abi.check(-1)
@@ -235,6 +235,79 @@ class VecEnv:
                 else:
                     self.topk_idx.fill_(-1)      # not produced by this call: never left stale next to the new observation
         return T * self.N
+
+    def _policy_io(self, agent, T, traj, add_noise, noise_seed, obs0):
+        """cn_policy_io for T periods of `agent`'s packed actor (Agent.sync_fused_weights) on this handle's buffers."""
+        if not hasattr(agent, "_fw_struct"):
+            agent.sync_fused_weights()
+        N, D, K = self.N, self.D, self.K
+        io = _abi.CnPolicyIO()
+        o0 = self.obs if obs0 is None else obs0
+        assert o0.device == self.device and o0.dtype == torch.float32 and o0.is_contiguous() and tuple(o0.shape) == (N, D)
+        io.obs0, io.n_steps = o0.data_ptr(), int(T)
+        io.max_v, io.max_w, io.sigma = agent.max_v, agent.max_w, (agent.explore_sigma if add_noise else 0.0)
+        io.seed = agent._noise_seed if noise_seed is None else int(noise_seed)
+        if traj is None:
+            if not hasattr(self, "_pol_action"):
+                self._pol_action = torch.zeros((N, 2), dtype=torch.float32, device=self.device)
+            io.action = self._pol_action.data_ptr()
+            io.obs, io.reward, io.done, io.topk_idx = self.obs.data_ptr(), self.reward.data_ptr(), self.done.data_ptr(), self.topk_idx.data_ptr()
+        else:
+            a, o, r, d = traj["action"], traj["obs"], traj["reward"], traj["done"]
+            assert tuple(a.shape) == (T, N, 2) and a.dtype == torch.float32 and a.is_contiguous()
+            assert tuple(o.shape) == (T, N, D) and o.dtype == torch.float32 and o.is_contiguous()
+            assert tuple(r.shape) == (T, N) and r.dtype == torch.float32 and r.is_contiguous()
+            assert tuple(d.shape) == (T, N) and d.dtype == torch.uint8 and d.is_contiguous()
+            io.action, io.obs, io.reward, io.done = a.data_ptr(), o.data_ptr(), r.data_ptr(), d.data_ptr()
+            io.action_stride, io.obs_stride, io.reward_stride, io.done_stride = 2 * N, N * D, N, N
+            tk = traj.get("topk_idx")
+            if tk is not None:
+                assert tuple(tk.shape) == (T, N, K) and tk.dtype == torch.int32 and tk.is_contiguous()
+                io.topk_idx, io.topk_stride = tk.data_ptr(), N * K
+        return io, (o0, traj, agent._fw_struct, agent._fw)
+
+    def rollout_policy(self, agent, n_steps, traj=None, add_noise=True, noise_seed=None, obs0=None):
+        """n_steps periods of (agent.act_mfma -> step(auto_reset="next")) as ONE launch (cn_rollout_policy): the packed actor
+        runs inside the step kernel, a workgroup of 16 envs joins only with itself, nothing returns to the host in between.
+        The first action is computed from `obs0` (default: self.obs, i.e. what reset() / the previous call left).
+        traj: None -- every period overwrites self.obs / reward / done / topk_idx in place (the last action taken is in
+        self.last_policy_action) -- or a dict of preallocated device tensors action [T, N, 2], obs [T, N, D], reward [T, N],
+        done [T, N] uint8, optionally topk_idx [T, N, K] (slot t: the action period t took and what its step returned; the
+        transition of period t is (obs[t - 1] or obs0, action[t], reward[t], obs[t], done[t]), to be skipped where the env
+        spent the period on its reset, i.e. where done[t - 1] was set).
+        Bit-identical to the n_steps pairs of calls; advances the agent's noise counter by n_steps.  Enqueues only."""
+        T = int(n_steps)
+        io, keep = self._policy_io(agent, T, traj, add_noise, noise_seed, obs0)
+        io.counter = agent._fused_calls + 1
+        agent._fused_calls += T
+        _abi.check(self.L.cn_rollout_policy(self.h, C.byref(agent._fw_struct), C.byref(io), self._stream()))
+        self._keep_pol = (io, keep)
+        if traj is not None:
+            with self._on_stream():
+                self.obs.copy_(traj["obs"][T - 1]); self.reward.copy_(traj["reward"][T - 1]); self.done.copy_(traj["done"][T - 1])
+                if traj.get("topk_idx") is not None:
+                    self.topk_idx.copy_(traj["topk_idx"][T - 1])
+                else:
+                    self.topk_idx.fill_(-1)
+        return T * self.N
+
+    @property
+    def last_policy_action(self):
+        return getattr(self, "_pol_action", None)
+
+    def bind_rollout_policy(self, agent, n_steps, add_noise=True, noise_seed=None):
+        """Pre-marshalled rollout_policy (in place): a zero-argument callable that only enqueues."""
+        T = int(n_steps)
+        io, keep = self._policy_io(agent, T, None, add_noise, noise_seed, None)
+        ref, w, st, h, fn, check = C.byref(io), C.byref(agent._fw_struct), self._stream(), self.h, self.L.cn_rollout_policy, _abi.check
+
+        def call(_keep=(io, keep)):
+            io.counter = agent._fused_calls + 1
+            agent._fused_calls += T
+            rc = fn(h, w, ref, st)
+            if rc:
+                check(rc)
+        return call
 
     def bind_step_sequence(self, actions):
         """Pre-marshalled step_sequence (in place) for a fixed [T, N, 2] action tensor: a zero-argument callable that only enqueues."""

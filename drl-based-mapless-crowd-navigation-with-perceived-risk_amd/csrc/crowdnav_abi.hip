@@ -46,6 +46,8 @@ extern "C" __global__ void cn_env_kernel_seq(CnKParams p);
 extern "C" __global__ void cn_env_kernel_s360(CnKParams p);
 extern "C" __global__ void cn_env_kernel_fair_s360(CnKParams p);
 extern "C" __global__ void cn_env_kernel_seq_s360(CnKParams p);
+extern "C" __global__ void cn_policy_kernel(CnKParams p);
+extern "C" __global__ void cn_policy_kernel_s360(CnKParams p);
 extern "C" __global__ void cn_env_kernel_s720(CnKParams p);
 extern "C" __global__ void cn_env_kernel_fair_s720(CnKParams p);
 extern "C" __global__ void cn_env_kernel_gt_seq(CnKParams p);
@@ -71,6 +73,7 @@ struct cn_env_s {
     std::vector<double> ped_init;
     int arbitration = CN_ARB_AUTO;    // cn_set_arbitration
     int n_cus = 0;                    // compute units of `device` (CN_ARB_AUTO: fair from 2 wavefronts per SIMD = 8 x n_cus envs)
+    size_t pol_wave_lds = 0, pol_lds = 0;   // cn_rollout_policy: bytes between the 16 environments' LDS working sets of a workgroup; the workgroup's total (0 = does not fit)
     bool shape360 = false;            // the headline shape (360 rays, 20 pedestrians, K = 8 and cn_create's sizes for it): the _s360 kernels
     bool shape720 = false;            // BASELINE configs[4] (720 rays, 100 pedestrians, K = 8): the _s720 kernels
 };
@@ -392,6 +395,19 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
         HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_orig_ext, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
         HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_orig_same, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
     }
+    {   // cn_rollout_policy: 16 environments per workgroup, their working sets 16-byte aligned one after the other (the actor's
+        // tile is laid out compactly over them between two steps), + the 16 actions
+        h->pol_wave_lds = (h->lds + 15) & ~(size_t)15;
+        const size_t tile = sizeof(float) * (16 * (size_t)(((k.R - 1 + 7 + 4 * k.K + 31) & ~31) + 1) + 16 * 257);
+        size_t tot = 16 * h->pol_wave_lds;
+        if (tot < tile) tot = tile;
+        tot += 16 * 2 * sizeof(float);
+        if (tot <= 160 * 1024 && h->cfg.obs_layout == CN_LAYOUT_RISK) {
+            h->pol_lds = tot;
+            HIPCHK(hipFuncSetAttribute((const void*)cn_policy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tot));
+            HIPCHK(hipFuncSetAttribute((const void*)cn_policy_kernel_s360, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tot));
+        }
+    }
     *out = guard.release();
     return CN_OK;
 }
@@ -483,7 +499,8 @@ static KernelChoice choose_sequence_kernel(const cn_env_s* h)
 
 extern "C" const char* cn_kernel_name(cn_handle h, int what)
 {
-    if (!h || what < 0 || what > 4) { fail(CN_ERR_ARG, "cn_kernel_name: bad argument"); return nullptr; }
+    if (!h || what < 0 || what > 5) { fail(CN_ERR_ARG, "cn_kernel_name: bad argument"); return nullptr; }
+    if (what == 5) return h->shape360 ? "cn_policy_kernel_s360" : "cn_policy_kernel";
     if (what == 2) return choose_sequence_kernel(h).name;
     return choose_kernel(h, what == 3, what == 1, what == 4).name;
 }
@@ -646,6 +663,37 @@ extern "C" int cn_step_sequence(cn_handle h, const cn_sequence_io* io, void* str
     DeviceScope scope(h->device);
     cn_kernel_fn fn = choose_sequence_kernel(h).fn;
     hipLaunchKernelGGL(fn, dim3(h->cfg.n_envs), dim3(64), h->lds, (hipStream_t)stream, kp);
+    HIPCHK(hipGetLastError());
+    return CN_OK;
+}
+
+extern "C" int cn_rollout_policy(cn_handle h, const cn_actor_weights* w, const cn_policy_io* io, void* stream)
+{
+    if (!h || !w || !io || !io->obs0 || !io->action || !io->obs || !io->reward || !io->done || !w->w1p || !w->b1 || !w->w2p || !w->b2 || !w->w3 || !w->b3)
+        return fail(CN_ERR_ARG, "cn_rollout_policy: null argument");
+    if (h->cfg.obs_layout != CN_LAYOUT_RISK || h->cfg.risk_mode != CN_RISK_LIDAR_TRACKER || h->cfg.ped_contact || h->cfg.ped_mode == 2 || h->cfg.wheel_accel > 0.0)
+        return fail(CN_ERR_CONFIG, "cn_rollout_policy: built for obs_layout 0, risk_mode 0 with the plain simulator (no contact / social-force / wheel-ramp ticks)");
+    if (!h->pol_lds)
+        return fail(CN_ERR_CONFIG, "cn_rollout_policy: 16 environments of this shape do not fit one CU's LDS (160 KiB)");
+    const int D = h->cfg.n_rays - 1 + 7 + 4 * h->cfg.k_obstacles;
+    if (w->hidden != 256 || w->obs_dim != D || w->obs_dim_padded != ((D + 31) & ~31))
+        return fail(CN_ERR_CONFIG, "cn_rollout_policy: the actor must be cn_actor_pack_weights' layout for this handle's observation width (hidden 256, obs_dim_padded = obs_dim rounded up to 32)");
+    if (io->n_steps < 0 || io->action_stride < 0 || io->obs_stride < 0 || io->reward_stride < 0 || io->done_stride < 0 || io->topk_stride < 0)
+        return fail(CN_ERR_ARG, "cn_rollout_policy: negative step count or stride");
+    if (io->n_steps == 0) return CN_OK;
+    CnKParams kp = h->kp;
+    kp.mode = CN_MODE_STEP; kp.auto_reset = 2;
+    kp.action = io->action; kp.step_counter = nullptr; kp.final_obs = nullptr; kp.obs_f64 = nullptr;
+    kp.obs = io->obs; kp.reward = io->reward; kp.done = io->done; kp.topk_idx = io->topk_idx;
+    kp.roll_steps = io->n_steps; kp.roll_action_in_stride = io->action_stride; kp.roll_obs_stride = io->obs_stride;
+    kp.roll_reward_stride = io->reward_stride; kp.roll_done_stride = io->done_stride; kp.roll_topk_stride = io->topk_stride;
+    kp.pol_w1p = w->w1p; kp.pol_b1 = w->b1; kp.pol_w2p = w->w2p; kp.pol_b2 = w->b2; kp.pol_w3 = w->w3; kp.pol_b3 = w->b3;
+    kp.pol_obs0 = io->obs0; kp.pol_seed = io->seed; kp.pol_counter = io->counter;
+    kp.pol_max_v = io->max_v; kp.pol_max_w = io->max_w; kp.pol_sigma = io->sigma;
+    kp.pol_D = D; kp.pol_Dp = w->obs_dim_padded; kp.pol_wave_lds = (int32_t)h->pol_wave_lds;
+    DeviceScope scope(h->device);
+    cn_kernel_fn fn = h->shape360 ? cn_policy_kernel_s360 : cn_policy_kernel;
+    hipLaunchKernelGGL(fn, dim3((h->cfg.n_envs + 15) / 16), dim3(1024), h->pol_lds, (hipStream_t)stream, kp);
     HIPCHK(hipGetLastError());
     return CN_OK;
 }

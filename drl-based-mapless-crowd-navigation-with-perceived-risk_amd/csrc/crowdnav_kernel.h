@@ -69,6 +69,13 @@ struct CnKParams {
     // cn_step_sequence (cn_env_kernel_seq): steps per launch and the elements between consecutive steps' slots of the action /
     // output buffers (0 = one slot: the same actions every step / every step's outputs in place)
     int64_t roll_steps, roll_action_in_stride, roll_obs_stride, roll_reward_stride, roll_done_stride, roll_topk_stride;
+    // cn_rollout_policy (cn_policy_kernel_s360): the TD3 actor of cn_actor_forward inside the step loop.  `action` above is then an
+    // OUTPUT (slot t = the action step t took); pol_obs0 = the observation the first action is computed from; pol_wave_lds = bytes
+    // between the LDS working sets of a workgroup's 16 environments
+    const float *pol_w1p, *pol_b1, *pol_w2p, *pol_b2, *pol_w3, *pol_b3, *pol_obs0;
+    uint64_t pol_seed, pol_counter;
+    float pol_max_v, pol_max_w, pol_sigma;
+    int32_t pol_D, pol_Dp, pol_wave_lds;
     long long* timing;      // profiling build only: [N, 32] s_memtime stamps
 };
 

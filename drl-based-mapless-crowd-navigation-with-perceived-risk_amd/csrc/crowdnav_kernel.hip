@@ -2191,9 +2191,11 @@ __device__ __forceinline__ double compute_reward(KP p, const Poly& pg, EnvRegs& 
 
 // `env`, `lane`: this wavefront's environment and lane; `smem`: its LDS working set (cn_lds_bytes).  The per-launch kernels pass
 // blockIdx.x / threadIdx.x / the block's dynamic LDS; the multi-step kernel (FUSED, cn_env_kernel_seq below) calls this once per
-// step, `t` steps into its launch, with the step's actions / outputs at slot t of the caller's buffers.
+// step, `t` steps into its launch, with the step's actions / outputs at slot t of the caller's buffers.  `act_here`: this
+// environment's (v, w) where the policy kernel's actor left it (LDS) instead of the caller's action array.
 template <bool EXT, bool TWO, int LAYOUT, bool GT = false, int SIM = 0, bool FUSED = false, bool FAIR = false, int SHAPE = 0>
-__device__ __forceinline__ void env_kernel_body(const int env, const int lane, char* const smem, const long long t = 0)
+__device__ __forceinline__ void env_kernel_body(const int env, const int lane, char* const smem, const long long t = 0,
+                                                const float* const act_here = nullptr)
 {
     KP p = (KP)__builtin_amdgcn_kernarg_segment_ptr();
     if constexpr (FUSED) {
@@ -2363,7 +2365,8 @@ __device__ __forceinline__ void env_kernel_body(const int env, const int lane, c
             sc = p->step_counter ? p->step_counter[env] : e.ep_step;
             double deq_x, deq_y, end_timestep;
             if (!ext) {
-                const double v = (double)io_action()[2 * env], w = (double)io_action()[2 * env + 1];
+                const float* const ain = act_here ? act_here : io_action() + 2 * (size_t)env;
+                const double v = (double)ain[0], w = (double)ain[1];
                 const double t0 = e.clock;
                 if constexpr (SIM == 3) { e.cv = v; e.cw = w; } else { e.rv = v; e.rw = w; }   // pub_cmd_vel.publish (ENV:1200)
                 e.clock += cn_div1000((double)p->dt_ms);              // time.sleep(0.15) (ENV:1201)
@@ -2754,7 +2757,9 @@ extern "C" __global__ void cn_policy_tail_kernel(const float* __restrict__ logit
     action[2 * i + 1] = fminf(fmaxf(w, -max_w), max_w);
 }
 
+#endif   // CN_TU 1
 // ---- fused TD3 actor: 3 x Linear(256) + ReLU + output stage in ONE launch (the caller of the hot path, A33) -------
+// (device helpers: both translation units -- cn_actor_kernel is unit 1's, cn_policy_kernel unit 2's)
 // Actor.forward (TD3:96-106) + Agent.act's noise and clip (TD3:209-215) for a tile of 16 environments per workgroup,
 // on the f32-input matrix cores: v_mfma_f32_16x16x4_f32 (exact f32: a k-ordered fmaf chain, same precision as the
 // reference's fp32 PyTorch actor).  Lane l feeds A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15].
@@ -2792,6 +2797,7 @@ __device__ __forceinline__ ActWPtr actor_wptr(const float* __restrict__ WP, int 
 {
     return ActWPtr{reinterpret_cast<const float4*>(WP) + (size_t)wave * (4 * 64), (unsigned)lane};
 }
+#if !defined(CN_TU) || CN_TU == 1
 extern "C" __global__ void cn_actor_pack_kernel(const float* __restrict__ wt, int K, float* __restrict__ packed)
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;        // index into `packed`
@@ -2800,6 +2806,7 @@ extern "C" __global__ void cn_actor_pack_kernel(const float* __restrict__ wt, in
     const int k = 32 * b + 4 * (2 * q + (j >> 1)) + (lane >> 4), c = 32 * w + 2 * (lane & 15) + (j & 1);
     packed[idx] = wt[(size_t)k * ACT_H + c];
 }
+#endif
 
 // One layer for this wave's 32 columns (two interleaved 16-column tiles: col = 32 wave + 2 j + t):
 // out[r][c] = relu(sum_k A[r][k] W^T[k][c] + bias[c]), K a multiple of 32, k ascending.  `first`: the weights of block 0,
@@ -2894,7 +2901,7 @@ __device__ __forceinline__ void actor_layer(const float* __restrict__ A, int lda
     }
 }
 
-#ifdef CN_TIMING
+#if defined(CN_TIMING) && (!defined(CN_TU) || CN_TU == 1)
 // profiling build: s_memtime stamps of workgroup b's wave 0 at [b][8] (tools/actor_timing.py)
 __device__ long long* cn_actor_timing = nullptr;
 extern "C" int cn_debug_set_actor_timing(long long* dev_buf)
@@ -2908,20 +2915,23 @@ extern "C" int cn_debug_set_actor_timing(long long* dev_buf)
 // One tile of 16 environments through the actor (TD3:96-106 + 209-215), by the NW waves of a workgroup (all of its threads must
 // call this).  obs / action: the tile's first row; n_live: rows of the tile that exist; act_sm: 16 (Dp + 1) + 16 * 257 floats of
 // LDS.  Ends with the actions in global memory (the caller synchronises before anyone reads them).
+// `active` (wave-uniform): the policy kernel's workgroups have 16 waves; the eight that do not take part in the tile only keep
+// the barrier count.  action2: a second copy of the actions (LDS, or NULL).
 template <int NW>        // NW = 8 (the packed weight layout is laid out for 8 waves x 32 columns)
 __device__ __forceinline__ void actor_tile(const float* __restrict__ obs, int n_live, int row0, int D, int Dp,
         const float* __restrict__ W1T, const float* __restrict__ b1, const float* __restrict__ W2T,
         const float* __restrict__ b2, const float* __restrict__ W3, const float* __restrict__ b3,
-        float* __restrict__ action, float* __restrict__ action2, float max_v, float max_w, float sigma, uint64_t seed, uint64_t counter,
-        float* __restrict__ act_sm)
+        float* __restrict__ action, float* action2, float max_v, float max_w, float sigma, uint64_t seed, uint64_t counter,
+        float* act_sm, const bool active = true, const int tid_in = -1)
 {
     static_assert(NW == 8, "packed weights: 8 waves x 32 columns");
     const int ldx = Dp + 1, ldh = ACT_H + 1;
     float* X = act_sm;                 // [16][Dp + 1]; layer 2 writes its output here (the observations are dead by then)
     float* H = X + ACT_M * ldx;        // [16][257] hidden activations of layer 1
-    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int tid = tid_in >= 0 ? tid_in : (int)threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     ActW w1, w2;
     ACT_T(0);
+    if (active) {
     actor_wload(w1, actor_wptr(W1T, wave, lane), 0);                   // in flight while the observations are staged
     // Staging the tile: rows by wave, coalesced.  Every load of a chunk (8 x 64 columns of each of the wave's rows) is issued
     // before the first store: written as `X[c] = src[c]` the loop paid one L2 round trip per 64 columns, in series -- 7 to 14 of
@@ -2949,16 +2959,19 @@ __device__ __forceinline__ void actor_tile(const float* __restrict__ obs, int n_
             }
         }
     }
+    }
     ACT_T(1);
     __syncthreads();
     ACT_T(2);
+    if (active) {
     actor_layer(X, ldx, Dp, W1T, b1, H, ldh, wave, lane, w1);
     actor_wload(w2, actor_wptr(W2T, wave, lane), 0);                   // ... and while the slowest wave finishes layer 1
+    }
     ACT_T(3);
     __syncthreads();
     ACT_T(4);
     float* PL = X;                     // [8 waves][16 rows][2]: the waves' partial logits (the observations are dead by now)
-    actor_layer<true>(H, ldh, ACT_H, W2T, b2, PL, 0, wave, lane, w2, W3);
+    if (active) actor_layer<true>(H, ldh, ACT_H, W2T, b2, PL, 0, wave, lane, w2, W3);
     ACT_T(5);
     __syncthreads();
     ACT_T(6);
@@ -2988,6 +3001,7 @@ __device__ __forceinline__ void actor_tile(const float* __restrict__ obs, int n_
     ACT_T(7);
 }
 
+#if !defined(CN_TU) || CN_TU == 1
 extern "C" __global__ void __launch_bounds__(ACT_THREADS) cn_actor_kernel(const float* __restrict__ obs, int n, int D, int Dp,
         const float* __restrict__ W1T, const float* __restrict__ b1, const float* __restrict__ W2T,
         const float* __restrict__ b2, const float* __restrict__ W3, const float* __restrict__ b3,
@@ -2998,6 +3012,59 @@ extern "C" __global__ void __launch_bounds__(ACT_THREADS) cn_actor_kernel(const 
     actor_tile<ACT_THREADS / 64>(obs + (size_t)row0 * D, min(ACT_M, n - row0), row0, D, Dp, W1T, b1, W2T, b2, W3, b3,
                                  action + 2 * (size_t)row0, nullptr, max_v, max_w, sigma, seed, counter, act_sm);
 }
+#endif
+
+#if !defined(CN_TU) || CN_TU == 2
+// ---- cn_rollout_policy: T control periods per launch with the POLICY IN THE LOOP --------------------------------------------
+// A workgroup = 16 environments = 16 wavefronts (one CU's worth at 4 per SIMD).  Per control period: the first eight waves run
+// the TD3 actor (actor_tile above: the arithmetic, noise keys and clip of cn_actor_forward) on the 16 observations the
+// workgroup's environments wrote one period earlier and leave the 16 actions in LDS and in slot t of the caller's action array;
+// a workgroup barrier; every wave advances its environment by one Env.step with its action (exactly cn_env_kernel's step,
+// next-step reset convention) and writes observation / reward / done / indices to slot t; a workgroup barrier.  No launch and
+// no device-wide join between periods -- the only joins are among the 16 waves of a CU -- and the observation -> actor hand-off
+// never leaves the CU's L2 slice.  Bit-identical to T x (cn_actor_forward, cn_step(auto_reset 2)) with counters c, c + 1, ...
+// The actor's LDS tile (42 KB) overlays the environments' working sets, which are dead between two steps (everything a step
+// needs it reloads from the state record); only the 16 actions live outside them.
+#define POL_ENVS 16
+#ifndef POL_FAIR
+#define POL_FAIR 1            /* experiments: 0 = the sequence kernel's rotating levels instead of the falling ones */
+#endif
+template <int SHAPE>
+__device__ __forceinline__ void policy_sequence_body()
+{
+    extern __shared__ __attribute__((aligned(16))) char cn_smem[];
+    KP p0 = (KP)__builtin_amdgcn_kernarg_segment_ptr();
+    const int T = (int)p0->roll_steps;
+    for (int t = 0; t < T; ++t) {
+        unsigned long long pp = (unsigned long long)p0;
+        asm volatile("" : "+s"(pp));             // per-period laundering (see env_kernel_body): the actor's ~20 parameters, the wave's
+        KP p = (KP)pp;                           // index and everything derived from them are re-made each period instead of living in
+        int tid_ = threadIdx.x;                  // registers across the whole step
+        asm volatile("" : "+v"(tid_));
+        const int lane_ = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
+        const int row0 = blockIdx.x * POL_ENVS, env = row0 + wave;
+        const int ws = p->pol_wave_lds, D = p->pol_D;
+        float* const act_lds = (float*)(cn_smem + (size_t)POL_ENVS * ws);          // [16][2]
+        const float* ob = (t == 0 ? p->pol_obs0 : p->obs + (size_t)((t - 1) * p->roll_obs_stride)) + (size_t)row0 * D;
+        float* ac = const_cast<float*>(p->action) + (size_t)(t * p->roll_action_in_stride) + 2 * (size_t)row0;
+        actor_tile<8>(ob, min(POL_ENVS, p->N - row0), row0, D, p->pol_Dp, p->pol_w1p, p->pol_b1, p->pol_w2p, p->pol_b2, p->pol_w3, p->pol_b3,
+                      ac, act_lds, p->pol_max_v, p->pol_max_w, p->pol_sigma, p->pol_seed, p->pol_counter + (uint64_t)t, (float*)cn_smem, wave < 8, tid_);
+        __syncthreads();
+        if (env < p->N)
+        {
+#if POL_FAIR == 0
+            cn_setprio_uniform((t + (int)__builtin_amdgcn_s_getreg(4 | (1 << 11))) & 3);
+#endif
+            env_kernel_body<false, false, 0, false, 0, true, POL_FAIR != 0, SHAPE>(env, lane_, cn_smem + (size_t)wave * ws, t, act_lds + 2 * wave);
+        }
+        __syncthreads();
+    }
+}
+extern "C" __global__ void __launch_bounds__(64 * POL_ENVS) cn_policy_kernel(CnKParams p) { policy_sequence_body<0>(); }
+extern "C" __global__ void __launch_bounds__(64 * POL_ENVS) cn_policy_kernel_s360(CnKParams p) { policy_sequence_body<360>(); }
+#endif
+
+#if !defined(CN_TU) || CN_TU == 1
 
 #ifdef CN_TIMING
 // ---- device arithmetic under test (PROFILING BUILD ONLY; tests/test_gpu_parity.py::test_device_math_*): the hand-written

@@ -319,6 +319,33 @@ typedef struct cn_sequence_io {
 } cn_sequence_io;
 int cn_step_sequence(cn_handle h, const cn_sequence_io* io, void* stream);
 
+/* n_steps control periods with the POLICY IN THE LOOP, as ONE launch: per period a_t = actor(o_t) + exploration noise, clipped
+ * (cn_actor_forward's arithmetic, noise keyed by (seed, counter + t, env row)), then Env.step(a_t) (cn_step, auto_reset = 2) --
+ * the collection loop of start_td3_training.py:104-168 (agent.act -> env.step) for every environment of the handle without a
+ * launch or a device-wide join between periods: a workgroup = 16 environments joins only with itself, the actor runs on its CU's
+ * matrix cores between two steps.  Results are bit-identical to n_steps x (cn_actor_forward, cn_step) with counters counter,
+ * counter + 1, ...  The weights are those of `actor` for the whole launch (a learner that updates every period sees a policy
+ * lag of at most n_steps periods; n_steps = 1 is the per-period loop as one launch instead of two).
+ *   obs0     dev [N, D]: the observation the first action is computed from (cn_reset's / the previous call's last slot; may
+ *            alias slot 0 of obs when obs_stride = 0)
+ *   action   dev n_steps slots [N, 2] float32, OUTPUT: slot t = the action period t took
+ *   obs / reward / done / topk_idx (or NULL): as cn_sequence_io (slot t = what period t's step returned)
+ * Requirements: those of cn_step_sequence, risk_mode 0, and an actor of cn_actor_pack_weights' layout for this handle's
+ * observation width (hidden 256). */
+typedef struct cn_policy_io {
+    const float* obs0;
+    float* action;
+    float* obs;
+    float* reward;
+    uint8_t* done;
+    int32_t* topk_idx;
+    int64_t action_stride, obs_stride, reward_stride, done_stride, topk_stride;
+    int32_t n_steps, reserved;
+    float max_v, max_w, sigma, reserved_f;
+    uint64_t seed, counter;
+} cn_policy_io;
+int cn_rollout_policy(cn_handle h, const cn_actor_weights* actor, const cn_policy_io* io, void* stream);
+
 /* get_episode_status / get_*_safety_violation_status inputs (ENV:1265-1283).
  * out: dev [N,14] = ego_viol, social_viol, obstacle_present_steps, ep_steps, success, failure, status, n_tracks,
  *                  episodes finished since cn_create, reset pending (auto_reset == 2),

@@ -534,6 +534,67 @@ def test_step_sequence_kernel_equals_step_by_step(oracle_mod, risk_mode):
         VecEnv(Config(n_envs=16, obs_layout=1)).step_sequence(torch.zeros((2, 16, 2), device="cuda"))
 
 
+@pytest.mark.parametrize("shape", ["s360", "generic"])
+def test_policy_rollout_kernel_equals_act_then_step(oracle_mod, shape):
+    """cn_rollout_policy -- T control periods with the TD3 actor INSIDE the step kernel (16 environments per workgroup, the
+    actor on their CU's matrix cores between two steps, no launch in between) -- leaves exactly what T pairs of
+    (cn_actor_forward with exploration noise, cn_step with the next-step reset) leave: the actions of every period, the
+    observations / rewards / done flags / indices of every period, the final state record, counters, returns and the agent's
+    noise counter; into trajectory buffers and in place, across consecutive calls, for an env count that is not a multiple of
+    16.  The step-by-step run is checked against the oracle (fed the same actions) at every step."""
+    import torch
+    from crowdnav import Config
+    from crowdnav.env import VecEnv
+    from crowdnav.td3 import Agent
+    N, T = (648, 30) if shape == "s360" else (200, 24)
+    cfg = (Config(n_envs=N, n_peds=20, max_steps=14, seed=47, ped_cycle_ms=1400) if shape == "s360" else
+           Config(n_envs=N, n_peds=12, n_rays=300, k_obstacles=6, max_steps=14, seed=48, ped_cycle_ms=1400))
+    ref, pol, inplace = VecEnv(cfg), VecEnv(cfg), VecEnv(cfg)
+    assert pol.kernel_name("policy") == ("cn_policy_kernel_s360" if shape == "s360" else "cn_policy_kernel")
+    orc = oracle_mod.Oracle(cfg.as_dict())
+    oracle_mod.set_num_threads()
+    agents = [Agent(obs_dim=cfg.obs_dim, device="cuda:0", seed=5, memory_size=16) for _ in range(3)]
+    for ag in agents:
+        ag.sync_fused_weights()
+    a_ref, a_pol, a_inp = agents
+    ref.reset(); pol.reset(); inplace.reset(); torch.cuda.synchronize()
+    orc.reset()
+    D, K = ref.D, ref.K
+    act = torch.zeros((N, 2), device="cuda")
+    n_done = 0
+    for call in range(3):
+        traj = dict(action=torch.zeros((T, N, 2), device="cuda"), obs=torch.zeros((T, N, D), device="cuda"),
+                    reward=torch.zeros((T, N), device="cuda"), done=torch.zeros((T, N), dtype=torch.uint8, device="cuda"),
+                    topk_idx=torch.zeros((T, N, K), dtype=torch.int32, device="cuda"))
+        pol.rollout_policy(a_pol, T, traj=traj, add_noise=(call != 2))
+        if call == 1:
+            inplace.bind_rollout_policy(a_inp, T)()
+        else:
+            inplace.rollout_policy(a_inp, T, add_noise=(call != 2))
+        for t in range(T):
+            a_ref.act_mfma(ref.obs, out=act, add_noise=(call != 2))
+            torch.cuda.synchronize()
+            assert torch.equal(traj["action"][t], act), (call, t)
+            ref.step(act, auto_reset="next")
+            torch.cuda.synchronize()
+            assert torch.equal(traj["obs"][t], ref.obs) and torch.equal(traj["reward"][t], ref.reward), (call, t)
+            assert torch.equal(traj["done"][t], ref.done) and torch.equal(traj["topk_idx"][t], ref.topk_idx), (call, t)
+            oc, rc, dc, ic = orc.step(act.cpu().numpy().astype(np.float64), auto_reset="next")
+            assert np.array_equal(ref.done.cpu().numpy(), dc) and np.array_equal(ref.topk_idx.cpu().numpy(), ic), (call, t)
+            assert np.array_equal(ref.obs.cpu().numpy(), oc.astype(np.float32)), (call, t)
+            n_done += int(dc.sum())
+        assert a_pol.noise_state() == a_ref.noise_state() == a_inp.noise_state()
+        for other in (pol, inplace):
+            assert torch.equal(other.obs, ref.obs) and torch.equal(other.reward, ref.reward) and torch.equal(other.done, ref.done)
+            assert np.array_equal(other.snapshot(), ref.snapshot())
+            assert torch.equal(other.counters(), ref.counters()) and torch.equal(other.returns()[0], ref.returns()[0])
+        assert torch.equal(inplace.topk_idx, ref.topk_idx) and torch.equal(inplace.last_policy_action, act)
+    assert n_done > N // 2
+    import crowdnav
+    with pytest.raises(crowdnav.CrowdNavError):
+        VecEnv(Config(n_envs=16, risk_mode=1)).rollout_policy(a_ref, 2)
+
+
 def test_bind_step_sequence_equals_step_by_step():
     """VecEnvGroups.bind_step_sequence -- the path bench.py's timed region goes through (K steps x G groups behind ONE
     cn_step_multi call, a C loop over the launches) -- leaves every env where K calls of VecEnv.step leave it: observations,
