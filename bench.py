@@ -463,6 +463,20 @@ def main():
         counters_src = "%s has no entry for %s" % (counters_src, hk)
     if traffic_all and not traffic:
         traffic_src = "%s has no entry for %s" % (traffic_src, hk)
+    # the other configs' kernels, where the committed profile has them (cn_policy_kernel_s360: tools/profile.sh's pol_* passes)
+    for oc in (other or {}).values():
+        ck = (counters_all or {}).get("kernels", {}).get(oc.get("kernel"))
+        tk = (traffic_all or {}).get("kernels", {}).get(oc.get("kernel"))
+        if ck:
+            oc["roofline"].update({"valu_busy": ck.get("valu_busy"), "wave_instr_per_env_step": ck.get("wave_instr_per_env_step"),
+                                   "counters_source": counters_src})
+        if tk:
+            oc["roofline"].update({"traffic_bytes_per_env_step": tk["bytes_per_env_step"],
+                                   "wasted_traffic_ratio": tk["bytes_per_env_step"] / oc["roofline"]["bytes_per_env_step_d4"]})
+        if str(oc.get("kernel", "")).startswith("cn_policy_kernel") or "actor" in oc.get("workload", ""):
+            # the actor's share priced on the f32 matrix cores (MI355X_MICROARCH.md: 157.3 TF, v_mfma_f32_16x16x4_f32)
+            mfma_flops = 2.0 * (((cfg.obs_dim + 31) // 32 * 32) * 256 + 256 * 256)
+            oc["roofline"].update({"actor_mfma_flops_per_env_step": mfma_flops, "frac_mfma_f32": oc["value"] * mfma_flops / 157.3e12})
     steps_per_launch = K if Gc == "sequence" else 1
     # HBM bytes the counters saw per launch of the headline kernel, scaled to this run's launch (envs per launch x steps per launch)
     traffic_b = float(traffic["bytes_per_env_step"]) * n_launch * steps_per_launch if traffic else None

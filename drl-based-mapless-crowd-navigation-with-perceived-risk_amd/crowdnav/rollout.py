@@ -115,6 +115,50 @@ def rollout(env, agent, n_steps, learn=False, add_noise=True, stats=None, policy
     return n_steps * env.N
 
 
+def collect_policy(env, agent, n_steps, periods=16, add_noise=True, store=True):
+    """Data collection with the policy INSIDE the step kernel (cn_rollout_policy): `periods` control periods per launch, the
+    actor frozen at the weights of `agent.sync_fused_weights()` for the whole call (TRAIN:104-168's act -> step -> memory.add
+    with a policy lag of at most `periods` periods).  store: the transitions go to agent.memory in the order the per-step loop
+    `rollout(env, agent, ..., policy="mfma")` would add them -- period-major, env order, an env's reset launch skipped -- by one
+    masked add per launch (no host read).  Enqueues only; returns env-steps issued (N per period)."""
+    agent.sync_fused_weights()
+    if not getattr(env, "_started", False):
+        env.reset()
+        env._started = True
+    N, D = env.N, env.D
+    resetting = getattr(env, "_resetting", None)
+    if resetting is None:
+        resetting = torch.zeros(N, dtype=torch.bool, device=env.device)
+    left = int(n_steps)
+    while left > 0:
+        T = min(int(periods), left)
+        if not store:
+            env.rollout_policy(agent, T, add_noise=add_noise)
+            resetting = env.done.bool()
+        else:
+            assert T * N <= agent.memory.cap, "one launch's transitions must fit the replay ring"
+            bufs = getattr(env, "_pol_traj", None)
+            if bufs is None or bufs["obs"].shape[0] != T + 1:
+                bufs = dict(obs=torch.zeros((T + 1, N, D), dtype=torch.float32, device=env.device),
+                            action=torch.zeros((T, N, 2), dtype=torch.float32, device=env.device),
+                            reward=torch.zeros((T, N), dtype=torch.float32, device=env.device),
+                            done=torch.zeros((T + 1, N), dtype=torch.uint8, device=env.device))
+                env._pol_traj = bufs
+            with env._on_stream():
+                bufs["obs"][0].copy_(env.obs)                       # s of period 0; slots 1..T receive what the steps return
+                bufs["done"][0].copy_(resetting)
+            traj = dict(obs=bufs["obs"][1:], action=bufs["action"], reward=bufs["reward"], done=bufs["done"][1:])
+            env.rollout_policy(agent, T, traj=traj, add_noise=add_noise, obs0=bufs["obs"][0])
+            with env._on_stream():
+                keep = ~bufs["done"][:T].bool().reshape(T * N)      # period t is a transition unless the env finished in period t - 1
+                agent.memory.add_masked(bufs["obs"][:T].reshape(T * N, D), bufs["action"].reshape(T * N, 2), bufs["reward"].reshape(T * N),
+                                        bufs["obs"][1:].reshape(T * N, D), bufs["done"][1:].reshape(T * N), keep)
+                resetting = bufs["done"][T].bool()
+        left -= T
+    env._resetting = resetting
+    return int(n_steps) * N
+
+
 def rollout_groups(envs, agent, n_steps, add_noise=True, auto_reset="next"):
     """Actor-in-the-loop rollout over a crowdnav.env.VecEnvGroups: each group runs its own act -> step chain
     (cn_actor_forward, then cn_step) on its own HIP stream, so the actor of one group overlaps the env step of

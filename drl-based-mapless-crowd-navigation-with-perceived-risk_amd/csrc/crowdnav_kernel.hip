@@ -3026,6 +3026,9 @@ extern "C" __global__ void __launch_bounds__(ACT_THREADS) cn_actor_kernel(const 
 // The actor's LDS tile (42 KB) overlays the environments' working sets, which are dead between two steps (everything a step
 // needs it reloads from the state record); only the 16 actions live outside them.
 #define POL_ENVS 16
+#ifndef POL_ACTOR_WAVES
+#define POL_ACTOR_WAVES(w) ((w) < 8)     /* experiments: (false) = barriers and heads only, to time the env phase alone */
+#endif
 #ifndef POL_FAIR
 #define POL_FAIR 1            /* experiments: 0 = the sequence kernel's rotating levels instead of the falling ones */
 #endif
@@ -3048,7 +3051,7 @@ __device__ __forceinline__ void policy_sequence_body()
         const float* ob = (t == 0 ? p->pol_obs0 : p->obs + (size_t)((t - 1) * p->roll_obs_stride)) + (size_t)row0 * D;
         float* ac = const_cast<float*>(p->action) + (size_t)(t * p->roll_action_in_stride) + 2 * (size_t)row0;
         actor_tile<8>(ob, min(POL_ENVS, p->N - row0), row0, D, p->pol_Dp, p->pol_w1p, p->pol_b1, p->pol_w2p, p->pol_b2, p->pol_w3, p->pol_b3,
-                      ac, act_lds, p->pol_max_v, p->pol_max_w, p->pol_sigma, p->pol_seed, p->pol_counter + (uint64_t)t, (float*)cn_smem, wave < 8, tid_);
+                      ac, act_lds, p->pol_max_v, p->pol_max_w, p->pol_sigma, p->pol_seed, p->pol_counter + (uint64_t)t, (float*)cn_smem, POL_ACTOR_WAVES(wave), tid_);
         __syncthreads();
         if (env < p->N)
         {

@@ -595,6 +595,42 @@ def test_policy_rollout_kernel_equals_act_then_step(oracle_mod, shape):
         VecEnv(Config(n_envs=16, risk_mode=1)).rollout_policy(a_ref, 2)
 
 
+def test_collect_policy_fills_the_replay_like_the_per_step_loop():
+    """crowdnav.rollout.collect_policy -- cn_rollout_policy launches of `periods` periods, one masked replay add per launch --
+    leaves the replay ring, its device-side position / fill level and the env exactly where the per-step loop (act_mfma ->
+    step(next-step reset) -> add_masked, TRAIN:104-168) leaves them, for a period count that does not divide the step count."""
+    import torch
+    from crowdnav import Config
+    from crowdnav.env import VecEnv
+    from crowdnav.rollout import collect_policy
+    from crowdnav.td3 import Agent
+    N, steps = 96, 53
+    cfg = Config(n_envs=N, max_steps=12, seed=21, ped_cycle_ms=1400)
+    e1, e2 = VecEnv(cfg), VecEnv(cfg)
+    a1 = Agent(obs_dim=cfg.obs_dim, device="cuda:0", seed=3, memory_size=4000)
+    a2 = Agent(obs_dim=cfg.obs_dim, device="cuda:0", seed=3, memory_size=4000)
+    assert collect_policy(e1, a1, steps, periods=8) == steps * N
+    a2.sync_fused_weights()
+    obs = e2.reset()
+    act = torch.zeros((N, 2), device="cuda")
+    resetting = torch.zeros(N, dtype=torch.bool, device="cuda")
+    for t in range(steps):
+        a2.act_mfma(obs, out=act)
+        prev = obs.clone()
+        obs, reward, done = e2.step(act, auto_reset="next")
+        a2.memory.add_masked(prev, act, reward, obs, done, ~resetting)
+        resetting = done.bool()
+    torch.cuda.synchronize()
+    m1, m2 = a1.memory, a2.memory
+    assert m1.sync_len() == m2.sync_len() and 0 < len(m2) < steps * N and m1.pos == m2.pos
+    n = len(m2)
+    for x, y in ((m1.s, m2.s), (m1.a, m2.a), (m1.r, m2.r), (m1.s2, m2.s2), (m1.d, m2.d)):
+        assert torch.equal(x[:n], y[:n])
+    assert float(m2.d[:n].sum()) > N // 2                       # episodes ended inside the run (max_steps 12)
+    assert torch.equal(e1.obs, e2.obs) and torch.equal(e1.done, e2.done) and np.array_equal(e1.snapshot(), e2.snapshot())
+    assert torch.equal(e1._resetting, resetting) and a1.noise_state() == a2.noise_state()
+
+
 def test_bind_step_sequence_equals_step_by_step():
     """VecEnvGroups.bind_step_sequence -- the path bench.py's timed region goes through (K steps x G groups behind ONE
     cn_step_multi call, a C loop over the launches) -- leaves every env where K calls of VecEnv.step leave it: observations,

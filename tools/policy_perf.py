@@ -18,6 +18,11 @@ agent = Agent(obs_dim=cfg.obs_dim, device="cuda:0", seed=0, memory_size=16)
 agent.sync_fused_weights()
 def marker():
     c = env.counters(); torch.cuda.synchronize(); return int((c[:, 8] - c[:, 9]).sum().item())
+if "--profile" in sys.argv:       # tools/profile.sh: every launch the same (100 periods), so per-dispatch counters / 100 = per period
+    for _ in range(13):
+        env.rollout_policy(agent, 100)
+    torch.cuda.synchronize()
+    sys.exit(0)
 env.rollout_policy(agent, 300); torch.cuda.synchronize()
 print("kernel:", env.kernel_name("policy"))
 for T in (1, 20, 100, 1000):

@@ -19,12 +19,19 @@ rocprofv3 --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU 
     -d "$OUT/pmc_sq" -o pmc -- $BENCH > "$OUT/bench_pmc_sq.log" 2>&1
 rocprofv3 --output-format csv --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE \
     -d "$OUT/pmc_sq2" -o pmc -- $BENCH > "$OUT/bench_pmc_sq2.log" 2>&1
+# cn_rollout_policy (BASELINE configs[2], the actor inside the step kernel): launches of 100 periods each
+POL="python $REPO/tools/policy_perf.py 4096 --profile"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/pol_trace" -o trace -- $POL > "$OUT/policy_trace.log" 2>&1
+rocprofv3 --output-format csv --pmc FETCH_SIZE -d "$OUT/pol_fetch" -o pmc -- $POL > "$OUT/policy_pmc_fetch.log" 2>&1
+rocprofv3 --output-format csv --pmc WRITE_SIZE -d "$OUT/pol_write" -o pmc -- $POL > "$OUT/policy_pmc_write.log" 2>&1
+rocprofv3 --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES \
+    -d "$OUT/pol_sq" -o pmc -- $POL > "$OUT/policy_pmc_sq.log" 2>&1
 rocprofv3 --output-format csv --pmc FETCH_SIZE -d "$OUT/calib_fetch" -o pmc -- python $REPO/tools/calib_pmc.py > "$OUT/calib_fetch.log" 2>&1
 rocprofv3 --output-format csv --pmc WRITE_SIZE -d "$OUT/calib_write" -o pmc -- python $REPO/tools/calib_pmc.py > "$OUT/calib_write.log" 2>&1
 cd "$REPO"
-CN_PROFILE_SEQ_STEPS=300 python tools/summarize_prof.py "$OUT" > "$OUT/summary.txt" 2>&1
+CN_PROFILE_SEQ_STEPS=300 CN_PROFILE_POL_STEPS=100 python tools/summarize_prof.py "$OUT" > "$OUT/summary.txt" 2>&1
 cat "$OUT/summary.txt"
 # gpurun merges at most 64 MiB back: keep the summaries and the kernel statistics, drop the raw traces / counter dumps
 mkdir -p "$OUT/keep"
-for d in trace trace_driver; do f=$(find "$OUT/$d" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/keep/kernel_stats_$d.csv"; done
+for d in trace trace_driver pol_trace; do f=$(find "$OUT/$d" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/keep/kernel_stats_$d.csv"; done
 find "$OUT" -mindepth 1 -maxdepth 1 -type d ! -name keep -exec rm -rf {} +

@@ -15,7 +15,8 @@ def find(d, pat):
 
 
 def main(d):
-    for tdir, what in (("trace", "bench.py --steps 300 --warmup 30"), ("trace_driver", "the driver's command: bench.py --steps 20 --warmup 5")):
+    for tdir, what in (("trace", "bench.py --steps 300 --warmup 30"), ("trace_driver", "the driver's command: bench.py --steps 20 --warmup 5"),
+                       ("pol_trace", "tools/policy_perf.py 4096 --profile (cn_rollout_policy, %s periods per launch)" % os.environ.get("CN_PROFILE_POL_STEPS", "100"))):
         st = find(os.path.join(d, tdir), "*kernel_stats.csv")
         if st:
             print("== kernel stats, %s (%s)" % (what, os.path.relpath(st, d)))
@@ -30,7 +31,7 @@ def main(d):
             legs = {}
             for r in csv.DictReader(open(tr)):
                 kn = r["Kernel_Name"].split("(")[0].strip()
-                if not kn.startswith("cn_env_kernel"):
+                if not (kn.startswith("cn_env_kernel") or kn.startswith("cn_policy_kernel")):
                     continue
                 g = int(r.get("Grid_Size_X", r.get("Grid_Size", 0)) or 0)
                 legs.setdefault((kn, g), []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
@@ -45,14 +46,17 @@ def main(d):
     # A sequence kernel's launch covers `seq_steps` control periods: its counters are divided by that.
     import json
     seq_steps = float(os.environ.get("CN_PROFILE_SEQ_STEPS", "300"))
+    pol_steps = float(os.environ.get("CN_PROFILE_POL_STEPS", "100"))
     per_kernel = {}
-    for tag in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
+    # pol_*: the same passes over tools/policy_perf.py --profile (every cn_policy_kernel launch there covers pol_steps periods)
+    for tag in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2", "pol_fetch", "pol_write", "pol_sq"):
         f = find(os.path.join(d, tag), "*counter_collection.csv")
         if not f:
             print("== %s: no counter csv" % tag)
             continue
         allrows = list(csv.DictReader(open(f)))
-        names = sorted({r.get("Kernel_Name", "").split("(")[0].strip() for r in allrows if r.get("Kernel_Name", "").startswith("cn_env_kernel")})
+        prefix = "cn_policy_kernel" if tag.startswith("pol_") else "cn_env_kernel"
+        names = sorted({r.get("Kernel_Name", "").split("(")[0].strip() for r in allrows if r.get("Kernel_Name", "").startswith(prefix)})
         for kname in names:
             rows = [r for r in allrows if r.get("Kernel_Name", "").split("(")[0].strip() == kname]
             gmax = max([int(r.get("Grid_Size", 0) or 0) for r in rows] or [0])
@@ -64,7 +68,7 @@ def main(d):
                 acc[k] = acc.get(k, 0.0) + v; cnt[k] = cnt.get(k, 0) + 1
             if not acc:
                 continue
-            steps = seq_steps if "_seq" in kname else 1.0
+            steps = seq_steps if "_seq" in kname else pol_steps if kname.startswith("cn_policy_kernel") else 1.0
             e = per_kernel.setdefault(kname, {"envs_per_launch": gmax // 64, "steps_per_launch": steps, "raw": {}})
             print("== %s (per %s dispatch of %d envs%s, mean of %s)" % (tag, kname, gmax // 64, " x %d steps" % steps if steps > 1 else "", sorted(set(cnt.values()))))
             for k in sorted(acc):
