@@ -1,8 +1,8 @@
 // crowdnav_td3.hip -- the TD3 update (td3.py:225-285 of the reference: Agent.learn) as a short chain of HIP kernels (gfx950).
 //
 // The caller of the hot path.  A vectorised environment makes the learner the bottleneck: through PyTorch one
-// update is ~150 small kernels (1.2 ms as a hipGraph at batch 128).  Here the same arithmetic is 11 launches for the critic
-// step and 12 more when the actor and the targets move, all float32 like the reference:
+// update is ~150 small kernels (1.2 ms as a hipGraph at batch 128).  Here the same arithmetic is 10 launches for the critic
+// step and 11 more when the actor and the targets move, all float32 like the reference:
 //   prep        sample the replay on the device (counter-based indices and target-policy noise), gather [s|a], [s2|.], r, d
 //   gemm F      Y = act(X W^T + b) on the f32 matrix cores (v_mfma_f32_16x16x4_f32), up to four networks per launch
 //   gemm G      dX = (dY W) (.) [H > 0]            (back-propagation through a ReLU layer)
@@ -46,12 +46,18 @@ struct GemmJob {
     int I, J, R;                                   // extents of i, j, r
     int lda, ldb, ldc;
     int relu;
+    // F, optional: the first link of the actor-loss chain written next to the activation it is masked by (TD3:268-269,
+    // -mean Q1(s, pi(s))): dz_out[m][n] = -(1 / dz_rows) dz_w3[n] [y > 0]  (was a kernel of its own: one more launch)
+    const float* dz_w3; float* dz_out; float dz_rows;
 };
 struct GemmArgs { GemmJob job[4]; float beta1, beta2, eps; };
 
 #define TD3_RC 128                 /* depth of a staged chunk: the loads of a whole chunk (16 + 16 per thread) are in flight together, so a
                                       layer's K = 398 pays four memory round trips, not thirteen (the tiles are latency-bound: 32 workgroups) */
-template <int MODE>
+// NCH > 0 (the reduction is at most NCH chunks deep: NCH = 2 covers the hidden layers' 256, NCH = 4 the input layers' 398 / 400):
+// the global loads of EVERY chunk are issued before the first one is staged -- one memory round trip per tile instead of one per
+// chunk (a tile is a chain of round trips and little else: 11 -> 7 us for the input layers).  Same MFMA order, same results.
+template <int MODE, int NCH = 0>
 __global__ void __launch_bounds__(256) td3_gemm_kernel(GemmArgs args)
 {
     const GemmJob& jb = args.job[blockIdx.z];
@@ -68,8 +74,9 @@ __global__ void __launch_bounds__(256) td3_gemm_kernel(GemmArgs args)
     // this thread's elements of a chunk, along the contiguous direction of the operand in memory:
     //   A: F, G -> A[i * lda + r] (r contiguous): r = lo + 32 (q & 3), i = hi + 8 (q >> 2);   H -> A[r * lda + i] (i contiguous): i = lo, r = hi + 8 q
     //   B: F    -> B[j * ldb + r] (r contiguous): r = lo + 32 (q & 3), j = hi + 8 (q >> 2);   G, H -> B[r * ldb + j] (j contiguous): j = lo, r = hi + 8 q
-    float ra[NQ], rb[NQ];
-    auto fetch = [&](int r0) {
+    constexpr int NCHX = NCH > 0 ? NCH : 1;
+    float rra[NCHX][NQ], rrb[NCHX][NQ];
+    auto fetch = [&](int r0, float (&ra)[NQ], float (&rb)[NQ]) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             if (MODE != GEMM_H) { const int r = r0 + lo + 32 * (q & 3), i = i0 + hi + 8 * (q >> 2); ra[q] = (r < R && i < I) ? A[(size_t)i * jb.lda + r] : 0.f; }
@@ -78,7 +85,7 @@ __global__ void __launch_bounds__(256) td3_gemm_kernel(GemmArgs args)
             else { const int j = j0 + lo, r = r0 + hi + 8 * q; rb[q] = (r < R && j < J) ? B[(size_t)r * jb.ldb + j] : 0.f; }
         }
     };
-    auto stage = [&]() {
+    auto stage = [&](const float (&ra)[NQ], const float (&rb)[NQ]) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             if (MODE != GEMM_H) As[lo + 32 * (q & 3)][hi + 8 * (q >> 2)] = ra[q]; else As[hi + 8 * q][lo] = ra[q];
@@ -89,18 +96,43 @@ __global__ void __launch_bounds__(256) td3_gemm_kernel(GemmArgs args)
     const int li = lane & 15, lk = lane >> 4;
     f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
     float bsum = 0.f;                                // H: sum over the rows of dY[.][i0 + tid] (threads 0..31 of the first j-tile)
-    fetch(0);
-    for (int r0 = 0; r0 < R; r0 += TD3_RC) {
-        stage();
-        __syncthreads();
-        if (r0 + TD3_RC < R) fetch(r0 + TD3_RC);
+    auto chunk = [&](int r0) {                       // the staged chunk starting at r0: its MFMAs (and H's bias row sums)
         const int steps = (min(TD3_RC, R - r0) + 3) >> 2;      // k-steps of 4 that hold data (the rest of the chunk is zero)
-        for (int s = 0; s < steps; ++s)
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(As[4 * s + lk][wi + li], Bs[4 * s + lk][wj + li], acc, 0, 0, 0);
+        // eight k-steps at a time: their 16 LDS reads are issued together, then the 8 MFMAs (one read pair per MFMA left the LDS
+        // latency exposed on every step: a wavefront is alone on its SIMD here).  Steps past `steps` multiply staged zeros.
+        for (int s0 = 0; s0 < steps; s0 += 8) {
+            float av[8], bv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { av[u] = As[4 * (s0 + u) + lk][wi + li]; bv[u] = Bs[4 * (s0 + u) + lk][wj + li]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+        }
         if (MODE == GEMM_H && blockIdx.x == 0 && tid < 32) {
             for (int r = 0; r < 4 * steps; ++r) bsum += As[r][tid];
         }
-        __syncthreads();
+    };
+    if constexpr (NCH > 0) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+            if (c * TD3_RC < R) fetch(c * TD3_RC, rra[c], rrb[c]);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            if (c * TD3_RC < R) {
+                stage(rra[c], rrb[c]);
+                __syncthreads();
+                chunk(c * TD3_RC);
+                __syncthreads();
+            }
+        }
+    } else {
+        fetch(0, rra[0], rrb[0]);
+        for (int r0 = 0; r0 < R; r0 += TD3_RC) {
+            stage(rra[0], rrb[0]);
+            __syncthreads();
+            if (r0 + TD3_RC < R) fetch(r0 + TD3_RC, rra[0], rrb[0]);
+            chunk(r0);
+            __syncthreads();
+        }
     }
     // epilogue: acc[q] = C[i0 + wi + 4 lk + q][j0 + wj + li]
     const int j = j0 + wj + li;
@@ -113,6 +145,7 @@ __global__ void __launch_bounds__(256) td3_gemm_kernel(GemmArgs args)
             float y = acc[q] + jb.bias[j];
             if (jb.relu) y = fmaxf(y, 0.f);
             jb.C[o] = y;
+            if (jb.dz_out) jb.dz_out[o] = y > 0.f ? -jb.dz_w3[j] / jb.dz_rows : 0.f;
         } else if (MODE == GEMM_G) {
             jb.C[o] = jb.mask[o] > 0.f ? acc[q] : 0.f;
         } else {
@@ -149,7 +182,7 @@ struct PrepArgs {
 __global__ void __launch_bounds__(256) td3_prep_kernel(PrepArgs p)
 {
     const int m = blockIdx.x, tid = threadIdx.x, Dc = p.D + 2;
-    const unsigned long long cnt = *p.counter;       // (advanced by td3_tick_kernel, the next launch on the stream)
+    const unsigned long long cnt = *p.counter;       // (advanced by td3_tick inside td3_q_head_kernel, a later launch on the stream)
     size_t row = (size_t)m;
     if (p.size_dev) {
         const unsigned long long size = (unsigned long long)(*p.size_dev > 0 ? *p.size_dev : 1);
@@ -178,10 +211,11 @@ __global__ void __launch_bounds__(256) td3_prep_kernel(PrepArgs p)
     if (tid == 2) p.r[m] = p.rr[row];
     if (tid == 3) p.d[m] = p.rd[row];
 }
-// one thread: advance the update counter and the Adam step counters, publish this update's bias corrections
-__global__ void td3_tick_kernel(PrepArgs p)
+// one thread: advance the update counter and the Adam step counters, publish this update's bias corrections.  Runs inside
+// td3_q_head_kernel (a kernel of its own cost a full launch, ~4.6 us, for six scalar operations): after td3_prep_kernel, which reads
+// the counter, and before the first kernel that reads the corrections (td3_critic_head_bwd_kernel).
+__device__ __forceinline__ void td3_tick(const PrepArgs& p)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
     *p.counter += 1ull;
     p.steps[0] += 1.f;
     p.adam[0] = p.lr_critic / (1.f - powf(p.beta1, p.steps[0]));
@@ -221,9 +255,10 @@ __global__ void __launch_bounds__(256) td3_actor_head_kernel(const float* __rest
     }
 }
 // Critic.forward's last layer for up to four critics, one wavefront per (critic, row): q[z][m] = h2[z][m] . W3[z] + b3[z]
-struct QHeadArgs { const float* h2[4]; const float* W3[4]; const float* b3[4]; float* q[4]; int B, H, nz; };
+struct QHeadArgs { const float* h2[4]; const float* W3[4]; const float* b3[4]; float* q[4]; int B, H, nz; PrepArgs tick; };
 __global__ void __launch_bounds__(256) td3_q_head_kernel(QHeadArgs a)
 {
+    if (blockIdx.x == 0 && threadIdx.x == 0) td3_tick(a.tick);
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (t >= a.nz * a.B) return;
     const int z = t / a.B, m = t - z * a.B;
@@ -277,10 +312,17 @@ __global__ void __launch_bounds__(256) td3_critic_head_bwd_kernel(CriticHeadBwdA
     float g = 0.f, w = 0.f;
     if (n < a.H) {
         w = a.W3[z][n];
-        for (int m = rg; m < a.B; m += 4) {
-            const float h = a.h2[z][(size_t)m * a.H + n];
-            a.dz2[z][(size_t)m * a.H + n] = h > 0.f ? dq[m] * w : 0.f;
-            g = fmaf(dq[m], h, g);
+        // eight rows per pass, their loads issued together: written as load - store - load the stores (which may alias the loads as
+        // far as the compiler knows) kept the 32 L2 round trips of a thread in series -- 13.6 us for a kernel with 64 KB to read
+        for (int m0 = rg; m0 < a.B; m0 += 32) {
+            float hv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int m = m0 + 4 * u; hv[u] = m < a.B ? a.h2[z][(size_t)m * a.H + n] : 0.f; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int m = m0 + 4 * u;
+                if (m < a.B) { a.dz2[z][(size_t)m * a.H + n] = hv[u] > 0.f ? dq[m] * w : 0.f; g = fmaf(dq[m], hv[u], g); }
+            }
         }
     }
     part[rg * 64 + c] = g;
@@ -293,15 +335,8 @@ __global__ void __launch_bounds__(256) td3_critic_head_bwd_kernel(CriticHeadBwdA
         a.W3[z][n] = w - a.adam[0] * mm / (sqrtf(vv) / a.adam[1] + a.eps);
     }
 }
-// actor loss -mean Q1(s, pi(s)) (TD3:268-269), first link of the chain: d/dh2 of the critic, dz2[m][n] = -(1 / B) W3[n] [h2[m][n] > 0]
-__global__ void __launch_bounds__(256) td3_policy_dz2_kernel(const float* __restrict__ h2, const float* __restrict__ W3, float* __restrict__ dz2, int B, int H)
-{
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= B * H) return;
-    const int n = t % H;
-    dz2[t] = h2[t] > 0.f ? -W3[n] / (float)B : 0.f;
-}
-// ... through the critic's first layer to the action (the two action columns of W1) and through the heads' derivatives to the
+// actor loss -mean Q1(s, pi(s)) (TD3:268-269): its first link (d/dh2 of the critic) is td3_gemm_kernel<F>'s optional epilogue;
+// then through the critic's first layer to the action (the two action columns of W1) and through the heads' derivatives to the
 // logits, one wavefront per row:  da[m][o] = sum_n dz1q[m][n] W1q[n][D + o];  dlogit = da (.) (max_v s (1 - s), max_w (1 - t^2))
 __global__ void __launch_bounds__(256) td3_dlogit_kernel(const float* __restrict__ dz1q, const float* __restrict__ W1q, const float* __restrict__ logits,
                                                          float* __restrict__ dl, int B, int H, int Dc, float max_v, float max_w)
@@ -322,6 +357,8 @@ __global__ void __launch_bounds__(256) td3_dlogit_kernel(const float* __restrict
         dl[2 * m + lane] = (lane == 0 ? a0 : a1) * dh;
     }
 }
+// (Folding this step into the next kernel -- every workgroup re-evaluating it for all rows -- was measured: 14 -> 30 us for that kernel,
+// a wavefront walks its 32 rows as a chain of memory round trips; one row per wavefront over 32 workgroups is 4.8 us.)
 // ... then linear3 of the ACTOR backward + its Adam step; workgroup x = 64 hidden units, 4 row groups x 64 units:
 //   dz2a[m][n] = sum_o dlogit[m][o] W3a[o][n] [h2a[m][n] > 0];  dW3a[o][n] = sum_m dlogit[m][o] h2a[m][n];  db3a[o] = sum_m dlogit[m][o]
 struct ActorHeadBwdArgs {
@@ -349,10 +386,18 @@ __global__ void __launch_bounds__(256) td3_actor_head_bwd_kernel(ActorHeadBwdArg
     float g0 = 0.f, g1 = 0.f, w0 = 0.f, w1 = 0.f;
     if (n < a.H) {
         w0 = a.W3[n]; w1 = a.W3[a.H + n];
-        for (int m = rg; m < a.B; m += 4) {
-            const float h = a.h2a[(size_t)m * a.H + n];
-            a.dz2a[(size_t)m * a.H + n] = h > 0.f ? fmaf(dl[2 * m + 1], w1, dl[2 * m] * w0) : 0.f;
-            g0 = fmaf(dl[2 * m], h, g0); g1 = fmaf(dl[2 * m + 1], h, g1);
+        for (int m0 = rg; m0 < a.B; m0 += 32) {     // eight rows per pass (see td3_critic_head_bwd_kernel)
+            float hv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int m = m0 + 4 * u; hv[u] = m < a.B ? a.h2a[(size_t)m * a.H + n] : 0.f; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int m = m0 + 4 * u;
+                if (m < a.B) {
+                    a.dz2a[(size_t)m * a.H + n] = hv[u] > 0.f ? fmaf(dl[2 * m + 1], w1, dl[2 * m] * w0) : 0.f;
+                    g0 = fmaf(dl[2 * m], hv[u], g0); g1 = fmaf(dl[2 * m + 1], hv[u], g1);
+                }
+            }
         }
     }
     part[rg * 64 + c] = g0; part[256 + rg * 64 + c] = g1;
@@ -418,8 +463,12 @@ template <int MODE>
 void launch_gemm(const GemmArgs& ga, int njobs, hipStream_t st)
 {
     int gx = 0, gy = 0;
-    for (int z = 0; z < njobs; ++z) { const int x_ = (ga.job[z].J + 31) / 32, y_ = (ga.job[z].I + 31) / 32; gx = x_ > gx ? x_ : gx; gy = y_ > gy ? y_ : gy; }
-    hipLaunchKernelGGL(td3_gemm_kernel<MODE>, dim3(gx, gy, njobs), dim3(256), 0, st, ga);
+    int rmax = 0;
+    for (int z = 0; z < njobs; ++z) { const int x_ = (ga.job[z].J + 31) / 32, y_ = (ga.job[z].I + 31) / 32; gx = x_ > gx ? x_ : gx; gy = y_ > gy ? y_ : gy; rmax = ga.job[z].R > rmax ? ga.job[z].R : rmax; }
+    const int nch = (rmax + TD3_RC - 1) / TD3_RC;          // chunks of the deepest reduction in this launch
+    if (nch == 2) hipLaunchKernelGGL((td3_gemm_kernel<MODE, 2>), dim3(gx, gy, njobs), dim3(256), 0, st, ga);
+    else if (nch == 3 || nch == 4) hipLaunchKernelGGL((td3_gemm_kernel<MODE, 4>), dim3(gx, gy, njobs), dim3(256), 0, st, ga);
+    else hipLaunchKernelGGL((td3_gemm_kernel<MODE>), dim3(gx, gy, njobs), dim3(256), 0, st, ga);
 }
 }  // namespace
 
@@ -493,7 +542,6 @@ extern "C" int cn_td3_update(cn_td3_handle h, int do_actor, const cn_td3_batch* 
     pa.seed = c.seed; pa.B = B; pa.D = D; pa.do_actor = do_actor ? 1 : 0;
     pa.lr_critic = c.lr_critic; pa.lr_actor = c.lr_actor; pa.beta1 = c.beta1; pa.beta2 = c.beta2; pa.noise_std = c.noise_std; pa.noise_clip = c.noise_clip;
     hipLaunchKernelGGL(td3_prep_kernel, dim3(B), dim3(256), 0, st, pa);
-    hipLaunchKernelGGL(td3_tick_kernel, dim3(1), dim3(64), 0, st, pa);
 
     auto fwd_job = [&](GemmJob& j, const float* X, int ldx, int K, const float* W, const float* b, float* Y) {
         memset(&j, 0, sizeof(j));
@@ -523,7 +571,7 @@ extern "C" int cn_td3_update(cn_td3_handle h, int do_actor, const cn_td3_batch* 
     launch_gemm<GEMM_F>(ga, 4, st);
     QHeadArgs qa;
     for (int z = 0; z < 4; ++z) { qa.h2[z] = h->c_h2[z]; qa.W3[z] = crit[z]->w3; qa.b3[z] = crit[z]->b3; qa.q[z] = h->c_q[z]; }
-    qa.B = B; qa.H = H; qa.nz = 4;
+    qa.B = B; qa.H = H; qa.nz = 4; qa.tick = pa;
     hipLaunchKernelGGL(td3_q_head_kernel, dim3((4 * B + 3) / 4), dim3(256), 0, st, qa);
     // 7. TD target, MSE gradients, linear3 backward + Adam (both critics)
     CriticHeadBwdArgs ca;
@@ -551,9 +599,10 @@ extern "C" int cn_td3_update(cn_td3_handle h, int do_actor, const cn_td3_batch* 
                            h->xs, h->logits, B, H, Dc, c.max_v, c.max_w);
         // 13-14. the UPDATED first critic on (s, pi(s)) (TD3:268)
         fwd_job(ga.job[0], h->xs, Dc, Dc, c.q1.w1, c.q1.b1, h->c_h1[0]); launch_gemm<GEMM_F>(ga, 1, st);
-        fwd_job(ga.job[0], h->c_h1[0], H, H, c.q1.w2, c.q1.b2, h->c_h2[0]); launch_gemm<GEMM_F>(ga, 1, st);
-        // 15-17. -mean Q back to the action, through the heads, linear3 of the actor + Adam
-        hipLaunchKernelGGL(td3_policy_dz2_kernel, dim3((B * H + 255) / 256), dim3(256), 0, st, h->c_h2[0], c.q1.w3, h->dz2[0], B, H);
+        fwd_job(ga.job[0], h->c_h1[0], H, H, c.q1.w2, c.q1.b2, h->c_h2[0]);
+        ga.job[0].dz_w3 = c.q1.w3; ga.job[0].dz_out = h->dz2[0]; ga.job[0].dz_rows = (float)B;      // 15. -mean Q's gradient at h2, in the epilogue
+        launch_gemm<GEMM_F>(ga, 1, st);
+        // 16-17. ... back to the action, through the heads, linear3 of the actor + Adam
         bwd_data_job(ga.job[0], h->dz2[0], c.q1.w2, h->c_h1[0], h->dz1[0]); launch_gemm<GEMM_G>(ga, 1, st);
         hipLaunchKernelGGL(td3_dlogit_kernel, dim3((B + 3) / 4), dim3(256), 0, st, h->dz1[0], c.q1.w1, h->logits, h->noise, B, H, Dc, c.max_v, c.max_w);
         ActorHeadBwdArgs aa;
