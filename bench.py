@@ -288,9 +288,9 @@ def main():
             torch.cuda.synchronize(dev)
             ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(G)]
             ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(G)]
-            t0 = time.perf_counter()
             for g in range(G):
                 ev0[g].record(grp.streams[g])
+            t0 = time.perf_counter()                   # the K steps start here: the next host action is their first enqueue
             if self.timed_call is not None and steps == K and not self.python_loop:
                 self.timed_call()
             else:
@@ -383,7 +383,7 @@ def main():
     if single_default and not a.no_plateau:
         import dataclasses
         pcfg = dataclasses.replace(cfg, n_envs=16384)
-        pm = measure(pcfg, [Gmax], lacts=open_loop_actions(16384, 99), repeats=1, probe=False)
+        pm = measure(pcfg, [Gmax], lacts=open_loop_actions(16384, 99), repeats=min(R, 3), probe=False)
         plateau = pm["legs"][Gmax]["median"]
 
     # BASELINE configs[2] (TD3 actor in the loop: random-init 398-256-256-2 actor, sigma = 1 exploration, cn_actor_forward ->

@@ -48,6 +48,7 @@ extern "C" __global__ void cn_env_kernel_fair_s360(CnKParams p);
 extern "C" __global__ void cn_env_kernel_seq_s360(CnKParams p);
 extern "C" __global__ void cn_policy_kernel(CnKParams p);
 extern "C" __global__ void cn_policy_kernel_s360(CnKParams p);
+extern "C" __global__ void cn_policy_kernel_gt(CnKParams p);
 extern "C" __global__ void cn_env_kernel_s720(CnKParams p);
 extern "C" __global__ void cn_env_kernel_fair_s720(CnKParams p);
 extern "C" __global__ void cn_env_kernel_gt_seq(CnKParams p);
@@ -406,6 +407,7 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
             h->pol_lds = tot;
             HIPCHK(hipFuncSetAttribute((const void*)cn_policy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tot));
             HIPCHK(hipFuncSetAttribute((const void*)cn_policy_kernel_s360, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tot));
+            HIPCHK(hipFuncSetAttribute((const void*)cn_policy_kernel_gt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tot));
         }
     }
     *out = guard.release();
@@ -500,7 +502,7 @@ static KernelChoice choose_sequence_kernel(const cn_env_s* h)
 extern "C" const char* cn_kernel_name(cn_handle h, int what)
 {
     if (!h || what < 0 || what > 5) { fail(CN_ERR_ARG, "cn_kernel_name: bad argument"); return nullptr; }
-    if (what == 5) return h->shape360 ? "cn_policy_kernel_s360" : "cn_policy_kernel";
+    if (what == 5) return h->cfg.risk_mode == CN_RISK_GT ? "cn_policy_kernel_gt" : h->shape360 ? "cn_policy_kernel_s360" : "cn_policy_kernel";
     if (what == 2) return choose_sequence_kernel(h).name;
     return choose_kernel(h, what == 3, what == 1, what == 4).name;
 }
@@ -671,8 +673,8 @@ extern "C" int cn_rollout_policy(cn_handle h, const cn_actor_weights* w, const c
 {
     if (!h || !w || !io || !io->obs0 || !io->action || !io->obs || !io->reward || !io->done || !w->w1p || !w->b1 || !w->w2p || !w->b2 || !w->w3 || !w->b3)
         return fail(CN_ERR_ARG, "cn_rollout_policy: null argument");
-    if (h->cfg.obs_layout != CN_LAYOUT_RISK || h->cfg.risk_mode != CN_RISK_LIDAR_TRACKER || h->cfg.ped_contact || h->cfg.ped_mode == 2 || h->cfg.wheel_accel > 0.0)
-        return fail(CN_ERR_CONFIG, "cn_rollout_policy: built for obs_layout 0, risk_mode 0 with the plain simulator (no contact / social-force / wheel-ramp ticks)");
+    if (h->cfg.obs_layout != CN_LAYOUT_RISK || h->cfg.ped_contact || h->cfg.ped_mode == 2 || h->cfg.wheel_accel > 0.0)
+        return fail(CN_ERR_CONFIG, "cn_rollout_policy: built for obs_layout 0 with the plain simulator (no contact / social-force / wheel-ramp ticks)");
     if (!h->pol_lds)
         return fail(CN_ERR_CONFIG, "cn_rollout_policy: 16 environments of this shape do not fit one CU's LDS (160 KiB)");
     const int D = h->cfg.n_rays - 1 + 7 + 4 * h->cfg.k_obstacles;
@@ -692,7 +694,7 @@ extern "C" int cn_rollout_policy(cn_handle h, const cn_actor_weights* w, const c
     kp.pol_max_v = io->max_v; kp.pol_max_w = io->max_w; kp.pol_sigma = io->sigma;
     kp.pol_D = D; kp.pol_Dp = w->obs_dim_padded; kp.pol_wave_lds = (int32_t)h->pol_wave_lds;
     DeviceScope scope(h->device);
-    cn_kernel_fn fn = h->shape360 ? cn_policy_kernel_s360 : cn_policy_kernel;
+    cn_kernel_fn fn = h->cfg.risk_mode == CN_RISK_GT ? cn_policy_kernel_gt : h->shape360 ? cn_policy_kernel_s360 : cn_policy_kernel;
     hipLaunchKernelGGL(fn, dim3((h->cfg.n_envs + 15) / 16), dim3(1024), h->pol_lds, (hipStream_t)stream, kp);
     HIPCHK(hipGetLastError());
     return CN_OK;

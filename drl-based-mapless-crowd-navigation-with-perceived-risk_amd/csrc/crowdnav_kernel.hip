@@ -3032,7 +3032,7 @@ extern "C" __global__ void __launch_bounds__(ACT_THREADS) cn_actor_kernel(const 
 #ifndef POL_FAIR
 #define POL_FAIR 1            /* experiments: 0 = the sequence kernel's rotating levels instead of the falling ones */
 #endif
-template <int SHAPE>
+template <int SHAPE, bool GT = false>
 __device__ __forceinline__ void policy_sequence_body()
 {
     extern __shared__ __attribute__((aligned(16))) char cn_smem[];
@@ -3058,13 +3058,14 @@ __device__ __forceinline__ void policy_sequence_body()
 #if POL_FAIR == 0
             cn_setprio_uniform((t + (int)__builtin_amdgcn_s_getreg(4 | (1 << 11))) & 3);
 #endif
-            env_kernel_body<false, false, 0, false, 0, true, POL_FAIR != 0, SHAPE>(env, lane_, cn_smem + (size_t)wave * ws, t, act_lds + 2 * wave);
+            env_kernel_body<false, false, 0, GT, 0, true, POL_FAIR != 0, SHAPE>(env, lane_, cn_smem + (size_t)wave * ws, t, act_lds + 2 * wave);
         }
         __syncthreads();
     }
 }
 extern "C" __global__ void __launch_bounds__(64 * POL_ENVS) cn_policy_kernel(CnKParams p) { policy_sequence_body<0>(); }
 extern "C" __global__ void __launch_bounds__(64 * POL_ENVS) cn_policy_kernel_s360(CnKParams p) { policy_sequence_body<360>(); }
+extern "C" __global__ void __launch_bounds__(64 * POL_ENVS) cn_policy_kernel_gt(CnKParams p) { policy_sequence_body<0, true>(); }   // risk_mode gt
 #endif
 
 #if !defined(CN_TU) || CN_TU == 1

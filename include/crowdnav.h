@@ -330,8 +330,8 @@ int cn_step_sequence(cn_handle h, const cn_sequence_io* io, void* stream);
  *            alias slot 0 of obs when obs_stride = 0)
  *   action   dev n_steps slots [N, 2] float32, OUTPUT: slot t = the action period t took
  *   obs / reward / done / topk_idx (or NULL): as cn_sequence_io (slot t = what period t's step returned)
- * Requirements: those of cn_step_sequence, risk_mode 0, and an actor of cn_actor_pack_weights' layout for this handle's
- * observation width (hidden 256). */
+ * Requirements: those of cn_step_sequence (either risk_mode), 16 environments of the handle's shape fitting one CU's LDS, and an
+ * actor of cn_actor_pack_weights' layout for this handle's observation width (hidden 256). */
 typedef struct cn_policy_io {
     const float* obs0;
     float* action;

@@ -534,23 +534,24 @@ def test_step_sequence_kernel_equals_step_by_step(oracle_mod, risk_mode):
         VecEnv(Config(n_envs=16, obs_layout=1)).step_sequence(torch.zeros((2, 16, 2), device="cuda"))
 
 
-@pytest.mark.parametrize("shape", ["s360", "generic"])
+@pytest.mark.parametrize("shape", ["s360", "generic", "gt"])
 def test_policy_rollout_kernel_equals_act_then_step(oracle_mod, shape):
     """cn_rollout_policy -- T control periods with the TD3 actor INSIDE the step kernel (16 environments per workgroup, the
     actor on their CU's matrix cores between two steps, no launch in between) -- leaves exactly what T pairs of
     (cn_actor_forward with exploration noise, cn_step with the next-step reset) leave: the actions of every period, the
     observations / rewards / done flags / indices of every period, the final state record, counters, returns and the agent's
-    noise counter; into trajectory buffers and in place, across consecutive calls, for an env count that is not a multiple of
-    16.  The step-by-step run is checked against the oracle (fed the same actions) at every step."""
+    noise counter; into trajectory buffers and in place, across consecutive calls, for env counts that are not multiples of
+    16, for the headline-shape kernel, the generic one and the gt (risk_mode 1) one.  The step-by-step run is checked against the oracle (fed the same actions) at every step."""
     import torch
     from crowdnav import Config
     from crowdnav.env import VecEnv
     from crowdnav.td3 import Agent
     N, T = (648, 30) if shape == "s360" else (200, 24)
     cfg = (Config(n_envs=N, n_peds=20, max_steps=14, seed=47, ped_cycle_ms=1400) if shape == "s360" else
-           Config(n_envs=N, n_peds=12, n_rays=300, k_obstacles=6, max_steps=14, seed=48, ped_cycle_ms=1400))
+           Config(n_envs=N, n_peds=12, n_rays=300, k_obstacles=6, max_steps=14, seed=48, ped_cycle_ms=1400) if shape == "generic" else
+           Config(n_envs=N, n_peds=20, max_steps=14, seed=49, ped_cycle_ms=1400, risk_mode=1))
     ref, pol, inplace = VecEnv(cfg), VecEnv(cfg), VecEnv(cfg)
-    assert pol.kernel_name("policy") == ("cn_policy_kernel_s360" if shape == "s360" else "cn_policy_kernel")
+    assert pol.kernel_name("policy") == {"s360": "cn_policy_kernel_s360", "generic": "cn_policy_kernel", "gt": "cn_policy_kernel_gt"}[shape]
     orc = oracle_mod.Oracle(cfg.as_dict())
     oracle_mod.set_num_threads()
     agents = [Agent(obs_dim=cfg.obs_dim, device="cuda:0", seed=5, memory_size=16) for _ in range(3)]
@@ -592,7 +593,7 @@ def test_policy_rollout_kernel_equals_act_then_step(oracle_mod, shape):
     assert n_done > N // 2
     import crowdnav
     with pytest.raises(crowdnav.CrowdNavError):
-        VecEnv(Config(n_envs=16, risk_mode=1)).rollout_policy(a_ref, 2)
+        VecEnv(Config(n_envs=16, ped_contact=1)).rollout_policy(a_ref, 2)
 
 
 def test_collect_policy_fills_the_replay_like_the_per_step_loop():

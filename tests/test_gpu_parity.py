@@ -1036,7 +1036,18 @@ def test_error_codes_and_limits():
     assert L.cn_reset(h, None, None, None, None) == -1
     assert L.cn_snapshot(h, C.c_void_p(1), 8) == -5              # buffer too small
     assert L.cn_step_sequence(h, None, None) == -1 and b"null" in L.cn_last_error()
+    assert L.cn_rollout_policy(h, None, None, None) == -1 and b"null" in L.cn_last_error()
     L.cn_destroy(h)
+    # cn_rollout_policy: an actor of another observation width, and a shape whose 16 working sets do not fit a CU's LDS
+    import torch
+    from crowdnav.env import VecEnv
+    from crowdnav.td3 import Agent
+    small = Agent(obs_dim=382, device="cuda:0", seed=0, memory_size=16)
+    with pytest.raises(crowdnav.CrowdNavError, match="observation width"):
+        VecEnv(Config(n_envs=16)).rollout_policy(small, 1)
+    big = VecEnv(Config(n_envs=16, n_rays=720, n_peds=100, room_half=2.4))
+    with pytest.raises(crowdnav.CrowdNavError, match="do not fit"):
+        big.rollout_policy(Agent(obs_dim=big.D, device="cuda:0", seed=0, memory_size=16), 1)
     # 1024 rays x 128 pedestrians still fits (LDS sized per configuration)
     from crowdnav.env import VecEnv
     env = VecEnv(Config(n_envs=2, n_rays=1024, n_peds=128, room_half=3.0))

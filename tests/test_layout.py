@@ -42,6 +42,43 @@ def test_config_struct_matches_header_and_oracle():
     assert Config().obs_dim == 398 and Config(k_obstacles=4).obs_dim == 382  # TRAIN:88, checkpoints
 
 
+def test_python_mirrors_match_the_header_field_by_field(tmp_path):
+    """Every struct that crosses the boundary: sizeof and the offset of EVERY field as gcc lays out include/crowdnav.h, against
+    the ctypes mirror the Python host passes (a field added to one side only, or a reordering, shows up here, not as a silently
+    misread pointer on the GPU)."""
+    import shutil
+    import subprocess
+    from crowdnav import _abi
+    from crowdnav.config import CnConfig
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    pairs = [("cn_config", CnConfig), ("cn_step_io", _abi.CnStepIO), ("cn_external_io", _abi.CnExternalIO),
+             ("cn_actor_weights", _abi.CnActorWeights), ("cn_td3_mlp", _abi.CnTd3Mlp), ("cn_td3_config", _abi.CnTd3Config),
+             ("cn_td3_batch", _abi.CnTd3Batch), ("cn_sequence_io", _abi.CnSequenceIO), ("cn_policy_io", _abi.CnPolicyIO),
+             ("cn_snapshot_header", _abi.CnSnapshotHeader)]
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "crowdnav.h"', 'int main(void) {']
+    for cname, cls in pairs:
+        lines.append('printf("%s sizeof %%zu\\n", sizeof(%s));' % (cname, cname))
+        for f in cls._fields_:
+            lines.append('printf("%s %s %%zu\\n", offsetof(%s, %s));' % (cname, f[0], cname, f[0]))
+    lines += ['return 0; }']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)], check=True)
+    got = {}
+    for ln in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines():
+        a, b, c = ln.split()
+        got[(a, b)] = int(c)
+    n = 0
+    for cname, cls in pairs:
+        assert got[(cname, "sizeof")] == C.sizeof(cls), cname
+        for f in cls._fields_:
+            assert got[(cname, f[0])] == getattr(cls, f[0]).offset, (cname, f[0])
+            n += 1
+    assert n > 150
+
+
 def test_no_cpu_fallback():
     import torch
     if torch.cuda.is_available():
