@@ -129,6 +129,31 @@ def test_config3_actor_in_the_loop_4096_envs(oracle_mod, sigma):
     envs.close()
 
 
+def test_training_return_rises(tmp_path):
+    """Does the return rise?  The as-logged training run -- presets.training(drop_cospawned=True), the reference's
+    hyper-parameters and its one update of 128 per env-step (16 envs x 16 updates per launch), the reward the published log shows
+    (waypoint_reward 0), cn_td3_update, the next-step reset kernel, seed 0 -- for 18 000 launches (~45 s): nothing is learnt during
+    the first 6 000 launches, and by the end the policy reaches the goal in a good part of its episodes.  The run is bit-reproducible
+    (counter-based sampling and noise, no atomics in the update), so this is a fixed trajectory, not a statistical test: the same
+    command as profiles/r04/train/td3_as_logged_fused_e16_u16_wp0.txt, whose launch-18000 line reads 1069 episodes."""
+    import re
+    from crowdnav import train as T
+    a = T.main.__globals__["argparse"].Namespace(scenario="training_as_logged", envs=16, launches=18000, max_steps=1000, updates=16, batch=128,
+                                                 memory=1_000_000, checkpoint_every=10 ** 9, log_every=1000, ped_vmax=None, seed=0, device=0,
+                                                 out=str(tmp_path / "run"), csv=False, load=None, load_episode=0, evaluate=False,
+                                                 episodes_per_env=1, graphs=1, waypoint_reward=0, scan_f32=None, wheel_accel=None,
+                                                 reset_mode="next", max_csv_rows=100000, time_limit=0.0, learner="fused")
+    agent, episodes = T.train(a)
+    lines = [l for l in open(os.path.join(a.out, "progress.txt")).read().splitlines() if l.startswith("launch")]
+    win = [(int(m.group(1)), float(m.group(2)), float(m.group(3))) for m in
+           (re.search(r"launch\s+(\d+) .* success ([0-9.]+)  mean return\s+(-?[0-9.]+)", l) for l in lines) if m]
+    assert len(win) == 18 and 900 <= episodes <= 1300, (episodes, lines)      # 1069 on every box so far
+    early, late = [w for w in win if w[0] <= 6000], [w for w in win if w[0] > 15000]
+    assert max(w[1] for w in early) <= 0.05, lines                     # sigma = 1 exploration alone does not reach the goal
+    assert max(w[1] for w in late) >= 0.4, lines                       # ... the trained policy does
+    assert max(w[2] for w in late) > max(w[2] for w in early) + 100.0, lines
+
+
 @pytest.mark.parametrize("reset_mode", ["next", "same"])
 def test_batched_trainer_runs_on_the_next_step_reset_kernel(tmp_path, reset_mode):
     """crowdnav.train (TRAIN:40-168 batched) without a host synchronisation per launch: the actor as one kernel
