@@ -170,31 +170,42 @@ class Agent:
         self._noise_seed, self._fused_calls = int(seed), int(calls)
 
     def sync_fused_weights(self):
-        """(Re)build the packed float32 copies cn_actor_forward reads (cn_actor_pack_weights); call after the actor's weights change."""
+        """(Re)build the packed float32 copies cn_actor_forward / cn_rollout_policy read (cn_actor_pack_weights); call after the
+        actor's weights change.  The packed buffers and the cn_actor_weights struct are allocated once and refreshed IN PLACE
+        (two small copies + two pack kernels on the current stream), so pre-marshalled calls (bind_act_mfma,
+        VecEnv.bind_rollout_policy) keep reading the current weights.  The refresh is ordered on torch's current stream: a caller
+        that runs the actor on other streams (VecEnvGroups) orders this call after them (join) and their next launches after it (fork)."""
         import ctypes as C
         from . import _abi
         a = self.actor
         D = a.linear1.in_features
         Dp = (D + 31) // 32 * 32          # zero rows up to the packed layout's block of 32 inputs
         with torch.no_grad():
-            w1t = torch.zeros((Dp, 256), dtype=torch.float32, device=self.device)
-            w1t[:D] = a.linear1.weight.detach().t()
-            w2t = a.linear2.weight.detach().t().contiguous().float()
+            st8 = getattr(self, "_fw_stage", None)
+            if st8 is None or st8[0].shape != (Dp, 256):
+                w1t = torch.zeros((Dp, 256), dtype=torch.float32, device=self.device)      # rows D..Dp stay zero
+                w2t = torch.empty((256, 256), dtype=torch.float32, device=self.device)
+                self._fw_stage = (w1t, w2t, torch.empty_like(w1t), torch.empty_like(w2t))
+            w1t, w2t, w1p, w2p = self._fw_stage
+            w1t[:D].copy_(a.linear1.weight.detach().t())
+            w2t.copy_(a.linear2.weight.detach().t())
             L = _abi.lib()
-            w1p, w2p = torch.empty_like(w1t), torch.empty_like(w2t)
             st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
             # K-major -> the order the kernel's wavefronts consume (16-byte loads, 4 KB contiguous per wavefront and block)
             _abi.check(L.cn_actor_pack_weights(C.c_void_p(w1t.data_ptr()), Dp, C.c_void_p(w1p.data_ptr()), self._dev_index, st))
             _abi.check(L.cn_actor_pack_weights(C.c_void_p(w2t.data_ptr()), 256, C.c_void_p(w2p.data_ptr()), self._dev_index, st))
-            # no host synchronise: the pack kernels were enqueued on torch's current stream, so the caching allocator's
-            # stream-ordered reuse of w1t / w2t (freed with this scope) cannot overtake them
+            # biases and linear3 are read where they live (float32, contiguous nn.Linear storages: .float().contiguous() is the tensor itself)
             self._fw = dict(w1p=w1p, b1=a.linear1.bias.detach().float().contiguous(),
                             w2p=w2p, b2=a.linear2.bias.detach().float().contiguous(),
                             w3=a.linear3.weight.detach().float().contiguous(), b3=a.linear3.bias.detach().float().contiguous())
         f = self._fw
-        self._fw_struct = _abi.CnActorWeights(w1p=f["w1p"].data_ptr(), b1=f["b1"].data_ptr(), w2p=f["w2p"].data_ptr(),
-                                              b2=f["b2"].data_ptr(), w3=f["w3"].data_ptr(), b3=f["b3"].data_ptr(),
-                                              obs_dim=D, obs_dim_padded=Dp, hidden=256, reserved=0)
+        vals = dict(w1p=f["w1p"].data_ptr(), b1=f["b1"].data_ptr(), w2p=f["w2p"].data_ptr(), b2=f["b2"].data_ptr(), w3=f["w3"].data_ptr(),
+                    b3=f["b3"].data_ptr(), obs_dim=D, obs_dim_padded=Dp, hidden=256, reserved=0)
+        if hasattr(self, "_fw_struct"):
+            for k, v in vals.items():
+                setattr(self._fw_struct, k, v)          # same object: byref()s taken earlier stay valid
+        else:
+            self._fw_struct = _abi.CnActorWeights(**vals)
 
     @torch.no_grad()
     def act_mfma(self, obs, out=None, add_noise=True, stream=None, noise_seed=None):
