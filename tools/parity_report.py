@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--scan-f32", type=int, default=0, help="cn_config.scan_f32")
     ap.add_argument("--wheel-accel", type=float, default=0.0, help="cn_config.wheel_accel")
     ap.add_argument("--waypoint-reward", type=int, default=200, help="cn_config.waypoint_reward")
+    ap.add_argument("--policy", type=int, default=0, help="T > 0: closed loop -- cn_rollout_policy launches of T periods (a random-init TD3 actor "
+                    "inside the step kernel, sigma = 1 exploration); the oracle replays the actions the kernel recorded")
     a = ap.parse_args()
     import torch
     from crowdnav import Config
@@ -63,6 +65,37 @@ def main():
     rng = np.random.default_rng(a.seed)
     tot = dict(obs_rows=0, scan=0, tail=0, feat=0, reward=0, done=0, idx=0, rows=0)
     shown = 0
+    if a.policy:
+        # closed loop: the policy kernel decides, the oracle is fed what it decided (float32 observations: the kernel's own output width)
+        from crowdnav.td3 import Agent
+        assert a.reset_mode == "next" and a.layout == 0
+        print("kernel: policy %s" % env.kernel_name("policy"))
+        agent = Agent(obs_dim=cfg.obs_dim, device="cuda:0", seed=a.seed, memory_size=16)
+        T, N, D, K = a.policy, a.envs, env.D, env.K
+        traj = dict(action=torch.zeros((T, N, 2), device="cuda"), obs=torch.zeros((T, N, D), device="cuda"), reward=torch.zeros((T, N), device="cuda"),
+                    done=torch.zeros((T, N), dtype=torch.uint8, device="cuda"), topk_idx=torch.zeros((T, N, K), dtype=torch.int32, device="cuda"))
+        moved = 0.0
+        for t0 in range(0, a.steps, T):
+            env.rollout_policy(agent, T, traj=traj)
+            torch.cuda.synchronize()
+            A = traj["action"].cpu().numpy(); O = traj["obs"].cpu().numpy(); R = traj["reward"].cpu().numpy(); Dn = traj["done"].cpu().numpy(); I = traj["topk_idx"].cpu().numpy()
+            moved += float(np.abs(A[:, :, 1]).mean())
+            for t in range(T):
+                oc, rc, dc, ic = orc.step(A[t].astype(np.float64), auto_reset="next")
+                oc = oc.astype(np.float32)
+                bad_rows = ~(O[t] == oc).all(1)
+                tot["rows"] += N; tot["obs_rows"] += int(bad_rows.sum())
+                tot["scan"] += int((O[t][:, :n] != oc[:, :n]).any(1).sum()); tot["tail"] += int((O[t][:, n:n + 7] != oc[:, n:n + 7]).any(1).sum())
+                tot["feat"] += int((O[t][:, n + 7:] != oc[:, n + 7:]).any(1).sum()); tot["reward"] += int((R[t] != rc.astype(np.float32)).sum())
+                tot["done"] += int((Dn[t] != dc).sum()); tot["idx"] += int((I[t] != ic).any(1).sum())
+                if bad_rows.any() and shown < a.verbose:
+                    shown += 1
+                    e = int(np.nonzero(bad_rows)[0][0]); cols = np.nonzero(O[t][e] != oc[e])[0]
+                    print("period %d env %d: bad cols %s gpu %s cpu %s" % (t0 + t, e, cols[:12], O[t][e][cols[:8]], oc[e][cols[:8]]))
+        print("TOTAL over %d env-steps: %s" % (tot["rows"], tot))
+        cg = env.counters().cpu().numpy(); cc = orc.counters()
+        print("counters equal:", np.array_equal(cg[:, :6], cc), " episodes finished:", int(cg[:, 8].sum()), " mean |w| commanded %.3f" % (moved / max(1, a.steps // T)))
+        return
     for t in range(a.steps):
         act = np.stack([rng.uniform(0, 0.22, a.envs), rng.uniform(-2, 2, a.envs)], 1).astype(np.float32)
         env.step(torch.from_numpy(act).cuda(), auto_reset=a.reset_mode, want_final=True)

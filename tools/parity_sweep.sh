@@ -34,4 +34,8 @@ $R --envs 2048 --steps $((200 * S)) --scan-f32 1 --wheel-accel 1.0 --waypoint-re
 $R --envs 1024 --steps $((200 * S)) --peds 60 --scan-f32 1 --wheel-accel 1.0 --risk-mode 1
 $R --envs 1024 --steps $((200 * S)) --peds 6 --waypoint-reward 0 --max-steps 300 --reset-mode next
 $R --envs 256 --steps $((100 * S)) --ped-mode 2 --peds 100 --rays 720 --room 2.4 --reset-mode next
+# round 4: the policy inside the step kernel (cn_rollout_policy, closed loop; the oracle replays the recorded actions): headline shape, generic shape, gt
+$R --envs 4096 --steps $((100 * S)) --max-steps 60 --reset-mode next --policy 20
+$R --envs 1000 --steps $((200 * S)) --peds 14 --k 4 --rays 300 --reset-mode next --policy 25
+$R --envs 1024 --steps $((200 * S)) --risk-mode 1 --reset-mode next --policy 40
 } 2>&1 | grep -v amdgpu.ids | tee "$OUT/$NAME.txt"
