@@ -395,11 +395,12 @@ def main():
         agent = Agent(obs_dim=cfg.obs_dim, device="cuda:%d" % dev_index, seed=0, memory_size=16)
         m3 = measure(cfg, list(cands) + ["policy_sequence"], agent=agent, repeats=min(R, 3))
         c5 = Config(n_envs=N, n_peds=100, n_rays=720, k_obstacles=a.k, max_steps=1000, seed=1234, ped_cycle_ms=1400, room_half=2.40)
-        m5 = measure(c5, [Gmax, 1] if Gmax > 1 else [1], lacts=acts, repeats=min(R, 3))
+        m5 = measure(c5, ([Gmax, 1] if Gmax > 1 else [1]) + ["sequence"], lacts=acts, repeats=min(R, 3))
         for key, m, P_, R_, what in (("configs[2]", m3, 20, 360, "4096 envs x 20 pedestrians x 360 rays, K=8, TD3 actor in the loop "
                                       "(f32-MFMA actor + exploration noise -> Env.step, closed loop: policy_sequence = the K periods as ONE "
                                       "cn_rollout_policy launch, the actor inside the step kernel; N_groups = a cn_actor_forward -> cn_step chain per stream group)"),
-                                     ("configs[4]", m5, 100, 720, "4096 envs x 100 pedestrians x 720 rays, K=8, room 4.8 m, open loop")):
+                                     ("configs[4]", m5, 100, 720, "4096 envs x 100 pedestrians x 720 rays, K=8, room 4.8 m, open loop (sequence = the K steps as "
+                                      "ONE cn_step_sequence launch, open-loop only; N_groups = one launch per step and stream group)")):
             l_ = m["legs"][m["chosen"]]
             d4 = d4_bytes(P_, R_, a.k)
             other[key] = {"workload": what, "value": l_["median"], "unit": "env-steps/s", "ms_per_step": l_["wall"] / K * 1e3,

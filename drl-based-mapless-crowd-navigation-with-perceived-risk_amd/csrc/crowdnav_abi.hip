@@ -46,6 +46,7 @@ extern "C" __global__ void cn_env_kernel_seq(CnKParams p);
 extern "C" __global__ void cn_env_kernel_s360(CnKParams p);
 extern "C" __global__ void cn_env_kernel_fair_s360(CnKParams p);
 extern "C" __global__ void cn_env_kernel_seq_s360(CnKParams p);
+extern "C" __global__ void cn_env_kernel_seq_s720(CnKParams p);
 extern "C" __global__ void cn_policy_kernel(CnKParams p);
 extern "C" __global__ void cn_policy_kernel_s360(CnKParams p);
 extern "C" __global__ void cn_policy_kernel_gt(CnKParams p);
@@ -375,6 +376,7 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
         HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_s360, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
         HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_fair_s360, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
         HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_seq_s360, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
+        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_seq_s720, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
         HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_s720, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
         HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_fair_s720, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
         HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_wa, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
@@ -496,7 +498,8 @@ static KernelChoice choose_kernel(const cn_env_s* h, bool ext, bool same, bool o
 }
 static KernelChoice choose_sequence_kernel(const cn_env_s* h)
 {
-    return h->cfg.risk_mode == CN_RISK_GT ? CN_KC(cn_env_kernel_gt_seq) : (h->shape360 ? CN_KC(cn_env_kernel_seq_s360) : CN_KC(cn_env_kernel_seq));
+    return h->cfg.risk_mode == CN_RISK_GT ? CN_KC(cn_env_kernel_gt_seq)
+         : h->shape360 ? CN_KC(cn_env_kernel_seq_s360) : h->shape720 ? CN_KC(cn_env_kernel_seq_s720) : CN_KC(cn_env_kernel_seq);
 }
 
 extern "C" const char* cn_kernel_name(cn_handle h, int what)

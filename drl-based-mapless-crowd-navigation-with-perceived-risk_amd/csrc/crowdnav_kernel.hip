@@ -2667,6 +2667,7 @@ __device__ __forceinline__ void sequence_body()
 }
 extern "C" __global__ void CN_HOT_BOUNDS cn_env_kernel_seq(CnKParams p) { sequence_body<false>(); }
 extern "C" __global__ void CN_HOT_BOUNDS cn_env_kernel_seq_s360(CnKParams p) { sequence_body<false, 360>(); }
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_seq_s720(CnKParams p) { sequence_body<false, 720>(); }
 extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_gt_seq(CnKParams p) { sequence_body<true>(); }
 #endif
 #if !defined(CN_TU) || CN_TU == 1

@@ -559,6 +559,33 @@ def test_step_sequence_kernel_equals_step_by_step(oracle_mod, risk_mode):
         VecEnv(Config(n_envs=16, obs_layout=1)).step_sequence(torch.zeros((2, 16, 2), device="cuda"))
 
 
+def test_step_sequence_kernel_of_the_dense_shape_equals_step_by_step():
+    """cn_env_kernel_seq_s720 (BASELINE configs[4]: 100 pedestrians x 720 rays, the sequence kernel compiled for that shape):
+    every step's outputs and the final state record equal T calls of cn_step."""
+    import torch
+    from crowdnav import Config
+    from crowdnav.env import VecEnv
+    N, T = 96, 40
+    cfg = Config(n_envs=N, n_peds=100, n_rays=720, room_half=2.4, max_steps=15, seed=5, ped_cycle_ms=1400)
+    ref, seq = VecEnv(cfg), VecEnv(cfg)
+    assert seq.kernel_name("sequence") == "cn_env_kernel_seq_s720" and ref.kernel_name("step") in ("cn_env_kernel_s720", "cn_env_kernel_fair_s720")
+    ref.reset(); seq.reset()
+    g = torch.Generator(device="cpu").manual_seed(8)
+    acts = torch.stack([torch.rand((T, N), generator=g) * 0.22, torch.rand((T, N), generator=g) * 4 - 2], 2).cuda().contiguous()
+    D, K = ref.D, ref.K
+    traj = dict(obs=torch.zeros((T, N, D), device="cuda"), reward=torch.zeros((T, N), device="cuda"),
+                done=torch.zeros((T, N), dtype=torch.uint8, device="cuda"), topk_idx=torch.zeros((T, N, K), dtype=torch.int32, device="cuda"))
+    seq.step_sequence(acts, traj=traj)
+    n_done = 0
+    for t in range(T):
+        ref.step(acts[t].contiguous(), auto_reset="next")
+        torch.cuda.synchronize()
+        assert torch.equal(traj["obs"][t], ref.obs) and torch.equal(traj["reward"][t], ref.reward), t
+        assert torch.equal(traj["done"][t], ref.done) and torch.equal(traj["topk_idx"][t], ref.topk_idx), t
+        n_done += int(ref.done.sum())
+    assert n_done > N and np.array_equal(seq.snapshot(), ref.snapshot())
+
+
 @pytest.mark.parametrize("shape", ["s360", "generic", "gt"])
 def test_policy_rollout_kernel_equals_act_then_step(oracle_mod, shape):
     """cn_rollout_policy -- T control periods with the TD3 actor INSIDE the step kernel (16 environments per workgroup, the
