@@ -189,6 +189,10 @@ __device__ __forceinline__ void waypoint_refresh(KP p, const Poly& pg, EnvRegs& 
 // the integration is cut in two -- x <- clamp(fma(v, split - tc, x)), then on from there -- exactly as two back-to-back calls
 // [t0, t0 + split], [t0 + split, t1] would: Env.step samples the world at +150 ms (deque) and +160 ms (scan), and the same
 // fma chain cut at the same instants gives the same bits while the schedule prologue runs once.
+// PACK (the shape kernels with 2 P <= 64): lane = (pedestrian, axis) -- the two coordinates of a pedestrian go through the same
+// fma / clamp chain and the same generator on different data, so 2 P lanes do in one pass what P lanes did twice (20 of 64 lanes
+// busy -> 40; same operations per coordinate, same bits).  The schedule arithmetic is per lane either way.
+template <bool PACK = false>
 __device__ __forceinline__ void ped_advance(KP p, int env, int lane, double* ped_p, double* ped_v, long long t0, long long t1, int split = 0)
 {
     const double lo = -p->room_half + p->ped_radius, hi = p->room_half - p->ped_radius;
@@ -204,6 +208,42 @@ __device__ __forceinline__ void ped_advance(KP p, int env, int lane, double* ped
     if (ph64 >= T) { cyc += 1; ph64 -= T; }
     const int ph = (int)ph64;
     const int dt = (int)(t1 - t0);
+    if constexpr (PACK) {
+        for (int l = lane; l < 2 * p->P; l += 64) {
+            const int i = l >> 1, ax = l & 1;
+            double x = ped_p[l], vx = ped_v[l];
+            const int offs = i * p->ped_stagger_ms;
+            const long long tt = cyc * (long long)T + (long long)(ph - offs);      // t0 - offs
+            unsigned m; int a;
+            if (tt <= 0) { m = 0u; a = (int)(-tt); }
+            else {
+                const int num = (ph - offs) + T - 1;
+                int q = (int)floor((double)num * invT);
+                int r = num - q * T;
+                if (r < 0) { q -= 1; r += T; }
+                if (r >= T) { q += 1; }
+                m = (unsigned)cyc + (unsigned)q;
+                a = q * T - (ph - offs);
+            }
+            int tc = 0;
+            while (a < dt) {
+                if (split > tc && a >= split) { x = cn_vclamp(fma(vx, cn_div1000((double)(split - tc)), x), lo, hi); tc = split; }
+                if (a > tc) { x = cn_vclamp(fma(vx, cn_div1000((double)(a - tc)), x), lo, hi); tc = a; }
+                if (p->ped_mode == 0) {
+                    const uint64_t hbase = cn_mix64(p->seed ^ cn_mix64((uint64_t)gid));
+                    const uint64_t h1 = cn_mix64(hbase ^ ((1ull << 32) | (uint64_t)(uint32_t)i));
+                    const double u = (double)(cn_mix64(h1 ^ (uint64_t)(uint32_t)(2u * m + (unsigned)ax)) >> 11) * (1.0 / 9007199254740992.0);
+                    vx = fma(2.0 * p->ped_vmax, u, -p->ped_vmax);
+                } else vx = preset[l];
+                a += T;
+                m += 1u;
+            }
+            if (split > tc) { x = cn_vclamp(fma(vx, cn_div1000((double)(split - tc)), x), lo, hi); tc = split; }
+            if (dt > tc) x = cn_vclamp(fma(vx, cn_div1000((double)(dt - tc)), x), lo, hi);
+            ped_p[l] = x; ped_v[l] = vx;
+        }
+        return;
+    }
     for (int i = lane; i < p->P; i += 64) {
         double x = ped_p[2 * i], y = ped_p[2 * i + 1];
         double vx = ped_v[2 * i], vy = ped_v[2 * i + 1];
@@ -2374,7 +2414,7 @@ __device__ __forceinline__ void env_kernel_body(const int env, const int lane, c
                 else {
                 if constexpr (LAYOUT == 0) { step_trig(p, e, lane, rs1, rc1, rs2, rc2, trig); have_trig = true; }
                 // pedestrians: ONE pass over [0, dt + scan latency], cut at dt (they are only looked at by the scan)
-                ped_advance(p, env, lane, L.ped, pedv, e.crowd_ms, e.crowd_ms + p->dt_ms + p->scan_latency_ms, p->dt_ms);
+                ped_advance<SHAPE == 360>(p, env, lane, L.ped, pedv, e.crowd_ms, e.crowd_ms + p->dt_ms + p->scan_latency_ms, p->dt_ms);
                 e.crowd_ms += p->dt_ms + p->scan_latency_ms;
                 if (have_trig) robot_advance_sc(p, e, p->dt_ms, rs1, rc1); else robot_advance(p, e, p->dt_ms);
                 }
