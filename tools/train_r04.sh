@@ -24,6 +24,8 @@ case "$SET" in
   resetab) # the reset convention isolated -- same seed, scenario, env count, learner; only --reset-mode differs
     run fused_next_e16 --envs 16 --updates 16 --waypoint-reward 0 --learner fused --reset-mode next
     run fused_same_e16 --envs 16 --updates 16 --waypoint-reward 0 --learner fused --reset-mode same ;;
+  final)   # the 16-env recipe on the final tree (cn_td3_update at 0.127 ms)
+    run final_fused_e16_u16_wp0 --envs 16 --updates 16 --waypoint-reward 0 --learner fused ;;
   fused)   # the same runs on cn_td3_update (csrc/crowdnav_td3.hip): the reference's ratio of one update per env-step, and 4x the envs
     run fused_e16_u16_wp0 --envs 16 --updates 16 --waypoint-reward 0 --learner fused
     run fused_e64_u64_wp0 --envs 64 --updates 64 --waypoint-reward 0 --learner fused ;;
