@@ -104,7 +104,7 @@ class Agent:
 
     def __init__(self, obs_dim=398, hidden=256, actor_lr=3e-4, critic_lr=3e-4, batch_size=128, memory_size=1_000_000,
                  gamma=0.99, tau=0.005, max_v=0.22, max_w=2.0, noise_std=0.2, noise_clip=0.5, policy_delay=2,
-                 explore_sigma=1.0, device="cuda", seed=0):
+                 explore_sigma=1.0, device="cuda", seed=0, actor_final_init=None):
         self.device = torch.device(device)
         g = torch.Generator().manual_seed(seed)
         torch.manual_seed(seed)
@@ -112,6 +112,13 @@ class Agent:
         self.actor_t = Actor(obs_dim, 2, hidden, max_v, max_w).to(self.device)
         self.q1, self.q2 = Critic(obs_dim, 2, hidden).to(self.device), Critic(obs_dim, 2, hidden).to(self.device)
         self.q1_t, self.q2_t = Critic(obs_dim, 2, hidden).to(self.device), Critic(obs_dim, 2, hidden).to(self.device)
+        if actor_final_init:
+            # NOT the reference (td3.py:81-95 keeps nn.Linear's default U(+-1/sqrt(256)) everywhere): the DDPG paper's small uniform
+            # initialisation of the actor's output layer, an opt-in for the seed sensitivity documented in profiles/r04/train/ (heads
+            # that start near the middle of the sigmoid / tanh instead of wherever the default range leaves them)
+            with torch.no_grad():
+                self.actor.linear3.weight.uniform_(-float(actor_final_init), float(actor_final_init))
+                self.actor.linear3.bias.uniform_(-float(actor_final_init), float(actor_final_init))
         for t, s in ((self.actor_t, self.actor), (self.q1_t, self.q1), (self.q2_t, self.q2)):
             t.load_state_dict(s.state_dict())
         fused = self.device.type == "cuda"        # one kernel per optimizer step instead of ~10 per parameter tensor;

@@ -91,7 +91,8 @@ def train(a):
     torch.cuda.set_device(dev)        # policy kernels and torch ops of this process all target the env's GPU
     env = make_env(a.scenario, a.envs, a.max_steps, a.seed, dev, a.ped_vmax, waypoint_reward=a.waypoint_reward,
                    scan_f32=a.scan_f32, wheel_accel=a.wheel_accel)
-    agent = Agent(obs_dim=env.D, device="cuda:%d" % dev, seed=a.seed, batch_size=a.batch, memory_size=a.memory)
+    agent = Agent(obs_dim=env.D, device="cuda:%d" % dev, seed=a.seed, batch_size=a.batch, memory_size=a.memory,
+                  actor_final_init=getattr(a, "actor_final_init", None))
     if a.load:
         agent.load_models(*[os.path.join(a.load, "td3_%s_model_ep%d.pt" % (n, a.load_episode)) for n in ("actor", "critic1", "critic2")])
         ns = os.path.join(a.load, "noise_state_ep%d.txt" % a.load_episode)
@@ -213,6 +214,7 @@ def main(argv=None):
     ap.add_argument("--reset-mode", default="next", choices=["next", "same"], help="next: the fast kernel, reset launches masked out of the replay; same: same-call reset + final_obs")
     ap.add_argument("--graphs", type=int, default=1, help="1: capture the TD3 update into hipGraphs (Agent.enable_graphs)")
     ap.add_argument("--learner", default="torch", choices=["torch", "fused"], help="torch: the PyTorch update (eager / hipGraph); fused: cn_td3_update (csrc/crowdnav_td3.hip)")
+    ap.add_argument("--actor-final-init", type=float, default=None, help="NOT the reference: U(+-x) initialisation of the actor's output layer (e.g. 0.003)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--out", default="runs/td3")

@@ -4,8 +4,8 @@
 SET="${1:-probe}"; LIM="${2:-420}"
 cd "$(dirname "$0")/.."; OUT="gpurun_out/train_$SET"; mkdir -p "$OUT"
 export PYTHONPATH="$PWD/drl-based-mapless-crowd-navigation-with-perceived-risk_amd:${PYTHONPATH:-}"
-run() { name="$1"; shift
-  python -m crowdnav.train --scenario training_as_logged --csv --log-every 250 --launches 100000000 --time-limit "$LIM" --out "$OUT/$name" "$@" 2>&1 | grep -v amdgpu.ids > "$OUT/$name.txt"
+run() { name="$1"; shift; CSV="--csv"; [ "${NOCSV:-0}" = 1 ] && CSV=""
+  python -m crowdnav.train --scenario training_as_logged $CSV --log-every 250 --launches 100000000 --time-limit "$LIM" --out "$OUT/$name" "$@" 2>&1 | grep -v amdgpu.ids > "$OUT/$name.txt"
   echo "== $name: $*"; tail -3 "$OUT/$name.txt"; rm -f "$OUT/$name"/*.pt; }
 case "$SET" in
   probe)   # the published log's reward (no way-point bonus) at the reference's update-to-data ratio of 1, and the committed reward beside it
@@ -24,6 +24,8 @@ case "$SET" in
   resetab) # the reset convention isolated -- same seed, scenario, env count, learner; only --reset-mode differs
     run fused_next_e16 --envs 16 --updates 16 --waypoint-reward 0 --learner fused --reset-mode next
     run fused_same_e16 --envs 16 --updates 16 --waypoint-reward 0 --learner fused --reset-mode same ;;
+  init)    # NOT the reference: the actor's output layer initialised U(+-0.003); does the seed sensitivity go away?
+    for S in 0 1 2 3 4 5 6 7; do run init003_fused_e16_seed$S --envs 16 --updates 16 --waypoint-reward 0 --learner fused --seed $S --actor-final-init 0.003; done ;;
   final)   # the 16-env recipe on the final tree (cn_td3_update at 0.127 ms)
     run final_fused_e16_u16_wp0 --envs 16 --updates 16 --waypoint-reward 0 --learner fused ;;
   fused)   # the same runs on cn_td3_update (csrc/crowdnav_td3.hip): the reference's ratio of one update per env-step, and 4x the envs
