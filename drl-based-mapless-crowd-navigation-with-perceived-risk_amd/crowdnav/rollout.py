@@ -60,6 +60,23 @@ class EpisodeStats:
             w = csv.writer(fp, dialect="excel")
             w.writerow(self.HEADERS)
             w.writerows(self.rows)
+        self._flushed = (path, len(self.rows))
+        return path
+
+    def append_csv(self, outdir, filename):
+        """Incremental write_csv: the header the first time, then only the rows added since the last call -- so a run that is
+        killed keeps every episode up to its last log interval (the reference appends one row per episode, UTL:53-64)."""
+        path = os.path.join(outdir, filename + ".csv")
+        done = getattr(self, "_flushed", (None, 0))
+        if done[0] != path:
+            os.makedirs(outdir, exist_ok=True)
+            with open(path, "w", newline="") as fp:
+                csv.writer(fp, dialect="excel").writerow(self.HEADERS)
+            done = (path, 0)
+        if len(self.rows) > done[1]:
+            with open(path, "a", newline="") as fp:
+                csv.writer(fp, dialect="excel").writerows(self.rows[done[1]:])
+        self._flushed = (path, len(self.rows))
         return path
 
 
@@ -101,8 +118,7 @@ def rollout(env, agent, n_steps, learn=False, add_noise=True, stats=None, policy
             if learn:
                 agent.memory.add_masked(prev, act, reward, env.final_obs, done, torch.ones_like(resetting))
         if learn:
-            agent.memory.sync_len()
-            agent.learn(t)
+            agent.learn(t)            # gates itself on DeviceReplay.ready(batch): no host read once the ring holds a batch
         if stats is not None and bool(done.any()):
             # columns 10..13 keep the finished episode's counters as they stood when Env.step returned done (what TRAIN:142-147
             # reads), terminal step included

@@ -42,14 +42,24 @@ class Critic(nn.Module):
         return self.linear3(x)
 
 
+def _device_scalar_view(ptr, device):
+    """A 0-d float32 tensor aliasing one device float owned by libcrowdnav (alive as long as its handle)."""
+    class _Arr:
+        __cuda_array_interface__ = {"shape": (1,), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
+    return torch.as_tensor(_Arr(), device=device).reshape(())
+
+
 class DeviceReplay:
-    """Ring buffer on the device (ReplayBuffer, TD3:19-37, without the Python list).  Write position and fill level live on the
-    device too (`pos_dev`, `size_dev`), so a masked add needs no host read: rows that are not transitions are written to a
-    spare row past the end of the ring.  `len()` is the host's count: exact after add(), a lower-bound estimate refreshed by
-    sync_len() after add_masked()."""
+    """Ring buffer on the device (ReplayBuffer, TD3:19-37, without the Python list).  ONE source of truth for the write position
+    and the fill level: the device scalars `pos_dev` / `size_dev`.  Every write -- add() and add_masked() alike -- indexes from
+    `pos_dev` on the device, so the two can be mixed freely; rows that are not transitions go to a spare row past the end of the
+    ring.  The host only keeps BOUNDS on the fill level (`_lb` <= size_dev <= `_ub`): add() moves both (every row is kept),
+    add_masked() moves the upper one only.  `ready(n)` answers "more than n rows?" from the bounds and reads the device scalar
+    only while they straddle n -- never again once the ring holds more than a batch -- and `len()` is exact (it reads the device
+    when the bounds differ)."""
 
     def __init__(self, capacity, obs_dim, device):
-        self.cap, self.pos, self.size = int(capacity), 0, 0
+        self.cap = int(capacity)
         cap1 = self.cap + 1                       # row `cap`: where add_masked() drops the rows it does not keep
         self.s = torch.zeros((cap1, obs_dim), dtype=torch.float32, device=device)
         self.s2 = torch.zeros((cap1, obs_dim), dtype=torch.float32, device=device)
@@ -58,35 +68,56 @@ class DeviceReplay:
         self.d = torch.zeros((cap1, 1), dtype=torch.float32, device=device)
         self.pos_dev = torch.zeros((), dtype=torch.int64, device=device)
         self.size_dev = torch.zeros((), dtype=torch.int64, device=device)
+        self._lb, self._ub = 0, 0
         self._ar = None
 
     def add(self, s, a, r, s2, d):
+        """ReplayBuffer.add for a batch of transitions (all rows kept).  Same device-side path as add_masked()."""
         n = s.shape[0]
-        idx = (torch.arange(n, device=s.device) + self.pos) % self.cap
-        self.s[idx], self.a[idx], self.s2[idx] = s, a, s2
-        self.r[idx, 0], self.d[idx, 0] = r, d.float()
-        self.pos = (self.pos + n) % self.cap
-        self.size = min(self.cap, self.size + n)
-        self.pos_dev.fill_(self.pos); self.size_dev.fill_(self.size)
+        self._write(s, a, r, s2, d, None)
+        self._lb, self._ub = min(self.cap, self._lb + n), min(self.cap, self._ub + n)
 
     def add_masked(self, s, a, r, s2, d, keep):
         """add() for the rows where `keep` (bool [n]) is set -- the others are not transitions (an env's reset launch under the
         next-step reset convention).  No host synchronisation: kept rows go to consecutive ring slots after `pos_dev`, the
-        rest to the spare row; the host-side len() only advances at sync_len()."""
+        rest to the spare row."""
+        self._write(s, a, r, s2, d, keep)
+        self._ub = min(self.cap, self._ub + s.shape[0])
+
+    def _write(self, s, a, r, s2, d, keep):
         n = s.shape[0]
-        k = keep.to(torch.int64)
-        c = torch.cumsum(k, 0)
-        idx = torch.where(keep, (self.pos_dev + c - 1) % self.cap, torch.full_like(c, self.cap))
+        if keep is None:
+            c = torch.arange(1, n + 1, device=s.device)
+            idx = (self.pos_dev + c - 1) % self.cap
+        else:
+            c = torch.cumsum(keep.to(torch.int64), 0)
+            idx = torch.where(keep, (self.pos_dev + c - 1) % self.cap, torch.full_like(c, self.cap))
         self.s.index_copy_(0, idx, s); self.a.index_copy_(0, idx, a); self.s2.index_copy_(0, idx, s2)
-        self.r.index_copy_(0, idx, r.reshape(n, 1)); self.d.index_copy_(0, idx, d.reshape(n, 1).float())
+        self.r.index_copy_(0, idx, r.reshape(n, 1).float()); self.d.index_copy_(0, idx, d.reshape(n, 1).float())
         tot = c[-1]
         self.pos_dev.copy_((self.pos_dev + tot) % self.cap)
         self.size_dev.copy_(torch.clamp(self.size_dev + tot, max=self.cap))
 
     def sync_len(self):
-        """Bring the host-side position / fill level up to date with the device's (one host read)."""
-        self.pos, self.size = int(self.pos_dev.item()), int(self.size_dev.item())
-        return self.size
+        """The exact fill level (one host read); collapses the host-side bounds onto it."""
+        self._lb = self._ub = int(self.size_dev.item())
+        return self._lb
+
+    def ready(self, n):
+        """len() > n, without a host read whenever the bounds already decide it."""
+        if self._lb > n:
+            return True
+        if self._ub <= n:
+            return False
+        return self.sync_len() > n
+
+    @property
+    def size(self):
+        return len(self)
+
+    @property
+    def pos(self):
+        return int(self.pos_dev.item())
 
     def sample(self, batch):
         """Uniform sample of the filled part; the indices are drawn on the device from the device-side fill level."""
@@ -96,7 +127,7 @@ class DeviceReplay:
         return self.s[idx], self.a[idx], self.r[idx], self.s2[idx], self.d[idx]
 
     def __len__(self):
-        return self.size
+        return self._lb if self._lb == self._ub else self.sync_len()
 
 
 class Agent:
@@ -390,13 +421,25 @@ class Agent:
         if batch is not None:
             s, a, r, s2, d = [t.contiguous().float() for t in batch]
             tn = target_noise.contiguous().float() if target_noise is not None else None
+            # the kernels read exactly cn_td3_config.batch rows of every array (fixed at enable_fused_update)
+            B, D = self.batch_size, self.actor.linear1.in_features
+            if s.shape != (B, D) or s2.shape != (B, D) or a.shape != (B, 2) or r.numel() != B or d.numel() != B or (
+                    tn is not None and tn.shape != (B, 2)):
+                raise ValueError("cn_td3_update was created for batches of %d x %d; got s %s a %s r %s s2 %s d %s noise %s" % (
+                    B, D, tuple(s.shape), tuple(a.shape), tuple(r.shape), tuple(s2.shape), tuple(d.shape),
+                    None if tn is None else tuple(tn.shape)))
             self._td3_keep = (s, a, r, s2, d, tn)            # alive until the next call: the launches are asynchronous
             bp = C.byref(_abi.CnTd3Batch(s.data_ptr(), a.data_ptr(), r.data_ptr(), s2.data_ptr(), d.data_ptr(),
                                          tn.data_ptr() if tn is not None else None))
         rc = L.cn_td3_update(self._td3_h, int(step % self.policy_delay == 0), bp, st)
         if rc != 0:
             raise _abi.CrowdNavError("cn_td3_update: %s" % L.cn_td3_last_error().decode())
-        return None
+        # the first critic's loss of this update, where the kernels left it: a 0-d view of the handle's device scalar, the same
+        # contract as the PyTorch learner (no host synchronisation; overwritten by the next update)
+        if self._td3_loss is None:
+            ptr = L.cn_td3_loss_dev(self._td3_h)
+            self._td3_loss = _device_scalar_view(ptr, self.device) if ptr else False
+        return self._td3_loss if self._td3_loss is not False else None
 
     def __del__(self):
         try:
@@ -415,11 +458,11 @@ class Agent:
         override the replay sample / the generator -- used by the parity test against the reference's update.
         Returns the first critic's loss as a 0-d tensor (no host synchronisation)."""
         if getattr(self, "_td3_h", None):
-            if batch is None and len(self.memory) <= self.batch_size:
+            if batch is None and not self.memory.ready(self.batch_size):
                 return None
             return self._fused_learn(step, batch, target_noise)
         if batch is None:
-            if len(self.memory) <= self.batch_size:
+            if not self.memory.ready(self.batch_size):
                 return None
             if getattr(self, "_graphs", None) and target_noise is None:
                 do_actor = step % self.policy_delay == 0

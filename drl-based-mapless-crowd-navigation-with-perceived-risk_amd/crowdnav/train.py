@@ -134,8 +134,8 @@ def train(a):
             agent.memory.add_masked(prev, act, reward, obs, done, keep)    # TRAIN:129-131; s' of a finished env = its terminal obs
             resetting = done.bool()
         elog.add(done, env.counters(), env.returns()[0], it, keep)
-        if not learning and it * N > a.batch:                          # TRAIN:132: only once the replay holds more than a batch
-            learning = agent.memory.sync_len() > a.batch               # (host reads until then; none afterwards)
+        if not learning:                                               # TRAIN:132: only once the replay holds more than a batch
+            learning = agent.memory.ready(a.batch)                     # (a host read only while the bounds straddle it; none afterwards)
         if learning:
             for u in range(a.updates):
                 updates_done += 1
@@ -155,9 +155,13 @@ def train(a):
                 line = "launch %6d  env-steps %10d  updates %9d  episodes %8d  success %.3f  mean return %8.1f  mean steps %6.1f  %.0f s" % (
                     it, env_steps, updates_done, episodes, tot[1] / ne, tot[2] / ne, tot[3] / ne, time.time() - t0)
                 print(line, flush=True); log.write(line + "\n"); log.flush()
+            if a.csv:
+                stats.append_csv(a.out, "td3_training")                  # incremental: a killed run keeps its rows up to here
             if episodes >= next_ckpt:                                    # TRAIN:150-154 (every 100 episodes there)
-                agent.save(a.out, next_ckpt)
-                open(os.path.join(a.out, "noise_state_ep%d.txt" % next_ckpt), "w").write("%d %d\n" % agent.noise_state())
+                # labelled with the episode count the weights really have behind them (checked at log time, so it can be past
+                # the threshold that triggered it)
+                agent.save(a.out, episodes)
+                open(os.path.join(a.out, "noise_state_ep%d.txt" % episodes), "w").write("%d %d\n" % agent.noise_state())
                 while next_ckpt <= episodes:
                     next_ckpt += a.checkpoint_every
             if last_launch:
@@ -174,7 +178,7 @@ def train(a):
             updates_done, updates_done / max(1e-9, time.time() - t0), env_steps / max(1e-9, time.time() - t0))
         print(line, flush=True); log.write(line + "\n"); log.flush()
     if a.csv:
-        stats.write_csv(a.out, "td3_training")
+        stats.append_csv(a.out, "td3_training")
     return agent, episodes
 
 
@@ -218,7 +222,9 @@ def main(argv=None):
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--out", default="runs/td3")
-    ap.add_argument("--csv", action="store_true", help="one CSV row per finished episode (recorded on the device, written at the end)")
+    ap.add_argument("--csv", action="store_true", help="one CSV row per finished episode in the reference's 8-column schema (recorded on the device, appended to the file at "
+                    "every log interval); `timelapse` = the episode's own virtual duration, steps x (0.15 s + scan wait) -- TRAIN:141 "
+                    "measures wall time since the episode's start, which the reference's time.sleep(0.15) makes the same quantity")
     ap.add_argument("--max-csv-rows", type=int, default=2_000_000)
     ap.add_argument("--load", default=None)
     ap.add_argument("--load-episode", type=int, default=0)

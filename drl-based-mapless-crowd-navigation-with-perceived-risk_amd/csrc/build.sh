@@ -18,15 +18,18 @@ WHAT="${1:-product}"
 build_lib() {   # $1 = output name, $2.. = extra flags
   local name="$1"; shift
   local T; T="$(mktemp -d)"
-  "$HIPCC" $FLAGS ${CN_EXTRA_FLAGS:-} "$@" -DCN_TU=1 -c -o "$T/k1.o" "$HERE/crowdnav_kernel.hip" &
-  "$HIPCC" $FLAGS ${CN_EXTRA_FLAGS:-} "$@" -DCN_TU=2 -mllvm -disable-machine-licm -c -o "$T/k2.o" "$HERE/crowdnav_kernel.hip" &
-  "$HIPCC" $FLAGS ${CN_EXTRA_FLAGS:-} "$@" -c -o "$T/abi.o" "$HERE/crowdnav_abi.hip" &
-  "$HIPCC" $FLAGS ${CN_EXTRA_FLAGS:-} "$@" -c -o "$T/td3.o" "$HERE/crowdnav_td3.hip" &
-  wait
+  trap 'rm -rf "$T"' RETURN
+  local pids=()
+  "$HIPCC" $FLAGS ${CN_EXTRA_FLAGS:-} "$@" -DCN_TU=1 -c -o "$T/k1.o" "$HERE/crowdnav_kernel.hip" & pids+=($!)
+  "$HIPCC" $FLAGS ${CN_EXTRA_FLAGS:-} "$@" -DCN_TU=2 -mllvm -disable-machine-licm -c -o "$T/k2.o" "$HERE/crowdnav_kernel.hip" & pids+=($!)
+  "$HIPCC" $FLAGS ${CN_EXTRA_FLAGS:-} "$@" -c -o "$T/abi.o" "$HERE/crowdnav_abi.hip" & pids+=($!)
+  "$HIPCC" $FLAGS ${CN_EXTRA_FLAGS:-} "$@" -c -o "$T/td3.o" "$HERE/crowdnav_td3.hip" & pids+=($!)
+  local failed=0 pid
+  for pid in "${pids[@]}"; do wait "$pid" || failed=1; done     # a bare `wait` returns 0 whatever the jobs returned
+  if [ "$failed" != 0 ]; then echo "build.sh: a compile of $name failed" >&2; return 1; fi
   # link next to the target and rename: a process that already mapped the old file keeps it, nobody maps a partial one
   "$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT/.$name.$$" "$T/k1.o" "$T/k2.o" "$T/abi.o" "$T/td3.o"
   mv -f "$OUT/.$name.$$" "$OUT/$name"
-  rm -rf "$T"
 }
 if [ "$WHAT" = "product" ] || [ "$WHAT" = "all" ]; then
   build_lib libcrowdnav.so

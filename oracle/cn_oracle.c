@@ -103,9 +103,11 @@ static int g_threads = 1;
 /* cn_config.py2_round of the handle whose call is running (set on entry of every public function that takes a handle;
  * read-only inside the OpenMP region).  0: Python-3 round(), 1: Python-2.7 round() (floatobject.c _Py_double_round: correctly
  * rounded, an EXACT tie -- 2-valuation of x equal to -(nd + 1) -- goes away from zero). */
-/* (A process-global on purpose: the oracle is test infrastructure, driven from one thread; handles with different py2_round
- * values may coexist because every public call sets it on entry, but they must not be stepped concurrently.) */
-static int g_py2 = 0;
+/* Thread-local, and set from the HANDLE's configuration by whichever thread is about to run that handle's arithmetic: on entry of
+ * every public function that takes a handle and again at the top of every OpenMP iteration (worker threads have their own copy).
+ * Handles with different py2_round values can therefore coexist AND be stepped concurrently from different threads; the
+ * handle-less helpers (cno_py_round ...) use the calling thread's last cno_set_py2_round / handle call. */
+static __thread int g_py2 = 0;
 void cno_set_py2_round(int on) { g_py2 = on ? 1 : 0; }
 
 /* Python round(x, nd): correctly rounded to nd decimals -- ties-to-even on the exact value (Python 3) or away from zero
@@ -1818,6 +1820,7 @@ int cno_reset(cno_sim* s, const uint8_t* mask, double* obs)
 #pragma omp parallel for num_threads(g_threads) schedule(static)
     for (int e = 0; e < N; ++e) {
         if (mask && !mask[e]) continue;
+        g_py2 = s->cfg.py2_round;
         env_reset_flow(s, &s->envs[e], s->cfg.env_index_base + e, obs + (size_t)e * s->D);
     }
     return 0;
@@ -1833,6 +1836,7 @@ int cno_step(cno_sim* s, const double* action, const int32_t* step_counter, int 
         env_t* en = &s->envs[e];
         int64_t gid = s->cfg.env_index_base + e;
         int32_t idx_local[16];
+        g_py2 = s->cfg.py2_round;
         int32_t* idx = topk_idx ? topk_idx + (size_t)e * K : idx_local;
         double* o = obs + (size_t)e * s->D;
         double r; int d;

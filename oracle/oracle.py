@@ -10,7 +10,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "_build", "libcn_oracle.so")
+# CN_ORACLE_LIB: load another build of the same source instead (oracle/Makefile `make ubsan`; never set by the product or the bench)
+_LIB_PATH = os.environ.get("CN_ORACLE_LIB") or os.path.join(_HERE, "_build", "libcn_oracle.so")
 MAX_TRACKS = 64
 
 
@@ -78,6 +79,8 @@ def make_config(**kw):
 
 
 def build(force=False):
+    if os.environ.get("CN_ORACLE_LIB"):
+        return _LIB_PATH
     if force or not os.path.exists(_LIB_PATH) or (
             os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(os.path.join(_HERE, f))
                                               for f in ("cn_oracle.c", "cn_oracle.h", "Makefile"))):

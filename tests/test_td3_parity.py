@@ -118,6 +118,39 @@ def test_device_replay_ring():
     assert bool((m2.sample(64)[0][:, 0] >= 10.0).all())
 
 
+def test_device_replay_mixes_masked_and_plain_adds_and_gates_learning_without_a_sync_len():
+    """ONE source of truth for the ring's position and fill level (the device scalars).  add() after add_masked()
+    continues where the masked add stopped (it used to index from a stale host position and rewind the device counters), and
+    the learn() gate -- DeviceReplay.ready(batch) -- turns true after masked adds alone (collect_policy -> learn with no
+    sync_len in between used to return None forever)."""
+    from crowdnav.td3 import DeviceReplay, Agent
+    m = DeviceReplay(16, 2, "cpu")
+    row = lambda v, n: (torch.full((n, 2), float(v)), torch.zeros(n, 2), torch.full((n,), float(v)), torch.full((n, 2), float(v) + .5), torch.zeros(n))
+    m.add_masked(*row(1, 4), torch.tensor([True, False, True, False]))        # rows 0, 1
+    m.add(*row(2, 3))                                                         # rows 2, 3, 4 -- not 0, 1, 2
+    m.add_masked(*row(3, 2), torch.tensor([False, True]))                     # row 5
+    m.add(*row(4, 1))                                                         # row 6
+    assert m.s[:7, 0].tolist() == [1, 1, 2, 2, 2, 3, 4] and int(m.pos_dev) == 7 and int(m.size_dev) == 7
+    assert len(m) == 7 and m.pos == 7 and m.size == 7
+    # the bounds: exact after add(), an upper bound after add_masked(); ready() only reads the device while they straddle n
+    m = DeviceReplay(64, 2, "cpu")
+    assert not m.ready(4) and (m._lb, m._ub) == (0, 0)
+    m.add_masked(*row(1, 4), torch.tensor([True, True, False, False]))
+    assert (m._lb, m._ub) == (0, 4) and not m.ready(4) and (m._lb, m._ub) == (0, 4)     # ub <= n: decided without a read
+    m.add_masked(*row(1, 4), torch.tensor([True, True, True, False]))
+    assert (m._lb, m._ub) == (0, 8) and m.ready(4) and (m._lb, m._ub) == (5, 5)         # straddles: one read, exact after it
+    m.add(*row(1, 2)); m.add_masked(*row(1, 2), torch.tensor([False, False]))
+    assert (m._lb, m._ub) == (7, 9) and m.ready(4) and (m._lb, m._ub) == (7, 9)         # lb > n: no read
+    assert len(m) == 7
+    # an Agent fed by masked adds only learns as soon as the ring holds more than a batch -- no sync_len() by the caller
+    ag = Agent(obs_dim=6, hidden=8, batch_size=4, memory_size=32, device="cpu", seed=0)
+    assert ag.learn(1) is None
+    for _ in range(2):
+        ag.memory.add_masked(torch.randn(4, 6), torch.rand(4, 2), torch.randn(4), torch.randn(4, 6), torch.zeros(4), torch.tensor([True, True, True, False]))
+    loss = ag.learn(1)
+    assert loss is not None and torch.isfinite(loss)
+
+
 def test_episode_csv_schema(tmp_path):
     """utils.record_data (UTL:53-64) + TRAIN:157-162: header row, then one row per finished episode
     [episode_number, success, failure, return, steps, ego_safety_score, social_safety_score, timelapse]."""
