@@ -10,9 +10,12 @@
 
 A "step" is every env of this rank's shard stepped once through cn_step (4096 envs x 20 pedestrians x 360 rays, K = 8,
 BASELINE.json configs[1]).  The shard runs as `--groups` independent stream groups (default 4 x 1024 envs), as 2, or as one
-launch per step.  Protocol (round 3; no choice is made on the reported sample):
+launch per step.  Protocol (no choice is made on the reported sample):
   1. after the W warm-up + pre-roll steps every decomposition runs ONE untimed-for-the-report probe of K steps; the best
-     probe decides which decomposition is the headline (`config.headline_choice`);
+     probe AMONG THE DECOMPOSITIONS THAT CAN SERVE A POLICY IN THE LOOP -- one cn_step launch per step, alone or as stream
+     groups: SURVEY 8(d) D1's "one env-step = one cn_step for one env" -- decides which one is the headline
+     (`config.headline_choice`).  The open-loop single-launch forms (cn_step_sequence in place / into trajectory buffers) are
+     timed as comparables (`config.leg_sequence*`), never as `value` (round 5, VERDICT r04 item 1);
   2. every decomposition is then timed `--repeats` (5) times: each sample = exactly K steps bracketed by barrier +
      torch.cuda.synchronize() on both sides (max over ranks); `value` / `ms_per_step` are the MEDIAN sample of the headline
      decomposition, `config.legs_env_steps_s` the medians of all of them, `config.samples_env_steps_s` every sample.
@@ -27,7 +30,12 @@ Adds to the JSON line:
   cpu_baseline   the CPU oracle (plain-C port of the reference path, oracle/cn_oracle.c) timed on this box's host cores on a
                  bounded sample of the same workload (rank 0, N = 1 only), the reference's own Python rate beside it
   config.other_configs   BASELINE configs[2] (TD3 actor in the loop) and configs[4] (100 pedestrians x 720 rays) under
-                 the same bracket, each with its own ms_per_step and D4-priced roofline fraction (N = 1 only)
+                 the same bracket, each with its own ms_per_step and D4-priced roofline fraction (N = 1 only); their
+                 headline numbers are repeated as flat scalars (config.configs2_* / configs4_* / leg_*) for record keepers
+                 that drop nested objects
+  config.sustained_*     the headline decomposition stepped back to back for >= --sustained-seconds (6 s): env-steps/s, the
+                 shader clock the chip held (s_memtime cycles / 100 MHz s_memrealtime ticks around the run, cn_device_clock) and
+                 the burst / sustained ratio.  Runs right after the headline legs, long before the CPU baseline.
 """
 import argparse
 import json
@@ -42,6 +50,10 @@ sys.path.insert(0, os.path.join(ROOT, "drl-based-mapless-crowd-navigation-with-p
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+VECTOR_PEAK_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md "Peak FP32 (vector)" (packed v_pk_fma_f32: 2 x 64 lanes x 2 flop per 4-cycle issue)
+# float64 vector peak: the guide has no row for it.  AMD's MI355X data sheet: 78.6 TFLOP/s (half the packed-f32 rate) -- and it is what
+# tools/micro/issue_cost.hip measures: one v_fma_f64 per 4 cycles per SIMD = 1024 SIMDs x 64 lanes x 2 flop / 4 cycles x 2.4 GHz.
+VECTOR_PEAK_F64_TFLOPS = 78.6
 N_ACT = 64             # distinct open-loop action tensors cycled through
 
 
@@ -136,6 +148,8 @@ def main():
     ap.add_argument("--k", type=int, default=8)
     ap.add_argument("--groups", type=int, default=4,
                     help="largest decomposition tried: the rank's envs as this many independent stream groups")
+    ap.add_argument("--sustained-seconds", type=float, default=6.0,
+                    help="length of the sustained leg (headline decomposition back to back); 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     a = ap.parse_args()
@@ -216,8 +230,9 @@ def main():
         actor in the loop (each group's act -> step chain on its own stream, crowdnav.rollout.rollout_groups)."""
 
         def __init__(self, lcfg, G, mode="next", lacts=None, agent=None, sequence=False, arbitration=None, python_loop=False,
-                     policy_sequence=False):
+                     policy_sequence=False, traj=False):
             self.cfg, self.G, self.mode, self.agent, self.sequence = lcfg, G, mode, agent, sequence
+            self.lacts = lacts
             self.timed_call = None
             self.python_loop = python_loop             # the timed K steps enqueued one foreign call per step from Python (as a trainer would)
             # arbitration None: the library's defaults (cn_set_arbitration) -- one launch per step picks the fair kernel when it
@@ -235,7 +250,23 @@ def main():
                 # cn_step_sequence: the K timed steps as ONE launch of persistent wavefronts (open-loop actions [K, N, 2] in HBM)
                 self.calls = [self.grp.bind_step_all(lacts[i], auto_reset=mode) for i in range(N_ACT)]
                 self.seq_actions = lacts[torch.arange(K, device=dev) % N_ACT].contiguous()
-                self.timed_call = self.grp.envs[0].bind_step_sequence(self.seq_actions)
+                if not traj:
+                    self.timed_call = self.grp.envs[0].bind_step_sequence(self.seq_actions)
+                else:
+                    # the same launch(es) with TRAJECTORY buffers: step t's observation / reward / done land in their own HBM slot
+                    # (what an offline consumer of an open-loop phase reads); launches of at most 50 steps so that the buffers stay
+                    # small whatever K is (50 x 4096 x 398 x 4 B = 326 MB)
+                    Tc = min(K, 50)
+                    D_ = e0.D
+                    self.traj = dict(obs=torch.zeros((Tc, lcfg.n_envs, D_), dtype=torch.float32, device=dev),
+                                     reward=torch.zeros((Tc, lcfg.n_envs), dtype=torch.float32, device=dev),
+                                     done=torch.zeros((Tc, lcfg.n_envs), dtype=torch.uint8, device=dev))
+                    parts = []
+                    for k0 in range(0, K, Tc):
+                        n_ = min(Tc, K - k0)
+                        parts.append(e0.bind_step_sequence(self.seq_actions[k0:k0 + n_],
+                                                           traj={k_: v_[:n_] for k_, v_ in self.traj.items()}))
+                    self.timed_call = (lambda ps=tuple(parts): [c_() for c_ in ps]) if len(parts) > 1 else parts[0]
             elif agent is None:
                 self.calls = [self.grp.bind_step_all(lacts[i], auto_reset=mode) for i in range(N_ACT)]
                 # the K timed steps as ONE pre-marshalled cn_step_multi (K x G entries): the host side of a sample is a C loop
@@ -310,6 +341,53 @@ def main():
                 taken -= int(sum(x.item() for x in m1) - sum(x.item() for x in m0))
             return wall, k_ms, taken
 
+        def sustained(self, seconds):
+            """The decomposition stepped back to back for ~`seconds`: pre-marshalled calls of S steps each, the host at most two
+            calls ahead of the device.  -> dict(env_steps_s, seconds, env_steps, clock_mhz, clock_mhz_idle)."""
+            grp, e0 = self.grp, self.grp.envs[0]
+            S = 500
+            per_call = self.cfg.n_envs * S
+            if self.sequence:
+                acts_ = self.lacts[torch.arange(S, device=dev) % N_ACT].contiguous()
+                call = e0.bind_step_sequence(acts_)
+            else:
+                call = grp.bind_step_sequence([self.lacts[i % N_ACT] for i in range(S)], auto_reset=self.mode)
+            # the shader clock of an idle chip, for comparison: the two counters around a host-side pause
+            for s_ in grp.streams:
+                s_.synchronize()
+            ci0 = e0.device_clock(); torch.cuda.synchronize(dev); time.sleep(0.25); ci1 = e0.device_clock(); torch.cuda.synchronize(dev)
+            call(); self.run(warm_tail)
+            m0 = self._reset_launch_marker()
+            for s_ in grp.streams:
+                s_.synchronize()
+            torch.cuda.synchronize(dev)
+            c0 = e0.device_clock()
+            t0 = time.perf_counter()
+            evs = []
+            n_calls = 0
+            while True:                                    # the host stays at most two calls (~40 ms) ahead of the device, so its clock
+                call()                                     # follows the device's: stop once `seconds` have passed
+                ev = torch.cuda.Event(); ev.record(grp.streams[0]); evs.append(ev)
+                n_calls += 1
+                if n_calls >= 3:
+                    evs[n_calls - 3].synchronize()
+                    if time.perf_counter() - t0 >= seconds:
+                        break
+            c1 = e0.device_clock()
+            bracket(grp.streams)
+            wall = time.perf_counter() - t0
+            taken = n_calls * per_call
+            if self.mode == "next":
+                m1 = self._reset_launch_marker()
+                torch.cuda.synchronize(dev)
+                taken -= int(sum(x.item() for x in m1) - sum(x.item() for x in m0))
+            c0, c1, ci0, ci1 = [x.cpu().tolist() for x in (c0, c1, ci0, ci1)]
+
+            def mhz(a_, b_):      # shader-clock cycles per microsecond of the 100 MHz counter
+                return (b_[0] - a_[0]) / max(1.0, (b_[1] - a_[1]) / 100.0)
+            return {"env_steps_s": taken / wall, "seconds": wall, "env_steps": taken, "launches": n_calls * S * self.G,
+                    "device_seconds": (c1[1] - c0[1]) / 1e8, "clock_mhz": mhz(c0, c1), "clock_mhz_idle": mhz(ci0, ci1)}
+
         def close(self):
             self.grp.close()
 
@@ -326,17 +404,22 @@ def main():
         return out, [x.cpu().tolist() for x in allr]
 
     def measure(lcfg, candidates, lacts=None, agent=None, mode="next", repeats=R, probe=True, sequence_leg=False):
-        """Every candidate decomposition of one config: pre-roll + warm-up, one probe of K steps each (decides the headline),
-        then `repeats` timed samples each.  Returns a dict with the chosen decomposition's median sample and all legs."""
+        """Every candidate decomposition of one config: pre-roll + warm-up, one probe of K steps each (the best probe among the
+        ELIGIBLE ones decides the headline), then `repeats` timed samples each.  Eligible = can serve a policy in the loop: stream
+        groups / one launch per step (integers) and cn_rollout_policy; the open-loop cn_step_sequence forms and the A/B legs are
+        comparables only.  Returns a dict with the chosen decomposition's median sample and all legs."""
         legs = {}
         if sequence_leg:
             # + the A/B of cn_set_arbitration on one launch per step (only where the library's default is the fair kernel)
             # + one launch per step enqueued from a Python loop, one foreign call per step (what a Python trainer pays; the other
             #   legs pre-marshal their K steps into ONE cn_step_multi / cn_step_sequence call)
+            # + cn_step_sequence: in place, and into trajectory buffers (every step's outputs in their own HBM slot)
             candidates = (list(candidates) + (["1_groups_oldest_first"] if 1 in candidates and lcfg.n_envs >= 2048 else [])
-                          + (["1_groups_python_enqueue"] if 1 in candidates else []) + ["sequence"])
+                          + (["1_groups_python_enqueue"] if 1 in candidates else []) + ["sequence", "sequence_traj"])
+        eligible = [G for G in candidates if isinstance(G, int) or G == "policy_sequence"]
         for G in candidates:
             lg = (Leg(lcfg, 1, lacts=lacts, sequence=True) if G == "sequence" else
+                  Leg(lcfg, 1, lacts=lacts, sequence=True, traj=True) if G == "sequence_traj" else
                   Leg(lcfg, 1, mode=mode, lacts=lacts, agent=agent, arbitration="oldest_first") if G == "1_groups_oldest_first" else
                   Leg(lcfg, 1, mode=mode, lacts=lacts, agent=agent, python_loop=True) if G == "1_groups_python_enqueue" else
                   Leg(lcfg, 1, agent=agent, policy_sequence=True) if G == "policy_sequence" else
@@ -349,10 +432,11 @@ def main():
             raw = [legs[G].sample() for G in candidates]
             red, _ = reduce_samples(raw)
             probes = {G: red[i][2] / red[i][0] for i, G in enumerate(candidates)}
-            chosen = max(candidates, key=lambda G: probes[G])
+            chosen = max(eligible, key=lambda G: probes[G])
         else:
-            chosen = candidates[0]
-        out = {"chosen": chosen, "probe_env_steps_s": {str(G): v for G, v in probes.items()}, "legs": {}}
+            chosen = eligible[0]
+        out = {"chosen": chosen, "eligible": [str(G) for G in eligible],
+               "probe_env_steps_s": {str(G): v for G, v in probes.items()}, "legs": {}}
         for G in candidates:
             raw = [legs[G].sample() for _ in range(repeats)]
             red, per_rank = reduce_samples(raw)
@@ -370,11 +454,25 @@ def main():
     def leg_name(g):
         return g if isinstance(g, str) else "%d_groups" % g
 
-    Gc = main_m["chosen"]                              # an int (stream groups) or "sequence" (one cn_step_sequence launch of K steps)
+    Gc = main_m["chosen"]                              # an int: the envs as that many stream groups (1 = one launch per step)
     G = 1 if isinstance(Gc, str) else Gc
     hl = main_m["legs"][Gc]
     value, wall, kernel_ms, taken_all = hl["median"], hl["wall"], hl["kernel_ms"], hl["taken"]
     one = main_m["legs"].get(1)
+
+    # Sustained: the headline decomposition back to back for >= 6 s, right after its burst samples (the CPU baseline, which takes
+    # most of this script's wall time, comes last).  A 20-step sample lasts 0.7 ms; this one shows what the chip holds.
+    sustained = None
+    if a.sustained_seconds > 0 and (a.peds, a.rays) == (20, 360):
+        lg = Leg(cfg, G, lacts=acts)
+        lg.run(a.preroll)
+        sustained = lg.sustained(a.sustained_seconds)
+        lg.close()
+        if use_dist:
+            t_ = torch.tensor([sustained["env_steps_s"], sustained["seconds"], sustained["clock_mhz"]], dtype=torch.float64, device=cdev)
+            sm_ = t_.clone(); dist.all_reduce(sm_, op=dist.ReduceOp.SUM)
+            mx_ = t_.clone(); dist.all_reduce(mx_, op=dist.ReduceOp.MAX)
+            sustained.update({"env_steps_s": float(sm_[0]), "seconds": float(mx_[1]), "clock_mhz": float(sm_[2]) / world})
 
     # Issue-bound ceiling of this kernel on this GPU, measured in the same run: 16384 resident envs in stream groups
     # (every SIMD has work in every phase).  Single-GPU run only.
@@ -477,12 +575,12 @@ def main():
         if str(oc.get("kernel", "")).startswith("cn_policy_kernel") or "actor" in oc.get("workload", ""):
             # the actor's share priced on the f32 matrix cores (MI355X_MICROARCH.md: 157.3 TF, v_mfma_f32_16x16x4_f32)
             mfma_flops = 2.0 * (((cfg.obs_dim + 31) // 32 * 32) * 256 + 256 * 256)
-            oc["roofline"].update({"actor_mfma_flops_per_env_step": mfma_flops, "frac_mfma_f32": oc["value"] * mfma_flops / 157.3e12})
-    steps_per_launch = K if Gc == "sequence" else 1
+            oc["roofline"].update({"actor_mfma_flops_per_env_step": mfma_flops,
+                                       "frac_mfma_f32": oc["value"] * mfma_flops / (VECTOR_PEAK_F32_TFLOPS * 1e12)})
+    steps_per_launch = 1
     # HBM bytes the counters saw per launch of the headline kernel, scaled to this run's launch (envs per launch x steps per launch)
     traffic_b = float(traffic["bytes_per_env_step"]) * n_launch * steps_per_launch if traffic else None
     flops_d5 = 79e3 if (a.peds, a.rays) == (20, 360) else 623e3 if (a.peds, a.rays) == (100, 720) else None
-    VALU_PEAK_F64 = 157.3e12                                                     # MI355X_MICROARCH.md: vector peak the survey's D3 prices against
     out = {
         "metric": baseline_metric(),
         "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -491,19 +589,22 @@ def main():
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "%s: %d envs/GPU x %d pedestrians x %d rays, K=%d, lidar-tracker risk features, "
                                "next-step auto-reset (reset launches not counted as env-steps), open-loop "
-                               "U(0,0.22)xU(-2,2) actions, %d untimed pre-roll steps; one step = every env stepped once, "
-                               "%s; median of %d samples of %d steps; the closed-loop comparables are "
-                               "config.one_launch_per_step_value and config.legs_env_steps_s" % (
+                               "U(0,0.22)xU(-2,2) actions, %d untimed pre-roll steps; one step = every env stepped once by ONE cn_step "
+                               "launch (SURVEY 8d D1: the decomposition that can serve a policy in the loop), "
+                               "%s; median of %d samples of %d steps; config.sustained_env_steps_s = the same decomposition for >= 6 s; the "
+                               "open-loop single-launch forms are comparables only: config.leg_sequence_env_steps_s (in place), "
+                               "config.leg_sequence_traj_env_steps_s (into trajectory buffers)" % (
                                    ("BASELINE configs[3] shape, %d envs total over %d GPU(s) (strong scaling)" % (a.envs_total, world))
                                    if a.envs_total else ("BASELINE configs[1] per GPU (weak scaling over %d GPU(s))" % world),
                                    N, a.peds, a.rays, a.k, a.preroll,
-                                   ("the K steps enqueued as ONE cn_step_sequence launch (persistent wavefronts, actions [K, N, 2] in HBM: an "
-                                    "OPEN-LOOP-ONLY decomposition -- it cannot serve a policy in the loop)"
-                                    if Gc == "sequence" else "the envs running as %d independent stream group(s) of %d" % (G, n_launch)), R, K),
+                                   "the envs running as %d independent stream group(s) of %d" % (G, n_launch), R, K),
                    "envs_per_gpu": N, "envs_total": N * world, "stream_groups": G, "stream_groups_requested": Gmax,
                    "decomposition": leg_name(Gc),
                    "repeats": R, "samples_env_steps_s": hl["samples"],
-                   "headline_choice": {"rule": "best untimed probe of K steps among the decompositions, taken before the timed samples",
+                   "headline_choice": {"rule": "best untimed probe of K steps among the decompositions that can serve a policy in the loop "
+                                               "(one cn_step launch per step, alone or as stream groups), taken before the timed samples; "
+                                               "cn_step_sequence legs are never eligible",
+                                       "eligible": main_m["eligible"],
                                        "probe_env_steps_s": main_m["probe_env_steps_s"], "chosen": leg_name(Gc)},
                    "legs_env_steps_s": {leg_name(g): v["median"] for g, v in main_m["legs"].items()},
                    "legs_samples_env_steps_s": {leg_name(g): v["samples"] for g, v in main_m["legs"].items()},
@@ -519,7 +620,8 @@ def main():
                    "per_rank": ([{"rank": r_, "wall_ms": pr[0] * 1e3, "env_steps": pr[2], "value": pr[2] / pr[0]}
                                  for r_, pr in enumerate(hl["per_rank"])] if hl["per_rank"] else None),
                    "returns_allgather": gather,
-                   "other_configs": other},
+                   "other_configs": other,
+                   "sustained": sustained},
         "roofline": {"bound": "hbm", "achieved": achieved_d4, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      # priced with SURVEY 8(d) D4's per-env-step figure (float32 state), the contract's definition
                      "frac": achieved_d4 / HBM_PEAK_GBS, "bytes_per_env_step": D4,
@@ -535,10 +637,13 @@ def main():
                      "kernel": hk, "kernel_ms": kernel_ms, "steps_per_launch": steps_per_launch,
                      "wasted_traffic_ratio": (traffic_b / (D4 * n_launch * steps_per_launch)) if traffic_b else None,
                      "wasted_traffic_ratio_f64_layout": (traffic_b / (B * n_launch * steps_per_launch)) if traffic_b else None,
-                     # the same speed priced in flops: SURVEY 8(d) D5 x env-steps/s over the vector peak D3 names
+                     # the same speed priced in flops: SURVEY 8(d) D5 x env-steps/s over the FLOAT64 vector peak (the path computes in
+                     # f64; rounds 3-4 divided by the packed-f32 peak, twice too generous) -- the f32 figure stays beside it
                      "flops_per_env_step_d5": flops_d5,
-                     "frac_valu": (value / world * flops_d5 / VALU_PEAK_F64) if flops_d5 else None,
-                     "valu_peak_tflops": VALU_PEAK_F64 / 1e12,
+                     "frac_valu_f64": (value / world * flops_d5 / (VECTOR_PEAK_F64_TFLOPS * 1e12)) if flops_d5 else None,
+                     "vector_peak_f64_tflops": VECTOR_PEAK_F64_TFLOPS,
+                     "frac_valu_f32_peak": (value / world * flops_d5 / (VECTOR_PEAK_F32_TFLOPS * 1e12)) if flops_d5 else None,
+                     "vector_peak_f32_tflops": VECTOR_PEAK_F32_TFLOPS,
                      "legs_kernels": {leg_name(g): v["kernel"] for g, v in main_m["legs"].items()},
                      # what actually binds: instruction issue (float64 VALU) and one wavefront's critical path, not HBM
                      "binding": "instruction issue (f64 VALU) above ~8k resident envs; one wavefront's critical path at 4096",
@@ -557,6 +662,29 @@ def main():
                                               "achieved": D4 * N / (one["kernel_ms"] * 1e-3) / 1e9,
                                               "frac": D4 * N / (one["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS} if one else None)},
     }
+    # Flat scalar copies (record keepers that drop nested objects keep these): every leg, the other configs, the sustained leg
+    fc = out["config"]
+    for g, v in main_m["legs"].items():
+        fc["leg_%s_env_steps_s" % leg_name(g)] = v["median"]
+        fc["leg_%s_kernel" % leg_name(g)] = v["kernel"]
+    fc["plateau_16384_envs_env_steps_s"] = plateau
+    for key, oc in (other or {}).items():
+        k_ = key.replace("[", "").replace("]", "")
+        fc["%s_env_steps_s" % k_] = oc["value"]
+        fc["%s_ms_per_step" % k_] = oc["ms_per_step"]
+        fc["%s_decomposition" % k_] = oc["decomposition"]
+        fc["%s_kernel" % k_] = oc["kernel"]
+        fc["%s_roofline_frac" % k_] = oc["roofline"]["frac"]
+        for g, v in oc["legs_env_steps_s"].items():
+            fc["%s_leg_%s_env_steps_s" % (k_, g)] = v
+    if sustained:
+        fc["sustained_env_steps_s"] = sustained["env_steps_s"]
+        fc["sustained_seconds"] = sustained["seconds"]
+        fc["sustained_clock_mhz"] = sustained["clock_mhz"]
+        fc["sustained_clock_mhz_idle"] = sustained.get("clock_mhz_idle")
+        fc["burst_over_sustained"] = value / sustained["env_steps_s"]
+        out["roofline"]["sustained_achieved"] = sustained["env_steps_s"] / world * D4 / 1e9
+        out["roofline"]["sustained_frac"] = sustained["env_steps_s"] / world * D4 / 1e9 / HBM_PEAK_GBS
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         from oracle import oracle
         ncpu = usable_cpus()

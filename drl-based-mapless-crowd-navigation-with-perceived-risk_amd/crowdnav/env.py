@@ -322,15 +322,26 @@ class VecEnv:
                 check(rc)
         return call
 
-    def bind_step_sequence(self, actions):
-        """Pre-marshalled step_sequence (in place) for a fixed [T, N, 2] action tensor: a zero-argument callable that only enqueues."""
+    def bind_step_sequence(self, actions, traj=None):
+        """Pre-marshalled step_sequence for a fixed [T, N, 2] action tensor: a zero-argument callable that only enqueues.  traj None:
+        outputs in place (every step overwrites self.obs / reward / done / topk_idx); traj = dict(obs [T, N, D], reward [T, N],
+        done [T, N] uint8): step t's outputs land in slot t of the caller's trajectory buffers (self.obs is NOT refreshed)."""
         a = actions
         assert a.device == self.device and a.dtype == torch.float32 and a.is_contiguous() and a.shape[1:] == (self.N, 2)
         io = _abi.CnSequenceIO()
-        io.action, io.action_stride, io.n_steps = a.data_ptr(), 2 * self.N, int(a.shape[0])
-        io.obs, io.reward, io.done, io.topk_idx = self.obs.data_ptr(), self.reward.data_ptr(), self.done.data_ptr(), self.topk_idx.data_ptr()
+        T = int(a.shape[0])
+        io.action, io.action_stride, io.n_steps = a.data_ptr(), 2 * self.N, T
+        if traj is None:
+            io.obs, io.reward, io.done, io.topk_idx = self.obs.data_ptr(), self.reward.data_ptr(), self.done.data_ptr(), self.topk_idx.data_ptr()
+        else:
+            o, r, d = traj["obs"], traj["reward"], traj["done"]
+            assert tuple(o.shape) == (T, self.N, self.D) and o.dtype == torch.float32 and o.is_contiguous()
+            assert tuple(r.shape) == (T, self.N) and r.dtype == torch.float32 and r.is_contiguous()
+            assert tuple(d.shape) == (T, self.N) and d.dtype == torch.uint8 and d.is_contiguous()
+            io.obs, io.reward, io.done = o.data_ptr(), r.data_ptr(), d.data_ptr()
+            io.obs_stride, io.reward_stride, io.done_stride = self.N * self.D, self.N, self.N
         ref, st, h, fn, check = C.byref(io), self._stream(), self.h, self.L.cn_step_sequence, _abi.check
-        keep = (io, a)
+        keep = (io, a, traj)
 
         def call(_keep=keep):
             rc = fn(h, ref, st)
@@ -357,6 +368,14 @@ class VecEnv:
         _abi.check(self.L.cn_observe_external(self.h, C.byref(io), self._stream()))
         self._keep = (rg, od, sc)
         return self.obs, self.reward, self.done
+
+    def device_clock(self, out=None):
+        """Enqueue cn_device_clock on this env's stream: (shader-clock counter, 100 MHz counter) into a 2-element int64 device
+        tensor (returned; read it after a synchronisation)."""
+        if out is None:
+            out = torch.zeros(2, dtype=torch.int64, device=self.device)
+        _abi.check(self.L.cn_device_clock(C.c_void_p(out.data_ptr()), self.device.index, self._stream()))
+        return out
 
     def counters(self):
         """[N,14] int32: ego_viol, social_viol, obstacle_present_steps, ep_steps, success, failure, status, n_tracks,

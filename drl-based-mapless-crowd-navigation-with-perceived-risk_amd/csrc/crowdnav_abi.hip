@@ -53,6 +53,36 @@ extern "C" __global__ void cn_policy_kernel_gt(CnKParams p);
 extern "C" __global__ void cn_env_kernel_s720(CnKParams p);
 extern "C" __global__ void cn_env_kernel_fair_s720(CnKParams p);
 extern "C" __global__ void cn_env_kernel_gt_seq(CnKParams p);
+extern "C" __global__ void cn_env_kernel_seq_sf(CnKParams p);
+extern "C" __global__ void cn_env_kernel_seq_sfd(CnKParams p);
+extern "C" __global__ void cn_env_kernel_seq_wa(CnKParams p);
+extern "C" __global__ void cn_env_kernel_gt_seq_sf(CnKParams p);
+extern "C" __global__ void cn_env_kernel_gt_seq_sfd(CnKParams p);
+extern "C" __global__ void cn_env_kernel_gt_seq_wa(CnKParams p);
+extern "C" __global__ void cn_policy_kernel_s720(CnKParams p);
+extern "C" __global__ void cn_policy_kernel_sf(CnKParams p);
+extern "C" __global__ void cn_policy_kernel_sfd(CnKParams p);
+extern "C" __global__ void cn_policy_kernel_wa(CnKParams p);
+extern "C" __global__ void cn_policy_kernel_gt_sf(CnKParams p);
+extern "C" __global__ void cn_policy_kernel_gt_sfd(CnKParams p);
+extern "C" __global__ void cn_policy_kernel_gt_wa(CnKParams p);
+// every kernel launched with cn_create's dynamic LDS size (hipFuncAttributeMaxDynamicSharedMemorySize above 64 KiB)
+static const void* const kDynamicLdsKernels[] = {
+    (const void*)cn_env_kernel, (const void*)cn_env_kernel_fair, (const void*)cn_env_kernel_ext, (const void*)cn_env_kernel_same,
+    (const void*)cn_env_kernel_gt, (const void*)cn_env_kernel_gt_same, (const void*)cn_env_kernel_ct, (const void*)cn_env_kernel_ct_same,
+    (const void*)cn_env_kernel_gt_ct, (const void*)cn_env_kernel_gt_ct_same, (const void*)cn_env_kernel_sf, (const void*)cn_env_kernel_sf_same,
+    (const void*)cn_env_kernel_gt_sf, (const void*)cn_env_kernel_gt_sf_same, (const void*)cn_env_kernel_rw, (const void*)cn_env_kernel_rw_same,
+    (const void*)cn_env_kernel_rw_ext, (const void*)cn_env_kernel_orig, (const void*)cn_env_kernel_orig_ext, (const void*)cn_env_kernel_orig_same,
+    (const void*)cn_env_kernel_sfd, (const void*)cn_env_kernel_sfd_same, (const void*)cn_env_kernel_gt_sfd, (const void*)cn_env_kernel_gt_sfd_same,
+    (const void*)cn_env_kernel_wa, (const void*)cn_env_kernel_wa_same, (const void*)cn_env_kernel_gt_wa, (const void*)cn_env_kernel_gt_wa_same,
+    (const void*)cn_env_kernel_seq, (const void*)cn_env_kernel_s360, (const void*)cn_env_kernel_fair_s360, (const void*)cn_env_kernel_seq_s360,
+    (const void*)cn_env_kernel_seq_s720, (const void*)cn_env_kernel_s720, (const void*)cn_env_kernel_fair_s720, (const void*)cn_env_kernel_gt_seq,
+    (const void*)cn_env_kernel_seq_sf, (const void*)cn_env_kernel_seq_sfd, (const void*)cn_env_kernel_seq_wa,
+    (const void*)cn_env_kernel_gt_seq_sf, (const void*)cn_env_kernel_gt_seq_sfd, (const void*)cn_env_kernel_gt_seq_wa};
+static const void* const kPolicyKernels[] = {
+    (const void*)cn_policy_kernel, (const void*)cn_policy_kernel_s360, (const void*)cn_policy_kernel_gt, (const void*)cn_policy_kernel_s720,
+    (const void*)cn_policy_kernel_sf, (const void*)cn_policy_kernel_sfd, (const void*)cn_policy_kernel_wa,
+    (const void*)cn_policy_kernel_gt_sf, (const void*)cn_policy_kernel_gt_sfd, (const void*)cn_policy_kernel_gt_wa};
 extern "C" __global__ void cn_bbox_kernel(CnKParams p, double* out);
 extern "C" __global__ void cn_gather_kernel(CnKParams p, float* last_ret, float* run_ret, int32_t* counters);
 
@@ -75,7 +105,10 @@ struct cn_env_s {
     std::vector<double> ped_init;
     int arbitration = CN_ARB_AUTO;    // cn_set_arbitration
     int n_cus = 0;                    // compute units of `device` (CN_ARB_AUTO: fair from 2 wavefronts per SIMD = 8 x n_cus envs)
-    size_t pol_wave_lds = 0, pol_lds = 0;   // cn_rollout_policy: bytes between the 16 environments' LDS working sets of a workgroup; the workgroup's total (0 = does not fit)
+    size_t lds_shape = 0;             // dynamic LDS of the _s720 kernels (compact layout); 0 = this handle has none
+    size_t pol_wave_lds = 0, pol_lds = 0;   // cn_rollout_policy: bytes between the environments' LDS working sets of a workgroup; the workgroup's total (0 = does not fit)
+    int pol_envs = 0;                 // ... environments per workgroup: 16, or 8 where 16 working sets do not fit one CU's LDS
+    size_t pol_act_off = 0;           // ... byte offset of the workgroup's actions (past the working sets and the actor tile)
     bool shape360 = false;            // the headline shape (360 rays, 20 pedestrians, K = 8 and cn_create's sizes for it): the _s360 kernels
     bool shape720 = false;            // BASELINE configs[4] (720 rays, 100 pedestrians, K = 8): the _s720 kernels
 };
@@ -125,14 +158,16 @@ static void build_assoc_table(CnKParams& k, int16_t* tab)
     k.assoc_k1 = K1; k.assoc_fast = 1;
 }
 
-static size_t lds_bytes_impl(int R, int P, int K, int max_conf, int trk_cap, bool near_separate, int layout = 0)
+static size_t lds_bytes_impl(int R, int P, int K, int max_conf, int trk_cap, bool near_separate, int layout = 0, bool compact = false)
 {
-    // must mirror the carve in cn_env_kernel
+    // must mirror the carve in cn_env_kernel (compact: the 720-ray shape kernels' layout -- int16 end points, 12-byte confirmed
+    // objects, the pedestrians' velocities overlaid on region A)
     size_t n = (size_t)(R - 1), mc = (size_t)max_conf;
-    size_t szA_pts = (10 * n + 7) & ~(size_t)7, szA_trk = 8 * (size_t)(CN_TF_COUNT * trk_cap);
+    size_t szA_pts = ((compact ? 6 : 10) * n + 7) & ~(size_t)7, szA_trk = 8 * (size_t)(CN_TF_COUNT * trk_cap);
     size_t szA = szA_pts > szA_trk ? szA_pts : szA_trk;
     size_t szB_g = (6 * n + 7) & ~(size_t)7;
-    size_t szB_c = 32 * mc + 8 * 64 + 8 * (size_t)(8 + 4 * K) + 4 * (size_t)CN_MAX_K;
+    size_t szC = compact ? ((12 * mc + 7) & ~(size_t)7) : 32 * mc;
+    size_t szB_c = szC + 8 * 64 + 8 * (size_t)(8 + 4 * K) + 4 * (size_t)CN_MAX_K;
     size_t szB = szB_g > szB_c ? szB_g : szB_c;
     if (szB < 8 * 64) szB = 8 * 64;
     if (!near_separate && szB < 32 * (size_t)(P + 1)) szB = 32 * (size_t)(P + 1);   // near-pedestrian list overlaid on region B
@@ -140,7 +175,8 @@ static size_t lds_bytes_impl(int R, int P, int K, int max_conf, int trk_cap, boo
     size_t b = szA + szB;
     b += 8 * (size_t)(CN_NMASK * Wn);             // bit words
     b += 8 * ((3 * Wn + 1) / 2);                  // wbase
-    b += 8 * (size_t)(2 * P + 2) * 2;             // ped, pedv
+    b += 8 * (size_t)(2 * P + 2) * (compact ? 1 : 2);   // ped, pedv (compact: pedv inside region A)
+    if (compact && 8 * (size_t)(2 * P + 2) > szA) return (size_t)1 << 30;
     if (near_separate) b += 32 * (size_t)(P + 1); // near-pedestrian list in its own region
     if (layout == CN_LAYOUT_REALWORLD) b = ((b + 15) & ~(size_t)15) + 12 * n + 16;   // filtered list, gradients, types (12 bytes per ray)
     return (b + 15) & ~(size_t)15;
@@ -242,6 +278,13 @@ static int upload_initial_state(cn_env_s* h)
     return CN_OK;
 }
 
+typedef void (*cn_kernel_fn)(CnKParams);
+struct KernelChoice { cn_kernel_fn fn; const char* name; bool compact = false; };      // compact: launched with h->lds_shape
+#define CN_KC(f) KernelChoice{f, #f}
+#define CN_KCC(f) KernelChoice{f, #f, true}
+static size_t lds_of(const cn_env_s* h, const KernelChoice& kc) { return kc.compact ? h->lds_shape : h->lds; }
+static KernelChoice choose_policy_kernel(const cn_env_s* h);
+
 extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
 {
     if (!cfg || !out) return fail(CN_ERR_ARG, "cn_create: null argument");
@@ -333,7 +376,9 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
     k.near_sep = cn_near_separate(R, P, K, h->max_conf, h->trk_cap);
     // the kernels compiled for the headline shape assume exactly these six values (crowdnav_kernel.hip, SHAPE == 360)
     h->shape360 = R == 360 && P == 20 && K == 8 && h->max_conf == 91 && h->trk_cap == 32 && k.near_sep == 1 && !getenv("CN_NO_SHAPE_KERNELS");
-    h->shape720 = R == 720 && P == 100 && K == 8 && h->max_conf == 181 && h->trk_cap == 64 && k.near_sep == 0 && !getenv("CN_NO_SHAPE_KERNELS");
+    h->shape720 = R == 720 && P == 100 && K == 8 && h->max_conf == 181 && h->trk_cap == 64 && k.near_sep == 0 && !getenv("CN_NO_SHAPE_KERNELS")
+                  && c.room_half + c.lidar_max + 1.0 < 32.0;       // the _s720 kernels keep end points as int16 thousandths
+    if (h->shape720) h->lds_shape = lds_bytes_impl(R, P, K, h->max_conf, h->trk_cap, false, c.obs_layout, true);
     k.max_conf = h->max_conf; k.trk_cap = h->trk_cap; k.env_index_base = c.env_index_base; k.seed = c.seed;
     k.room_half = c.room_half; k.ped_radius = c.ped_radius; k.ped_vmax = c.ped_vmax; k.robot_clearance = c.robot_clearance;
     k.lidar_min = c.lidar_min; k.lidar_max = c.lidar_max; k.lidar_offset_x = c.lidar_offset_x;
@@ -360,57 +405,20 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
         HIPCHK(hipMemcpy((void*)k.assoc_tab, tab, sizeof(tab), hipMemcpyHostToDevice));
     }
     if (h->lds > 64 * 1024)
-    {
-        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
-        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_fair, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
-        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_ext, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
-        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_same, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
-        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_ct, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
-        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_ct_same, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
-        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_gt_ct, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
-        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_gt_ct_same, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
-        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_sf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
-        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_sf_same, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
-        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_gt_sf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
-        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_gt_sf_same, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
-        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_s360, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
-        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_fair_s360, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
-        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_seq_s360, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
-        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_seq_s720, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
-        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_s720, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
-        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_fair_s720, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
-        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_wa, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
-        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_wa_same, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
-        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_gt_wa, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
-        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_gt_wa_same, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
-        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_seq, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
-        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_gt_seq, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
-        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_sfd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
-        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_sfd_same, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
-        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_gt_sfd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
-        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_gt_sfd_same, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
-        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_gt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
-        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_gt_same, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
-        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_rw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
-        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_rw_same, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
-        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_rw_ext, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
-        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_orig, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
-        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_orig_ext, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
-        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_orig_same, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
-    }
-    {   // cn_rollout_policy: 16 environments per workgroup, their working sets 16-byte aligned one after the other (the actor's
-        // tile is laid out compactly over them between two steps), + the 16 actions
-        h->pol_wave_lds = (h->lds + 15) & ~(size_t)15;
+        for (const void* f : kDynamicLdsKernels) HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
+    {   // cn_rollout_policy: 16 (or 8) environments per workgroup, their working sets 16-byte aligned one after the other (the
+        // actor's 16-row tile is laid out compactly over them between two steps), + the workgroup's actions
+        // (whichever kernel choose_policy_kernel picks for this handle: the 720-ray shape's has the compact layout)
+        h->pol_wave_lds = ((choose_policy_kernel(h).compact ? h->lds_shape : h->lds) + 15) & ~(size_t)15;
         const size_t tile = sizeof(float) * (16 * (size_t)(((k.R - 1 + 7 + 4 * k.K + 31) & ~31) + 1) + 16 * 257);
-        size_t tot = 16 * h->pol_wave_lds;
-        if (tot < tile) tot = tile;
-        tot += 16 * 2 * sizeof(float);
-        if (tot <= 160 * 1024 && h->cfg.obs_layout == CN_LAYOUT_RISK) {
-            h->pol_lds = tot;
-            HIPCHK(hipFuncSetAttribute((const void*)cn_policy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tot));
-            HIPCHK(hipFuncSetAttribute((const void*)cn_policy_kernel_s360, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tot));
-            HIPCHK(hipFuncSetAttribute((const void*)cn_policy_kernel_gt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tot));
+        for (int pe = 16; pe >= 8 && !h->pol_lds && h->cfg.obs_layout == CN_LAYOUT_RISK; pe -= 8) {
+            size_t off = (size_t)pe * h->pol_wave_lds;
+            if (off < tile) off = (tile + 15) & ~(size_t)15;
+            const size_t tot = off + (size_t)pe * 2 * sizeof(float);
+            if (tot <= 160 * 1024) { h->pol_lds = tot; h->pol_envs = pe; h->pol_act_off = off; }
         }
+        if (h->pol_lds > 64 * 1024)
+            for (const void* f : kPolicyKernels) HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->pol_lds));
     }
     *out = guard.release();
     return CN_OK;
@@ -470,9 +478,6 @@ static bool fair_launch(const cn_env_s* h, bool overlapped)
     return h->n_cus > 0 && h->cfg.n_envs >= 8 * h->n_cus;
 }
 
-typedef void (*cn_kernel_fn)(CnKParams);
-struct KernelChoice { cn_kernel_fn fn; const char* name; };
-#define CN_KC(f) KernelChoice{f, #f}
 
 // Which kernel a launch of this handle runs.  ext: externally supplied /scan + /odom; same: Env.step + same-call reset.
 static KernelChoice choose_kernel(const cn_env_s* h, bool ext, bool same, bool overlapped)
@@ -493,21 +498,56 @@ static KernelChoice choose_kernel(const cn_env_s* h, bool ext, bool same, bool o
     if (same) return CN_KC(cn_env_kernel_same);
     const bool fair = fair_launch(h, overlapped);
     if (h->shape360) return fair ? CN_KC(cn_env_kernel_fair_s360) : CN_KC(cn_env_kernel_s360);
-    if (h->shape720) return fair ? CN_KC(cn_env_kernel_fair_s720) : CN_KC(cn_env_kernel_s720);
+    if (h->shape720) return fair ? CN_KCC(cn_env_kernel_fair_s720) : CN_KCC(cn_env_kernel_s720);
     return fair ? CN_KC(cn_env_kernel_fair) : CN_KC(cn_env_kernel);
 }
+// cn_step_sequence / cn_rollout_policy: obs_layout 0, every simulator but the contact ticks (NULL otherwise)
+static bool one_launch_config(const cn_env_s* h) { return h->cfg.obs_layout == CN_LAYOUT_RISK && !h->cfg.ped_contact; }
 static KernelChoice choose_sequence_kernel(const cn_env_s* h)
 {
-    return h->cfg.risk_mode == CN_RISK_GT ? CN_KC(cn_env_kernel_gt_seq)
-         : h->shape360 ? CN_KC(cn_env_kernel_seq_s360) : h->shape720 ? CN_KC(cn_env_kernel_seq_s720) : CN_KC(cn_env_kernel_seq);
+    const cn_config& c = h->cfg;
+    if (!one_launch_config(h)) return KernelChoice{nullptr, nullptr};
+    const bool gt = c.risk_mode == CN_RISK_GT, sf = c.ped_mode == 2, wa = c.wheel_accel > 0.0;
+    const bool sfd = sf && !h->kp.sf_pair_matrix && c.n_peds <= 128;
+    if (wa) return gt ? CN_KC(cn_env_kernel_gt_seq_wa) : CN_KC(cn_env_kernel_seq_wa);          // (choose_kernel: the wheel ramp comes first)
+    if (sfd) return gt ? CN_KC(cn_env_kernel_gt_seq_sfd) : CN_KC(cn_env_kernel_seq_sfd);
+    if (sf) return gt ? CN_KC(cn_env_kernel_gt_seq_sf) : CN_KC(cn_env_kernel_seq_sf);
+    return gt ? CN_KC(cn_env_kernel_gt_seq)
+         : h->shape360 ? CN_KC(cn_env_kernel_seq_s360) : h->shape720 ? CN_KCC(cn_env_kernel_seq_s720) : CN_KC(cn_env_kernel_seq);
+}
+static KernelChoice choose_policy_kernel(const cn_env_s* h)
+{
+    const cn_config& c = h->cfg;
+    if (!one_launch_config(h)) return KernelChoice{nullptr, nullptr};
+    const bool gt = c.risk_mode == CN_RISK_GT, sf = c.ped_mode == 2, wa = c.wheel_accel > 0.0;
+    const bool sfd = sf && !h->kp.sf_pair_matrix && c.n_peds <= 128;
+    if (wa) return gt ? CN_KC(cn_policy_kernel_gt_wa) : CN_KC(cn_policy_kernel_wa);
+    if (sfd) return gt ? CN_KC(cn_policy_kernel_gt_sfd) : CN_KC(cn_policy_kernel_sfd);
+    if (sf) return gt ? CN_KC(cn_policy_kernel_gt_sf) : CN_KC(cn_policy_kernel_sf);
+    return gt ? CN_KC(cn_policy_kernel_gt)
+         : h->shape360 ? CN_KC(cn_policy_kernel_s360) : h->shape720 ? CN_KCC(cn_policy_kernel_s720) : CN_KC(cn_policy_kernel);
 }
 
 extern "C" const char* cn_kernel_name(cn_handle h, int what)
 {
     if (!h || what < 0 || what > 5) { fail(CN_ERR_ARG, "cn_kernel_name: bad argument"); return nullptr; }
-    if (what == 5) return h->cfg.risk_mode == CN_RISK_GT ? "cn_policy_kernel_gt" : h->shape360 ? "cn_policy_kernel_s360" : "cn_policy_kernel";
-    if (what == 2) return choose_sequence_kernel(h).name;
+    if (what == 5) { const char* n_ = choose_policy_kernel(h).name; if (!n_) fail(CN_ERR_CONFIG, "cn_kernel_name: cn_rollout_policy has no kernel for this configuration"); return n_; }
+    if (what == 2) { const char* n_ = choose_sequence_kernel(h).name; if (!n_) fail(CN_ERR_CONFIG, "cn_kernel_name: cn_step_sequence has no kernel for this configuration"); return n_; }
     return choose_kernel(h, what == 3, what == 1, what == 4).name;
+}
+
+__global__ void cn_clock_kernel(long long* out)
+{
+    out[0] = (long long)__builtin_amdgcn_s_memtime();
+    out[1] = (long long)__builtin_amdgcn_s_memrealtime();
+}
+extern "C" int cn_device_clock(int64_t* out_dev, int device, void* stream)
+{
+    if (!out_dev) return fail(CN_ERR_ARG, "cn_device_clock: null argument");
+    DeviceScope scope(device);
+    hipLaunchKernelGGL(cn_clock_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (long long*)out_dev);
+    HIPCHK(hipGetLastError());
+    return CN_OK;
 }
 
 static int launch(cn_handle h, const CnKParams& kp, hipStream_t st, bool overlapped = false)
@@ -518,7 +558,7 @@ static int launch(cn_handle h, const CnKParams& kp, hipStream_t st, bool overlap
     if (!kc.fn)
         return fail(CN_ERR_CONFIG, "cn_observe_external: risk_mode gt reads the library simulator's pedestrians; "
                                    "external /scan + /odom only exist in lidar_tracker mode");
-    hipLaunchKernelGGL(kc.fn, dim3(kp.N), dim3(64), h->lds, st, kp);
+    hipLaunchKernelGGL(kc.fn, dim3(kp.N), dim3(64), lds_of(h, kc), st, kp);
     HIPCHK(hipGetLastError());
     return CN_OK;
 }
@@ -654,8 +694,8 @@ extern "C" int cn_actor_forward(const cn_actor_weights* w, const float* obs, flo
 extern "C" int cn_step_sequence(cn_handle h, const cn_sequence_io* io, void* stream)
 {
     if (!h || !io || !io->action || !io->obs || !io->reward || !io->done) return fail(CN_ERR_ARG, "cn_step_sequence: null argument");
-    if (h->cfg.obs_layout != CN_LAYOUT_RISK || h->cfg.ped_contact || h->cfg.ped_mode == 2 || h->cfg.wheel_accel > 0.0)
-        return fail(CN_ERR_CONFIG, "cn_step_sequence: built for obs_layout 0 with the plain simulator (no contact / social-force / wheel-ramp ticks)");
+    if (!one_launch_config(h))
+        return fail(CN_ERR_CONFIG, "cn_step_sequence: built for obs_layout 0 (every simulator but the contact ticks: ped_contact = 0)");
     if (io->n_steps < 0 || io->action_stride < 0 || io->obs_stride < 0 || io->reward_stride < 0 || io->done_stride < 0 || io->topk_stride < 0)
         return fail(CN_ERR_ARG, "cn_step_sequence: negative step count or stride");
     if (io->n_steps == 0) return CN_OK;
@@ -666,8 +706,8 @@ extern "C" int cn_step_sequence(cn_handle h, const cn_sequence_io* io, void* str
     kp.roll_steps = io->n_steps; kp.roll_action_in_stride = io->action_stride; kp.roll_obs_stride = io->obs_stride;
     kp.roll_reward_stride = io->reward_stride; kp.roll_done_stride = io->done_stride; kp.roll_topk_stride = io->topk_stride;
     DeviceScope scope(h->device);
-    cn_kernel_fn fn = choose_sequence_kernel(h).fn;
-    hipLaunchKernelGGL(fn, dim3(h->cfg.n_envs), dim3(64), h->lds, (hipStream_t)stream, kp);
+    const KernelChoice kc = choose_sequence_kernel(h);
+    hipLaunchKernelGGL(kc.fn, dim3(h->cfg.n_envs), dim3(64), lds_of(h, kc), (hipStream_t)stream, kp);
     HIPCHK(hipGetLastError());
     return CN_OK;
 }
@@ -676,10 +716,10 @@ extern "C" int cn_rollout_policy(cn_handle h, const cn_actor_weights* w, const c
 {
     if (!h || !w || !io || !io->obs0 || !io->action || !io->obs || !io->reward || !io->done || !w->w1p || !w->b1 || !w->w2p || !w->b2 || !w->w3 || !w->b3)
         return fail(CN_ERR_ARG, "cn_rollout_policy: null argument");
-    if (h->cfg.obs_layout != CN_LAYOUT_RISK || h->cfg.ped_contact || h->cfg.ped_mode == 2 || h->cfg.wheel_accel > 0.0)
-        return fail(CN_ERR_CONFIG, "cn_rollout_policy: built for obs_layout 0 with the plain simulator (no contact / social-force / wheel-ramp ticks)");
+    if (!one_launch_config(h))
+        return fail(CN_ERR_CONFIG, "cn_rollout_policy: built for obs_layout 0 (every simulator but the contact ticks: ped_contact = 0)");
     if (!h->pol_lds)
-        return fail(CN_ERR_CONFIG, "cn_rollout_policy: 16 environments of this shape do not fit one CU's LDS (160 KiB)");
+        return fail(CN_ERR_CONFIG, "cn_rollout_policy: not even 8 environments of this shape fit one CU's LDS (160 KiB)");
     const int D = h->cfg.n_rays - 1 + 7 + 4 * h->cfg.k_obstacles;
     if (w->hidden != 256 || w->obs_dim != D || w->obs_dim_padded != ((D + 31) & ~31))
         return fail(CN_ERR_CONFIG, "cn_rollout_policy: the actor must be cn_actor_pack_weights' layout for this handle's observation width (hidden 256, obs_dim_padded = obs_dim rounded up to 32)");
@@ -696,9 +736,10 @@ extern "C" int cn_rollout_policy(cn_handle h, const cn_actor_weights* w, const c
     kp.pol_obs0 = io->obs0; kp.pol_seed = io->seed; kp.pol_counter = io->counter;
     kp.pol_max_v = io->max_v; kp.pol_max_w = io->max_w; kp.pol_sigma = io->sigma;
     kp.pol_D = D; kp.pol_Dp = w->obs_dim_padded; kp.pol_wave_lds = (int32_t)h->pol_wave_lds;
+    kp.pol_envs = h->pol_envs; kp.pol_act_off = (int32_t)h->pol_act_off;
     DeviceScope scope(h->device);
-    cn_kernel_fn fn = h->cfg.risk_mode == CN_RISK_GT ? cn_policy_kernel_gt : h->shape360 ? cn_policy_kernel_s360 : cn_policy_kernel;
-    hipLaunchKernelGGL(fn, dim3((h->cfg.n_envs + 15) / 16), dim3(1024), h->pol_lds, (hipStream_t)stream, kp);
+    cn_kernel_fn fn = choose_policy_kernel(h).fn;
+    hipLaunchKernelGGL(fn, dim3((h->cfg.n_envs + h->pol_envs - 1) / h->pol_envs), dim3(64 * h->pol_envs), h->pol_lds, (hipStream_t)stream, kp);
     HIPCHK(hipGetLastError());
     return CN_OK;
 }

@@ -96,7 +96,30 @@ struct Lds {
     int wstride;      // words per mask
     double* tail;     // [7 + 4K]
     int* kidx;        // [K]
+    // COMPACT layout (the 720-ray shape kernels; see "LDS map" in env_kernel_body): end points as int16 thousandths, confirmed objects
+    // as integer thousandths + byte flags.  The values are the same integers either way (x == cn_div1000(mil) bit for bit).
+    short* ptx16; short* pty16;
+    int* cfxi; int* cfyi; unsigned short* cfdm; unsigned char* cft8; unsigned char* chk8;
 };
+// typed access to the arrays that have two representations (CMP = compact)
+template <bool CMP> __device__ __forceinline__ int ptx_at(const Lds& L, int i) { if constexpr (CMP) return (int)L.ptx16[i]; else return L.ptx[i]; }
+template <bool CMP> __device__ __forceinline__ int pty_at(const Lds& L, int i) { if constexpr (CMP) return (int)L.pty16[i]; else return L.pty[i]; }
+template <bool CMP> __device__ __forceinline__ void pt_set(const Lds& L, int i, int x, int y)
+{
+    if constexpr (CMP) { L.ptx16[i] = (short)x; L.pty16[i] = (short)y; } else { L.ptx[i] = x; L.pty[i] = y; }
+}
+template <bool CMP> __device__ __forceinline__ double cfx_at(const Lds& L, int j) { if constexpr (CMP) return cn_div1000((double)L.cfxi[j]); else return L.cfx[j]; }
+template <bool CMP> __device__ __forceinline__ double cfy_at(const Lds& L, int j) { if constexpr (CMP) return cn_div1000((double)L.cfyi[j]); else return L.cfy[j]; }
+template <bool CMP> __device__ __forceinline__ double cfd_at(const Lds& L, int j) { if constexpr (CMP) return cn_div1000((double)L.cfdm[j]); else return L.cfd[j]; }
+template <bool CMP> __device__ __forceinline__ int cft_at(const Lds& L, int j) { if constexpr (CMP) return (int)L.cft8[j]; else return L.cft[j]; }
+template <bool CMP> __device__ __forceinline__ int chk_at(const Lds& L, int j) { if constexpr (CMP) return (int)L.chk8[j]; else return L.checked[j]; }
+template <bool CMP> __device__ __forceinline__ void chk_set(const Lds& L, int j, int v) { if constexpr (CMP) L.chk8[j] = (unsigned char)v; else L.checked[j] = v; }
+// a confirmed object from its centre ray's end point / range in thousandths
+template <bool CMP> __device__ __forceinline__ void conf_set(const Lds& L, int slot, int obj, int xmil, int ymil, int dmil_)
+{
+    if constexpr (CMP) { L.cft8[slot] = (unsigned char)obj; L.cfxi[slot] = xmil; L.cfyi[slot] = ymil; L.cfdm[slot] = (unsigned short)dmil_; }
+    else { L.cft[slot] = obj; L.cfx[slot] = cn_div1000((double)xmil); L.cfy[slot] = cn_div1000((double)ymil); L.cfd[slot] = cn_div1000((double)dmil_); }
+}
 
 __device__ __forceinline__ double heading_to_goal(KP p, const EnvRegs& e, double px, double py, double yaw)
 {
@@ -912,6 +935,7 @@ __device__ __forceinline__ double bbox_size(KP p, double* stage, int lane, int n
 
 // ---- ENV:656-743 tracker (the same block is RW:478-571), on the confirmed objects L.cfx / cfy / cfd / cft [nconf] ----------
 #define TRK(f, i) T[(f) * L.tcap + (i)]
+template <bool CMP = false>
 __device__ __forceinline__ void tracker_stage(KP p, EnvRegs& e, const Lds& L, double* const T, int lane, int nconf, double now)
 {
     // ---- ENV:656-743 tracker -----------------------------------------------------------------------
@@ -927,7 +951,7 @@ __device__ __forceinline__ void tracker_stage(KP p, EnvRegs& e, const Lds& L, do
     bool add_unchecked = false;
     if (CN_ABLATE(16)) { e.ntracks = 0; nconf = 0; }
     if (e.ntracks == 0) {
-        for (int j = lane; j < nconf; j += 64) L.checked[j] = 0;
+        for (int j = lane; j < nconf; j += 64) chk_set<CMP>(L, j, 0);
         add_unchecked = true;  // every 'o' object becomes a track
     } else {
         const int nt0 = e.ntracks;
@@ -935,7 +959,7 @@ __device__ __forceinline__ void tracker_stage(KP p, EnvRegs& e, const Lds& L, do
             TRK(CN_TF_D0X, lane) = TRK(CN_TF_D1X, lane); TRK(CN_TF_D0Y, lane) = TRK(CN_TF_D1Y, lane);
             TRK(CN_TF_DQLEN, lane) = 1.0;
         }
-        for (int j = lane; j < nconf; j += 64) L.checked[j] = 0;
+        for (int j = lane; j < nconf; j += 64) chk_set<CMP>(L, j, 0);
         CN_SYNC();
         if (nconf == 0) {
             e.ntracks = 0;  // ENV:683-686 nets out to clearing every track
@@ -955,7 +979,7 @@ __device__ __forceinline__ void tracker_stage(KP p, EnvRegs& e, const Lds& L, do
                 if (ti < nt0) {
                     const double tx = TRK(CN_TF_PX, ti), ty_ = TRK(CN_TF_PY, ti);
                     for (int oj = lane & 7; oj < nconf; oj += 8) {
-                        const double u = cn_iou3(tx, ty_, L.cfx[oj], L.cfy[oj], 0.0505, PY2);
+                        const double u = cn_iou3(tx, ty_, cfx_at<CMP>(L, oj), cfy_at<CMP>(L, oj), 0.0505, PY2);
                         if (u > best) { best = u; bj = oj; }
                     }
                 }
@@ -977,11 +1001,11 @@ __device__ __forceinline__ void tracker_stage(KP p, EnvRegs& e, const Lds& L, do
             }
             if (lane < nt0 && ((matchm >> lane) & 1ull)) {          // ENV:702-712
                 const int i = lane;
-                double cxj = L.cfx[mybj], cyj = L.cfy[mybj];
-                TRK(CN_TF_PX, i) = cxj; TRK(CN_TF_PY, i) = cyj; TRK(CN_TF_DIST, i) = L.cfd[mybj];
+                double cxj = cfx_at<CMP>(L, mybj), cyj = cfy_at<CMP>(L, mybj);
+                TRK(CN_TF_PX, i) = cxj; TRK(CN_TF_PY, i) = cyj; TRK(CN_TF_DIST, i) = cfd_at<CMP>(L, mybj);
                 if (TRK(CN_TF_DQLEN, i) < 1.5) { TRK(CN_TF_D1X, i) = cxj; TRK(CN_TF_D1Y, i) = cyj; TRK(CN_TF_DQLEN, i) = 2.0; }
                 TRK(CN_TF_T, i) = now - TRK(CN_TF_T, i);
-                L.checked[mybj] = 1;
+                chk_set<CMP>(L, mybj, 1);
             }
             CN_SYNC();
             // compact the survivors, order preserved
@@ -1005,13 +1029,13 @@ __device__ __forceinline__ void tracker_stage(KP p, EnvRegs& e, const Lds& L, do
     if (add_unchecked) {
         for (int j0 = 0; j0 < nconf; j0 += 64) {
             int j = j0 + lane;
-            bool want = (j < nconf) && !L.checked[j] && (L.cft[j] == TY_O);
+            bool want = (j < nconf) && !chk_at<CMP>(L, j) && (cft_at<CMP>(L, j) == TY_O);
             unsigned long long m = __ballot(want);
             int slot = e.ntracks + __popcll(m & ((1ull << lane) - 1ull));
             if (want) {
                 if (slot < L.tcap) {
-                    double cxj = L.cfx[j], cyj = L.cfy[j];
-                    TRK(CN_TF_PX, slot) = cxj; TRK(CN_TF_PY, slot) = cyj; TRK(CN_TF_DIST, slot) = L.cfd[j];
+                    double cxj = cfx_at<CMP>(L, j), cyj = cfy_at<CMP>(L, j);
+                    TRK(CN_TF_PX, slot) = cxj; TRK(CN_TF_PY, slot) = cyj; TRK(CN_TF_DIST, slot) = cfd_at<CMP>(L, j);
                     TRK(CN_TF_D0X, slot) = cxj; TRK(CN_TF_D0Y, slot) = cyj; TRK(CN_TF_D1X, slot) = 0.0; TRK(CN_TF_D1Y, slot) = 0.0;
                     TRK(CN_TF_T, slot) = now; TRK(CN_TF_SPEED, slot) = -1.0;
                     TRK(CN_TF_VX, slot) = 0.0; TRK(CN_TF_VY, slot) = 0.0; TRK(CN_TF_DQLEN, slot) = 1.0;
@@ -1025,7 +1049,7 @@ __device__ __forceinline__ void tracker_stage(KP p, EnvRegs& e, const Lds& L, do
     CN_SYNC();
 }
 
-template <bool EXT, bool GT = false, bool FAIR = false>
+template <bool EXT, bool GT = false, bool FAIR = false, bool CMP = false>
 __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const Lds& L, int env, int lane, int step_counter,
                         float* obs32, float* fin32, double* obs64, int* done_out, bool have_tg = false, Trig tg = Trig{0.0, 0.0, 0.0, 0.0})
 {
@@ -1099,8 +1123,7 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
             // sin/cos(radians(j * inc) - yaw) by angle addition from a host table of sin/cos(radians(j * inc))
             if constexpr (!GT) {      // end points feed the segmentation only
             const double sa = fma(tS, cy, -(tC * sy)), ca = fma(tC, cy, tS * sy);
-            L.ptx[j] = (int)cn_round_scaled(px + (sc * ca), 1000.0, PY2);
-            L.pty[j] = (int)cn_round_scaled(py + (sc * sa) * -1.0, 1000.0, PY2);
+            pt_set<CMP>(L, j, (int)cn_round_scaled(px + (sc * ca), 1000.0, PY2), (int)cn_round_scaled(py + (sc * sa) * -1.0, 1000.0, PY2));
             L.dmil[j] = (unsigned short)(int)cn_round_scaled(sc, 1000.0, PY2);
             }
             double so = cn_np_around3_t<!EXT>(sc);  // ENV:1042
@@ -1132,8 +1155,8 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
     const int W = (n + 63) >> 6;  // 64-ray words; ray i = bit (i & 63) of word (i >> 6)
 #define WORD(id, q) L.w64[__mul24((id), L.wstride) + (q)]   /* 24-bit multiply: full rate (v_mul_lo_u32 is quarter rate) */
 #define BIT(id, i) ((WORD(id, (i) >> 6) >> ((i) & 63)) & 1ull)
-#define PX(i) cn_div1000((double)L.ptx[i])
-#define PY(i) cn_div1000((double)L.pty[i])
+#define PX(i) cn_div1000((double)ptx_at<CMP>(L, (i)))
+#define PY(i) cn_div1000((double)pty_at<CMP>(L, (i)))
 #define GNONE 0x7fffffff
     // ENV:329-346 gradients between consecutive end points, kept as integer thousandths (GNONE = None), and
     // ENV:348-367 the flag words of the type machine.  Only OCCUPIED rays (range != 0.6, typically a third of the scan)
@@ -1163,9 +1186,9 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
         const bool va = ca < nocc, vb = cb < nocc;
         const int ia = va ? (int)occlist[ca] : 0, ib = vb ? (int)occlist[cb] : 0;
         const int ja = (ia == n - 1) ? 0 : ia + 1, jb = (ib == n - 1) ? 0 : ib + 1;
-        const int xai = L.ptx[ia], yai = L.pty[ia], xaj = L.ptx[ja], yaj = L.pty[ja];
+        const int xai = ptx_at<CMP>(L, ia), yai = pty_at<CMP>(L, ia), xaj = ptx_at<CMP>(L, ja), yaj = pty_at<CMP>(L, ja);
         int xbi = 0, ybi = 0, xbj = 0, ybj = 0;
-        if (two) { xbi = L.ptx[ib]; ybi = L.pty[ib]; xbj = L.ptx[jb]; ybj = L.pty[jb]; }
+        if (two) { xbi = ptx_at<CMP>(L, ib); ybi = pty_at<CMP>(L, ib); xbj = ptx_at<CMP>(L, jb); ybj = pty_at<CMP>(L, jb); }
         const double dya = cn_div1000((double)yai) - cn_div1000((double)yaj);
         const double qa = (dya == 0) ? 0.0 : cn_div(cn_div1000((double)xai) - cn_div1000((double)xaj), dya);   // |dy| >= 0.001 or the lane is discarded
         if (va) L.gq[ia] = (int)cn_round_scaled(qa, 1000.0, PY2);
@@ -1301,7 +1324,7 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
                 // here: sources are never aliased themselves, and both ends are occupied rays, so the occupancy words
                 // (range != 0.6) gathered before the gradients stay valid -- no separate pass over all rays.
                 const int i_ = 64 * q + t;
-                L.dmil[i_] = L.dmil[src]; L.ptx[i_] = L.ptx[src]; L.pty[i_] = L.pty[src];
+                L.dmil[i_] = L.dmil[src]; pt_set<CMP>(L, i_, ptx_at<CMP>(L, src), pty_at<CMP>(L, src));
             }
         }
         (void)al;
@@ -1376,7 +1399,7 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
         for (int q = 0; q < QB; ++q) {
             const int i = lane + 64 * q;
             dxm[q] = 0; dym[q] = 0;
-            if (q < W && i < n - 1) { dxm[q] = L.ptx[i] - L.ptx[i + 1]; dym[q] = L.pty[i] - L.pty[i + 1]; }
+            if (q < W && i < n - 1) { dxm[q] = ptx_at<CMP>(L, i) - ptx_at<CMP>(L, i + 1); dym[q] = pty_at<CMP>(L, i) - pty_at<CMP>(L, i + 1); }
         }
 #pragma unroll
         for (int q = 0; q < QB; ++q) { dxm[q] = min(abs(dxm[q]), K1 + 1); lim[q] = (q < W) ? (int)amax[dxm[q]] : 0; }
@@ -1397,7 +1420,7 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
             brk = true;
             if (i < n - 1) {
                 if (fast_assoc) {
-                    const int dx_ = abs(L.ptx[i] - L.ptx[i + 1]), dy_ = abs(L.pty[i] - L.pty[i + 1]);
+                    const int dx_ = abs(ptx_at<CMP>(L, i) - ptx_at<CMP>(L, i + 1)), dy_ = abs(pty_at<CMP>(L, i) - pty_at<CMP>(L, i + 1));
                     brk = dy_ > (int)amax[min(dx_, K1 + 1)];
                 } else brk = !cn_iou3_positive(PX(i), PY(i), PX(i + 1), PY(i + 1), e.bb, PY2);
             }
@@ -1501,7 +1524,7 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
             if (((sw >> lane) & 1ull) && r >= 0 && r < segcap) seglist[r] = (unsigned short)(lane + 64 * q);
         }
         CN_SYNC();
-        int obj = -1, m = 0; double dm = 0.0;
+        int obj = -1, m = 0; double dm = 0.0; int dmi = 0;
         if (lane < min(segcap, nseg - c0)) {
             const int k = seglist[lane], q = k >> 6, bl = k & 63;
             const u64 sw = WORD(M_SEG, q);
@@ -1521,7 +1544,8 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
             const bool occ = (WORD(M_OCC, q) >> bl) & 1ull;  // segments are homogeneous after the split
             if (occ && len >= 4) {
                 m = ORDER(k0 + len / 2);  // ENV:577 Python-2 integer division
-                dm = cn_div1000((double)L.dmil[m]);
+                dmi = (int)L.dmil[m];
+                dm = cn_div1000((double)dmi);
                 int est = 3 + (int)floor(cn_div(29 * (p->max_scan_range - dm), p->max_scan_range - p->min_scan_range));   // cn_create: max > min
                 int mn = len < est ? len : est;
                 double score = cn_div((double)no, (double)mn);          // mn >= 3
@@ -1539,7 +1563,7 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
         const u64 cwd = __ballot(obj >= 0);
         if (obj >= 0) {
             int slot = nconf + __popcll(cwd & ((1ull << lane) - 1ull));
-            if (slot < p->max_conf) { L.cft[slot] = obj; L.cfx[slot] = PX(m); L.cfy[slot] = PY(m); L.cfd[slot] = dm; }
+            if (slot < p->max_conf) conf_set<CMP>(L, slot, obj, ptx_at<CMP>(L, m), pty_at<CMP>(L, m), dmi);
         }
         nconf += __popcll(cwd);
         CN_SYNC();
@@ -1557,14 +1581,14 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
     // ENV:637-654
     int n_obst = 0;
     for (int j = lane; j < nconf; j += 64) {
-        if (L.cft[j] == TY_O) { n_obst += 1; if (L.cfd[j] < 0.140) ego_hit = 1; }
+        if (cft_at<CMP>(L, j) == TY_O) { n_obst += 1; if (cfd_at<CMP>(L, j) < 0.140) ego_hit = 1; }
     }
     n_obst = cn_wave_sum_i(n_obst);
     ego_hit = cn_wave_max_i(ego_hit);
     if (n_obst > 0) e.obst_steps += 1;
 
     CN_T(13);
-    tracker_stage(p, e, L, T, lane, nconf, now);
+    tracker_stage<CMP>(p, e, L, T, lane, nconf, now);
     } else {
         // ---- risk_mode gt (SURVEY 7 "two risk-feature modes", include/crowdnav.h): rows A21-A24 fed with the simulator's own
         // pedestrians instead of tracked lidar blobs -- the north star's "K-nearest perceived-risk feature extraction".
@@ -1698,7 +1722,7 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
         // track's value is 0 by induction (it starts at 0 and a track without a collision point resets it to 0).
         const double rv = agent_vel - obstacle_vel;
         const int hcap = min(p->max_conf, 64);         // tracks per chunk: one lane each, 4 doubles of LDS each
-        double* const hitp = L.cfx;                     // [4][hcap]: first hit x, y, second hit x, y
+        double* const hitp = L.cfx;                     // [4][hcap]: first hit x, y, second hit x, y (L.cfx = the start of the confirmed-object arrays in both layouts)
         for (int c0 = 0; c0 < nt; c0 += hcap) {
             const int c1 = min(nt, c0 + hcap);
             u64 nearm = 0, hasm = 0;
@@ -2263,6 +2287,13 @@ __device__ __forceinline__ void env_kernel_body(const int env, const int lane, c
         if (p->mode == CN_MODE_RESET && p->mask && !p->mask[env]) return;
     }
     const int R = p->R, n = R - 1, P = p->P, K = p->K;
+    // COMPACT LDS layout (round 5; BASELINE configs[4]'s shape only): 18.5 KB per environment left 8 wavefronts on a CU (2 per SIMD);
+    // 13.2 KB leaves 12.  Three changes, none of which touches a value: (1) end points as int16 thousandths (|x| <= 32.767 m: cn_create
+    // checks the room), (2) confirmed objects as integer thousandths + byte flags (12 instead of 32 bytes each), (3) the pedestrians'
+    // velocities live in region A, which is idle whenever the simulator runs, and go to the state record before the observation
+    // overwrites them (a reset brings them back for its settle advance).  crowdnav_abi.hip lds_bytes_impl(compact) mirrors the carve.
+    constexpr bool CMP = SHAPE == 720;
+    static_assert(!CMP || (!EXT && !TWO && LAYOUT == 0 && !GT && SIM == 0), "the compact layout is the 720-ray shape kernels' own");
     // where this step's outputs go: the caller's buffers, or (FUSED) slot t of its trajectory buffers (stride 0 = in place)
     auto io_obs = [&]() -> float* { if constexpr (FUSED) return p->obs + (size_t)(t * p->roll_obs_stride); else return p->obs; };
     auto io_reward = [&]() -> float* { if constexpr (FUSED) return p->reward + (size_t)(t * p->roll_reward_stride); else return p->reward; };
@@ -2275,13 +2306,14 @@ __device__ __forceinline__ void env_kernel_body(const int env, const int lane, c
     {
         // LDS map.  Region A: end points (integer thousandths) | tracker table.
         // Region B: gradients + alias sources | bbox staging | confirmed objects, CP, observation tail.
-        const size_t szA_pts = (size_t)(10 * n + 7) & ~(size_t)7;
+        const size_t szA_pts = (size_t)((CMP ? 6 : 10) * n + 7) & ~(size_t)7;
         const size_t szA_trk = 8 * (size_t)(CN_TF_COUNT * p->trk_cap);
         L.tcap = p->trk_cap;
         const size_t szA = szA_pts > szA_trk ? szA_pts : szA_trk;
         const size_t mc = (size_t)p->max_conf;
         const size_t szB_g = (size_t)(6 * n + 7) & ~(size_t)7;
-        const size_t szB_c = 32 * mc + 8 * 64 + 8 * (size_t)(8 + 4 * K) + 4 * (size_t)CN_MAX_K;
+        const size_t szC = CMP ? ((12 * mc + 7) & ~(size_t)7) : 32 * mc;          // the confirmed-object arrays
+        const size_t szB_c = szC + 8 * 64 + 8 * (size_t)(8 + 4 * K) + 4 * (size_t)CN_MAX_K;
         size_t szB = szB_g > szB_c ? szB_g : szB_c;
         if (szB < 8 * 64) szB = 8 * 64;
         if (!p->near_sep && szB < 32 * (size_t)(P + 1)) szB = 32 * (size_t)(P + 1);   // near-pedestrian list overlaid on B
@@ -2289,12 +2321,16 @@ __device__ __forceinline__ void env_kernel_body(const int env, const int lane, c
         char* B = A + szA;
         char* Cw = B + szB;
         L.ptx = (int*)A; L.pty = (int*)(A + 4 * (size_t)n); L.dmil = (unsigned short*)(A + 8 * (size_t)n);
+        L.ptx16 = (short*)A; L.pty16 = (short*)(A + 2 * (size_t)n);
+        if constexpr (CMP) L.dmil = (unsigned short*)(A + 4 * (size_t)n);
         L.trk = (double*)A;
         L.gq = (int*)B; L.srcidx = (unsigned short*)(B + 4 * (size_t)n);
         L.stage = (double*)B;
         L.cfx = (double*)B; L.cfy = (double*)(B + 8 * mc); L.cfd = (double*)(B + 16 * mc);
         L.cft = (int*)(B + 24 * mc); L.checked = (int*)(B + 28 * mc);
-        L.cpv = (double*)(B + 32 * mc);
+        L.cfxi = (int*)B; L.cfyi = (int*)(B + 4 * mc); L.cfdm = (unsigned short*)(B + 8 * mc);
+        L.cft8 = (unsigned char*)(B + 10 * mc); L.chk8 = (unsigned char*)(B + 11 * mc);
+        L.cpv = (double*)(B + szC);
         L.tail = L.cpv + 64;
         L.kidx = (int*)(L.tail + (8 + 4 * K));
         const int Wn = (n + 63) >> 6;
@@ -2302,7 +2338,8 @@ __device__ __forceinline__ void env_kernel_body(const int env, const int lane, c
         L.w64 = (u64*)Cw; Cw += 8 * (size_t)(M_COUNT * Wn);
         L.wbase = (int*)Cw; Cw += 8 * (size_t)((3 * Wn + 1) / 2);
         L.ped = (double*)Cw; Cw += 8 * (size_t)(2 * P + 2);
-        L.pedv = (double*)Cw; Cw += 8 * (size_t)(2 * P + 2);
+        if constexpr (CMP) L.pedv = (double*)A;         // (3) above: 8 (2 P + 2) <= szA
+        else { L.pedv = (double*)Cw; Cw += 8 * (size_t)(2 * P + 2); }
         L.nearp = p->near_sep ? (double*)Cw : (double*)B;   // ray loop only: region B is dead until the gradients are written
         if (p->near_sep) Cw += 32 * (size_t)(P + 1);
         L.gtrk = p->trk + (size_t)env * CN_TF_COUNT * p->trk_cap;
@@ -2370,6 +2407,9 @@ __device__ __forceinline__ void env_kernel_body(const int env, const int lane, c
     double* pedv = L.pedv;  // velocities are only needed while advancing
     for (int i = lane; i < 2 * P; i += 64) { L.ped[i] = gped_p[i]; pedv[i] = gped_v[i]; }
     CN_SYNC();
+    // compact layout: the velocities' LDS space becomes the end points during the observation
+    auto pedv_save = [&]() { if constexpr (CMP) { for (int i = lane; i < 2 * P; i += 64) gped_v[i] = pedv[i]; } };
+    auto pedv_restore = [&]() { if constexpr (CMP) { for (int i = lane; i < 2 * P; i += 64) pedv[i] = gped_v[i]; CN_SYNC(); } };
 
     CN_T(1);
     int done = 0;
@@ -2461,11 +2501,12 @@ __device__ __forceinline__ void env_kernel_body(const int env, const int lane, c
             e.prev_head = heading_to_goal(p, e, e.rx, e.ry, e.ryaw);  // ENV:1244
             }
         }
+        pedv_save();
         CN_SYNC();
         if (ph_obs) {
             if constexpr (LAYOUT == 1) observe_original<EXT>(p, e, L, env, lane, sc, io_obs(), fin, p->obs_f64, &done);
             else if constexpr (LAYOUT == 2) observe_realworld<EXT>(p, pg, e, L, RQ, env, lane, sc, io_obs(), fin, p->obs_f64, &done);
-            else observe<EXT, GT, FAIR>(p, pg, e, L, env, lane, sc, io_obs(), fin, p->obs_f64, &done, have_trig, trig);
+            else observe<EXT, GT, FAIR, CMP>(p, pg, e, L, env, lane, sc, io_obs(), fin, p->obs_f64, &done, have_trig, trig);
         } else if constexpr (EXT) {
             // Env.compute_reward(state, step_counter, done) on its own (ENV:1046): heading and distance are state[n], state[n+1]
             // (LAYOUT 1: state[-2], state[-1] are what ORIG:324-330 reads), `done` is the caller's
@@ -2508,8 +2549,11 @@ __device__ __forceinline__ void env_kernel_body(const int env, const int lane, c
             e.social_viol = 0; e.ego_viol = 0; e.obst_steps = 0;  // ENV:1260-1262
             if (!ext) {
                 e.clock += cn_div1000((double)p->settle_ms);          // TRAIN:114 time.sleep(0.1)
+                pedv_restore();
                 if constexpr (SIM != 0) sim_advance_ticks<SIM>(p, e, env, lane, L.ped, pedv, (double*)smem, p->settle_ms);
                 else sim_advance(p, e, env, lane, L.ped, pedv, p->settle_ms);
+                CN_SYNC();
+                pedv_save();
             }
             e.done = 0;                                           // TRAIN:116
             e.ep_step = 0; e.ep_ret = 0.0; e.pending = 0;
@@ -2642,7 +2686,7 @@ __device__ __forceinline__ void env_kernel_body(const int env, const int lane, c
     asm volatile("" :: "v"(trk_warm));   // keeps the warming load (its value is irrelevant)
     CN_T(18);
     // ---- write env state back ---------------------------------------------------------------------
-    for (int i = lane; i < 2 * P; i += 64) { gped_p[i] = L.ped[i]; gped_v[i] = pedv[i]; }
+    for (int i = lane; i < 2 * P; i += 64) { gped_p[i] = L.ped[i]; if constexpr (!CMP) gped_v[i] = pedv[i]; }     // (compact: pedv_save() did)
     if (lane == 0) {
         sd[CN_SD_RX] = e.rx; sd[CN_SD_RY] = e.ry; sd[CN_SD_RYAW] = e.ryaw; sd[CN_SD_RV] = e.rv; sd[CN_SD_RW] = e.rw;
         sd[CN_SD_CLOCK] = e.clock; sd[CN_SD_WPX] = e.wpx; sd[CN_SD_WPY] = e.wpy;
@@ -2683,14 +2727,14 @@ extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_fair_s720(CnKPara
 extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_same(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, true, 0>(blockIdx.x, threadIdx.x, cn_smem); }
 extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_ext(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<true, false, 0>(blockIdx.x, threadIdx.x, cn_smem); }
 #endif
-#if !defined(CN_TU) || CN_TU == 2
+#if !defined(CN_TU) || CN_TU == 2 || CN_TU == 3
 // cn_step_sequence: T control periods per launch with OPEN-LOOP actions (resident in HBM: [T][N][2], or one [N][2] held for T
 // periods).  One wavefront keeps its environment for the whole launch and walks its T steps at its own pace: no launch boundary,
 // no device-wide join between steps -- the launch ends with its slowest wavefront's T steps, not with T x the slowest single
 // step -- and after a few steps the wavefronts of a SIMD are out of phase (they stop contending for the same unit at the same
 // time), which is what one launch per step can never be.  Each step is exactly cn_env_kernel's (next-step reset convention) and
 // writes its observation / reward / done / indices to slot t of the caller's buffers (stride 0: in place).
-template <bool GT, int SHAPE = 0>
+template <bool GT, int SHAPE = 0, int SIM = 0>
 __device__ __forceinline__ void sequence_body()
 {
     extern __shared__ __attribute__((aligned(16))) char cn_smem[];
@@ -2702,13 +2746,25 @@ __device__ __forceinline__ void sequence_body()
         asm volatile("" : "+v"(lane_));          // per-step laundering (see env_kernel_body): nothing is hoisted out of the step loop
         lane_ &= 63;
         cn_setprio_uniform((int)(t + wslot) & 3);      // see "issue arbitration" at the top: every slot gets every level in turn
-        env_kernel_body<false, false, 0, GT, 0, true, false, SHAPE>(blockIdx.x, lane_, cn_smem, t);
+        env_kernel_body<false, false, 0, GT, SIM, true, false, SHAPE>(blockIdx.x, lane_, cn_smem, t);
     }
 }
+#endif
+#if !defined(CN_TU) || CN_TU == 2
 extern "C" __global__ void CN_HOT_BOUNDS cn_env_kernel_seq(CnKParams p) { sequence_body<false>(); }
 extern "C" __global__ void CN_HOT_BOUNDS cn_env_kernel_seq_s360(CnKParams p) { sequence_body<false, 360>(); }
 extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_seq_s720(CnKParams p) { sequence_body<false, 720>(); }
 extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_gt_seq(CnKParams p) { sequence_body<true>(); }
+#endif
+#if !defined(CN_TU) || CN_TU == 3
+// round 5: the same persistent-wavefront form for the other simulators (SIM 2 / 4: social-force pedestrians, pair matrix / dense;
+// SIM 3: the diff-drive plugin's wheel ramp) -- the worlds one trains in "as Gazebo delivers it" -- in both risk modes
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_seq_sf(CnKParams p) { sequence_body<false, 0, 2>(); }
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_seq_sfd(CnKParams p) { sequence_body<false, 0, 4>(); }
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_seq_wa(CnKParams p) { sequence_body<false, 0, 3>(); }
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_gt_seq_sf(CnKParams p) { sequence_body<true, 0, 2>(); }
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_gt_seq_sfd(CnKParams p) { sequence_body<true, 0, 4>(); }
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_gt_seq_wa(CnKParams p) { sequence_body<true, 0, 3>(); }
 #endif
 #if !defined(CN_TU) || CN_TU == 1
 // risk_mode gt: the perceived-risk features from the simulator's own pedestrians (no segmentation, no tracker)
@@ -3055,7 +3111,7 @@ extern "C" __global__ void __launch_bounds__(ACT_THREADS) cn_actor_kernel(const 
 }
 #endif
 
-#if !defined(CN_TU) || CN_TU == 2
+#if !defined(CN_TU) || CN_TU == 2 || CN_TU == 4
 // ---- cn_rollout_policy: T control periods per launch with the POLICY IN THE LOOP --------------------------------------------
 // A workgroup = 16 environments = 16 wavefronts (one CU's worth at 4 per SIMD).  Per control period: the first eight waves run
 // the TD3 actor (actor_tile above: the arithmetic, noise keys and clip of cn_actor_forward) on the 16 observations the
@@ -3066,14 +3122,17 @@ extern "C" __global__ void __launch_bounds__(ACT_THREADS) cn_actor_kernel(const 
 // never leaves the CU's L2 slice.  Bit-identical to T x (cn_actor_forward, cn_step(auto_reset 2)) with counters c, c + 1, ...
 // The actor's LDS tile (42 KB) overlays the environments' working sets, which are dead between two steps (everything a step
 // needs it reloads from the state record); only the 16 actions live outside them.
-#define POL_ENVS 16
+// Round 5: the workgroup is 16 OR 8 environments (blockDim.x / 64, cn_create picks: 8 where 16 working sets do not fit one CU's LDS --
+// 720 rays x 100 pedestrians, dense social force -- then two workgroups share a CU and run out of phase by themselves; the actor
+// tile keeps its 16 rows, the upper 8 are padding), and the step body is instantiated for every simulator.
+#define POL_ENVS 16            /* the largest workgroup: launch bounds, the actor tile's rows */
 #ifndef POL_ACTOR_WAVES
 #define POL_ACTOR_WAVES(w) ((w) < 8)     /* experiments: (false) = barriers and heads only, to time the env phase alone */
 #endif
 #ifndef POL_FAIR
 #define POL_FAIR 1            /* experiments: 0 = the sequence kernel's rotating levels instead of the falling ones */
 #endif
-template <int SHAPE, bool GT = false>
+template <int SHAPE, bool GT = false, int SIM = 0>
 __device__ __forceinline__ void policy_sequence_body()
 {
     extern __shared__ __attribute__((aligned(16))) char cn_smem[];
@@ -3086,12 +3145,13 @@ __device__ __forceinline__ void policy_sequence_body()
         int tid_ = threadIdx.x;                  // registers across the whole step
         asm volatile("" : "+v"(tid_));
         const int lane_ = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
-        const int row0 = blockIdx.x * POL_ENVS, env = row0 + wave;
+        const int PE = p->pol_envs;                                               // environments (= waves) per workgroup: 16 or 8
+        const int row0 = blockIdx.x * PE, env = row0 + wave;
         const int ws = p->pol_wave_lds, D = p->pol_D;
-        float* const act_lds = (float*)(cn_smem + (size_t)POL_ENVS * ws);          // [16][2]
+        float* const act_lds = (float*)(cn_smem + (size_t)p->pol_act_off);          // [PE][2], past the working sets and the tile
         const float* ob = (t == 0 ? p->pol_obs0 : p->obs + (size_t)((t - 1) * p->roll_obs_stride)) + (size_t)row0 * D;
         float* ac = const_cast<float*>(p->action) + (size_t)(t * p->roll_action_in_stride) + 2 * (size_t)row0;
-        actor_tile<8>(ob, min(POL_ENVS, p->N - row0), row0, D, p->pol_Dp, p->pol_w1p, p->pol_b1, p->pol_w2p, p->pol_b2, p->pol_w3, p->pol_b3,
+        actor_tile<8>(ob, min(PE, p->N - row0), row0, D, p->pol_Dp, p->pol_w1p, p->pol_b1, p->pol_w2p, p->pol_b2, p->pol_w3, p->pol_b3,
                       ac, act_lds, p->pol_max_v, p->pol_max_w, p->pol_sigma, p->pol_seed, p->pol_counter + (uint64_t)t, (float*)cn_smem, POL_ACTOR_WAVES(wave), tid_);
         __syncthreads();
         if (env < p->N)
@@ -3099,14 +3159,25 @@ __device__ __forceinline__ void policy_sequence_body()
 #if POL_FAIR == 0
             cn_setprio_uniform((t + (int)__builtin_amdgcn_s_getreg(4 | (1 << 11))) & 3);
 #endif
-            env_kernel_body<false, false, 0, GT, 0, true, POL_FAIR != 0, SHAPE>(env, lane_, cn_smem + (size_t)wave * ws, t, act_lds + 2 * wave);
+            env_kernel_body<false, false, 0, GT, SIM, true, POL_FAIR != 0, SHAPE>(env, lane_, cn_smem + (size_t)wave * ws, t, act_lds + 2 * wave);
         }
         __syncthreads();
     }
 }
+#endif
+#if !defined(CN_TU) || CN_TU == 2
 extern "C" __global__ void __launch_bounds__(64 * POL_ENVS) cn_policy_kernel(CnKParams p) { policy_sequence_body<0>(); }
 extern "C" __global__ void __launch_bounds__(64 * POL_ENVS) cn_policy_kernel_s360(CnKParams p) { policy_sequence_body<360>(); }
 extern "C" __global__ void __launch_bounds__(64 * POL_ENVS) cn_policy_kernel_gt(CnKParams p) { policy_sequence_body<0, true>(); }   // risk_mode gt
+#endif
+#if !defined(CN_TU) || CN_TU == 4
+extern "C" __global__ void __launch_bounds__(64 * POL_ENVS) cn_policy_kernel_s720(CnKParams p) { policy_sequence_body<720>(); }      // BASELINE configs[4]: 8 per workgroup
+extern "C" __global__ void __launch_bounds__(64 * POL_ENVS) cn_policy_kernel_sf(CnKParams p) { policy_sequence_body<0, false, 2>(); }
+extern "C" __global__ void __launch_bounds__(64 * POL_ENVS) cn_policy_kernel_sfd(CnKParams p) { policy_sequence_body<0, false, 4>(); }
+extern "C" __global__ void __launch_bounds__(64 * POL_ENVS) cn_policy_kernel_wa(CnKParams p) { policy_sequence_body<0, false, 3>(); }
+extern "C" __global__ void __launch_bounds__(64 * POL_ENVS) cn_policy_kernel_gt_sf(CnKParams p) { policy_sequence_body<0, true, 2>(); }
+extern "C" __global__ void __launch_bounds__(64 * POL_ENVS) cn_policy_kernel_gt_sfd(CnKParams p) { policy_sequence_body<0, true, 4>(); }
+extern "C" __global__ void __launch_bounds__(64 * POL_ENVS) cn_policy_kernel_gt_wa(CnKParams p) { policy_sequence_body<0, true, 3>(); }
 #endif
 
 #if !defined(CN_TU) || CN_TU == 1

@@ -508,6 +508,48 @@ def test_config4_full_workload_16384_envs_as_8_shards(oracle_mod):
     assert np.array_equal(torch.cat(cnts).cpu().numpy()[:, :6], orc.counters())
 
 
+def test_step_sequence_at_the_bench_shape_4096_envs_20_steps_equals_step_by_step():
+    """The exact launches bench.py's sequence legs time (VERDICT r04 "weak" 1): cn_env_kernel_seq_s360 over 4096 envs x T = 20
+    after the bench's pre-roll -- in place (bind_step_sequence) and into trajectory buffers (the round-5 `sequence_traj` leg) --
+    against 20 calls of cn_step (cn_env_kernel_fair_s360): every step's observation / reward / done in the trajectory, the final
+    outputs, the whole state record, counters and returns.  Same seed, pedestrian cycle and open-loop action law as bench.py."""
+    import torch
+    from crowdnav import Config
+    from crowdnav.env import VecEnv
+    N, T, PRE = 4096, 20, 60
+    cfg = Config(n_envs=N, n_peds=20, n_rays=360, k_obstacles=8, max_steps=1000, seed=1234, ped_cycle_ms=1400)
+    ref, inplace, tr = VecEnv(cfg), VecEnv(cfg), VecEnv(cfg)
+    assert ref.kernel_name("sequence") == "cn_env_kernel_seq_s360" and ref.kernel_name("step") == "cn_env_kernel_fair_s360"
+    g = torch.Generator(device="cuda").manual_seed(1234)
+    acts = torch.stack([torch.rand((PRE + 2 * T, N), generator=g, device="cuda") * 0.22,
+                        torch.rand((PRE + 2 * T, N), generator=g, device="cuda") * 4.0 - 2.0], 2).contiguous()
+    for e in (ref, inplace, tr):
+        e.reset()
+        e.bind_step_sequence(acts[:PRE])()             # pre-roll: de-phased envs, live tracks, some finished episodes
+    torch.cuda.synchronize()
+    assert np.array_equal(ref.snapshot(), inplace.snapshot())
+    D = ref.D
+    traj = dict(obs=torch.zeros((T, N, D), device="cuda"), reward=torch.zeros((T, N), device="cuda"),
+                done=torch.zeros((T, N), dtype=torch.uint8, device="cuda"))
+    for rnd in range(2):                                # two consecutive 20-step launches, as consecutive bench samples are
+        a = acts[PRE + rnd * T:PRE + (rnd + 1) * T]
+        inplace.bind_step_sequence(a)()
+        tr.bind_step_sequence(a, traj=traj)()
+        n_done = 0
+        for t in range(T):
+            ref.step(a[t], auto_reset="next")
+            torch.cuda.synchronize()
+            assert torch.equal(traj["obs"][t], ref.obs) and torch.equal(traj["reward"][t], ref.reward), (rnd, t)
+            assert torch.equal(traj["done"][t], ref.done), (rnd, t)
+            n_done += int(ref.done.sum())
+        assert n_done > 0
+        assert torch.equal(inplace.obs, ref.obs) and torch.equal(inplace.reward, ref.reward) and torch.equal(inplace.done, ref.done)
+        assert torch.equal(inplace.topk_idx, ref.topk_idx)
+        for other in (inplace, tr):
+            assert np.array_equal(other.snapshot(), ref.snapshot())
+            assert torch.equal(other.counters(), ref.counters()) and torch.equal(other.returns()[0], ref.returns()[0])
+
+
 @pytest.mark.parametrize("risk_mode", [0, 1])
 def test_step_sequence_kernel_equals_step_by_step(oracle_mod, risk_mode):
     """cn_step_sequence -- T open-loop steps in ONE launch, every wavefront keeping its env and walking the T steps at its own
@@ -648,6 +690,85 @@ def test_policy_rollout_kernel_equals_act_then_step(oracle_mod, shape):
         VecEnv(Config(n_envs=16, ped_contact=1)).rollout_policy(a_ref, 2)
 
 
+ONE_LAUNCH_WORLDS = {
+    # name: (config keywords, cn_step_sequence kernel, cn_rollout_policy kernel, environments per policy workgroup)
+    "sf": (dict(n_peds=20, ped_mode=2), "cn_env_kernel_seq_sf", "cn_policy_kernel_sf"),
+    "gt_sf": (dict(n_peds=20, ped_mode=2, risk_mode=1), "cn_env_kernel_gt_seq_sf", "cn_policy_kernel_gt_sf"),
+    "sfd": (dict(n_peds=60, ped_mode=2, room_half=2.40), "cn_env_kernel_seq_sfd", "cn_policy_kernel_sfd"),
+    "gt_sfd": (dict(n_peds=60, ped_mode=2, room_half=2.40, risk_mode=1), "cn_env_kernel_gt_seq_sfd", "cn_policy_kernel_gt_sfd"),
+    "wa": (dict(n_peds=20, wheel_accel=1.0, scan_f32=1), "cn_env_kernel_seq_wa", "cn_policy_kernel_wa"),
+    "gt_wa": (dict(n_peds=20, wheel_accel=1.0, risk_mode=1), "cn_env_kernel_gt_seq_wa", "cn_policy_kernel_gt_wa"),
+    "s720": (dict(n_peds=100, n_rays=720, room_half=2.40), "cn_env_kernel_seq_s720", "cn_policy_kernel_s720"),
+}
+
+
+@pytest.mark.parametrize("world", sorted(ONE_LAUNCH_WORLDS))
+def test_one_launch_paths_of_the_other_simulators_equal_step_by_step(world):
+    """Round 5: cn_step_sequence and cn_rollout_policy exist for every simulator of obs_layout 0 but the contact
+    ticks -- social-force pedestrians (pair-matrix and dense kernels), the diff-drive plugin's wheel ramp, both risk modes -- and for
+    BASELINE configs[4]'s shape, whose 16 working sets do not fit one CU's LDS: there the policy kernel runs 8 environments per
+    workgroup.  Each leaves exactly what T calls of cn_step (resp. T pairs of cn_actor_forward, cn_step) leave: every period's
+    actions / observations / rewards / done flags / indices, the final state record, counters and returns, across two calls,
+    with an env count that is not a multiple of the workgroup size.  (The step-by-step kernels of these worlds are pinned
+    against the oracle by tests/test_gpu_parity.py.)"""
+    import torch
+    import crowdnav
+    from crowdnav import Config
+    from crowdnav.env import VecEnv
+    from crowdnav.td3 import Agent
+    kw, kseq, kpol = ONE_LAUNCH_WORLDS[world]
+    N, T = (76, 8) if world == "s720" else (148, 12)
+    cfg = Config(n_envs=N, max_steps=9, seed=61, ped_cycle_ms=1400, **kw)
+    ref, seq, ref2, pol = VecEnv(cfg), VecEnv(cfg), VecEnv(cfg), VecEnv(cfg)
+    assert seq.kernel_name("sequence") == kseq and pol.kernel_name("policy") == kpol
+    D, K = ref.D, ref.K
+    for e in (ref, seq, ref2, pol):
+        e.reset()
+    torch.cuda.synchronize()
+    # ---- cn_step_sequence (open loop) against T calls of cn_step
+    g = torch.Generator(device="cpu").manual_seed(3)
+    n_done = 0
+    for call in range(2):
+        acts = torch.stack([torch.rand((T, N), generator=g) * 0.22, torch.rand((T, N), generator=g) * 4 - 2], 2).cuda().contiguous()
+        traj = dict(obs=torch.zeros((T, N, D), device="cuda"), reward=torch.zeros((T, N), device="cuda"),
+                    done=torch.zeros((T, N), dtype=torch.uint8, device="cuda"), topk_idx=torch.zeros((T, N, K), dtype=torch.int32, device="cuda"))
+        seq.step_sequence(acts, traj=traj)
+        for t in range(T):
+            ref.step(acts[t].contiguous(), auto_reset="next")
+            torch.cuda.synchronize()
+            assert torch.equal(traj["obs"][t], ref.obs) and torch.equal(traj["reward"][t], ref.reward), (call, t)
+            assert torch.equal(traj["done"][t], ref.done) and torch.equal(traj["topk_idx"][t], ref.topk_idx), (call, t)
+            n_done += int(ref.done.sum())
+        assert np.array_equal(seq.snapshot(), ref.snapshot())
+        assert torch.equal(seq.counters(), ref.counters()) and torch.equal(seq.returns()[0], ref.returns()[0])
+    assert n_done > N // 2
+    # ---- cn_rollout_policy (the actor inside the step kernel) against T pairs of (cn_actor_forward, cn_step)
+    a_ref, a_pol = [Agent(obs_dim=cfg.obs_dim, device="cuda:0", seed=6, memory_size=16) for _ in range(2)]
+    a_ref.sync_fused_weights(); a_pol.sync_fused_weights()
+    act = torch.zeros((N, 2), device="cuda")
+    for call in range(2):
+        traj = dict(action=torch.zeros((T, N, 2), device="cuda"), obs=torch.zeros((T, N, D), device="cuda"),
+                    reward=torch.zeros((T, N), device="cuda"), done=torch.zeros((T, N), dtype=torch.uint8, device="cuda"),
+                    topk_idx=torch.zeros((T, N, K), dtype=torch.int32, device="cuda"))
+        pol.rollout_policy(a_pol, T, traj=traj)
+        for t in range(T):
+            a_ref.act_mfma(ref2.obs, out=act, add_noise=True)
+            torch.cuda.synchronize()
+            assert torch.equal(traj["action"][t], act), (call, t)
+            ref2.step(act, auto_reset="next")
+            torch.cuda.synchronize()
+            assert torch.equal(traj["obs"][t], ref2.obs) and torch.equal(traj["reward"][t], ref2.reward), (call, t)
+            assert torch.equal(traj["done"][t], ref2.done) and torch.equal(traj["topk_idx"][t], ref2.topk_idx), (call, t)
+        assert a_pol.noise_state() == a_ref.noise_state()
+        assert np.array_equal(pol.snapshot(), ref2.snapshot())
+        assert torch.equal(pol.counters(), ref2.counters()) and torch.equal(pol.returns()[0], ref2.returns()[0])
+    # what is still refused: the contact ticks and the other observation layouts
+    for bad in (dict(ped_contact=1), dict(obs_layout=1), dict(obs_layout=2, dt_ms=50)):
+        e = VecEnv(Config(n_envs=16, **bad))
+        with pytest.raises(crowdnav.CrowdNavError):
+            e.step_sequence(torch.zeros((2, 16, 2), device="cuda"))
+
+
 def test_collect_policy_fills_the_replay_like_the_per_step_loop():
     """crowdnav.rollout.collect_policy -- cn_rollout_policy launches of `periods` periods, one masked replay add per launch --
     leaves the replay ring, its device-side position / fill level and the env exactly where the per-step loop (act_mfma ->
@@ -763,7 +884,7 @@ def test_bench_under_the_launcher_runs_the_rccl_path_at_world_size_one():
         env.pop(k, None)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2",
-                        "--preroll", "20", "--repeats", "2", "--no-cpu-baseline", "--no-plateau", "--no-other-configs"],
+                        "--preroll", "20", "--repeats", "2", "--no-cpu-baseline", "--no-plateau", "--no-other-configs", "--sustained-seconds", "0.5"],
                        capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -776,6 +897,15 @@ def test_bench_under_the_launcher_runs_the_rccl_path_at_world_size_one():
     pr = out["config"]["per_rank"]
     assert [p_["rank"] for p_ in pr] == [0] and abs(pr[0]["value"] - out["value"]) <= 1e-6 * out["value"]
     assert out["roofline"]["kernel"].startswith("cn_env_kernel") and out["roofline"]["kernel"] == out["roofline"]["legs_kernels"][out["config"]["decomposition"]]
+    # round 5: the headline is a decomposition that can serve a policy (one cn_step launch per step) -- never a cn_step_sequence leg --
+    # the open-loop legs stay as comparables, flat scalar copies exist, and the sustained leg reports a rate and a shader clock
+    c = out["config"]
+    assert c["decomposition"] in ("4_groups", "2_groups", "1_groups") and "sequence" not in out["roofline"]["kernel"]
+    assert c["leg_sequence_env_steps_s"] > 0 and c["leg_sequence_traj_env_steps_s"] > 0 and c["leg_1_groups_env_steps_s"] > 0
+    assert c["leg_sequence_kernel"] == "cn_env_kernel_seq_s360"
+    assert c["sustained_env_steps_s"] > 0 and c["sustained_seconds"] >= 0.4 and 500 < c["sustained_clock_mhz"] < 4000
+    assert 0.5 < c["burst_over_sustained"] < 2.0
+    assert out["roofline"]["vector_peak_f64_tflops"] == 78.6 and out["roofline"]["frac_valu_f64"] > 0
 
 
 def test_td3_update_on_the_gpu_matches_reference_learn():

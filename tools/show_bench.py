@@ -17,6 +17,10 @@ for f in sys.argv[1:]:
     for k, v in (c.get("other_configs") or {}).items():
         print("  %s: %.2f M, ms/step %.4f, %s, frac %.4f, legs %s" % (k, v["value"] / 1e6, v["ms_per_step"], v["decomposition"], v["roofline"]["frac"],
                                                                   {a: M(b) for a, b in v["legs_env_steps_s"].items()}))
+    su = c.get("sustained")
+    if su:
+        print("  sustained %.2f M env-steps/s over %.2f s (%d launches), shader clock %.0f MHz (idle %.0f), burst/sustained %.3f" % (
+            su["env_steps_s"] / 1e6, su["seconds"], su["launches"], su["clock_mhz"], su["clock_mhz_idle"], c["burst_over_sustained"]))
     cb = j.get("cpu_baseline")
     if cb:
         print("  cpu_baseline %.0f env-steps/s on %d cores (one core %.0f); reference python %s" % (cb["value"], cb["cores"], cb["one_core_value"], cb["reference_python"]["value"]))
