@@ -150,6 +150,7 @@ def main():
                     help="largest decomposition tried: the rank's envs as this many independent stream groups")
     ap.add_argument("--sustained-seconds", type=float, default=6.0,
                     help="length of the sustained leg (headline decomposition back to back); 0 = skip")
+    ap.add_argument("--no-sequence-traj", action="store_true", help="skip the sequence_traj leg (profiling passes: one kind of launch per kernel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     a = ap.parse_args()
@@ -415,7 +416,7 @@ def main():
             #   legs pre-marshal their K steps into ONE cn_step_multi / cn_step_sequence call)
             # + cn_step_sequence: in place, and into trajectory buffers (every step's outputs in their own HBM slot)
             candidates = (list(candidates) + (["1_groups_oldest_first"] if 1 in candidates and lcfg.n_envs >= 2048 else [])
-                          + (["1_groups_python_enqueue"] if 1 in candidates else []) + ["sequence", "sequence_traj"])
+                          + (["1_groups_python_enqueue"] if 1 in candidates else []) + ["sequence"] + ([] if a.no_sequence_traj else ["sequence_traj"]))
         eligible = [G for G in candidates if isinstance(G, int) or G == "policy_sequence"]
         for G in candidates:
             lg = (Leg(lcfg, 1, lacts=lacts, sequence=True) if G == "sequence" else
@@ -668,6 +669,11 @@ def main():
         fc["leg_%s_env_steps_s" % leg_name(g)] = v["median"]
         fc["leg_%s_kernel" % leg_name(g)] = v["kernel"]
     fc["plateau_16384_envs_env_steps_s"] = plateau
+    for leg_, key_ in (("sequence", ""), ("sequence_traj", "+traj")):         # HBM bytes the counters saw per env-step of the open-loop legs
+        lk_ = main_m["legs"].get(leg_)
+        tk_ = (traffic_all or {}).get("kernels", {}).get(lk_["kernel"] + key_) if lk_ else None
+        if tk_:
+            fc["leg_%s_traffic_bytes_per_env_step" % leg_] = tk_["bytes_per_env_step"]
     for key, oc in (other or {}).items():
         k_ = key.replace("[", "").replace("]", "")
         fc["%s_env_steps_s" % k_] = oc["value"]

@@ -42,8 +42,11 @@ __device__ __forceinline__ void cn_setprio_uniform(int v)      // v: wave-unifor
     else if (v == 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(3);
 }
 // at stage stamp k (a literal; FAIR is a template parameter of the enclosing function): the four level changes of a FAIR kernel
+// (SFENCE, a constexpr of the enclosing function: the oldest-first 720-ray kernel gets a scheduling fence where its fair sibling has an
+//  s_setprio -- the only difference between the two bodies, and the sibling allocates with 13 scalar spills where this one had 66)
 #define CN_FAIR_AT(k) do { if constexpr (FAIR) { if ((k) == 0) __builtin_amdgcn_s_setprio(3); else if ((k) == 7) __builtin_amdgcn_s_setprio(2); \
-                           else if ((k) == 11) __builtin_amdgcn_s_setprio(1); else if ((k) == 15) __builtin_amdgcn_s_setprio(0); } } while (0)
+                           else if ((k) == 11) __builtin_amdgcn_s_setprio(1); else if ((k) == 15) __builtin_amdgcn_s_setprio(0); } \
+                           else if constexpr (SFENCE) { if ((k) == 0 || (k) == 7 || (k) == 11 || (k) == 15) __builtin_amdgcn_s_setprio(0); } } while (0)
 #ifdef CN_TIMING
 #define CN_ABLATE(bit) (p->ablate & (bit))   /* stage-skipping mask of tools/ablate.py: timing build only */
 /* bits 8..15 of the mask: stamp number + 1 at which every wavefront ENDS (tools/stage_instr.py: the PMC counters of a launch cut
@@ -1053,6 +1056,7 @@ template <bool EXT, bool GT = false, bool FAIR = false, bool CMP = false>
 __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const Lds& L, int env, int lane, int step_counter,
                         float* obs32, float* fin32, double* obs64, int* done_out, bool have_tg = false, Trig tg = Trig{0.0, 0.0, 0.0, 0.0})
 {
+    constexpr bool SFENCE = CMP && !FAIR;
     const int R = p->R, n = R - 1, K = p->K, D = n + 7 + 4 * K;
     const double MAXR = p->max_scan_range;
     const double px = e.rx, py = e.ry, yaw = e.ryaw, v = e.rv, w = e.rw, now = e.clock;
@@ -2261,6 +2265,7 @@ template <bool EXT, bool TWO, int LAYOUT, bool GT = false, int SIM = 0, bool FUS
 __device__ __forceinline__ void env_kernel_body(const int env, const int lane, char* const smem, const long long t = 0,
                                                 const float* const act_here = nullptr)
 {
+    constexpr bool SFENCE = SHAPE == 720 && !FAIR && !FUSED;
     KP p = (KP)__builtin_amdgcn_kernarg_segment_ptr();
     if constexpr (FUSED) {
         // Inside the multi-step kernel's step loop everything below is loop-invariant as far as the compiler can see, and it
@@ -2710,8 +2715,12 @@ __device__ __forceinline__ void env_kernel_body(const int env, const int lane, c
 // (Not in the profiling build: there the bound trips an LLVM "even aligned vector registers" assertion.)
 #ifdef CN_TIMING
 #define CN_HOT_BOUNDS __launch_bounds__(64)
+#define CN_S720_BOUNDS __launch_bounds__(64)
 #else
 #define CN_HOT_BOUNDS __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
+// the 720-ray shape: 13.2 KB of LDS per environment puts 12 wavefronts on a CU (3 per SIMD) whatever the register count, so the
+// allocator may use the 168 VGPRs that occupancy allows instead of squeezing into 128 (cn_env_kernel_s720: 66 -> SGPR spills below)
+#define CN_S720_BOUNDS __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
 #endif
 // Two translation units (csrc/build.sh): CN_TU 1 = every kernel except the sequence kernels, CN_TU 2 = the sequence kernels alone,
 // compiled with -mllvm -disable-machine-licm.  Their step loop wraps the whole step body; MachineLICM hoists every constant and
@@ -2722,8 +2731,8 @@ extern "C" __global__ void CN_HOT_BOUNDS cn_env_kernel(CnKParams p) { extern __s
 extern "C" __global__ void CN_HOT_BOUNDS cn_env_kernel_fair(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, false, 0, false, 0, false, true>(blockIdx.x, threadIdx.x, cn_smem); }
 extern "C" __global__ void CN_HOT_BOUNDS cn_env_kernel_s360(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, false, 0, false, 0, false, false, 360>(blockIdx.x, threadIdx.x, cn_smem); }
 extern "C" __global__ void CN_HOT_BOUNDS cn_env_kernel_fair_s360(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, false, 0, false, 0, false, true, 360>(blockIdx.x, threadIdx.x, cn_smem); }
-extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_s720(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, false, 0, false, 0, false, false, 720>(blockIdx.x, threadIdx.x, cn_smem); }
-extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_fair_s720(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, false, 0, false, 0, false, true, 720>(blockIdx.x, threadIdx.x, cn_smem); }
+extern "C" __global__ void CN_S720_BOUNDS cn_env_kernel_s720(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, false, 0, false, 0, false, false, 720>(blockIdx.x, threadIdx.x, cn_smem); }
+extern "C" __global__ void CN_S720_BOUNDS cn_env_kernel_fair_s720(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, false, 0, false, 0, false, true, 720>(blockIdx.x, threadIdx.x, cn_smem); }
 extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_same(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, true, 0>(blockIdx.x, threadIdx.x, cn_smem); }
 extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_ext(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<true, false, 0>(blockIdx.x, threadIdx.x, cn_smem); }
 #endif
@@ -2753,7 +2762,7 @@ __device__ __forceinline__ void sequence_body()
 #if !defined(CN_TU) || CN_TU == 2
 extern "C" __global__ void CN_HOT_BOUNDS cn_env_kernel_seq(CnKParams p) { sequence_body<false>(); }
 extern "C" __global__ void CN_HOT_BOUNDS cn_env_kernel_seq_s360(CnKParams p) { sequence_body<false, 360>(); }
-extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_seq_s720(CnKParams p) { sequence_body<false, 720>(); }
+extern "C" __global__ void CN_S720_BOUNDS cn_env_kernel_seq_s720(CnKParams p) { sequence_body<false, 720>(); }
 extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_gt_seq(CnKParams p) { sequence_body<true>(); }
 #endif
 #if !defined(CN_TU) || CN_TU == 3

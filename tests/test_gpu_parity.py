@@ -1045,9 +1045,12 @@ def test_error_codes_and_limits():
     small = Agent(obs_dim=382, device="cuda:0", seed=0, memory_size=16)
     with pytest.raises(crowdnav.CrowdNavError, match="observation width"):
         VecEnv(Config(n_envs=16)).rollout_policy(small, 1)
+    # (round 5: 720 rays x 100 pedestrians runs with 8 environments per workgroup; 1024 x 128 does not fit even so)
     big = VecEnv(Config(n_envs=16, n_rays=720, n_peds=100, room_half=2.4))
-    with pytest.raises(crowdnav.CrowdNavError, match="do not fit"):
-        big.rollout_policy(Agent(obs_dim=big.D, device="cuda:0", seed=0, memory_size=16), 1)
+    big.reset(); big.rollout_policy(Agent(obs_dim=big.D, device="cuda:0", seed=0, memory_size=16), 1)
+    huge = VecEnv(Config(n_envs=16, n_rays=1024, n_peds=128, room_half=3.0))
+    with pytest.raises(crowdnav.CrowdNavError, match="fit one CU's LDS"):
+        huge.rollout_policy(Agent(obs_dim=huge.D, device="cuda:0", seed=0, memory_size=16), 1)
     # 1024 rays x 128 pedestrians still fits (LDS sized per configuration)
     from crowdnav.env import VecEnv
     env = VecEnv(Config(n_envs=2, n_rays=1024, n_peds=128, room_half=3.0))

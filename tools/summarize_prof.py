@@ -49,7 +49,9 @@ def main(d):
     pol_steps = float(os.environ.get("CN_PROFILE_POL_STEPS", "100"))
     per_kernel = {}
     # pol_*: the same passes over tools/policy_perf.py --profile (every cn_policy_kernel launch there covers pol_steps periods)
-    for tag in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2", "pol_fetch", "pol_write", "pol_sq"):
+    traj_steps = float(os.environ.get("CN_PROFILE_TRAJ_STEPS", "50"))
+    # traj_*: tools/seq_traj_profile.py -- the sequence kernel writing every step into trajectory buffers; keyed "<kernel>+traj"
+    for tag in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2", "pol_fetch", "pol_write", "pol_sq", "traj_fetch", "traj_write"):
         f = find(os.path.join(d, tag), "*counter_collection.csv")
         if not f:
             print("== %s: no counter csv" % tag)
@@ -68,7 +70,11 @@ def main(d):
                 acc[k] = acc.get(k, 0.0) + v; cnt[k] = cnt.get(k, 0) + 1
             if not acc:
                 continue
-            steps = seq_steps if "_seq" in kname else pol_steps if kname.startswith("cn_policy_kernel") else 1.0
+            steps = traj_steps if tag.startswith("traj_") else seq_steps if "_seq" in kname else pol_steps if kname.startswith("cn_policy_kernel") else 1.0
+            if tag.startswith("traj_"):
+                if "_seq" not in kname:
+                    continue                     # (its reset launch)
+                kname = kname + "+traj"
             e = per_kernel.setdefault(kname, {"envs_per_launch": gmax // 64, "steps_per_launch": steps, "raw": {}})
             print("== %s (per %s dispatch of %d envs%s, mean of %s)" % (tag, kname, gmax // 64, " x %d steps" % steps if steps > 1 else "", sorted(set(cnt.values()))))
             for k in sorted(acc):
