@@ -411,7 +411,8 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
         // (whichever kernel choose_policy_kernel picks for this handle: the 720-ray shape's has the compact layout)
         h->pol_wave_lds = ((choose_policy_kernel(h).compact ? h->lds_shape : h->lds) + 15) & ~(size_t)15;
         const size_t tile = sizeof(float) * (16 * (size_t)(((k.R - 1 + 7 + 4 * k.K + 31) & ~31) + 1) + 16 * 257);
-        for (int pe = 16; pe >= 8 && !h->pol_lds && h->cfg.obs_layout == CN_LAYOUT_RISK; pe -= 8) {
+        const char* pe_env = getenv("CN_POL_ENVS");             // experiments: CN_POL_ENVS=8 forces the 8-environment workgroups
+        for (int pe = (pe_env && atoi(pe_env) == 8) ? 8 : 16; pe >= 8 && !h->pol_lds && h->cfg.obs_layout == CN_LAYOUT_RISK; pe -= 8) {
             size_t off = (size_t)pe * h->pol_wave_lds;
             if (off < tile) off = (tile + 15) & ~(size_t)15;
             const size_t tot = off + (size_t)pe * 2 * sizeof(float);

@@ -23,11 +23,19 @@ __device__ __forceinline__ double cn_round_scaled(double x, double p, cn_kflag p
     double y = x * p;
     double r = rint(y);
     double d = y - r;
-    if (__builtin_expect(fabs(d) == 0.5, 0)) {       // a decimal tie of the PRODUCT: rare; keep its block off the fall-through path
-        double err = fma(x, p, -y);
-        if (err > 0.0) r = y + 0.5;
-        else if (err < 0.0) r = y - 0.5;
-        else if (*py2) r = y + copysign(0.5, y);     // exact tie under Python 2.7: half away from zero
+    // A decimal tie of the PRODUCT is rare: the common path pays ONE compare and ONE scalar branch on "any lane has a tie" (the
+    // wave's vote) -- as a per-lane `if` it was a compare, an exec save, a branch and an exec restore at each of the ~40 roundings
+    // of a step (round 5: the instruction stream is what a step costs, whatever the class: tools/micro/issue_cost.hip).
+    const bool tie = fabs(d) == 0.5;
+    unsigned long long any_tie = __builtin_amdgcn_ballot_w64(tie);
+    asm("" : "+s"(any_tie));                          // (opaque: otherwise the compiler folds the vote back into a per-lane branch)
+    if (__builtin_expect(any_tie != 0ull, 0)) {
+        if (tie) {
+            double err = fma(x, p, -y);
+            if (err > 0.0) r = y + 0.5;
+            else if (err < 0.0) r = y - 0.5;
+            else if (*py2) r = y + copysign(0.5, y);     // exact tie under Python 2.7: half away from zero
+        }
     }
     return r;
 }

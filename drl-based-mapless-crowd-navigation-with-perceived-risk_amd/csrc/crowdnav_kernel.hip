@@ -146,7 +146,7 @@ __device__ __forceinline__ bool in_box(double x, double y, double gx, double gy,
 {
     // ENV:1285-1319 half-open box
     double xp = gx + eps, xm = gx - eps, yp = gy + eps, ym = gy - eps;
-    return (x <= xp) && (x > xm) && (y <= yp) && (y > ym);
+    return (x <= xp) & (x > xm) & (y <= yp) & (y > ym);        // (bitwise: four compares, no short-circuit branches)
 }
 
 // Ring (64-gon of radius r about (cx,cy), vertex k at angle -k*pi/32) against segment a->b.

@@ -2,7 +2,7 @@
 # The GPU-vs-oracle sweeps DESIGN.md quotes (every observation / reward / done flag / index / counter compared, zero
 # differences expected).  Writes gpurun_out/<tag>/parity_sweep.txt; copy it to profiles/<tag>/.
 #   tools/parity_sweep.sh r02 [scale]      scale multiplies every --steps (10 -> 36 M env-steps, ~10 min; output parity_sweep_x10.txt)
-TAG="${1:-r04}"; S="${2:-1}"; cd "$(dirname "$0")/.."; OUT="gpurun_out/$TAG"; mkdir -p "$OUT"
+TAG="${1:-r05}"; S="${2:-1}"; cd "$(dirname "$0")/.."; OUT="gpurun_out/$TAG"; mkdir -p "$OUT"
 R="python tools/parity_report.py --verbose 2"
 NAME=parity_sweep; [ "$S" != 1 ] && NAME="parity_sweep_x$S"
 {
@@ -38,4 +38,10 @@ $R --envs 256 --steps $((100 * S)) --ped-mode 2 --peds 100 --rays 720 --room 2.4
 $R --envs 4096 --steps $((100 * S)) --max-steps 60 --reset-mode next --policy 20
 $R --envs 1000 --steps $((200 * S)) --peds 14 --k 4 --rays 300 --reset-mode next --policy 25
 $R --envs 1024 --steps $((200 * S)) --risk-mode 1 --reset-mode next --policy 40
+# round 5: the compact 720-ray layout (3 waves per SIMD) under the next-step reset; cn_rollout_policy for the 720-ray shape (8 environments
+# per workgroup), for social-force pedestrians and for the "as Gazebo delivers it" world (float32 scans + wheel ramp)
+$R --envs 1024 --steps $((120 * S)) --peds 100 --rays 720 --room 2.4 --reset-mode next --max-steps 60
+$R --envs 520 --steps $((100 * S)) --peds 100 --rays 720 --room 2.4 --reset-mode next --max-steps 60 --policy 10
+$R --envs 1024 --steps $((200 * S)) --ped-mode 2 --reset-mode next --policy 20
+$R --envs 1000 --steps $((200 * S)) --scan-f32 1 --wheel-accel 1.0 --waypoint-reward 0 --reset-mode next --policy 25
 } 2>&1 | grep -v amdgpu.ids | tee "$OUT/$NAME.txt"

@@ -4,6 +4,9 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "drl-based-mapless-crowd-navigation-with-perceived-risk_amd"))
 import torch
+from crowdnav import _abi
+if os.environ.get("CN_LIB"):
+    _abi.LIB_PATH = os.path.abspath(os.environ["CN_LIB"]); _abi.build = lambda force=False: _abi.LIB_PATH
 from crowdnav import Config
 from crowdnav.env import VecEnv
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096

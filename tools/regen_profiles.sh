@@ -1,7 +1,7 @@
 #!/bin/bash
 # Everything under profiles/<tag>/ except the rocprofv3 passes (tools/profile.sh) and the parity sweep (tools/parity_sweep.sh),
 # in one go on the GPU box:  tools/regen_profiles.sh r02   -> gpurun_out/<tag>/*; copy what should be judged into profiles/<tag>/.
-TAG="${1:-r04}"; cd "$(dirname "$0")/.."; OUT="gpurun_out/$TAG"; mkdir -p "$OUT"
+TAG="${1:-r05}"; cd "$(dirname "$0")/.."; OUT="gpurun_out/$TAG"; mkdir -p "$OUT"
 F='amdgpu.ids'
 python bench.py 2>/dev/null | tail -1 > "$OUT/bench_n1.json"
 python bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > "$OUT/bench_n1_driver_command.json"
