@@ -158,6 +158,19 @@ static void build_assoc_table(CnKParams& k, int16_t* tab)
     k.assoc_k1 = K1; k.assoc_fast = 1;
 }
 
+// regions A + B of the carve below: the simulators' scratch (idle while the world advances)
+static size_t lds_scratch_bytes(int R, int P, int K, int max_conf, int trk_cap, bool near_separate)
+{
+    size_t n = (size_t)(R - 1), mc = (size_t)max_conf;
+    size_t szA_pts = (10 * n + 7) & ~(size_t)7, szA_trk = 8 * (size_t)(CN_TF_COUNT * trk_cap);
+    size_t szA = szA_pts > szA_trk ? szA_pts : szA_trk;
+    size_t szB_g = (6 * n + 7) & ~(size_t)7;
+    size_t szB_c = 32 * mc + 8 * 64 + 8 * (size_t)(8 + 4 * K) + 4 * (size_t)CN_MAX_K;
+    size_t szB = szB_g > szB_c ? szB_g : szB_c;
+    if (szB < 8 * 64) szB = 8 * 64;
+    if (!near_separate && szB < 32 * (size_t)(P + 1)) szB = 32 * (size_t)(P + 1);
+    return szA + szB;
+}
 static size_t lds_bytes_impl(int R, int P, int K, int max_conf, int trk_cap, bool near_separate, int layout = 0, bool compact = false)
 {
     // must mirror the carve in cn_env_kernel (compact: the 720-ray shape kernels' layout -- int16 end points, 12-byte confirmed
@@ -304,6 +317,9 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
                             !(c.sf_wall_B > 0.0) || !(c.sf_goal_eps >= 0.0) || c.sf_tick_ms < 0 || 64 * (size_t)c.n_peds > 16 * (size_t)(c.n_rays - 1)))
         return fail(CN_ERR_CONFIG, "cn_create: ped_mode 2 (social force) needs obs_layout 0, ped_contact 0, positive sf_tau / sf_B / "
                                    "sf_wall_B and n_peds <= (n_rays - 1) / 4");
+    // the pedestrians' repulsion is summed on a 2^-36 grid (include/crowdnav.h): exact while the sum stays below 2^16
+    if (c.ped_mode == 2 && !((double)c.n_peds * fabs(c.sf_A) * exp(2.0 * c.ped_radius / c.sf_B) < 32768.0))
+        return fail(CN_ERR_CONFIG, "cn_create: ped_mode 2: n_peds * sf_A * exp(2 ped_radius / sf_B) must stay below 2^15 (exact force sums)");
     if (!(c.max_scan_range > c.min_scan_range))    // ENV:581, UTL:322 divide by their difference (ZeroDivisionError in the reference)
         return fail(CN_ERR_CONFIG, "cn_create: max_scan_range must exceed min_scan_range");
     if (c.obs_layout == CN_LAYOUT_REALWORLD && (c.n_rays - 1 > 65535 / 2))
@@ -372,6 +388,13 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
     k.sf_tau = c.sf_tau; k.sf_A = c.sf_A; k.sf_B = c.sf_B; k.sf_wall_A = c.sf_wall_A; k.sf_wall_B = c.sf_wall_B;
     k.sf_goal_eps2 = c.sf_goal_eps * c.sf_goal_eps; k.sf_tick_ms = c.sf_tick_ms > 0 ? c.sf_tick_ms : 10;
     // pair matrix G [P][P] + next state + goal records in the simulator's LDS scratch (regions A + B, 16 (R - 1) bytes)?
+    {   // dense social force: the near-pair list behind next / aux [8 P] and acc [2 P] doubles of the scratch
+        const size_t scr = lds_scratch_bytes(R, P, K, h->max_conf, h->trk_cap, cn_near_separate(R, P, K, h->max_conf, h->trk_cap) != 0);
+        const size_t used = 80 * (size_t)P;
+        size_t cap = scr > used ? (scr - used) / 2 : 0;
+        k.sf_pair_cap = (c.ped_mode == 2 && P <= 128) ? (int32_t)(cap > 60000 ? 60000 : cap) : 0;
+        k.sf_reserved = 0;
+    }
     k.sf_pair_matrix = (c.ped_mode == 2 && P >= 2 && P < 256 && 8 * (size_t)P * P + 64 * (size_t)P + (size_t)P * (P - 1) + 16 <= 16 * (size_t)(R - 1)) ? 1 : 0;
     k.near_sep = cn_near_separate(R, P, K, h->max_conf, h->trk_cap);
     // the kernels compiled for the headline shape assume exactly these six values (crowdnav_kernel.hip, SHAPE == 360)

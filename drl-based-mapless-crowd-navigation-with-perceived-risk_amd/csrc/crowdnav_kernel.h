@@ -17,6 +17,7 @@ struct CnKParams {
     int32_t ext_phase;       // cn_external_io.phase (CN_PHASE_* mask, 0 = whole flow); CN_MODE_EXT_STEP only
     int32_t geos_untyped_empty, ped_contact, risk_mode, py2_round;   // cn_config switches
     int32_t sf_tick_ms, sf_pair_matrix;   // ped_mode 2: physics tick; 1 = the pair matrix fits in the simulator's LDS scratch
+    int32_t sf_pair_cap, sf_reserved;     // dense social force: near pairs (2 bytes each) that fit in the scratch behind next / aux / acc (0: none)
     int32_t lidar_min_positive;           // lidar_min > 0: the simulated sensor never returns a range of exactly 0 (UTL:382's test is then dead)
     int32_t scan_f32, waypoint_reward;    // cn_config: float32 LaserScan.ranges; ENV:1116's way-point reward (200, or 0 = as logged)
     int64_t env_index_base;

@@ -514,6 +514,15 @@ __device__ __forceinline__ void sim_advance_contact(KP p, EnvRegs& e, int env, i
 // cn_create found room for the pair matrix) (regions A + B are idle while the simulator
 // runs): next state [4 P] and this call's copy of the goal records + desired speeds [4 P] (goal x, y, counter, v0), so that the
 // 16 ticks of a step pay no global-memory round trip and no RNG evaluation.
+// A pedestrian-pedestrian force component enters the sum on a grid of 2^-36 m/s^2: every partial sum of such values is exact
+// (cn_create bounds P A e^{2r/B} below 2^15), so the total is independent of the ORDER of the additions (round 5; the oracle's
+// sf_quant).  That is what allows one evaluation per unordered pair with +- scattered by LDS atomics below.
+__device__ __forceinline__ double cn_sf_quant(double v) { return rint(v * 68719476736.0) * (1.0 / 68719476736.0); }
+__device__ __forceinline__ void cn_lds_add_f64(double* lds_ptr, double v)     // ds_add_f64: exact here, so the arrival order is immaterial
+{
+    const unsigned a = (unsigned)(size_t)(__attribute__((address_space(3))) double*)lds_ptr;
+    asm volatile("ds_add_f64 %0, %1" :: "v"(a), "v"(v) : "memory");
+}
 template <bool DENSE>      // DENSE (SIM 4): the per-lane near masks below, for crowds of up to 128 whose pair matrix does not fit in LDS
 __device__ __forceinline__ void sim_advance_sf(KP p, EnvRegs& e, int env, int lane, double* ped_p, double* ped_v, double* scr, int ms)
 {
@@ -526,20 +535,27 @@ __device__ __forceinline__ void sim_advance_sf(KP p, EnvRegs& e, int env, int la
     double* const gaux = p->ped_aux + (size_t)env * 3 * P;
     double* const nxt = scr;
     double* const aux = scr + 4 * P;
-    // Small crowds (the pair matrix fits in the scratch: P <= 22 at 360 rays): the pair term g_ij = A e^{(2r - d)/B} / d is
-    // symmetric in (i, j) bit for bit (d^2 is built from squares of the same differences), so each unordered pair is evaluated
-    // ONCE, lane = pair over all 64 lanes (P (P - 1) / 2 = 190 pairs = 3 passes at P = 20 instead of 20 loop iterations with 20
-    // active lanes), into G [P][P]; the per-pedestrian sum then only reads g and applies it in the oracle's order.
+    // Small crowds (cn_create: sf_pair_matrix, P <= 22 at 360 rays): ALL P (P - 1) / 2 unordered pairs, lane = pair over all 64 lanes
+    // (190 pairs = 3 passes at P = 20), each evaluated ONCE and scattered +- into acc by LDS atomics -- exact sums, see cn_sf_quant.
+    // The static list is in round-robin order -- (i, i + k mod P) for k = 1 .. P / 2 -- so that the 64 pairs of a pass touch every
+    // pedestrian at most a handful of times (in (i, j) order nineteen consecutive lanes would add to the same address).
     const bool pairm = !DENSE && p->sf_pair_matrix != 0;
-    double* const G = scr + 8 * P;
-    unsigned short* const plist = (unsigned short*)(G + P * P);      // pair t -> (i << 8) | j, i < j, row-major
+    // DENSE, round 5: one evaluation per unordered near pair.  acc [2 P]: the pedestrians' summed repulsion (LDS atomics, exact);
+    // nlist: the near pairs (i << 8) | j, i < j, compacted -- sf_pair_cap of them fit behind acc (0: no room, the per-lane walk runs)
+    double* const acc = scr + 8 * P;
+    unsigned short* const nlist = (unsigned short*)(acc + 2 * P);
+    const int pcap = DENSE ? p->sf_pair_cap : 0;
+    unsigned short* const plist = nlist;                             // pair t -> (i << 8) | j, round-robin order
     const int npairs = (P * (P - 1)) >> 1;
     for (int i = lane; i < P; i += 64) {
         aux[4 * i] = gaux[3 * i]; aux[4 * i + 1] = gaux[3 * i + 1]; aux[4 * i + 2] = gaux[3 * i + 2];
         aux[4 * i + 3] = p->ped_vmax * fma(0.5, cn_rng_u01(p->seed, gid, 4u, (uint32_t)i, 0u), 0.5);     // desired speed v0
-        if (pairm) {
-            const int base = (i * (2 * P - i - 1)) >> 1;
-            for (int j = i + 1; j < P; ++j) plist[base + (j - i - 1)] = (unsigned short)((i << 8) | j);
+        if (pairm) {      // round k = 1 .. P / 2 holds the pairs (i, (i + k) mod P): P of them, or P / 2 in the last round of an even P
+            for (int k = 1; 2 * k <= P; ++k) {
+                if (2 * k == P && i >= k) break;
+                const int j = (i + k) % P;
+                plist[(k - 1) * P + i] = (unsigned short)((i << 8) | j);
+            }
         }
     }
     CN_SYNC();
@@ -549,21 +565,92 @@ __device__ __forceinline__ void sim_advance_sf(KP p, EnvRegs& e, int env, int la
         const double hs = cn_div1000((double)h);
         robot_advance(p, e, h);
         if (pairm) {
+            for (int i = lane; i < 2 * P; i += 64) acc[i] = 0.0;
+            CN_SYNC();
             for (int t0 = 0; t0 < npairs; t0 += 64) {
                 const int t = t0 + lane;
                 if (t < npairs) {
                     const int ij = plist[t], i = ij >> 8, j = ij & 255;
                     const double ddx = ped_p[2 * i] - ped_p[2 * j], ddy = ped_p[2 * i + 1] - ped_p[2 * j + 1];
                     const double d2 = fma(ddx, ddx, ddy * ddy);
-                    double g = CN_NAN;
                     if (d2 > 0.0 && !(d2 > cut2)) {
                         const double d = sqrt(d2), arg = (2.0 * r - d) / B;
-                        if (!(arg < -12.0)) g = (A * cn_det_exp(arg)) * (1.0 / d);
+                        if (!(arg < -12.0)) {
+                            const double f = (A * cn_det_exp(arg)) * (1.0 / d);
+                            const double cx = cn_sf_quant(f * ddx), cy = cn_sf_quant(f * ddy);
+                            cn_lds_add_f64(acc + 2 * i, cx); cn_lds_add_f64(acc + 2 * i + 1, cy);
+                            cn_lds_add_f64(acc + 2 * j, -cx); cn_lds_add_f64(acc + 2 * j + 1, -cy);
+                        }
                     }
-                    G[i * P + j] = g; G[j * P + i] = g;
                 }
             }
             CN_SYNC();
+        }
+        bool use_pairs = false;
+        if constexpr (DENSE) {
+            if (pcap > 0) {
+                // (1) each lane marks, for its pedestrian of either pass (i = lane, lane + 64), the near pedestrians ABOVE it: broadcast
+                //     reads, a dozen instructions per j; (2) the pairs are counted -- if they fit, (3) compacted into nlist in (i, j)
+                //     order and (4) evaluated lane = pair, 64 at a time: the expensive part (sqrt, two divides, the exponential) runs
+                //     ceil(near pairs / 64) times per tick instead of (busiest lane's neighbour count) x 2 passes, every pair once.
+                u64 mk[2][2] = {{0ull, 0ull}, {0ull, 0ull}};
+                int cnt[2] = {0, 0};
+#pragma unroll
+                for (int ps = 0; ps < 2; ++ps) {
+                    const int i = 64 * ps + lane;
+                    if (64 * ps < P) {
+                        const bool act_ = i < P;
+                        const double xi_ = act_ ? ped_p[2 * i] : 0.0, yi_ = act_ ? ped_p[2 * i + 1] : 0.0;
+                        for (int j = 64 * ps + 1; j < P; ++j) {
+                            const double ddx = xi_ - ped_p[2 * j], ddy = yi_ - ped_p[2 * j + 1];
+                            const double d2 = fma(ddx, ddx, ddy * ddy);
+                            const u64 nr = (act_ && j > i && d2 > 0.0 && !(d2 > cut2)) ? 1ull : 0ull;
+                            if (j < 64) mk[ps][0] |= nr << j; else mk[ps][1] |= nr << (j - 64);
+                        }
+                        cnt[ps] = __popcll(mk[ps][0]) + __popcll(mk[ps][1]);
+                    }
+                }
+                const int tot0 = cn_wave_sum_i(cnt[0]), tot1 = cn_wave_sum_i(cnt[1]);
+                const int npairs_ = tot0 + tot1;
+                use_pairs = npairs_ <= pcap;
+                if (use_pairs) {
+                    for (int i = lane; i < 2 * P; i += 64) acc[i] = 0.0;
+#pragma unroll
+                    for (int ps = 0; ps < 2; ++ps) {
+                        int incl = cnt[ps];                       // inclusive prefix sum over the lanes
+#pragma unroll
+                        for (int d_ = 1; d_ < 64; d_ <<= 1) { const int o_ = __shfl_up(incl, d_, 64); if (lane >= d_) incl += o_; }
+                        int k = (ps ? tot0 : 0) + incl - cnt[ps];
+                        u64 a0 = mk[ps][0], a1 = mk[ps][1];
+                        const int i = 64 * ps + lane;
+                        while (a0 | a1) {
+                            int j;
+                            if (a0) { j = __builtin_ctzll(a0); a0 &= a0 - 1ull; } else { j = 64 + __builtin_ctzll(a1); a1 &= a1 - 1ull; }
+                            nlist[k++] = (unsigned short)((i << 8) | j);
+                        }
+                    }
+                    CN_SYNC();
+                    // lane l takes the pairs l * passes + q, q = 0 .. passes - 1: consecutive lanes are `passes` entries apart in the
+                    // (i, j)-ordered list, i.e. mostly on different pedestrians i (side by side they would queue on one LDS address)
+                    const int passes = (npairs_ + 63) >> 6;
+                    for (int q = 0; q < passes; ++q) {
+                        const int t = lane * passes + q;
+                        if (t < npairs_) {
+                            const int ij = nlist[t], i = ij >> 8, j = ij & 255;
+                            const double ddx = ped_p[2 * i] - ped_p[2 * j], ddy = ped_p[2 * i + 1] - ped_p[2 * j + 1];
+                            const double d2 = fma(ddx, ddx, ddy * ddy);
+                            const double d = sqrt(d2), arg = (2.0 * r - d) / B;
+                            if (!(arg < -12.0)) {
+                                const double f = (A * cn_det_exp(arg)) * (1.0 / d);
+                                const double cx = cn_sf_quant(f * ddx), cy = cn_sf_quant(f * ddy);
+                                cn_lds_add_f64(acc + 2 * i, cx); cn_lds_add_f64(acc + 2 * i + 1, cy);
+                                cn_lds_add_f64(acc + 2 * j, -cx); cn_lds_add_f64(acc + 2 * j + 1, -cy);
+                            }
+                        }
+                    }
+                    CN_SYNC();
+                }
+            }
         }
         for (int i0 = 0; i0 < P; i0 += 64) {
             const int i = i0 + lane;
@@ -585,12 +672,9 @@ __device__ __forceinline__ void sim_advance_sf(KP p, EnvRegs& e, int env, int la
             double ex = 0.0, ey = 0.0;
             if (gd2 > 0.0) { const double ginv = 1.0 / sqrt(gd2); ex = gdx * ginv; ey = gdy * ginv; }
             double ax = (v0 * ex - vxi) / tau, ay = (v0 * ey - vyi) / tau;
-            if (pairm) {
-                for (int j = 0; j < P; ++j) {
-                    const double g = act ? G[i * P + j] : CN_NAN;
-                    const double ddx = xi - ped_p[2 * j], ddy = yi - ped_p[2 * j + 1];
-                    if (j != i && g == g) { ax = fma(g, ddx, ax); ay = fma(g, ddy, ay); }     // NaN = no contribution (skipped pair)
-                }
+            double sx = 0.0, sy = 0.0;                     // the other pedestrians' repulsion: an exact sum of cn_sf_quant()ed components
+            if (pairm || (DENSE && use_pairs)) {
+                if (act) { sx = acc[2 * i]; sy = acc[2 * i + 1]; }
             } else if constexpr (DENSE) {
                 // Dense crowds (no room for the pair matrix): the expensive part of a pair term -- sqrt, two divides, the exponential,
                 // ~80 float64 instructions -- is only owed for pedestrians within the cut-off, a quarter of a 100-pedestrian room.
@@ -614,7 +698,7 @@ __device__ __forceinline__ void sim_advance_sf(KP p, EnvRegs& e, int env, int la
                         const double d = sqrt(d2), arg = (2.0 * r - d) / B;
                         if (!(arg < -12.0)) {
                             const double f = (A * cn_det_exp(arg)) * (1.0 / d);
-                            ax = fma(f, ddx, ax); ay = fma(f, ddy, ay);
+                            sx += cn_sf_quant(f * ddx); sy += cn_sf_quant(f * ddy);
                         }
                     }
                 }
@@ -626,11 +710,12 @@ __device__ __forceinline__ void sim_advance_sf(KP p, EnvRegs& e, int env, int la
                     const double d = sqrt(d2), arg = (2.0 * r - d) / B;
                     if (!(arg < -12.0)) {
                         const double f = (A * cn_det_exp(arg)) * (1.0 / d);
-                        ax = fma(f, ddx, ax); ay = fma(f, ddy, ay);
+                        sx += cn_sf_quant(f * ddx); sy += cn_sf_quant(f * ddy);
                     }
                 }
             }
             }
+            ax = ax + sx; ay = ay + sy;
             if (act) {
                 {   // walls: distance from the centre to the wall plane, pushing inwards
                     double arg = (r - (xi + H)) / Bw;

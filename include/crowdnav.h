@@ -119,7 +119,11 @@ typedef struct cn_config {
     double goal_eps;         /* ENV:1285,1303 -> 0.20 */
     /* ped_mode 2 (social force).  Per pedestrian i: desired speed v0_i = ped_vmax (0.5 + 0.5 u_i), a goal point drawn uniformly
      * in the room (re-drawn when within sf_goal_eps of it), and per 10 ms tick
-     *   a = (v0 e_goal - v) / sf_tau + sum_j sf_A exp((2 r - d_ij) / sf_B) n_ij          (other pedestrians, index order)
+     *   a = (v0 e_goal - v) / sf_tau + sum_j q(sf_A exp((2 r - d_ij) / sf_B) n_ij)       (other pedestrians; q rounds each component to
+     *                                                                                    the nearest multiple of 2^-36 m/s^2, which makes
+     *                                                                                    the sum exact and independent of its order -- the
+     *                                                                                    kernels evaluate every unordered pair once and
+     *                                                                                    scatter +-; needs n_peds sf_A e^(2r/sf_B) < 2^15)
      *     + sum_walls sf_wall_A exp((r - d_w) / sf_wall_B) n_w                            (-x, +x, -y, +y)
      *     + sf_A exp((r + robot_clearance - d_ir) / sf_B) n_ir                            (the robot)
      *   v <- v + a h, |v| capped at 1.3 v0;  x <- clamp(x + v h) into the room   (semi-implicit Euler, h = sf_tick_ms) */

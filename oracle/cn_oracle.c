@@ -428,6 +428,11 @@ static double sf_desired_speed(const cno_config* c, int64_t gid, int i)
  * the room).  Contributions whose exponent is below -12 are dropped (6e-6 of the strength).  A goal within sf_goal_eps at a
  * tick start is replaced by the next one of the pedestrian's sequence.  No reference source (CROWD:98-126 is a random-velocity
  * walker): pinned by the analytic cases of tests/test_simulator_known_answers.py. */
+/* A pedestrian-pedestrian force component enters the sum on a grid of 2^-36 m/s^2 (1.5e-11): every partial sum of such values is
+ * exactly representable (cn_create / cno_create bound P A e^{2r/B} below 2^15), so the total does not depend on the order of the
+ * additions -- which is what lets the kernels evaluate each unordered pair ONCE and scatter +- its contribution (round 5). */
+static double sf_quant(double v) { return rint(v * 68719476736.0) * (1.0 / 68719476736.0); }
+
 static void sim_advance_sf(const cno_sim* s, env_t* e, int64_t gid, int64_t ms)
 {
     const cno_config* c = &s->cfg;
@@ -456,6 +461,7 @@ static void sim_advance_sf(const cno_sim* s, env_t* e, int64_t gid, int64_t ms)
             double ex = 0.0, ey = 0.0;
             if (gd2 > 0.0) { const double ginv = 1.0 / sqrt(gd2); ex = gdx * ginv; ey = gdy * ginv; }
             double ax = (v0 * ex - vxi) / tau, ay = (v0 * ey - vyi) / tau;
+            double sx = 0.0, sy = 0.0;                           /* the pedestrians' repulsion: an exact sum (sf_quant) */
             for (int j = 0; j < P; ++j) {
                 if (j == i) continue;
                 const double ddx = xi - e->ped_p[2 * j], ddy = yi - e->ped_p[2 * j + 1];
@@ -464,8 +470,9 @@ static void sim_advance_sf(const cno_sim* s, env_t* e, int64_t gid, int64_t ms)
                 const double d = sqrt(d2), arg = (2.0 * r - d) / B;
                 if (arg < -12.0) continue;
                 const double f = (A * cno_det_exp(arg)) * (1.0 / d);
-                ax = fma(f, ddx, ax); ay = fma(f, ddy, ay);
+                sx += sf_quant(f * ddx); sy += sf_quant(f * ddy);
             }
+            ax = ax + sx; ay = ay + sy;
             {   /* walls: distance from the centre to the wall plane, pushing inwards */
                 double arg = (r - (xi + H)) / Bw;
                 if (!(arg < -12.0)) ax = ax + Aw * cno_det_exp(arg);
@@ -1737,6 +1744,7 @@ int cno_create(const cno_config* cfg, cno_sim** out)
     if (cfg->ped_cycle_ms < 1 || cfg->dt_ms < 1) return -2;
     if (cfg->ped_mode < 0 || cfg->ped_mode > 2) return -2;
     if (cfg->ped_mode == 2 && (cfg->ped_contact || !(cfg->sf_tau > 0.0) || !(cfg->sf_B > 0.0) || !(cfg->sf_wall_B > 0.0) || cfg->sf_tick_ms < 0)) return -2;
+    if (cfg->ped_mode == 2 && !((double)cfg->n_peds * fabs(cfg->sf_A) * exp(2.0 * cfg->ped_radius / cfg->sf_B) < 32768.0)) return -2;   /* sf_quant: exact sums */
     if (!(cfg->wheel_accel >= 0.0) || (cfg->wheel_accel > 0.0 && (cfg->ped_contact || cfg->ped_mode == 2 || cfg->obs_layout != 0 ||
                                                                     !(cfg->wheel_separation > 0.0)))) return -2;
     if (cfg->scan_f32 < 0 || cfg->scan_f32 > 1) return -2;

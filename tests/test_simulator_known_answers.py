@@ -287,13 +287,14 @@ def test_social_force_tick_is_part_of_the_model(oracle_mod):
 
 def test_social_force_pair_repulsion_is_antisymmetric_and_has_the_stated_strength(oracle_mod):
     """Two pedestrians 0.2 m apart, goals straight ahead in +y: after one tick from rest the x-velocities are exactly opposite and
-    equal h A exp((2 r - d) / B); they drift apart until the force has faded, never crossing."""
+    equal h A exp((2 r - d) / B) -- to the model's force grid of 2^-36 m/s^2 (round 5: pair components are summed exactly on
+    that grid, so the sum has no order); they drift apart until the force has faded, never crossing."""
     o, v0 = _sf_world(oracle_mod, [[-0.1, 0.0], [0.1, 0.0]], [[-0.1, 5.0], [0.1, 5.0]])
     c = o.cfg
     o.hsim_advance(10, 0.0, 0.0)
     _, pp, pv, _ = o.sim_state()
     f = c.sf_A * math.exp((2 * c.ped_radius - 0.2) / c.sf_B)
-    assert pv[0, 0] == -pv[1, 0] and abs(pv[1, 0] - f * 0.01) < 1e-15
+    assert pv[0, 0] == -pv[1, 0] and abs(pv[1, 0] - f * 0.01) <= 0.5 * 2.0 ** -36 * 0.01 + 1e-15
     assert np.allclose(pv[:, 1], v0 * 0.01 / c.sf_tau, rtol=0, atol=1e-15)      # the goal term alone drives y
     gaps = []
     for _ in range(100):
