@@ -353,18 +353,20 @@ def main():
                 call = e0.bind_step_sequence(acts_)
             else:
                 call = grp.bind_step_sequence([self.lacts[i % N_ACT] for i in range(S)], auto_reset=self.mode)
-            # the shader clock of an idle chip, for comparison: the two counters around a host-side pause
+            # the shader clock of an otherwise idle chip, for comparison (the probe wave alone, 2 ms)
             for s_ in grp.streams:
                 s_.synchronize()
-            ci0 = e0.device_clock(); torch.cuda.synchronize(dev); time.sleep(0.25); ci1 = e0.device_clock(); torch.cuda.synchronize(dev)
+            side = torch.cuda.Stream(device=dev)
+            time.sleep(0.25)
+            ci = e0.device_clock(2000, stream=side); torch.cuda.synchronize(dev)
             call(); self.run(warm_tail)
             m0 = self._reset_launch_marker()
             for s_ in grp.streams:
                 s_.synchronize()
             torch.cuda.synchronize(dev)
-            c0 = e0.device_clock()
             t0 = time.perf_counter()
-            evs = []
+            evs, probes = [], []
+            n_probes = min(8, max(1, int(seconds / 1.5)))
             n_calls = 0
             while True:                                    # the host stays at most two calls (~40 ms) ahead of the device, so its clock
                 call()                                     # follows the device's: stop once `seconds` have passed
@@ -372,9 +374,12 @@ def main():
                 n_calls += 1
                 if n_calls >= 3:
                     evs[n_calls - 3].synchronize()
-                    if time.perf_counter() - t0 >= seconds:
+                    el = time.perf_counter() - t0
+                    # clock probes on a side stream while the env launches keep coming: one every ~1.5 s, 5 ms each
+                    if len(probes) < n_probes and el >= seconds * (len(probes) + 0.5) / n_probes:
+                        probes.append(e0.device_clock(5000, stream=side))
+                    if el >= seconds:
                         break
-            c1 = e0.device_clock()
             bracket(grp.streams)
             wall = time.perf_counter() - t0
             taken = n_calls * per_call
@@ -382,12 +387,14 @@ def main():
                 m1 = self._reset_launch_marker()
                 torch.cuda.synchronize(dev)
                 taken -= int(sum(x.item() for x in m1) - sum(x.item() for x in m0))
-            c0, c1, ci0, ci1 = [x.cpu().tolist() for x in (c0, c1, ci0, ci1)]
+            torch.cuda.synchronize(dev)
 
-            def mhz(a_, b_):      # shader-clock cycles per microsecond of the 100 MHz counter
-                return (b_[0] - a_[0]) / max(1.0, (b_[1] - a_[1]) / 100.0)
+            def mhz(x_):          # shader-clock cycles per microsecond of the 100 MHz counter, inside one probe wave
+                x_ = x_.cpu().tolist()
+                return x_[0] / max(1.0, x_[1] / 100.0)
+            pm = [mhz(x_) for x_ in probes]
             return {"env_steps_s": taken / wall, "seconds": wall, "env_steps": taken, "launches": n_calls * S * self.G,
-                    "device_seconds": (c1[1] - c0[1]) / 1e8, "clock_mhz": mhz(c0, c1), "clock_mhz_idle": mhz(ci0, ci1)}
+                    "clock_mhz": (sum(pm) / len(pm)) if pm else None, "clock_mhz_probes": pm, "clock_mhz_idle": mhz(ci)}
 
         def close(self):
             self.grp.close()
@@ -470,7 +477,7 @@ def main():
         sustained = lg.sustained(a.sustained_seconds)
         lg.close()
         if use_dist:
-            t_ = torch.tensor([sustained["env_steps_s"], sustained["seconds"], sustained["clock_mhz"]], dtype=torch.float64, device=cdev)
+            t_ = torch.tensor([sustained["env_steps_s"], sustained["seconds"], sustained["clock_mhz"] or 0.0], dtype=torch.float64, device=cdev)
             sm_ = t_.clone(); dist.all_reduce(sm_, op=dist.ReduceOp.SUM)
             mx_ = t_.clone(); dist.all_reduce(mx_, op=dist.ReduceOp.MAX)
             sustained.update({"env_steps_s": float(sm_[0]), "seconds": float(mx_[1]), "clock_mhz": float(sm_[2]) / world})

@@ -200,7 +200,7 @@ def lib():
                                 "(csrc/build.sh)" % (LIB_PATH, L.cn_abi_version(), EXPECTED_ABI))
         L.cn_last_error.restype = C.c_char_p
         L.cn_kernel_name.argtypes = [C.c_void_p, C.c_int]; L.cn_kernel_name.restype = C.c_char_p
-        L.cn_device_clock.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.cn_device_clock.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.cn_create.argtypes = [C.POINTER(CnConfig), C.c_int, C.POINTER(vp)]
         L.cn_destroy.argtypes = [vp]; L.cn_destroy.restype = None
         L.cn_obs_dim.argtypes = [vp]

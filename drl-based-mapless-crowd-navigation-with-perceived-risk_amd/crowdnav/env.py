@@ -369,12 +369,14 @@ class VecEnv:
         self._keep = (rg, od, sc)
         return self.obs, self.reward, self.done
 
-    def device_clock(self, out=None):
-        """Enqueue cn_device_clock on this env's stream: (shader-clock counter, 100 MHz counter) into a 2-element int64 device
-        tensor (returned; read it after a synchronisation)."""
+    def device_clock(self, span_us=2000, stream=None, out=None):
+        """Enqueue cn_device_clock on `stream` (a torch stream; default: this env's): a one-thread kernel that lives `span_us`
+        microseconds and leaves (shader-clock cycles, 100 MHz ticks) of that interval in a 2-element int64 device tensor
+        (returned; read it after a synchronisation).  cycles / (ticks / 100) = the clock in MHz under the load of that moment."""
         if out is None:
             out = torch.zeros(2, dtype=torch.int64, device=self.device)
-        _abi.check(self.L.cn_device_clock(C.c_void_p(out.data_ptr()), self.device.index, self._stream()))
+        st = self._stream() if stream is None else C.c_void_p(stream.cuda_stream)
+        _abi.check(self.L.cn_device_clock(C.c_void_p(out.data_ptr()), int(span_us), self.device.index, st))
         return out
 
     def counters(self):

@@ -560,16 +560,21 @@ extern "C" const char* cn_kernel_name(cn_handle h, int what)
     return choose_kernel(h, what == 3, what == 1, what == 4).name;
 }
 
-__global__ void cn_clock_kernel(long long* out)
+// Both counters are per-XCD (two one-thread kernels can land on different dies: their readings do not subtract), so the interval
+// is taken INSIDE one wave: it reads both, idles on s_sleep until `span_ticks` of the 100 MHz counter have passed, reads both again.
+__global__ void cn_clock_kernel(long long* out, long long span_ticks)
 {
-    out[0] = (long long)__builtin_amdgcn_s_memtime();
-    out[1] = (long long)__builtin_amdgcn_s_memrealtime();
+    const long long t0 = (long long)__builtin_amdgcn_s_memtime(), r0 = (long long)__builtin_amdgcn_s_memrealtime();
+    long long r1 = r0;
+    while (r1 - r0 < span_ticks) { __builtin_amdgcn_s_sleep(32); r1 = (long long)__builtin_amdgcn_s_memrealtime(); }
+    out[0] = (long long)__builtin_amdgcn_s_memtime() - t0;
+    out[1] = r1 - r0;
 }
-extern "C" int cn_device_clock(int64_t* out_dev, int device, void* stream)
+extern "C" int cn_device_clock(int64_t* out_dev, int span_us, int device, void* stream)
 {
-    if (!out_dev) return fail(CN_ERR_ARG, "cn_device_clock: null argument");
+    if (!out_dev || span_us < 1 || span_us > 1000000) return fail(CN_ERR_ARG, "cn_device_clock: null argument or span outside 1 us .. 1 s");
     DeviceScope scope(device);
-    hipLaunchKernelGGL(cn_clock_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (long long*)out_dev);
+    hipLaunchKernelGGL(cn_clock_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (long long*)out_dev, (long long)span_us * 100);
     HIPCHK(hipGetLastError());
     return CN_OK;
 }

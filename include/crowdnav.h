@@ -233,11 +233,12 @@ int cn_get_arbitration(cn_handle h);
  * shape is the headline one (360 rays, 20 pedestrians, K = 8, default tracker slots) get kernels compiled for exactly that
  * shape (`..._s360`: the LDS map, word counts and loop bounds are constants there); results are identical.  NULL on error. */
 const char* cn_kernel_name(cn_handle h, int what);
-/* Diagnostics (bench.py's sustained leg): enqueues a one-thread kernel on `stream` that stores the shader-clock counter (s_memtime)
- * in out_dev[0] and the constant 100 MHz counter (s_memrealtime) in out_dev[1].  Two of these around a stretch of work give its
- * duration on the device (out[1]) and the cycles the shader clock made in it (out[0]): their ratio is the clock the chip really
- * ran at under that load.  No reference counterpart. */
-int cn_device_clock(int64_t* out_dev, int device, void* stream);
+/* Diagnostics (bench.py's sustained leg): enqueues a one-thread kernel on `stream` that lives for `span_us` microseconds of the
+ * constant 100 MHz counter (s_memrealtime) and stores in out_dev[0] the shader-clock cycles (s_memtime) and in out_dev[1] the 100 MHz
+ * ticks that passed meanwhile: out[0] / (out[1] / 100) is the clock in MHz the chip ran at during that interval under whatever load
+ * the other streams put on it.  (One wave, one die: the two counters are per XCD and readings of different kernels do not subtract.)
+ * No reference counterpart. */
+int cn_device_clock(int64_t* out_dev, int span_us, int device, void* stream);
 /* n calls of cn_step in one crossing of the boundary: handle i steps with ios[i] on streams[i] (env batches run as
  * independent stream groups, DESIGN.md section 6: the launches are the same, the host thread pays the foreign-call
  * overhead once per step instead of once per group).  Stops at the first error and returns it. */

@@ -190,6 +190,33 @@ __global__ void __launch_bounds__(1024) branch_thr(Res* out, int iters, unsigned
     if (a0 + a1 == 12345u) out[blockIdx.x].cyc = 0;
 }
 
+// The env kernel's own instruction mix -- per 12 instructions: 6 VALU (4 float64 + 2 plain 32-bit), 3 SALU, 1 branch (not taken), 1 LDS
+// read, 1 s_waitcnt -- issued by the four waves of a SIMD IN LOCKSTEP (one launch per step: all four run the same stage at the same
+// time), and with the waves started a third of the block apart.  How busy can the vector unit get with this mix?
+template <int DEPHASE>
+__global__ void __launch_bounds__(1024) kernel_mix(Res* out, int iters, double x, double y)
+{
+    __shared__ double buf[1024];
+    double a0 = x, a1 = x + threadIdx.x, a2 = x, a3 = x; unsigned b0 = threadIdx.x, b1 = 3; double l0 = 0.0;
+    buf[threadIdx.x] = x;
+    const unsigned la = (unsigned)(size_t)(__attribute__((address_space(3))) double*)&buf[threadIdx.x];
+    T_BEGIN()
+    if (DEPHASE) {       // wave slot k of the SIMD idles k x ~1/4 of a block's issue time before it starts
+        const int k = (threadIdx.x >> 6) >> 2;
+        for (int w = 0; w < k * 6; ++w) asm volatile("s_nop 7\ns_nop 7\ns_nop 7\ns_nop 7\n");
+    }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            asm volatile("v_fma_f64 %0, %0, %7, %8\n s_add_u32 s20, s20, 1\n v_mul_f64 %1, %1, %7\n v_add_u32 %4, %4, %5\n"
+                         "s_and_b64 s[22:23], s[22:23], exec\n v_add_f64 %2, %2, %8\n ds_read_b64 %6, %9\n v_fma_f64 %3, %3, %7, %8\n"
+                         "s_cmp_eq_u32 s20, 0x7fffffff\n s_cbranch_scc1 1f\n v_and_b32 %5, %5, %4\n s_waitcnt lgkmcnt(0)\n1:\n"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(l0) : "v"(x), "v"(y), "v"(la) : "scc", "s20", "s22", "s23", "memory");
+    }
+    T_END()
+    if (a0 + a1 + a2 + a3 + l0 == 12345.0 && b0 + b1 == 7u) out[blockIdx.x].cyc = 0;
+}
+
 template <typename K, typename T>
 static int run(const char* name, K kern, int per_iter, T x, T y, Res* d, double* out4)
 {
@@ -238,6 +265,15 @@ int main()
     if (run("ds_read_b32 chase dep", lds_chase_lat, 32, 0u, 0u, d, nullptr)) return 1;
     if (run("ds_bpermute dep", bpermute_lat, 32, 0u, 0u, d, nullptr)) return 1;
     if (run("4 v_add + taken branch", branch_thr, 8 * 6, 3u, 0u, d, nullptr)) return 1;
+    {   // the mix: 48 instructions per iteration (4 x 12), of which 24 VALU (16 float64 at 4.2 cycles + 8 plain at 2.4 = 86 cycles per wave)
+        double m4[2];
+        if (run("kernel mix, lockstep", kernel_mix<0>, 48, 1.0000001, 1e-9, d, &m4[0])) return 1;
+        if (run("kernel mix, de-phased", kernel_mix<1>, 48, 1.0000001, 1e-9, d, &m4[1])) return 1;
+        for (int k = 0; k < 2; ++k)
+            printf("  %s: %.1f cycles per 12-instruction group per SIMD at 4 waves -> the vector unit is busy %.0f %% of the time "
+                   "(4 waves x (4 x 4.2 + 2 x 2.4) cycles of VALU issue per group)\n", k ? "de-phased" : "lockstep ", m4[k] * 12.0 * 4.0,
+                   100.0 * 4.0 * (4 * 4.2 + 2 * 2.4) / (m4[k] * 12.0 * 4.0));
+    }
     printf("(the cmp64 + 2 cndmask / rdlane_use / s_csel rows count each of their instructions separately; the branch row is per instruction of a "
            "{4 x v_add_u32, s_cmp, s_cbranch} group)\n");
     return 0;

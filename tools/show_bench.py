@@ -20,7 +20,7 @@ for f in sys.argv[1:]:
     su = c.get("sustained")
     if su:
         print("  sustained %.2f M env-steps/s over %.2f s (%d launches), shader clock %.0f MHz (idle %.0f), burst/sustained %.3f" % (
-            su["env_steps_s"] / 1e6, su["seconds"], su["launches"], su["clock_mhz"], su["clock_mhz_idle"], c["burst_over_sustained"]))
+            su["env_steps_s"] / 1e6, su["seconds"], su["launches"], su["clock_mhz"] or 0, su["clock_mhz_idle"] or 0, c["burst_over_sustained"]))
     cb = j.get("cpu_baseline")
     if cb:
         print("  cpu_baseline %.0f env-steps/s on %d cores (one core %.0f); reference python %s" % (cb["value"], cb["cores"], cb["one_core_value"], cb["reference_python"]["value"]))
