@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_PKG, "lib", "libcrowdnav.so")
 BUILD_SH = os.path.join(_PKG, "csrc", "build.sh")
 
 CN_MAX_TRACKS = 64
-EXPECTED_ABI = 5       # the version the ctypes structs below were written against (include/crowdnav.h CN_ABI_VERSION)
+EXPECTED_ABI = 6       # the version the ctypes structs below were written against (include/crowdnav.h CN_ABI_VERSION)
 CN_PHASE_ALL, CN_PHASE_PRE, CN_PHASE_GET_STATE, CN_PHASE_REWARD = 0, 1, 2, 4
 CN_SD_COUNT = 24
 CN_SI_COUNT = 16
@@ -26,7 +26,7 @@ SI = dict(DONE=0, DQ_LEN=1, NTRACKS=2, EGO_VIOL=3, SOCIAL_VIOL=4, OBST_STEPS=5, 
 TF = dict(PX=0, PY=1, DIST=2, D0X=3, D0Y=4, D1X=5, D1Y=6, T=7, SPEED=8, VX=9, VY=10, DQLEN=11)
 
 EXPORTS = ["cn_abi_version", "cn_last_error", "cn_create", "cn_destroy", "cn_obs_dim", "cn_config_of",
-           "cn_set_ped_init", "cn_get_ped_init", "cn_set_ped_preset_vel", "cn_reset", "cn_step", "cn_step_multi", "cn_set_arbitration", "cn_get_arbitration", "cn_kernel_name", "cn_device_clock",
+           "cn_set_ped_init", "cn_get_ped_init", "cn_set_ped_preset_vel", "cn_reset", "cn_step", "cn_step_multi", "cn_set_arbitration", "cn_get_arbitration", "cn_set_group_envs", "cn_kernel_name", "cn_device_clock",
            "cn_observe_external",
            "cn_policy_tail", "cn_actor_pack_weights", "cn_actor_forward", "cn_step_sequence", "cn_rollout_policy", "cn_get_counters",
            "cn_get_returns", "cn_debug_env", "cn_lds_bytes", "cn_near_separate", "cn_snapshot_size", "cn_snapshot", "cn_restore",
@@ -200,6 +200,7 @@ def lib():
                                 "(csrc/build.sh)" % (LIB_PATH, L.cn_abi_version(), EXPECTED_ABI))
         L.cn_last_error.restype = C.c_char_p
         L.cn_kernel_name.argtypes = [C.c_void_p, C.c_int]; L.cn_kernel_name.restype = C.c_char_p
+        L.cn_set_group_envs.argtypes = [C.c_void_p, C.c_int64]
         L.cn_device_clock.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.cn_create.argtypes = [C.POINTER(CnConfig), C.c_int, C.POINTER(vp)]
         L.cn_destroy.argtypes = [vp]; L.cn_destroy.restype = None

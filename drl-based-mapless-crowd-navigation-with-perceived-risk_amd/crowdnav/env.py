@@ -539,6 +539,8 @@ class VecEnvGroups:
             out = dict(obs=self.obs[sl], final_obs=self.final_obs[sl], reward=self.reward[sl], done=self.done[sl],
                        topk_idx=self.topk_idx[sl])
             self.envs.append(VecEnv(self._group_cfg(g), device=device, stream=streams[g], out=out, arbitration=arbitration))
+        for e in self.envs:      # the groups' launches overlap: the library sizes its workgroups for the environments in flight together
+            _abi.check(e.L.cn_set_group_envs(e.h, self.N))
         self.streams = [e.stream for e in self.envs]
 
     def _group_cfg(self, g):

@@ -46,6 +46,9 @@ extern "C" __global__ void cn_env_kernel_seq(CnKParams p);
 extern "C" __global__ void cn_env_kernel_s360(CnKParams p);
 extern "C" __global__ void cn_env_kernel_fair_s360(CnKParams p);
 extern "C" __global__ void cn_env_kernel_seq_s360(CnKParams p);
+extern "C" __global__ void cn_env_kernel_s360_w4(CnKParams p);
+extern "C" __global__ void cn_env_kernel_fair_s360_w4(CnKParams p);
+
 extern "C" __global__ void cn_env_kernel_seq_s720(CnKParams p);
 extern "C" __global__ void cn_policy_kernel(CnKParams p);
 extern "C" __global__ void cn_policy_kernel_s360(CnKParams p);
@@ -78,7 +81,8 @@ static const void* const kDynamicLdsKernels[] = {
     (const void*)cn_env_kernel_seq, (const void*)cn_env_kernel_s360, (const void*)cn_env_kernel_fair_s360, (const void*)cn_env_kernel_seq_s360,
     (const void*)cn_env_kernel_seq_s720, (const void*)cn_env_kernel_s720, (const void*)cn_env_kernel_fair_s720, (const void*)cn_env_kernel_gt_seq,
     (const void*)cn_env_kernel_seq_sf, (const void*)cn_env_kernel_seq_sfd, (const void*)cn_env_kernel_seq_wa,
-    (const void*)cn_env_kernel_gt_seq_sf, (const void*)cn_env_kernel_gt_seq_sfd, (const void*)cn_env_kernel_gt_seq_wa};
+    (const void*)cn_env_kernel_gt_seq_sf, (const void*)cn_env_kernel_gt_seq_sfd, (const void*)cn_env_kernel_gt_seq_wa,
+    (const void*)cn_env_kernel_s360_w4, (const void*)cn_env_kernel_fair_s360_w4};
 static const void* const kPolicyKernels[] = {
     (const void*)cn_policy_kernel, (const void*)cn_policy_kernel_s360, (const void*)cn_policy_kernel_gt, (const void*)cn_policy_kernel_s720,
     (const void*)cn_policy_kernel_sf, (const void*)cn_policy_kernel_sfd, (const void*)cn_policy_kernel_wa,
@@ -109,6 +113,8 @@ struct cn_env_s {
     size_t pol_wave_lds = 0, pol_lds = 0;   // cn_rollout_policy: bytes between the environments' LDS working sets of a workgroup; the workgroup's total (0 = does not fit)
     int pol_envs = 0;                 // ... environments per workgroup: 16, or 8 where 16 working sets do not fit one CU's LDS
     size_t pol_act_off = 0;           // ... byte offset of the workgroup's actions (past the working sets and the actor tile)
+    int64_t group_envs = 0;           // cn_set_group_envs: environments in flight together with this handle's (0 = alone)
+    int wpb4 = 0;                     // 4: the 360-ray step kernels run four environments per workgroup (launches of at most one round of wavefronts); 0: one
     bool shape360 = false;            // the headline shape (360 rays, 20 pedestrians, K = 8 and cn_create's sizes for it): the _s360 kernels
     bool shape720 = false;            // BASELINE configs[4] (720 rays, 100 pedestrians, K = 8): the _s720 kernels
 };
@@ -292,7 +298,7 @@ static int upload_initial_state(cn_env_s* h)
 }
 
 typedef void (*cn_kernel_fn)(CnKParams);
-struct KernelChoice { cn_kernel_fn fn; const char* name; bool compact = false; };      // compact: launched with h->lds_shape
+struct KernelChoice { cn_kernel_fn fn; const char* name; bool compact = false; int wpb = 1; };      // compact: launched with h->lds_shape; wpb: environments (waves) per workgroup
 #define CN_KC(f) KernelChoice{f, #f}
 #define CN_KCC(f) KernelChoice{f, #f, true}
 static size_t lds_of(const cn_env_s* h, const KernelChoice& kc) { return kc.compact ? h->lds_shape : h->lds; }
@@ -401,6 +407,13 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
     h->shape360 = R == 360 && P == 20 && K == 8 && h->max_conf == 91 && h->trk_cap == 32 && k.near_sep == 1 && !getenv("CN_NO_SHAPE_KERNELS");
     h->shape720 = R == 720 && P == 100 && K == 8 && h->max_conf == 181 && h->trk_cap == 64 && k.near_sep == 0 && !getenv("CN_NO_SHAPE_KERNELS")
                   && c.room_half + c.lidar_max + 1.0 < 32.0;       // the _s720 kernels keep end points as int16 thousandths
+    // Four environments per workgroup for the 360-ray step kernels when the whole launch is resident at once (n_envs <= 16 wavefronts
+    // x CUs): a quarter of the workgroups for the dispatcher to create, + 2-3 % in every decomposition at 4096 envs; with several
+    // rounds of wavefronts (16384 envs) the coarser release of LDS / wave slots costs 3.6 % instead, and the 720-ray shape (12
+    // wavefronts per CU, 1.33 rounds at 4096) loses 7-25 % (profiles/r05/ab_wpb.txt).  Decided per launch in choose_kernel() from
+    // max(n_envs, cn_set_group_envs).  CN_WPB=1 / 2 / 4 / 8 / 16 overrides for A/B runs.
+    h->wpb4 = 4;
+    if (getenv("CN_WPB")) { h->wpb4 = atoi(getenv("CN_WPB")); if (h->wpb4 != 2 && h->wpb4 != 4 && h->wpb4 != 8 && h->wpb4 != 16) h->wpb4 = 0; }
     if (h->shape720) h->lds_shape = lds_bytes_impl(R, P, K, h->max_conf, h->trk_cap, false, c.obs_layout, true);
     k.max_conf = h->max_conf; k.trk_cap = h->trk_cap; k.env_index_base = c.env_index_base; k.seed = c.seed;
     k.room_half = c.room_half; k.ped_radius = c.ped_radius; k.ped_vmax = c.ped_vmax; k.robot_clearance = c.robot_clearance;
@@ -426,6 +439,10 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
         build_assoc_table(k, tab);
         k.assoc_tab = (const int16_t*)(h->d_poly + 128);
         HIPCHK(hipMemcpy((void*)k.assoc_tab, tab, sizeof(tab), hipMemcpyHostToDevice));
+    }
+    if (h->wpb4 * h->lds > 64 * 1024) {
+        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_s360_w4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(h->wpb4 * (h->lds + 16))));
+        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_fair_s360_w4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(h->wpb4 * (h->lds + 16))));
     }
     if (h->lds > 64 * 1024)
         for (const void* f : kDynamicLdsKernels) HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
@@ -521,6 +538,8 @@ static KernelChoice choose_kernel(const cn_env_s* h, bool ext, bool same, bool o
     if (ct) return same ? CN_KC(cn_env_kernel_ct_same) : CN_KC(cn_env_kernel_ct);
     if (same) return CN_KC(cn_env_kernel_same);
     const bool fair = fair_launch(h, overlapped);
+    const int64_t resident = h->group_envs > h->cfg.n_envs ? h->group_envs : (int64_t)h->cfg.n_envs;
+    if (h->shape360 && h->wpb4 && h->n_cus > 0 && resident <= 16 * (int64_t)h->n_cus) return fair ? KernelChoice{cn_env_kernel_fair_s360_w4, "cn_env_kernel_fair_s360_w4", false, h->wpb4} : KernelChoice{cn_env_kernel_s360_w4, "cn_env_kernel_s360_w4", false, h->wpb4};
     if (h->shape360) return fair ? CN_KC(cn_env_kernel_fair_s360) : CN_KC(cn_env_kernel_s360);
     if (h->shape720) return fair ? CN_KCC(cn_env_kernel_fair_s720) : CN_KCC(cn_env_kernel_s720);
     return fair ? CN_KC(cn_env_kernel_fair) : CN_KC(cn_env_kernel);
@@ -587,6 +606,11 @@ static int launch(cn_handle h, const CnKParams& kp, hipStream_t st, bool overlap
     if (!kc.fn)
         return fail(CN_ERR_CONFIG, "cn_observe_external: risk_mode gt reads the library simulator's pedestrians; "
                                    "external /scan + /odom only exist in lidar_tracker mode");
+    if (kc.wpb > 1) {
+        CnKParams k4 = kp;
+        k4.wave_lds = (int32_t)((lds_of(h, kc) + 15) & ~(size_t)15);
+        hipLaunchKernelGGL(kc.fn, dim3((kp.N + kc.wpb - 1) / kc.wpb), dim3(64 * kc.wpb), (size_t)k4.wave_lds * kc.wpb, st, k4);
+    } else
     hipLaunchKernelGGL(kc.fn, dim3(kp.N), dim3(64), lds_of(h, kc), st, kp);
     HIPCHK(hipGetLastError());
     return CN_OK;
@@ -618,6 +642,13 @@ extern "C" int cn_set_arbitration(cn_handle h, int mode)
     if (mode != CN_ARB_AUTO && mode != CN_ARB_OLDEST_FIRST && mode != CN_ARB_FAIR)
         return fail(CN_ERR_ARG, "cn_set_arbitration: mode must be CN_ARB_AUTO (0), CN_ARB_OLDEST_FIRST (1) or CN_ARB_FAIR (2)");
     h->arbitration = mode;
+    return CN_OK;
+}
+
+extern "C" int cn_set_group_envs(cn_handle h, int64_t total_envs)
+{
+    if (!h || total_envs < 0) return fail(CN_ERR_ARG, "cn_set_group_envs: null handle or negative count");
+    h->group_envs = total_envs;
     return CN_OK;
 }
 

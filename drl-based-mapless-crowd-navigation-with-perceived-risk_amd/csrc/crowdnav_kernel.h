@@ -77,6 +77,7 @@ struct CnKParams {
     uint64_t pol_seed, pol_counter;
     float pol_max_v, pol_max_w, pol_sigma;
     int32_t pol_D, pol_Dp, pol_wave_lds;
+    int32_t wave_lds, wave_lds_pad;   // cn_env_kernel*_w4 (4 environments per workgroup): bytes between their LDS working sets
     int32_t pol_envs, pol_act_off;    // environments per workgroup (16 or 8); byte offset of the workgroup's [pol_envs][2] actions in its LDS
     long long* timing;      // profiling build only: [N, 32] s_memtime stamps
 };

@@ -2816,6 +2816,15 @@ extern "C" __global__ void CN_HOT_BOUNDS cn_env_kernel(CnKParams p) { extern __s
 extern "C" __global__ void CN_HOT_BOUNDS cn_env_kernel_fair(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, false, 0, false, 0, false, true>(blockIdx.x, threadIdx.x, cn_smem); }
 extern "C" __global__ void CN_HOT_BOUNDS cn_env_kernel_s360(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, false, 0, false, 0, false, false, 360>(blockIdx.x, threadIdx.x, cn_smem); }
 extern "C" __global__ void CN_HOT_BOUNDS cn_env_kernel_fair_s360(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, false, 0, false, 0, false, true, 360>(blockIdx.x, threadIdx.x, cn_smem); }
+// FOUR environments per workgroup (256 threads; one wavefront is still one environment and the four never synchronise): a quarter of
+// the workgroups for the dispatcher to create per launch -- the grid's start-up ramp is part of every step of a one-launch-per-step chain
+#ifdef CN_TIMING
+#define CN_HOT4_BOUNDS __launch_bounds__(1024)
+#else
+#define CN_HOT4_BOUNDS __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4)))
+#endif
+extern "C" __global__ void CN_HOT4_BOUNDS cn_env_kernel_s360_w4(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; const int w_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); env_kernel_body<false, false, 0, false, 0, false, false, 360>(blockIdx.x * (blockDim.x >> 6) + w_, threadIdx.x & 63, cn_smem + (size_t)w_ * ((KP)__builtin_amdgcn_kernarg_segment_ptr())->wave_lds); }
+extern "C" __global__ void CN_HOT4_BOUNDS cn_env_kernel_fair_s360_w4(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; const int w_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); env_kernel_body<false, false, 0, false, 0, false, true, 360>(blockIdx.x * (blockDim.x >> 6) + w_, threadIdx.x & 63, cn_smem + (size_t)w_ * ((KP)__builtin_amdgcn_kernarg_segment_ptr())->wave_lds); }
 extern "C" __global__ void CN_S720_BOUNDS cn_env_kernel_s720(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, false, 0, false, 0, false, false, 720>(blockIdx.x, threadIdx.x, cn_smem); }
 extern "C" __global__ void CN_S720_BOUNDS cn_env_kernel_fair_s720(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, false, 0, false, 0, false, true, 720>(blockIdx.x, threadIdx.x, cn_smem); }
 extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_same(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, true, 0>(blockIdx.x, threadIdx.x, cn_smem); }

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CN_ABI_VERSION 5
+#define CN_ABI_VERSION 6
 #define CN_MAX_TRACKS 64      /* largest per-env capacity of the obstacle tracker (ENV:656-743): one lane per track */
 #define CN_MAX_K 16
 
@@ -227,6 +227,11 @@ int cn_step(cn_handle h, const cn_step_io* io, void* stream);
 #define CN_ARB_FAIR 2
 int cn_set_arbitration(cn_handle h, int mode);
 int cn_get_arbitration(cn_handle h);
+/* Stream groups (ABI 6): how many environments the caller keeps in flight on this device TOGETHER with this handle's -- the sum over
+ * the handles whose launches overlap (crowdnav.env.VecEnvGroups sets it for every group).  0 (the default) = this handle alone.
+ * The 360-ray step kernels run four environments per workgroup while that total is resident at once (<= 16 wavefronts per CU) and
+ * one per workgroup beyond; results are identical either way. */
+int cn_set_group_envs(cn_handle h, int64_t total_envs);
 /* Name of the device kernel a call on this handle launches right now (diagnostics: bench.py and the profile summaries key the
  * PMC counters of a run by it).  what: 0 = cn_step with auto_reset 0 / 2 and cn_reset, 1 = cn_step with auto_reset 1 (same-call
  * reset), 2 = cn_step_sequence, 3 = cn_observe_external, 4 = cn_step inside a cn_step_multi over several handles.  Handles whose

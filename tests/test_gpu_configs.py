@@ -511,7 +511,7 @@ def test_config4_full_workload_16384_envs_as_8_shards(oracle_mod):
 def test_step_sequence_at_the_bench_shape_4096_envs_20_steps_equals_step_by_step():
     """The exact launches bench.py's sequence legs time (VERDICT r04 "weak" 1): cn_env_kernel_seq_s360 over 4096 envs x T = 20
     after the bench's pre-roll -- in place (bind_step_sequence) and into trajectory buffers (the round-5 `sequence_traj` leg) --
-    against 20 calls of cn_step (cn_env_kernel_fair_s360): every step's observation / reward / done in the trajectory, the final
+    against 20 calls of cn_step (cn_env_kernel_fair_s360_w4: four environments per workgroup since round 5): every step's observation / reward / done in the trajectory, the final
     outputs, the whole state record, counters and returns.  Same seed, pedestrian cycle and open-loop action law as bench.py."""
     import torch
     from crowdnav import Config
@@ -519,7 +519,7 @@ def test_step_sequence_at_the_bench_shape_4096_envs_20_steps_equals_step_by_step
     N, T, PRE = 4096, 20, 60
     cfg = Config(n_envs=N, n_peds=20, n_rays=360, k_obstacles=8, max_steps=1000, seed=1234, ped_cycle_ms=1400)
     ref, inplace, tr = VecEnv(cfg), VecEnv(cfg), VecEnv(cfg)
-    assert ref.kernel_name("sequence") == "cn_env_kernel_seq_s360" and ref.kernel_name("step") == "cn_env_kernel_fair_s360"
+    assert ref.kernel_name("sequence") == "cn_env_kernel_seq_s360" and ref.kernel_name("step") == "cn_env_kernel_fair_s360_w4"
     g = torch.Generator(device="cuda").manual_seed(1234)
     acts = torch.stack([torch.rand((PRE + 2 * T, N), generator=g, device="cuda") * 0.22,
                         torch.rand((PRE + 2 * T, N), generator=g, device="cuda") * 4.0 - 2.0], 2).contiguous()

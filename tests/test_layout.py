@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(L, s), "libcrowdnav.so does not export %s" % s
     assert set(syms) == set(crowdnav._abi.EXPORTS)
-    assert L.cn_abi_version() == crowdnav._abi.EXPECTED_ABI == 5
+    assert L.cn_abi_version() == crowdnav._abi.EXPECTED_ABI == 6
 
 
 def test_config_struct_matches_header_and_oracle():

@@ -21,21 +21,24 @@ if os.environ.get("CN_AB_CHILD"):
         call(); torch.cuda.synchronize(); dt = time.perf_counter() - t0
         r = (N * STEPS - (envs.episodes() - ep0)) / dt / 1e6
         envs.close(); return r
-    out = [run(4096, 1), run(4096, 2), run(4096, 4), run(16384, 4)]
     if os.environ.get("CN_AB_CFG5"):
-        out.append(run(4096, 4, 100, 720, 2.4))
+        out = [run(4096, 1, 100, 720, 2.4), run(4096, 2, 100, 720, 2.4), run(4096, 4, 100, 720, 2.4), run(2048, 1, 100, 720, 2.4)]
+    else:
+        out = [run(4096, 1), run(4096, 2), run(4096, 4), run(16384, 4)]
     print(" ".join("%.2f" % x for x in out)); sys.exit(0)
 libs = sys.argv[1:]
 rounds = int(os.environ.get("CN_AB_ROUNDS", "3"))
 res = {l: [] for l in libs}
 for r in range(rounds):
     for l in libs:
-        o = subprocess.run([sys.executable, os.path.abspath(__file__)], env=dict(os.environ, CN_AB_CHILD="1", CN_LIB=l), capture_output=True, text=True)
+        lib_, _, kv = l.partition("@")            # "lib.so@VAR=VALUE": the same library with an environment switch
+        extra = dict([kv.split("=", 1)]) if kv else {}
+        o = subprocess.run([sys.executable, os.path.abspath(__file__)], env=dict(os.environ, CN_AB_CHILD="1", CN_LIB=lib_, **extra), capture_output=True, text=True)
         line = [x for x in o.stdout.splitlines() if x and x[0].isdigit()]
         if not line:
             print(l, "FAILED", o.stderr[-500:]); continue
         res[l].append([float(x) for x in line[-1].split()])
-print("%-40s %s" % ("library (median of %d)" % rounds, "4096x1   4096x2   4096x4  16384x4" + ("  cfg5x4" if os.environ.get("CN_AB_CFG5") else "")))
+print("%-40s %s" % ("library (median of %d)" % rounds, ("cfg5: 4096x1   4096x2   4096x4   2048x1" if os.environ.get("CN_AB_CFG5") else "4096x1   4096x2   4096x4  16384x4")))
 for l in libs:
     if res[l]:
         cols = list(zip(*res[l]))
