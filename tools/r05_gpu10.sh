@@ -1,0 +1,7 @@
+#!/bin/bash
+# round 5: refresh everything under profiles/r05 that depends on the kernel sources (rocprofv3 passes, bench JSONs, quick perf)
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
+mkdir -p gpurun_out/r05; export TMPDIR=/tmp
+python tools/csrc_hash.py
+tools/profile.sh r05 > gpurun_out/profile_r05.log 2>&1; grep -E "^== (counters|traffic)" gpurun_out/prof_r05/summary.txt
+tools/regen_profiles.sh r05 > gpurun_out/r05/regen.log 2>&1; tail -8 gpurun_out/r05/regen.log
