@@ -306,6 +306,39 @@ def test_social_force_pair_repulsion_is_antisymmetric_and_has_the_stated_strengt
     assert (pp[:, 1] > 0.9).all()                                              # ... while both keep walking to their goals
 
 
+def test_social_force_pair_sums_are_exact_and_order_free(oracle_mod):
+    """Round 5: every pedestrian-pedestrian force component enters the sum as a multiple of 2^-36 m/s^2, so the total is exact and has
+    no order (the kernels evaluate each unordered pair once and scatter +- with LDS atomics).  Checked on the oracle: a ring of
+    pedestrians listed in two different index orders ends the tick with the same pair accelerations, pedestrian for pedestrian, to
+    within the few grid steps the (index-keyed) goal term's own rounding leaves in the difference; the configuration bound that
+    keeps the sums exact is enforced at creation.  (GPU = oracle bit for bit on these worlds: tests/test_gpu_parity.py.)"""
+    rng = np.random.default_rng(5)
+    P = 24
+    ang = rng.uniform(0, 2 * np.pi, P); rad = rng.uniform(0.2, 0.9, P)
+    pos = np.stack([rad * np.cos(ang), rad * np.sin(ang)], 1)
+    goals = pos * 4.0
+    perm = rng.permutation(P)
+    o1, v1 = _sf_world(oracle_mod, pos, goals, sf_goal_eps=0.0)
+    o2, v2 = _sf_world(oracle_mod, pos[perm], goals[perm], sf_goal_eps=0.0)
+    o1.hsim_advance(10, 0.0, 0.0); o2.hsim_advance(10, 0.0, 0.0)
+    _, _, pv1, _ = o1.sim_state(); _, _, pv2, _ = o2.sim_state()
+    # the pair term: velocity change minus the (per-pedestrian, order-free) goal term v0 e_goal / tau * h
+    c = o1.cfg
+    def pair_part(pv, v0, p_, g_):
+        e = (g_ - p_) / np.linalg.norm(g_ - p_, axis=1, keepdims=True)
+        return pv - (v0[:, None] * e) / c.sf_tau * 0.01
+    a1, a2 = pair_part(pv1, v1, pos, goals), pair_part(pv2, v2, pos[perm], goals[perm])
+    assert np.abs(a1).max() > 1e-3                                   # the ring is crowded enough to repel
+    # same pedestrians, other summation order: identical to the last bit once the desired-speed draw (keyed by index) is taken out
+    q = 2.0 ** -36 * 0.01
+    assert np.abs(a1[perm] - a2).max() <= 4 * q                      # (the goal term's own rounding differs with v0_i: a few grid steps)
+    L = oracle_mod.lib()
+    import ctypes as C
+    bad = oracle_mod.make_config(n_envs=1, n_peds=100, ped_mode=2, sf_B=0.005)         # 100 * 0.8 * e^(0.101 / 0.005) >> 2^15
+    h = C.c_void_p()
+    assert L.cno_create(C.byref(bad), C.byref(h)) == -2
+
+
 def test_social_force_wall_stand_off(oracle_mod):
     """A pedestrian whose goal lies behind the +x wall stops where the wall's push equals the goal's pull:
     v0 / tau = A_w exp((r - d) / B_w)  ->  d = r - B_w ln(v0 / (tau A_w))."""
