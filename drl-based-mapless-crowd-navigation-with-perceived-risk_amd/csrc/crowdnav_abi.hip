@@ -48,6 +48,7 @@ extern "C" __global__ void cn_env_kernel_fair_s360(CnKParams p);
 extern "C" __global__ void cn_env_kernel_seq_s360(CnKParams p);
 extern "C" __global__ void cn_env_kernel_s360_w4(CnKParams p);
 extern "C" __global__ void cn_env_kernel_fair_s360_w4(CnKParams p);
+extern "C" __global__ void cn_env_kernel_s360_x2(CnKParams p);
 
 extern "C" __global__ void cn_env_kernel_seq_s720(CnKParams p);
 extern "C" __global__ void cn_policy_kernel(CnKParams p);
@@ -82,7 +83,7 @@ static const void* const kDynamicLdsKernels[] = {
     (const void*)cn_env_kernel_seq_s720, (const void*)cn_env_kernel_s720, (const void*)cn_env_kernel_fair_s720, (const void*)cn_env_kernel_gt_seq,
     (const void*)cn_env_kernel_seq_sf, (const void*)cn_env_kernel_seq_sfd, (const void*)cn_env_kernel_seq_wa,
     (const void*)cn_env_kernel_gt_seq_sf, (const void*)cn_env_kernel_gt_seq_sfd, (const void*)cn_env_kernel_gt_seq_wa,
-    (const void*)cn_env_kernel_s360_w4, (const void*)cn_env_kernel_fair_s360_w4};
+    (const void*)cn_env_kernel_s360_w4, (const void*)cn_env_kernel_fair_s360_w4, (const void*)cn_env_kernel_s360_x2};
 static const void* const kPolicyKernels[] = {
     (const void*)cn_policy_kernel, (const void*)cn_policy_kernel_s360, (const void*)cn_policy_kernel_gt, (const void*)cn_policy_kernel_s720,
     (const void*)cn_policy_kernel_sf, (const void*)cn_policy_kernel_sfd, (const void*)cn_policy_kernel_wa,
@@ -114,6 +115,7 @@ struct cn_env_s {
     int pol_envs = 0;                 // ... environments per workgroup: 16, or 8 where 16 working sets do not fit one CU's LDS
     size_t pol_act_off = 0;           // ... byte offset of the workgroup's actions (past the working sets and the actor tile)
     int64_t group_envs = 0;           // cn_set_group_envs: environments in flight together with this handle's (0 = alone)
+    int x2 = -1;                      // cn_env_kernel_s360_x2 (two wavefronts per environment): -1 = by grid size, 0 / 1 = CN_X2 override
     int wpb4 = 0;                     // 4: the 360-ray step kernels run four environments per workgroup (launches of at most one round of wavefronts); 0: one
     bool shape360 = false;            // the headline shape (360 rays, 20 pedestrians, K = 8 and cn_create's sizes for it): the _s360 kernels
     bool shape720 = false;            // BASELINE configs[4] (720 rays, 100 pedestrians, K = 8): the _s720 kernels
@@ -298,7 +300,7 @@ static int upload_initial_state(cn_env_s* h)
 }
 
 typedef void (*cn_kernel_fn)(CnKParams);
-struct KernelChoice { cn_kernel_fn fn; const char* name; bool compact = false; int wpb = 1; };      // compact: launched with h->lds_shape; wpb: environments (waves) per workgroup
+struct KernelChoice { cn_kernel_fn fn; const char* name; bool compact = false; int wpb = 1; bool x2 = false; };      // compact: launched with h->lds_shape; wpb: environments (waves) per workgroup
 #define CN_KC(f) KernelChoice{f, #f}
 #define CN_KCC(f) KernelChoice{f, #f, true}
 static size_t lds_of(const cn_env_s* h, const KernelChoice& kc) { return kc.compact ? h->lds_shape : h->lds; }
@@ -413,6 +415,7 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
     // wavefronts per CU, 1.33 rounds at 4096) loses 7-25 % (profiles/r05/ab_wpb.txt).  Decided per launch in choose_kernel() from
     // max(n_envs, cn_set_group_envs).  CN_WPB=1 / 2 / 4 / 8 / 16 overrides for A/B runs.
     h->wpb4 = 4;
+    if (getenv("CN_X2")) h->x2 = atoi(getenv("CN_X2")) ? 1 : 0;
     if (getenv("CN_WPB")) { h->wpb4 = atoi(getenv("CN_WPB")); if (h->wpb4 != 2 && h->wpb4 != 4 && h->wpb4 != 8 && h->wpb4 != 16) h->wpb4 = 0; }
     if (h->shape720) h->lds_shape = lds_bytes_impl(R, P, K, h->max_conf, h->trk_cap, false, c.obs_layout, true);
     k.max_conf = h->max_conf; k.trk_cap = h->trk_cap; k.env_index_base = c.env_index_base; k.seed = c.seed;
@@ -539,6 +542,9 @@ static KernelChoice choose_kernel(const cn_env_s* h, bool ext, bool same, bool o
     if (same) return CN_KC(cn_env_kernel_same);
     const bool fair = fair_launch(h, overlapped);
     const int64_t resident = h->group_envs > h->cfg.n_envs ? h->group_envs : (int64_t)h->cfg.n_envs;
+    // small grids: two wavefronts per environment while all of them fit at two per SIMD (CN_X2=0 / 1 overrides for A/B runs)
+    if (h->shape360 && h->n_cus > 0 && (h->x2 == 1 || (h->x2 < 0 && resident <= 8 * (int64_t)h->n_cus)))
+        return KernelChoice{cn_env_kernel_s360_x2, "cn_env_kernel_s360_x2", false, 1, true};
     if (h->shape360 && h->wpb4 && h->n_cus > 0 && resident <= 16 * (int64_t)h->n_cus) return fair ? KernelChoice{cn_env_kernel_fair_s360_w4, "cn_env_kernel_fair_s360_w4", false, h->wpb4} : KernelChoice{cn_env_kernel_s360_w4, "cn_env_kernel_s360_w4", false, h->wpb4};
     if (h->shape360) return fair ? CN_KC(cn_env_kernel_fair_s360) : CN_KC(cn_env_kernel_s360);
     if (h->shape720) return fair ? CN_KCC(cn_env_kernel_fair_s720) : CN_KCC(cn_env_kernel_s720);
@@ -606,7 +612,11 @@ static int launch(cn_handle h, const CnKParams& kp, hipStream_t st, bool overlap
     if (!kc.fn)
         return fail(CN_ERR_CONFIG, "cn_observe_external: risk_mode gt reads the library simulator's pedestrians; "
                                    "external /scan + /odom only exist in lidar_tracker mode");
-    if (kc.wpb > 1) {
+    if (kc.x2) {
+        CnKParams k2 = kp;
+        k2.wave_lds = (int32_t)((lds_of(h, kc) + 15) & ~(size_t)15);
+        hipLaunchKernelGGL(kc.fn, dim3(kp.N), dim3(128), (size_t)k2.wave_lds + 256, st, k2);
+    } else if (kc.wpb > 1) {
         CnKParams k4 = kp;
         k4.wave_lds = (int32_t)((lds_of(h, kc) + 15) & ~(size_t)15);
         hipLaunchKernelGGL(kc.fn, dim3((kp.N + kc.wpb - 1) / kc.wpb), dim3(64 * kc.wpb), (size_t)k4.wave_lds * kc.wpb, st, k4);

@@ -58,6 +58,13 @@ __device__ __forceinline__ void cn_setprio_uniform(int v)      // v: wave-unifor
 #define CN_T(k) CN_FAIR_AT(k)
 #endif
 
+// TWO WAVEFRONTS PER ENVIRONMENT (cn_env_kernel_s360_x2; small grids: at most two wavefronts per SIMD would be resident anyway).
+// Wave 0 runs the step as always; wave 1 takes the pedestrians' advance off its hands while it does the robot's, then half of every
+// lane = ray stage (ray loop, gradients, flag words, association).  They meet at s_barrier with only the LDS counter drained (the
+// hand-offs are all through LDS; a __syncthreads() would also wait for the observation's global stores).  `mb`: the pair's mailbox,
+// 256 bytes of LDS behind the working set.
+#define CN_XBAR() do { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); } while (0)
+struct XMail { double px, py, sy, cy, ox, oy, smin1, pad; int nnear, wall_x, wall_y, nocc, fast_assoc, k1, fe1, lb1, ns1; };
 #define TY_NONE 0
 #define TY_W 1
 #define TY_O 2
@@ -1137,38 +1144,58 @@ __device__ __forceinline__ void tracker_stage(KP p, EnvRegs& e, const Lds& L, do
     CN_SYNC();
 }
 
-template <bool EXT, bool GT = false, bool FAIR = false, bool CMP = false>
+template <bool EXT, bool GT = false, bool FAIR = false, bool CMP = false, bool X2 = false>
 __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const Lds& L, int env, int lane, int step_counter,
-                        float* obs32, float* fin32, double* obs64, int* done_out, bool have_tg = false, Trig tg = Trig{0.0, 0.0, 0.0, 0.0})
+                        float* obs32, float* fin32, double* obs64, int* done_out, bool have_tg = false, Trig tg = Trig{0.0, 0.0, 0.0, 0.0},
+                        const int wv = 0, XMail* const mb = nullptr)
 {
     constexpr bool SFENCE = CMP && !FAIR;
+    static_assert(!X2 || (!EXT && !GT), "two wavefronts per environment: simulated sensors, lidar-tracker mode");
+    const bool w0 = !X2 || wv == 0;             // wave 0 (or the only wave): everything that is not split
     const int R = p->R, n = R - 1, K = p->K, D = n + 7 + 4 * K;
     const double MAXR = p->max_scan_range;
-    const double px = e.rx, py = e.ry, yaw = e.ryaw, v = e.rv, w = e.rw, now = e.clock;
-
+    double px = e.rx, py = e.ry;
+    const double yaw = e.ryaw, v = e.rv, w = e.rw, now = e.clock;
+    double distance_to_goal = 0.0, heading = 0.0, agent_vel_x = 0.0, agent_vel_y = 0.0;
+    double sy = 0.0, cy = 0.0, ox = 0.0, oy = 0.0;
+    const double h = p->room_half;
+    int nnear = 0;
+    bool wall_x = false, wall_y = false;
+    if (w0) {
     // ENV:246-265
     CN_T(22);
     if (step_counter == 1) waypoint_refresh(p, pg, e, lane, px, py);
-    double distance_to_goal = cn_round_np64_2_t<!EXT>(dist3(px, py, e.wpx, e.wpy), PY2);   // round(np.float64, 2), ENV:255
-    double heading = cn_py_round2_t<!EXT>(heading_to_goal(p, e, px, py, yaw), PY2);
+    distance_to_goal = cn_round_np64_2_t<!EXT>(dist3(px, py, e.wpx, e.wpy), PY2);   // round(np.float64, 2), ENV:255
+    heading = cn_py_round2_t<!EXT>(heading_to_goal(p, e, px, py, yaw), PY2);
     CN_T(23);
     if (step_counter % 5 == 0 || distance_to_goal < e.prev_dist) waypoint_refresh(p, pg, e, lane, px, py);
     CN_T(24);
     // ENV:267-268: the angular velocity is used as the angle
     double sw_, cw_;
     if (have_tg) { sw_ = tg.sw; cw_ = tg.cw; } else cn_det_sincos_t(p->trig, w, &sw_, &cw_);
-    double agent_vel_x = -1.0 * (v * cw_);
-    double agent_vel_y = v * sw_;
+    agent_vel_x = -1.0 * (v * cw_);
+    agent_vel_y = v * sw_;
 
     CN_T(2);
     // ---- lidar raycast (XACRO:150-178) + UTL:375-392 sanitise + UTL:110-126 end points ----------
-    double sy, cy;
     if (have_tg) { sy = tg.sy; cy = tg.cy; } else cn_det_sincos_t(p->trig, yaw, &sy, &cy);
-    const double ox = fma(p->lidar_offset_x, cy, px), oy = fma(p->lidar_offset_x, sy, py);
-    const double h = p->room_half;
-    const int nnear = near_peds(p, L, lane, ox, oy, sy, cy);
-    const bool wall_x = !(h - fabs(ox) > p->lidar_max + 1e-6);
-    const bool wall_y = !(h - fabs(oy) > p->lidar_max + 1e-6);
+    ox = fma(p->lidar_offset_x, cy, px); oy = fma(p->lidar_offset_x, sy, py);
+    if constexpr (X2) { if (lane == 0) { mb->px = px; mb->py = py; mb->sy = sy; mb->cy = cy; mb->ox = ox; mb->oy = oy; } }
+    }
+    if constexpr (X2) CN_XBAR();          // wave 1 has advanced the pedestrians, wave 0 the robot (and published where the lidar is)
+    if (w0) {
+    nnear = near_peds(p, L, lane, ox, oy, sy, cy);
+    wall_x = !(h - fabs(ox) > p->lidar_max + 1e-6);
+    wall_y = !(h - fabs(oy) > p->lidar_max + 1e-6);
+    if constexpr (X2) { if (lane == 0) { mb->nnear = nnear; mb->wall_x = wall_x; mb->wall_y = wall_y; } }
+    }
+    if constexpr (X2) {
+        CN_XBAR();                        // the near-pedestrian list and its block words are in LDS
+        if (!w0) {
+            px = mb->px; py = mb->py; sy = mb->sy; cy = mb->cy; ox = mb->ox; oy = mb->oy;
+            nnear = mb->nnear; wall_x = mb->wall_x != 0; wall_y = mb->wall_y != 0;
+        }
+    }
     CN_T(3);
     double smin = 1e300;
     float* o32 = obs32 + (size_t)env * D;
@@ -1186,7 +1213,7 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
     // stage wants it (one VGPR held across the ray loop)
     short assoc_pre = 0;
     if (!GT && p->assoc_fast && lane <= p->assoc_k1 + 1) assoc_pre = p->assoc_tab[lane];
-    for (int k = lane; k < R; k += 64) {
+    for (int k = X2 ? lane + 64 * wv : lane; k < R; k += X2 ? 128 : 64) {     // (X2: the 64-ray blocks alternate between the two waves)
         // (unsigned 32-bit element offsets from the uniform table bases: one VALU instruction per address)
         double lc = 0.0, ls = 0.0, tS = 0.0, tC = 0.0;
         if (!EXT) { lc = cn_ldg(lidc, (unsigned)k); ls = cn_ldg(lids, (unsigned)k); }
@@ -1224,8 +1251,13 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
     CN_T(4);
     smin = cn_wave_min_d(smin);
     CN_SYNC();
+    if constexpr (X2) {
+        if (!w0 && lane == 0) mb->smin1 = smin;
+        CN_XBAR();                        // every ray's end point and range are in LDS
+        if (w0) smin = cn_vmin(smin, mb->smin1);
+    }
 
-    if (step_counter == 0) {  // UTL:405-419 + ENV:287-294: mean spacing of the end points of an all-max scan
+    if (w0 && step_counter == 0) {  // UTL:405-419 + ENV:287-294: mean spacing of the end points of an all-max scan
         // After a simulated reset the robot stands exactly at the spawn pose (reset_simulation, then 10 ms at zero twist),
         // so the value is a constant of the configuration: cn_create evaluates bbox_size() once on the device and the
         // 359 sincos pairs + the strictly serial Python sum() leave the reset path (they made a resetting wavefront 30 %
@@ -1256,6 +1288,7 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
     unsigned short* occlist = L.srcidx;            // free until the type machine records alias sources
     int nocc = 0;
     u64 occraw = 0ull;                             // lane q keeps word q of the ray-space occupancy (range != 0.6)
+    if (w0)
     for (int q = 0; q < W; ++q) {
         const int i = lane + 64 * q;
         const bool oc = (i < n) && (L.dmil[i] != 600);
@@ -1265,13 +1298,18 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
         if (lane == q) occraw = bo;
         nocc += __popcll(bo);
     }
-    if (lane < W) { WORD(M_NONE, lane) = ~0ull; WORD(M_ZERO, lane) = 0ull; WORD(M_EQ, lane) = 0ull; WORD(M_NNONE, lane) = 0ull; WORD(M_NZERO, lane) = 0ull; }
+    if (w0 && lane < W) { WORD(M_NONE, lane) = ~0ull; WORD(M_ZERO, lane) = 0ull; WORD(M_EQ, lane) = 0ull; WORD(M_NNONE, lane) = 0ull; WORD(M_NZERO, lane) = 0ull; }
     CN_SYNC();
+    if constexpr (X2) {
+        if (w0 && lane == 0) mb->nocc = nocc;
+        CN_XBAR();                        // the occupied-ray list
+        if (!w0) nocc = mb->nocc;
+    }
     // two list entries per lane and pass (128 occupied rays cover almost every scan): both entries' index and end-point reads
     // are issued before the first use, and the two divides overlap
     for (int c0 = 0; c0 < nocc; c0 += 128) {
-        const int ca = c0 + lane, cb = ca + 64;
-        const bool two = c0 + 64 < nocc;                   // wave-uniform: is there a second entry for anyone?
+        const int ca = X2 ? c0 + 64 * wv + lane : c0 + lane, cb = X2 ? nocc : ca + 64;      // (X2: one entry per lane, the second 64 are the other wave's)
+        const bool two = !X2 && c0 + 64 < nocc;            // wave-uniform: is there a second entry for anyone?
         const bool va = ca < nocc, vb = cb < nocc;
         const int ia = va ? (int)occlist[ca] : 0, ib = vb ? (int)occlist[cb] : 0;
         const int ja = (ia == n - 1) ? 0 : ia + 1, jb = (ib == n - 1) ? 0 : ib + 1;
@@ -1294,6 +1332,7 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
         if (lastnn == n - 1) lastnn = (nocc > 1) ? (int)occlist[nocc - 2] : -1;
     }
     CN_SYNC();
+    if constexpr (X2) CN_XBAR();          // both waves' gradients
     // change of gradient c[i] = |g[i]-g[i+1]| (None if either is None), recomputed where needed;
     // ray n-1 takes `last_grad`, i.e. c[lastnn] of the last valid gradient before it.
 #define CHG(a_, b_) (((a_) == GNONE || (b_) == GNONE) ? CN_NAN : fabs(cn_div1000((double)(a_)) - cn_div1000((double)(b_))))
@@ -1301,7 +1340,7 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
     if (L.gq[n - 1] != GNONE && lastnn >= 0) clast = CHG(L.gq[lastnn], L.gq[lastnn + 1]);
     CN_T(6);
     for (int c0 = 0; c0 < nocc; c0 += 128) {       // two list entries per lane and pass, reads batched
-        const int ca = c0 + lane, cb = ca + 64;
+        const int ca = X2 ? c0 + 64 * wv + lane : c0 + lane, cb = X2 ? nocc : ca + 64;
         const int ia = (ca < nocc) ? (int)occlist[ca] : n, ib = (cb < nocc) ? (int)occlist[cb] : n;
         const bool va = ia < n - 1, vb = ib < n - 1;     // the machine never visits ray n-1 (ENV:380-381)
         int ga0 = GNONE, ga1 = GNONE, ga2 = GNONE, gb0 = GNONE, gb1 = GNONE, gb2 = GNONE;
@@ -1324,10 +1363,11 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
             }
         };
         flags(va, ia, ga0, ga1, ga2);
-        if (c0 + 64 < nocc) flags(vb, ib, gb0, gb1, gb2);
+        if (!X2 && c0 + 64 < nocc) flags(vb, ib, gb0, gb1, gb2);
     }
 #undef CHG
     CN_SYNC();
+    if constexpr (X2) CN_XBAR();          // both waves' flag bits
     // ENV:372-410 object-type state machine, on the scalar unit, processed in RUNS instead of rays.
     // With z = change == 0, nz = next change == 0, nn = next change is None, eq = |change - next| == 0
     // the per-ray rules (ENV:383-410) are
@@ -1339,7 +1379,7 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
     // so within a 64-ray word the state only changes at the rays that flip du; everything between two
     // flips is a handful of 64-bit mask operations.
     CN_T(7);
-    {
+    if (w0) {
         // lane = word (W <= 16).  (Round 4 also ran this stage on the SCALAR unit, one word after the other with every mask in SGPRs:
         // 283 -> 164 vector instructions but + 670 scalar ones per observation, and 4-8 % SLOWER in every leg -- the scalar unit
         // is shared by the CU's wavefronts and its dependent 64-bit chains do not overlap; profiles/r04/stage_instr_scalar_type_machine.txt.)
@@ -1433,10 +1473,11 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
     // (about 12 instructions instead of about 200 float64 ones per 64 rays x 6 blocks).  If the guard band is touched
     // (T within 1e-7 of an integer, a table cut within 1e-6 of the threshold) or T > 254 the float test runs instead.
     int fe = n, lb = -1, nsegs0 = 0;
-    bool fast_assoc;
-    int K1;
+    bool fast_assoc = false;
+    int K1 = 0;
     short* const amax = (short*)L.gq;                  // region B is free between the type machine and the confirmation
-    if (p->assoc_fast && e.bb == p->bb_spawn && !(CN_ABLATE(32))) {
+    if (!w0) { }
+    else if (p->assoc_fast && e.bb == p->bb_spawn && !(CN_ABLATE(32))) {
         // the table for the spawn pose's box size (every env of a simulated run), built by cn_create: a copy
         // (its first 64 entries were requested before the ray loop, see assoc_pre)
         K1 = p->assoc_k1; fast_assoc = true;
@@ -1468,6 +1509,11 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
         }
         CN_SYNC();
     }
+    if constexpr (X2) {
+        if (w0 && lane == 0) { mb->fast_assoc = fast_assoc; mb->k1 = K1; }
+        CN_XBAR();                        // wave 0's type machine (it rewrites aliased end points) and the association table
+        if (!w0) { fast_assoc = mb->fast_assoc != 0; K1 = mb->k1; }
+    }
     auto note_breaks = [&](int q, u64 bw) {
         if (lane == 0) WORD(M_BRK, q) = bw;
         if (bw) {
@@ -1488,13 +1534,14 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
         for (int q = 0; q < QB; ++q) {
             const int i = lane + 64 * q;
             dxm[q] = 0; dym[q] = 0;
+            if (X2 && (q & 1) != wv) continue;        // (X2: even blocks are wave 0's, odd blocks wave 1's)
             if (q < W && i < n - 1) { dxm[q] = ptx_at<CMP>(L, i) - ptx_at<CMP>(L, i + 1); dym[q] = pty_at<CMP>(L, i) - pty_at<CMP>(L, i + 1); }
         }
 #pragma unroll
         for (int q = 0; q < QB; ++q) { dxm[q] = min(abs(dxm[q]), K1 + 1); lim[q] = (q < W) ? (int)amax[dxm[q]] : 0; }
 #pragma unroll
         for (int q = 0; q < QB; ++q) {
-            if (q < W) {
+            if (q < W && !(X2 && (q & 1) != wv)) {
                 const int i = lane + 64 * q;
                 const bool brk = (i < n) && ((i == n - 1) || abs(dym[q]) > lim[q]);
                 note_breaks(q, __ballot(brk));
@@ -1502,7 +1549,7 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
         }
         q_done = W < QB ? W : QB;
     }
-    for (int q = q_done; q < W; ++q) {
+    for (int q = q_done; q < W && w0; ++q) {          // (X2: whatever the batched path does not cover stays with wave 0)
         int i = lane + 64 * q;
         bool brk = false;
         if (i < n) {
@@ -1515,6 +1562,12 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
             }
         }
         note_breaks(q, __ballot(brk));
+    }
+    if constexpr (X2) {
+        if (!w0 && lane == 0) { mb->fe1 = fe; mb->lb1 = lb; mb->ns1 = nsegs0; }
+        CN_XBAR();                        // both waves' break words
+        if (!w0) return;                  // wave 1 is done: everything from here on is lane = word / segment / track / edge
+        fe = min(fe, mb->fe1); lb = max(lb, mb->lb1); nsegs0 += mb->ns1;
     }
     const int ls = lb + 1;            // start of the last segment
     // ENV:490-502 first <-> last with twice the box
@@ -2346,10 +2399,11 @@ __device__ __forceinline__ double compute_reward(KP p, const Poly& pg, EnvRegs& 
 // blockIdx.x / threadIdx.x / the block's dynamic LDS; the multi-step kernel (FUSED, cn_env_kernel_seq below) calls this once per
 // step, `t` steps into its launch, with the step's actions / outputs at slot t of the caller's buffers.  `act_here`: this
 // environment's (v, w) where the policy kernel's actor left it (LDS) instead of the caller's action array.
-template <bool EXT, bool TWO, int LAYOUT, bool GT = false, int SIM = 0, bool FUSED = false, bool FAIR = false, int SHAPE = 0>
+template <bool EXT, bool TWO, int LAYOUT, bool GT = false, int SIM = 0, bool FUSED = false, bool FAIR = false, int SHAPE = 0, bool X2 = false>
 __device__ __forceinline__ void env_kernel_body(const int env, const int lane, char* const smem, const long long t = 0,
-                                                const float* const act_here = nullptr)
+                                                const float* const act_here = nullptr, const int wv = 0)
 {
+    static_assert(!X2 || (!EXT && !TWO && LAYOUT == 0 && !GT && SIM == 0 && !FUSED), "two wavefronts per environment: the plain step kernel");
     constexpr bool SFENCE = SHAPE == 720 && !FAIR && !FUSED;
     KP p = (KP)__builtin_amdgcn_kernarg_segment_ptr();
     if constexpr (FUSED) {
@@ -2495,8 +2549,11 @@ __device__ __forceinline__ void env_kernel_body(const int env, const int lane, c
     double* gped_v = (double*)(rec + CN_ST_OFF_PED_V(P));
     const double* gped_init = p->ped_init + (size_t)env * 2 * P;
     double* pedv = L.pedv;  // velocities are only needed while advancing
+    if constexpr (!X2) {    // (X2: wave 1 brings the pedestrians in, below, once it is known that this launch is a step)
     for (int i = lane; i < 2 * P; i += 64) { L.ped[i] = gped_p[i]; pedv[i] = gped_v[i]; }
     CN_SYNC();
+    }
+    XMail* const mb = X2 ? (XMail*)(smem + p->wave_lds) : nullptr;
     // compact layout: the velocities' LDS space becomes the end points during the observation
     auto pedv_save = [&]() { if constexpr (CMP) { for (int i = lane; i < 2 * P; i += 64) gped_v[i] = pedv[i]; } };
     auto pedv_restore = [&]() { if constexpr (CMP) { for (int i = lane; i < 2 * P; i += 64) pedv[i] = gped_v[i]; CN_SYNC(); } };
@@ -2517,8 +2574,27 @@ __device__ __forceinline__ void env_kernel_body(const int env, const int lane, c
         if (p->mode == CN_MODE_STEP && p->auto_reset == 2 && e.pending) {
             do_reset = true;
             e.pending = 0;
+            if (!X2 || wv == 0) {
             if (lane == 0) { io_reward()[env] = 0.0f; io_done()[env] = 0; }
             if (io_topk() && lane < K) io_topk()[(size_t)env * K + lane] = -1;
+            }
+        }
+        if constexpr (X2) {
+            if (wv != 0) {
+                // WAVE 1 of the pair: the pedestrians' advance (while wave 0 advances the robot and does the goal geometry), then its
+                // half of the lane = ray stages inside observe(), which it leaves after the association.  A reset launch leaves the
+                // pedestrians to wave 0 (initial poses, two short advances).
+                if (!do_reset) {
+                    for (int i = lane; i < 2 * P; i += 64) { L.ped[i] = gped_p[i]; pedv[i] = gped_v[i]; }
+                    CN_SYNC();
+                    ped_advance<SHAPE == 360>(p, env, lane, L.ped, pedv, e.crowd_ms, e.crowd_ms + p->dt_ms + p->scan_latency_ms, p->dt_ms);
+                }
+                CN_SYNC();
+                int d1 = 0;
+                observe<EXT, GT, FAIR, CMP, true>(p, pg, e, L, env, lane, 0, io_obs(), do_reset ? nullptr : p->final_obs, p->obs_f64, &d1, false,
+                                                  Trig{0.0, 0.0, 0.0, 0.0}, 1, mb);
+                return;
+            }
         }
         int sc = 0;
         float* fin = nullptr;
@@ -2544,6 +2620,7 @@ __device__ __forceinline__ void env_kernel_body(const int env, const int lane, c
                 else {
                 if constexpr (LAYOUT == 0) { step_trig(p, e, lane, rs1, rc1, rs2, rc2, trig); have_trig = true; }
                 // pedestrians: ONE pass over [0, dt + scan latency], cut at dt (they are only looked at by the scan)
+                if constexpr (!X2)
                 ped_advance<SHAPE == 360>(p, env, lane, L.ped, pedv, e.crowd_ms, e.crowd_ms + p->dt_ms + p->scan_latency_ms, p->dt_ms);
                 e.crowd_ms += p->dt_ms + p->scan_latency_ms;
                 if (have_trig) robot_advance_sc(p, e, p->dt_ms, rs1, rc1); else robot_advance(p, e, p->dt_ms);
@@ -2596,7 +2673,7 @@ __device__ __forceinline__ void env_kernel_body(const int env, const int lane, c
         if (ph_obs) {
             if constexpr (LAYOUT == 1) observe_original<EXT>(p, e, L, env, lane, sc, io_obs(), fin, p->obs_f64, &done);
             else if constexpr (LAYOUT == 2) observe_realworld<EXT>(p, pg, e, L, RQ, env, lane, sc, io_obs(), fin, p->obs_f64, &done);
-            else observe<EXT, GT, FAIR, CMP>(p, pg, e, L, env, lane, sc, io_obs(), fin, p->obs_f64, &done, have_trig, trig);
+            else observe<EXT, GT, FAIR, CMP, X2>(p, pg, e, L, env, lane, sc, io_obs(), fin, p->obs_f64, &done, have_trig, trig, 0, mb);
         } else if constexpr (EXT) {
             // Env.compute_reward(state, step_counter, done) on its own (ENV:1046): heading and distance are state[n], state[n+1]
             // (LAYOUT 1: state[-2], state[-1] are what ORIG:324-330 reads), `done` is the caller's
@@ -2825,6 +2902,14 @@ extern "C" __global__ void CN_HOT_BOUNDS cn_env_kernel_fair_s360(CnKParams p) { 
 #endif
 extern "C" __global__ void CN_HOT4_BOUNDS cn_env_kernel_s360_w4(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; const int w_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); env_kernel_body<false, false, 0, false, 0, false, false, 360>(blockIdx.x * (blockDim.x >> 6) + w_, threadIdx.x & 63, cn_smem + (size_t)w_ * ((KP)__builtin_amdgcn_kernarg_segment_ptr())->wave_lds); }
 extern "C" __global__ void CN_HOT4_BOUNDS cn_env_kernel_fair_s360_w4(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; const int w_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); env_kernel_body<false, false, 0, false, 0, false, true, 360>(blockIdx.x * (blockDim.x >> 6) + w_, threadIdx.x & 63, cn_smem + (size_t)w_ * ((KP)__builtin_amdgcn_kernarg_segment_ptr())->wave_lds); }
+// TWO wavefronts per environment (128 threads): small grids -- up to two wavefronts per SIMD would be resident anyway (cn_create: n_envs
+// <= 8 x CUs, BASELINE configs[3]'s 2048-env shard, the N = 1 `Env`) -- where a step is as long as ONE wavefront's dependent chain
+#ifdef CN_TIMING
+#define CN_X2_BOUNDS __launch_bounds__(128)
+#else
+#define CN_X2_BOUNDS __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4)))
+#endif
+extern "C" __global__ void CN_X2_BOUNDS cn_env_kernel_s360_x2(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, false, 0, false, 0, false, false, 360, true>(blockIdx.x, threadIdx.x & 63, cn_smem, 0, nullptr, __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)); }
 extern "C" __global__ void CN_S720_BOUNDS cn_env_kernel_s720(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, false, 0, false, 0, false, false, 720>(blockIdx.x, threadIdx.x, cn_smem); }
 extern "C" __global__ void CN_S720_BOUNDS cn_env_kernel_fair_s720(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, false, 0, false, 0, false, true, 720>(blockIdx.x, threadIdx.x, cn_smem); }
 extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_same(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, true, 0>(blockIdx.x, threadIdx.x, cn_smem); }

@@ -690,6 +690,55 @@ def test_policy_rollout_kernel_equals_act_then_step(oracle_mod, shape):
         VecEnv(Config(n_envs=16, ped_contact=1)).rollout_policy(a_ref, 2)
 
 
+def test_small_grids_run_two_wavefronts_per_environment_with_identical_results(oracle_mod):
+    """Round 5: up to 8 x CUs environments of the 360-ray shape run cn_env_kernel_s360_x2 -- a workgroup of two
+    wavefronts per environment: wave 1 advances the pedestrians while wave 0 advances the robot, then takes every other 64-ray block
+    of the ray loop, half of the gradient / flag-word entries and half of the association blocks; the hand-offs are LDS + s_barrier.
+    Same arithmetic, same order: observations, rewards, done flags, indices and the whole state record equal the one-wave kernel's
+    (CN_X2=0 at creation) step for step, and the oracle's, across resets (both reset paths of the pair)."""
+    import torch
+    from crowdnav import Config
+    from crowdnav.env import VecEnv, VecEnvGroups
+    N = 300
+    cfg = Config(n_envs=N, n_peds=20, max_steps=25, seed=71, ped_cycle_ms=1400)
+    two = VecEnv(cfg)
+    os.environ["CN_X2"] = "0"
+    try:
+        one = VecEnv(cfg)
+    finally:
+        del os.environ["CN_X2"]
+    assert two.kernel_name("step") == "cn_env_kernel_s360_x2" and one.kernel_name("step") == "cn_env_kernel_s360_w4"
+    orc = oracle_mod.Oracle(cfg.as_dict())
+    oracle_mod.set_num_threads()
+    o2 = two.reset(); o1 = one.reset(); torch.cuda.synchronize()
+    assert torch.equal(o1, o2) and np.array_equal(o2.cpu().numpy(), orc.reset().astype(np.float32))
+    g = torch.Generator(device="cpu").manual_seed(9)
+    n_done = 0
+    for t in range(90):
+        a = torch.stack([torch.rand(N, generator=g) * 0.22, torch.rand(N, generator=g) * 4 - 2], 1).cuda().contiguous()
+        two.step(a, auto_reset="next", want_final=True); one.step(a, auto_reset="next", want_final=True)
+        torch.cuda.synchronize()
+        assert torch.equal(two.obs, one.obs) and torch.equal(two.reward, one.reward) and torch.equal(two.done, one.done), t
+        assert torch.equal(two.topk_idx, one.topk_idx) and torch.equal(two.final_obs, one.final_obs), t
+        oc, rc, dc, ic = orc.step(a.cpu().numpy().astype(np.float64), auto_reset="next")
+        assert np.array_equal(two.done.cpu().numpy(), dc) and np.array_equal(two.topk_idx.cpu().numpy(), ic), t
+        assert np.array_equal(two.obs.cpu().numpy(), oc.astype(np.float32)), t
+        n_done += int(dc.sum())
+    assert n_done > N
+    assert np.array_equal(two.snapshot(), one.snapshot())
+    assert torch.equal(two.counters(), one.counters()) and torch.equal(two.returns()[0], one.returns()[0])
+    # which kernel a launch gets: two waves per environment up to 8 x CUs environments in flight, four environments per workgroup up
+    # to 16 x CUs, one wavefront per workgroup beyond -- stream groups count together (cn_set_group_envs)
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    assert VecEnv(Config(n_envs=8 * ncu)).kernel_name("step") == "cn_env_kernel_s360_x2"
+    assert VecEnv(Config(n_envs=8 * ncu + 1)).kernel_name("step") == "cn_env_kernel_fair_s360_w4"
+    assert VecEnv(Config(n_envs=16 * ncu + 64)).kernel_name("step") == "cn_env_kernel_fair_s360"
+    grp = VecEnvGroups(Config(n_envs=16 * ncu), groups=4)
+    assert grp.envs[0].kernel_name("multi") == "cn_env_kernel_s360_w4"
+    grp = VecEnvGroups(Config(n_envs=8 * ncu), groups=2)
+    assert grp.envs[0].kernel_name("multi") == "cn_env_kernel_s360_x2"
+
+
 ONE_LAUNCH_WORLDS = {
     # name: (config keywords, cn_step_sequence kernel, cn_rollout_policy kernel, environments per policy workgroup)
     "sf": (dict(n_peds=20, ped_mode=2), "cn_env_kernel_seq_sf", "cn_policy_kernel_sf"),
