@@ -62,6 +62,8 @@ def main(d):
         for kname in names:
             rows = [r for r in allrows if r.get("Kernel_Name", "").split("(")[0].strip() == kname]
             gmax = max([int(r.get("Grid_Size", 0) or 0) for r in rows] or [0])
+            if gmax < 1024 * 64:
+                continue                         # not a bench leg (bench.py's stream probe steps a few small handles)
             acc, cnt = {}, {}
             for row in rows:
                 if int(row.get("Grid_Size", 0) or 0) != gmax:
