@@ -41,3 +41,5 @@ if "--speed" in sys.argv:
     for N in (1, 256, 1024, 2048, 4096):
         for x2 in (0, 1):
             print(child("speed", N, x2))
+        if os.environ.get("CN_X2_PRIO_AB"):
+            os.environ["CN_X2_PRIO"] = "1"; print("prio: " + child("speed", N, 1)); del os.environ["CN_X2_PRIO"]
