@@ -2112,26 +2112,61 @@ __device__ __forceinline__ void observe_realworld(KP p, const Poly& pg, EnvRegs&
         Q.g[c] = (int)cn_round_scaled(q, 1000.0, PY2);
     }
     CN_SYNC();
-    // ---- RW:284-333 change of gradient + the object-type machine, on the scalar unit (F is a few dozen) --------------------------
-    // change c(i) = |g[i] - g[i+1]| for i < F-1 and c(F-1) = c(F-2) (`last_grad`); the machine never types entry F-1
-    if (lane == 0) {
-        int last_type = 0, last_src = 0, du = 0;
-        double c1 = (F >= 2) ? fabs(cn_div1000((double)Q.g[0]) - cn_div1000((double)Q.g[1])) : 0.0;   // c(0)
-        for (int i = 0; i + 1 < F; ++i) {
-            const double c0 = c1;                                                                     // c(i)
-            c1 = (i + 2 < F) ? fabs(cn_div1000((double)Q.g[i + 1]) - cn_div1000((double)Q.g[i + 2])) : c0;   // c(i+1); c(F-1) = c(F-2)
-            int ty, src = i;
-            if (c0 == 0) { ty = TY_W; last_type = TY_W; last_src = i; }
-            else if (du != 1) {
-                if (c1 == 0 || fabs(c0 - c1) == 0) { ty = TY_W; last_type = TY_W; last_src = i; du = 0; }
-                else { ty = last_type; src = last_src; du += 1; }        // = last_type: carries THAT entry's range and pose
-            } else {
-                ty = TY_O; last_type = TY_O; last_src = i;
-                if (c1 == 0) du = 0;
+    // ---- RW:284-333 change of gradient + the object-type machine ------------------------------------------------------------------
+    // change c(i) = |g[i] - g[i+1]| for i < F-1 and c(F-1) = c(F-2) (`last_grad`); the machine never types entry F-1.
+    // Round 5: lane = entry, 64 entries at a time (it was one serial loop on lane 0: ~3 600 instructions a step, the largest single
+    // piece of this layout's 4 x cost).  With z = (c(i) == 0), nz = (c(i+1) == 0), eq = (|c(i) - c(i+1)| == 0) entry i maps the
+    // machine's `du` (0 / 1) to
+    //     z: du                         'w' fresh, becomes last_type
+    //    !z, du = 0:  nz or eq -> 0     'w' fresh, becomes last_type;       else -> 1   ALIAS of last_type (its entry's range and pose)
+    //    !z, du = 1:  nz -> 0, else 1   'o' fresh, becomes last_type
+    // -- a map {0, 1} -> {0, 1} per entry: an inclusive scan of map composition over the lanes (6 shuffle steps) gives every entry
+    // its incoming du; the last entry that set last_type below each one is a max-scan of (index, type) keys.
+    {
+        int du_in = 0, key_in = -1;                       // carried over the 64-entry blocks: du, and (index << 2 | type) of the last setter
+        for (int i0 = 0; i0 + 1 < F; i0 += 64) {
+            const int i = i0 + lane;
+            const bool act = i + 1 < F;
+            int f0 = 0, f1 = 1;                           // this entry's map (identity past the end)
+            bool z = false, nzq = false;
+            if (act) {
+                const double g0 = cn_div1000((double)Q.g[i]), g1 = cn_div1000((double)Q.g[i + 1]);
+                const double c0 = fabs(g0 - g1);
+                const double c1 = (i + 2 < F) ? fabs(g1 - cn_div1000((double)Q.g[i + 2])) : c0;
+                z = c0 == 0;
+                const bool nz = c1 == 0, eq = fabs(c0 - c1) == 0;
+                nzq = nz || eq;
+                if (!z) { f0 = nzq ? 0 : 1; f1 = nz ? 0 : 1; }
             }
-            Q.tt[i] = (unsigned char)ty; Q.ts[i] = (unsigned short)src;
+            int s0 = f0, s1 = f1;                         // inclusive composition of the maps of lanes 0 .. lane (earlier entries first)
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int p0 = __shfl_up(s0, d, 64), p1 = __shfl_up(s1, d, 64);        // the block of maps ending d lanes below
+                if (lane >= d) { const int n0 = p0 ? s1 : s0, n1 = p1 ? s1 : s0; s0 = n0; s1 = n1; }   // (mine after theirs)(x) = mine(theirs(x))
+            }
+            int e0 = __shfl_up(s0, 1, 64), e1 = __shfl_up(s1, 1, 64);                  // exclusive: the maps strictly below this lane
+            if (lane == 0) { e0 = 0; e1 = 1; }
+            const int du = du_in ? e1 : e0;               // du on entry i
+            const bool fresh_w = act && (z || (du == 0 && nzq));
+            const bool fresh_o = act && !z && du == 1;
+            const bool alias = act && !z && du == 0 && !nzq;
+            int key = (fresh_w || fresh_o) ? ((i << 2) | (fresh_w ? TY_W : TY_O)) : -1;
+            int mk = key;                                 // inclusive max-scan: the last setter at or below this lane
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const int o_ = __shfl_up(mk, d, 64); if (lane >= d) mk = max(mk, o_); }
+            int below = __shfl_up(mk, 1, 64);
+            if (lane == 0) below = -1;
+            below = max(below, key_in);
+            if (act) {
+                int ty = fresh_w ? TY_W : (fresh_o ? TY_O : 0), src = i;
+                if (alias) { ty = below >= 0 ? (below & 3) : 0; src = below >= 0 ? (below >> 2) : 0; }
+                Q.tt[i] = (unsigned char)ty; Q.ts[i] = (unsigned short)src;
+            }
+            const int so0 = __builtin_amdgcn_readlane(s0, 63), so1 = __builtin_amdgcn_readlane(s1, 63);
+            du_in = du_in ? so1 : so0;
+            key_in = max(key_in, __builtin_amdgcn_readlane(mk, 63));
         }
-        if (F >= 1) { Q.tt[F - 1] = 0; Q.ts[F - 1] = (unsigned short)(F - 1); }
+        if (lane == 0 && F >= 1) { Q.tt[F - 1] = 0; Q.ts[F - 1] = (unsigned short)(F - 1); }
     }
     CN_SYNC();
     // ---- RW:335-366 the typed entries, flattened in order: type, source entry (its rounded range and pose travel with it) --------
@@ -2148,13 +2183,20 @@ __device__ __forceinline__ void observe_realworld(KP p, const Poly& pg, EnvRegs&
     // ---- RW:368-403 segmentation: a segment closes after entry m unless m and m + 1 associate (bit words, entry space) -----------
     u64* const segw = L.w64;                       // ceil(M / 64) words
     const int Wm = (M + 63) >> 6;
+    const bool rw_fast = p->assoc_fast && e.bb == p->bb_spawn;      // cn_create's table for the spawn pose's box size (simulated runs)
     int nseg = 0;
     for (int q = 0; q < Wm; ++q) {
         const int m = lane + 64 * q;
         bool brk = false;
         if (m < M) {
             brk = true;
-            if (m < M - 1) { const int a = ERAY(m), b = ERAY(m + 1); brk = !cn_iou3_positive(PX(a), PY(a), PX(b), PY(b), e.bb, PY2); }
+            if (m < M - 1) {
+                const int a = ERAY(m), b = ERAY(m + 1);
+                if (rw_fast) {        // the main layout's integer association table (same box size, same function of |dx|, |dy| in thousandths)
+                    const int dx_ = abs(L.ptx[a] - L.ptx[b]), dy_ = abs(L.pty[a] - L.pty[b]);
+                    brk = dy_ > (int)p->assoc_tab[min(dx_, p->assoc_k1 + 1)];
+                } else brk = !cn_iou3_positive(PX(a), PY(a), PX(b), PY(b), e.bb, PY2);
+            }
         }
         const u64 bw = __ballot(brk);
         if (lane == 0) segw[q] = bw;
@@ -2183,7 +2225,16 @@ __device__ __forceinline__ void observe_realworld(KP p, const Poly& pg, EnvRegs&
         while (k0 < M) {
             int k1 = k0;
             if (merged && k0 == 0) k1 = first_end + nl;
-            else { for (;;) { const int m = ORD(k1); if ((uni64(segw[m >> 6]) >> (m & 63)) & 1ull) break; ++k1; } }
+            else {
+                // the next segment end at or after k0: past the merged first segment order space is entry space shifted by nl, so it is
+                // the next set bit of the break words (the last entry before the moved range always closes one) -- bit scans instead
+                // of one loop iteration per entry
+                const int off = merged ? nl : 0, m0 = k0 - off;
+                int q = m0 >> 6;
+                u64 bw = uni64(segw[q]) & (~0ull << (m0 & 63));
+                while (!bw) { ++q; bw = uni64(segw[q]); }
+                k1 = 64 * q + __builtin_ctzll(bw) + off;
+            }
             const int len = k1 - k0 + 1;
             int no = 0, nw = 0;
             for (int k = k0 + lane; k <= k1; k += 64) { const int t_ = Q.et[ORD(k)]; no += (t_ == TY_O); nw += (t_ == TY_W); }
@@ -2257,7 +2308,28 @@ __device__ __forceinline__ void observe_realworld(KP p, const Poly& pg, EnvRegs&
         for (int i = 0; i < nt; ++i) {
             const double tx = TRK(CN_TF_PX, i), ty_ = TRK(CN_TF_PY, i), td = TRK(CN_TF_DIST, i);
             int has = 0; double dcp = 0.0;
+            // Round 5: the pre-rejection of the main layout's cone (ENV:818-860 above).  The 64-gon lies inside its circle, so a candidate
+            // segment whose closest point to the centre is farther than the radius (with slack) cannot touch an edge: the same "empty"
+            // result as the ring test, without its 64-lane intersection arithmetic (up to 8 candidates per track, most of them far).
+            unsigned nearm;
+            {
+                const int x2l = hi - lane;
+                bool nearc = false;
+                if (lane < 8 && x2l > lo) {
+                    const double y2l = ((double)x2l * gradient) + bb0;
+                    const double ex = (double)x2l - a0x, ey = y2l - a0y, fx = tx - a0x, fy = ty_ - a0y;
+                    const double ee = ex * ex + ey * ey, ff = fx * fx + fy * fy, num = fx * ex + fy * ey;
+                    const double rr2 = p->min_scan_range * p->min_scan_range * 1.000001;
+                    bool far_;
+                    if (num <= 0.0) far_ = ff > rr2;
+                    else if (num >= ee) far_ = (fx - ex) * (fx - ex) + (fy - ey) * (fy - ey) > rr2;
+                    else far_ = (ff - rr2) * ee > num * num * 1.000001;
+                    nearc = !far_;
+                }
+                nearm = (unsigned)(__ballot(nearc) & 0xffull);
+            }
             for (int x2 = hi; x2 > lo; --x2) {
+                if (!((nearm >> (hi - x2)) & 1u)) { if (p->geos_untyped_empty) break; continue; }       // certainly no intersection
                 const double y2 = ((double)x2 * gradient) + bb0;
                 double hx = 0.0, hy = 0.0;
                 const u64 m = ring_segment(pg, lane, tx, ty_, p->min_scan_range, a0x, a0y, (double)x2, y2, &hx, &hy);
