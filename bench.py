@@ -502,7 +502,13 @@ def main():
         m3 = measure(cfg, list(cands) + ["policy_sequence"], agent=agent, repeats=min(R, 3))
         c5 = Config(n_envs=N, n_peds=100, n_rays=720, k_obstacles=a.k, max_steps=1000, seed=1234, ped_cycle_ms=1400, room_half=2.40)
         m5 = measure(c5, ([Gmax, 1] if Gmax > 1 else [1]) + ["sequence"], lacts=acts, repeats=min(R, 3))
-        for key, m, P_, R_, what in (("configs[2]", m3, 20, 360, "4096 envs x 20 pedestrians x 360 rays, K=8, TD3 actor in the loop "
+        # BASELINE configs[3]'s per-GPU shard: 16384 envs over 8 GPUs = 2048 envs on this one (the other seven would run the same)
+        import dataclasses as _dc
+        c3s = _dc.replace(cfg, n_envs=2048)
+        m3s = measure(c3s, [g for g in (4, 2, 1) if g <= Gmax], lacts=open_loop_actions(2048, 77), repeats=min(R, 3))
+        for key, m, P_, R_, what in (("configs[3]_shard", m3s, 20, 360, "2048 envs x 20 pedestrians x 360 rays, K=8: ONE GPU's shard of BASELINE configs[3] "
+                                      "(16384 envs over 8 GPUs), open loop; two wavefronts per environment (cn_env_kernel_s360_x2)"),
+                                     ("configs[2]", m3, 20, 360, "4096 envs x 20 pedestrians x 360 rays, K=8, TD3 actor in the loop "
                                       "(f32-MFMA actor + exploration noise -> Env.step, closed loop: policy_sequence = the K periods as ONE "
                                       "cn_rollout_policy launch, the actor inside the step kernel; N_groups = a cn_actor_forward -> cn_step chain per stream group)"),
                                      ("configs[4]", m5, 100, 720, "4096 envs x 100 pedestrians x 720 rays, K=8, room 4.8 m, open loop (sequence = the K steps as "
