@@ -2,13 +2,14 @@
 //
 // The caller of the hot path.  A vectorised environment makes the learner the bottleneck: through PyTorch one
 // update is ~150 small kernels (1.2 ms as a hipGraph at batch 128).  Here the same arithmetic is 10 launches for the critic
-// step and 11 more when the actor and the targets move, all float32 like the reference:
+// step and 7 more when the actor and the targets move (the policy's forward pass rides in the target policy's launches, the
+// soft updates in the Adam epilogues), all float32 like the reference:
 //   prep        sample the replay on the device (counter-based indices and target-policy noise), gather [s|a], [s2|.], r, d
 //   gemm F      Y = act(X W^T + b) on the f32 matrix cores (v_mfma_f32_16x16x4_f32), up to four networks per launch
 //   gemm G      dX = (dY W) (.) [H > 0]            (back-propagation through a ReLU layer)
 //   gemm H      dW = dY^T X folded into the Adam step of W (and of b): the gradient never exists in memory
 //   head kernels (linear3 + sigmoid / tanh heads forward, TD target + MSE gradient + linear3 backward, actor-loss chain)
-//   soft        target <- (1 - tau) target + tau local
+//   (soft updates: target <- (1 - tau) target + tau local in the epilogue that steps the local weight)
 // The parameters are the caller's (PyTorch nn.Linear storages, weight [out][in]); Adam's moments and step counters live here.
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -28,9 +29,15 @@ thread_local std::string g_td3_err;
 int td3_fail(int code, const std::string& msg) { g_td3_err = msg; return code; }
 #define TD3CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return td3_fail(CN_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
 
-// ---- the one GEMM kernel ------------------------------------------------------------------------------------------------
-// C[i][j] = sum_r A(i, r) B(r, j), a 32 x 32 tile of C per workgroup of four wavefronts (2 x 2 MFMA tiles of 16 x 16), r in
-// chunks of 32 staged through LDS with the next chunk's global loads in flight.  MODE decides what A, B and the epilogue are:
+// ---- the three GEMM kernels ---------------------------------------------------------------------------------------------
+// C[i][j] = sum_r A(i, r) B(r, j) on v_mfma_f32_16x16x4_f32.  These layers are tiny (batch 128 x 256 units x 400 inputs =
+// 26 MFLOP) and latency-bound, so the shape is: many small workgroups (a 16 x 16 / 16 x 32 / 32 x 32 tile of C each), the
+// reduction split over the workgroup's four wavefronts, every operand loaded from global memory STRAIGHT into the MFMA operand
+// registers as 8 / 16-byte vectors along the direction that is contiguous in memory -- no LDS staging, no barrier before the
+// single one of the cross-wavefront sum.  What makes that possible: the order in which a reduction's terms are fed to the
+// matrix core is free as long as both operands use the same order (F), and an operand whose contiguous direction is the OUTPUT
+// index can feed several accumulators from one vector (G: two, H: two x two).  (Rounds 3-4 staged 32 x 32 tiles through LDS in
+// 128-deep chunks, 32 workgroups a network: 9-13 us a launch, now 4-6.)
 //   F  forward          i = row m, j = unit n, r = input k :  A = X[m][k],  B = W[n][k],   C = act(acc + bias[n])
 //   G  backward (data)  i = row m, j = input k, r = unit n :  A = dY[m][n], B = W[n][k],   C = acc * [mask[m][k] > 0]
 //   H  backward (weights) + Adam   i = unit n, j = input k, r = row m :  A = dY[m][n], B = X[m][k],  W[n][k] <- Adam(acc);
@@ -49,122 +56,238 @@ struct GemmJob {
     // F, optional: the first link of the actor-loss chain written next to the activation it is masked by (TD3:268-269,
     // -mean Q1(s, pi(s))): dz_out[m][n] = -(1 / dz_rows) dz_w3[n] [y > 0]  (was a kernel of its own: one more launch)
     const float* dz_w3; float* dz_out; float dz_rows;
+    // H, optional (actor updates): the target network's copy of the weight / bias, soft-updated from the value just stepped
+    // (TD3:287-299; was an 18-tensor launch of its own at the end of the update)
+    float* tgt; float* btgt;
 };
-struct GemmArgs { GemmJob job[4]; float beta1, beta2, eps; };
+struct GemmArgs { GemmJob job[4]; float beta1, beta2, eps, tau; };
+// target <- target (1 - tau) + local tau (TD3:297-299)
+__device__ __forceinline__ float td3_soft(float target, float local, float tau) { return target * (1.f - tau) + local * tau; }
 
-#define TD3_RC 128                 /* depth of a staged chunk: the loads of a whole chunk (16 + 16 per thread) are in flight together, so a
-                                      layer's K = 398 pays four memory round trips, not thirteen (the tiles are latency-bound: 32 workgroups) */
-// NCH > 0 (the reduction is at most NCH chunks deep: NCH = 2 covers the hidden layers' 256, NCH = 4 the input layers' 398 / 400):
-// the global loads of EVERY chunk are issued before the first one is staged -- one memory round trip per tile instead of one per
-// chunk (a tile is a chain of round trips and little else: 11 -> 7 us for the input layers).  Same MFMA order, same results.
-template <int MODE, int NCH = 0>
-__global__ void __launch_bounds__(256) td3_gemm_kernel(GemmArgs args)
+// vectors that are only 4-byte aligned (a row of 398 floats starts on an 8-byte boundary at best): global_load_dwordx2 / x4
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2u_t __attribute__((ext_vector_type(2), aligned(4)));
+typedef float f32x4u_t __attribute__((ext_vector_type(4), aligned(4)));
+__device__ __forceinline__ f32x4_t td3_ld4(const float* __restrict__ p, int c, int n)     // p[c .. c + 3], zero at and past n
+{
+    f32x4_t v = {0.f, 0.f, 0.f, 0.f};
+    if (c < n) v[0] = p[c];
+    if (c + 1 < n) v[1] = p[c + 1];
+    if (c + 2 < n) v[2] = p[c + 2];
+    if (c + 3 < n) v[3] = p[c + 3];
+    return v;
+}
+__device__ __forceinline__ f32x2_t td3_ld2(const float* __restrict__ p, int c, int n)
+{
+    f32x2_t v = {0.f, 0.f};
+    if (c < n) v[0] = p[c];
+    if (c + 1 < n) v[1] = p[c + 1];
+    return v;
+}
+#define TD3_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+// MFMA 16x16x4 operand / result layout, lane l: a = A[row l & 15][k l >> 4], b = B[k l >> 4][col l & 15], acc[q] = C[row 4 (l >> 4) + q][col l & 15]
+
+// F: a 16 x 16 tile per workgroup; the reduction in blocks of 16 inputs, block t = wavefront t mod 4.  Lane (li, lk) loads
+// X[i0 + li][16 t + 4 lk ..+3] and W[j0 + li][the same]: component e of the two vectors is the pair the lane feeds to MFMA e of
+// the block (k = 16 t + 4 lk + e on both sides).
+#define TD3_FKB 8          /* blocks a wavefront has in flight (16 dwordx4 loads) */
+__global__ void __launch_bounds__(256) td3_fwd_kernel(GemmArgs args)
+{
+    const GemmJob& jb = args.job[blockIdx.z];
+    const int I = jb.I, J = jb.J, R = jb.R;
+    const int i0 = blockIdx.y * 16, j0 = blockIdx.x * 16;
+    if (i0 >= I || j0 >= J) return;
+    __shared__ float red[4][4][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
+    const float* __restrict__ arow = jb.A + (size_t)min(i0 + li, I - 1) * jb.lda;       // (rows past the edge: loaded, never stored)
+    const float* __restrict__ brow = jb.B + (size_t)min(j0 + li, J - 1) * jb.ldb;
+    const int nfull = R >> 4;
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    const bool ragged = (R & 15) && (nfull & 3) == wave;          // the last, partial block: loaded first, multiplied last
+    f32x4_t ta = {0.f, 0.f, 0.f, 0.f}, tb = {0.f, 0.f, 0.f, 0.f};
+    if (ragged) { ta = td3_ld4(arow, 16 * nfull + 4 * lk, R); tb = td3_ld4(brow, 16 * nfull + 4 * lk, R); }
+    for (int t0 = wave; t0 < nfull; t0 += 4 * TD3_FKB) {
+        f32x4_t av[TD3_FKB], bv[TD3_FKB];
+#pragma unroll
+        for (int u = 0; u < TD3_FKB; ++u) {
+            const int t = min(t0 + 4 * u, nfull - 1);         // (past the end: a block that is loaded and not used)
+            av[u] = *(const f32x4u_t*)(arow + 16 * t + 4 * lk);
+            bv[u] = *(const f32x4u_t*)(brow + 16 * t + 4 * lk);
+        }
+#pragma unroll
+        for (int u = 0; u < TD3_FKB; ++u) {
+            if (t0 + 4 * u < nfull) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = TD3_MFMA(av[u][e], bv[u][e], acc);
+            }
+        }
+    }
+    if (ragged) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = TD3_MFMA(ta[e], tb[e], acc);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) red[wave][q][lane] = acc[q];
+    __syncthreads();
+    const int q = wave, i = i0 + 4 * lk + q, j = j0 + li;      // thread -> one element of the tile
+    if (i >= I || j >= J) return;
+    float y = ((red[0][q][lane] + red[1][q][lane]) + red[2][q][lane]) + red[3][q][lane];
+    y += jb.bias[j];
+    if (jb.relu) y = fmaxf(y, 0.f);
+    const size_t o = (size_t)i * jb.ldc + j;
+    jb.C[o] = y;
+    if (jb.dz_out) jb.dz_out[o] = y > 0.f ? -jb.dz_w3[j] / jb.dz_rows : 0.f;
+}
+
+// G: a 16 x 32 tile per workgroup.  dY's rows are contiguous along the reduction (as in F), W's along the OUTPUT: lane (li, lk)
+// loads W[16 t + 4 lk + e][j0 + 2 li, + 1] for e = 0..3 -- two accumulators, columns j0 + 2 c and j0 + 2 c + 1.
+#define TD3_GKB 4
+__global__ void __launch_bounds__(256) td3_dgrad_kernel(GemmArgs args)
+{
+    const GemmJob& jb = args.job[blockIdx.z];
+    const int I = jb.I, J = jb.J, R = jb.R;
+    const int i0 = blockIdx.y * 16, j0 = blockIdx.x * 32;
+    if (i0 >= I || j0 >= J) return;
+    __shared__ float red[4][8][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
+    const float* __restrict__ arow = jb.A + (size_t)min(i0 + li, I - 1) * jb.lda;
+    const float* __restrict__ B = jb.B;
+    const int jc = j0 + 2 * li;
+    const int nb = (R + 15) >> 4;
+    const bool inner = j0 + 32 <= J;               // (uniform) no ragged edge along j
+    f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    for (int t0 = wave; t0 < nb; t0 += 4 * TD3_GKB) {
+        f32x4_t av[TD3_GKB];
+        f32x2_t bv[TD3_GKB][4];
+#pragma unroll
+        for (int u = 0; u < TD3_GKB; ++u) {
+            const int t = t0 + 4 * u, k = 16 * t + 4 * lk;
+            if (t < nb && inner && 16 * t + 16 <= R) {
+                av[u] = *(const f32x4u_t*)(arow + k);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bv[u][e] = *(const f32x2u_t*)(B + (size_t)(k + e) * jb.ldb + jc);
+            } else if (t < nb) {
+                av[u] = td3_ld4(arow, k, R);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bv[u][e] = k + e < R ? td3_ld2(B + (size_t)(k + e) * jb.ldb, jc, J) : f32x2_t{0.f, 0.f};
+            } else {
+                av[u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bv[u][e] = f32x2_t{0.f, 0.f};
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < TD3_GKB; ++u) {
+            if (t0 + 4 * u < nb) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { acc0 = TD3_MFMA(av[u][e], bv[u][e][0], acc0); acc1 = TD3_MFMA(av[u][e], bv[u][e][1], acc1); }
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { red[wave][q][lane] = acc0[q]; red[wave][4 + q][lane] = acc1[q]; }
+    __syncthreads();
+    const int q = wave, i = i0 + 4 * lk + q;
+    if (i >= I) return;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int j = jc + c;
+        if (j >= J) continue;
+        const float d = ((red[0][4 * c + q][lane] + red[1][4 * c + q][lane]) + red[2][4 * c + q][lane]) + red[3][4 * c + q][lane];
+        const size_t o = (size_t)i * jb.ldc + j;
+        jb.C[o] = jb.mask[o] > 0.f ? d : 0.f;
+    }
+}
+
+// H: a 32 x 32 tile per workgroup, the batch rows split over the four wavefronts in steps of 4 (step s = wavefront s mod 4).
+// Both operands are contiguous along their output index: lane (li, lk) loads dY[4 s + lk][i0 + 2 li, + 1] and
+// X[4 s + lk][j0 + 2 li, + 1] -- 2 x 2 accumulators, acc[a][b] = the (rows i0 + 2 r + a) x (columns j0 + 2 c + b) sub-lattice.
+#define TD3_HKS 8          /* steps a wavefront has in flight (16 dwordx2 loads, 32 MFMAs) */
+__global__ void __launch_bounds__(256) td3_wgrad_kernel(GemmArgs args)
 {
     const GemmJob& jb = args.job[blockIdx.z];
     const int I = jb.I, J = jb.J, R = jb.R;
     const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
     if (i0 >= I || j0 >= J) return;
-    __shared__ float As[TD3_RC][33];       // [r][i]
-    __shared__ float Bs[TD3_RC][33];       // [r][j]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int lo = tid & 31, hi = tid >> 5;          // hi: 0..7
+    __shared__ float red[4][16][64];
+    __shared__ float bred[4][4][32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
     const float* __restrict__ A = jb.A;
     const float* __restrict__ B = jb.B;
-    constexpr int NQ = TD3_RC / 8;                   // elements per thread, operand and chunk
-    // this thread's elements of a chunk, along the contiguous direction of the operand in memory:
-    //   A: F, G -> A[i * lda + r] (r contiguous): r = lo + 32 (q & 3), i = hi + 8 (q >> 2);   H -> A[r * lda + i] (i contiguous): i = lo, r = hi + 8 q
-    //   B: F    -> B[j * ldb + r] (r contiguous): r = lo + 32 (q & 3), j = hi + 8 (q >> 2);   G, H -> B[r * ldb + j] (j contiguous): j = lo, r = hi + 8 q
-    constexpr int NCHX = NCH > 0 ? NCH : 1;
-    float rra[NCHX][NQ], rrb[NCHX][NQ];
-    auto fetch = [&](int r0, float (&ra)[NQ], float (&rb)[NQ]) {
+    const int ic = i0 + 2 * li, jc = j0 + 2 * li;
+    const int ns = (R + 3) >> 2;
+    const bool inner = i0 + 32 <= I && j0 + 32 <= J;
+    f32x4_t acc[2][2];
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            if (MODE != GEMM_H) { const int r = r0 + lo + 32 * (q & 3), i = i0 + hi + 8 * (q >> 2); ra[q] = (r < R && i < I) ? A[(size_t)i * jb.lda + r] : 0.f; }
-            else { const int i = i0 + lo, r = r0 + hi + 8 * q; ra[q] = (r < R && i < I) ? A[(size_t)r * jb.lda + i] : 0.f; }
-            if (MODE == GEMM_F) { const int r = r0 + lo + 32 * (q & 3), j = j0 + hi + 8 * (q >> 2); rb[q] = (r < R && j < J) ? B[(size_t)j * jb.ldb + r] : 0.f; }
-            else { const int j = j0 + lo, r = r0 + hi + 8 * q; rb[q] = (r < R && j < J) ? B[(size_t)r * jb.ldb + j] : 0.f; }
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    float bs0 = 0.f, bs1 = 0.f;                    // sums of dY over this lane's rows (the bias gradient, first j-tile only)
+    for (int s0 = wave; s0 < ns; s0 += 4 * TD3_HKS) {
+        f32x2_t av[TD3_HKS], bv[TD3_HKS];
+#pragma unroll
+        for (int u = 0; u < TD3_HKS; ++u) {
+            const int s = s0 + 4 * u, k = 4 * s + lk;
+            if (s < ns && inner && 4 * s + 4 <= R) {
+                av[u] = *(const f32x2u_t*)(A + (size_t)k * jb.lda + ic);
+                bv[u] = *(const f32x2u_t*)(B + (size_t)k * jb.ldb + jc);
+            } else if (s < ns && k < R) {
+                av[u] = td3_ld2(A + (size_t)k * jb.lda, ic, I);
+                bv[u] = td3_ld2(B + (size_t)k * jb.ldb, jc, J);
+            } else { av[u] = f32x2_t{0.f, 0.f}; bv[u] = f32x2_t{0.f, 0.f}; }
         }
-    };
-    auto stage = [&](const float (&ra)[NQ], const float (&rb)[NQ]) {
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            if (MODE != GEMM_H) As[lo + 32 * (q & 3)][hi + 8 * (q >> 2)] = ra[q]; else As[hi + 8 * q][lo] = ra[q];
-            if (MODE == GEMM_F) Bs[lo + 32 * (q & 3)][hi + 8 * (q >> 2)] = rb[q]; else Bs[hi + 8 * q][lo] = rb[q];
-        }
-    };
-    const int wi = (wave & 1) * 16, wj = (wave >> 1) * 16;
-    const int li = lane & 15, lk = lane >> 4;
-    f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    float bsum = 0.f;                                // H: sum over the rows of dY[.][i0 + tid] (threads 0..31 of the first j-tile)
-    auto chunk = [&](int r0) {                       // the staged chunk starting at r0: its MFMAs (and H's bias row sums)
-        const int steps = (min(TD3_RC, R - r0) + 3) >> 2;      // k-steps of 4 that hold data (the rest of the chunk is zero)
-        // eight k-steps at a time: their 16 LDS reads are issued together, then the 8 MFMAs (one read pair per MFMA left the LDS
-        // latency exposed on every step: a wavefront is alone on its SIMD here).  Steps past `steps` multiply staged zeros.
-        for (int s0 = 0; s0 < steps; s0 += 8) {
-            float av[8], bv[8];
+        for (int u = 0; u < TD3_HKS; ++u) {
+            if (s0 + 4 * u < ns) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { av[u] = As[4 * (s0 + u) + lk][wi + li]; bv[u] = Bs[4 * (s0 + u) + lk][wj + li]; }
+                for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
-        }
-        if (MODE == GEMM_H && blockIdx.x == 0 && tid < 32) {
-            for (int r = 0; r < 4 * steps; ++r) bsum += As[r][tid];
-        }
-    };
-    if constexpr (NCH > 0) {
-#pragma unroll
-        for (int c = 0; c < NCH; ++c)
-            if (c * TD3_RC < R) fetch(c * TD3_RC, rra[c], rrb[c]);
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            if (c * TD3_RC < R) {
-                stage(rra[c], rrb[c]);
-                __syncthreads();
-                chunk(c * TD3_RC);
-                __syncthreads();
+                    for (int b = 0; b < 2; ++b) acc[a][b] = TD3_MFMA(av[u][a], bv[u][b], acc[a][b]);
+                bs0 += av[u][0]; bs1 += av[u][1];
             }
         }
-    } else {
-        fetch(0, rra[0], rrb[0]);
-        for (int r0 = 0; r0 < R; r0 += TD3_RC) {
-            stage(rra[0], rrb[0]);
-            __syncthreads();
-            if (r0 + TD3_RC < R) fetch(r0 + TD3_RC, rra[0], rrb[0]);
-            chunk(r0);
-            __syncthreads();
-        }
     }
-    // epilogue: acc[q] = C[i0 + wi + 4 lk + q][j0 + wj + li]
-    const int j = j0 + wj + li;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int i = i0 + wi + 4 * lk + q;
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) red[wave][(2 * a + b) * 4 + q][lane] = acc[a][b][q];
+    bred[wave][lk][2 * li] = bs0; bred[wave][lk][2 * li + 1] = bs1;
+    __syncthreads();
+    // thread -> four elements of the tile, 32 consecutive columns per half-wavefront: row ii = 2 (4 g + q) + a, column jj = 2 c + b
+#pragma unroll
+    for (int z = 0; z < 4; ++z) {
+        const int ii = (tid >> 5) + 8 * z, jj = tid & 31;
+        const int a = ii & 1, g = ii >> 3, q = (ii >> 1) & 3, c = jj >> 1, b = jj & 1;
+        const int slot = (2 * a + b) * 4 + q, l = 16 * g + c;
+        const int i = i0 + ii, j = j0 + jj;
         if (i >= I || j >= J) continue;
+        const float gsum = ((red[0][slot][l] + red[1][slot][l]) + red[2][slot][l]) + red[3][slot][l];
         const size_t o = (size_t)i * jb.ldc + j;
-        if (MODE == GEMM_F) {
-            float y = acc[q] + jb.bias[j];
-            if (jb.relu) y = fmaxf(y, 0.f);
-            jb.C[o] = y;
-            if (jb.dz_out) jb.dz_out[o] = y > 0.f ? -jb.dz_w3[j] / jb.dz_rows : 0.f;
-        } else if (MODE == GEMM_G) {
-            jb.C[o] = jb.mask[o] > 0.f ? acc[q] : 0.f;
-        } else {
-            const float g = acc[q];
-            const float m = args.beta1 * jb.m[o] + (1.f - args.beta1) * g;
-            const float v = args.beta2 * jb.v[o] + (1.f - args.beta2) * g * g;
-            jb.m[o] = m; jb.v[o] = v;
-            jb.C[o] -= jb.adam[0] * m / (sqrtf(v) / jb.adam[1] + args.eps);
-        }
+        const float m = args.beta1 * jb.m[o] + (1.f - args.beta1) * gsum;
+        const float v = args.beta2 * jb.v[o] + (1.f - args.beta2) * gsum * gsum;
+        jb.m[o] = m; jb.v[o] = v;
+        const float w = jb.C[o] - jb.adam[0] * m / (sqrtf(v) / jb.adam[1] + args.eps);
+        jb.C[o] = w;
+        if (jb.tgt) jb.tgt[o] = td3_soft(jb.tgt[o], w, args.tau);
     }
-    if (MODE == GEMM_H && blockIdx.x == 0 && tid < 32 && i0 + tid < I && jb.bparam) {
+    if (blockIdx.x == 0 && tid < 32 && i0 + tid < I && jb.bparam) {
         const int i = i0 + tid;
-        const float g = bsum;
-        const float m = args.beta1 * jb.bm[i] + (1.f - args.beta1) * g;
-        const float v = args.beta2 * jb.bv[i] + (1.f - args.beta2) * g * g;
+        float gsum = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) gsum += bred[w][k][tid];
+        const float m = args.beta1 * jb.bm[i] + (1.f - args.beta1) * gsum;
+        const float v = args.beta2 * jb.bv[i] + (1.f - args.beta2) * gsum * gsum;
         jb.bm[i] = m; jb.bv[i] = v;
-        jb.bparam[i] -= jb.adam[0] * m / (sqrtf(v) / jb.adam[1] + args.eps);
+        const float b = jb.bparam[i] - jb.adam[0] * m / (sqrtf(v) / jb.adam[1] + args.eps);
+        jb.bparam[i] = b;
+        if (jb.btgt) jb.btgt[i] = td3_soft(jb.btgt[i], b, args.tau);
     }
 }
+
 
 // ---- small kernels ------------------------------------------------------------------------------------------------------
 struct PrepArgs {
@@ -172,6 +295,7 @@ struct PrepArgs {
     const float* noise_in;                         // explicit target-policy noise [B][2] (unit variance, before the clip) or null
     const int64_t* size_dev;                       // live replay size (device) or null = the rows ARE the batch
     float *xs, *x2, *r, *d, *noise;                // outputs: [B][D + 2] x 2, [B], [B], [B][2]
+    float* xp;                                     // actor updates: a second copy of the states, [B][D + 2]; pi(s) goes into ITS action columns
     float* adam;                                   // [2 optimizers][2]: lr / (1 - beta1^t), sqrt(1 - beta2^t)
     float* steps;                                  // [2] step counters (critics, actor), advanced here
     unsigned long long* counter;                   // update counter (keys the sampling)
@@ -194,6 +318,7 @@ __global__ void __launch_bounds__(256) td3_prep_kernel(PrepArgs p)
     for (int c = tid; c < p.D; c += blockDim.x) {
         p.xs[(size_t)m * Dc + c] = s[c];
         p.x2[(size_t)m * Dc + c] = s2[c];
+        if (p.xp) p.xp[(size_t)m * Dc + c] = s[c];
     }
     if (tid < 2) {
         p.xs[(size_t)m * Dc + p.D + tid] = p.ra[row * 2 + tid];
@@ -236,22 +361,23 @@ __device__ __forceinline__ float td3_wave_sum(float v)
 // Actor.forward's last layer and heads (TD3:101-105) for a batch, one WAVEFRONT per row (lanes over the hidden units): logits =
 // h2 W3^T + b3, action = (sigmoid max_v, tanh max_w) (+ the clipped target-policy noise, not re-clipped to the action bounds:
 // TD3:244-247) written into columns D, D + 1 of x.
-__global__ void __launch_bounds__(256) td3_actor_head_kernel(const float* __restrict__ h2, const float* __restrict__ W3, const float* __restrict__ b3,
-                                                             const float* __restrict__ noise, float* __restrict__ x, float* __restrict__ logits,
-                                                             int B, int H, int Dc, float max_v, float max_w)
+struct ActorHeadJob { const float* h2; const float* W3; const float* b3; const float* noise; float* x; float* logits; };
+struct ActorHeadArgs { ActorHeadJob job[2]; int B, H, Dc; float max_v, max_w; };
+__global__ void __launch_bounds__(256) td3_actor_head_kernel(ActorHeadArgs a)
 {
-    const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (m >= B) return;
-    const float* hr = h2 + (size_t)m * H;
+    const ActorHeadJob& jb = a.job[blockIdx.y];       // y = 0: the target policy on s2 (+ noise); y = 1 (actor updates): the policy on s
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, H = a.H;
+    if (m >= a.B) return;
+    const float* hr = jb.h2 + (size_t)m * H;
     float a0 = 0.f, a1 = 0.f;
-    for (int n = lane; n < H; n += 64) { const float h = hr[n]; a0 = fmaf(h, W3[n], a0); a1 = fmaf(h, W3[H + n], a1); }
-    a0 = td3_wave_sum(a0) + b3[0]; a1 = td3_wave_sum(a1) + b3[1];
+    for (int n = lane; n < H; n += 64) { const float h = hr[n]; a0 = fmaf(h, jb.W3[n], a0); a1 = fmaf(h, jb.W3[H + n], a1); }
+    a0 = td3_wave_sum(a0) + jb.b3[0]; a1 = td3_wave_sum(a1) + jb.b3[1];
     if (lane < 2) {
         const float lg = lane == 0 ? a0 : a1;
-        if (logits) logits[2 * m + lane] = lg;
-        float a = lane == 0 ? max_v / (1.f + expf(-lg)) : max_w * tanhf(lg);
-        if (noise) a += noise[2 * m + lane];
-        x[(size_t)m * Dc + (Dc - 2) + lane] = a;
+        if (jb.logits) jb.logits[2 * m + lane] = lg;
+        float act = lane == 0 ? a.max_v / (1.f + expf(-lg)) : a.max_w * tanhf(lg);
+        if (jb.noise) act += jb.noise[2 * m + lane];
+        jb.x[(size_t)m * a.Dc + (a.Dc - 2) + lane] = act;
     }
 }
 // Critic.forward's last layer for up to four critics, one wavefront per (critic, row): q[z][m] = h2[z][m] . W3[z] + b3[z]
@@ -277,7 +403,8 @@ struct CriticHeadBwdArgs {
     const float* q[2]; const float* h2[2]; float* dz2[2];
     float* W3[2]; float* b3[2]; float* m3[2]; float* v3[2]; float* mb3[2]; float* vb3[2];
     const float* adam; float* loss;
-    int B, H; float gamma, beta1, beta2, eps;
+    float* W3t[2]; float* b3t[2];                  // actor updates: the target critics' last layers (soft-updated here), else null
+    int B, H; float gamma, beta1, beta2, eps, tau;
 };
 __global__ void __launch_bounds__(256) td3_critic_head_bwd_kernel(CriticHeadBwdArgs a)
 {
@@ -305,7 +432,9 @@ __global__ void __launch_bounds__(256) td3_critic_head_bwd_kernel(CriticHeadBwdA
             const float mm = a.beta1 * a.mb3[z][0] + (1.f - a.beta1) * g;
             const float vv = a.beta2 * a.vb3[z][0] + (1.f - a.beta2) * g * g;
             a.mb3[z][0] = mm; a.vb3[z][0] = vv;
-            a.b3[z][0] -= a.adam[0] * mm / (sqrtf(vv) / a.adam[1] + a.eps);
+            const float b = a.b3[z][0] - a.adam[0] * mm / (sqrtf(vv) / a.adam[1] + a.eps);
+            a.b3[z][0] = b;
+            if (a.b3t[z]) a.b3t[z][0] = td3_soft(a.b3t[z][0], b, a.tau);
         }
     }
     const int rg = tid >> 6, c = tid & 63, n = blockIdx.x * 64 + c;
@@ -332,10 +461,12 @@ __global__ void __launch_bounds__(256) td3_critic_head_bwd_kernel(CriticHeadBwdA
         const float mm = a.beta1 * a.m3[z][n] + (1.f - a.beta1) * g;
         const float vv = a.beta2 * a.v3[z][n] + (1.f - a.beta2) * g * g;
         a.m3[z][n] = mm; a.v3[z][n] = vv;
-        a.W3[z][n] = w - a.adam[0] * mm / (sqrtf(vv) / a.adam[1] + a.eps);
+        const float wn = w - a.adam[0] * mm / (sqrtf(vv) / a.adam[1] + a.eps);
+        a.W3[z][n] = wn;
+        if (a.W3t[z]) a.W3t[z][n] = td3_soft(a.W3t[z][n], wn, a.tau);
     }
 }
-// actor loss -mean Q1(s, pi(s)) (TD3:268-269): its first link (d/dh2 of the critic) is td3_gemm_kernel<F>'s optional epilogue;
+// actor loss -mean Q1(s, pi(s)) (TD3:268-269): its first link (d/dh2 of the critic) is td3_fwd_kernel's optional epilogue;
 // then through the critic's first layer to the action (the two action columns of W1) and through the heads' derivatives to the
 // logits, one wavefront per row:  da[m][o] = sum_n dz1q[m][n] W1q[n][D + o];  dlogit = da (.) (max_v s (1 - s), max_w (1 - t^2))
 __global__ void __launch_bounds__(256) td3_dlogit_kernel(const float* __restrict__ dz1q, const float* __restrict__ W1q, const float* __restrict__ logits,
@@ -364,8 +495,9 @@ __global__ void __launch_bounds__(256) td3_dlogit_kernel(const float* __restrict
 struct ActorHeadBwdArgs {
     const float *dl, *h2a; float* dz2a;
     float *W3, *b3, *m3, *v3, *mb3, *vb3;
+    float *W3t, *b3t;                              // the target actor's last layer, soft-updated here
     const float* adam;
-    int B, H; float beta1, beta2, eps;
+    int B, H; float beta1, beta2, eps, tau;
 };
 __global__ void __launch_bounds__(256) td3_actor_head_bwd_kernel(ActorHeadBwdArgs a)
 {
@@ -380,7 +512,9 @@ __global__ void __launch_bounds__(256) td3_actor_head_bwd_kernel(ActorHeadBwdArg
         const float mm = a.beta1 * a.mb3[tid] + (1.f - a.beta1) * g;
         const float vv = a.beta2 * a.vb3[tid] + (1.f - a.beta2) * g * g;
         a.mb3[tid] = mm; a.vb3[tid] = vv;
-        a.b3[tid] -= a.adam[2] * mm / (sqrtf(vv) / a.adam[3] + a.eps);
+        const float b = a.b3[tid] - a.adam[2] * mm / (sqrtf(vv) / a.adam[3] + a.eps);
+        a.b3[tid] = b;
+        a.b3t[tid] = td3_soft(a.b3t[tid], b, a.tau);
     }
     const int rg = tid >> 6, c = tid & 63, n = blockIdx.x * 64 + c;
     float g0 = 0.f, g1 = 0.f, w0 = 0.f, w1 = 0.f;
@@ -411,19 +545,12 @@ __global__ void __launch_bounds__(256) td3_actor_head_bwd_kernel(ActorHeadBwdArg
             const float mm = a.beta1 * a.m3[ix] + (1.f - a.beta1) * g;
             const float vv = a.beta2 * a.v3[ix] + (1.f - a.beta2) * g * g;
             a.m3[ix] = mm; a.v3[ix] = vv;
-            a.W3[ix] = w[o] - a.adam[2] * mm / (sqrtf(vv) / a.adam[3] + a.eps);
+            const float wn = w[o] - a.adam[2] * mm / (sqrtf(vv) / a.adam[3] + a.eps);
+            a.W3[ix] = wn;
+            a.W3t[ix] = td3_soft(a.W3t[ix], wn, a.tau);
         }
     }
 }
-// soft updates (TD3:287-299): target <- target (1 - tau) + local tau, 18 tensors in one launch
-struct SoftArgs { float* dst[18]; const float* src[18]; int n[18]; float tau; };
-__global__ void __launch_bounds__(256) td3_soft_kernel(SoftArgs a)
-{
-    const int k = blockIdx.y;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n[k]; i += gridDim.x * blockDim.x)
-        a.dst[k][i] = a.dst[k][i] * (1.f - a.tau) + a.src[k][i] * a.tau;
-}
-
 }  // namespace
 
 // ---- host side ------------------------------------------------------------------------------------------------------------
@@ -433,7 +560,7 @@ struct cn_td3_s {
     int B, D, Dc, H;
     float* pool = nullptr;         // one allocation for the whole workspace
     // batch
-    float *xs, *x2, *r, *d, *noise, *logits;
+    float *xs, *x2, *xp, *r, *d, *noise, *logits;
     float *t_h1, *t_h2;            // target actor
     float *c_h1[4], *c_h2[4], *c_q[4];      // q1, q2, q1_t, q2_t
     float *a_h1, *a_h2;            // actor
@@ -453,7 +580,6 @@ struct DevScope {
     ~DevScope() { if (prev >= 0 && prev != want) (void)hipSetDevice(prev); }
 };
 const cn_td3_mlp& net_of(const cn_td3_config& c, int k) { return k == 0 ? c.actor : k == 1 ? c.q1 : c.q2; }
-float* param_of(const cn_td3_mlp& n, int j) { return j == 0 ? n.w1 : j == 1 ? n.b1 : j == 2 ? n.w2 : j == 3 ? n.b2 : j == 4 ? n.w3 : n.b3; }
 size_t param_count(const cn_td3_s* h, int net, int j)
 {
     const size_t in1 = net == 0 ? (size_t)h->D : (size_t)h->Dc, out3 = net == 0 ? 2 : 1, H = (size_t)h->H;
@@ -462,13 +588,12 @@ size_t param_count(const cn_td3_s* h, int net, int j)
 template <int MODE>
 void launch_gemm(const GemmArgs& ga, int njobs, hipStream_t st)
 {
+    constexpr int TI = MODE == GEMM_H ? 32 : 16, TJ = MODE == GEMM_F ? 16 : 32;      // the kernel's tile of C
     int gx = 0, gy = 0;
-    int rmax = 0;
-    for (int z = 0; z < njobs; ++z) { const int x_ = (ga.job[z].J + 31) / 32, y_ = (ga.job[z].I + 31) / 32; gx = x_ > gx ? x_ : gx; gy = y_ > gy ? y_ : gy; rmax = ga.job[z].R > rmax ? ga.job[z].R : rmax; }
-    const int nch = (rmax + TD3_RC - 1) / TD3_RC;          // chunks of the deepest reduction in this launch
-    if (nch == 2) hipLaunchKernelGGL((td3_gemm_kernel<MODE, 2>), dim3(gx, gy, njobs), dim3(256), 0, st, ga);
-    else if (nch == 3 || nch == 4) hipLaunchKernelGGL((td3_gemm_kernel<MODE, 4>), dim3(gx, gy, njobs), dim3(256), 0, st, ga);
-    else hipLaunchKernelGGL((td3_gemm_kernel<MODE>), dim3(gx, gy, njobs), dim3(256), 0, st, ga);
+    for (int z = 0; z < njobs; ++z) { const int x_ = (ga.job[z].J + TJ - 1) / TJ, y_ = (ga.job[z].I + TI - 1) / TI; gx = x_ > gx ? x_ : gx; gy = y_ > gy ? y_ : gy; }
+    if (MODE == GEMM_F) hipLaunchKernelGGL(td3_fwd_kernel, dim3(gx, gy, njobs), dim3(256), 0, st, ga);
+    else if (MODE == GEMM_G) hipLaunchKernelGGL(td3_dgrad_kernel, dim3(gx, gy, njobs), dim3(256), 0, st, ga);
+    else hipLaunchKernelGGL(td3_wgrad_kernel, dim3(gx, gy, njobs), dim3(256), 0, st, ga);
 }
 }  // namespace
 
@@ -491,7 +616,7 @@ extern "C" int cn_td3_create(const cn_td3_config* cfg, int device, cn_td3_handle
     if (!h) return td3_fail(CN_ERR_ARG, "cn_td3_create: out of memory");
     h->cfg = c; h->device = device; h->B = c.batch; h->D = c.obs_dim; h->Dc = c.obs_dim + 2; h->H = c.hidden;
     const size_t B = h->B, Dc = h->Dc, H = h->H;
-    size_t words = 2 * B * Dc + 2 * B + 2 * B + 2 * B          // xs, x2, r, d, noise, logits
+    size_t words = 3 * B * Dc + 2 * B + 2 * B + 2 * B          // xs, x2, xp, r, d, noise, logits
                    + 2 * B * H + 4 * (2 * B * H + B) + 2 * B * H + 4 * B * H + 1 + 4 + 2 + 2;   // t_h, c_h / c_q, a_h, dz, loss, adam, steps, counter
     size_t mom_words = 0;
     for (int net = 0; net < 3; ++net) for (int j = 0; j < 6; ++j) mom_words += 2 * param_count(h, net, j);
@@ -502,7 +627,7 @@ extern "C" int cn_td3_create(const cn_td3_config* cfg, int device, cn_td3_handle
     float* q = h->pool;
     auto take = [&](size_t n) { float* r_ = q; q += n; return r_; };
     h->counter = (unsigned long long*)take(2);       // first: 8-byte aligned
-    h->xs = take(B * Dc); h->x2 = take(B * Dc); h->r = take(B); h->d = take(B); h->noise = take(2 * B); h->logits = take(2 * B);
+    h->xs = take(B * Dc); h->x2 = take(B * Dc); h->xp = take(B * Dc); h->r = take(B); h->d = take(B); h->noise = take(2 * B); h->logits = take(2 * B);
     h->t_h1 = take(B * H); h->t_h2 = take(B * H);
     for (int z = 0; z < 4; ++z) { h->c_h1[z] = take(B * H); h->c_h2[z] = take(B * H); h->c_q[z] = take(B); }
     h->a_h1 = take(B * H); h->a_h2 = take(B * H);
@@ -538,7 +663,7 @@ extern "C" int cn_td3_update(cn_td3_handle h, int do_actor, const cn_td3_batch* 
     memset(&pa, 0, sizeof(pa));
     if (batch) { pa.rs = batch->s; pa.ra = batch->a; pa.rr = batch->r; pa.rs2 = batch->s2; pa.rd = batch->d; pa.noise_in = batch->target_noise; pa.size_dev = nullptr; }
     else { pa.rs = c.replay_s; pa.ra = c.replay_a; pa.rr = c.replay_r; pa.rs2 = c.replay_s2; pa.rd = c.replay_d; pa.noise_in = nullptr; pa.size_dev = c.replay_size_dev; }
-    pa.xs = h->xs; pa.x2 = h->x2; pa.r = h->r; pa.d = h->d; pa.noise = h->noise; pa.adam = h->adam; pa.steps = h->steps; pa.counter = h->counter;
+    pa.xs = h->xs; pa.x2 = h->x2; pa.xp = do_actor ? h->xp : nullptr; pa.r = h->r; pa.d = h->d; pa.noise = h->noise; pa.adam = h->adam; pa.steps = h->steps; pa.counter = h->counter;
     pa.seed = c.seed; pa.B = B; pa.D = D; pa.do_actor = do_actor ? 1 : 0;
     pa.lr_critic = c.lr_critic; pa.lr_actor = c.lr_actor; pa.beta1 = c.beta1; pa.beta2 = c.beta2; pa.noise_std = c.noise_std; pa.noise_clip = c.noise_clip;
     hipLaunchKernelGGL(td3_prep_kernel, dim3(B), dim3(256), 0, st, pa);
@@ -557,12 +682,22 @@ extern "C" int cn_td3_update(cn_td3_handle h, int do_actor, const cn_td3_batch* 
         j.m = h->mom[net][wj][0]; j.v = h->mom[net][wj][1]; j.bparam = bparam; j.bm = h->mom[net][wj + 1][0]; j.bv = h->mom[net][wj + 1][1]; j.adam = adam;
     };
     GemmArgs ga;
-    ga.beta1 = c.beta1; ga.beta2 = c.beta2; ga.eps = c.eps;
-    // 1-3. target actor on s2 -> a2 = pi_t(s2) + clipped noise, into x2's action columns (TD3:238-247)
-    fwd_job(ga.job[0], h->x2, Dc, D, c.actor_t.w1, c.actor_t.b1, h->t_h1); launch_gemm<GEMM_F>(ga, 1, st);
-    fwd_job(ga.job[0], h->t_h1, H, H, c.actor_t.w2, c.actor_t.b2, h->t_h2); launch_gemm<GEMM_F>(ga, 1, st);
-    hipLaunchKernelGGL(td3_actor_head_kernel, dim3((B + 3) / 4), dim3(256), 0, st, h->t_h2, c.actor_t.w3, c.actor_t.b3, h->noise, h->x2,
-                       (float*)nullptr, B, H, Dc, c.max_v, c.max_w);
+    ga.beta1 = c.beta1; ga.beta2 = c.beta2; ga.eps = c.eps; ga.tau = c.tau;
+    // 1-3. target actor on s2 -> a2 = pi_t(s2) + clipped noise, into x2's action columns (TD3:238-247).  On actor updates the
+    // policy's own forward pass pi(s) (TD3:268; it reads the actor, which the critic step does not touch) rides in the same three
+    // launches as a second job and lands in xp's action columns -- xs keeps the batch's actions for steps 4 and 9.
+    const int na = do_actor ? 2 : 1;
+    fwd_job(ga.job[0], h->x2, Dc, D, c.actor_t.w1, c.actor_t.b1, h->t_h1);
+    fwd_job(ga.job[1], h->xp, Dc, D, c.actor.w1, c.actor.b1, h->a_h1);
+    launch_gemm<GEMM_F>(ga, na, st);
+    fwd_job(ga.job[0], h->t_h1, H, H, c.actor_t.w2, c.actor_t.b2, h->t_h2);
+    fwd_job(ga.job[1], h->a_h1, H, H, c.actor.w2, c.actor.b2, h->a_h2);
+    launch_gemm<GEMM_F>(ga, na, st);
+    ActorHeadArgs ha;
+    ha.job[0] = {h->t_h2, c.actor_t.w3, c.actor_t.b3, h->noise, h->x2, nullptr};
+    ha.job[1] = {h->a_h2, c.actor.w3, c.actor.b3, nullptr, h->xp, h->logits};
+    ha.B = B; ha.H = H; ha.Dc = Dc; ha.max_v = c.max_v; ha.max_w = c.max_w;
+    hipLaunchKernelGGL(td3_actor_head_kernel, dim3((B + 3) / 4, na), dim3(256), 0, st, ha);
     // 4-6. the four critics forward: q1, q2 on (s, a); q1_t, q2_t on (s2, a2)
     const cn_td3_mlp* crit[4] = {&c.q1, &c.q2, &c.q1_t, &c.q2_t};
     for (int z = 0; z < 4; ++z) fwd_job(ga.job[z], z < 2 ? h->xs : h->x2, Dc, Dc, crit[z]->w1, crit[z]->b1, h->c_h1[z]);
@@ -580,6 +715,8 @@ extern "C" int cn_td3_update(cn_td3_handle h, int do_actor, const cn_td3_batch* 
         ca.q[z] = h->c_q[z]; ca.h2[z] = h->c_h2[z]; ca.dz2[z] = h->dz2[z]; ca.W3[z] = crit[z]->w3; ca.b3[z] = crit[z]->b3;
         ca.m3[z] = h->mom[1 + z][4][0]; ca.v3[z] = h->mom[1 + z][4][1]; ca.mb3[z] = h->mom[1 + z][5][0]; ca.vb3[z] = h->mom[1 + z][5][1];
     }
+    for (int z = 0; z < 2; ++z) { ca.W3t[z] = do_actor ? crit[2 + z]->w3 : nullptr; ca.b3t[z] = do_actor ? crit[2 + z]->b3 : nullptr; }
+    ca.tau = c.tau;
     ca.adam = h->adam; ca.loss = h->loss; ca.B = B; ca.H = H; ca.gamma = c.gamma; ca.beta1 = c.beta1; ca.beta2 = c.beta2; ca.eps = c.eps;
     hipLaunchKernelGGL(td3_critic_head_bwd_kernel, dim3((H + 63) / 64, 2), dim3(256), (B + 512) * sizeof(float), st, ca);
     // 8. through the second hidden layer: dz1 = (dz2 W2) (.) [h1 > 0]   (W2 is read here, stepped in 9)
@@ -589,16 +726,16 @@ extern "C" int cn_td3_update(cn_td3_handle h, int do_actor, const cn_td3_batch* 
     for (int z = 0; z < 2; ++z) {
         wgrad_job(ga.job[z], h->dz2[z], h->c_h1[z], H, H, crit[z]->w2, crit[z]->b2, 1 + z, 2, h->adam);
         wgrad_job(ga.job[2 + z], h->dz1[z], h->xs, Dc, Dc, crit[z]->w1, crit[z]->b1, 1 + z, 0, h->adam);
+        if (do_actor) {      // the target critics follow in the same epilogue (nothing reads them again in this update)
+            ga.job[z].tgt = crit[2 + z]->w2; ga.job[z].btgt = crit[2 + z]->b2;
+            ga.job[2 + z].tgt = crit[2 + z]->w1; ga.job[2 + z].btgt = crit[2 + z]->b1;
+        }
     }
     launch_gemm<GEMM_H>(ga, 4, st);
     if (do_actor) {
-        // 10-12. pi(s) into xs's action columns (the batch's own actions are not needed any more)
-        fwd_job(ga.job[0], h->xs, Dc, D, c.actor.w1, c.actor.b1, h->a_h1); launch_gemm<GEMM_F>(ga, 1, st);
-        fwd_job(ga.job[0], h->a_h1, H, H, c.actor.w2, c.actor.b2, h->a_h2); launch_gemm<GEMM_F>(ga, 1, st);
-        hipLaunchKernelGGL(td3_actor_head_kernel, dim3((B + 3) / 4), dim3(256), 0, st, h->a_h2, c.actor.w3, c.actor.b3, (const float*)nullptr,
-                           h->xs, h->logits, B, H, Dc, c.max_v, c.max_w);
+        // (10-12, pi(s) into xp's action columns, ran inside launches 1-3)
         // 13-14. the UPDATED first critic on (s, pi(s)) (TD3:268)
-        fwd_job(ga.job[0], h->xs, Dc, Dc, c.q1.w1, c.q1.b1, h->c_h1[0]); launch_gemm<GEMM_F>(ga, 1, st);
+        fwd_job(ga.job[0], h->xp, Dc, Dc, c.q1.w1, c.q1.b1, h->c_h1[0]); launch_gemm<GEMM_F>(ga, 1, st);
         fwd_job(ga.job[0], h->c_h1[0], H, H, c.q1.w2, c.q1.b2, h->c_h2[0]);
         ga.job[0].dz_w3 = c.q1.w3; ga.job[0].dz_out = h->dz2[0]; ga.job[0].dz_rows = (float)B;      // 15. -mean Q's gradient at h2, in the epilogue
         launch_gemm<GEMM_F>(ga, 1, st);
@@ -608,26 +745,16 @@ extern "C" int cn_td3_update(cn_td3_handle h, int do_actor, const cn_td3_batch* 
         ActorHeadBwdArgs aa;
         aa.dl = h->noise; aa.h2a = h->a_h2; aa.dz2a = h->dz2[1];       // (the noise buffer is free by now: it holds dlogit [B][2])
         aa.W3 = c.actor.w3; aa.b3 = c.actor.b3; aa.m3 = h->mom[0][4][0]; aa.v3 = h->mom[0][4][1]; aa.mb3 = h->mom[0][5][0]; aa.vb3 = h->mom[0][5][1];
+        aa.W3t = c.actor_t.w3; aa.b3t = c.actor_t.b3; aa.tau = c.tau;
         aa.adam = h->adam; aa.B = B; aa.H = H; aa.beta1 = c.beta1; aa.beta2 = c.beta2; aa.eps = c.eps;
         hipLaunchKernelGGL(td3_actor_head_bwd_kernel, dim3((H + 63) / 64), dim3(256), (2 * B + 512) * sizeof(float), st, aa);
         // 18-19. the actor's hidden layers
         bwd_data_job(ga.job[0], h->dz2[1], c.actor.w2, h->a_h1, h->dz1[1]); launch_gemm<GEMM_G>(ga, 1, st);
         wgrad_job(ga.job[0], h->dz2[1], h->a_h1, H, H, c.actor.w2, c.actor.b2, 0, 2, h->adam + 2);
         wgrad_job(ga.job[1], h->dz1[1], h->xs, Dc, D, c.actor.w1, c.actor.b1, 0, 0, h->adam + 2);
+        ga.job[0].tgt = c.actor_t.w2; ga.job[0].btgt = c.actor_t.b2; ga.job[1].tgt = c.actor_t.w1; ga.job[1].btgt = c.actor_t.b1;
         launch_gemm<GEMM_H>(ga, 2, st);
-        // 20. soft updates of the three targets
-        SoftArgs sa;
-        const cn_td3_mlp* loc[3] = {&c.q1, &c.q2, &c.actor};
-        const cn_td3_mlp* tgt[3] = {&c.q1_t, &c.q2_t, &c.actor_t};
-        const int netid[3] = {1, 2, 0};
-        int k = 0, nmax = 0;
-        for (int t = 0; t < 3; ++t)
-            for (int j = 0; j < 6; ++j, ++k) {
-                sa.dst[k] = param_of(*tgt[t], j); sa.src[k] = param_of(*loc[t], j); sa.n[k] = (int)param_count(h, netid[t], j);
-                nmax = sa.n[k] > nmax ? sa.n[k] : nmax;
-            }
-        sa.tau = c.tau;
-        hipLaunchKernelGGL(td3_soft_kernel, dim3((nmax + 255) / 256 < 64 ? (nmax + 255) / 256 : 64, 18), dim3(256), 0, st, sa);
+        // (20, the soft updates of the three targets, ran in the Adam epilogues of 7, 9, 17 and 19)
     }
     TD3CHK(hipGetLastError());
     return CN_OK;

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """TD3 updates per second: the eager torch path, Agent.enable_graphs (one hipGraph launch per update) and cn_td3_update
-(Agent.enable_fused_update: 10 + 11 hand-written launches, csrc/crowdnav_td3.hip; also captured into hipGraphs here)."""
+(Agent.enable_fused_update: 10 + 7 hand-written launches, csrc/crowdnav_td3.hip; also captured into hipGraphs here)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "drl-based-mapless-crowd-navigation-with-perceived-risk_amd"))
@@ -21,8 +21,14 @@ def timed(fn, K=400, warm=50):
     return (time.perf_counter() - t0) / K * 1e3
 
 
+ONLY_FUSED = os.environ.get("CN_LEARN_MODES", "") == "fused"      # (tools/learn_profile.sh: the fused chain alone under rocprofv3)
 for B in [int(x) for x in os.environ.get("CN_BATCHES", "128,1024").split(",")]:
     row = []
+    if ONLY_FUSED:
+        ag = Agent(obs_dim=398, device="cuda", seed=0, batch_size=B, memory_size=200000)
+        fill(ag); ag.enable_fused_update()
+        print("batch %5d: fused %.3f ms per update" % (B, timed(ag.learn)), flush=True)
+        continue
     for mode in ("eager", "graphs", "fused"):
         ag = Agent(obs_dim=398, device="cuda", seed=0, batch_size=B, memory_size=200000)
         fill(ag)
