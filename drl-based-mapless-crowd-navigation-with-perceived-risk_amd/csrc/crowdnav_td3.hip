@@ -103,6 +103,7 @@ __global__ void __launch_bounds__(256) td3_fwd_kernel(GemmArgs args)
     const float* __restrict__ brow = jb.B + (size_t)min(j0 + li, J - 1) * jb.ldb;
     const int nfull = R >> 4;
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    const float pbias = jb.bias[min(j0 + li, J - 1)];
     const bool ragged = (R & 15) && (nfull & 3) == wave;          // the last, partial block: loaded first, multiplied last
     f32x4_t ta = {0.f, 0.f, 0.f, 0.f}, tb = {0.f, 0.f, 0.f, 0.f};
     if (ragged) { ta = td3_ld4(arow, 16 * nfull + 4 * lk, R); tb = td3_ld4(brow, 16 * nfull + 4 * lk, R); }
@@ -132,7 +133,7 @@ __global__ void __launch_bounds__(256) td3_fwd_kernel(GemmArgs args)
     const int q = wave, i = i0 + 4 * lk + q, j = j0 + li;      // thread -> one element of the tile
     if (i >= I || j >= J) return;
     float y = ((red[0][q][lane] + red[1][q][lane]) + red[2][q][lane]) + red[3][q][lane];
-    y += jb.bias[j];
+    y += pbias;
     if (jb.relu) y = fmaxf(y, 0.f);
     const size_t o = (size_t)i * jb.ldc + j;
     jb.C[o] = y;
@@ -156,6 +157,9 @@ __global__ void __launch_bounds__(256) td3_dgrad_kernel(GemmArgs args)
     const int nb = (R + 15) >> 4;
     const bool inner = j0 + 32 <= J;               // (uniform) no ragged edge along j
     f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    float pmask[2];                                // the ReLU mask of this thread's two elements, requested before the reduction
+#pragma unroll
+    for (int c = 0; c < 2; ++c) { const int i = i0 + 4 * lk + wave, j = jc + c; pmask[c] = (i < I && j < J) ? jb.mask[(size_t)i * jb.ldc + j] : 0.f; }
     for (int t0 = wave; t0 < nb; t0 += 4 * TD3_GKB) {
         f32x4_t av[TD3_GKB];
         f32x2_t bv[TD3_GKB][4];
@@ -195,7 +199,7 @@ __global__ void __launch_bounds__(256) td3_dgrad_kernel(GemmArgs args)
         if (j >= J) continue;
         const float d = ((red[0][4 * c + q][lane] + red[1][4 * c + q][lane]) + red[2][4 * c + q][lane]) + red[3][4 * c + q][lane];
         const size_t o = (size_t)i * jb.ldc + j;
-        jb.C[o] = jb.mask[o] > 0.f ? d : 0.f;
+        jb.C[o] = pmask[c] > 0.f ? d : 0.f;
     }
 }
 
@@ -216,21 +220,36 @@ __global__ void __launch_bounds__(256) td3_wgrad_kernel(GemmArgs args)
     const float* __restrict__ B = jb.B;
     const int ic = i0 + 2 * li, jc = j0 + 2 * li;
     const int ns = (R + 3) >> 2;
-    const bool inner = i0 + 32 <= I && j0 + 32 <= J;
+    // a lane's pair of rows / columns: 2 = both inside, 1 = only the first (odd extents), 0 = past the edge (a ragged tile: the lane
+    // loads a pair that IS inside and its products are never stored).  Pairs that straddle the edge take the element-wise path.
+    const int amode = ic + 1 < I ? 2 : ic < I ? 1 : 0, bmode = jc + 1 < J ? 2 : jc < J ? 1 : 0;
+    const bool vec = __all(amode != 1 && bmode != 1) && I >= 2 && J >= 2;
+    const int icv = amode == 2 ? ic : 0, jcv = bmode == 2 ? jc : 0;
+    const float adam0 = jb.adam[0], adam1 = jb.adam[1];
     f32x4_t acc[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     float bs0 = 0.f, bs1 = 0.f;                    // sums of dY over this lane's rows (the bias gradient, first j-tile only)
+    // the Adam step's operands of this thread's four elements, requested now: their round trip overlaps the reduction's
+    float pm[4], pv[4], pw[4], pt[4];
+#pragma unroll
+    for (int z = 0; z < 4; ++z) {
+        const int i = i0 + (tid >> 5) + 8 * z, j = j0 + (tid & 31);
+        const bool in = i < I && j < J;
+        const size_t o = in ? (size_t)i * jb.ldc + j : 0;
+        pm[z] = in ? jb.m[o] : 0.f; pv[z] = in ? jb.v[o] : 0.f; pw[z] = in ? jb.C[o] : 0.f; pt[z] = (in && jb.tgt) ? jb.tgt[o] : 0.f;
+    }
     for (int s0 = wave; s0 < ns; s0 += 4 * TD3_HKS) {
         f32x2_t av[TD3_HKS], bv[TD3_HKS];
 #pragma unroll
         for (int u = 0; u < TD3_HKS; ++u) {
             const int s = s0 + 4 * u, k = 4 * s + lk;
-            if (s < ns && inner && 4 * s + 4 <= R) {
-                av[u] = *(const f32x2u_t*)(A + (size_t)k * jb.lda + ic);
-                bv[u] = *(const f32x2u_t*)(B + (size_t)k * jb.ldb + jc);
+            if (s < ns && vec && 4 * s + 4 <= R) {
+                av[u] = *(const f32x2u_t*)(A + (size_t)k * jb.lda + icv);
+                bv[u] = *(const f32x2u_t*)(B + (size_t)k * jb.ldb + jcv);
+                if (amode == 0) av[u] = f32x2_t{0.f, 0.f};
             } else if (s < ns && k < R) {
                 av[u] = td3_ld2(A + (size_t)k * jb.lda, ic, I);
                 bv[u] = td3_ld2(B + (size_t)k * jb.ldb, jc, J);
@@ -265,12 +284,12 @@ __global__ void __launch_bounds__(256) td3_wgrad_kernel(GemmArgs args)
         if (i >= I || j >= J) continue;
         const float gsum = ((red[0][slot][l] + red[1][slot][l]) + red[2][slot][l]) + red[3][slot][l];
         const size_t o = (size_t)i * jb.ldc + j;
-        const float m = args.beta1 * jb.m[o] + (1.f - args.beta1) * gsum;
-        const float v = args.beta2 * jb.v[o] + (1.f - args.beta2) * gsum * gsum;
+        const float m = args.beta1 * pm[z] + (1.f - args.beta1) * gsum;
+        const float v = args.beta2 * pv[z] + (1.f - args.beta2) * gsum * gsum;
         jb.m[o] = m; jb.v[o] = v;
-        const float w = jb.C[o] - jb.adam[0] * m / (sqrtf(v) / jb.adam[1] + args.eps);
+        const float w = pw[z] - adam0 * m / (sqrtf(v) / adam1 + args.eps);
         jb.C[o] = w;
-        if (jb.tgt) jb.tgt[o] = td3_soft(jb.tgt[o], w, args.tau);
+        if (jb.tgt) jb.tgt[o] = td3_soft(pt[z], w, args.tau);
     }
     if (blockIdx.x == 0 && tid < 32 && i0 + tid < I && jb.bparam) {
         const int i = i0 + tid;
@@ -282,7 +301,7 @@ __global__ void __launch_bounds__(256) td3_wgrad_kernel(GemmArgs args)
         const float m = args.beta1 * jb.bm[i] + (1.f - args.beta1) * gsum;
         const float v = args.beta2 * jb.bv[i] + (1.f - args.beta2) * gsum * gsum;
         jb.bm[i] = m; jb.bv[i] = v;
-        const float b = jb.bparam[i] - jb.adam[0] * m / (sqrtf(v) / jb.adam[1] + args.eps);
+        const float b = jb.bparam[i] - adam0 * m / (sqrtf(v) / adam1 + args.eps);
         jb.bparam[i] = b;
         if (jb.btgt) jb.btgt[i] = td3_soft(jb.btgt[i], b, args.tau);
     }
@@ -394,8 +413,8 @@ __global__ void __launch_bounds__(256) td3_q_head_kernel(QHeadArgs a)
     acc = td3_wave_sum(acc);
     if (lane == 0) a.q[z][m] = acc + a.b3[z][0];
 }
-// TD target, MSE gradient and linear3's backward + Adam step for the two critics; workgroup (x, z) = 64 hidden units of critic z,
-// its 256 threads = 4 row groups x 64 units:
+// TD target, MSE gradient and linear3's backward + Adam step for the two critics; workgroup (x, z) = 16 hidden units of critic z,
+// its 256 threads = 16 row groups x 16 units:
 //   y = r + (1 - d) gamma min(q1_t, q2_t)  (TD3:249-252);  loss_z = mean (q_z - y)^2;  dq_z = 2 (q_z - y) / B
 //   dz2_z[m][n] = dq_z[m] W3_z[n] [h2_z[m][n] > 0];  dW3_z[n] = sum_m dq_z[m] h2_z[m][n];  db3_z = sum_m dq_z[m]
 struct CriticHeadBwdArgs {
@@ -406,11 +425,27 @@ struct CriticHeadBwdArgs {
     float* W3t[2]; float* b3t[2];                  // actor updates: the target critics' last layers (soft-updated here), else null
     int B, H; float gamma, beta1, beta2, eps, tau;
 };
+// Shape of this kernel and of td3_actor_head_bwd_kernel: 16 hidden units x 16 row groups per workgroup (H / 16 workgroups a
+// network; four workgroups of 64 units were four round trips of eight loads in series behind the dq phase: 9.8 us), a thread's
+// eight rows of h2 in flight BEFORE the dq phase, the Adam moments too -- the kernel is one memory round trip, not six.
+#define TD3_HC 16
 __global__ void __launch_bounds__(256) td3_critic_head_bwd_kernel(CriticHeadBwdArgs a)
 {
-    extern __shared__ float sm[];                   // dq [B] | partial [4][64] | red [256]
+    extern __shared__ float sm[];                   // dq [B] | partial [16][16] | red [8]
     float* dq = sm; float* part = sm + a.B; float* red = part + 256;
     const int z = blockIdx.y, tid = threadIdx.x;
+    const int rg = tid >> 4, c = tid & 15, n = blockIdx.x * TD3_HC + c;
+    const bool on = n < a.H;
+    const float* __restrict__ h2 = a.h2[z];
+    float hv[8];
+    auto load = [&](int m0) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int m = m0 + 16 * u; hv[u] = (on && m < a.B) ? h2[(size_t)m * a.H + n] : 0.f; }
+    };
+    load(rg);
+    const float w = on ? a.W3[z][n] : 0.f;
+    float m3 = 0.f, v3 = 0.f;
+    if (rg == 0 && on) { m3 = a.m3[z][n]; v3 = a.v3[z][n]; }
     float e2 = 0.f, sdq = 0.f;
     for (int m = tid; m < a.B; m += 256) {
         const float y = a.r[m] + (1.f - a.d[m]) * a.gamma * fminf(a.qt1[m], a.qt2[m]);
@@ -418,48 +453,41 @@ __global__ void __launch_bounds__(256) td3_critic_head_bwd_kernel(CriticHeadBwdA
         const float g = 2.f * e / (float)a.B;
         dq[m] = g; e2 += e * e; sdq += g;
     }
-    __syncthreads();
     if (blockIdx.x == 0) {                           // the loss (critic 1: what Agent.learn returns) and the bias of linear3
-        red[tid] = z == 0 ? e2 : 0.f;
-        __syncthreads();
-        if (tid == 0 && z == 0) { float s_ = 0.f; for (int i = 0; i < 256; ++i) s_ += red[i]; a.loss[0] = s_ / (float)a.B; }
-        __syncthreads();
-        red[tid] = sdq;
-        __syncthreads();
-        if (tid == 0) {
-            float g = 0.f;
-            for (int i = 0; i < 256; ++i) g += red[i];
-            const float mm = a.beta1 * a.mb3[z][0] + (1.f - a.beta1) * g;
-            const float vv = a.beta2 * a.vb3[z][0] + (1.f - a.beta2) * g * g;
-            a.mb3[z][0] = mm; a.vb3[z][0] = vv;
-            const float b = a.b3[z][0] - a.adam[0] * mm / (sqrtf(vv) / a.adam[1] + a.eps);
-            a.b3[z][0] = b;
-            if (a.b3t[z]) a.b3t[z][0] = td3_soft(a.b3t[z][0], b, a.tau);
-        }
+        e2 = td3_wave_sum(e2); sdq = td3_wave_sum(sdq);
+        if ((tid & 63) == 0) { red[tid >> 6] = e2; red[4 + (tid >> 6)] = sdq; }
     }
-    const int rg = tid >> 6, c = tid & 63, n = blockIdx.x * 64 + c;
-    float g = 0.f, w = 0.f;
-    if (n < a.H) {
-        w = a.W3[z][n];
-        // eight rows per pass, their loads issued together: written as load - store - load the stores (which may alias the loads as
-        // far as the compiler knows) kept the 32 L2 round trips of a thread in series -- 13.6 us for a kernel with 64 KB to read
-        for (int m0 = rg; m0 < a.B; m0 += 32) {
-            float hv[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { const int m = m0 + 4 * u; hv[u] = m < a.B ? a.h2[z][(size_t)m * a.H + n] : 0.f; }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int m = m0 + 4 * u;
-                if (m < a.B) { a.dz2[z][(size_t)m * a.H + n] = hv[u] > 0.f ? dq[m] * w : 0.f; g = fmaf(dq[m], hv[u], g); }
-            }
-        }
-    }
-    part[rg * 64 + c] = g;
     __syncthreads();
-    if (rg == 0 && n < a.H) {
-        g = (part[c] + part[64 + c]) + (part[128 + c] + part[192 + c]);
-        const float mm = a.beta1 * a.m3[z][n] + (1.f - a.beta1) * g;
-        const float vv = a.beta2 * a.v3[z][n] + (1.f - a.beta2) * g * g;
+    if (blockIdx.x == 0 && tid == 0) {
+        if (z == 0) a.loss[0] = ((red[0] + red[1]) + (red[2] + red[3])) / (float)a.B;
+        const float g = (red[4] + red[5]) + (red[6] + red[7]);
+        const float mm = a.beta1 * a.mb3[z][0] + (1.f - a.beta1) * g;
+        const float vv = a.beta2 * a.vb3[z][0] + (1.f - a.beta2) * g * g;
+        a.mb3[z][0] = mm; a.vb3[z][0] = vv;
+        const float b = a.b3[z][0] - a.adam[0] * mm / (sqrtf(vv) / a.adam[1] + a.eps);
+        a.b3[z][0] = b;
+        if (a.b3t[z]) a.b3t[z][0] = td3_soft(a.b3t[z][0], b, a.tau);
+    }
+    float g = 0.f;
+    for (int m0 = rg; m0 < a.B; m0 += 128) {
+        float cur[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) cur[u] = hv[u];
+        if (m0 + 128 < a.B) load(m0 + 128);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int m = m0 + 16 * u;
+            if (on && m < a.B) { a.dz2[z][(size_t)m * a.H + n] = cur[u] > 0.f ? dq[m] * w : 0.f; g = fmaf(dq[m], cur[u], g); }
+        }
+    }
+    part[rg * 16 + c] = g;
+    __syncthreads();
+    if (rg == 0 && on) {
+        g = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r += 4) g += (part[r * 16 + c] + part[(r + 1) * 16 + c]) + (part[(r + 2) * 16 + c] + part[(r + 3) * 16 + c]);
+        const float mm = a.beta1 * m3 + (1.f - a.beta1) * g;
+        const float vv = a.beta2 * v3 + (1.f - a.beta2) * g * g;
         a.m3[z][n] = mm; a.v3[z][n] = vv;
         const float wn = w - a.adam[0] * mm / (sqrtf(vv) / a.adam[1] + a.eps);
         a.W3[z][n] = wn;
@@ -490,7 +518,7 @@ __global__ void __launch_bounds__(256) td3_dlogit_kernel(const float* __restrict
 }
 // (Folding this step into the next kernel -- every workgroup re-evaluating it for all rows -- was measured: 14 -> 30 us for that kernel,
 // a wavefront walks its 32 rows as a chain of memory round trips; one row per wavefront over 32 workgroups is 4.8 us.)
-// ... then linear3 of the ACTOR backward + its Adam step; workgroup x = 64 hidden units, 4 row groups x 64 units:
+// ... then linear3 of the ACTOR backward + its Adam step; workgroup x = 16 hidden units, 16 row groups x 16 units:
 //   dz2a[m][n] = sum_o dlogit[m][o] W3a[o][n] [h2a[m][n] > 0];  dW3a[o][n] = sum_m dlogit[m][o] h2a[m][n];  db3a[o] = sum_m dlogit[m][o]
 struct ActorHeadBwdArgs {
     const float *dl, *h2a; float* dz2a;
@@ -501,49 +529,64 @@ struct ActorHeadBwdArgs {
 };
 __global__ void __launch_bounds__(256) td3_actor_head_bwd_kernel(ActorHeadBwdArgs a)
 {
-    extern __shared__ float sm[];                   // dl [2 B] | partial [2][4][64]
+    extern __shared__ float sm[];                   // dl [2 B] | partial [2][16][16]
     float* dl = sm; float* part = sm + 2 * a.B;
     const int tid = threadIdx.x;
+    const int rg = tid >> 4, c = tid & 15, n = blockIdx.x * TD3_HC + c;
+    const bool on = n < a.H;
+    float hv[8];
+    auto load = [&](int m0) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int m = m0 + 16 * u; hv[u] = (on && m < a.B) ? a.h2a[(size_t)m * a.H + n] : 0.f; }
+    };
+    load(rg);
+    const float w0 = on ? a.W3[n] : 0.f, w1 = on ? a.W3[a.H + n] : 0.f;
+    float m3[2] = {0.f, 0.f}, v3[2] = {0.f, 0.f};
+    if (rg == 0 && on) { m3[0] = a.m3[n]; v3[0] = a.v3[n]; m3[1] = a.m3[a.H + n]; v3[1] = a.v3[a.H + n]; }
     for (int t = tid; t < 2 * a.B; t += 256) dl[t] = a.dl[t];
     __syncthreads();
-    if (blockIdx.x == 0 && tid < 2) {
-        float g = 0.f;
-        for (int m = 0; m < a.B; ++m) g += dl[2 * m + tid];
-        const float mm = a.beta1 * a.mb3[tid] + (1.f - a.beta1) * g;
-        const float vv = a.beta2 * a.vb3[tid] + (1.f - a.beta2) * g * g;
-        a.mb3[tid] = mm; a.vb3[tid] = vv;
-        const float b = a.b3[tid] - a.adam[2] * mm / (sqrtf(vv) / a.adam[3] + a.eps);
-        a.b3[tid] = b;
-        a.b3t[tid] = td3_soft(a.b3t[tid], b, a.tau);
+    if (blockIdx.x == 0 && tid < 64) {               // the bias of linear3: lanes over the rows, then across the wavefront
+        float s0 = 0.f, s1 = 0.f;
+        for (int m = tid; m < a.B; m += 64) { s0 += dl[2 * m]; s1 += dl[2 * m + 1]; }
+        s0 = td3_wave_sum(s0); s1 = td3_wave_sum(s1);
+        if (tid < 2) {
+            const float g = tid == 0 ? s0 : s1;
+            const float mm = a.beta1 * a.mb3[tid] + (1.f - a.beta1) * g;
+            const float vv = a.beta2 * a.vb3[tid] + (1.f - a.beta2) * g * g;
+            a.mb3[tid] = mm; a.vb3[tid] = vv;
+            const float b = a.b3[tid] - a.adam[2] * mm / (sqrtf(vv) / a.adam[3] + a.eps);
+            a.b3[tid] = b;
+            a.b3t[tid] = td3_soft(a.b3t[tid], b, a.tau);
+        }
     }
-    const int rg = tid >> 6, c = tid & 63, n = blockIdx.x * 64 + c;
-    float g0 = 0.f, g1 = 0.f, w0 = 0.f, w1 = 0.f;
-    if (n < a.H) {
-        w0 = a.W3[n]; w1 = a.W3[a.H + n];
-        for (int m0 = rg; m0 < a.B; m0 += 32) {     // eight rows per pass (see td3_critic_head_bwd_kernel)
-            float hv[8];
+    float g0 = 0.f, g1 = 0.f;
+    for (int m0 = rg; m0 < a.B; m0 += 128) {
+        float cur[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { const int m = m0 + 4 * u; hv[u] = m < a.B ? a.h2a[(size_t)m * a.H + n] : 0.f; }
+        for (int u = 0; u < 8; ++u) cur[u] = hv[u];
+        if (m0 + 128 < a.B) load(m0 + 128);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int m = m0 + 4 * u;
-                if (m < a.B) {
-                    a.dz2a[(size_t)m * a.H + n] = hv[u] > 0.f ? fmaf(dl[2 * m + 1], w1, dl[2 * m] * w0) : 0.f;
-                    g0 = fmaf(dl[2 * m], hv[u], g0); g1 = fmaf(dl[2 * m + 1], hv[u], g1);
-                }
+        for (int u = 0; u < 8; ++u) {
+            const int m = m0 + 16 * u;
+            if (on && m < a.B) {
+                a.dz2a[(size_t)m * a.H + n] = cur[u] > 0.f ? fmaf(dl[2 * m + 1], w1, dl[2 * m] * w0) : 0.f;
+                g0 = fmaf(dl[2 * m], cur[u], g0); g1 = fmaf(dl[2 * m + 1], cur[u], g1);
             }
         }
     }
-    part[rg * 64 + c] = g0; part[256 + rg * 64 + c] = g1;
+    part[rg * 16 + c] = g0; part[256 + rg * 16 + c] = g1;
     __syncthreads();
-    if (rg == 0 && n < a.H) {
+    if (rg == 0 && on) {
         const float w[2] = {w0, w1};
+#pragma unroll
         for (int o = 0; o < 2; ++o) {
             const float* pp = part + 256 * o;
-            const float g = (pp[c] + pp[64 + c]) + (pp[128 + c] + pp[192 + c]);
+            float g = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; r += 4) g += (pp[r * 16 + c] + pp[(r + 1) * 16 + c]) + (pp[(r + 2) * 16 + c] + pp[(r + 3) * 16 + c]);
             const size_t ix = (size_t)o * a.H + n;
-            const float mm = a.beta1 * a.m3[ix] + (1.f - a.beta1) * g;
-            const float vv = a.beta2 * a.v3[ix] + (1.f - a.beta2) * g * g;
+            const float mm = a.beta1 * m3[o] + (1.f - a.beta1) * g;
+            const float vv = a.beta2 * v3[o] + (1.f - a.beta2) * g * g;
             a.m3[ix] = mm; a.v3[ix] = vv;
             const float wn = w[o] - a.adam[2] * mm / (sqrtf(vv) / a.adam[3] + a.eps);
             a.W3[ix] = wn;
@@ -718,7 +761,7 @@ extern "C" int cn_td3_update(cn_td3_handle h, int do_actor, const cn_td3_batch* 
     for (int z = 0; z < 2; ++z) { ca.W3t[z] = do_actor ? crit[2 + z]->w3 : nullptr; ca.b3t[z] = do_actor ? crit[2 + z]->b3 : nullptr; }
     ca.tau = c.tau;
     ca.adam = h->adam; ca.loss = h->loss; ca.B = B; ca.H = H; ca.gamma = c.gamma; ca.beta1 = c.beta1; ca.beta2 = c.beta2; ca.eps = c.eps;
-    hipLaunchKernelGGL(td3_critic_head_bwd_kernel, dim3((H + 63) / 64, 2), dim3(256), (B + 512) * sizeof(float), st, ca);
+    hipLaunchKernelGGL(td3_critic_head_bwd_kernel, dim3((H + TD3_HC - 1) / TD3_HC, 2), dim3(256), (B + 512) * sizeof(float), st, ca);
     // 8. through the second hidden layer: dz1 = (dz2 W2) (.) [h1 > 0]   (W2 is read here, stepped in 9)
     for (int z = 0; z < 2; ++z) bwd_data_job(ga.job[z], h->dz2[z], crit[z]->w2, h->c_h1[z], h->dz1[z]);
     launch_gemm<GEMM_G>(ga, 2, st);
@@ -747,7 +790,7 @@ extern "C" int cn_td3_update(cn_td3_handle h, int do_actor, const cn_td3_batch* 
         aa.W3 = c.actor.w3; aa.b3 = c.actor.b3; aa.m3 = h->mom[0][4][0]; aa.v3 = h->mom[0][4][1]; aa.mb3 = h->mom[0][5][0]; aa.vb3 = h->mom[0][5][1];
         aa.W3t = c.actor_t.w3; aa.b3t = c.actor_t.b3; aa.tau = c.tau;
         aa.adam = h->adam; aa.B = B; aa.H = H; aa.beta1 = c.beta1; aa.beta2 = c.beta2; aa.eps = c.eps;
-        hipLaunchKernelGGL(td3_actor_head_bwd_kernel, dim3((H + 63) / 64), dim3(256), (2 * B + 512) * sizeof(float), st, aa);
+        hipLaunchKernelGGL(td3_actor_head_bwd_kernel, dim3((H + TD3_HC - 1) / TD3_HC), dim3(256), (2 * B + 512) * sizeof(float), st, aa);
         // 18-19. the actor's hidden layers
         bwd_data_job(ga.job[0], h->dz2[1], c.actor.w2, h->a_h1, h->dz1[1]); launch_gemm<GEMM_G>(ga, 1, st);
         wgrad_job(ga.job[0], h->dz2[1], h->a_h1, H, H, c.actor.w2, c.actor.b2, 0, 2, h->adam + 2);
