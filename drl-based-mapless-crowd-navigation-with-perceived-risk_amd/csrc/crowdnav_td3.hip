@@ -1,15 +1,19 @@
 // crowdnav_td3.hip -- the TD3 update (td3.py:225-285 of the reference: Agent.learn) as a short chain of HIP kernels (gfx950).
 //
 // The caller of the hot path.  A vectorised environment makes the learner the bottleneck: through PyTorch one
-// update is ~150 small kernels (1.2 ms as a hipGraph at batch 128).  Here the same arithmetic is 10 launches for the critic
-// step and 7 more when the actor and the targets move (the policy's forward pass rides in the target policy's launches, the
-// soft updates in the Adam epilogues), all float32 like the reference:
+// update is ~150 small kernels (1.2 ms as a hipGraph at batch 128).  Here the same arithmetic is 8 launches for the critic
+// step and 6 more when the actor and the targets move (rounds 3-4: 10 + 11), all float32 like the reference:
 //   prep        sample the replay on the device (counter-based indices and target-policy noise), gather [s|a], [s2|.], r, d
-//   gemm F      Y = act(X W^T + b) on the f32 matrix cores (v_mfma_f32_16x16x4_f32), up to four networks per launch
-//   gemm G      dX = (dY W) (.) [H > 0]            (back-propagation through a ReLU layer)
-//   gemm H      dW = dY^T X folded into the Adam step of W (and of b): the gradient never exists in memory
-//   head kernels (linear3 + sigmoid / tanh heads forward, TD target + MSE gradient + linear3 backward, actor-loss chain)
-//   (soft updates: target <- (1 - tau) target + tau local in the epilogue that steps the local weight)
+//   gemm F      Y = act(X W^T + b) on the f32 matrix cores (v_mfma_f32_16x16x4_f32), up to four networks per launch;
+//               optional: the policy's last layer + heads evaluated in place of X's action columns, the critic's last layer
+//               as per-tile partial sums of the activation just written, the first link of the actor-loss chain
+//   gemm G      dX = (dY W) (.) [H > 0]   (back-propagation through a ReLU layer); optional: the action gradient's partial sums
+//   gemm H      dW = dY^T X folded into the Adam step of W (and of b) and the soft update of the target's copy: the gradient
+//               never exists in memory
+//   two head-backward kernels (TD target + MSE gradient + the critics' linear3 backward; heads' derivatives + the actor's)
+// Launch order: prep | actor_t L1 (+ actor L1) | L2 (+ L2) | critics L1 (target actions from the head) | critics L2 (+ q partials,
+// tick) | critic heads backward | G | H   and, every policy_delay-th update:  q1 L1 on (s, pi(s)) | q1 L2 (+ dz) | G (+ da
+// partials) | actor head backward | G | H.
 // The parameters are the caller's (PyTorch nn.Linear storages, weight [out][in]); Adam's moments and step counters live here.
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -43,6 +47,32 @@ int td3_fail(int code, const std::string& msg) { g_td3_err = msg; return code; }
 //   H  backward (weights) + Adam   i = unit n, j = input k, r = row m :  A = dY[m][n], B = X[m][k],  W[n][k] <- Adam(acc);
 //      the workgroups of the first j-tile also reduce dY over the rows and step the bias
 enum { GEMM_F = 0, GEMM_G = 1, GEMM_H = 2 };
+// one thread: advance the update counter and the Adam step counters, publish this update's bias corrections.  Runs inside a forward
+// launch (a kernel of its own cost a full launch, ~4.6 us, for six scalar operations): after td3_prep_kernel, which reads the
+// counter, and before the first kernel that reads the corrections (td3_critic_head_bwd_kernel).
+struct TickArgs {
+    float* adam;                                   // [2 optimizers][2]: lr / (1 - beta1^t), sqrt(1 - beta2^t)
+    float* steps;                                  // [2] step counters (critics, actor)
+    double* pw;                                    // [2 optimizers][2]: beta1^t, beta2^t as running products (powf was most of this thread's time)
+    unsigned long long* counter;                   // update counter (keys the sampling)
+    int do_actor; float lr_critic, lr_actor, beta1, beta2;
+};
+__device__ __forceinline__ void td3_tick(const TickArgs& p)
+{
+    *p.counter += 1ull;
+    p.steps[0] += 1.f;
+    const double c1 = p.pw[0] * (double)p.beta1, c2 = p.pw[1] * (double)p.beta2;
+    p.pw[0] = c1; p.pw[1] = c2;
+    p.adam[0] = p.lr_critic / (float)(1.0 - c1);
+    p.adam[1] = sqrtf((float)(1.0 - c2));
+    if (p.do_actor) {
+        p.steps[1] += 1.f;
+        const double a1 = p.pw[2] * (double)p.beta1, a2 = p.pw[3] * (double)p.beta2;
+        p.pw[2] = a1; p.pw[3] = a2;
+        p.adam[2] = p.lr_actor / (float)(1.0 - a1);
+        p.adam[3] = sqrtf((float)(1.0 - a2));
+    }
+}
 struct GemmJob {
     const float* A; const float* B; float* C;      // H: C = the weight being stepped
     const float* bias;                             // F: bias[n]
@@ -59,8 +89,22 @@ struct GemmJob {
     // H, optional (actor updates): the target network's copy of the weight / bias, soft-updated from the value just stepped
     // (TD3:287-299; was an 18-tensor launch of its own at the end of the update)
     float* tgt; float* btgt;
+    // F, optional: the LAST TWO columns of A are not read but evaluated here -- they are a policy's action on the row,
+    // Actor.forward's last layer and heads (TD3:101-105) on the policy's second hidden activation hd_h2 [I][hd_H]:
+    //   logits = hd_h2 hd_W3^T + hd_b3,  action = (sigmoid max_v, tanh max_w) (+ hd_noise: the clipped target-policy noise, not
+    //   re-clipped to the action bounds, TD3:244-247);  R counts the columns before them, B's row has R + 2.
+    // Their share of the product is rank 2 and is added after the cross-wavefront sum.  (Was a launch of its own that wrote the
+    // actions into A.)  hd_logits [I][2], optional: the logits, kept for the backward pass (written by the first column tile).
+    const float* hd_h2; const float* hd_W3; const float* hd_b3; const float* hd_noise; float* hd_logits;
+    int hd_H; float hd_max_v, hd_max_w;
+    // F, optional: Critic.forward's last layer on the activation this job writes, q = C . qp_w3 + qp_b3 (TD3:139), as partial sums
+    // over the tile's 16 units: qp_out[i * qp_nt + column tile] (the bias rides in tile 0; the consumer adds the tiles in order)
+    const float* qp_w3; const float* qp_b3; float* qp_out; int qp_nt;
+    // G, optional: the next link of the actor-loss chain, through the critic's first layer to the action: partial sums over the
+    // tile's 32 units of C[i][j] da_w[j * da_ld + o], o = 0, 1 (the two action columns of W1): da_out[(2 i + o) * da_nt + column tile]
+    const float* da_w; float* da_out; int da_ld, da_nt;
 };
-struct GemmArgs { GemmJob job[4]; float beta1, beta2, eps, tau; };
+struct GemmArgs { GemmJob job[4]; float beta1, beta2, eps, tau; TickArgs tick; int do_tick; };
 // target <- target (1 - tau) + local tau (TD3:297-299)
 __device__ __forceinline__ float td3_soft(float target, float local, float tau) { return target * (1.f - tau) + local * tau; }
 
@@ -96,6 +140,7 @@ __global__ void __launch_bounds__(256) td3_fwd_kernel(GemmArgs args)
     const GemmJob& jb = args.job[blockIdx.z];
     const int I = jb.I, J = jb.J, R = jb.R;
     const int i0 = blockIdx.y * 16, j0 = blockIdx.x * 16;
+    if (args.do_tick && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) td3_tick(args.tick);
     if (i0 >= I || j0 >= J) return;
     __shared__ float red[4][4][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
@@ -107,6 +152,30 @@ __global__ void __launch_bounds__(256) td3_fwd_kernel(GemmArgs args)
     const bool ragged = (R & 15) && (nfull & 3) == wave;          // the last, partial block: loaded first, multiplied last
     f32x4_t ta = {0.f, 0.f, 0.f, 0.f}, tb = {0.f, 0.f, 0.f, 0.f};
     if (ragged) { ta = td3_ld4(arow, 16 * nfull + 4 * lk, R); tb = td3_ld4(brow, 16 * nfull + 4 * lk, R); }
+    // the policy head of this tile's 16 rows: the hidden units in runs of 4, run c of every 16 = (wavefront c >> 2, lane group c & 3)
+    const bool head = jb.hd_h2 != nullptr;
+    __shared__ float hred[4][2][16];
+    float hp0 = 0.f, hp1 = 0.f, wa0 = 0.f, wa1 = 0.f;
+    if (head) {
+        const int HH = jb.hd_H;
+        const float* __restrict__ hrow = jb.hd_h2 + (size_t)min(i0 + li, I - 1) * HH;
+        const float* __restrict__ w3 = jb.hd_W3;
+        wa0 = brow[R]; wa1 = brow[R + 1];
+        if ((HH & 3) == 0) {
+#pragma unroll 4
+            for (int n = 4 * (4 * wave + lk); n < HH; n += 64) {
+                const f32x4_t hv = *(const f32x4u_t*)(hrow + n), u0 = *(const f32x4u_t*)(w3 + n), u1 = *(const f32x4u_t*)(w3 + HH + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { hp0 = fmaf(hv[e], u0[e], hp0); hp1 = fmaf(hv[e], u1[e], hp1); }
+            }
+        } else {
+            for (int n = 4 * (4 * wave + lk); n < HH; n += 64) {
+                const f32x4_t hv = td3_ld4(hrow, n, HH), u0 = td3_ld4(w3, n, HH), u1 = td3_ld4(w3 + HH, n, HH);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { hp0 = fmaf(hv[e], u0[e], hp0); hp1 = fmaf(hv[e], u1[e], hp1); }
+            }
+        }
+    }
     for (int t0 = wave; t0 < nfull; t0 += 4 * TD3_FKB) {
         f32x4_t av[TD3_FKB], bv[TD3_FKB];
 #pragma unroll
@@ -129,15 +198,36 @@ __global__ void __launch_bounds__(256) td3_fwd_kernel(GemmArgs args)
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) red[wave][q][lane] = acc[q];
+    if (head) {
+        hp0 += __shfl_xor(hp0, 16, 64); hp0 += __shfl_xor(hp0, 32, 64);
+        hp1 += __shfl_xor(hp1, 16, 64); hp1 += __shfl_xor(hp1, 32, 64);
+        if (lk == 0) { hred[wave][0][li] = hp0; hred[wave][1][li] = hp1; }
+    }
     __syncthreads();
     const int q = wave, i = i0 + 4 * lk + q, j = j0 + li;      // thread -> one element of the tile
-    if (i >= I || j >= J) return;
+    const bool in = i < I && j < J;
     float y = ((red[0][q][lane] + red[1][q][lane]) + red[2][q][lane]) + red[3][q][lane];
+    if (head && in) {
+        const int r = 4 * lk + q;
+        const float lg0 = (((hred[0][0][r] + hred[1][0][r]) + hred[2][0][r]) + hred[3][0][r]) + jb.hd_b3[0];
+        const float lg1 = (((hred[0][1][r] + hred[1][1][r]) + hred[2][1][r]) + hred[3][1][r]) + jb.hd_b3[1];
+        float a0 = jb.hd_max_v / (1.f + expf(-lg0)), a1 = jb.hd_max_w * tanhf(lg1);
+        if (jb.hd_noise) { a0 += jb.hd_noise[2 * i]; a1 += jb.hd_noise[2 * i + 1]; }
+        if (jb.hd_logits && blockIdx.x == 0 && li == 0) { jb.hd_logits[2 * i] = lg0; jb.hd_logits[2 * i + 1] = lg1; }
+        y = fmaf(a1, wa1, fmaf(a0, wa0, y));
+    }
     y += pbias;
     if (jb.relu) y = fmaxf(y, 0.f);
-    const size_t o = (size_t)i * jb.ldc + j;
-    jb.C[o] = y;
-    if (jb.dz_out) jb.dz_out[o] = y > 0.f ? -jb.dz_w3[j] / jb.dz_rows : 0.f;
+    if (in) {
+        const size_t o = (size_t)i * jb.ldc + j;
+        jb.C[o] = y;
+        if (jb.dz_out) jb.dz_out[o] = y > 0.f ? -jb.dz_w3[j] / jb.dz_rows : 0.f;
+    }
+    if (jb.qp_out) {                                // (uniform) this tile's share of q[i]: the 16 lanes of a row, then tile x's slot
+        float pq = in ? y * jb.qp_w3[j] : 0.f;
+        pq += __shfl_xor(pq, 1, 64); pq += __shfl_xor(pq, 2, 64); pq += __shfl_xor(pq, 4, 64); pq += __shfl_xor(pq, 8, 64);
+        if (li == 0 && i < I) jb.qp_out[(size_t)i * jb.qp_nt + blockIdx.x] = blockIdx.x == 0 ? pq + jb.qp_b3[0] : pq;
+    }
 }
 
 // G: a 16 x 32 tile per workgroup.  dY's rows are contiguous along the reduction (as in F), W's along the OUTPUT: lane (li, lk)
@@ -160,6 +250,12 @@ __global__ void __launch_bounds__(256) td3_dgrad_kernel(GemmArgs args)
     float pmask[2];                                // the ReLU mask of this thread's two elements, requested before the reduction
 #pragma unroll
     for (int c = 0; c < 2; ++c) { const int i = i0 + 4 * lk + wave, j = jc + c; pmask[c] = (i < I && j < J) ? jb.mask[(size_t)i * jb.ldc + j] : 0.f; }
+    float pdw[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    if (jb.da_out) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+            if (jc + c < J) { pdw[c][0] = jb.da_w[(size_t)(jc + c) * jb.da_ld]; pdw[c][1] = jb.da_w[(size_t)(jc + c) * jb.da_ld + 1]; }
+    }
     for (int t0 = wave; t0 < nb; t0 += 4 * TD3_GKB) {
         f32x4_t av[TD3_GKB];
         f32x2_t bv[TD3_GKB][4];
@@ -192,14 +288,21 @@ __global__ void __launch_bounds__(256) td3_dgrad_kernel(GemmArgs args)
     for (int q = 0; q < 4; ++q) { red[wave][q][lane] = acc0[q]; red[wave][4 + q][lane] = acc1[q]; }
     __syncthreads();
     const int q = wave, i = i0 + 4 * lk + q;
-    if (i >= I) return;
+    float dv[2];
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         const int j = jc + c;
-        if (j >= J) continue;
         const float d = ((red[0][4 * c + q][lane] + red[1][4 * c + q][lane]) + red[2][4 * c + q][lane]) + red[3][4 * c + q][lane];
-        const size_t o = (size_t)i * jb.ldc + j;
-        jb.C[o] = pmask[c] > 0.f ? d : 0.f;
+        dv[c] = (i < I && j < J && pmask[c] > 0.f) ? d : 0.f;
+        if (i < I && j < J) jb.C[(size_t)i * jb.ldc + j] = dv[c];
+    }
+    if (jb.da_out) {                                // (uniform)
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            float pa = fmaf(dv[1], pdw[1][o], dv[0] * pdw[0][o]);
+            pa += __shfl_xor(pa, 1, 64); pa += __shfl_xor(pa, 2, 64); pa += __shfl_xor(pa, 4, 64); pa += __shfl_xor(pa, 8, 64);
+            if (li == 0 && i < I) jb.da_out[((size_t)2 * i + o) * jb.da_nt + blockIdx.x] = pa;
+        }
     }
 }
 
@@ -314,18 +417,15 @@ struct PrepArgs {
     const float* noise_in;                         // explicit target-policy noise [B][2] (unit variance, before the clip) or null
     const int64_t* size_dev;                       // live replay size (device) or null = the rows ARE the batch
     float *xs, *x2, *r, *d, *noise;                // outputs: [B][D + 2] x 2, [B], [B], [B][2]
-    float* xp;                                     // actor updates: a second copy of the states, [B][D + 2]; pi(s) goes into ITS action columns
-    float* adam;                                   // [2 optimizers][2]: lr / (1 - beta1^t), sqrt(1 - beta2^t)
-    float* steps;                                  // [2] step counters (critics, actor), advanced here
-    unsigned long long* counter;                   // update counter (keys the sampling)
+    const unsigned long long* counter;             // update counter (keys the sampling; advanced by td3_tick)
     uint64_t seed;
-    int B, D, do_actor;
-    float lr_critic, lr_actor, beta1, beta2, noise_std, noise_clip;
+    int B, D;
+    float noise_std, noise_clip;
 };
 __global__ void __launch_bounds__(256) td3_prep_kernel(PrepArgs p)
 {
     const int m = blockIdx.x, tid = threadIdx.x, Dc = p.D + 2;
-    const unsigned long long cnt = *p.counter;       // (advanced by td3_tick inside td3_q_head_kernel, a later launch on the stream)
+    const unsigned long long cnt = *p.counter;       // (advanced by td3_tick inside a later launch on the stream)
     size_t row = (size_t)m;
     if (p.size_dev) {
         const unsigned long long size = (unsigned long long)(*p.size_dev > 0 ? *p.size_dev : 1);
@@ -337,7 +437,6 @@ __global__ void __launch_bounds__(256) td3_prep_kernel(PrepArgs p)
     for (int c = tid; c < p.D; c += blockDim.x) {
         p.xs[(size_t)m * Dc + c] = s[c];
         p.x2[(size_t)m * Dc + c] = s2[c];
-        if (p.xp) p.xp[(size_t)m * Dc + c] = s[c];
     }
     if (tid < 2) {
         p.xs[(size_t)m * Dc + p.D + tid] = p.ra[row * 2 + tid];
@@ -355,71 +454,20 @@ __global__ void __launch_bounds__(256) td3_prep_kernel(PrepArgs p)
     if (tid == 2) p.r[m] = p.rr[row];
     if (tid == 3) p.d[m] = p.rd[row];
 }
-// one thread: advance the update counter and the Adam step counters, publish this update's bias corrections.  Runs inside
-// td3_q_head_kernel (a kernel of its own cost a full launch, ~4.6 us, for six scalar operations): after td3_prep_kernel, which reads
-// the counter, and before the first kernel that reads the corrections (td3_critic_head_bwd_kernel).
-__device__ __forceinline__ void td3_tick(const PrepArgs& p)
-{
-    *p.counter += 1ull;
-    p.steps[0] += 1.f;
-    p.adam[0] = p.lr_critic / (1.f - powf(p.beta1, p.steps[0]));
-    p.adam[1] = sqrtf(1.f - powf(p.beta2, p.steps[0]));
-    if (p.do_actor) {
-        p.steps[1] += 1.f;
-        p.adam[2] = p.lr_actor / (1.f - powf(p.beta1, p.steps[1]));
-        p.adam[3] = sqrtf(1.f - powf(p.beta2, p.steps[1]));
-    }
-}
-
 __device__ __forceinline__ float td3_wave_sum(float v)
 {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
     return v;
 }
-// Actor.forward's last layer and heads (TD3:101-105) for a batch, one WAVEFRONT per row (lanes over the hidden units): logits =
-// h2 W3^T + b3, action = (sigmoid max_v, tanh max_w) (+ the clipped target-policy noise, not re-clipped to the action bounds:
-// TD3:244-247) written into columns D, D + 1 of x.
-struct ActorHeadJob { const float* h2; const float* W3; const float* b3; const float* noise; float* x; float* logits; };
-struct ActorHeadArgs { ActorHeadJob job[2]; int B, H, Dc; float max_v, max_w; };
-__global__ void __launch_bounds__(256) td3_actor_head_kernel(ActorHeadArgs a)
-{
-    const ActorHeadJob& jb = a.job[blockIdx.y];       // y = 0: the target policy on s2 (+ noise); y = 1 (actor updates): the policy on s
-    const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, H = a.H;
-    if (m >= a.B) return;
-    const float* hr = jb.h2 + (size_t)m * H;
-    float a0 = 0.f, a1 = 0.f;
-    for (int n = lane; n < H; n += 64) { const float h = hr[n]; a0 = fmaf(h, jb.W3[n], a0); a1 = fmaf(h, jb.W3[H + n], a1); }
-    a0 = td3_wave_sum(a0) + jb.b3[0]; a1 = td3_wave_sum(a1) + jb.b3[1];
-    if (lane < 2) {
-        const float lg = lane == 0 ? a0 : a1;
-        if (jb.logits) jb.logits[2 * m + lane] = lg;
-        float act = lane == 0 ? a.max_v / (1.f + expf(-lg)) : a.max_w * tanhf(lg);
-        if (jb.noise) act += jb.noise[2 * m + lane];
-        jb.x[(size_t)m * a.Dc + (a.Dc - 2) + lane] = act;
-    }
-}
-// Critic.forward's last layer for up to four critics, one wavefront per (critic, row): q[z][m] = h2[z][m] . W3[z] + b3[z]
-struct QHeadArgs { const float* h2[4]; const float* W3[4]; const float* b3[4]; float* q[4]; int B, H, nz; PrepArgs tick; };
-__global__ void __launch_bounds__(256) td3_q_head_kernel(QHeadArgs a)
-{
-    if (blockIdx.x == 0 && threadIdx.x == 0) td3_tick(a.tick);
-    const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (t >= a.nz * a.B) return;
-    const int z = t / a.B, m = t - z * a.B;
-    const float* hr = a.h2[z] + (size_t)m * a.H;
-    float acc = 0.f;
-    for (int n = lane; n < a.H; n += 64) acc = fmaf(hr[n], a.W3[z][n], acc);
-    acc = td3_wave_sum(acc);
-    if (lane == 0) a.q[z][m] = acc + a.b3[z][0];
-}
 // TD target, MSE gradient and linear3's backward + Adam step for the two critics; workgroup (x, z) = 16 hidden units of critic z,
 // its 256 threads = 16 row groups x 16 units:
 //   y = r + (1 - d) gamma min(q1_t, q2_t)  (TD3:249-252);  loss_z = mean (q_z - y)^2;  dq_z = 2 (q_z - y) / B
 //   dz2_z[m][n] = dq_z[m] W3_z[n] [h2_z[m][n] > 0];  dW3_z[n] = sum_m dq_z[m] h2_z[m][n];  db3_z = sum_m dq_z[m]
 struct CriticHeadBwdArgs {
-    const float *r, *d, *qt1, *qt2;
-    const float* q[2]; const float* h2[2]; float* dz2[2];
+    const float *r, *d;
+    const float* qpart; int qnt;                   // q of the four critics as partial sums: qpart[(net * B + m) * qnt + tile] (td3_fwd_kernel)
+    const float* h2[2]; float* dz2[2];
     float* W3[2]; float* b3[2]; float* m3[2]; float* v3[2]; float* mb3[2]; float* vb3[2];
     const float* adam; float* loss;
     float* W3t[2]; float* b3t[2];                  // actor updates: the target critics' last layers (soft-updated here), else null
@@ -448,8 +496,19 @@ __global__ void __launch_bounds__(256) td3_critic_head_bwd_kernel(CriticHeadBwdA
     if (rg == 0 && on) { m3 = a.m3[z][n]; v3 = a.v3[z][n]; }
     float e2 = 0.f, sdq = 0.f;
     for (int m = tid; m < a.B; m += 256) {
-        const float y = a.r[m] + (1.f - a.d[m]) * a.gamma * fminf(a.qt1[m], a.qt2[m]);
-        const float e = a.q[z][m] - y;
+        float qs[3];                               // this critic, the two target critics
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float* __restrict__ pp = a.qpart + ((size_t)(k == 0 ? z : 1 + k) * a.B + m) * a.qnt;
+            float acc = 0.f;
+            int t = 0;
+#pragma unroll 4
+            for (; t + 4 <= a.qnt; t += 4) { const f32x4_t v = *(const f32x4u_t*)(pp + t); acc += (v[0] + v[1]) + (v[2] + v[3]); }
+            for (; t < a.qnt; ++t) acc += pp[t];
+            qs[k] = acc;
+        }
+        const float y = a.r[m] + (1.f - a.d[m]) * a.gamma * fminf(qs[1], qs[2]);
+        const float e = qs[0] - y;
         const float g = 2.f * e / (float)a.B;
         dq[m] = g; e2 += e * e; sdq += g;
     }
@@ -495,33 +554,16 @@ __global__ void __launch_bounds__(256) td3_critic_head_bwd_kernel(CriticHeadBwdA
     }
 }
 // actor loss -mean Q1(s, pi(s)) (TD3:268-269): its first link (d/dh2 of the critic) is td3_fwd_kernel's optional epilogue;
-// then through the critic's first layer to the action (the two action columns of W1) and through the heads' derivatives to the
-// logits, one wavefront per row:  da[m][o] = sum_n dz1q[m][n] W1q[n][D + o];  dlogit = da (.) (max_v s (1 - s), max_w (1 - t^2))
-__global__ void __launch_bounds__(256) td3_dlogit_kernel(const float* __restrict__ dz1q, const float* __restrict__ W1q, const float* __restrict__ logits,
-                                                         float* __restrict__ dl, int B, int H, int Dc, float max_v, float max_w)
-{
-    const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (m >= B) return;
-    float a0 = 0.f, a1 = 0.f;
-    for (int n = lane; n < H; n += 64) {
-        const float g = dz1q[(size_t)m * H + n];
-        a0 = fmaf(g, W1q[(size_t)n * Dc + (Dc - 2)], a0); a1 = fmaf(g, W1q[(size_t)n * Dc + (Dc - 1)], a1);
-    }
-    a0 = td3_wave_sum(a0); a1 = td3_wave_sum(a1);
-    if (lane < 2) {
-        const float lg = logits[2 * m + lane];
-        float dh;
-        if (lane == 0) { const float s_ = 1.f / (1.f + expf(-lg)); dh = max_v * s_ * (1.f - s_); }
-        else { const float th = tanhf(lg); dh = max_w * (1.f - th * th); }
-        dl[2 * m + lane] = (lane == 0 ? a0 : a1) * dh;
-    }
-}
-// (Folding this step into the next kernel -- every workgroup re-evaluating it for all rows -- was measured: 14 -> 30 us for that kernel,
-// a wavefront walks its 32 rows as a chain of memory round trips; one row per wavefront over 32 workgroups is 4.8 us.)
+// then through the critic's first layer to the action (the two action columns of W1): da[m][o] = sum_n dz1q[m][n] W1q[n][D + o],
+// partial sums per tile in td3_dgrad_kernel's epilogue, added up here; through the heads' derivatives to the logits:
+// dlogit = da (.) (max_v s (1 - s), max_w (1 - t^2)).  (Rounds 3-4: a kernel of its own, one wavefront per row, 4.8 us.  Every
+// workgroup re-evaluating the whole product for all rows was measured then: 14 -> 30 us.)
 // ... then linear3 of the ACTOR backward + its Adam step; workgroup x = 16 hidden units, 16 row groups x 16 units:
 //   dz2a[m][n] = sum_o dlogit[m][o] W3a[o][n] [h2a[m][n] > 0];  dW3a[o][n] = sum_m dlogit[m][o] h2a[m][n];  db3a[o] = sum_m dlogit[m][o]
 struct ActorHeadBwdArgs {
-    const float *dl, *h2a; float* dz2a;
+    const float* dapart; int dant;                 // the action gradient as partial sums: dapart[(2 m + o) * dant + tile] (td3_dgrad_kernel)
+    const float* logits; float max_v, max_w;       // the policy's logits on the batch (td3_fwd_kernel's head)
+    const float* h2a; float* dz2a;
     float *W3, *b3, *m3, *v3, *mb3, *vb3;
     float *W3t, *b3t;                              // the target actor's last layer, soft-updated here
     const float* adam;
@@ -543,7 +585,20 @@ __global__ void __launch_bounds__(256) td3_actor_head_bwd_kernel(ActorHeadBwdArg
     const float w0 = on ? a.W3[n] : 0.f, w1 = on ? a.W3[a.H + n] : 0.f;
     float m3[2] = {0.f, 0.f}, v3[2] = {0.f, 0.f};
     if (rg == 0 && on) { m3[0] = a.m3[n]; v3[0] = a.v3[n]; m3[1] = a.m3[a.H + n]; v3[1] = a.v3[a.H + n]; }
-    for (int t = tid; t < 2 * a.B; t += 256) dl[t] = a.dl[t];
+    // through the heads' derivatives to the logits: dlogit = da (.) (max_v s (1 - s), max_w (1 - t^2))
+    for (int t = tid; t < 2 * a.B; t += 256) {
+        const float* __restrict__ pp = a.dapart + (size_t)t * a.dant;
+        float da = 0.f;
+        int k = 0;
+#pragma unroll 2
+        for (; k + 4 <= a.dant; k += 4) { const f32x4_t v = *(const f32x4u_t*)(pp + k); da += (v[0] + v[1]) + (v[2] + v[3]); }
+        for (; k < a.dant; ++k) da += pp[k];
+        const float lg = a.logits[t];
+        float dh;
+        if ((t & 1) == 0) { const float s_ = 1.f / (1.f + expf(-lg)); dh = a.max_v * s_ * (1.f - s_); }
+        else { const float th = tanhf(lg); dh = a.max_w * (1.f - th * th); }
+        dl[t] = da * dh;
+    }
     __syncthreads();
     if (blockIdx.x == 0 && tid < 64) {               // the bias of linear3: lanes over the rows, then across the wavefront
         float s0 = 0.f, s1 = 0.f;
@@ -603,14 +658,16 @@ struct cn_td3_s {
     int B, D, Dc, H;
     float* pool = nullptr;         // one allocation for the whole workspace
     // batch
-    float *xs, *x2, *xp, *r, *d, *noise, *logits;
+    float *xs, *x2, *r, *d, *noise, *logits;
     float *t_h1, *t_h2;            // target actor
-    float *c_h1[4], *c_h2[4], *c_q[4];      // q1, q2, q1_t, q2_t
+    float *c_h1[4], *c_h2[4];               // q1, q2, q1_t, q2_t
+    float *qpart, *dapart; int qnt, dant;   // partial sums of the critics' outputs [4][B][qnt] and of the action gradient [B][2][dant]
     float *a_h1, *a_h2;            // actor
     float *dz2[2], *dz1[2];
     float* loss;
     float* adam;                   // [4]
     float* steps;                  // [2]
+    double* pw;                    // [4] running products beta^t
     unsigned long long* counter;
     // Adam moments: actor, q1, q2 x {w1, b1, w2, b2, w3, b3} x {m, v}
     float* mom[3][6][2];
@@ -659,8 +716,9 @@ extern "C" int cn_td3_create(const cn_td3_config* cfg, int device, cn_td3_handle
     if (!h) return td3_fail(CN_ERR_ARG, "cn_td3_create: out of memory");
     h->cfg = c; h->device = device; h->B = c.batch; h->D = c.obs_dim; h->Dc = c.obs_dim + 2; h->H = c.hidden;
     const size_t B = h->B, Dc = h->Dc, H = h->H;
-    size_t words = 3 * B * Dc + 2 * B + 2 * B + 2 * B          // xs, x2, xp, r, d, noise, logits
-                   + 2 * B * H + 4 * (2 * B * H + B) + 2 * B * H + 4 * B * H + 1 + 4 + 2 + 2;   // t_h, c_h / c_q, a_h, dz, loss, adam, steps, counter
+    size_t words = 2 * B * Dc + 2 * B + 2 * B + 2 * B          // xs, x2, r, d, noise, logits
+                   + 2 * B * H + 4 * (2 * B * H) + 2 * B * H + 4 * B * H + 1 + 4 + 2 + 2 + 8  // t_h, c_h, a_h, dz, loss, adam, steps, counter, pw
+                   + 4 * B * ((H + 15) / 16) + 2 * B * ((H + 31) / 32);                        // qpart, dapart
     size_t mom_words = 0;
     for (int net = 0; net < 3; ++net) for (int j = 0; j < 6; ++j) mom_words += 2 * param_count(h, net, j);
     hipError_t e = hipMalloc(&h->pool, (words + mom_words) * sizeof(float));
@@ -670,9 +728,14 @@ extern "C" int cn_td3_create(const cn_td3_config* cfg, int device, cn_td3_handle
     float* q = h->pool;
     auto take = [&](size_t n) { float* r_ = q; q += n; return r_; };
     h->counter = (unsigned long long*)take(2);       // first: 8-byte aligned
-    h->xs = take(B * Dc); h->x2 = take(B * Dc); h->xp = take(B * Dc); h->r = take(B); h->d = take(B); h->noise = take(2 * B); h->logits = take(2 * B);
+    h->pw = (double*)take(8);
+    { const double one[4] = {1.0, 1.0, 1.0, 1.0}; e = hipMemcpy(h->pw, one, sizeof(one), hipMemcpyHostToDevice); }
+    if (e != hipSuccess) { (void)hipFree(h->pool); delete h; return td3_fail(CN_ERR_HIP, std::string("cn_td3_create: hipMemcpy: ") + hipGetErrorString(e)); }
+    h->xs = take(B * Dc); h->x2 = take(B * Dc); h->r = take(B); h->d = take(B); h->noise = take(2 * B); h->logits = take(2 * B);
     h->t_h1 = take(B * H); h->t_h2 = take(B * H);
-    for (int z = 0; z < 4; ++z) { h->c_h1[z] = take(B * H); h->c_h2[z] = take(B * H); h->c_q[z] = take(B); }
+    for (int z = 0; z < 4; ++z) { h->c_h1[z] = take(B * H); h->c_h2[z] = take(B * H); }
+    h->qnt = (int)((H + 15) / 16); h->dant = (int)((H + 31) / 32);
+    h->qpart = take(4 * B * h->qnt); h->dapart = take(2 * B * h->dant);
     h->a_h1 = take(B * H); h->a_h2 = take(B * H);
     for (int z = 0; z < 2; ++z) { h->dz2[z] = take(B * H); h->dz1[z] = take(B * H); }
     h->loss = take(1); h->adam = take(4); h->steps = take(2);
@@ -706,9 +769,8 @@ extern "C" int cn_td3_update(cn_td3_handle h, int do_actor, const cn_td3_batch* 
     memset(&pa, 0, sizeof(pa));
     if (batch) { pa.rs = batch->s; pa.ra = batch->a; pa.rr = batch->r; pa.rs2 = batch->s2; pa.rd = batch->d; pa.noise_in = batch->target_noise; pa.size_dev = nullptr; }
     else { pa.rs = c.replay_s; pa.ra = c.replay_a; pa.rr = c.replay_r; pa.rs2 = c.replay_s2; pa.rd = c.replay_d; pa.noise_in = nullptr; pa.size_dev = c.replay_size_dev; }
-    pa.xs = h->xs; pa.x2 = h->x2; pa.xp = do_actor ? h->xp : nullptr; pa.r = h->r; pa.d = h->d; pa.noise = h->noise; pa.adam = h->adam; pa.steps = h->steps; pa.counter = h->counter;
-    pa.seed = c.seed; pa.B = B; pa.D = D; pa.do_actor = do_actor ? 1 : 0;
-    pa.lr_critic = c.lr_critic; pa.lr_actor = c.lr_actor; pa.beta1 = c.beta1; pa.beta2 = c.beta2; pa.noise_std = c.noise_std; pa.noise_clip = c.noise_clip;
+    pa.xs = h->xs; pa.x2 = h->x2; pa.r = h->r; pa.d = h->d; pa.noise = h->noise; pa.counter = h->counter;
+    pa.seed = c.seed; pa.B = B; pa.D = D; pa.noise_std = c.noise_std; pa.noise_clip = c.noise_clip;
     hipLaunchKernelGGL(td3_prep_kernel, dim3(B), dim3(256), 0, st, pa);
 
     auto fwd_job = [&](GemmJob& j, const float* X, int ldx, int K, const float* W, const float* b, float* Y) {
@@ -726,36 +788,40 @@ extern "C" int cn_td3_update(cn_td3_handle h, int do_actor, const cn_td3_batch* 
     };
     GemmArgs ga;
     ga.beta1 = c.beta1; ga.beta2 = c.beta2; ga.eps = c.eps; ga.tau = c.tau;
-    // 1-3. target actor on s2 -> a2 = pi_t(s2) + clipped noise, into x2's action columns (TD3:238-247).  On actor updates the
-    // policy's own forward pass pi(s) (TD3:268; it reads the actor, which the critic step does not touch) rides in the same three
-    // launches as a second job and lands in xp's action columns -- xs keeps the batch's actions for steps 4 and 9.
+    ga.tick.adam = h->adam; ga.tick.steps = h->steps; ga.tick.pw = h->pw; ga.tick.counter = h->counter; ga.tick.do_actor = do_actor ? 1 : 0;
+    ga.tick.lr_critic = c.lr_critic; ga.tick.lr_actor = c.lr_actor; ga.tick.beta1 = c.beta1; ga.tick.beta2 = c.beta2;
+    ga.do_tick = 0;
+    // 1-2. the target actor's hidden layers on s2 (TD3:238).  On actor updates the policy's own hidden layers on s (TD3:268; they
+    // read the actor, which the critic step does not touch) ride in the same two launches as a second job.
     const int na = do_actor ? 2 : 1;
     fwd_job(ga.job[0], h->x2, Dc, D, c.actor_t.w1, c.actor_t.b1, h->t_h1);
-    fwd_job(ga.job[1], h->xp, Dc, D, c.actor.w1, c.actor.b1, h->a_h1);
+    fwd_job(ga.job[1], h->xs, Dc, D, c.actor.w1, c.actor.b1, h->a_h1);
     launch_gemm<GEMM_F>(ga, na, st);
     fwd_job(ga.job[0], h->t_h1, H, H, c.actor_t.w2, c.actor_t.b2, h->t_h2);
     fwd_job(ga.job[1], h->a_h1, H, H, c.actor.w2, c.actor.b2, h->a_h2);
     launch_gemm<GEMM_F>(ga, na, st);
-    ActorHeadArgs ha;
-    ha.job[0] = {h->t_h2, c.actor_t.w3, c.actor_t.b3, h->noise, h->x2, nullptr};
-    ha.job[1] = {h->a_h2, c.actor.w3, c.actor.b3, nullptr, h->xp, h->logits};
-    ha.B = B; ha.H = H; ha.Dc = Dc; ha.max_v = c.max_v; ha.max_w = c.max_w;
-    hipLaunchKernelGGL(td3_actor_head_kernel, dim3((B + 3) / 4, na), dim3(256), 0, st, ha);
+    // (3, the policies' last layer and heads, runs inside the launches that consume the actions: 4 and 13)
+    auto head_job = [&](GemmJob& j, const float* h2, const cn_td3_mlp& pol, const float* noise, float* logits) {
+        j.R = D; j.hd_h2 = h2; j.hd_W3 = pol.w3; j.hd_b3 = pol.b3; j.hd_noise = noise; j.hd_logits = logits; j.hd_H = H; j.hd_max_v = c.max_v; j.hd_max_w = c.max_w;
+    };
     // 4-6. the four critics forward: q1, q2 on (s, a); q1_t, q2_t on (s2, a2)
     const cn_td3_mlp* crit[4] = {&c.q1, &c.q2, &c.q1_t, &c.q2_t};
     for (int z = 0; z < 4; ++z) fwd_job(ga.job[z], z < 2 ? h->xs : h->x2, Dc, Dc, crit[z]->w1, crit[z]->b1, h->c_h1[z]);
+    for (int z = 2; z < 4; ++z) head_job(ga.job[z], h->t_h2, c.actor_t, h->noise, nullptr);      // a2 = pi_t(s2) + clipped noise
     launch_gemm<GEMM_F>(ga, 4, st);
-    for (int z = 0; z < 4; ++z) fwd_job(ga.job[z], h->c_h1[z], H, H, crit[z]->w2, crit[z]->b2, h->c_h2[z]);
+    // 5-6. ... their second layers, and the last (q = h2 . W3 + b3) as per-tile partial sums in the same epilogue; the tick too
+    for (int z = 0; z < 4; ++z) {
+        fwd_job(ga.job[z], h->c_h1[z], H, H, crit[z]->w2, crit[z]->b2, h->c_h2[z]);
+        ga.job[z].qp_w3 = crit[z]->w3; ga.job[z].qp_b3 = crit[z]->b3; ga.job[z].qp_out = h->qpart + (size_t)z * B * h->qnt; ga.job[z].qp_nt = h->qnt;
+    }
+    ga.do_tick = 1;
     launch_gemm<GEMM_F>(ga, 4, st);
-    QHeadArgs qa;
-    for (int z = 0; z < 4; ++z) { qa.h2[z] = h->c_h2[z]; qa.W3[z] = crit[z]->w3; qa.b3[z] = crit[z]->b3; qa.q[z] = h->c_q[z]; }
-    qa.B = B; qa.H = H; qa.nz = 4; qa.tick = pa;
-    hipLaunchKernelGGL(td3_q_head_kernel, dim3((4 * B + 3) / 4), dim3(256), 0, st, qa);
+    ga.do_tick = 0;
     // 7. TD target, MSE gradients, linear3 backward + Adam (both critics)
     CriticHeadBwdArgs ca;
-    ca.r = h->r; ca.d = h->d; ca.qt1 = h->c_q[2]; ca.qt2 = h->c_q[3];
+    ca.r = h->r; ca.d = h->d; ca.qpart = h->qpart; ca.qnt = h->qnt;
     for (int z = 0; z < 2; ++z) {
-        ca.q[z] = h->c_q[z]; ca.h2[z] = h->c_h2[z]; ca.dz2[z] = h->dz2[z]; ca.W3[z] = crit[z]->w3; ca.b3[z] = crit[z]->b3;
+        ca.h2[z] = h->c_h2[z]; ca.dz2[z] = h->dz2[z]; ca.W3[z] = crit[z]->w3; ca.b3[z] = crit[z]->b3;
         ca.m3[z] = h->mom[1 + z][4][0]; ca.v3[z] = h->mom[1 + z][4][1]; ca.mb3[z] = h->mom[1 + z][5][0]; ca.vb3[z] = h->mom[1 + z][5][1];
     }
     for (int z = 0; z < 2; ++z) { ca.W3t[z] = do_actor ? crit[2 + z]->w3 : nullptr; ca.b3t[z] = do_actor ? crit[2 + z]->b3 : nullptr; }
@@ -776,17 +842,21 @@ extern "C" int cn_td3_update(cn_td3_handle h, int do_actor, const cn_td3_batch* 
     }
     launch_gemm<GEMM_H>(ga, 4, st);
     if (do_actor) {
-        // (10-12, pi(s) into xp's action columns, ran inside launches 1-3)
+        // (10-11, the policy's hidden layers on s, ran inside launches 1-2; 12, its head, runs inside 13)
         // 13-14. the UPDATED first critic on (s, pi(s)) (TD3:268)
-        fwd_job(ga.job[0], h->xp, Dc, Dc, c.q1.w1, c.q1.b1, h->c_h1[0]); launch_gemm<GEMM_F>(ga, 1, st);
+        fwd_job(ga.job[0], h->xs, Dc, Dc, c.q1.w1, c.q1.b1, h->c_h1[0]);    // (xs's own action columns are not read: head_job)
+        head_job(ga.job[0], h->a_h2, c.actor, nullptr, h->logits);                                  // pi(s)
+        launch_gemm<GEMM_F>(ga, 1, st);
         fwd_job(ga.job[0], h->c_h1[0], H, H, c.q1.w2, c.q1.b2, h->c_h2[0]);
         ga.job[0].dz_w3 = c.q1.w3; ga.job[0].dz_out = h->dz2[0]; ga.job[0].dz_rows = (float)B;      // 15. -mean Q's gradient at h2, in the epilogue
         launch_gemm<GEMM_F>(ga, 1, st);
         // 16-17. ... back to the action, through the heads, linear3 of the actor + Adam
-        bwd_data_job(ga.job[0], h->dz2[0], c.q1.w2, h->c_h1[0], h->dz1[0]); launch_gemm<GEMM_G>(ga, 1, st);
-        hipLaunchKernelGGL(td3_dlogit_kernel, dim3((B + 3) / 4), dim3(256), 0, st, h->dz1[0], c.q1.w1, h->logits, h->noise, B, H, Dc, c.max_v, c.max_w);
+        bwd_data_job(ga.job[0], h->dz2[0], c.q1.w2, h->c_h1[0], h->dz1[0]);
+        ga.job[0].da_w = c.q1.w1 + D; ga.job[0].da_ld = Dc; ga.job[0].da_out = h->dapart; ga.job[0].da_nt = h->dant;     // the action columns of W1
+        launch_gemm<GEMM_G>(ga, 1, st);
         ActorHeadBwdArgs aa;
-        aa.dl = h->noise; aa.h2a = h->a_h2; aa.dz2a = h->dz2[1];       // (the noise buffer is free by now: it holds dlogit [B][2])
+        aa.dapart = h->dapart; aa.dant = h->dant; aa.logits = h->logits; aa.max_v = c.max_v; aa.max_w = c.max_w;
+        aa.h2a = h->a_h2; aa.dz2a = h->dz2[1];
         aa.W3 = c.actor.w3; aa.b3 = c.actor.b3; aa.m3 = h->mom[0][4][0]; aa.v3 = h->mom[0][4][1]; aa.mb3 = h->mom[0][5][0]; aa.vb3 = h->mom[0][5][1];
         aa.W3t = c.actor_t.w3; aa.b3t = c.actor_t.b3; aa.tau = c.tau;
         aa.adam = h->adam; aa.B = B; aa.H = H; aa.beta1 = c.beta1; aa.beta2 = c.beta2; aa.eps = c.eps;
