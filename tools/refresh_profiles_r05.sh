@@ -5,3 +5,5 @@ mkdir -p gpurun_out/r05; export TMPDIR=/tmp
 python tools/csrc_hash.py
 tools/profile.sh r05 > gpurun_out/profile_r05.log 2>&1; grep -E "^== (counters|traffic)" gpurun_out/prof_r05/summary.txt
 tools/regen_profiles.sh r05 > gpurun_out/r05/regen.log 2>&1; tail -8 gpurun_out/r05/regen.log
+python tools/learn_bench.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r05/learn_bench.txt; cat gpurun_out/r05/learn_bench.txt
+tools/learn_profile.sh r05 > /dev/null 2>&1
