@@ -18,7 +18,7 @@ PY
 T=$(find "$D" -name '*kernel_trace.csv' | head -1)
 python - "$T" >> "$OUT/learn_kernels.txt" <<'PY'
 # per position in the update's launch sequence (an update starts at td3_prep_kernel): mean duration, and the mean gap to the next launch
-import csv, sys, collections
+import csv, sys, re
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if "td3" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 seqs, cur = [], []
@@ -31,7 +31,7 @@ for n in sorted(set(len(q) for q in seqs)):
     if len(grp) < 20: continue
     print(f"\nupdates of {n} launches ({len(grp)} of them): span first start -> last end {sum(int(q[-1]['End_Timestamp']) - int(q[0]['Start_Timestamp']) for q in grp) / len(grp) / 1e3:.1f} us")
     for k in range(n):
-        name = grp[0][k]["Kernel_Name"].split("::")[-1].split("(")[0]
+        name = re.search(r"td3_\w+", grp[0][k]["Kernel_Name"]).group(0)
         dur = sum(int(q[k]["End_Timestamp"]) - int(q[k]["Start_Timestamp"]) for q in grp) / len(grp) / 1e3
         gap = sum(int(q[k + 1]["Start_Timestamp"]) - int(q[k]["End_Timestamp"]) for q in grp) / len(grp) / 1e3 if k + 1 < n else 0.0
         gx = grp[0][k].get("Grid_Size_X", "?"); 

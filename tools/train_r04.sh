@@ -26,6 +26,8 @@ case "$SET" in
     run fused_same_e16 --envs 16 --updates 16 --waypoint-reward 0 --learner fused --reset-mode same ;;
   init)    # NOT the reference: the actor's output layer initialised U(+-0.003); does the seed sensitivity go away?
     for S in 0 1 2 3 4 5 6 7; do run init003_fused_e16_seed$S --envs 16 --updates 16 --waypoint-reward 0 --learner fused --seed $S --actor-final-init 0.003; done ;;
+  r05)     # round 5: the 16-env recipe on cn_td3_update at 0.068 ms (other summation order than round 4: other trajectories)
+    for S in 0 1; do run fused_e16_u16_wp0_seed$S --envs 16 --updates 16 --waypoint-reward 0 --learner fused --seed $S; done ;;
   final)   # the 16-env recipe on the final tree (cn_td3_update at 0.127 ms)
     run final_fused_e16_u16_wp0 --envs 16 --updates 16 --waypoint-reward 0 --learner fused ;;
   fused)   # the same runs on cn_td3_update (csrc/crowdnav_td3.hip): the reference's ratio of one update per env-step, and 4x the envs
