@@ -1,19 +1,20 @@
 // crowdnav_td3.hip -- the TD3 update (td3.py:225-285 of the reference: Agent.learn) as a short chain of HIP kernels (gfx950).
 //
 // The caller of the hot path.  A vectorised environment makes the learner the bottleneck: through PyTorch one
-// update is ~150 small kernels (1.2 ms as a hipGraph at batch 128).  Here the same arithmetic is 8 launches for the critic
-// step and 6 more when the actor and the targets move (rounds 3-4: 10 + 11), all float32 like the reference:
+// update is ~150 small kernels (1.2 ms as a hipGraph at batch 128).  Here the same arithmetic is 7 launches for the critic
+// step and 5 more when the actor and the targets move (rounds 3-4: 10 + 11), all float32 like the reference:
 //   prep        sample the replay on the device (counter-based indices and target-policy noise), gather [s|a], [s2|.], r, d
 //   gemm F      Y = act(X W^T + b) on the f32 matrix cores (v_mfma_f32_16x16x4_f32), up to four networks per launch;
 //               optional: the policy's last layer + heads evaluated in place of X's action columns, the critic's last layer
 //               as per-tile partial sums of the activation just written, the first link of the actor-loss chain
-//   gemm G      dX = (dY W) (.) [H > 0]   (back-propagation through a ReLU layer); optional: the action gradient's partial sums
+//   gemm G      dX = (dY W) (.) [H > 0]   (back-propagation through a ReLU layer); optional: dY evaluated, not read -- the TD
+//               target + MSE gradient + linear3 backward of a critic, or the heads' derivatives + linear3 backward of the actor;
+//               the action gradient's partial sums
 //   gemm H      dW = dY^T X folded into the Adam step of W (and of b) and the soft update of the target's copy: the gradient
-//               never exists in memory
-//   two head-backward kernels (TD target + MSE gradient + the critics' linear3 backward; heads' derivatives + the actor's)
+//               never exists in memory; linear3's gradients are one- and two-row jobs of the same launch
 // Launch order: prep | actor_t L1 (+ actor L1) | L2 (+ L2) | critics L1 (target actions from the head) | critics L2 (+ q partials,
-// tick) | critic heads backward | G | H   and, every policy_delay-th update:  q1 L1 on (s, pi(s)) | q1 L2 (+ dz) | G (+ da
-// partials) | actor head backward | G | H.
+// tick) | G (dq, dz2 evaluated) | H (six jobs)   and, every policy_delay-th update:  q1 L1 on (s, pi(s)) | q1 L2 (+ dz) | G (+ da
+// partials) | G (dl, dz2a evaluated) | H (three jobs).
 // The parameters are the caller's (PyTorch nn.Linear storages, weight [out][in]); Adam's moments and step counters live here.
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -103,8 +104,25 @@ struct GemmJob {
     // G, optional: the next link of the actor-loss chain, through the critic's first layer to the action: partial sums over the
     // tile's 32 units of C[i][j] da_w[j * da_ld + o], o = 0, 1 (the two action columns of W1): da_out[(2 i + o) * da_nt + column tile]
     const float* da_w; float* da_out; int da_ld, da_nt;
+    // G, optional: A is not read but evaluated -- it is the gradient at a critic's second hidden layer (TD3:249-260),
+    //   A[m][k] = dq[m] hb_w3[k] [hb_h2[m][k] > 0],   dq[m] = 2 (q[m] - y[m]) / I,   y = r + (1 - d) gamma min(q1_t, q2_t)[m],
+    // q of network hb_net and of the two targets (networks 2, 3) from td3_fwd_kernel's per-tile partial sums hb_qpart.  dq scales a
+    // whole row, so the reduction runs on hb_w3 (.) [h2 > 0] and the epilogue multiplies.  The first column tile also writes what
+    // the weight-gradient launch needs: hb_dq [I] (linear3's gradient = dq^T h2: a job of that launch) and hb_dz2 [I][R] = A.
+    // (Was td3_critic_head_bwd_kernel: a launch between the forward pass and this one.)
+    const float* hb_h2; const float* hb_w3; const float* hb_qpart; const float* hb_r; const float* hb_d;
+    float* hb_dq; float* hb_dz2; int hb_qnt, hb_net; float hb_gamma;
+    // G, optional, the ACTOR's counterpart (TD3:268-269, -mean Q1(s, pi(s)) arriving at the policy's second hidden layer):
+    //   A[m][k] = (dl[m][0] ab_w3[k] + dl[m][1] ab_w3[R + k]) [ab_h2[m][k] > 0],   dl[m][o] = da[m][o] (max_v s (1 - s), max_w (1 - t^2)),
+    // da from this kernel's own per-tile partial sums of the launch before (ab_dapart), s / t from the policy's logits.  The first
+    // column tile writes ab_dl [I][2] (linear3's gradient = dl^T h2: a two-row job of the weight-gradient launch) and ab_dz2 = A.
+    // (Was td3_actor_head_bwd_kernel.)
+    const float* ab_h2; const float* ab_w3; const float* ab_dapart; const float* ab_logits;
+    float* ab_dl; float* ab_dz2; int ab_dant; float ab_max_v, ab_max_w;
+    // H, optional: A is one column (I = 1) of per-row loss gradients dq; loss_out[0] = mean squared TD error = (R / 4) sum dq^2
+    float* loss_out;
 };
-struct GemmArgs { GemmJob job[4]; float beta1, beta2, eps, tau; TickArgs tick; int do_tick; };
+struct GemmArgs { GemmJob job[6]; float beta1, beta2, eps, tau; TickArgs tick; int do_tick; };
 // target <- target (1 - tau) + local tau (TD3:297-299)
 __device__ __forceinline__ float td3_soft(float target, float local, float tau) { return target * (1.f - tau) + local * tau; }
 
@@ -256,6 +274,53 @@ __global__ void __launch_bounds__(256) td3_dgrad_kernel(GemmArgs args)
         for (int c = 0; c < 2; ++c)
             if (jc + c < J) { pdw[c][0] = jb.da_w[(size_t)(jc + c) * jb.da_ld]; pdw[c][1] = jb.da_w[(size_t)(jc + c) * jb.da_ld + 1]; }
     }
+    // head-backward mode: this lane's row of dq (14 loads in flight with the operands')
+    const bool hb = jb.hb_h2 != nullptr;
+    __shared__ float dqs[16];
+    float dq_li = 0.f;
+    if (hb) arow = jb.hb_h2 + (size_t)min(i0 + li, I - 1) * jb.lda;
+    if (hb && (blockIdx.x == 0 || (wave == 0 && lk == 0))) {      // (the first column tile needs dq in every lane: it stores dz2)
+        const int m = min(i0 + li, I - 1);
+        float qs[3];                               // this critic, the two target critics
+#pragma unroll
+        for (int n = 0; n < 3; ++n) {
+            const float* __restrict__ pp = jb.hb_qpart + ((size_t)(n == 0 ? jb.hb_net : 1 + n) * I + m) * jb.hb_qnt;
+            float a_ = 0.f;
+            int t = 0;
+#pragma unroll 4
+            for (; t + 4 <= jb.hb_qnt; t += 4) { const f32x4_t v = *(const f32x4u_t*)(pp + t); a_ += (v[0] + v[1]) + (v[2] + v[3]); }
+            for (; t < jb.hb_qnt; ++t) a_ += pp[t];
+            qs[n] = a_;
+        }
+        const float y = jb.hb_r[m] + (1.f - jb.hb_d[m]) * jb.hb_gamma * fminf(qs[1], qs[2]);
+        dq_li = 2.f * (qs[0] - y) / (float)I;
+        if (wave == 0 && lk == 0) {
+            dqs[li] = dq_li;
+            if (blockIdx.x == 0 && i0 + li < I) jb.hb_dq[i0 + li] = dq_li;
+        }
+    }
+    const bool ab = jb.ab_h2 != nullptr;
+    float dl0 = 0.f, dl1 = 0.f;
+    if (ab) {
+        const int m = min(i0 + li, I - 1);
+        float da[2];
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            const float* __restrict__ pp = jb.ab_dapart + ((size_t)2 * m + o) * jb.ab_dant;
+            float a_ = 0.f;
+            int t = 0;
+#pragma unroll 2
+            for (; t + 4 <= jb.ab_dant; t += 4) { const f32x4_t v = *(const f32x4u_t*)(pp + t); a_ += (v[0] + v[1]) + (v[2] + v[3]); }
+            for (; t < jb.ab_dant; ++t) a_ += pp[t];
+            da[o] = a_;
+        }
+        const float lg0 = jb.ab_logits[2 * m], lg1 = jb.ab_logits[2 * m + 1];
+        const float s_ = 1.f / (1.f + expf(-lg0)), th = tanhf(lg1);
+        dl0 = da[0] * (jb.ab_max_v * s_ * (1.f - s_));
+        dl1 = da[1] * (jb.ab_max_w * (1.f - th * th));
+        if (blockIdx.x == 0 && wave == 0 && lk == 0 && i0 + li < I) { jb.ab_dl[2 * (i0 + li)] = dl0; jb.ab_dl[2 * (i0 + li) + 1] = dl1; }
+        arow = jb.ab_h2 + (size_t)m * jb.lda;
+    }
     for (int t0 = wave; t0 < nb; t0 += 4 * TD3_GKB) {
         f32x4_t av[TD3_GKB];
         f32x2_t bv[TD3_GKB][4];
@@ -264,10 +329,30 @@ __global__ void __launch_bounds__(256) td3_dgrad_kernel(GemmArgs args)
             const int t = t0 + 4 * u, k = 16 * t + 4 * lk;
             if (t < nb && inner && 16 * t + 16 <= R) {
                 av[u] = *(const f32x4u_t*)(arow + k);
+                if (hb) {
+                    const f32x4_t wv = *(const f32x4u_t*)(jb.hb_w3 + k);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) av[u][e] = av[u][e] > 0.f ? wv[e] : 0.f;
+                }
+                if (ab) {
+                    const f32x4_t w0 = *(const f32x4u_t*)(jb.ab_w3 + k), w1 = *(const f32x4u_t*)(jb.ab_w3 + R + k);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) av[u][e] = av[u][e] > 0.f ? fmaf(dl1, w1[e], dl0 * w0[e]) : 0.f;
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) bv[u][e] = *(const f32x2u_t*)(B + (size_t)(k + e) * jb.ldb + jc);
             } else if (t < nb) {
                 av[u] = td3_ld4(arow, k, R);
+                if (hb) {
+                    const f32x4_t wv = td3_ld4(jb.hb_w3, k, R);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) av[u][e] = av[u][e] > 0.f ? wv[e] : 0.f;
+                }
+                if (ab) {
+                    const f32x4_t w0 = td3_ld4(jb.ab_w3, k, R), w1 = td3_ld4(jb.ab_w3 + R, k, R);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) av[u][e] = av[u][e] > 0.f ? fmaf(dl1, w1[e], dl0 * w0[e]) : 0.f;
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) bv[u][e] = k + e < R ? td3_ld2(B + (size_t)(k + e) * jb.ldb, jc, J) : f32x2_t{0.f, 0.f};
             } else {
@@ -283,16 +368,31 @@ __global__ void __launch_bounds__(256) td3_dgrad_kernel(GemmArgs args)
                 for (int e = 0; e < 4; ++e) { acc0 = TD3_MFMA(av[u][e], bv[u][e][0], acc0); acc1 = TD3_MFMA(av[u][e], bv[u][e][1], acc1); }
             }
         }
+        if ((hb || ab) && blockIdx.x == 0 && i0 + li < I) {      // dz2 = A, for the weight-gradient launch
+            const float sc = hb ? dq_li : 1.f;
+            float* __restrict__ zb = (hb ? jb.hb_dz2 : jb.ab_dz2) + (size_t)(i0 + li) * jb.lda;
+#pragma unroll
+            for (int u = 0; u < TD3_GKB; ++u) {
+                const int t = t0 + 4 * u, k = 16 * t + 4 * lk;
+                if (t >= nb) continue;
+                float* __restrict__ zr = zb + k;
+                if (k + 4 <= R) *(f32x4u_t*)zr = av[u] * sc;
+                else
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (k + e < R) zr[e] = av[u][e] * sc;
+            }
+        }
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) { red[wave][q][lane] = acc0[q]; red[wave][4 + q][lane] = acc1[q]; }
     __syncthreads();
     const int q = wave, i = i0 + 4 * lk + q;
+    const float rowscale = hb ? dqs[4 * lk + q] : 1.f;
     float dv[2];
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         const int j = jc + c;
-        const float d = ((red[0][4 * c + q][lane] + red[1][4 * c + q][lane]) + red[2][4 * c + q][lane]) + red[3][4 * c + q][lane];
+        const float d = (((red[0][4 * c + q][lane] + red[1][4 * c + q][lane]) + red[2][4 * c + q][lane]) + red[3][4 * c + q][lane]) * rowscale;
         dv[c] = (i < I && j < J && pmask[c] > 0.f) ? d : 0.f;
         if (i < I && j < J) jb.C[(size_t)i * jb.ldc + j] = dv[c];
     }
@@ -318,6 +418,7 @@ __global__ void __launch_bounds__(256) td3_wgrad_kernel(GemmArgs args)
     if (i0 >= I || j0 >= J) return;
     __shared__ float red[4][16][64];
     __shared__ float bred[4][4][32];
+    __shared__ float lred[4][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
     const float* __restrict__ A = jb.A;
     const float* __restrict__ B = jb.B;
@@ -326,8 +427,8 @@ __global__ void __launch_bounds__(256) td3_wgrad_kernel(GemmArgs args)
     // a lane's pair of rows / columns: 2 = both inside, 1 = only the first (odd extents), 0 = past the edge (a ragged tile: the lane
     // loads a pair that IS inside and its products are never stored).  Pairs that straddle the edge take the element-wise path.
     const int amode = ic + 1 < I ? 2 : ic < I ? 1 : 0, bmode = jc + 1 < J ? 2 : jc < J ? 1 : 0;
-    const bool vec = __all(amode != 1 && bmode != 1) && I >= 2 && J >= 2;
-    const int icv = amode == 2 ? ic : 0, jcv = bmode == 2 ? jc : 0;
+    const bool vec = __all(bmode != 1) && J >= 2;       // (an odd last ROW of the tile -- or I = 1, the linear3 jobs -- loads one element)
+    const int jcv = bmode == 2 ? jc : 0;
     const float adam0 = jb.adam[0], adam1 = jb.adam[1];
     f32x4_t acc[2][2];
 #pragma unroll
@@ -335,6 +436,7 @@ __global__ void __launch_bounds__(256) td3_wgrad_kernel(GemmArgs args)
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     float bs0 = 0.f, bs1 = 0.f;                    // sums of dY over this lane's rows (the bias gradient, first j-tile only)
+    float ls0 = 0.f;                               // ... and of dY[.][0]^2 (loss_out)
     // the Adam step's operands of this thread's four elements, requested now: their round trip overlaps the reduction's
     float pm[4], pv[4], pw[4], pt[4];
 #pragma unroll
@@ -350,9 +452,10 @@ __global__ void __launch_bounds__(256) td3_wgrad_kernel(GemmArgs args)
         for (int u = 0; u < TD3_HKS; ++u) {
             const int s = s0 + 4 * u, k = 4 * s + lk;
             if (s < ns && vec && 4 * s + 4 <= R) {
-                av[u] = *(const f32x2u_t*)(A + (size_t)k * jb.lda + icv);
+                av[u] = f32x2_t{0.f, 0.f};
+                if (amode == 2) av[u] = *(const f32x2u_t*)(A + (size_t)k * jb.lda + ic);
+                else if (amode == 1) av[u][0] = A[(size_t)k * jb.lda + ic];
                 bv[u] = *(const f32x2u_t*)(B + (size_t)k * jb.ldb + jcv);
-                if (amode == 0) av[u] = f32x2_t{0.f, 0.f};
             } else if (s < ns && k < R) {
                 av[u] = td3_ld2(A + (size_t)k * jb.lda, ic, I);
                 bv[u] = td3_ld2(B + (size_t)k * jb.ldb, jc, J);
@@ -365,7 +468,7 @@ __global__ void __launch_bounds__(256) td3_wgrad_kernel(GemmArgs args)
                 for (int a = 0; a < 2; ++a)
 #pragma unroll
                     for (int b = 0; b < 2; ++b) acc[a][b] = TD3_MFMA(av[u][a], bv[u][b], acc[a][b]);
-                bs0 += av[u][0]; bs1 += av[u][1];
+                bs0 += av[u][0]; bs1 += av[u][1]; ls0 = fmaf(av[u][0], av[u][0], ls0);
             }
         }
     }
@@ -376,7 +479,16 @@ __global__ void __launch_bounds__(256) td3_wgrad_kernel(GemmArgs args)
 #pragma unroll
             for (int q = 0; q < 4; ++q) red[wave][(2 * a + b) * 4 + q][lane] = acc[a][b][q];
     bred[wave][lk][2 * li] = bs0; bred[wave][lk][2 * li + 1] = bs1;
+    if (li == 0) lred[wave][lk] = ls0;
     __syncthreads();
+    if (jb.loss_out && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
+        float l_ = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) l_ += lred[w][k];
+        jb.loss_out[0] = l_ * (0.25f * (float)R);
+    }
     // thread -> four elements of the tile, 32 consecutive columns per half-wavefront: row ii = 2 (4 g + q) + a, column jj = 2 c + b
 #pragma unroll
     for (int z = 0; z < 4; ++z) {
@@ -460,195 +572,11 @@ __device__ __forceinline__ float td3_wave_sum(float v)
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
     return v;
 }
-// TD target, MSE gradient and linear3's backward + Adam step for the two critics; workgroup (x, z) = 16 hidden units of critic z,
-// its 256 threads = 16 row groups x 16 units:
-//   y = r + (1 - d) gamma min(q1_t, q2_t)  (TD3:249-252);  loss_z = mean (q_z - y)^2;  dq_z = 2 (q_z - y) / B
-//   dz2_z[m][n] = dq_z[m] W3_z[n] [h2_z[m][n] > 0];  dW3_z[n] = sum_m dq_z[m] h2_z[m][n];  db3_z = sum_m dq_z[m]
-struct CriticHeadBwdArgs {
-    const float *r, *d;
-    const float* qpart; int qnt;                   // q of the four critics as partial sums: qpart[(net * B + m) * qnt + tile] (td3_fwd_kernel)
-    const float* h2[2]; float* dz2[2];
-    float* W3[2]; float* b3[2]; float* m3[2]; float* v3[2]; float* mb3[2]; float* vb3[2];
-    const float* adam; float* loss;
-    float* W3t[2]; float* b3t[2];                  // actor updates: the target critics' last layers (soft-updated here), else null
-    int B, H; float gamma, beta1, beta2, eps, tau;
-};
-// Shape of this kernel and of td3_actor_head_bwd_kernel: 16 hidden units x 16 row groups per workgroup (H / 16 workgroups a
-// network; four workgroups of 64 units were four round trips of eight loads in series behind the dq phase: 9.8 us), a thread's
-// eight rows of h2 in flight BEFORE the dq phase, the Adam moments too -- the kernel is one memory round trip, not six.
-#define TD3_HC 16
-__global__ void __launch_bounds__(256) td3_critic_head_bwd_kernel(CriticHeadBwdArgs a)
-{
-    extern __shared__ float sm[];                   // dq [B] | partial [16][16] | red [8]
-    float* dq = sm; float* part = sm + a.B; float* red = part + 256;
-    const int z = blockIdx.y, tid = threadIdx.x;
-    const int rg = tid >> 4, c = tid & 15, n = blockIdx.x * TD3_HC + c;
-    const bool on = n < a.H;
-    const float* __restrict__ h2 = a.h2[z];
-    float hv[8];
-    auto load = [&](int m0) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { const int m = m0 + 16 * u; hv[u] = (on && m < a.B) ? h2[(size_t)m * a.H + n] : 0.f; }
-    };
-    load(rg);
-    const float w = on ? a.W3[z][n] : 0.f;
-    float m3 = 0.f, v3 = 0.f;
-    if (rg == 0 && on) { m3 = a.m3[z][n]; v3 = a.v3[z][n]; }
-    float e2 = 0.f, sdq = 0.f;
-    for (int m = tid; m < a.B; m += 256) {
-        float qs[3];                               // this critic, the two target critics
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const float* __restrict__ pp = a.qpart + ((size_t)(k == 0 ? z : 1 + k) * a.B + m) * a.qnt;
-            float acc = 0.f;
-            int t = 0;
-#pragma unroll 4
-            for (; t + 4 <= a.qnt; t += 4) { const f32x4_t v = *(const f32x4u_t*)(pp + t); acc += (v[0] + v[1]) + (v[2] + v[3]); }
-            for (; t < a.qnt; ++t) acc += pp[t];
-            qs[k] = acc;
-        }
-        const float y = a.r[m] + (1.f - a.d[m]) * a.gamma * fminf(qs[1], qs[2]);
-        const float e = qs[0] - y;
-        const float g = 2.f * e / (float)a.B;
-        dq[m] = g; e2 += e * e; sdq += g;
-    }
-    if (blockIdx.x == 0) {                           // the loss (critic 1: what Agent.learn returns) and the bias of linear3
-        e2 = td3_wave_sum(e2); sdq = td3_wave_sum(sdq);
-        if ((tid & 63) == 0) { red[tid >> 6] = e2; red[4 + (tid >> 6)] = sdq; }
-    }
-    __syncthreads();
-    if (blockIdx.x == 0 && tid == 0) {
-        if (z == 0) a.loss[0] = ((red[0] + red[1]) + (red[2] + red[3])) / (float)a.B;
-        const float g = (red[4] + red[5]) + (red[6] + red[7]);
-        const float mm = a.beta1 * a.mb3[z][0] + (1.f - a.beta1) * g;
-        const float vv = a.beta2 * a.vb3[z][0] + (1.f - a.beta2) * g * g;
-        a.mb3[z][0] = mm; a.vb3[z][0] = vv;
-        const float b = a.b3[z][0] - a.adam[0] * mm / (sqrtf(vv) / a.adam[1] + a.eps);
-        a.b3[z][0] = b;
-        if (a.b3t[z]) a.b3t[z][0] = td3_soft(a.b3t[z][0], b, a.tau);
-    }
-    float g = 0.f;
-    for (int m0 = rg; m0 < a.B; m0 += 128) {
-        float cur[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) cur[u] = hv[u];
-        if (m0 + 128 < a.B) load(m0 + 128);
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int m = m0 + 16 * u;
-            if (on && m < a.B) { a.dz2[z][(size_t)m * a.H + n] = cur[u] > 0.f ? dq[m] * w : 0.f; g = fmaf(dq[m], cur[u], g); }
-        }
-    }
-    part[rg * 16 + c] = g;
-    __syncthreads();
-    if (rg == 0 && on) {
-        g = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; r += 4) g += (part[r * 16 + c] + part[(r + 1) * 16 + c]) + (part[(r + 2) * 16 + c] + part[(r + 3) * 16 + c]);
-        const float mm = a.beta1 * m3 + (1.f - a.beta1) * g;
-        const float vv = a.beta2 * v3 + (1.f - a.beta2) * g * g;
-        a.m3[z][n] = mm; a.v3[z][n] = vv;
-        const float wn = w - a.adam[0] * mm / (sqrtf(vv) / a.adam[1] + a.eps);
-        a.W3[z][n] = wn;
-        if (a.W3t[z]) a.W3t[z][n] = td3_soft(a.W3t[z][n], wn, a.tau);
-    }
-}
-// actor loss -mean Q1(s, pi(s)) (TD3:268-269): its first link (d/dh2 of the critic) is td3_fwd_kernel's optional epilogue;
-// then through the critic's first layer to the action (the two action columns of W1): da[m][o] = sum_n dz1q[m][n] W1q[n][D + o],
-// partial sums per tile in td3_dgrad_kernel's epilogue, added up here; through the heads' derivatives to the logits:
-// dlogit = da (.) (max_v s (1 - s), max_w (1 - t^2)).  (Rounds 3-4: a kernel of its own, one wavefront per row, 4.8 us.  Every
-// workgroup re-evaluating the whole product for all rows was measured then: 14 -> 30 us.)
-// ... then linear3 of the ACTOR backward + its Adam step; workgroup x = 16 hidden units, 16 row groups x 16 units:
-//   dz2a[m][n] = sum_o dlogit[m][o] W3a[o][n] [h2a[m][n] > 0];  dW3a[o][n] = sum_m dlogit[m][o] h2a[m][n];  db3a[o] = sum_m dlogit[m][o]
-struct ActorHeadBwdArgs {
-    const float* dapart; int dant;                 // the action gradient as partial sums: dapart[(2 m + o) * dant + tile] (td3_dgrad_kernel)
-    const float* logits; float max_v, max_w;       // the policy's logits on the batch (td3_fwd_kernel's head)
-    const float* h2a; float* dz2a;
-    float *W3, *b3, *m3, *v3, *mb3, *vb3;
-    float *W3t, *b3t;                              // the target actor's last layer, soft-updated here
-    const float* adam;
-    int B, H; float beta1, beta2, eps, tau;
-};
-__global__ void __launch_bounds__(256) td3_actor_head_bwd_kernel(ActorHeadBwdArgs a)
-{
-    extern __shared__ float sm[];                   // dl [2 B] | partial [2][16][16]
-    float* dl = sm; float* part = sm + 2 * a.B;
-    const int tid = threadIdx.x;
-    const int rg = tid >> 4, c = tid & 15, n = blockIdx.x * TD3_HC + c;
-    const bool on = n < a.H;
-    float hv[8];
-    auto load = [&](int m0) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { const int m = m0 + 16 * u; hv[u] = (on && m < a.B) ? a.h2a[(size_t)m * a.H + n] : 0.f; }
-    };
-    load(rg);
-    const float w0 = on ? a.W3[n] : 0.f, w1 = on ? a.W3[a.H + n] : 0.f;
-    float m3[2] = {0.f, 0.f}, v3[2] = {0.f, 0.f};
-    if (rg == 0 && on) { m3[0] = a.m3[n]; v3[0] = a.v3[n]; m3[1] = a.m3[a.H + n]; v3[1] = a.v3[a.H + n]; }
-    // through the heads' derivatives to the logits: dlogit = da (.) (max_v s (1 - s), max_w (1 - t^2))
-    for (int t = tid; t < 2 * a.B; t += 256) {
-        const float* __restrict__ pp = a.dapart + (size_t)t * a.dant;
-        float da = 0.f;
-        int k = 0;
-#pragma unroll 2
-        for (; k + 4 <= a.dant; k += 4) { const f32x4_t v = *(const f32x4u_t*)(pp + k); da += (v[0] + v[1]) + (v[2] + v[3]); }
-        for (; k < a.dant; ++k) da += pp[k];
-        const float lg = a.logits[t];
-        float dh;
-        if ((t & 1) == 0) { const float s_ = 1.f / (1.f + expf(-lg)); dh = a.max_v * s_ * (1.f - s_); }
-        else { const float th = tanhf(lg); dh = a.max_w * (1.f - th * th); }
-        dl[t] = da * dh;
-    }
-    __syncthreads();
-    if (blockIdx.x == 0 && tid < 64) {               // the bias of linear3: lanes over the rows, then across the wavefront
-        float s0 = 0.f, s1 = 0.f;
-        for (int m = tid; m < a.B; m += 64) { s0 += dl[2 * m]; s1 += dl[2 * m + 1]; }
-        s0 = td3_wave_sum(s0); s1 = td3_wave_sum(s1);
-        if (tid < 2) {
-            const float g = tid == 0 ? s0 : s1;
-            const float mm = a.beta1 * a.mb3[tid] + (1.f - a.beta1) * g;
-            const float vv = a.beta2 * a.vb3[tid] + (1.f - a.beta2) * g * g;
-            a.mb3[tid] = mm; a.vb3[tid] = vv;
-            const float b = a.b3[tid] - a.adam[2] * mm / (sqrtf(vv) / a.adam[3] + a.eps);
-            a.b3[tid] = b;
-            a.b3t[tid] = td3_soft(a.b3t[tid], b, a.tau);
-        }
-    }
-    float g0 = 0.f, g1 = 0.f;
-    for (int m0 = rg; m0 < a.B; m0 += 128) {
-        float cur[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) cur[u] = hv[u];
-        if (m0 + 128 < a.B) load(m0 + 128);
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int m = m0 + 16 * u;
-            if (on && m < a.B) {
-                a.dz2a[(size_t)m * a.H + n] = cur[u] > 0.f ? fmaf(dl[2 * m + 1], w1, dl[2 * m] * w0) : 0.f;
-                g0 = fmaf(dl[2 * m], cur[u], g0); g1 = fmaf(dl[2 * m + 1], cur[u], g1);
-            }
-        }
-    }
-    part[rg * 16 + c] = g0; part[256 + rg * 16 + c] = g1;
-    __syncthreads();
-    if (rg == 0 && on) {
-        const float w[2] = {w0, w1};
-#pragma unroll
-        for (int o = 0; o < 2; ++o) {
-            const float* pp = part + 256 * o;
-            float g = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; r += 4) g += (pp[r * 16 + c] + pp[(r + 1) * 16 + c]) + (pp[(r + 2) * 16 + c] + pp[(r + 3) * 16 + c]);
-            const size_t ix = (size_t)o * a.H + n;
-            const float mm = a.beta1 * m3[o] + (1.f - a.beta1) * g;
-            const float vv = a.beta2 * v3[o] + (1.f - a.beta2) * g * g;
-            a.m3[ix] = mm; a.v3[ix] = vv;
-            const float wn = w[o] - a.adam[2] * mm / (sqrtf(vv) / a.adam[3] + a.eps);
-            a.W3[ix] = wn;
-            a.W3t[ix] = td3_soft(a.W3t[ix], wn, a.tau);
-        }
-    }
-}
+// The actor-loss chain -mean Q1(s, pi(s)) (TD3:268-269) has no kernel of its own: its first link (d/dh2 of the critic) is
+// td3_fwd_kernel's dz epilogue; through the critic's first layer to the action (the two action columns of W1) = per-tile partial
+// sums in td3_dgrad_kernel's da epilogue; through the heads' derivatives and the actor's linear3 = the same kernel's ab mode on
+// the next launch; dW3a = dl^T h2a = a two-row job of td3_wgrad_kernel.  (Rounds 3-4: td3_dlogit_kernel, one wavefront per row,
+// 4.8 us, and td3_actor_head_bwd_kernel, 9 us; the critics had td3_q_head_kernel and td3_critic_head_bwd_kernel.)
 }  // namespace
 
 // ---- host side ------------------------------------------------------------------------------------------------------------
@@ -661,6 +589,8 @@ struct cn_td3_s {
     float *xs, *x2, *r, *d, *noise, *logits;
     float *t_h1, *t_h2;            // target actor
     float *c_h1[4], *c_h2[4];               // q1, q2, q1_t, q2_t
+    float *dq[2];                           // the critics' loss gradients per row (td3_dgrad_kernel's head-backward mode)
+    float *dl;                              // the actor's: dlogit [B][2]
     float *qpart, *dapart; int qnt, dant;   // partial sums of the critics' outputs [4][B][qnt] and of the action gradient [B][2][dant]
     float *a_h1, *a_h2;            // actor
     float *dz2[2], *dz1[2];
@@ -718,7 +648,7 @@ extern "C" int cn_td3_create(const cn_td3_config* cfg, int device, cn_td3_handle
     const size_t B = h->B, Dc = h->Dc, H = h->H;
     size_t words = 2 * B * Dc + 2 * B + 2 * B + 2 * B          // xs, x2, r, d, noise, logits
                    + 2 * B * H + 4 * (2 * B * H) + 2 * B * H + 4 * B * H + 1 + 4 + 2 + 2 + 8  // t_h, c_h, a_h, dz, loss, adam, steps, counter, pw
-                   + 4 * B * ((H + 15) / 16) + 2 * B * ((H + 31) / 32);                        // qpart, dapart
+                   + 4 * B * ((H + 15) / 16) + 2 * B * ((H + 31) / 32) + 2 * B + 2 * B;                        // qpart, dapart
     size_t mom_words = 0;
     for (int net = 0; net < 3; ++net) for (int j = 0; j < 6; ++j) mom_words += 2 * param_count(h, net, j);
     hipError_t e = hipMalloc(&h->pool, (words + mom_words) * sizeof(float));
@@ -735,7 +665,7 @@ extern "C" int cn_td3_create(const cn_td3_config* cfg, int device, cn_td3_handle
     h->t_h1 = take(B * H); h->t_h2 = take(B * H);
     for (int z = 0; z < 4; ++z) { h->c_h1[z] = take(B * H); h->c_h2[z] = take(B * H); }
     h->qnt = (int)((H + 15) / 16); h->dant = (int)((H + 31) / 32);
-    h->qpart = take(4 * B * h->qnt); h->dapart = take(2 * B * h->dant);
+    h->qpart = take(4 * B * h->qnt); h->dapart = take(2 * B * h->dant); h->dq[0] = take(B); h->dq[1] = take(B); h->dl = take(2 * B);
     h->a_h1 = take(B * H); h->a_h2 = take(B * H);
     for (int z = 0; z < 2; ++z) { h->dz2[z] = take(B * H); h->dz1[z] = take(B * H); }
     h->loss = take(1); h->adam = take(4); h->steps = take(2);
@@ -817,30 +747,29 @@ extern "C" int cn_td3_update(cn_td3_handle h, int do_actor, const cn_td3_batch* 
     ga.do_tick = 1;
     launch_gemm<GEMM_F>(ga, 4, st);
     ga.do_tick = 0;
-    // 7. TD target, MSE gradients, linear3 backward + Adam (both critics)
-    CriticHeadBwdArgs ca;
-    ca.r = h->r; ca.d = h->d; ca.qpart = h->qpart; ca.qnt = h->qnt;
+    // 7-8. TD target, MSE gradient (per row, evaluated where it is consumed) and through the second hidden layer:
+    // dz1 = (dz2 W2) (.) [h1 > 0], dz2 = dq W3 (.) [h2 > 0]   (W2, W3 are read here, stepped in 9)
     for (int z = 0; z < 2; ++z) {
-        ca.h2[z] = h->c_h2[z]; ca.dz2[z] = h->dz2[z]; ca.W3[z] = crit[z]->w3; ca.b3[z] = crit[z]->b3;
-        ca.m3[z] = h->mom[1 + z][4][0]; ca.v3[z] = h->mom[1 + z][4][1]; ca.mb3[z] = h->mom[1 + z][5][0]; ca.vb3[z] = h->mom[1 + z][5][1];
+        bwd_data_job(ga.job[z], h->c_h2[z], crit[z]->w2, h->c_h1[z], h->dz1[z]);
+        GemmJob& j = ga.job[z];
+        j.hb_h2 = h->c_h2[z]; j.hb_w3 = crit[z]->w3; j.hb_qpart = h->qpart; j.hb_qnt = h->qnt; j.hb_net = z; j.hb_r = h->r; j.hb_d = h->d;
+        j.hb_gamma = c.gamma; j.hb_dq = h->dq[z]; j.hb_dz2 = h->dz2[z];
     }
-    for (int z = 0; z < 2; ++z) { ca.W3t[z] = do_actor ? crit[2 + z]->w3 : nullptr; ca.b3t[z] = do_actor ? crit[2 + z]->b3 : nullptr; }
-    ca.tau = c.tau;
-    ca.adam = h->adam; ca.loss = h->loss; ca.B = B; ca.H = H; ca.gamma = c.gamma; ca.beta1 = c.beta1; ca.beta2 = c.beta2; ca.eps = c.eps;
-    hipLaunchKernelGGL(td3_critic_head_bwd_kernel, dim3((H + TD3_HC - 1) / TD3_HC, 2), dim3(256), (B + 512) * sizeof(float), st, ca);
-    // 8. through the second hidden layer: dz1 = (dz2 W2) (.) [h1 > 0]   (W2 is read here, stepped in 9)
-    for (int z = 0; z < 2; ++z) bwd_data_job(ga.job[z], h->dz2[z], crit[z]->w2, h->c_h1[z], h->dz1[z]);
     launch_gemm<GEMM_G>(ga, 2, st);
-    // 9. weight gradients folded into Adam: W2, b2, W1, b1 of both critics
+    // 9. weight gradients folded into Adam: W2, b2, W1, b1 of both critics, and linear3 (dW3 = dq^T h2, db3 = sum dq: one-row jobs)
     for (int z = 0; z < 2; ++z) {
         wgrad_job(ga.job[z], h->dz2[z], h->c_h1[z], H, H, crit[z]->w2, crit[z]->b2, 1 + z, 2, h->adam);
         wgrad_job(ga.job[2 + z], h->dz1[z], h->xs, Dc, Dc, crit[z]->w1, crit[z]->b1, 1 + z, 0, h->adam);
+        wgrad_job(ga.job[4 + z], h->dq[z], h->c_h2[z], H, H, crit[z]->w3, crit[z]->b3, 1 + z, 4, h->adam);
+        ga.job[4 + z].I = 1; ga.job[4 + z].lda = 1;
+        if (z == 0) ga.job[4].loss_out = h->loss;             // the first critic's MSE: what Agent.learn returns
         if (do_actor) {      // the target critics follow in the same epilogue (nothing reads them again in this update)
             ga.job[z].tgt = crit[2 + z]->w2; ga.job[z].btgt = crit[2 + z]->b2;
             ga.job[2 + z].tgt = crit[2 + z]->w1; ga.job[2 + z].btgt = crit[2 + z]->b1;
+            ga.job[4 + z].tgt = crit[2 + z]->w3; ga.job[4 + z].btgt = crit[2 + z]->b3;
         }
     }
-    launch_gemm<GEMM_H>(ga, 4, st);
+    launch_gemm<GEMM_H>(ga, 6, st);
     if (do_actor) {
         // (10-11, the policy's hidden layers on s, ran inside launches 1-2; 12, its head, runs inside 13)
         // 13-14. the UPDATED first critic on (s, pi(s)) (TD3:268)
@@ -854,19 +783,22 @@ extern "C" int cn_td3_update(cn_td3_handle h, int do_actor, const cn_td3_batch* 
         bwd_data_job(ga.job[0], h->dz2[0], c.q1.w2, h->c_h1[0], h->dz1[0]);
         ga.job[0].da_w = c.q1.w1 + D; ga.job[0].da_ld = Dc; ga.job[0].da_out = h->dapart; ga.job[0].da_nt = h->dant;     // the action columns of W1
         launch_gemm<GEMM_G>(ga, 1, st);
-        ActorHeadBwdArgs aa;
-        aa.dapart = h->dapart; aa.dant = h->dant; aa.logits = h->logits; aa.max_v = c.max_v; aa.max_w = c.max_w;
-        aa.h2a = h->a_h2; aa.dz2a = h->dz2[1];
-        aa.W3 = c.actor.w3; aa.b3 = c.actor.b3; aa.m3 = h->mom[0][4][0]; aa.v3 = h->mom[0][4][1]; aa.mb3 = h->mom[0][5][0]; aa.vb3 = h->mom[0][5][1];
-        aa.W3t = c.actor_t.w3; aa.b3t = c.actor_t.b3; aa.tau = c.tau;
-        aa.adam = h->adam; aa.B = B; aa.H = H; aa.beta1 = c.beta1; aa.beta2 = c.beta2; aa.eps = c.eps;
-        hipLaunchKernelGGL(td3_actor_head_bwd_kernel, dim3((H + TD3_HC - 1) / TD3_HC), dim3(256), (2 * B + 512) * sizeof(float), st, aa);
-        // 18-19. the actor's hidden layers
-        bwd_data_job(ga.job[0], h->dz2[1], c.actor.w2, h->a_h1, h->dz1[1]); launch_gemm<GEMM_G>(ga, 1, st);
+        // 17-19. through the heads' derivatives and the actor's hidden layers (the heads' part evaluated inside the backward GEMM,
+        // linear3's gradient dl^T h2 as a two-row job of the weight-gradient launch)
+        bwd_data_job(ga.job[0], h->a_h2, c.actor.w2, h->a_h1, h->dz1[1]);
+        {
+            GemmJob& j = ga.job[0];
+            j.ab_h2 = h->a_h2; j.ab_w3 = c.actor.w3; j.ab_dapart = h->dapart; j.ab_dant = h->dant; j.ab_logits = h->logits;
+            j.ab_max_v = c.max_v; j.ab_max_w = c.max_w; j.ab_dl = h->dl; j.ab_dz2 = h->dz2[1];
+        }
+        launch_gemm<GEMM_G>(ga, 1, st);
         wgrad_job(ga.job[0], h->dz2[1], h->a_h1, H, H, c.actor.w2, c.actor.b2, 0, 2, h->adam + 2);
         wgrad_job(ga.job[1], h->dz1[1], h->xs, Dc, D, c.actor.w1, c.actor.b1, 0, 0, h->adam + 2);
+        wgrad_job(ga.job[2], h->dl, h->a_h2, H, H, c.actor.w3, c.actor.b3, 0, 4, h->adam + 2);
+        ga.job[2].I = 2; ga.job[2].lda = 2;
         ga.job[0].tgt = c.actor_t.w2; ga.job[0].btgt = c.actor_t.b2; ga.job[1].tgt = c.actor_t.w1; ga.job[1].btgt = c.actor_t.b1;
-        launch_gemm<GEMM_H>(ga, 2, st);
+        ga.job[2].tgt = c.actor_t.w3; ga.job[2].btgt = c.actor_t.b3;
+        launch_gemm<GEMM_H>(ga, 3, st);
         // (20, the soft updates of the three targets, ran in the Adam epilogues of 7, 9, 17 and 19)
     }
     TD3CHK(hipGetLastError());
