@@ -375,11 +375,11 @@ class Agent:
                         cur["step"].fill_(float(prev["step"]))
         torch.cuda.synchronize(dev)
 
-    # ---- the same update as 8 (+ 6) hand-written launches: libcrowdnav's cn_td3_update (csrc/crowdnav_td3.hip) ----------------------
+    # ---- the same update as 7 (+ 5) hand-written launches: libcrowdnav's cn_td3_update (csrc/crowdnav_td3.hip) ----------------------
     def enable_fused_update(self):
         """Hand the update to cn_td3_update: forward / backward GEMMs of the six networks on the f32 matrix cores, weight gradients
-        and soft updates folded into the Adam step, TD target / heads in epilogues or small kernels, replay indices and target noise
-        drawn on the device -- 8 launches for the critic step, 6 more with the actor and the targets, against ~150 through PyTorch.  The
+        and soft updates folded into the Adam step, TD target / heads inside the GEMMs, replay indices and target noise
+        drawn on the device -- 7 launches for the critic step, 5 more with the actor and the targets, against ~150 through PyTorch.  The
         networks stay these nn.Modules (the kernels step their parameter storages in place); Adam's moments restart from zero
         inside the library (torch.optim state is not carried over), so call this before training, not in the middle of it."""
         import ctypes as C

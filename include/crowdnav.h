@@ -277,9 +277,9 @@ int cn_actor_forward(const cn_actor_weights* w, const float* obs, float* action,
 /* The TD3 update -- Agent.learn (td3.py:225-285) with the hyper-parameters of start_td3_training.py:62-72 -- as a short chain
  * of launches on the caller's stream (crowdnav_td3.hip): the forward and backward GEMMs of the six 3-layer networks on the f32
  * matrix cores, weight gradients folded into the Adam step (a gradient never exists in memory), the TD target / MSE gradient /
- * heads in the GEMMs' epilogues or as small kernels, replay sampling and target-policy noise drawn on the device.  8 launches for
- * the critic step, 6 more when the actor and the targets move (every policy_delay-th update); through PyTorch the same update is
- * ~150 kernels.
+ * heads evaluated inside those GEMMs, replay sampling and target-policy noise drawn on the device.  7 launches for the critic
+ * step, 5 more when the actor and the targets move (every policy_delay-th update); through PyTorch the same update is ~150
+ * kernels.
  * The parameters stay the caller's: device pointers to the nn.Linear storages (weight [out][in] row-major float32, bias
  * [out]) of actor / critics and their targets, stepped in place.  Adam's moments and step counters are the handle's (zero at
  * cn_td3_create, like a fresh torch.optim.Adam).  Arithmetic: float32 throughout like the reference; same formulas as

@@ -282,8 +282,8 @@ def test_graphed_td3_update_equals_the_eager_update():
 
 @pytest.mark.parametrize("shape", [(398, 256, 128), (46, 32, 16), (370, 64, 48), (45, 24, 10), (131, 72, 37), (7, 5, 3)])
 def test_fused_td3_update_matches_the_pytorch_update(shape):
-    """cn_td3_update (csrc/crowdnav_td3.hip: the TD3 update as 8 + 6 hand-written launches -- MFMA GEMMs forward and backward,
-    weight gradients and soft updates folded into Adam, TD target / heads as small kernels) against crowdnav.td3.Agent._update (the
+    """cn_td3_update (csrc/crowdnav_td3.hip: the TD3 update as 7 + 5 hand-written launches -- MFMA GEMMs forward and backward,
+    weight gradients and soft updates folded into Adam, TD target / heads evaluated inside the GEMMs) against crowdnav.td3.Agent._update (the
     PyTorch restatement of td3.py:225-285, itself pinned on the reference's learn() goldens): two identically initialised agents,
     the same explicit batches and target-policy noise, six updates (three with the actor step and the soft updates) -- every
     parameter of the six networks agrees up to float32 summation order.  Shapes: the product's (398 -> 256 -> 256, batch 128), the

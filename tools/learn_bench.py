@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """TD3 updates per second: the eager torch path, Agent.enable_graphs (one hipGraph launch per update) and cn_td3_update
-(Agent.enable_fused_update: 8 + 6 hand-written launches, csrc/crowdnav_td3.hip; also captured into hipGraphs here)."""
+(Agent.enable_fused_update: 7 + 5 hand-written launches, csrc/crowdnav_td3.hip; also captured into hipGraphs here)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "drl-based-mapless-crowd-navigation-with-perceived-risk_amd"))
