@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_PKG, "lib", "libcrowdnav.so")
 BUILD_SH = os.path.join(_PKG, "csrc", "build.sh")
 
 CN_MAX_TRACKS = 64
-EXPECTED_ABI = 6       # the version the ctypes structs below were written against (include/crowdnav.h CN_ABI_VERSION)
+EXPECTED_ABI = 7       # the version the ctypes structs below were written against (include/crowdnav.h CN_ABI_VERSION)
 CN_PHASE_ALL, CN_PHASE_PRE, CN_PHASE_GET_STATE, CN_PHASE_REWARD = 0, 1, 2, 4
 CN_SD_COUNT = 24
 CN_SI_COUNT = 16
@@ -30,7 +30,8 @@ EXPORTS = ["cn_abi_version", "cn_last_error", "cn_create", "cn_destroy", "cn_obs
            "cn_observe_external",
            "cn_policy_tail", "cn_actor_pack_weights", "cn_actor_forward", "cn_step_sequence", "cn_rollout_policy", "cn_get_counters",
            "cn_get_returns", "cn_debug_env", "cn_lds_bytes", "cn_near_separate", "cn_snapshot_size", "cn_snapshot", "cn_restore",
-           "cn_td3_create", "cn_td3_destroy", "cn_td3_update", "cn_td3_loss_dev", "cn_td3_last_error"]
+           "cn_td3_create", "cn_td3_destroy", "cn_td3_update", "cn_td3_loss_dev", "cn_td3_last_error",
+           "cn_replay_write", "cn_episode_log_add"]
 
 
 class CnStepIO(C.Structure):
@@ -117,6 +118,17 @@ class CnTd3Config(C.Structure):
 
 class CnTd3Batch(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("s", "a", "r", "s2", "d", "target_noise")]
+
+
+class CnReplayRing(C.Structure):
+    """Mirror of `cn_replay_ring` (include/crowdnav.h)."""
+    _fields_ = [(n, C.c_void_p) for n in ("s", "a", "r", "s2", "d")] + [("capacity", C.c_int64), ("pos_dev", C.c_void_p),
+                                                                         ("size_dev", C.c_void_p), ("obs_dim", C.c_int32), ("reserved", C.c_int32)]
+
+
+class CnEpisodeLog(C.Structure):
+    """Mirror of `cn_episode_log` (include/crowdnav.h)."""
+    _fields_ = [("rows", C.c_void_p), ("max_rows", C.c_int64), ("n_dev", C.c_void_p), ("tot_dev", C.c_void_p)]
 
 
 class CnSequenceIO(C.Structure):
@@ -232,6 +244,8 @@ def lib():
         L.cn_td3_update.argtypes = [vp, C.c_int, C.POINTER(CnTd3Batch), vp]
         L.cn_td3_loss_dev.argtypes = [vp]; L.cn_td3_loss_dev.restype = vp
         L.cn_td3_last_error.restype = C.c_char_p
+        L.cn_replay_write.argtypes = [C.POINTER(CnReplayRing), vp, vp, vp, vp, vp, vp, C.c_int, vp, C.c_int, vp]
+        L.cn_episode_log_add.argtypes = [C.POINTER(CnEpisodeLog), vp, vp, C.c_int, vp, vp, C.c_float, C.c_int, C.c_int, vp]
         _lib = L
     return _lib
 

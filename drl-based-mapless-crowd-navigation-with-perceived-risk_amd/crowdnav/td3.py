@@ -56,10 +56,15 @@ class DeviceReplay:
     ring.  The host only keeps BOUNDS on the fill level (`_lb` <= size_dev <= `_ub`): add() moves both (every row is kept),
     add_masked() moves the upper one only.  `ready(n)` answers "more than n rows?" from the bounds and reads the device scalar
     only while they straddle n -- never again once the ring holds more than a batch -- and `len()` is exact (it reads the device
-    when the bounds differ)."""
+    when the bounds differ).  On a HIP device a write is libcrowdnav's cn_replay_write (two launches); `fused=False` keeps the
+    PyTorch formulation (~15 kernels: cumulative sum, index arithmetic, five index_copy_), which is also what runs on the CPU
+    and what the GPU tests compare the fused write against."""
 
-    def __init__(self, capacity, obs_dim, device):
+    def __init__(self, capacity, obs_dim, device, fused=True):
         self.cap = int(capacity)
+        self.obs_dim = int(obs_dim)
+        self.fused = bool(fused) and torch.device(device).type == "cuda"
+        self._ring = None
         cap1 = self.cap + 1                       # row `cap`: where add_masked() drops the rows it does not keep
         self.s = torch.zeros((cap1, obs_dim), dtype=torch.float32, device=device)
         self.s2 = torch.zeros((cap1, obs_dim), dtype=torch.float32, device=device)
@@ -84,7 +89,36 @@ class DeviceReplay:
         self._write(s, a, r, s2, d, keep)
         self._ub = min(self.cap, self._ub + s.shape[0])
 
+    def _write_fused(self, s, a, r, s2, d, keep):
+        import ctypes as C
+        from . import _abi
+        L = _abi.lib()
+        n = s.shape[0]
+        dev = self.s.device
+        if self._ring is None:
+            self._ring = _abi.CnReplayRing(s=self.s.data_ptr(), a=self.a.data_ptr(), r=self.r.data_ptr(), s2=self.s2.data_ptr(), d=self.d.data_ptr(),
+                                           capacity=self.cap, pos_dev=self.pos_dev.data_ptr(), size_dev=self.size_dev.data_ptr(),
+                                           obs_dim=self.obs_dim, reserved=0)
+            self._slot = torch.zeros(0, dtype=torch.int32, device=dev)
+        if self._slot.numel() < n:
+            self._slot = torch.zeros(n, dtype=torch.int32, device=dev)
+        f32 = lambda x, shape: x.reshape(shape).to(torch.float32).contiguous()        # (no-ops for what Env.step and Agent.act hand over)
+        s, s2, a, r = f32(s, (n, self.obs_dim)), f32(s2, (n, self.obs_dim)), f32(a, (n, 2)), f32(r, (n,))
+        d = d.reshape(n)
+        d8 = d.contiguous() if d.dtype in (torch.uint8, torch.bool) else (d != 0)
+        k8 = None
+        if keep is not None:
+            k8 = keep.reshape(n).contiguous() if keep.dtype in (torch.uint8, torch.bool) else (keep.reshape(n) != 0)
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        rc = L.cn_replay_write(C.byref(self._ring), C.c_void_p(s.data_ptr()), C.c_void_p(a.data_ptr()), C.c_void_p(r.data_ptr()),
+                               C.c_void_p(s2.data_ptr()), C.c_void_p(d8.data_ptr()), C.c_void_p(k8.data_ptr() if k8 is not None else None),
+                               n, C.c_void_p(self._slot.data_ptr()), dev.index if dev.index is not None else torch.cuda.current_device(), st)
+        if rc != 0:
+            raise _abi.CrowdNavError("cn_replay_write: %s" % L.cn_td3_last_error().decode())
+
     def _write(self, s, a, r, s2, d, keep):
+        if self.fused:
+            return self._write_fused(s, a, r, s2, d, keep)
         n = s.shape[0]
         if keep is None:
             c = torch.arange(1, n + 1, device=s.device)

@@ -53,16 +53,39 @@ def make_env(scenario, n_envs, max_steps, seed, device, ped_vmax=None, **switche
 class DeviceEpisodeLog:
     """Finished episodes, recorded on the device: running totals for the progress line and one row per episode for the CSV
     (success, failure, return, steps, ego / social violations, obstacle-present steps, launch index) -- appended with a
-    cumulative-sum scatter, rows of envs that did not finish go to a spare row.  One host read per flush()."""
+    cumulative-sum scatter, rows of envs that did not finish go to a spare row.  One host read per flush().  On a HIP device add()
+    is libcrowdnav's cn_episode_log_add (one launch instead of ~20 PyTorch kernels); `fused=False` keeps the PyTorch formulation."""
 
-    def __init__(self, device, max_rows):
+    def __init__(self, device, max_rows, fused=True):
         self.max_rows = int(max_rows)
+        self.fused = bool(fused) and torch.device(device).type == "cuda"
+        self._log = None
         self.rows = torch.zeros((self.max_rows + 1, 8), dtype=torch.float32, device=device)
         self.n = torch.zeros((), dtype=torch.int64, device=device)
         self.tot = torch.zeros(5, dtype=torch.float64, device=device)     # episodes, successes, return sum, step sum, env-steps
         self._flushed = 0
 
+    def _add_fused(self, done, counters, last_return, launch, transitions):
+        import ctypes as C
+        from . import _abi
+        L = _abi.lib()
+        dev = self.rows.device
+        if self._log is None:
+            self._log = _abi.CnEpisodeLog(rows=self.rows.data_ptr(), max_rows=self.max_rows, n_dev=self.n.data_ptr(), tot_dev=self.tot.data_ptr())
+        n = done.shape[0]
+        d8 = done.contiguous() if done.dtype in (torch.uint8, torch.bool) else (done != 0)
+        t8 = transitions.contiguous() if transitions.dtype in (torch.uint8, torch.bool) else (transitions != 0)
+        cnt = counters if counters.dtype == torch.int32 and counters.is_contiguous() else counters.to(torch.int32).contiguous()
+        ret = last_return if last_return.dtype == torch.float32 and last_return.is_contiguous() else last_return.float().contiguous()
+        rc = L.cn_episode_log_add(C.byref(self._log), C.c_void_p(d8.data_ptr()), C.c_void_p(cnt.data_ptr()), cnt.shape[1], C.c_void_p(ret.data_ptr()),
+                                  C.c_void_p(t8.data_ptr()), float(launch), n, dev.index if dev.index is not None else torch.cuda.current_device(),
+                                  C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        if rc != 0:
+            raise _abi.CrowdNavError("cn_episode_log_add: %s" % L.cn_td3_last_error().decode())
+
     def add(self, done, counters, last_return, launch, transitions):
+        if self.fused:
+            return self._add_fused(done, counters, last_return, launch, transitions)
         d = done.bool()
         k = d.to(torch.int64)
         c = torch.cumsum(k, 0)
@@ -99,7 +122,7 @@ def train(a):
         if os.path.exists(ns):           # continue the exploration-noise stream instead of replaying it
             agent.set_noise_state(*[int(x) for x in open(ns).read().split()])
     if a.learner == "fused":
-        agent.enable_fused_update()   # cn_td3_update: the update as 10 (+ 11) hand-written launches
+        agent.enable_fused_update()   # cn_td3_update: the update as 7 (+ 5) hand-written launches
     elif a.graphs:
         agent.enable_graphs()         # a TD3 update as one hipGraph launch (the eager update is launch-bound at batch 128)
     stats = EpisodeStats()

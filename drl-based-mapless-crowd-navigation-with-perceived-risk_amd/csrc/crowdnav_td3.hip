@@ -577,6 +577,105 @@ __device__ __forceinline__ float td3_wave_sum(float v)
 // sums in td3_dgrad_kernel's da epilogue; through the heads' derivatives and the actor's linear3 = the same kernel's ab mode on
 // the next launch; dW3a = dl^T h2a = a two-row job of td3_wgrad_kernel.  (Rounds 3-4: td3_dlogit_kernel, one wavefront per row,
 // 4.8 us, and td3_actor_head_bwd_kernel, 9 us; the critics had td3_q_head_kernel and td3_critic_head_bwd_kernel.)
+// ---- the collection loop's bookkeeping (cn_replay_write, cn_episode_log_add) --------------------------------------------------
+// inclusive scan of one int per thread over a 1024-thread workgroup (wave scans + a scan of the 16 wave totals)
+__device__ __forceinline__ int cn_block_scan_1024(int v, int* __restrict__ wsum, int& total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int u = __shfl_up(v, d, 64); if (lane >= d) v += u; }
+    if (lane == 63) wsum[wave] = v;
+    __syncthreads();
+    int before = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { const int x = wsum[w]; if (w < wave) before += x; tot += x; }
+    __syncthreads();
+    total = tot;
+    return v + before;
+}
+// slots of the kept rows, in row order; the ring's position and fill level move at the end (one workgroup: they are read first)
+__global__ void __launch_bounds__(1024) cn_replay_slot_kernel(const uint8_t* __restrict__ keep, int n, int64_t cap, int64_t* pos_dev,
+                                                              int64_t* size_dev, int32_t* __restrict__ slot)
+{
+    __shared__ int wsum[16];
+    const int64_t pos = *pos_dev, size = *size_dev;
+    int64_t carry = 0;
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int k = i < n ? (keep ? (keep[i] != 0) : 1) : 0;
+        int tot;
+        const int c = cn_block_scan_1024(k, wsum, tot);
+        if (i < n) slot[i] = k ? (int32_t)((pos + carry + c - 1) % cap) : -1;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) {
+        *pos_dev = (pos + carry) % cap;
+        *size_dev = size + carry < cap ? size + carry : cap;
+    }
+}
+struct ReplayCopyArgs { cn_replay_ring ring; const float *s, *a, *r, *s2; const uint8_t* done; const int32_t* slot; };
+__global__ void __launch_bounds__(256) cn_replay_copy_kernel(ReplayCopyArgs p)
+{
+    const int i = blockIdx.x, D = p.ring.obs_dim;
+    const int32_t sl = p.slot[i];
+    if (sl < 0) return;
+    const float* __restrict__ s = p.s + (size_t)i * D;
+    const float* __restrict__ s2 = p.s2 + (size_t)i * D;
+    float* __restrict__ ds = p.ring.s + (size_t)sl * D;
+    float* __restrict__ ds2 = p.ring.s2 + (size_t)sl * D;
+    for (int c = threadIdx.x; c < D; c += blockDim.x) { ds[c] = s[c]; ds2[c] = s2[c]; }
+    if (threadIdx.x < 2) p.ring.a[(size_t)sl * 2 + threadIdx.x] = p.a[(size_t)i * 2 + threadIdx.x];
+    if (threadIdx.x == 2) p.ring.r[sl] = p.r[i];
+    if (threadIdx.x == 3) p.ring.d[sl] = p.done[i] ? 1.f : 0.f;
+}
+// the finished episodes' rows and the running totals, one workgroup
+struct EpisodeLogArgs { cn_episode_log log; const uint8_t* done; const int32_t* counters; int cols; const float* ret; const uint8_t* trans; float launch; int n; };
+__global__ void __launch_bounds__(1024) cn_episode_log_kernel(EpisodeLogArgs p)
+{
+    __shared__ int wsum[16];
+    __shared__ double red[5][16];
+    const int64_t n0 = *p.log.n_dev;
+    int64_t carry = 0;
+    double t[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int base = 0; base < p.n; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int k = i < p.n ? (p.done[i] != 0) : 0;
+        int tot;
+        const int c = cn_block_scan_1024(k, wsum, tot);
+        if (i < p.n) {
+            const int32_t* __restrict__ cr = p.counters + (size_t)i * p.cols;
+            if (k) {
+                const int64_t at = n0 + carry + c - 1;
+                if (at < p.log.max_rows) {
+                    float* __restrict__ row = p.log.rows + (size_t)at * 8;
+                    row[0] = (float)cr[4]; row[1] = (float)cr[5]; row[2] = p.ret[i]; row[3] = (float)cr[13];
+                    row[4] = (float)cr[10]; row[5] = (float)cr[11]; row[6] = (float)cr[12]; row[7] = p.launch;
+                }
+                t[0] += 1.0; t[1] += (double)(float)cr[4]; t[2] += (double)p.ret[i]; t[3] += (double)(float)cr[13];
+            }
+            if (p.trans[i]) t[4] += 1.0;
+        }
+        carry += tot;
+    }
+    // totals: lanes, then wavefronts, in a fixed order
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        double v = t[q];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+        if (lane == 0) red[q][wave] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 5) {
+        double v = 0.0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) v += red[threadIdx.x][w];
+        p.log.tot_dev[threadIdx.x] += v;
+    }
+    if (threadIdx.x == 0) *p.log.n_dev = n0 + carry;
+}
+
 }  // namespace
 
 // ---- host side ------------------------------------------------------------------------------------------------------------
@@ -801,6 +900,37 @@ extern "C" int cn_td3_update(cn_td3_handle h, int do_actor, const cn_td3_batch* 
         launch_gemm<GEMM_H>(ga, 3, st);
         // (20, the soft updates of the three targets, ran in the Adam epilogues of 7, 9, 17 and 19)
     }
+    TD3CHK(hipGetLastError());
+    return CN_OK;
+}
+
+extern "C" int cn_replay_write(const cn_replay_ring* ring, const float* s, const float* a, const float* r, const float* s2,
+                               const uint8_t* done, const uint8_t* keep, int n, int32_t* slot_scratch, int device, void* stream)
+{
+    if (!ring || !s || !a || !r || !s2 || !done || !slot_scratch) return td3_fail(CN_ERR_ARG, "cn_replay_write: null argument");
+    if (!ring->s || !ring->a || !ring->r || !ring->s2 || !ring->d || !ring->pos_dev || !ring->size_dev || ring->capacity < 1 || ring->obs_dim < 1)
+        return td3_fail(CN_ERR_ARG, "cn_replay_write: incomplete ring");
+    if (n < 1) return td3_fail(CN_ERR_ARG, "cn_replay_write: n < 1");
+    DevScope scope(device);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(cn_replay_slot_kernel, dim3(1), dim3(1024), 0, st, keep, n, ring->capacity, ring->pos_dev, ring->size_dev, slot_scratch);
+    ReplayCopyArgs ca;
+    ca.ring = *ring; ca.s = s; ca.a = a; ca.r = r; ca.s2 = s2; ca.done = done; ca.slot = slot_scratch;
+    hipLaunchKernelGGL(cn_replay_copy_kernel, dim3(n), dim3(256), 0, st, ca);
+    TD3CHK(hipGetLastError());
+    return CN_OK;
+}
+
+extern "C" int cn_episode_log_add(const cn_episode_log* log, const uint8_t* done, const int32_t* counters, int counter_cols,
+                                  const float* last_return, const uint8_t* transitions, float launch, int n, int device, void* stream)
+{
+    if (!log || !log->rows || !log->n_dev || !log->tot_dev || !done || !counters || !last_return || !transitions)
+        return td3_fail(CN_ERR_ARG, "cn_episode_log_add: null argument");
+    if (n < 1 || counter_cols < 14 || log->max_rows < 0) return td3_fail(CN_ERR_ARG, "cn_episode_log_add: n < 1, fewer than 14 counter columns or max_rows < 0");
+    DevScope scope(device);
+    EpisodeLogArgs ea;
+    ea.log = *log; ea.done = done; ea.counters = counters; ea.cols = counter_cols; ea.ret = last_return; ea.trans = transitions; ea.launch = launch; ea.n = n;
+    hipLaunchKernelGGL(cn_episode_log_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, ea);
     TD3CHK(hipGetLastError());
     return CN_OK;
 }

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CN_ABI_VERSION 6
+#define CN_ABI_VERSION 7
 #define CN_MAX_TRACKS 64      /* largest per-env capacity of the obstacle tracker (ENV:656-743): one lane per track */
 #define CN_MAX_K 16
 
@@ -315,6 +315,37 @@ void cn_td3_destroy(cn_td3_handle h);
 int cn_td3_update(cn_td3_handle h, int do_actor, const cn_td3_batch* batch, void* stream);
 const float* cn_td3_loss_dev(cn_td3_handle h);      /* device pointer: the first critic's MSE loss of the last update */
 const char* cn_td3_last_error(void);
+
+/* The collection loop's bookkeeping between Env.step and Agent.learn (start_td3_training.py:129-149) for a batch of environments,
+ * without a host read: ReplayBuffer.add (td3.py:24-31) into a ring on the device, and the per-episode record TRAIN:139-149 prints
+ * and utils.record_data writes.  (crowdnav.td3.DeviceReplay and crowdnav.train.DeviceEpisodeLog do the same through ~35 PyTorch
+ * kernels per launch; next to a 0.065 ms update that is a seventh of a training launch.)  Both enqueue only.
+ *
+ * cn_replay_write: rows i < n with keep[i] != 0 (keep NULL = all) go to consecutive ring slots (*pos_dev + rank) mod capacity in
+ * row order; then *pos_dev advances by their number and *size_dev grows up to capacity.  Rows not kept (an environment's reset
+ * launch under the next-step reset convention) are not written.  Arrays: s, s2 [capacity][obs_dim], a [capacity][2], r, d
+ * [capacity]; done / keep are bytes.  slot_scratch: n int32 of device scratch. */
+typedef struct cn_replay_ring {
+    float *s, *a, *r, *s2, *d;
+    int64_t capacity;
+    int64_t* pos_dev;        /* next write position */
+    int64_t* size_dev;       /* fill level (what cn_td3_config.replay_size_dev points at) */
+    int32_t obs_dim, reserved;
+} cn_replay_ring;
+int cn_replay_write(const cn_replay_ring* ring, const float* s, const float* a, const float* r, const float* s2,
+                    const uint8_t* done, const uint8_t* keep, int n, int32_t* slot_scratch, int device, void* stream);
+/* cn_episode_log_add: one 8-float row per environment with done[i] != 0, appended at *n_dev in row order (rows past max_rows are
+ * dropped, *n_dev keeps counting): {success, failure, return, steps, ego violations, social violations, obstacle-present steps,
+ * launch} from the counter columns 4, 5, 13, 10, 11, 12 (cn_get_counters) and last_return (cn_get_returns); and the running
+ * totals tot_dev[5] += {episodes, successes, sum of returns, sum of steps, number of rows with transitions[i] != 0}. */
+typedef struct cn_episode_log {
+    float* rows;             /* [max_rows][8] */
+    int64_t max_rows;
+    int64_t* n_dev;
+    double* tot_dev;         /* [5] */
+} cn_episode_log;
+int cn_episode_log_add(const cn_episode_log* log, const uint8_t* done, const int32_t* counters, int counter_cols,
+                       const float* last_return, const uint8_t* transitions, float launch, int n, int device, void* stream);
 
 /* n_steps calls of cn_step (auto_reset = 2, the next-step reset convention) with OPEN-LOOP actions -- scripted or recorded
  * actions, action repeat, the uniform-random warm-up phase of an off-policy learner -- as ONE launch: a wavefront keeps its

@@ -157,6 +157,47 @@ def test_training_return_rises(tmp_path):
     assert max(w[2] for w in late) > max(w[2] for w in early) + 100.0, lines
 
 
+def test_fused_replay_write_and_episode_log_equal_the_pytorch_formulation():
+    """cn_replay_write / cn_episode_log_add (the collection loop's bookkeeping, TRAIN:129-149 + ReplayBuffer.add TD3:24-31, as two
+    and one launches) against the PyTorch formulation they replace (DeviceReplay / DeviceEpisodeLog with fused=False): the same
+    calls on both -- masked and plain adds mixed, row counts below and above one scan chunk (1024), the ring wrapping several times,
+    the episode log running past its capacity -- leave the same ring, position, fill level, rows, row count and totals."""
+    import torch
+    from crowdnav.td3 import DeviceReplay
+    from crowdnav.train import DeviceEpisodeLog
+    g = torch.Generator(device="cuda").manual_seed(5)
+    cap, D = 5003, 11
+    A, B = DeviceReplay(cap, D, "cuda"), DeviceReplay(cap, D, "cuda", fused=False)
+    assert A.fused and not B.fused
+    EA, EB = DeviceEpisodeLog(torch.device("cuda"), 700), DeviceEpisodeLog(torch.device("cuda"), 700, fused=False)
+    assert EA.fused and not EB.fused
+    rnd = lambda *sh: torch.randn(sh, generator=g, device="cuda")
+    coin = lambda n, p: torch.rand(n, generator=g, device="cuda") < p
+    for it in range(14):
+        n = [5, 16, 1, 1024, 2050, 1025, 333][it % 7]
+        s, a, r, s2 = rnd(n, D), rnd(n, 2), rnd(n), rnd(n, D)
+        d = coin(n, 0.3).to(torch.uint8) if it % 2 else coin(n, 0.3)
+        keep = coin(n, 0.7)
+        for R in (A, B):
+            if it % 3 == 2: R.add(s, a, r, s2, d)
+            else: R.add_masked(s, a, r, s2, d, keep)
+        cnt = torch.randint(0, 50, (n, 14), generator=g, device="cuda", dtype=torch.int32)
+        ret = rnd(n) * 100
+        for E in (EA, EB):
+            E.add(d, cnt, ret, it + 1, keep)
+        torch.cuda.synchronize()
+        assert int(A.pos_dev) == int(B.pos_dev) and int(A.size_dev) == int(B.size_dev), it
+        for x, y in ((A.s, B.s), (A.a, B.a), (A.r, B.r), (A.s2, B.s2), (A.d, B.d)):
+            assert torch.equal(x[:cap], y[:cap]), it
+        assert len(A) == len(B)
+        assert int(EA.n) == int(EB.n)
+        assert torch.equal(EA.rows[:700], EB.rows[:700]), it
+        assert torch.allclose(EA.tot, EB.tot, rtol=1e-12, atol=0), (EA.tot, EB.tot)
+    assert int(A.size_dev) == cap and int(EA.n) > 700                # the ring wrapped; the log ran past its capacity
+    ra, ta = EA.flush(); rb, tb = EB.flush()
+    assert torch.equal(ra, rb) and ra.shape[0] == 700 and ta[0] == tb[0]
+
+
 @pytest.mark.parametrize("reset_mode", ["next", "same"])
 def test_batched_trainer_runs_on_the_next_step_reset_kernel(tmp_path, reset_mode):
     """crowdnav.train (TRAIN:40-168 batched) without a host synchronisation per launch: the actor as one kernel

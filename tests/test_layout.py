@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(L, s), "libcrowdnav.so does not export %s" % s
     assert set(syms) == set(crowdnav._abi.EXPORTS)
-    assert L.cn_abi_version() == crowdnav._abi.EXPECTED_ABI == 6
+    assert L.cn_abi_version() == crowdnav._abi.EXPECTED_ABI == 7
 
 
 def test_config_struct_matches_header_and_oracle():
@@ -54,7 +54,7 @@ def test_python_mirrors_match_the_header_field_by_field(tmp_path):
         pytest.skip("no gcc")
     pairs = [("cn_config", CnConfig), ("cn_step_io", _abi.CnStepIO), ("cn_external_io", _abi.CnExternalIO),
              ("cn_actor_weights", _abi.CnActorWeights), ("cn_td3_mlp", _abi.CnTd3Mlp), ("cn_td3_config", _abi.CnTd3Config),
-             ("cn_td3_batch", _abi.CnTd3Batch), ("cn_sequence_io", _abi.CnSequenceIO), ("cn_policy_io", _abi.CnPolicyIO),
+             ("cn_td3_batch", _abi.CnTd3Batch), ("cn_replay_ring", _abi.CnReplayRing), ("cn_episode_log", _abi.CnEpisodeLog), ("cn_sequence_io", _abi.CnSequenceIO), ("cn_policy_io", _abi.CnPolicyIO),
              ("cn_snapshot_header", _abi.CnSnapshotHeader)]
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "crowdnav.h"', 'int main(void) {']
     for cname, cls in pairs:
