@@ -524,6 +524,31 @@ def main():
                           "roofline": {"bound": "hbm", "bytes_per_env_step_d4": d4, "achieved": l_["median"] * d4 / 1e9,
                                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": l_["median"] * d4 / 1e9 / HBM_PEAK_GBS}}
 
+    # The caller of the path: the TD3 update the collected transitions feed -- cn_td3_update (csrc/crowdnav_td3.hip) at the
+    # reference's batch of 128, sampled from a 100 000-row device replay of synthetic transitions, 50 untimed + 400 timed updates
+    # (tools/learn_bench.py is the same measurement with the PyTorch update beside it).  Not an env-steps figure: reported as flat keys.
+    learner = None
+    if single_default and N == 4096 and not a.no_other_configs:
+        from crowdnav.td3 import Agent as _Agent
+        la = _Agent(obs_dim=cfg.obs_dim, device="cuda:%d" % dev_index, seed=0, batch_size=128, memory_size=200000)
+        nrep = 100000
+        la.memory.add(torch.randn((nrep, cfg.obs_dim), device=la.device), torch.rand((nrep, 2), device=la.device),
+                      torch.randn(nrep, device=la.device), torch.randn((nrep, cfg.obs_dim), device=la.device),
+                      torch.rand(nrep, device=la.device) < 0.05)
+        la.enable_fused_update()
+        for i in range(50):
+            la.learn(i)
+        torch.cuda.synchronize(dev_index)
+        t0 = time.perf_counter()
+        for i in range(400):
+            la.learn(i)
+        torch.cuda.synchronize(dev_index)
+        dt = (time.perf_counter() - t0) / 400
+        learner = {"what": "cn_td3_update, batch 128, obs_dim %d, hidden 256, policy_delay 2 (every other update steps the actor and the targets), "
+                           "replay of %d synthetic rows on the device" % (cfg.obs_dim, nrep),
+                   "update_ms": dt * 1e3, "updates_s": 1.0 / dt, "launches_per_update": "7 (critic step) / 12 (with the actor step)"}
+        del la
+
     gather = None
     if use_dist:
         # the path's one exchange: all-gather of per-env episode returns over xGMI.  A fresh handle stepped a few
@@ -696,6 +721,11 @@ def main():
         fc["%s_roofline_frac" % k_] = oc["roofline"]["frac"]
         for g, v in oc["legs_env_steps_s"].items():
             fc["%s_leg_%s_env_steps_s" % (k_, g)] = v
+    if learner:
+        fc["learner"] = learner["what"]
+        fc["learner_td3_update_ms"] = learner["update_ms"]
+        fc["learner_td3_updates_s"] = learner["updates_s"]
+        fc["learner_launches_per_update"] = learner["launches_per_update"]
     if sustained:
         fc["sustained_env_steps_s"] = sustained["env_steps_s"]
         fc["sustained_seconds"] = sustained["seconds"]
