@@ -123,6 +123,7 @@ struct GemmJob {
     float* loss_out;
 };
 struct GemmArgs { GemmJob job[6]; float beta1, beta2, eps, tau; TickArgs tick; int do_tick; };
+static_assert(sizeof(GemmArgs) <= 4096, "GemmArgs travels in the kernarg segment (4 KB)");
 // target <- target (1 - tau) + local tau (TD3:297-299)
 __device__ __forceinline__ float td3_soft(float target, float local, float tau) { return target * (1.f - tau) + local * tau; }
 
