@@ -1038,6 +1038,15 @@ def test_error_codes_and_limits():
     assert L.cn_step_sequence(h, None, None) == -1 and b"null" in L.cn_last_error()
     assert L.cn_rollout_policy(h, None, None, None) == -1 and b"null" in L.cn_last_error()
     L.cn_destroy(h)
+    # the bookkeeping entry points (their messages come from cn_td3_last_error, like the learner's)
+    from crowdnav import _abi
+    assert L.cn_replay_write(None, None, None, None, None, None, None, 4, None, 0, None) == -1 and b"null" in L.cn_td3_last_error()
+    ring = _abi.CnReplayRing()          # all-null ring
+    one = C.c_void_p(8)
+    assert L.cn_replay_write(C.byref(ring), one, one, one, one, one, None, 4, one, 0, None) == -1 and b"incomplete ring" in L.cn_td3_last_error()
+    assert L.cn_episode_log_add(None, None, None, 14, None, None, 1.0, 4, 0, None) == -1 and b"null" in L.cn_td3_last_error()
+    elog = _abi.CnEpisodeLog(rows=8, max_rows=4, n_dev=8, tot_dev=8)
+    assert L.cn_episode_log_add(C.byref(elog), one, one, 13, one, one, 1.0, 4, 0, None) == -1 and b"14 counter columns" in L.cn_td3_last_error()
     # cn_rollout_policy: an actor of another observation width, and a shape whose 16 working sets do not fit a CU's LDS
     import torch
     from crowdnav.env import VecEnv
