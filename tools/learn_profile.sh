@@ -4,7 +4,7 @@
 TAG="${1:-r05}"; cd "$(dirname "$0")/.."; OUT="$PWD/gpurun_out/$TAG"; mkdir -p "$OUT"
 export TMPDIR=/tmp
 D=/tmp/learn_prof; rm -rf "$D"
-CN_BATCHES=128 CN_LEARN_MODES=fused rocprofv3 --kernel-trace --stats -d "$D" -o learn --output-format csv -- python tools/learn_bench.py > /dev/null 2>&1
+CN_BATCHES=${CN_BATCHES:-128} CN_LEARN_MODES=fused rocprofv3 --kernel-trace --stats -d "$D" -o learn --output-format csv -- python tools/learn_bench.py > /dev/null 2>&1
 F=$(find "$D" -name '*kernel_stats.csv' | head -1)
 python - "$F" > "$OUT/learn_kernels.txt" <<'PY'
 import csv, sys
