@@ -912,6 +912,7 @@ extern "C" int cn_replay_write(const cn_replay_ring* ring, const float* s, const
     if (!ring->s || !ring->a || !ring->r || !ring->s2 || !ring->d || !ring->pos_dev || !ring->size_dev || ring->capacity < 1 || ring->obs_dim < 1)
         return td3_fail(CN_ERR_ARG, "cn_replay_write: incomplete ring");
     if (n < 1) return td3_fail(CN_ERR_ARG, "cn_replay_write: n < 1");
+    if ((int64_t)n > ring->capacity) return td3_fail(CN_ERR_ARG, "cn_replay_write: more rows than the ring holds (two rows of one call would share a slot)");
     DevScope scope(device);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(cn_replay_slot_kernel, dim3(1), dim3(1024), 0, st, keep, n, ring->capacity, ring->pos_dev, ring->size_dev, slot_scratch);

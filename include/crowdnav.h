@@ -324,7 +324,7 @@ const char* cn_td3_last_error(void);
  * cn_replay_write: rows i < n with keep[i] != 0 (keep NULL = all) go to consecutive ring slots (*pos_dev + rank) mod capacity in
  * row order; then *pos_dev advances by their number and *size_dev grows up to capacity.  Rows not kept (an environment's reset
  * launch under the next-step reset convention) are not written.  Arrays: s, s2 [capacity][obs_dim], a [capacity][2], r, d
- * [capacity]; done / keep are bytes.  slot_scratch: n int32 of device scratch. */
+ * [capacity]; done / keep are bytes; n <= capacity.  slot_scratch: n int32 of device scratch. */
 typedef struct cn_replay_ring {
     float *s, *a, *r, *s2, *d;
     int64_t capacity;

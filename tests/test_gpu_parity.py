@@ -1044,6 +1044,8 @@ def test_error_codes_and_limits():
     ring = _abi.CnReplayRing()          # all-null ring
     one = C.c_void_p(8)
     assert L.cn_replay_write(C.byref(ring), one, one, one, one, one, None, 4, one, 0, None) == -1 and b"incomplete ring" in L.cn_td3_last_error()
+    full = _abi.CnReplayRing(s=8, a=8, r=8, s2=8, d=8, capacity=3, pos_dev=8, size_dev=8, obs_dim=4, reserved=0)
+    assert L.cn_replay_write(C.byref(full), one, one, one, one, one, None, 4, one, 0, None) == -1 and b"more rows than the ring" in L.cn_td3_last_error()
     assert L.cn_episode_log_add(None, None, None, 14, None, None, 1.0, 4, 0, None) == -1 and b"null" in L.cn_td3_last_error()
     elog = _abi.CnEpisodeLog(rows=8, max_rows=4, n_dev=8, tot_dev=8)
     assert L.cn_episode_log_add(C.byref(elog), one, one, 13, one, one, 1.0, 4, 0, None) == -1 and b"14 counter columns" in L.cn_td3_last_error()
