@@ -28,6 +28,8 @@ case "$SET" in
     for S in 0 1 2 3 4 5 6 7; do run init003_fused_e16_seed$S --envs 16 --updates 16 --waypoint-reward 0 --learner fused --seed $S --actor-final-init 0.003; done ;;
   r05)     # round 5: the 16-env recipe on cn_td3_update at 0.068 ms (other summation order than round 4: other trajectories)
     for S in 0 1; do run fused_e16_u16_wp0_seed$S --envs 16 --updates 16 --waypoint-reward 0 --learner fused --seed $S; done ;;
+  r05long) # round 5: the same recipe, seed 0, for as long as the second argument says (900 s: where does it level off?)
+    run fused_e16_u16_wp0_seed0_long --envs 16 --updates 16 --waypoint-reward 0 --learner fused --seed 0 ;;
   final)   # the 16-env recipe on the final tree (cn_td3_update at 0.127 ms)
     run final_fused_e16_u16_wp0 --envs 16 --updates 16 --waypoint-reward 0 --learner fused ;;
   fused)   # the same runs on cn_td3_update (csrc/crowdnav_td3.hip): the reference's ratio of one update per env-step, and 4x the envs
