@@ -149,20 +149,21 @@ class VecEnv:
         return self.obs
 
     _warned_default_reset = False
+    _UNSET = object()          # "auto_reset omitted" (-> "next" with a one-time warning); an explicit None keeps meaning False
 
-    def step(self, action, step_counter=None, auto_reset=None, want_final=False):
+    def step(self, action, step_counter=None, auto_reset=_UNSET, want_final=False):
         """Env.step for every env.  action: [N,2] float32 device tensor (v, w).
         auto_reset: "next" (a finished env returns its TERMINAL observation with done = 1 and spends the next call on Env.reset
         -- that call ignores its action and returns the new episode's first observation with reward 0, done 0; one observation
         per wavefront, the fast kernel) | True / "same" (finished envs run Env.reset inside the same call: obs = the new
         episode's first observation, the terminal one in final_obs when want_final; a launch then lasts two observations for
-        any env that finishes -- ~55 % of the speed) | False (no reset: the caller resets).
+        any env that finishes -- ~55 % of the speed) | False / None (no reset: the caller resets).
         Omitted: "next" (the default since round 4; it was "same" before) with a one-time warning, because a caller written for
         the same-call convention that stores EVERY returned row as a transition would silently record reset launches: under
         "next" the rows of the call AFTER done = 1 are not transitions -- keep `resetting = done.bool().clone()` from one call
         and drop those rows of the next (crowdnav.rollout.rollout does exactly that).
         Returns (obs, reward, done) device tensors (views of internal buffers)."""
-        if auto_reset is None:
+        if auto_reset is VecEnv._UNSET:
             auto_reset = "next"
             if not VecEnv._warned_default_reset:
                 VecEnv._warned_default_reset = True
@@ -180,7 +181,7 @@ class VecEnv:
                            obs=self.obs.data_ptr(), final_obs=self.final_obs.data_ptr() if want_final else None,
                            obs_f64=self.obs_f64.data_ptr() if self.obs_f64 is not None else None,
                            reward=self.reward.data_ptr(), done=self.done.data_ptr(), topk_idx=self.topk_idx.data_ptr(),
-                           auto_reset={False: 0, True: 1, "same": 1, "next": 2}.get(auto_reset, auto_reset),
+                           auto_reset={False: 0, None: 0, True: 1, "same": 1, "next": 2}.get(auto_reset, auto_reset),
                            reserved=0)
         _abi.check(self.L.cn_step(self.h, C.byref(io), self._stream()))
         return self.obs, self.reward, self.done

@@ -63,19 +63,34 @@ class EpisodeStats:
         self._flushed = (path, len(self.rows))
         return path
 
-    def append_csv(self, outdir, filename):
+    def append_csv(self, outdir, filename, resume=False):
         """Incremental write_csv: the header the first time, then only the rows added since the last call -- so a run that is
-        killed keeps every episode up to its last log interval (the reference appends one row per episode, UTL:53-64)."""
+        killed keeps every episode up to its last log interval (the reference appends one row per episode, UTL:53-64).
+        resume=True (a run continued with --load into the same --out): an existing file is kept and appended to, and this
+        run's episode numbers continue after its last row -- utils.record_data never truncates either.  A fresh start
+        (resume=False) truncates."""
         path = os.path.join(outdir, filename + ".csv")
         done = getattr(self, "_flushed", (None, 0))
         if done[0] != path:
             os.makedirs(outdir, exist_ok=True)
-            with open(path, "w", newline="") as fp:
-                csv.writer(fp, dialect="excel").writerow(self.HEADERS)
+            self._episode_base = 0
+            if resume and os.path.exists(path) and os.path.getsize(path) > 0:
+                with open(path, newline="") as fp:
+                    prior = [r for r in csv.reader(fp, dialect="excel") if r]
+                if prior and prior[0] == self.HEADERS:
+                    prior = prior[1:]
+                try:
+                    self._episode_base = int(prior[-1][0]) if prior else 0
+                except ValueError:
+                    self._episode_base = len(prior)
+            else:
+                with open(path, "w", newline="") as fp:
+                    csv.writer(fp, dialect="excel").writerow(self.HEADERS)
             done = (path, 0)
         if len(self.rows) > done[1]:
+            base = getattr(self, "_episode_base", 0)
             with open(path, "a", newline="") as fp:
-                csv.writer(fp, dialect="excel").writerows(self.rows[done[1]:])
+                csv.writer(fp, dialect="excel").writerows([[r[0] + base] + r[1:] for r in self.rows[done[1]:]])
         self._flushed = (path, len(self.rows))
         return path
 

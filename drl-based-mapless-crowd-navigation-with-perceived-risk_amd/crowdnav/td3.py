@@ -468,12 +468,13 @@ class Agent:
         rc = L.cn_td3_update(self._td3_h, int(step % self.policy_delay == 0), bp, st)
         if rc != 0:
             raise _abi.CrowdNavError("cn_td3_update: %s" % L.cn_td3_last_error().decode())
-        # the first critic's loss of this update, where the kernels left it: a 0-d view of the handle's device scalar, the same
-        # contract as the PyTorch learner (no host synchronisation; overwritten by the next update)
+        # the first critic's loss of this update, where the kernels left it: a fresh 0-d tensor per call, the same contract as the
+        # PyTorch learner (no host synchronisation: one 4-byte device-to-device copy on the update's stream).  The view of the
+        # handle's device scalar itself is overwritten by the next update and dies with cn_td3_destroy, so it is not handed out.
         if self._td3_loss is None:
             ptr = L.cn_td3_loss_dev(self._td3_h)
             self._td3_loss = _device_scalar_view(ptr, self.device) if ptr else False
-        return self._td3_loss if self._td3_loss is not False else None
+        return self._td3_loss.clone() if self._td3_loss is not False else None
 
     def __del__(self):
         try:

@@ -1,7 +1,11 @@
 """Batched counterpart of start_td3_training.py (TRAIN:40-168): TD3 on N environments of one MI355X.
 
     python -m crowdnav.train --scenario training_as_logged --waypoint-reward 0 --envs 16 --updates 16 --launches 25000 --csv --out runs/td3
-    python -m crowdnav.train --evaluate --load runs/td3 --load-episode 3000 --scenario crossing_8
+    python -m crowdnav.train --evaluate --load runs/td3 --load-episode latest --scenario crossing_8
+
+Checkpoints are labelled with the episode count the weights really have behind them (N envs finish episodes in batches, so the
+count at a log interval is rarely a round number); every save also rewrites `latest_checkpoint.txt` with that count, and
+`--load-episode latest` (the default) reads it -- resume / evaluate commands can be written before the run exists.
 
 What it keeps from the reference loop: Agent hyper-parameters (TRAIN:62-72), exploration noise sigma = 1.0 with the
 clip to v in [0, 0.22], w in [-2, 2], 1-based per-env step counters, `learn()` only once the replay holds more than a
@@ -109,6 +113,25 @@ class DeviceEpisodeLog:
         return new, tot
 
 
+def resolve_load_episode(load_dir, episode):
+    """--load-episode: an integer, or "latest" = the count in <load_dir>/latest_checkpoint.txt (save_checkpoint writes it)."""
+    if isinstance(episode, str) and episode.strip().lower() == "latest":
+        path = os.path.join(load_dir, "latest_checkpoint.txt")
+        if not os.path.exists(path):
+            raise FileNotFoundError("--load-episode latest: %s does not exist (no checkpoint was saved into %s)" % (path, load_dir))
+        return int(open(path).read().split()[0])
+    return int(episode)
+
+
+def save_checkpoint(agent, outdir, episodes):
+    """TRAIN:150-154's checkpoint + the exploration-noise stream's position + the `latest` pointer."""
+    agent.save(outdir, episodes)
+    open(os.path.join(outdir, "noise_state_ep%d.txt" % episodes), "w").write("%d %d\n" % agent.noise_state())
+    tmp = os.path.join(outdir, ".latest_checkpoint.txt.%d" % os.getpid())
+    open(tmp, "w").write("%d\n" % episodes)
+    os.replace(tmp, os.path.join(outdir, "latest_checkpoint.txt"))
+
+
 def train(a):
     dev = a.device
     torch.cuda.set_device(dev)        # policy kernels and torch ops of this process all target the env's GPU
@@ -117,6 +140,7 @@ def train(a):
     agent = Agent(obs_dim=env.D, device="cuda:%d" % dev, seed=a.seed, batch_size=a.batch, memory_size=a.memory,
                   actor_final_init=getattr(a, "actor_final_init", None))
     if a.load:
+        a.load_episode = resolve_load_episode(a.load, a.load_episode)
         agent.load_models(*[os.path.join(a.load, "td3_%s_model_ep%d.pt" % (n, a.load_episode)) for n in ("actor", "critic1", "critic2")])
         ns = os.path.join(a.load, "noise_state_ep%d.txt" % a.load_episode)
         if os.path.exists(ns):           # continue the exploration-noise stream instead of replaying it
@@ -127,6 +151,8 @@ def train(a):
         agent.enable_graphs()         # a TD3 update as one hipGraph launch (the eager update is launch-bound at batch 128)
     stats = EpisodeStats()
     os.makedirs(a.out, exist_ok=True)
+    # a run continued into the directory it was loaded from appends to that run's CSV (as progress.txt always did)
+    resumed = bool(a.load) and os.path.abspath(a.load) == os.path.abspath(a.out)
     obs = env.reset()
     t0 = time.time()
     episodes = 0
@@ -179,19 +205,17 @@ def train(a):
                     it, env_steps, updates_done, episodes, tot[1] / ne, tot[2] / ne, tot[3] / ne, time.time() - t0)
                 print(line, flush=True); log.write(line + "\n"); log.flush()
             if a.csv:
-                stats.append_csv(a.out, "td3_training")                  # incremental: a killed run keeps its rows up to here
+                stats.append_csv(a.out, "td3_training", resume=resumed)   # incremental: a killed run keeps its rows up to here
             if episodes >= next_ckpt:                                    # TRAIN:150-154 (every 100 episodes there)
                 # labelled with the episode count the weights really have behind them (checked at log time, so it can be past
                 # the threshold that triggered it)
-                agent.save(a.out, episodes)
-                open(os.path.join(a.out, "noise_state_ep%d.txt" % episodes), "w").write("%d %d\n" % agent.noise_state())
+                save_checkpoint(agent, a.out, episodes)
                 while next_ckpt <= episodes:
                     next_ckpt += a.checkpoint_every
             if last_launch:
                 break
     agent.memory.sync_len()
-    agent.save(a.out, episodes)
-    open(os.path.join(a.out, "noise_state_ep%d.txt" % episodes), "w").write("%d %d\n" % agent.noise_state())
+    save_checkpoint(agent, a.out, episodes)
     last = stats.rows[-500:]
     if last:
         line = "last %d episodes: success %.3f  mean return %.1f  mean steps %.1f  ego %.3f  social %.3f  | %d updates, %.0f updates/s, %.0f env-steps/s overall" % (
@@ -201,7 +225,7 @@ def train(a):
             updates_done, updates_done / max(1e-9, time.time() - t0), env_steps / max(1e-9, time.time() - t0))
         print(line, flush=True); log.write(line + "\n"); log.flush()
     if a.csv:
-        stats.append_csv(a.out, "td3_training")
+        stats.append_csv(a.out, "td3_training", resume=resumed)
     return agent, episodes
 
 
@@ -210,6 +234,7 @@ def run_evaluation(a):
     env = make_env(a.scenario, a.envs, a.max_steps, a.seed, a.device, a.ped_vmax, waypoint_reward=a.waypoint_reward,
                    scan_f32=a.scan_f32, wheel_accel=a.wheel_accel)
     agent = Agent(obs_dim=env.D, device="cuda:%d" % a.device, seed=a.seed, memory_size=16)
+    a.load_episode = resolve_load_episode(a.load, a.load_episode)
     agent.load_models(*[os.path.join(a.load, "td3_%s_model_ep%d.pt" % (n, a.load_episode)) for n in ("actor", "critic1", "critic2")])
     st = evaluate(env, agent, episodes_per_env=a.episodes_per_env)
     n = len(st.rows)
@@ -250,7 +275,7 @@ def main(argv=None):
                     "measures wall time since the episode's start, which the reference's time.sleep(0.15) makes the same quantity")
     ap.add_argument("--max-csv-rows", type=int, default=2_000_000)
     ap.add_argument("--load", default=None)
-    ap.add_argument("--load-episode", type=int, default=0)
+    ap.add_argument("--load-episode", default="latest", help="the <N> of td3_*_model_ep<N>.pt, or `latest` = the count in <load>/latest_checkpoint.txt")
     ap.add_argument("--evaluate", action="store_true")
     ap.add_argument("--episodes-per-env", type=int, default=1)
     a = ap.parse_args(argv)

@@ -443,9 +443,13 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
         k.assoc_tab = (const int16_t*)(h->d_poly + 128);
         HIPCHK(hipMemcpy((void*)k.assoc_tab, tab, sizeof(tab), hipMemcpyHostToDevice));
     }
-    if (h->wpb4 * h->lds > 64 * 1024) {
-        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_s360_w4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(h->wpb4 * (h->lds + 16))));
-        HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_fair_s360_w4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(h->wpb4 * (h->lds + 16))));
+    if (h->shape360 && h->wpb4) {     // the _w4 kernels are only ever launched for the headline shape (choose_kernel)
+        const size_t w4 = (size_t)h->wpb4 * ((h->lds + 15) & ~(size_t)15);      // what launch() asks for
+        if (w4 > 160 * 1024) h->wpb4 = 0;                                        // (a CN_WPB override that does not fit a CU's LDS: one per workgroup)
+        else if (w4 > 64 * 1024) {
+            HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_s360_w4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)w4));
+            HIPCHK(hipFuncSetAttribute((const void*)cn_env_kernel_fair_s360_w4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)w4));
+        }
     }
     if (h->lds > 64 * 1024)
         for (const void* f : kDynamicLdsKernels) HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));

@@ -384,12 +384,19 @@ def test_fused_td3_update_on_the_reference_learn_goldens():
     ag.enable_fused_update()
     dev = lambda x: torch.from_numpy(x).cuda()
     batch = (dev(G["upd_s"]), dev(G["upd_a"]), dev(G["upd_r"])[:, None], dev(G["upd_s2"]), dev(G["upd_d"])[:, None])
+    losses = []
     for step in range(4):
-        ag.learn(step, batch=batch, target_noise=dev(G["upd_noise"][step]))
+        losses.append(ag.learn(step, batch=batch, target_noise=dev(G["upd_noise"][step])))
         torch.cuda.synchronize()
         for k, m_ in nets.items():
             for n, v in m_.state_dict().items():
                 np.testing.assert_allclose(v.cpu().numpy(), G["step%d.%s.%s" % (step, k, n)], rtol=5e-4, atol=2e-6, err_msg="step %d %s.%s" % (step, k, n))
+    # every call returns its own loss tensor (a collected list keeps four values, not four aliases of the last one),
+    # and the tensors outlive the handle
+    vals = [float(l) for l in losses]
+    assert len({l.data_ptr() for l in losses}) == 4 and len(set(vals)) > 1 and all(np.isfinite(vals))
+    del ag
+    assert [float(l) for l in losses] == vals
 
 
 @pytest.mark.parametrize("reset_mode", ["next", "same"])

@@ -149,3 +149,48 @@ def test_training_preset_and_the_cospawned_obstacles():
     cfg6, init6 = presets.training(n_envs=3, drop_cospawned=True)
     assert cfg6.n_peds == 6 and cfg6.ped_cycle_ms == 1400 and init6.shape == (3, 6, 2)
     assert (init6[0] == init[0, :6]).all() and cfg6.ped_vmax == cfg.ped_vmax == 0.2
+
+
+def test_episode_csv_resumes_instead_of_truncating(tmp_path):
+    """utils.record_data (UTL:53-64) appends; a run continued into its own directory must not truncate the rows it wrote before
+    (ADVICE r05), and a fresh start must."""
+    import csv
+    from crowdnav.rollout import EpisodeStats
+    a = EpisodeStats()
+    a.add(1, 0, 10.0, 50, 1.0, 0.9, 8.0); a.add(0, 1, -200.0, 20, 0.5, 0.5, 3.2)
+    a.append_csv(str(tmp_path), "td3_training")
+    a.add(1, 0, 12.0, 40, 1.0, 1.0, 6.4)
+    path = a.append_csv(str(tmp_path), "td3_training")
+    rows = list(csv.reader(open(path)))
+    assert rows[0] == EpisodeStats.HEADERS and [r[0] for r in rows[1:]] == ["1", "2", "3"]
+    b = EpisodeStats()                                 # the resumed process: its own rows start at 1 again
+    b.add(1, 0, 7.0, 30, 1.0, 1.0, 4.8)
+    b.append_csv(str(tmp_path), "td3_training", resume=True)
+    b.add(0, 1, -1.0, 31, 1.0, 1.0, 4.96)
+    b.append_csv(str(tmp_path), "td3_training", resume=True)
+    rows = list(csv.reader(open(path)))
+    assert rows[0] == EpisodeStats.HEADERS and sum(1 for r in rows if r == EpisodeStats.HEADERS) == 1
+    assert [r[0] for r in rows[1:]] == ["1", "2", "3", "4", "5"] and rows[4][3] == "7.0"
+    c = EpisodeStats()                                 # a fresh start truncates
+    c.add(1, 0, 1.0, 1, 1.0, 1.0, 0.16)
+    c.append_csv(str(tmp_path), "td3_training")
+    assert [r[0] for r in list(csv.reader(open(path)))[1:]] == ["1"]
+
+
+def test_load_episode_latest_pointer(tmp_path):
+    """Checkpoints carry the live episode count; `--load-episode latest` finds the newest one."""
+    import pytest
+    from crowdnav import train
+
+    class FakeAgent:
+        def save(self, outdir, ep): open(os.path.join(outdir, "td3_actor_model_ep%d.pt" % ep), "w").close()
+        def noise_state(self): return (3, 4)
+
+    with pytest.raises(FileNotFoundError):
+        train.resolve_load_episode(str(tmp_path), "latest")
+    train.save_checkpoint(FakeAgent(), str(tmp_path), 28013)
+    train.save_checkpoint(FakeAgent(), str(tmp_path), 28127)
+    assert train.resolve_load_episode(str(tmp_path), "latest") == 28127
+    assert train.resolve_load_episode(str(tmp_path), "28013") == 28013 and train.resolve_load_episode(str(tmp_path), 5) == 5
+    assert open(tmp_path / "noise_state_ep28127.txt").read().split() == ["3", "4"]
+    assert os.path.exists(tmp_path / "td3_actor_model_ep28013.pt")
