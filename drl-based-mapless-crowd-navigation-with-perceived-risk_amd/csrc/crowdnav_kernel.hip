@@ -3411,9 +3411,22 @@ __device__ __forceinline__ void policy_sequence_body()
         float* const act_lds = (float*)(cn_smem + (size_t)p->pol_act_off);          // [PE][2], past the working sets and the tile
         const float* ob = (t == 0 ? p->pol_obs0 : p->obs + (size_t)((t - 1) * p->roll_obs_stride)) + (size_t)row0 * D;
         float* ac = const_cast<float*>(p->action) + (size_t)(t * p->roll_action_in_stride) + 2 * (size_t)row0;
+        // (Round 6, measured and not kept: a per-CU lock that makes the two 8-environment workgroups of a CU take turns in the actor
+        //  phase.  They already run an actor phase apart by themselves -- tools/policy_phase_timing.py -- and it buys nothing, because a
+        //  wave streaming v_mfma_f32_16x16x4_f32 holds the SIMD's vector issue for its 32 cycles: another wave of that SIMD gets ONE
+        //  vector instruction in per MFMA (tools/micro/mfma_valu_mix.hip: 5.5 -> 37.8 cycles per v_fma_f64).  Matrix-core time and
+        //  vector time ADD on a SIMD; one workgroup's tile beside another's Env.step overlaps nothing.  profiles/r06/.)
+#ifdef CN_TIMING
+#define POL_T(k) do { if (p->timing && tid_ == 0) p->timing[(size_t)row0 * 32 + 27 + (k)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define POL_T(k) do { } while (0)
+#endif
+        POL_T(0);
+        POL_T(1);
         actor_tile<8>(ob, min(PE, p->N - row0), row0, D, p->pol_Dp, p->pol_w1p, p->pol_b1, p->pol_w2p, p->pol_b2, p->pol_w3, p->pol_b3,
                       ac, act_lds, p->pol_max_v, p->pol_max_w, p->pol_sigma, p->pol_seed, p->pol_counter + (uint64_t)t, (float*)cn_smem, POL_ACTOR_WAVES(wave), tid_);
         __syncthreads();
+        POL_T(2);
         if (env < p->N)
         {
 #if POL_FAIR == 0
@@ -3421,7 +3434,9 @@ __device__ __forceinline__ void policy_sequence_body()
 #endif
             env_kernel_body<false, false, 0, GT, SIM, true, POL_FAIR != 0, SHAPE>(env, lane_, cn_smem + (size_t)wave * ws, t, act_lds + 2 * wave);
         }
+        POL_T(3);
         __syncthreads();
+        POL_T(4);
     }
 }
 #endif
