@@ -50,9 +50,11 @@ __device__ __forceinline__ void cn_setprio_uniform(int v)      // v: wave-unifor
 #ifdef CN_TIMING
 #define CN_ABLATE(bit) (p->ablate & (bit))   /* stage-skipping mask of tools/ablate.py: timing build only */
 /* bits 8..15 of the mask: stamp number + 1 at which every wavefront ENDS (tools/stage_instr.py: the PMC counters of a launch cut
-   at stamp k are the instructions issued up to k, and the differences between consecutive cuts the dynamic ledger of the stages) */
+   at stamp k are the instructions issued up to k, and the differences between consecutive cuts the dynamic ledger of the stages);
+   bit 16: only the wavefronts of environments with (env & 3) != 0 end there (tools/pack_bound_probe.py: an upper bound for what
+   sharing the narrow stages between the four environments of a workgroup could buy) */
 #define CN_T(k) do { CN_FAIR_AT(k); if (p->timing && lane == 0) p->timing[(size_t)env * 32 + (k)] = (long long)__builtin_amdgcn_s_memtime(); \
-                     if (((p->ablate >> 8) & 0xff) == (k) + 1) __builtin_amdgcn_endpgm(); } while (0)
+                     if (((p->ablate >> 8) & 0xff) == (k) + 1 && (!((p->ablate >> 16) & 1) || (env & 3) != 0)) __builtin_amdgcn_endpgm(); } while (0)
 #else
 #define CN_ABLATE(bit) 0
 #define CN_T(k) CN_FAIR_AT(k)
