@@ -8,7 +8,8 @@
 #                       what makes the simulator bit-reproducible against the CPU oracle
 # crowdnav_kernel.hip is compiled as four units: CN_TU=1 (every one-step kernel), CN_TU=2 (the sequence / policy kernels of the
 # plain simulator), CN_TU=3 (the sequence kernels of the social-force / wheel-ramp simulators), CN_TU=4 (their policy kernels + the
-# 720-ray one) -- units 2-4 with -mllvm -disable-machine-licm: see the note above the kernel definitions.
+# 720-ray one), CN_TU=5 (round 6: the sequence / policy kernels of the contact ticks and of the two older observation layouts)
+# -- units 2-5 with -mllvm -disable-machine-licm: see the note above the kernel definitions.
 set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 OUT="$HERE/../lib"
@@ -25,13 +26,14 @@ build_lib() {   # $1 = output name, $2.. = extra flags
   "$HIPCC" $FLAGS ${CN_EXTRA_FLAGS:-} "$@" -DCN_TU=2 -mllvm -disable-machine-licm -c -o "$T/k2.o" "$HERE/crowdnav_kernel.hip" & pids+=($!)
   "$HIPCC" $FLAGS ${CN_EXTRA_FLAGS:-} "$@" -DCN_TU=3 -mllvm -disable-machine-licm -c -o "$T/k3.o" "$HERE/crowdnav_kernel.hip" & pids+=($!)
   "$HIPCC" $FLAGS ${CN_EXTRA_FLAGS:-} "$@" -DCN_TU=4 -mllvm -disable-machine-licm -c -o "$T/k4.o" "$HERE/crowdnav_kernel.hip" & pids+=($!)
+  "$HIPCC" $FLAGS ${CN_EXTRA_FLAGS:-} "$@" -DCN_TU=5 -mllvm -disable-machine-licm -c -o "$T/k5.o" "$HERE/crowdnav_kernel.hip" & pids+=($!)
   "$HIPCC" $FLAGS ${CN_EXTRA_FLAGS:-} "$@" -c -o "$T/abi.o" "$HERE/crowdnav_abi.hip" & pids+=($!)
   "$HIPCC" $FLAGS ${CN_EXTRA_FLAGS:-} "$@" -c -o "$T/td3.o" "$HERE/crowdnav_td3.hip" & pids+=($!)
   local failed=0 pid
   for pid in "${pids[@]}"; do wait "$pid" || failed=1; done     # a bare `wait` returns 0 whatever the jobs returned
   if [ "$failed" != 0 ]; then echo "build.sh: a compile of $name failed" >&2; return 1; fi
   # link next to the target and rename: a process that already mapped the old file keeps it, nobody maps a partial one
-  "$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT/.$name.$$" "$T/k1.o" "$T/k2.o" "$T/k3.o" "$T/k4.o" "$T/abi.o" "$T/td3.o"
+  "$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT/.$name.$$" "$T/k1.o" "$T/k2.o" "$T/k3.o" "$T/k4.o" "$T/k5.o" "$T/abi.o" "$T/td3.o"
   mv -f "$OUT/.$name.$$" "$OUT/$name"
 }
 if [ "$WHAT" = "product" ] || [ "$WHAT" = "all" ]; then

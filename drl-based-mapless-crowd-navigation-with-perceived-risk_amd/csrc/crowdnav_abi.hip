@@ -70,6 +70,14 @@ extern "C" __global__ void cn_policy_kernel_wa(CnKParams p);
 extern "C" __global__ void cn_policy_kernel_gt_sf(CnKParams p);
 extern "C" __global__ void cn_policy_kernel_gt_sfd(CnKParams p);
 extern "C" __global__ void cn_policy_kernel_gt_wa(CnKParams p);
+extern "C" __global__ void cn_env_kernel_seq_ct(CnKParams p);
+extern "C" __global__ void cn_env_kernel_gt_seq_ct(CnKParams p);
+extern "C" __global__ void cn_env_kernel_seq_orig(CnKParams p);
+extern "C" __global__ void cn_env_kernel_seq_rw(CnKParams p);
+extern "C" __global__ void cn_policy_kernel_ct(CnKParams p);
+extern "C" __global__ void cn_policy_kernel_gt_ct(CnKParams p);
+extern "C" __global__ void cn_policy_kernel_orig(CnKParams p);
+extern "C" __global__ void cn_policy_kernel_rw(CnKParams p);
 // every kernel launched with cn_create's dynamic LDS size (hipFuncAttributeMaxDynamicSharedMemorySize above 64 KiB)
 static const void* const kDynamicLdsKernels[] = {
     (const void*)cn_env_kernel, (const void*)cn_env_kernel_fair, (const void*)cn_env_kernel_ext, (const void*)cn_env_kernel_same,
@@ -83,11 +91,13 @@ static const void* const kDynamicLdsKernels[] = {
     (const void*)cn_env_kernel_seq_s720, (const void*)cn_env_kernel_s720, (const void*)cn_env_kernel_fair_s720, (const void*)cn_env_kernel_gt_seq,
     (const void*)cn_env_kernel_seq_sf, (const void*)cn_env_kernel_seq_sfd, (const void*)cn_env_kernel_seq_wa,
     (const void*)cn_env_kernel_gt_seq_sf, (const void*)cn_env_kernel_gt_seq_sfd, (const void*)cn_env_kernel_gt_seq_wa,
-    (const void*)cn_env_kernel_s360_w4, (const void*)cn_env_kernel_fair_s360_w4, (const void*)cn_env_kernel_s360_x2};
+    (const void*)cn_env_kernel_s360_w4, (const void*)cn_env_kernel_fair_s360_w4, (const void*)cn_env_kernel_s360_x2,
+    (const void*)cn_env_kernel_seq_ct, (const void*)cn_env_kernel_gt_seq_ct, (const void*)cn_env_kernel_seq_orig, (const void*)cn_env_kernel_seq_rw};
 static const void* const kPolicyKernels[] = {
     (const void*)cn_policy_kernel, (const void*)cn_policy_kernel_s360, (const void*)cn_policy_kernel_gt, (const void*)cn_policy_kernel_s720,
     (const void*)cn_policy_kernel_sf, (const void*)cn_policy_kernel_sfd, (const void*)cn_policy_kernel_wa,
-    (const void*)cn_policy_kernel_gt_sf, (const void*)cn_policy_kernel_gt_sfd, (const void*)cn_policy_kernel_gt_wa};
+    (const void*)cn_policy_kernel_gt_sf, (const void*)cn_policy_kernel_gt_sfd, (const void*)cn_policy_kernel_gt_wa,
+    (const void*)cn_policy_kernel_ct, (const void*)cn_policy_kernel_gt_ct, (const void*)cn_policy_kernel_orig, (const void*)cn_policy_kernel_rw};
 extern "C" __global__ void cn_bbox_kernel(CnKParams p, double* out);
 extern "C" __global__ void cn_gather_kernel(CnKParams p, float* last_ret, float* run_ret, int32_t* counters);
 
@@ -457,9 +467,10 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
         // actor's 16-row tile is laid out compactly over them between two steps), + the workgroup's actions
         // (whichever kernel choose_policy_kernel picks for this handle: the 720-ray shape's has the compact layout)
         h->pol_wave_lds = ((choose_policy_kernel(h).compact ? h->lds_shape : h->lds) + 15) & ~(size_t)15;
-        const size_t tile = sizeof(float) * (16 * (size_t)(((k.R - 1 + 7 + 4 * k.K + 31) & ~31) + 1) + 16 * 257);
+        const size_t tile = sizeof(float) * (16 * (size_t)(((h->D + 31) & ~31) + 1) + 16 * 257);
         const char* pe_env = getenv("CN_POL_ENVS");             // experiments: CN_POL_ENVS=8 forces the 8-environment workgroups
-        for (int pe = (pe_env && atoi(pe_env) == 8) ? 8 : 16; pe >= 8 && !h->pol_lds && h->cfg.obs_layout == CN_LAYOUT_RISK; pe -= 8) {
+        // (cn_policy_kernel_rw is compiled for 8 waves: the RW observation needs more than the 128 vector registers a 16-wave workgroup leaves a wave)
+        for (int pe = ((pe_env && atoi(pe_env) == 8) || h->cfg.obs_layout == CN_LAYOUT_REALWORLD) ? 8 : 16; pe >= 8 && !h->pol_lds; pe -= 8) {
             size_t off = (size_t)pe * h->pol_wave_lds;
             if (off < tile) off = (tile + 15) & ~(size_t)15;
             const size_t tot = off + (size_t)pe * 2 * sizeof(float);
@@ -554,29 +565,33 @@ static KernelChoice choose_kernel(const cn_env_s* h, bool ext, bool same, bool o
     if (h->shape720) return fair ? CN_KCC(cn_env_kernel_fair_s720) : CN_KCC(cn_env_kernel_s720);
     return fair ? CN_KC(cn_env_kernel_fair) : CN_KC(cn_env_kernel);
 }
-// cn_step_sequence / cn_rollout_policy: obs_layout 0, every simulator but the contact ticks (NULL otherwise)
-static bool one_launch_config(const cn_env_s* h) { return h->cfg.obs_layout == CN_LAYOUT_RISK && !h->cfg.ped_contact; }
+// cn_step_sequence / cn_rollout_policy: every configuration cn_create accepts has both (round 6: the contact ticks and the two older
+// observation layouts included) -- the same selection order as choose_kernel
 static KernelChoice choose_sequence_kernel(const cn_env_s* h)
 {
     const cn_config& c = h->cfg;
-    if (!one_launch_config(h)) return KernelChoice{nullptr, nullptr};
-    const bool gt = c.risk_mode == CN_RISK_GT, sf = c.ped_mode == 2, wa = c.wheel_accel > 0.0;
+    if (c.obs_layout == CN_LAYOUT_REALWORLD) return CN_KC(cn_env_kernel_seq_rw);
+    if (c.obs_layout == CN_LAYOUT_ORIGINAL) return CN_KC(cn_env_kernel_seq_orig);
+    const bool gt = c.risk_mode == CN_RISK_GT, ct = c.ped_contact != 0, sf = c.ped_mode == 2, wa = c.wheel_accel > 0.0;
     const bool sfd = sf && !h->kp.sf_pair_matrix && c.n_peds <= 128;
     if (wa) return gt ? CN_KC(cn_env_kernel_gt_seq_wa) : CN_KC(cn_env_kernel_seq_wa);          // (choose_kernel: the wheel ramp comes first)
     if (sfd) return gt ? CN_KC(cn_env_kernel_gt_seq_sfd) : CN_KC(cn_env_kernel_seq_sfd);
     if (sf) return gt ? CN_KC(cn_env_kernel_gt_seq_sf) : CN_KC(cn_env_kernel_seq_sf);
+    if (ct) return gt ? CN_KC(cn_env_kernel_gt_seq_ct) : CN_KC(cn_env_kernel_seq_ct);
     return gt ? CN_KC(cn_env_kernel_gt_seq)
          : h->shape360 ? CN_KC(cn_env_kernel_seq_s360) : h->shape720 ? CN_KCC(cn_env_kernel_seq_s720) : CN_KC(cn_env_kernel_seq);
 }
 static KernelChoice choose_policy_kernel(const cn_env_s* h)
 {
     const cn_config& c = h->cfg;
-    if (!one_launch_config(h)) return KernelChoice{nullptr, nullptr};
-    const bool gt = c.risk_mode == CN_RISK_GT, sf = c.ped_mode == 2, wa = c.wheel_accel > 0.0;
+    if (c.obs_layout == CN_LAYOUT_REALWORLD) return CN_KC(cn_policy_kernel_rw);
+    if (c.obs_layout == CN_LAYOUT_ORIGINAL) return CN_KC(cn_policy_kernel_orig);
+    const bool gt = c.risk_mode == CN_RISK_GT, ct = c.ped_contact != 0, sf = c.ped_mode == 2, wa = c.wheel_accel > 0.0;
     const bool sfd = sf && !h->kp.sf_pair_matrix && c.n_peds <= 128;
     if (wa) return gt ? CN_KC(cn_policy_kernel_gt_wa) : CN_KC(cn_policy_kernel_wa);
     if (sfd) return gt ? CN_KC(cn_policy_kernel_gt_sfd) : CN_KC(cn_policy_kernel_sfd);
     if (sf) return gt ? CN_KC(cn_policy_kernel_gt_sf) : CN_KC(cn_policy_kernel_sf);
+    if (ct) return gt ? CN_KC(cn_policy_kernel_gt_ct) : CN_KC(cn_policy_kernel_ct);
     return gt ? CN_KC(cn_policy_kernel_gt)
          : h->shape360 ? CN_KC(cn_policy_kernel_s360) : h->shape720 ? CN_KCC(cn_policy_kernel_s720) : CN_KC(cn_policy_kernel);
 }
@@ -768,8 +783,6 @@ extern "C" int cn_actor_forward(const cn_actor_weights* w, const float* obs, flo
 extern "C" int cn_step_sequence(cn_handle h, const cn_sequence_io* io, void* stream)
 {
     if (!h || !io || !io->action || !io->obs || !io->reward || !io->done) return fail(CN_ERR_ARG, "cn_step_sequence: null argument");
-    if (!one_launch_config(h))
-        return fail(CN_ERR_CONFIG, "cn_step_sequence: built for obs_layout 0 (every simulator but the contact ticks: ped_contact = 0)");
     if (io->n_steps < 0 || io->action_stride < 0 || io->obs_stride < 0 || io->reward_stride < 0 || io->done_stride < 0 || io->topk_stride < 0)
         return fail(CN_ERR_ARG, "cn_step_sequence: negative step count or stride");
     if (io->n_steps == 0) return CN_OK;
@@ -790,11 +803,9 @@ extern "C" int cn_rollout_policy(cn_handle h, const cn_actor_weights* w, const c
 {
     if (!h || !w || !io || !io->obs0 || !io->action || !io->obs || !io->reward || !io->done || !w->w1p || !w->b1 || !w->w2p || !w->b2 || !w->w3 || !w->b3)
         return fail(CN_ERR_ARG, "cn_rollout_policy: null argument");
-    if (!one_launch_config(h))
-        return fail(CN_ERR_CONFIG, "cn_rollout_policy: built for obs_layout 0 (every simulator but the contact ticks: ped_contact = 0)");
     if (!h->pol_lds)
         return fail(CN_ERR_CONFIG, "cn_rollout_policy: not even 8 environments of this shape fit one CU's LDS (160 KiB)");
-    const int D = h->cfg.n_rays - 1 + 7 + 4 * h->cfg.k_obstacles;
+    const int D = h->D;      // 366 + 4 K, or 363 / 370 at 360 rays for the two older layouts
     if (w->hidden != 256 || w->obs_dim != D || w->obs_dim_padded != ((D + 31) & ~31))
         return fail(CN_ERR_CONFIG, "cn_rollout_policy: the actor must be cn_actor_pack_weights' layout for this handle's observation width (hidden 256, obs_dim_padded = obs_dim rounded up to 32)");
     if (io->n_steps < 0 || io->action_stride < 0 || io->obs_stride < 0 || io->reward_stride < 0 || io->done_stride < 0 || io->topk_stride < 0)

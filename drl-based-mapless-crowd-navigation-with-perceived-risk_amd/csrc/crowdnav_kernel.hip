@@ -2989,14 +2989,14 @@ extern "C" __global__ void CN_S720_BOUNDS cn_env_kernel_fair_s720(CnKParams p) {
 extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_same(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<false, true, 0>(blockIdx.x, threadIdx.x, cn_smem); }
 extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_ext(CnKParams p) { extern __shared__ __attribute__((aligned(16))) char cn_smem[]; env_kernel_body<true, false, 0>(blockIdx.x, threadIdx.x, cn_smem); }
 #endif
-#if !defined(CN_TU) || CN_TU == 2 || CN_TU == 3
+#if !defined(CN_TU) || CN_TU == 2 || CN_TU == 3 || CN_TU == 5
 // cn_step_sequence: T control periods per launch with OPEN-LOOP actions (resident in HBM: [T][N][2], or one [N][2] held for T
 // periods).  One wavefront keeps its environment for the whole launch and walks its T steps at its own pace: no launch boundary,
 // no device-wide join between steps -- the launch ends with its slowest wavefront's T steps, not with T x the slowest single
 // step -- and after a few steps the wavefronts of a SIMD are out of phase (they stop contending for the same unit at the same
 // time), which is what one launch per step can never be.  Each step is exactly cn_env_kernel's (next-step reset convention) and
 // writes its observation / reward / done / indices to slot t of the caller's buffers (stride 0: in place).
-template <bool GT, int SHAPE = 0, int SIM = 0>
+template <bool GT, int SHAPE = 0, int SIM = 0, int LAYOUT = 0>
 __device__ __forceinline__ void sequence_body()
 {
     extern __shared__ __attribute__((aligned(16))) char cn_smem[];
@@ -3008,7 +3008,7 @@ __device__ __forceinline__ void sequence_body()
         asm volatile("" : "+v"(lane_));          // per-step laundering (see env_kernel_body): nothing is hoisted out of the step loop
         lane_ &= 63;
         cn_setprio_uniform((int)(t + wslot) & 3);      // see "issue arbitration" at the top: every slot gets every level in turn
-        env_kernel_body<false, false, 0, GT, SIM, true, false, SHAPE>(blockIdx.x, lane_, cn_smem, t);
+        env_kernel_body<false, false, LAYOUT, GT, SIM, true, false, SHAPE>(blockIdx.x, lane_, cn_smem, t);
     }
 }
 #endif
@@ -3027,6 +3027,14 @@ extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_seq_wa(CnKParams 
 extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_gt_seq_sf(CnKParams p) { sequence_body<true, 0, 2>(); }
 extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_gt_seq_sfd(CnKParams p) { sequence_body<true, 0, 4>(); }
 extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_gt_seq_wa(CnKParams p) { sequence_body<true, 0, 3>(); }
+#endif
+#if !defined(CN_TU) || CN_TU == 5
+// round 6: ... and for the worlds that were still refused -- the contact ticks (SIM 1, both risk modes) and the two older observation
+// layouts (ORIG: 363 inputs, RW: 370 inputs).  Every configuration cn_create accepts now has both one-launch forms.
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_seq_ct(CnKParams p) { sequence_body<false, 0, 1>(); }
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_gt_seq_ct(CnKParams p) { sequence_body<true, 0, 1>(); }
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_seq_orig(CnKParams p) { sequence_body<false, 0, 0, 1>(); }
+extern "C" __global__ void __launch_bounds__(64) cn_env_kernel_seq_rw(CnKParams p) { sequence_body<false, 0, 0, 2>(); }
 #endif
 #if !defined(CN_TU) || CN_TU == 1
 // risk_mode gt: the perceived-risk features from the simulator's own pedestrians (no segmentation, no tracker)
@@ -3373,7 +3381,7 @@ extern "C" __global__ void __launch_bounds__(ACT_THREADS) cn_actor_kernel(const 
 }
 #endif
 
-#if !defined(CN_TU) || CN_TU == 2 || CN_TU == 4
+#if !defined(CN_TU) || CN_TU == 2 || CN_TU == 4 || CN_TU == 5
 // ---- cn_rollout_policy: T control periods per launch with the POLICY IN THE LOOP --------------------------------------------
 // A workgroup = 16 environments = 16 wavefronts (one CU's worth at 4 per SIMD).  Per control period: the first eight waves run
 // the TD3 actor (actor_tile above: the arithmetic, noise keys and clip of cn_actor_forward) on the 16 observations the
@@ -3394,7 +3402,7 @@ extern "C" __global__ void __launch_bounds__(ACT_THREADS) cn_actor_kernel(const 
 #ifndef POL_FAIR
 #define POL_FAIR 1            /* experiments: 0 = the sequence kernel's rotating levels instead of the falling ones */
 #endif
-template <int SHAPE, bool GT = false, int SIM = 0>
+template <int SHAPE, bool GT = false, int SIM = 0, int LAYOUT = 0>
 __device__ __forceinline__ void policy_sequence_body()
 {
     extern __shared__ __attribute__((aligned(16))) char cn_smem[];
@@ -3434,7 +3442,7 @@ __device__ __forceinline__ void policy_sequence_body()
 #if POL_FAIR == 0
             cn_setprio_uniform((t + (int)__builtin_amdgcn_s_getreg(4 | (1 << 11))) & 3);
 #endif
-            env_kernel_body<false, false, 0, GT, SIM, true, POL_FAIR != 0, SHAPE>(env, lane_, cn_smem + (size_t)wave * ws, t, act_lds + 2 * wave);
+            env_kernel_body<false, false, LAYOUT, GT, SIM, true, POL_FAIR != 0 && LAYOUT == 0, SHAPE>(env, lane_, cn_smem + (size_t)wave * ws, t, act_lds + 2 * wave);
         }
         POL_T(3);
         __syncthreads();
@@ -3455,6 +3463,15 @@ extern "C" __global__ void __launch_bounds__(64 * POL_ENVS) cn_policy_kernel_wa(
 extern "C" __global__ void __launch_bounds__(64 * POL_ENVS) cn_policy_kernel_gt_sf(CnKParams p) { policy_sequence_body<0, true, 2>(); }
 extern "C" __global__ void __launch_bounds__(64 * POL_ENVS) cn_policy_kernel_gt_sfd(CnKParams p) { policy_sequence_body<0, true, 4>(); }
 extern "C" __global__ void __launch_bounds__(64 * POL_ENVS) cn_policy_kernel_gt_wa(CnKParams p) { policy_sequence_body<0, true, 3>(); }
+#endif
+#if !defined(CN_TU) || CN_TU == 5
+// round 6: the contact ticks and the two older observation layouts (their actors take 363 / 370 inputs: cn_actor_pack_weights pads
+// any width to a multiple of 32)
+extern "C" __global__ void __launch_bounds__(64 * POL_ENVS) cn_policy_kernel_ct(CnKParams p) { policy_sequence_body<0, false, 1>(); }
+extern "C" __global__ void __launch_bounds__(64 * POL_ENVS) cn_policy_kernel_gt_ct(CnKParams p) { policy_sequence_body<0, true, 1>(); }
+extern "C" __global__ void __launch_bounds__(64 * POL_ENVS) cn_policy_kernel_orig(CnKParams p) { policy_sequence_body<0, false, 0, 1>(); }
+// (the RW observation needs 140 vector registers: 8 environments per workgroup -- two waves per SIMD -- so that the cap is 256, not 128)
+extern "C" __global__ void __launch_bounds__(64 * 8) cn_policy_kernel_rw(CnKParams p) { policy_sequence_body<0, false, 0, 2>(); }
 #endif
 
 #if !defined(CN_TU) || CN_TU == 1

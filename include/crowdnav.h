@@ -143,7 +143,7 @@ typedef struct cn_config {
      *   else  cl += clamp(tl - cl, -a h, +a h),  cr += clamp(tr - cr, -a h, +a h)
      *   the tick's twist v = (cl + cr) / 2, w = (cr - cl) / sep moves the robot by the mid-point rule; /odom reports that twist.
      * A commanded 0 <-> 0.22 m/s then takes 0.22 s (1.5 control periods), a full turn command w = 2 rad/s 0.16 s.
-     * Requires obs_layout 0 and the plain simulator (ped_contact 0, ped_mode 0 / 1); cn_step_sequence refuses it. */
+     * Requires obs_layout 0 and the plain simulator (ped_contact 0, ped_mode 0 / 1). */
     double wheel_accel;      /* m/s^2 at the wheel rim; 0 = off */
     double wheel_separation; /* XACRO:68 -> 0.160 */
 } cn_config;
@@ -354,7 +354,8 @@ int cn_episode_log_add(const cn_episode_log* log, const uint8_t* done, const int
  * stride 0 = one slot (actions: the same [N, 2] held for every step; outputs: every step overwrites the slot).
  *   action  dev n_steps slots [N, 2] float32;  obs dev n_steps slots [N, D] float32 (slot t = the observation step t returns)
  *   reward / done / topk_idx (or NULL): n_steps slots [N] / [N] / [N, K]
- * Requirements: obs_layout 0, plain simulator (ped_contact 0, ped_mode 0 / 1). */
+ * Every configuration cn_create accepts has this form (round 5: social force, wheel ramp, both risk modes, the 720-ray shape; round 6:
+ * the contact ticks and obs_layout 1 / 2): cn_kernel_name(h, 2) says which kernel runs it. */
 typedef struct cn_sequence_io {
     const float* action;
     float* obs;
@@ -377,8 +378,10 @@ int cn_step_sequence(cn_handle h, const cn_sequence_io* io, void* stream);
  *            alias slot 0 of obs when obs_stride = 0)
  *   action   dev n_steps slots [N, 2] float32, OUTPUT: slot t = the action period t took
  *   obs / reward / done / topk_idx (or NULL): as cn_sequence_io (slot t = what period t's step returned)
- * Requirements: those of cn_step_sequence (either risk_mode), 16 environments of the handle's shape fitting one CU's LDS, and an
- * actor of cn_actor_pack_weights' layout for this handle's observation width (hidden 256). */
+ * Requirements: 8 environments of the handle's shape fitting one CU's LDS (16 per workgroup where they fit; obs_layout 2 always runs
+ * 8: its observation needs more registers than a 16-wave workgroup leaves a wave), and an actor of cn_actor_pack_weights' layout for
+ * this handle's observation width cn_obs_dim(h) -- 366 + 4 K, or 363 / 370 for obs_layout 1 / 2 at 360 rays -- with hidden = 256.
+ * Every configuration cn_create accepts has this form as well (cn_kernel_name(h, 5)). */
 typedef struct cn_policy_io {
     const float* obs0;
     float* action;

@@ -800,15 +800,20 @@ ONE_LAUNCH_WORLDS = {
     "wa": (dict(n_peds=20, wheel_accel=1.0, scan_f32=1), "cn_env_kernel_seq_wa", "cn_policy_kernel_wa"),
     "gt_wa": (dict(n_peds=20, wheel_accel=1.0, risk_mode=1), "cn_env_kernel_gt_seq_wa", "cn_policy_kernel_gt_wa"),
     "s720": (dict(n_peds=100, n_rays=720, room_half=2.40), "cn_env_kernel_seq_s720", "cn_policy_kernel_s720"),
+    # round 6: the worlds round 5 still refused -- the contact ticks (both risk modes) and the two older observation layouts
+    "ct": (dict(n_peds=20, ped_contact=1), "cn_env_kernel_seq_ct", "cn_policy_kernel_ct"),
+    "gt_ct": (dict(n_peds=20, ped_contact=1, risk_mode=1), "cn_env_kernel_gt_seq_ct", "cn_policy_kernel_gt_ct"),
+    "orig": (dict(n_peds=20, obs_layout=1), "cn_env_kernel_seq_orig", "cn_policy_kernel_orig"),
+    "rw": (dict(n_peds=20, obs_layout=2, dt_ms=50), "cn_env_kernel_seq_rw", "cn_policy_kernel_rw"),
 }
 
 
 @pytest.mark.parametrize("world", sorted(ONE_LAUNCH_WORLDS))
 def test_one_launch_paths_of_the_other_simulators_equal_step_by_step(world):
-    """Round 5: cn_step_sequence and cn_rollout_policy exist for every simulator of obs_layout 0 but the contact
-    ticks -- social-force pedestrians (pair-matrix and dense kernels), the diff-drive plugin's wheel ramp, both risk modes -- and for
-    BASELINE configs[4]'s shape, whose 16 working sets do not fit one CU's LDS: there the policy kernel runs 8 environments per
-    workgroup.  Each leaves exactly what T calls of cn_step (resp. T pairs of cn_actor_forward, cn_step) leave: every period's
+    """Round 5: cn_step_sequence and cn_rollout_policy exist for social-force pedestrians (pair-matrix and dense
+    kernels), the diff-drive plugin's wheel ramp, both risk modes -- and for BASELINE configs[4]'s shape, whose 16 working sets do
+    not fit one CU's LDS: there the policy kernel runs 8 environments per workgroup.  Round 6: and for the contact ticks and the two
+    older observation layouts (363 / 370 actor inputs), so every configuration cn_create accepts has both forms.  Each leaves exactly what T calls of cn_step (resp. T pairs of cn_actor_forward, cn_step) leave: every period's
     actions / observations / rewards / done flags / indices, the final state record, counters and returns, across two calls,
     with an env count that is not a multiple of the workgroup size.  (The step-by-step kernels of these worlds are pinned
     against the oracle by tests/test_gpu_parity.py.)"""
@@ -863,11 +868,11 @@ def test_one_launch_paths_of_the_other_simulators_equal_step_by_step(world):
         assert a_pol.noise_state() == a_ref.noise_state()
         assert np.array_equal(pol.snapshot(), ref2.snapshot())
         assert torch.equal(pol.counters(), ref2.counters()) and torch.equal(pol.returns()[0], ref2.returns()[0])
-    # what is still refused: the contact ticks and the other observation layouts
-    for bad in (dict(ped_contact=1), dict(obs_layout=1), dict(obs_layout=2, dt_ms=50)):
-        e = VecEnv(Config(n_envs=16, **bad))
-        with pytest.raises(crowdnav.CrowdNavError):
-            e.step_sequence(torch.zeros((2, 16, 2), device="cuda"))
+    # an actor packed for another observation width is refused (the check reads the handle's own width, whatever the layout)
+    wrong = Agent(obs_dim=cfg.obs_dim + 1, device="cuda:0", seed=6, memory_size=16)
+    wrong.sync_fused_weights()
+    with pytest.raises(crowdnav.CrowdNavError):
+        pol.rollout_policy(wrong, 2)
 
 
 def test_collect_policy_fills_the_replay_like_the_per_step_loop():

@@ -68,7 +68,7 @@ def main():
     if a.policy:
         # closed loop: the policy kernel decides, the oracle is fed what it decided (float32 observations: the kernel's own output width)
         from crowdnav.td3 import Agent
-        assert a.reset_mode == "next" and a.layout == 0
+        assert a.reset_mode == "next"
         print("kernel: policy %s" % env.kernel_name("policy"))
         agent = Agent(obs_dim=cfg.obs_dim, device="cuda:0", seed=a.seed, memory_size=16)
         T, N, D, K = a.policy, a.envs, env.D, env.K

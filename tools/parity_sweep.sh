@@ -2,7 +2,7 @@
 # The GPU-vs-oracle sweeps DESIGN.md quotes (every observation / reward / done flag / index / counter compared, zero
 # differences expected).  Writes gpurun_out/<tag>/parity_sweep.txt; copy it to profiles/<tag>/.
 #   tools/parity_sweep.sh r02 [scale]      scale multiplies every --steps (10 -> 36 M env-steps, ~10 min; output parity_sweep_x10.txt)
-TAG="${1:-r05}"; S="${2:-1}"; cd "$(dirname "$0")/.."; OUT="gpurun_out/$TAG"; mkdir -p "$OUT"
+TAG="${1:-r06}"; S="${2:-1}"; cd "$(dirname "$0")/.."; OUT="gpurun_out/$TAG"; mkdir -p "$OUT"
 R="python tools/parity_report.py --verbose 2"
 NAME=parity_sweep; [ "$S" != 1 ] && NAME="parity_sweep_x$S"
 {
@@ -44,4 +44,9 @@ $R --envs 1024 --steps $((120 * S)) --peds 100 --rays 720 --room 2.4 --reset-mod
 $R --envs 520 --steps $((100 * S)) --peds 100 --rays 720 --room 2.4 --reset-mode next --max-steps 60 --policy 10
 $R --envs 1024 --steps $((200 * S)) --ped-mode 2 --reset-mode next --policy 20
 $R --envs 1000 --steps $((200 * S)) --scan-f32 1 --wheel-accel 1.0 --waypoint-reward 0 --reset-mode next --policy 25
+# round 6: cn_rollout_policy for the worlds round 5 still refused -- the contact ticks (both risk modes) and the two older observation layouts
+$R --envs 520 --steps $((200 * S)) --peds 40 --contact 1 --reset-mode next --policy 20
+$R --envs 520 --steps $((200 * S)) --peds 40 --contact 1 --risk-mode 1 --vmax 0.5 --reset-mode next --policy 25
+$R --envs 1000 --steps $((200 * S)) --layout 1 --reset-mode next --policy 20
+$R --envs 1000 --steps $((200 * S)) --layout 2 --dt-ms 50 --reset-mode next --policy 40
 } 2>&1 | grep -v amdgpu.ids | tee "$OUT/$NAME.txt"
