@@ -648,9 +648,23 @@ def test_step_sequence_kernel_equals_step_by_step(oracle_mod, risk_mode):
             assert np.array_equal(other.snapshot(), ref.snapshot())
             assert torch.equal(other.counters(), ref.counters()) and torch.equal(other.returns()[0], ref.returns()[0])
         assert torch.equal(inplace.topk_idx, ref.topk_idx)
+    # (round 6: the other observation layouts and the contact ticks have the one-launch forms too --
+    #  test_one_launch_paths_of_the_other_simulators_equal_step_by_step)
     import crowdnav
     with pytest.raises(crowdnav.CrowdNavError):
-        VecEnv(Config(n_envs=16, obs_layout=1)).step_sequence(torch.zeros((2, 16, 2), device="cuda"))
+        _abi_check_negative_stride(VecEnv(Config(n_envs=16)))
+
+
+def _abi_check_negative_stride(env):
+    """cn_step_sequence still validates its arguments: a negative stride is CN_ERR_ARG"""
+    import ctypes as C
+    from crowdnav import _abi
+    import torch
+    a = torch.zeros((2, env.N, 2), device="cuda")
+    io = _abi.CnSequenceIO()
+    io.action, io.action_stride, io.n_steps = a.data_ptr(), -1, 2
+    io.obs, io.reward, io.done, io.topk_idx = env.obs.data_ptr(), env.reward.data_ptr(), env.done.data_ptr(), env.topk_idx.data_ptr()
+    _abi.check(env.L.cn_step_sequence(env.h, C.byref(io), env._stream()))
 
 
 def test_step_sequence_kernel_of_the_dense_shape_equals_step_by_step():
@@ -738,8 +752,8 @@ def test_policy_rollout_kernel_equals_act_then_step(oracle_mod, shape):
         assert torch.equal(inplace.topk_idx, ref.topk_idx) and torch.equal(inplace.last_policy_action, act)
     assert n_done > N // 2
     import crowdnav
-    with pytest.raises(crowdnav.CrowdNavError):
-        VecEnv(Config(n_envs=16, ped_contact=1)).rollout_policy(a_ref, 2)
+    with pytest.raises(crowdnav.CrowdNavError):      # an actor of another observation width (K = 4 -> 382 inputs) is refused
+        VecEnv(Config(n_envs=16, k_obstacles=4)).rollout_policy(a_ref, 2)
 
 
 def test_small_grids_run_two_wavefronts_per_environment_with_identical_results(oracle_mod):

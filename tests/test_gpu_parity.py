@@ -380,15 +380,15 @@ def test_snapshot_restore_replays_bit_exact():
     g = torch.Generator(device="cpu").manual_seed(0)
     acts = [torch.stack([torch.rand(32, generator=g) * 0.22, torch.rand(32, generator=g) * 4 - 2], 1).cuda() for _ in range(40)]
     for a in acts[:10]:
-        env.step(a)
+        env.step(a, auto_reset="next")
     snap = env.snapshot()
     outs = []
     for a in acts[10:]:
-        o, r, d = env.step(a)
+        o, r, d = env.step(a, auto_reset="next")
         outs.append((o.clone(), r.clone(), d.clone()))
     env.restore(snap)
     for a, (o0, r0, d0) in zip(acts[10:], outs):
-        o, r, d = env.step(a)
+        o, r, d = env.step(a, auto_reset="next")
         assert torch.equal(o, o0) and torch.equal(r, r0) and torch.equal(d, d0)
 
 
