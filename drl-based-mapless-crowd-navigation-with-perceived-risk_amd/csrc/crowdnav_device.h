@@ -416,6 +416,12 @@ __device__ __forceinline__ double cn_dpp_d(double ident, double v)
     int hi = __builtin_amdgcn_update_dpp(__double2hiint(ident), __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
     return __hiloint2double(hi, lo);
 }
+// lane i <- lane i - N (row_shr) / lane i + N (row_shl) of its own row of 16 lanes, 1 <= N <= 15; a lane whose source would lie
+// outside the row keeps `ident`.  One VALU instruction where __shfl_up / __shfl_down are a ds_bpermute round trip through the LDS
+// crossbar (an address, the permute, a wait: tools/profc counted 60 of them per env-step, a fifth of the LDS instructions, eighteen
+// of them in dependent scan steps) -- for the lane = word scans, whose at most 16 words all sit in row 0.
+template <int N> __device__ __forceinline__ int cn_row_shr_i(int ident, int v) { static_assert(N >= 1 && N <= 15, "row_shr"); return cn_dpp_i<0x110 + N, 0xf>(ident, v); }
+template <int N> __device__ __forceinline__ int cn_row_shl_i(int ident, int v) { static_assert(N >= 1 && N <= 15, "row_shl"); return cn_dpp_i<0x100 + N, 0xf>(ident, v); }
 #define CN_DPP_REDUCE(T, DPP, v, ident, OP)                         \
     do {                                                            \
         v = OP(v, DPP<0x111, 0xf>(ident, v)); /* row_shr:1 */       \

@@ -190,9 +190,10 @@ __device__ __forceinline__ unsigned long long ring_segment(const Poly& pg, int l
     return __ballot(hit);
 }
 
-__device__ __forceinline__ double bcast_d(double v, int src)
+__device__ __forceinline__ double bcast_d(double v, int src)      // src: wave-uniform (a bit position of a ballot) -> v_readlane
 {
-    int lo = __shfl(__double2loint(v), src, 64), hi = __shfl(__double2hiint(v), src, 64);
+    const int su = __builtin_amdgcn_readfirstlane(src);
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), su), hi = __builtin_amdgcn_readlane(__double2hiint(v), su);
     return __hiloint2double(hi, lo);
 }
 
@@ -1080,12 +1081,15 @@ __device__ __forceinline__ void tracker_stage(KP p, EnvRegs& e, const Lds& L, do
                         if (u > best) { best = u; bj = oj; }
                     }
                 }
-#pragma unroll
-                for (int m = 4; m >= 1; m >>= 1) {
-                    double ob = cn_shfl_xor_d(best, m);
-                    int ojx = __shfl_xor(bj, m, 64);
-                    if (ob > best || (ob == best && ojx < bj)) { best = ob; bj = ojx; }
-                }
+                // (only lane 0 of each 8-lane group is read below: a reduction tree into it -- lane + 1, lane + 2 by quad permutes,
+                // lane + 4 by row_shl:4, all DPP inside the row -- instead of a 3-step xor butterfly of nine ds_bpermute round trips;
+                // the order (larger IoU first, then the lower object index) is total, so the tree's shape does not matter)
+#define CN_AM_STEP(CTRL) { const double ob = cn_dpp_d<CTRL, 0xf>(best, best); const int ojx = cn_dpp_i<CTRL, 0xf>(bj, bj); \
+                           if (ob > best || (ob == best && ojx < bj)) { best = ob; bj = ojx; } }
+                CN_AM_STEP(0xF5)      /* quad_perm [1,1,3,3] */
+                CN_AM_STEP(0xEE)      /* quad_perm [2,3,2,3] */
+                CN_AM_STEP(0x104)     /* row_shl:4 */
+#undef CN_AM_STEP
                 const u64 posm = __ballot(best > 0.0);             // bit 8 g (any lane of group g): track t0 + g matched
                 const int wb = __shfl(bj, (lane & 7) * 8, 64);     // lane t0 + g <- group g's winner
                 if ((lane >> 3) == (t0 >> 3)) { mybj = wb; mymatch = ((posm >> (8 * (lane & 7))) & 1ull) != 0ull; }
@@ -1251,12 +1255,14 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
         }
     }
     CN_T(4);
-    smin = cn_wave_min_d(smin);
+    // ENV:1011 is the only reader of the scan's minimum, and all it asks is whether ANY range lies below min_scan_range: one compare
+    // and a wave vote on the per-lane minima instead of a six-step float64 DPP reduction (min(x) < c <=> some x < c; no NaNs here)
+    bool too_close = __ballot(smin < p->min_scan_range) != 0ull;
     CN_SYNC();
     if constexpr (X2) {
-        if (!w0 && lane == 0) mb->smin1 = smin;
+        if (!w0 && lane == 0) mb->smin1 = too_close ? -1.0 : 1e300;
         CN_XBAR();                        // every ray's end point and range are in LDS
-        if (w0) smin = cn_vmin(smin, mb->smin1);
+        if (w0) too_close = too_close || (mb->smin1 < 0.0);
     }
 
     if (w0 && step_counter == 0) {  // UTL:405-419 + ENV:287-294: mean spacing of the end points of an all-max scan
@@ -1416,13 +1422,24 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
         int fv = (int)((PI >> 63) & 1ull);
         if (fc) fv = 1 ^ fv ^ (int)((PI >> (63 - __builtin_clzll(cD))) & 1ull);
         int sc_ = fc, sv_ = fv;                       // inclusive scan of the composition over the words below
+        int du;                                       // du entering this word: the maps below applied to du = 0
+        // (W <= 16 words sit in one row of 16 lanes: the scan steps are DPP row shifts -- one VALU instruction each -- instead of
+        // ds_bpermute round trips; a lane without a lower neighbour reads the identity, so the `lane >= d` tests fall away)
+        const bool rowscan = W <= 16;
+        if (rowscan) {
+#define CN_TM_STEP(D) { const int lc = cn_row_shr_i<D>(0, sc_), lv = cn_row_shr_i<D>(0, sv_); if (!sc_) { sc_ = lc; sv_ ^= lv; } }
+            CN_TM_STEP(1) CN_TM_STEP(2) CN_TM_STEP(4) CN_TM_STEP(8)
+#undef CN_TM_STEP
+            du = cn_row_shr_i<1>(0, sv_);
+        } else {
 #pragma unroll
-        for (int d = 1; d < 16; d <<= 1) {
-            const int lc = __shfl_up(sc_, d, 64), lv = __shfl_up(sv_, d, 64);
-            if (lane >= d && !sc_) { sc_ = lc; sv_ ^= lv; }   // (this o lower): a constant map absorbs what is below it
+            for (int d = 1; d < 32; d <<= 1) {
+                const int lc = __shfl_up(sc_, d, 64), lv = __shfl_up(sv_, d, 64);
+                if (lane >= d && !sc_) { sc_ = lc; sv_ ^= lv; }   // (this o lower): a constant map absorbs what is below it
+            }
+            du = __shfl_up(sv_, 1, 64);
+            if (lane == 0) du = 0;
         }
-        int du = __shfl_up(sv_, 1, 64);               // du entering this word: the maps below applied to du = 0
-        if (lane == 0) du = 0;
         const u64 haveE = have << 1, FE = F << 1;     // ... strictly below
         const u64 DU = (haveE & ~(PE ^ FE)) | (~haveE & (du ? ~PE : PE));   // du before each ray
         const u64 du1 = DU & occ, du0 = ~DU & occ;
@@ -1433,13 +1450,21 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
         // last ray that set last_type at or below each word: packed (valid, type, index), fill-forward over the lanes
         int pk = 0;
         if (S) { const int hb = 63 - __builtin_clzll(S); pk = (1 << 30) | ((((setW >> hb) & 1ull) ? TY_W : TY_O) << 16) | (64 * q + hb); }
+        int below;                                    // ... strictly below this word
+        if (rowscan) {
+#define CN_PK_STEP(D) { const int lo_ = cn_row_shr_i<D>(0, pk); if (!pk) pk = lo_; }
+            CN_PK_STEP(1) CN_PK_STEP(2) CN_PK_STEP(4) CN_PK_STEP(8)
+#undef CN_PK_STEP
+            below = cn_row_shr_i<1>(0, pk);
+        } else {
 #pragma unroll
-        for (int d = 1; d < 16; d <<= 1) {
-            const int lo_ = __shfl_up(pk, d, 64);
-            if (lane >= d && !pk) pk = lo_;
+            for (int d = 1; d < 32; d <<= 1) {
+                const int lo_ = __shfl_up(pk, d, 64);
+                if (lane >= d && !pk) pk = lo_;
+            }
+            below = __shfl_up(pk, 1, 64);
+            if (lane == 0) below = 0;
         }
-        int below = __shfl_up(pk, 1, 64);             // ... strictly below this word
-        if (lane == 0) below = 0;
         u64 alias = du0 & cD;                          // T[i] = last_type: carries that ray's range and pose
         while (alias) {
             const int t = __builtin_ctzll(alias);
@@ -1642,13 +1667,21 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
             if (sw) le = 64 * lane + 63 - __builtin_clzll(sw);
         }
         int sw_ = pw, so_ = po, sl_ = le, ss_ = ps;    // inclusive scans
+        int pl;                                         // last segment end before this word
+        if (W <= 16) {                                  // one row of 16 lanes: DPP row shifts (identity 0 / -1 where there is no lower lane)
+#define CN_PF_STEP(D) { sw_ += cn_row_shr_i<D>(0, sw_); so_ += cn_row_shr_i<D>(0, so_); sl_ = max(sl_, cn_row_shr_i<D>(-1, sl_)); ss_ += cn_row_shr_i<D>(0, ss_); }
+            CN_PF_STEP(1) CN_PF_STEP(2) CN_PF_STEP(4) CN_PF_STEP(8)
+#undef CN_PF_STEP
+            pl = cn_row_shr_i<1>(-1, sl_);
+        } else {
 #pragma unroll
-        for (int d = 1; d < 32; d <<= 1) {              // CN_MAXW = 17 words <= 32 lanes
-            const int aw = __shfl_up(sw_, d, 64), ao = __shfl_up(so_, d, 64), al_ = __shfl_up(sl_, d, 64), as_ = __shfl_up(ss_, d, 64);
-            if (lane >= d) { sw_ += aw; so_ += ao; sl_ = max(sl_, al_); ss_ += as_; }
+            for (int d = 1; d < 32; d <<= 1) {
+                const int aw = __shfl_up(sw_, d, 64), ao = __shfl_up(so_, d, 64), al_ = __shfl_up(sl_, d, 64), as_ = __shfl_up(ss_, d, 64);
+                if (lane >= d) { sw_ += aw; so_ += ao; sl_ = max(sl_, al_); ss_ += as_; }
+            }
+            pl = __shfl_up(sl_, 1, 64);
         }
         segbase = ss_ - ps;                             // lane q: segment ends before word q
-        const int pl = __shfl_up(sl_, 1, 64);           // last segment end before this word
         if (lane < W) {
             L.wbase[lane] = sw_ - pw; L.wbase[L.wstride + lane] = so_ - po; L.wbase[2 * L.wstride + lane] = lane ? pl : -1;
         }
@@ -1664,7 +1697,7 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
     for (int c0 = 0; c0 < ((CN_ABLATE(4)) ? 0 : nseg); c0 += segcap) {
         for (int q = 0; q < W; ++q) {
             const u64 sw = uni64(WORD(M_SEG, q));
-            const int r = __shfl(segbase, q, 64) + __popcll(sw & ((1ull << lane) - 1ull)) - c0;
+            const int r = __builtin_amdgcn_readlane(segbase, q) + __popcll(sw & ((1ull << lane) - 1ull)) - c0;   // (q is wave-uniform: v_readlane, no LDS permute)
             if (((sw >> lane) & 1ull) && r >= 0 && r < segcap) seglist[r] = (unsigned short)(lane + 64 * q);
         }
         CN_SYNC();
@@ -1951,9 +1984,11 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
         }
         e.nent = nt;
         CN_SYNC();
-        if (nt == 0) { e.cprob = 0.0; e.ego = 0.0; }  // ENV:862-876
-        else {  // ENV:878-905: stable descending sort, keep the LAST K
-            e.ego = ego_max;
+        // (both fields are written once, after the branch: a store in each arm gets merged into one store through a pointer phi,
+        // which keeps the whole EnvRegs field pair on the stack)
+        double cprob_new = 0.0, ego_new = 0.0;         // ENV:862-876: no tracks
+        if (nt != 0) {  // ENV:878-905: stable descending sort, keep the LAST K
+            ego_new = ego_max;
             int first = nt > K ? nt - K : 0;
             int rank = -1; double mycp = 0.0;
             if (lane < nt) {
@@ -1971,8 +2006,9 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
                 }
             }
             unsigned long long mf = __ballot(rank == first);
-            e.cprob = bcast_d(mycp, __ffsll((long long)mf) - 1);
+            cprob_new = bcast_d(mycp, __ffsll((long long)mf) - 1);
         }
+        e.cprob = cprob_new; e.ego = ego_new;
         // ENV:990-996
         e.dq0x = e.dq1x; e.dq0y = e.dq1y; e.dq_len = 1;
         if (!GT && lane < nt) TRK(CN_TF_T, lane) = now;
@@ -1983,7 +2019,7 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
     if (e.ego > 0.4) e.social_viol += 1;
     // ENV:1011-1023 done
     if (!e.done) {
-        if (smin < p->min_scan_range) e.done = 1;
+        if (too_close) e.done = 1;
         if (in_box(px, py, p->goal_x, p->goal_y, p->goal_eps)) e.done = 1;
         if (step_counter >= p->max_steps) e.done = 1;
     }

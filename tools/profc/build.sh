@@ -1,12 +1,12 @@
 #!/bin/bash
-# tools/profc/build.sh -> <pkg>/lib/ab/libcrowdnav_profc.so + /tmp/profc/k1.out (the counted code object) + tools/profc/symbols.json
+# tools/profc/build.sh -> <pkg>/lib/prof/libcrowdnav_profc.so + /tmp/profc/k1.out (the counted code object) + tools/profc/symbols.json
 # The region-counter build of translation unit 1 (every one-step kernel); the other units are the product's.  Profiling only.
 #   1. device code of unit 1 -> optimised LLVM IR with clang's region counters (atomic updates) and coverage mapping
 #   2. tools/profc/rewrite_ir.py: every counter update -> cn_prof_hit() (per-wavefront + per-lane counts)
 #   3. IR -> code object -> offload bundle; host side of unit 1 compiled against that bundle; link with the other units
 set -euo pipefail
 ROOT="$(cd "$(dirname "${BASH_SOURCE[0]}")/../.." && pwd)"
-PKG="$ROOT/drl-based-mapless-crowd-navigation-with-perceived-risk_amd"; SRC="$PKG/csrc"; W="${CN_PROFC_TMP:-/tmp/profc}"; mkdir -p "$W" "$PKG/lib/ab"
+PKG="$ROOT/drl-based-mapless-crowd-navigation-with-perceived-risk_amd"; SRC="$PKG/csrc"; W="${CN_PROFC_TMP:-/tmp/profc}"; mkdir -p "$W" "$PKG/lib/prof"
 LL=/opt/rocm/lib/llvm/bin; HIPCC=/opt/rocm/bin/hipcc
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-builtin-pow -Wno-unused-function"
 INJ="-DCN_TU=1 -DCN_PROFC -include $ROOT/tools/profc/profc_block.h"
@@ -27,6 +27,6 @@ $LL/clang-offload-bundler -type=o -bundle-align=4096 -targets=host-x86_64-unknow
 $HIPCC $FLAGS $INJ --cuda-host-only -Xclang -fcuda-include-gpubinary -Xclang "$W/k1.hipfb" -c -o "$W/k1.o" "$SRC/crowdnav_kernel.hip" 2>&1 | grep -v "argument unused" || true
 failed=0; for pid in "${pids[@]}"; do wait "$pid" || failed=1; done
 [ "$failed" = 0 ] || { echo "profc/build.sh: a compile failed" >&2; exit 1; }
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$PKG/lib/ab/libcrowdnav_profc.so" "$W"/k1.o "$W"/k2.o "$W"/k3.o "$W"/k4.o "$W"/k5.o "$W"/abi.o "$W"/td3.o
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$PKG/lib/prof/libcrowdnav_profc.so" "$W"/k1.o "$W"/k2.o "$W"/k3.o "$W"/k4.o "$W"/k5.o "$W"/abi.o "$W"/td3.o
 python3 "$ROOT/tools/profc/covmap.py" "$W/k1.out" "$ROOT/tools/profc/symbols.json"
-ls -la "$PKG/lib/ab/libcrowdnav_profc.so" "$ROOT/tools/profc/symbols.json"
+ls -la "$PKG/lib/prof/libcrowdnav_profc.so" "$ROOT/tools/profc/symbols.json"

@@ -1,5 +1,5 @@
 // tools/profc/profc_block.h -- injected with `-include` into translation unit 1 of crowdnav_kernel.hip by tools/profc/build.sh
-// (REGION-COUNTER BUILD ONLY -> lib/ab/libcrowdnav_profc.so; never part of the product or of csrc/build.sh).
+// (REGION-COUNTER BUILD ONLY -> lib/prof/libcrowdnav_profc.so; never part of the product or of csrc/build.sh).
 //
 // The device code of that unit is compiled with clang's source-region counters (-fprofile-instr-generate -fprofile-update=atomic
 // -fcoverage-mapping) and every counter update in the optimised IR is rewritten (tools/profc/rewrite_ir.py) into a call of

@@ -2,7 +2,7 @@
 """tools/profc/run.py [envs=4096] [steps=100] [preroll=200] -> gpurun_out/profc/counters_<envs>.npz
 
 Runs the headline workload (bench.py's configuration: 4096 envs x 20 pedestrians x 360 rays, open-loop actions, next-step reset,
-one cn_step launch per step) on the REGION-COUNTER build (lib/ab/libcrowdnav_profc.so, tools/profc/build.sh), zeroes the counters
+one cn_step launch per step) on the REGION-COUNTER build (lib/prof/libcrowdnav_profc.so, tools/profc/build.sh), zeroes the counters
 after the pre-roll and copies them out after `steps` launches.  Every counter holds (wavefront executions << 32) | lane executions
 of one source region of the step kernel.  tools/profc/report.py turns the file into a per-line / per-stage dynamic instruction ledger."""
 import ctypes as C
@@ -16,7 +16,7 @@ sys.path.insert(0, PKG)
 import numpy as np
 import torch
 from crowdnav import _abi
-_abi.LIB_PATH = os.path.join(PKG, "lib", "ab", "libcrowdnav_profc.so"); _abi.build = lambda force=False: _abi.LIB_PATH
+_abi.LIB_PATH = os.path.join(PKG, "lib", "prof", "libcrowdnav_profc.so"); _abi.build = lambda force=False: _abi.LIB_PATH
 from crowdnav import Config
 from crowdnav.env import VecEnv
 
