@@ -804,7 +804,9 @@ __device__ __forceinline__ void sim_advance(KP p, EnvRegs& e, int env, int lane,
 // with u_q the block's axis (robot frame: a host table) and oc rotated into the robot frame.  Evaluated with slack, so a
 // cleared bit only ever skips a test that could not hit (ranges unchanged); a crowded env otherwise pays every near
 // pedestrian in every block, and the launch waits for its most crowded env.
-__device__ __forceinline__ int near_peds(KP p, const Lds& L, int lane, double ox, double oy, double sy, double cy)
+// blkw (optional): lane q receives block q's word in a register and the LDS copy is not written -- the ray loop of the same wavefront
+// then takes it with two lane reads per block instead of an LDS round trip (one wavefront per environment, lidar-tracker layout).
+__device__ __forceinline__ int near_peds(KP p, const Lds& L, int lane, double ox, double oy, double sy, double cy, u64* blkw = nullptr)
 {
     // The list holds what the ray test needs (not indices): the inner loop then reads three independent values per
     // pedestrian instead of chasing index -> position through two dependent LDS reads for every ray block.
@@ -844,10 +846,13 @@ __device__ __forceinline__ int near_peds(KP p, const Lds& L, int lane, double ox
     // (The flag-word area is free until the ray loop is over.)
     u64 mytag = 0ull;
     if (lane < nnear) mytag = ((const u64*)L.nearp)[4 * lane + 3];
+    u64 mine = 0ull;
     for (int q = 0; q < Wb; ++q) {
         const u64 bm = __ballot(((mytag >> q) & 1ull) != 0ull);
-        if (lane == 0) L.w64[q] = bm;
+        if (blkw) { if (lane == q) mine = bm; }
+        else if (lane == 0) L.w64[q] = bm;
     }
+    if (blkw) *blkw = mine;
     CN_SYNC();
     return nnear;
 }
@@ -856,7 +861,7 @@ __device__ __forceinline__ int near_peds(KP p, const Lds& L, int lane, double ox
 // lc, ls: ray k in the robot frame = the host table of cn_det_sincos(k * step), loaded by the caller.
 template <bool EXT>
 __device__ __forceinline__ double cast_ray(KP p, const Lds& L, int env, int k, double ox, double oy, double sy,
-                                           double cy, int nnear, bool wall_x, bool wall_y, double lc, double ls)
+                                           double cy, int nnear, bool wall_x, bool wall_y, double lc, double ls, const u64* blkw = nullptr)
 {
     if constexpr (EXT) {
         return p->ext_ranges[(size_t)env * p->R + k];   // Gazebo / a physical lidar
@@ -890,7 +895,9 @@ __device__ __forceinline__ double cast_ray(KP p, const Lds& L, int env, int k, d
                 }
             }
         };
-        u64 bm = uni64(L.w64[q]);                              // list slots some ray of this block can reach
+        // list slots some ray of this block can reach: lane q of near_peds' register copy, or the LDS word
+        u64 bm = blkw ? (((u64)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(*blkw >> 32), q) << 32) | (u64)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)*blkw, q))
+                      : uni64(L.w64[q]);
         while (bm) {
             const int c = __builtin_ctzll(bm);
             bm &= bm - 1ull;
@@ -1166,6 +1173,7 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
     double sy = 0.0, cy = 0.0, ox = 0.0, oy = 0.0;
     const double h = p->room_half;
     int nnear = 0;
+    u64 blkw = 0ull;
     bool wall_x = false, wall_y = false;
     if (w0) {
     // ENV:246-265
@@ -1190,7 +1198,7 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
     }
     if constexpr (X2) CN_XBAR();          // wave 1 has advanced the pedestrians, wave 0 the robot (and published where the lidar is)
     if (w0) {
-    nnear = near_peds(p, L, lane, ox, oy, sy, cy);
+    nnear = near_peds(p, L, lane, ox, oy, sy, cy, X2 ? nullptr : &blkw);    // (X2: wave 1 reads the block words from LDS)
     wall_x = !(h - fabs(ox) > p->lidar_max + 1e-6);
     wall_y = !(h - fabs(oy) > p->lidar_max + 1e-6);
     if constexpr (X2) { if (lane == 0) { mb->nnear = nnear; mb->wall_x = wall_x; mb->wall_y = wall_y; } }
@@ -1224,7 +1232,7 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
         double lc = 0.0, ls = 0.0, tS = 0.0, tC = 0.0;
         if (!EXT) { lc = cn_ldg(lidc, (unsigned)k); ls = cn_ldg(lids, (unsigned)k); }
         if (!GT && k >= 1) { tS = cn_ldg(angs, (unsigned)(R - 1 - k)); tC = cn_ldg(angc, (unsigned)(R - 1 - k)); }
-        const double t = cast_ray<EXT>(p, L, env, k, ox, oy, sy, cy, nnear, wall_x, wall_y, lc, ls);
+        const double t = cast_ray<EXT>(p, L, env, k, ox, oy, sy, cy, nnear, wall_x, wall_y, lc, ls, X2 ? nullptr : &blkw);
         if (k >= 1) {
             const unsigned j = (unsigned)(R - 1 - k);  // UTL:389-390 reverse, drop last
             double r = t;
@@ -1609,6 +1617,7 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
     // built by lane = word with 64-bit field moves (two source words + a funnel shift per range) instead of one
     // pass per word with five LDS reads per ray.
     int nseg = 0;
+    u64 segw_keep = 0ull;
     {
         // 64 bits of mask `id` starting at ray `pos` (bits past the last word read as 0)
         auto extract = [&](int id, int pos) -> u64 {
@@ -1653,7 +1662,7 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
                 WORD(M_SEG, q) = segw;
             } else WORD(g == 0 ? M_OCC : (g == 1 ? M_KW : M_KO), q) = mine;
         }
-        nseg = cn_wave_sum_i(__popcll(segw));
+        segw_keep = segw;                               // lane 48 + q keeps word q of the segment ends for the list pass below
     }
     CN_SYNC();
     CN_T(11);
@@ -1682,6 +1691,7 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
             pl = __shfl_up(sl_, 1, 64);
         }
         segbase = ss_ - ps;                             // lane q: segment ends before word q
+        nseg = __builtin_amdgcn_readlane(ss_, W - 1);   // ... and the inclusive total of the last word = the number of segments
         if (lane < W) {
             L.wbase[lane] = sw_ - pw; L.wbase[L.wstride + lane] = so_ - po; L.wbase[2 * L.wstride + lane] = lane ? pl : -1;
         }
@@ -1696,7 +1706,9 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
     const int segcap = min(64, 20 * W);
     for (int c0 = 0; c0 < ((CN_ABLATE(4)) ? 0 : nseg); c0 += segcap) {
         for (int q = 0; q < W; ++q) {
-            const u64 sw = uni64(WORD(M_SEG, q));
+            // (word q of the segment ends: still in the register of the lane that built it -- two lane reads with a uniform index
+            // instead of an LDS round trip per word)
+            const u64 sw = ((u64)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(segw_keep >> 32), 48 + q) << 32) | (u64)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)segw_keep, 48 + q);
             const int r = __builtin_amdgcn_readlane(segbase, q) + __popcll(sw & ((1ull << lane) - 1ull)) - c0;   // (q is wave-uniform: v_readlane, no LDS permute)
             if (((sw >> lane) & 1ull) && r >= 0 && r < segcap) seglist[r] = (unsigned short)(lane + 64 * q);
         }
@@ -1991,13 +2003,23 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
             ego_new = ego_max;
             int first = nt > K ? nt - K : 0;
             int rank = -1; double mycp = 0.0;
-            if (lane < nt) {
-                mycp = L.cpv[lane];
+            if (lane < nt) mycp = L.cpv[lane];
+            if (nt <= 8) {
+                // up to 8 tracks (almost every call): every ordered pair at once, lane = 8 i + j -- one compare and a wave vote
+                // instead of a serial pass over the tracks with an LDS read per iteration; track i's rank = the set bits of byte i
+                const int ti = lane >> 3, tj = lane & 7;
+                bool beats = false;
+                if (ti < nt && tj < nt) { const double ci = L.cpv[ti], cj = L.cpv[tj]; beats = (cj > ci) || (cj == ci && tj < ti); }
+                const u64 bm = __ballot(beats);
+                if (lane < nt) rank = __popc((unsigned)(bm >> (8 * lane)) & 0xffu);
+            } else if (lane < nt) {
                 rank = 0;
                 for (int j = 0; j < nt; ++j) {
                     double c = L.cpv[j];
                     rank += (c > mycp) || (c == mycp && j < lane);
                 }
+            }
+            if (lane < nt) {
                 if (rank >= first) {
                     int kk = rank - first;
                     L.tail[7 + 4 * kk + 0] = TRK(CN_TF_PX, lane); L.tail[7 + 4 * kk + 1] = TRK(CN_TF_PY, lane);
