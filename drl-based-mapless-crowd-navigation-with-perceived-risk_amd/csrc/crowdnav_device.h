@@ -422,6 +422,29 @@ __device__ __forceinline__ double cn_dpp_d(double ident, double v)
 // of them in dependent scan steps) -- for the lane = word scans, whose at most 16 words all sit in row 0.
 template <int N> __device__ __forceinline__ int cn_row_shr_i(int ident, int v) { static_assert(N >= 1 && N <= 15, "row_shr"); return cn_dpp_i<0x110 + N, 0xf>(ident, v); }
 template <int N> __device__ __forceinline__ int cn_row_shl_i(int ident, int v) { static_assert(N >= 1 && N <= 15, "row_shl"); return cn_dpp_i<0x100 + N, 0xf>(ident, v); }
+// v with lane `l` (wave-uniform) replaced by the wave-uniform 64-bit value x: two v_writelane_b32 -- where `if (lane == l) v = x`
+// compiles to a compare and two selects with the scalar pair moved into vector registers first
+// (clang has no writelane builtin; the lane select goes through m0, which does not count against the one-scalar-operand limit.
+// m0 is a reserved register the compiler only loads right in front of the few instructions that read it -- none in these kernels:
+// no LDS instruction of gfx950 does -- hence the warning about clobbering it is switched off here.)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ unsigned long long cn_writelane_u64(unsigned long long v, unsigned long long x, int l)
+{
+    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+    const unsigned xl = __builtin_amdgcn_readfirstlane((unsigned)x), xh = __builtin_amdgcn_readfirstlane((unsigned)(x >> 32));
+    const int ls = __builtin_amdgcn_readfirstlane(l);
+    asm("s_mov_b32 m0, %4\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0"
+        : "+v"(lo), "+v"(hi) : "s"(xl), "s"(xh), "s"(ls) : "m0");
+    return ((unsigned long long)hi << 32) | lo;
+}
+#pragma clang diagnostic pop
+// lane `l` (wave-uniform) of v as a wave-uniform 64-bit value: two v_readlane_b32
+__device__ __forceinline__ unsigned long long cn_readlane_u64(unsigned long long v, int l)
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
+    return ((unsigned long long)hi << 32) | lo;
+}
 #define CN_DPP_REDUCE(T, DPP, v, ident, OP)                         \
     do {                                                            \
         v = OP(v, DPP<0x111, 0xf>(ident, v)); /* row_shr:1 */       \

@@ -849,7 +849,7 @@ __device__ __forceinline__ int near_peds(KP p, const Lds& L, int lane, double ox
     u64 mine = 0ull;
     for (int q = 0; q < Wb; ++q) {
         const u64 bm = __ballot(((mytag >> q) & 1ull) != 0ull);
-        if (blkw) { if (lane == q) mine = bm; }
+        if (blkw) mine = cn_writelane_u64(mine, bm, q);
         else if (lane == 0) L.w64[q] = bm;
     }
     if (blkw) *blkw = mine;
@@ -896,8 +896,7 @@ __device__ __forceinline__ double cast_ray(KP p, const Lds& L, int env, int k, d
             }
         };
         // list slots some ray of this block can reach: lane q of near_peds' register copy, or the LDS word
-        u64 bm = blkw ? (((u64)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(*blkw >> 32), q) << 32) | (u64)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)*blkw, q))
-                      : uni64(L.w64[q]);
+        u64 bm = blkw ? cn_readlane_u64(*blkw, q) : uni64(L.w64[q]);
         while (bm) {
             const int c = __builtin_ctzll(bm);
             bm &= bm - 1ull;
@@ -1311,7 +1310,7 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
         if (i < n) L.gq[i] = GNONE;
         const u64 bo = __ballot(oc);
         if (oc) occlist[nocc + __popcll(bo & ((1ull << lane) - 1ull))] = (unsigned short)i;
-        if (lane == q) occraw = bo;
+        occraw = cn_writelane_u64(occraw, bo, q);
         nocc += __popcll(bo);
     }
     if (w0 && lane < W) { WORD(M_NONE, lane) = ~0ull; WORD(M_ZERO, lane) = 0ull; WORD(M_EQ, lane) = 0ull; WORD(M_NNONE, lane) = 0ull; WORD(M_NZERO, lane) = 0ull; }
@@ -1549,8 +1548,12 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
         CN_XBAR();                        // wave 0's type machine (it rewrites aliased end points) and the association table
         if (!w0) { fast_assoc = mb->fast_assoc != 0; K1 = mb->k1; }
     }
+    // (one wavefront per environment: the break words collect in a register, lane q = word q -- two v_writelane each -- and go to
+    // LDS in one store after the last block; X2: each wave stores the words of its own blocks at once, as before)
+    u64 brkw = 0ull;
     auto note_breaks = [&](int q, u64 bw) {
-        if (lane == 0) WORD(M_BRK, q) = bw;
+        if constexpr (X2) { if (lane == 0) WORD(M_BRK, q) = bw; }
+        else brkw = cn_writelane_u64(brkw, bw, q);
         if (bw) {
             if (fe == n) fe = 64 * q + __builtin_ctzll(bw);
             u64 bl = (q == W - 1) ? (bw & ~(1ull << ((n - 1) & 63))) : bw;  // breaks before ray n-1
@@ -1598,6 +1601,7 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
         }
         note_breaks(q, __ballot(brk));
     }
+    if constexpr (!X2) { if (lane < W) WORD(M_BRK, lane) = brkw; }
     if constexpr (X2) {
         if (!w0 && lane == 0) { mb->fe1 = fe; mb->lb1 = lb; mb->ns1 = nsegs0; }
         CN_XBAR();                        // both waves' break words
@@ -1708,7 +1712,7 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
         for (int q = 0; q < W; ++q) {
             // (word q of the segment ends: still in the register of the lane that built it -- two lane reads with a uniform index
             // instead of an LDS round trip per word)
-            const u64 sw = ((u64)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(segw_keep >> 32), 48 + q) << 32) | (u64)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)segw_keep, 48 + q);
+            const u64 sw = cn_readlane_u64(segw_keep, 48 + q);
             const int r = __builtin_amdgcn_readlane(segbase, q) + __popcll(sw & ((1ull << lane) - 1ull)) - c0;   // (q is wave-uniform: v_readlane, no LDS permute)
             if (((sw >> lane) & 1ull) && r >= 0 && r < segcap) seglist[r] = (unsigned short)(lane + 64 * q);
         }

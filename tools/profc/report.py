@@ -186,7 +186,7 @@ def main():
             continue
         parts = s.split(None, 1)
         op, args = parts[0], (parts[1] if len(parts) > 1 else "")
-        cls = IL.classify(op, args)
+        cls = "other" if op == "s_nop" else IL.classify(op, args)      # (s_nop: its own column, `other`)
         # executions of this instruction: outermost frame first -- E(kernel frame) = its region's count; one level further in,
         # E = (count of the callee's region at this position) x E(call site) / (calls of the callee over ALL its call sites): a
         # callee's counters sum over its call sites, the caller's region says how many of those calls came from here
