@@ -1156,12 +1156,12 @@ __device__ __forceinline__ void tracker_stage(KP p, EnvRegs& e, const Lds& L, do
     CN_SYNC();
 }
 
-template <bool EXT, bool GT = false, bool FAIR = false, bool CMP = false, bool X2 = false>
+template <bool EXT, bool GT = false, bool FAIR = false, bool CMP = false, bool X2 = false, bool SF = false>
 __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const Lds& L, int env, int lane, int step_counter,
                         float* obs32, float* fin32, double* obs64, int* done_out, bool have_tg = false, Trig tg = Trig{0.0, 0.0, 0.0, 0.0},
                         const int wv = 0, XMail* const mb = nullptr)
 {
-    constexpr bool SFENCE = CMP && !FAIR;
+    constexpr bool SFENCE = SF || (CMP && !FAIR);
     static_assert(!X2 || (!EXT && !GT), "two wavefronts per environment: simulated sensors, lidar-tracker mode");
     const bool w0 = !X2 || wv == 0;             // wave 0 (or the only wave): everything that is not split
     const int R = p->R, n = R - 1, K = p->K, D = n + 7 + 4 * K;
@@ -1230,7 +1230,7 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
         // (unsigned 32-bit element offsets from the uniform table bases: one VALU instruction per address)
         double lc = 0.0, ls = 0.0, tS = 0.0, tC = 0.0;
         if (!EXT) { lc = cn_ldg(lidc, (unsigned)k); ls = cn_ldg(lids, (unsigned)k); }
-        if (!GT && k >= 1) { tS = cn_ldg(angs, (unsigned)(R - 1 - k)); tC = cn_ldg(angc, (unsigned)(R - 1 - k)); }
+        if (!GT) { tS = cn_ldg(angs, (unsigned)(R - 1 - k)); tC = cn_ldg(angc, (unsigned)(R - 1 - k)); }   // (ray 0 reads entry R - 1 and never uses it: no exec mask around two loads)
         const double t = cast_ray<EXT>(p, L, env, k, ox, oy, sy, cy, nnear, wall_x, wall_y, lc, ls, X2 ? nullptr : &blkw);
         if (k >= 1) {
             const unsigned j = (unsigned)(R - 1 - k);  // UTL:389-390 reverse, drop last
@@ -2540,7 +2540,8 @@ __device__ __forceinline__ void env_kernel_body(const int env, const int lane, c
                                                 const float* const act_here = nullptr, const int wv = 0)
 {
     static_assert(!X2 || (!EXT && !TWO && LAYOUT == 0 && !GT && SIM == 0 && !FUSED), "two wavefronts per environment: the plain step kernel");
-    constexpr bool SFENCE = SHAPE == 720 && !FAIR && !FUSED;
+    // (round 6: the oldest-first 360-ray step kernels as well -- 26 scalar spills without the fences, see tools/kernel_resources.sh)
+    constexpr bool SFENCE = (SHAPE == 720 || (SHAPE == 360 && !X2)) && !FAIR && !FUSED;
     KP p = (KP)__builtin_amdgcn_kernarg_segment_ptr();
     if constexpr (FUSED) {
         // Inside the multi-step kernel's step loop everything below is loop-invariant as far as the compiler can see, and it
@@ -2809,7 +2810,7 @@ __device__ __forceinline__ void env_kernel_body(const int env, const int lane, c
         if (ph_obs) {
             if constexpr (LAYOUT == 1) observe_original<EXT>(p, e, L, env, lane, sc, io_obs(), fin, p->obs_f64, &done);
             else if constexpr (LAYOUT == 2) observe_realworld<EXT>(p, pg, e, L, RQ, env, lane, sc, io_obs(), fin, p->obs_f64, &done);
-            else observe<EXT, GT, FAIR, CMP, X2>(p, pg, e, L, env, lane, sc, io_obs(), fin, p->obs_f64, &done, have_trig, trig, 0, mb);
+            else observe<EXT, GT, FAIR, CMP, X2, SFENCE>(p, pg, e, L, env, lane, sc, io_obs(), fin, p->obs_f64, &done, have_trig, trig, 0, mb);
         } else if constexpr (EXT) {
             // Env.compute_reward(state, step_counter, done) on its own (ENV:1046): heading and distance are state[n], state[n+1]
             // (LAYOUT 1: state[-2], state[-1] are what ORIG:324-330 reads), `done` is the caller's
