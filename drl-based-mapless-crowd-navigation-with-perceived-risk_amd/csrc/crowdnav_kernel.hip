@@ -2649,6 +2649,18 @@ __device__ __forceinline__ void env_kernel_body(const int env, const int lane, c
     char* rec = p->state + (size_t)env * (size_t)p->state_stride;
     double* sd = (double*)(rec + CN_ST_OFF_SD);
     int* si = (int*)(rec + CN_ST_OFF_SI);
+    // Round 6: every global load the first phase waits for is ASKED FOR before the first wait.  The pedestrians (behind a branch on
+    // the loaded track count) and the action (behind the branch on the loaded pending-reset flag) used to be a second and a third
+    // memory round trip in a row on a wavefront's critical path -- HBM-side latency each, since a launch finds nothing in its L2;
+    // now they travel with the state record: one coordinate per lane while 2 P <= 64, the action in two registers.
+    double* const gped_p = (double*)(rec + CN_ST_OFF_PED_P);
+    double* const gped_v = (double*)(rec + CN_ST_OFF_PED_V(p->P));
+    const bool ped_pre = !X2 && 2 * p->P <= 64;
+    double pp_pre = 0.0, pv_pre = 0.0;
+    if (ped_pre) { const int li = lane < 2 * p->P ? lane : 2 * p->P - 1; pp_pre = gped_p[li]; pv_pre = gped_v[li]; }
+    const bool act_pre = !EXT && !act_here && p->mode == CN_MODE_STEP;
+    float a0_pre = 0.0f, a1_pre = 0.0f;
+    if (act_pre) { const float* const ain_ = io_action() + 2 * (size_t)env; a0_pre = ain_[0]; a1_pre = ain_[1]; }
     EnvRegs e;
     e.rx = sd[CN_SD_RX]; e.ry = sd[CN_SD_RY]; e.ryaw = sd[CN_SD_RYAW]; e.rv = sd[CN_SD_RV]; e.rw = sd[CN_SD_RW];
     e.clock = sd[CN_SD_CLOCK]; e.wpx = sd[CN_SD_WPX]; e.wpy = sd[CN_SD_WPY];
@@ -2682,12 +2694,11 @@ __device__ __forceinline__ void env_kernel_body(const int env, const int lane, c
     // 128-byte line of the live records -- so that the real load, ~20 us later, hits the L2.
     int trk_warm = 0;
     if (LAYOUT == 0 && lane * 128 < e.ntracks * (CN_TF_COUNT * 8)) trk_warm = ((const volatile int*)L.gtrk)[lane * 32];
-    double* gped_p = (double*)(rec + CN_ST_OFF_PED_P);
-    double* gped_v = (double*)(rec + CN_ST_OFF_PED_V(P));
     const double* gped_init = p->ped_init + (size_t)env * 2 * P;
     double* pedv = L.pedv;  // velocities are only needed while advancing
     if constexpr (!X2) {    // (X2: wave 1 brings the pedestrians in, below, once it is known that this launch is a step)
-    for (int i = lane; i < 2 * P; i += 64) { L.ped[i] = gped_p[i]; pedv[i] = gped_v[i]; }
+    if (ped_pre) { if (lane < 2 * P) { L.ped[lane] = pp_pre; pedv[lane] = pv_pre; } }
+    else for (int i = lane; i < 2 * P; i += 64) { L.ped[i] = gped_p[i]; pedv[i] = gped_v[i]; }
     CN_SYNC();
     }
     XMail* const mb = X2 ? (XMail*)(smem + p->wave_lds) : nullptr;
@@ -2748,8 +2759,9 @@ __device__ __forceinline__ void env_kernel_body(const int env, const int lane, c
             sc = p->step_counter ? p->step_counter[env] : e.ep_step;
             double deq_x, deq_y, end_timestep;
             if (!ext) {
-                const float* const ain = act_here ? act_here : io_action() + 2 * (size_t)env;
-                const double v = (double)ain[0], w = (double)ain[1];
+                double v, w;
+                if (act_pre) { v = (double)a0_pre; w = (double)a1_pre; }          // (asked for with the state record)
+                else { const float* const ain = act_here ? act_here : io_action() + 2 * (size_t)env; v = (double)ain[0]; w = (double)ain[1]; }
                 const double t0 = e.clock;
                 if constexpr (SIM == 3) { e.cv = v; e.cw = w; } else { e.rv = v; e.rw = w; }   // pub_cmd_vel.publish (ENV:1200)
                 e.clock += cn_div1000((double)p->dt_ms);              // time.sleep(0.15) (ENV:1201)

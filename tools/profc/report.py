@@ -152,7 +152,12 @@ def main():
     lost = 0
     block = 0
     recs = []
-    want = {int(x) for x in a.lines.split(",") if x}
+    want = set()
+    for x in a.lines.split(","):            # "1183,247-345": single lines and ranges
+        if "-" in x:
+            lo_, hi_ = x.split("-"); want |= set(range(int(lo_), int(hi_) + 1))
+        elif x:
+            want.add(int(x))
     detail = []
     entry = lookup("crowdnav_kernel.hip", 1, 1)
     for line in open(a.asm):
