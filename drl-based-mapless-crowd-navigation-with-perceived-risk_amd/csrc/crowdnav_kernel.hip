@@ -2655,9 +2655,15 @@ __device__ __forceinline__ void env_kernel_body(const int env, const int lane, c
     // now they travel with the state record: one coordinate per lane while 2 P <= 64, the action in two registers.
     double* const gped_p = (double*)(rec + CN_ST_OFF_PED_P);
     double* const gped_v = (double*)(rec + CN_ST_OFF_PED_V(p->P));
-    const bool ped_pre = !X2 && 2 * p->P <= 64;
-    double pp_pre = 0.0, pv_pre = 0.0;
-    if (ped_pre) { const int li = lane < 2 * p->P ? lane : 2 * p->P - 1; pp_pre = gped_p[li]; pv_pre = gped_v[li]; }
+    // (up to four coordinates per lane: 2 P <= 256 covers BASELINE configs[4]'s 100 pedestrians)
+    const int P2_ = 2 * p->P;
+    const bool ped_pre = !X2 && P2_ <= 256;
+    double pp_pre[4] = {0.0, 0.0, 0.0, 0.0}, pv_pre[4] = {0.0, 0.0, 0.0, 0.0};
+    if (ped_pre) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (64 * c < P2_) { const int li = lane + 64 * c < P2_ ? lane + 64 * c : P2_ - 1; pp_pre[c] = gped_p[li]; pv_pre[c] = gped_v[li]; }
+    }
     const bool act_pre = !EXT && !act_here && p->mode == CN_MODE_STEP;
     float a0_pre = 0.0f, a1_pre = 0.0f;
     if (act_pre) { const float* const ain_ = io_action() + 2 * (size_t)env; a0_pre = ain_[0]; a1_pre = ain_[1]; }
@@ -2697,7 +2703,11 @@ __device__ __forceinline__ void env_kernel_body(const int env, const int lane, c
     const double* gped_init = p->ped_init + (size_t)env * 2 * P;
     double* pedv = L.pedv;  // velocities are only needed while advancing
     if constexpr (!X2) {    // (X2: wave 1 brings the pedestrians in, below, once it is known that this launch is a step)
-    if (ped_pre) { if (lane < 2 * P) { L.ped[lane] = pp_pre; pedv[lane] = pv_pre; } }
+    if (ped_pre) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (lane + 64 * c < 2 * P) { L.ped[lane + 64 * c] = pp_pre[c]; pedv[lane + 64 * c] = pv_pre[c]; }
+    }
     else for (int i = lane; i < 2 * P; i += 64) { L.ped[i] = gped_p[i]; pedv[i] = gped_v[i]; }
     CN_SYNC();
     }
