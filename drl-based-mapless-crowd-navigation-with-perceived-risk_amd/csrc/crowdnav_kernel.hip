@@ -2695,6 +2695,22 @@ __device__ __forceinline__ void env_kernel_body(const int env, const int lane, c
     e.crowd_ms = (long long)(((unsigned long long)(unsigned)si[CN_SI_CROWD_HI] << 32) | (unsigned)si[CN_SI_CROWD_LO]);
     e.cv = 0.0; e.cw = 0.0;       // the command lives inside one call: a step publishes its action first, a reset leaves it zero
 
+    // Round 6: the kernel-argument block (1 048 bytes: every parameter is read in place, where it is used) spans 17 lines of the
+    // scalar cache, which a launch finds empty: each line's FIRST touch -- the trig table in front of the first sine, the pedestrian
+    // schedule, the goal geometry ... -- was a miss all the way to memory on the critical path of every wavefront of the CU (they
+    // run the same stage at the same time): ~2 000 cycles per stage that opens a new line (tools/stage_timing_physics.py).  All 17
+    // lines are touched here, behind the state record's loads that are already in flight: the misses overlap each other and the
+    // HBM round trip this wavefront waits for anyway.  (One destination register for all of them: the values are not used.)
+    if constexpr (!FUSED) {
+        static_assert(sizeof(CnKParams) <= 17 * 64, "kernarg lines touched below");
+        unsigned kp_warm_;
+        asm volatile("s_load_dword %0, %1, 0x0\n\ts_load_dword %0, %1, 0x40\n\ts_load_dword %0, %1, 0x80\n\ts_load_dword %0, %1, 0xc0\n\t"
+                     "s_load_dword %0, %1, 0x100\n\ts_load_dword %0, %1, 0x140\n\ts_load_dword %0, %1, 0x180\n\ts_load_dword %0, %1, 0x1c0\n\t"
+                     "s_load_dword %0, %1, 0x200\n\ts_load_dword %0, %1, 0x240\n\ts_load_dword %0, %1, 0x280\n\ts_load_dword %0, %1, 0x2c0\n\t"
+                     "s_load_dword %0, %1, 0x300\n\ts_load_dword %0, %1, 0x340\n\ts_load_dword %0, %1, 0x380\n\ts_load_dword %0, %1, 0x3c0\n\t"
+                     "s_load_dword %0, %1, 0x400\n\ts_load_dword %0, %1, 0x414\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(kp_warm_) : "s"(p) : "memory");
+    }
     // The tracker table is read from HBM in the middle of the observation (its LDS space holds the end points until then),
     // which would put a full memory round trip on the wavefront's critical path.  Touch its lines now -- one dword per
     // 128-byte line of the live records -- so that the real load, ~20 us later, hits the L2.
@@ -2778,9 +2794,11 @@ __device__ __forceinline__ void env_kernel_body(const int env, const int lane, c
                 if constexpr (SIM != 0) sim_advance_ticks<SIM>(p, e, env, lane, L.ped, pedv, (double*)smem, p->dt_ms);
                 else {
                 if constexpr (LAYOUT == 0) { step_trig(p, e, lane, rs1, rc1, rs2, rc2, trig); have_trig = true; }
+                CN_T(27);
                 // pedestrians: ONE pass over [0, dt + scan latency], cut at dt (they are only looked at by the scan)
                 if constexpr (!X2)
                 ped_advance<SHAPE == 360>(p, env, lane, L.ped, pedv, e.crowd_ms, e.crowd_ms + p->dt_ms + p->scan_latency_ms, p->dt_ms);
+                CN_T(28);
                 e.crowd_ms += p->dt_ms + p->scan_latency_ms;
                 if (have_trig) robot_advance_sc(p, e, p->dt_ms, rs1, rc1); else robot_advance(p, e, p->dt_ms);
                 }

@@ -11,8 +11,8 @@ tb = torch.zeros((N, 32), dtype=torch.int64, device="cuda")
 env.L.cn_debug_set_timing(env.h, C.c_void_p(tb.data_ptr()))
 g = torch.Generator(device="cuda").manual_seed(1)
 acts = torch.stack([torch.rand((16, N), generator=g, device="cuda") * 0.22, torch.rand((16, N), generator=g, device="cuda") * 4 - 2], 2).contiguous()
-seq = [1, 20, 21, 22, 23, 24, 2]
-names = ["advance 150 ms", "deque + advance 10 ms", "-> observe entry", "waypoint (step 1)", "dist + heading (atan2) + round", "waypoint refresh", "sincos(w), sincos(yaw), origin"]
+seq = [1, 27, 28, 20, 21, 22, 23, 24, 2]
+names = ["trig of the step (sincos x 4, packed)", "pedestrians: one pass over 160 ms", "robot advance 150 ms", "deque + advance 10 ms", "-> observe entry", "waypoint (step 1)", "dist + heading (atan2) + round", "waypoint refresh", "sincos(w), sincos(yaw), origin"]
 acc = np.zeros(len(seq) - 1); cnt = 0
 for i in range(60):
     tb.zero_(); env.step(acts[i % 16], auto_reset="next"); torch.cuda.synchronize()
