@@ -861,8 +861,12 @@ __device__ __forceinline__ int near_peds(KP p, const Lds& L, int lane, double ox
 // lc, ls: ray k in the robot frame = the host table of cn_det_sincos(k * step), loaded by the caller.
 template <bool EXT>
 __device__ __forceinline__ double cast_ray(KP p, const Lds& L, int env, int k, double ox, double oy, double sy,
-                                           double cy, int nnear, bool wall_x, bool wall_y, double lc, double ls, const u64* blkw = nullptr)
+                                           double cy, int nnear, bool wall_x, bool wall_y, double lc, double ls, const u64* blkw = nullptr,
+                                           const double* lmin_reg = nullptr, const bool defer_f32 = false)
 {
+    // lmin_reg / defer_f32 (the lidar-tracker layout's ray loop): lidar_min comes in a vector register the caller loaded before the
+    // loop, and the float32 rounding of cn_config.scan_f32 is the caller's -- read in place, the two parameters and the caller's own
+    // lidar_min_positive flag were three scalar loads with three waits in every 64-ray block
     if constexpr (EXT) {
         return p->ext_ranges[(size_t)env * p->R + k];   // Gazebo / a physical lidar
     } else {
@@ -880,7 +884,7 @@ __device__ __forceinline__ double cast_ray(KP p, const Lds& L, int env, int k, d
         const double reach = p->lidar_max * (1.0 + 1e-9);
         if (wall_x && dx != 0.0 && h - cn_xorsign(ox, dx) <= fma(reach, fabs(dx), 1e-12)) t = cn_vmin(t, cn_div(copysign(h, dx) - ox, dx));
         if (wall_y && dy != 0.0 && h - cn_xorsign(oy, dy) <= fma(reach, fabs(dy), 1e-12)) t = cn_vmin(t, cn_div(copysign(h, dy) - oy, dy));
-        t = cn_vmax_s(t, p->lidar_min);                        // (one v_max_f64: t is +inf or a finite quotient here, never a NaN)
+        t = lmin_reg ? cn_vmax(t, *lmin_reg) : cn_vmax_s(t, p->lidar_min);   // (one v_max_f64: t is +inf or a finite quotient here, never a NaN)
         const int q = k >> 6;                                  // this block of 64 rays (wave-uniform)
         auto test = [&](int c) {
             const double ocx = L.nearp[4 * c], ocy = L.nearp[4 * c + 1], cc = L.nearp[4 * c + 2];
@@ -889,8 +893,8 @@ __device__ __forceinline__ double cast_ray(KP p, const Lds& L, int env, int k, d
             if (disc >= 0.0) {
                 double sq = cn_sqrt(disc);
                 double t2 = b + sq;
-                if (t2 >= p->lidar_min) {
-                    double t1 = cn_vmax_s(b - sq, p->lidar_min);
+                if (t2 >= (lmin_reg ? *lmin_reg : p->lidar_min)) {
+                    double t1 = lmin_reg ? cn_vmax(b - sq, *lmin_reg) : cn_vmax_s(b - sq, p->lidar_min);
                     t = cn_vmin(t, t1);
                 }
             }
@@ -906,7 +910,7 @@ __device__ __forceinline__ double cast_ray(KP p, const Lds& L, int env, int k, d
             if ((((const u64*)L.nearp)[4 * c + 3] >> q) & 1ull) test(c);
         t = (t > p->lidar_max) ? INFINITY : t;          // the simulated sensor reports no return beyond its range
         // cn_config.scan_f32: sensor_msgs/LaserScan.ranges is float32[] (XACRO:172-175) -- what Gazebo hands ENV:1218
-        if (__builtin_expect(p->scan_f32 != 0, 0)) t = (double)(float)t;
+        if (!defer_f32 && __builtin_expect(p->scan_f32 != 0, 0)) t = (double)(float)t;
         return t;
     }
 }
@@ -1156,7 +1160,7 @@ __device__ __forceinline__ void tracker_stage(KP p, EnvRegs& e, const Lds& L, do
     CN_SYNC();
 }
 
-template <bool EXT, bool GT = false, bool FAIR = false, bool CMP = false, bool X2 = false, bool SF = false>
+template <bool EXT, bool GT = false, bool FAIR = false, bool CMP = false, bool X2 = false, bool SF = false, bool HOIST = true>
 __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const Lds& L, int env, int lane, int step_counter,
                         float* obs32, float* fin32, double* obs64, int* done_out, bool have_tg = false, Trig tg = Trig{0.0, 0.0, 0.0, 0.0},
                         const int wv = 0, XMail* const mb = nullptr)
@@ -1226,12 +1230,22 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
     // stage wants it (one VGPR held across the ray loop)
     short assoc_pre = 0;
     if (!GT && p->assoc_fast && lane <= p->assoc_k1 + 1) assoc_pre = p->assoc_tab[lane];
+    // the ray loop's three per-block parameters, once, in vector registers (see cast_ray): lidar_min, and the two rare switches
+    // (float32 ranges, a zero lidar_min) as one word tested once per block
+    // (HOIST = false: cn_policy_kernel_s720, whose 128-register cap has no room for them -- it reads the parameters in place)
+    double lmin_reg = 0.0;
+    int rare_reg = 0;
+    if constexpr (HOIST) {
+        lmin_reg = p->lidar_min;
+        rare_reg = (p->scan_f32 != 0 ? 1 : 0) | (p->lidar_min_positive ? 0 : 2);
+        asm volatile("" : "+v"(lmin_reg), "+v"(rare_reg));
+    }
     for (int k = X2 ? lane + 64 * wv : lane; k < R; k += X2 ? 128 : 64) {     // (X2: the 64-ray blocks alternate between the two waves)
         // (unsigned 32-bit element offsets from the uniform table bases: one VALU instruction per address)
         double lc = 0.0, ls = 0.0, tS = 0.0, tC = 0.0;
         if (!EXT) { lc = cn_ldg(lidc, (unsigned)k); ls = cn_ldg(lids, (unsigned)k); }
         if (!GT) { tS = cn_ldg(angs, (unsigned)(R - 1 - k)); tC = cn_ldg(angc, (unsigned)(R - 1 - k)); }   // (ray 0 reads entry R - 1 and never uses it: no exec mask around two loads)
-        const double t = cast_ray<EXT>(p, L, env, k, ox, oy, sy, cy, nnear, wall_x, wall_y, lc, ls, X2 ? nullptr : &blkw);
+        const double t = cast_ray<EXT>(p, L, env, k, ox, oy, sy, cy, nnear, wall_x, wall_y, lc, ls, X2 ? nullptr : &blkw, HOIST ? &lmin_reg : nullptr, HOIST);
         if (k >= 1) {
             const unsigned j = (unsigned)(R - 1 - k);  // UTL:389-390 reverse, drop last
             double r = t;
@@ -1246,7 +1260,13 @@ __device__ __forceinline__ void observe(KP p, const Poly& pg, EnvRegs& e, const 
                 // the simulated sensor returns +inf or a finite range >= lidar_min >= 0, never a NaN: the same chain, shorter.
                 // With lidar_min > 0 (cn_create records it) a zero range cannot occur either, and +inf falls out of the min.
                 sc = cn_vmin(r, MAXR);
-                if (__builtin_expect(!p->lidar_min_positive, 0)) sc = (r == 0.0) ? MAXR : sc;
+                // (a scalar branch: one lane read, a compare, a branch; without the hoist cast_ray has done the float32 rounding)
+                const int rare = HOIST ? __builtin_amdgcn_readfirstlane(rare_reg) : (p->lidar_min_positive ? 0 : 2);
+                if (__builtin_expect(rare != 0, 0)) {              // scan_f32 (cast_ray left the rounding to us) and / or lidar_min == 0
+                    if (rare & 1) r = (double)(float)r;
+                    sc = cn_vmin(r, MAXR);
+                    if ((rare & 2) && r == 0.0) sc = MAXR;
+                }
             }
             smin = cn_vmin(smin, sc);
             // sin/cos(radians(j * inc) - yaw) by angle addition from a host table of sin/cos(radians(j * inc))
@@ -2541,7 +2561,7 @@ __device__ __forceinline__ void env_kernel_body(const int env, const int lane, c
 {
     static_assert(!X2 || (!EXT && !TWO && LAYOUT == 0 && !GT && SIM == 0 && !FUSED), "two wavefronts per environment: the plain step kernel");
     // (round 6: the oldest-first 360-ray step kernels as well -- 26 scalar spills without the fences, see tools/kernel_resources.sh)
-    constexpr bool SFENCE = (SHAPE == 720 || (SHAPE == 360 && !X2)) && !FAIR && !FUSED;
+    constexpr bool SFENCE = (SHAPE == 720 || SHAPE == 360) && !FAIR && !FUSED;
     KP p = (KP)__builtin_amdgcn_kernarg_segment_ptr();
     if constexpr (FUSED) {
         // Inside the multi-step kernel's step loop everything below is loop-invariant as far as the compiler can see, and it
@@ -2765,7 +2785,7 @@ __device__ __forceinline__ void env_kernel_body(const int env, const int lane, c
                 }
                 CN_SYNC();
                 int d1 = 0;
-                observe<EXT, GT, FAIR, CMP, true>(p, pg, e, L, env, lane, 0, io_obs(), do_reset ? nullptr : p->final_obs, p->obs_f64, &d1, false,
+                observe<EXT, GT, FAIR, CMP, true, SFENCE>(p, pg, e, L, env, lane, 0, io_obs(), do_reset ? nullptr : p->final_obs, p->obs_f64, &d1, false,
                                                   Trig{0.0, 0.0, 0.0, 0.0}, 1, mb);
                 return;
             }
@@ -2850,7 +2870,7 @@ __device__ __forceinline__ void env_kernel_body(const int env, const int lane, c
         if (ph_obs) {
             if constexpr (LAYOUT == 1) observe_original<EXT>(p, e, L, env, lane, sc, io_obs(), fin, p->obs_f64, &done);
             else if constexpr (LAYOUT == 2) observe_realworld<EXT>(p, pg, e, L, RQ, env, lane, sc, io_obs(), fin, p->obs_f64, &done);
-            else observe<EXT, GT, FAIR, CMP, X2, SFENCE>(p, pg, e, L, env, lane, sc, io_obs(), fin, p->obs_f64, &done, have_trig, trig, 0, mb);
+            else observe<EXT, GT, FAIR, CMP, X2, SFENCE, !(FUSED && SHAPE == 720)>(p, pg, e, L, env, lane, sc, io_obs(), fin, p->obs_f64, &done, have_trig, trig, 0, mb);
         } else if constexpr (EXT) {
             // Env.compute_reward(state, step_counter, done) on its own (ENV:1046): heading and distance are state[n], state[n+1]
             // (LAYOUT 1: state[-2], state[-1] are what ORIG:324-330 reads), `done` is the caller's
