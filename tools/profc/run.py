@@ -38,7 +38,11 @@ def dump(zero):
     return buf.cpu().numpy().view(np.uint64).copy()
 
 
-env = VecEnv(Config(n_envs=N, n_peds=20, n_rays=360, k_obstacles=8, max_steps=1000, seed=1234, ped_cycle_ms=1400, room_half=1.40),
+# CN_PROFC_CFG: extra Config fields as "key=value,key=value" (e.g. ped_mode=2 for the social-force kernels)
+extra = {}
+for kv in filter(None, os.environ.get("CN_PROFC_CFG", "").split(",")):
+    k_, v_ = kv.split("="); extra[k_] = float(v_) if "." in v_ else int(v_)
+env = VecEnv(Config(**{**dict(n_envs=N, n_peds=20, n_rays=360, k_obstacles=8, max_steps=1000, seed=1234, ped_cycle_ms=1400, room_half=1.40), **extra}),
              arbitration=os.environ.get("CN_ARB", "auto"))
 env.reset()
 g = torch.Generator(device="cuda").manual_seed(1234)
@@ -52,7 +56,7 @@ for i in range(STEPS):
 c = dump(False)
 kern = env.kernel_name("step") if hasattr(env, "kernel_name") else "?"
 out = os.path.join(ROOT, "gpurun_out", "profc"); os.makedirs(out, exist_ok=True)
-np.savez_compressed(os.path.join(out, "counters_%d.npz" % N), counters=c, envs=N, steps=STEPS, preroll=PRE, kernel=kern)
+np.savez_compressed(os.path.join(out, "counters_%d%s.npz" % (N, os.environ.get("CN_PROFC_TAG", ""))), counters=c, envs=N, steps=STEPS, preroll=PRE, kernel=kern)
 nz = int((c != 0).sum())
 print("profc: %d envs x %d launches of %s; %d of %d counters non-zero; wave executions total %d, lane executions total %d" % (
     N, STEPS, kern, nz, n_cnt, int((c >> np.uint64(32)).sum()), int((c & np.uint64(0xffffffff)).sum())))
