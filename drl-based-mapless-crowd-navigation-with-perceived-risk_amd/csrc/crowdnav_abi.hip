@@ -436,7 +436,16 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
     k.start_x = c.start_x; k.start_y = c.start_y; k.spawn_x = c.spawn_x; k.spawn_y = c.spawn_y; k.spawn_yaw = c.spawn_yaw;
     k.waypoint_radius = c.waypoint_radius; k.goal_eps = c.goal_eps; k.angle_inc_deg = angle_increment_deg(R); k.lidar_step = step;
     { static const double trig[CN_TRIG_COUNT] = CN_TRIG_TABLE; static_assert(sizeof(trig) == sizeof(k.trig), "CnKParams::trig"); memcpy(k.trig, trig, sizeof(trig)); }
-    k.blk_dir = h->d_lidar + 4 * (size_t)R; k.blk_cb = cos(32.5 * step); k.blk_sb = sin(32.5 * step);
+    k.blk_dir = h->d_lidar + 4 * (size_t)R;
+    {   // near_peds' block test  oc . u_q >= cos(beta) sqrt(d^2 - r^2) - sin(beta) r  is  theta <= beta + asin(r / d)  only while
+        // beta + asin(r / d) <= pi (cos decreasing).  With few rays a block's half-width beta = 32.5 steps passes pi / 2 (R < 130) or
+        // even pi (R < 66) and the test would clear bits of pedestrians a ray can hit (found by tools/fuzz_parity.py: 13 / 42 / 46
+        // rays).  There the block bits are switched off: (cb, sb) = (-1, 1) makes the threshold -(sqrt(d^2 - r^2) + r) <= -d,
+        // which every direction passes, so every listed pedestrian is tested in every block.
+        const double beta = 32.5 * fabs(step);
+        const bool cone_ok = beta < 1.5707;
+        k.blk_cb = cone_ok ? cos(beta) : -1.0; k.blk_sb = cone_ok ? sin(beta) : 1.0;
+    }
     k.lidar_c = h->d_lidar; k.lidar_s = h->d_lidar + R; k.ang_s = h->d_lidar + 2 * R; k.ang_c = h->d_lidar + 3 * R; k.poly_c = h->d_poly; k.poly_s = h->d_poly + 64;
     k.state = h->d_state; k.state_stride = (int64_t)h->stride; k.ped_init = h->d_ped_init;
     k.ped_preset = h->d_ped_preset; k.trk = h->d_trk; k.ped_aux = h->d_ped_aux;

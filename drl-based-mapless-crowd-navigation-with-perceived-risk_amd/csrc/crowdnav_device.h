@@ -334,14 +334,25 @@ __device__ __forceinline__ double cn_atan2_t(cn_ktab t, double y, double x)
     return copysign(a, y);
 }
 
-// hypot() for lengths of a few metres: the device library's version wraps the same sqrt(fma(a, a, b b)), a = the larger
-// magnitude, in exponent scaling and inf/nan handling (frexp / ldexp / class tests, a third of its instructions) that
-// coordinates in thousandths of a metre never need.  hypot(x, 0) = |x| exactly, as in C.
+// hypot() for lengths of a few metres, BIT-EQUAL to the C library's the reference's math.hypot resolves to under Python 2.7 and the
+// goldens were recorded on (ENV:754, UTL:283-284; oracle/cn_oracle.c cno_hypot has the note): glibc 2.35's algorithm -- the square
+// root of the plain sum of squares and one correction step -- restated operation by operation (the build has -ffp-contract=off;
+// cn_sqrt / cn_div are correctly rounded).  Rounds 1-6 used sqrt(fma(a, a, b b)), which differs from it in the last bit on 13 % of
+// the arguments; that was inside every float tolerance, but ENV:826 compares two speeds for EXACT equality (`relative_vel == 0`
+// picks between two formulas a factor of two apart) and a robot driving straight past a static object makes them equal on
+// paper -- tools/fuzz_parity.py found worlds whose top-K sets differed for it.  glibc's scaling branches for huge / tiny
+// arguments never apply to coordinates in thousandths of a metre; hypot(x, 0) = |x| exactly, as in C.
 __device__ __forceinline__ double cn_hypot(double x, double y)
 {
-    const double ax = fabs(x), ay = fabs(y);
-    const double a = cn_vmax(ax, ay), b = cn_vmin(ax, ay);
-    return cn_sqrt(fma(a, a, b * b));
+    const double fx = fabs(x), fy = fabs(y);
+    const double ax = cn_vmax(fx, fy), ay = cn_vmin(fx, fy);
+    double h = cn_sqrt(ax * ax + ay * ay);
+    const bool lo = h <= 2.0 * ay;
+    const double delta = h - (lo ? ay : ax);
+    const double t1 = lo ? ax * (2.0 * delta - ax) : 2.0 * delta * (ax - 2.0 * ay);
+    const double t2 = lo ? (delta - 2.0 * (ax - ay)) * delta : (4.0 * delta - ay) * ay + delta * delta;
+    h -= cn_div(t1 + t2, 2.0 * h);
+    return (ay == 0.0) ? ax : h;
 }
 
 // ---- counter-based RNG (CROWD:101-102 random.uniform) ---------------------------------------

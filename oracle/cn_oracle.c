@@ -143,6 +143,36 @@ static double round_np64(double x, int nd) { return g_py2 ? cno_py_round(x, nd) 
 /* Deterministic sin/cos used by the simulator (physics + lidar direction table): only + * fma
  * and rint, so every IEEE-754 implementation returns the same bits.  Cody-Waite reduction by
  * pi/2 (three-part constant) followed by the classic degree-13/14 minimax kernels on [-pi/4, pi/4]. */
+/* math.hypot (ENV:754, UTL:283-284, 409-413) = the C library's hypot under the reference's Python 2.7 (oracle/harness/refenv.py
+ * binds math.hypot to libm for that reason; CPython >= 3.8 has its own, correctly rounded one, which differs from this image's on
+ * 0.5 % of the path's arguments).  Its last bit decides exact comparisons downstream -- ENV:826 `relative_vel == 0` picks between
+ * two formulas whose results differ by a factor of two, and a robot driving straight past a static object makes the two speeds
+ * equal on paper -- so the function is part of the semantics and is spelled out here instead of left to whatever libm the oracle
+ * is linked against: glibc 2.35's algorithm (sysdeps/ieee754/dbl-64/e_hypot.c, the kernel without hardware fma: the square root of
+ * the plain sum of squares and one correction step, < 1 ulp), the C library the goldens were recorded on; bit-equal to this
+ * image's hypot() on every sample of tests/test_simulator_known_answers.py::test_hypot_restatement_is_the_c_librarys.  The device
+ * code restates the same operations (crowdnav_device.h cn_hypot).  Lengths of a few metres: glibc's scaling branches for huge /
+ * tiny arguments never apply; hypot(x, 0) = |x|. */
+double cno_hypot(double x, double y)
+{
+    double ax = fabs(x), ay = fabs(y);
+    if (ax < ay) { double t = ax; ax = ay; ay = t; }
+    if (ay == 0.0 || ax >= ay / 0x1p-54) return ax + ay;
+    double h = sqrt(ax * ax + ay * ay), t1, t2;
+    if (h <= 2.0 * ay) {
+        double delta = h - ay;
+        t1 = ax * (2.0 * delta - ax);
+        t2 = (delta - 2.0 * (ax - ay)) * delta;
+    } else {
+        double delta = h - ax;
+        t1 = 2.0 * delta * (ax - 2.0 * ay);
+        t2 = (4.0 * delta - ay) * ay + delta * delta;
+    }
+    h -= (t1 + t2) / (2.0 * h);
+    return h;
+}
+void cno_hypot_array(int n, const double* x, const double* y, double* out) { for (int i = 0; i < n; ++i) out[i] = cno_hypot(x[i], y[i]); }
+
 void cno_det_sincos(double x, double* sn, double* cs)
 {
     const double two_over_pi = 6.36619772367581382433e-01;
@@ -627,7 +657,7 @@ double cno_bbox_size(const double* pts, int n)
     double sum = 0.0; /* Python sum(): left-to-right float adds starting from int 0 */
     for (int i = 0; i < n; ++i) {
         int j = (i == n - 1) ? 0 : i + 1;
-        sum += hypot(pts[2 * i] - pts[2 * j], pts[2 * i + 1] - pts[2 * j + 1]);
+        sum += cno_hypot(pts[2 * i] - pts[2 * j], pts[2 * i + 1] - pts[2 * j + 1]);
     }
     return sum / (double)n;
 }
@@ -727,8 +757,8 @@ static int collision_point_impl(const double* pc, const double* ps, double a0x, 
             continue;
         }
         if (cnt == 1) return 0;     /* Point has no .geoms -> except -> None, break */
-        double d1 = hypot(a0x - hit[0].x, a0y - hit[0].y);
-        double d2 = hypot(a0x - hit[1].x, a0y - hit[1].y);
+        double d1 = cno_hypot(a0x - hit[0].x, a0y - hit[0].y);
+        double d2 = cno_hypot(a0x - hit[1].x, a0y - hit[1].y);
         *dist = fmin(d1, d2);
         return 1;
     }
@@ -1140,7 +1170,7 @@ static void env_get_state(const cno_sim* s, env_t* e, const double* ranges, doub
     for (int i = 0; i < e->ntracks; ++i) {
         track_t* t = &e->tracks[i];
         if (t->dq_len > 1) {
-            double dc = hypot(t->dq[0].y - t->dq[1].y, t->dq[0].x - t->dq[1].x);
+            double dc = cno_hypot(t->dq[0].y - t->dq[1].y, t->dq[0].x - t->dq[1].x);
             t->speed = dc / t->t;
         }
     }
@@ -1521,7 +1551,7 @@ static void rw_get_state(const cno_sim* s, env_t* e, const double* ranges, doubl
     tracker_update(e, conf, nconf, now, tmp);
     for (int i = 0; i < e->ntracks; ++i) {                                   /* RW:573-589 */
         track_t* t = &e->tracks[i];
-        if (t->dq_len > 1) t->speed = hypot(t->dq[0].y - t->dq[1].y, t->dq[0].x - t->dq[1].x) / t->t;
+        if (t->dq_len > 1) t->speed = cno_hypot(t->dq[0].y - t->dq[1].y, t->dq[0].x - t->dq[1].x) / t->t;
     }
     e->n_entries = 0;
     if (e->agent_dq_len == 2) {                                              /* RW:595-700 */

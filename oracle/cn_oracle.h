@@ -133,6 +133,8 @@ void cno_ext_set_done(cno_sim* s, int env, int done);
 double cno_py_round(double x, int ndigits);
 double cno_np_around(double x, int ndigits);
 void   cno_det_sincos(double x, double* s, double* c);
+double cno_hypot(double x, double y);   /* math.hypot as this image's C library computes it, spelled out (cn_oracle.c) */
+void   cno_hypot_array(int n, const double* x, const double* y, double* out);
 void   cno_scan_sanitize(const double* ranges, int R, double max_range, double* scan);
 void   cno_scan_to_points(const double* scan, int R, double px, double py, double yaw, double* pts);
 int    cno_waypoint(double ax, double ay, double gx, double gy, double radius, double* wp);

@@ -28,6 +28,30 @@ def test_det_sincos_matches_libm(oracle_mod):
     assert worst < 3e-16
 
 
+def test_hypot_restatement_is_the_c_librarys(oracle_mod):
+    """cno_hypot (glibc 2.35's algorithm spelled out: the reference's math.hypot under Python 2.7 is the C library's) against the
+    hypot of the C library this test runs on, BIT FOR BIT, on the arguments the path feeds it (differences of coordinates in
+    thousandths) and on general ones -- ENV:826 compares two speeds for exact equality, so the last bit is part of the semantics;
+    within half an ulp of the exact value on Pythagorean-free samples is implied by glibc's own bound and not asserted here."""
+    L = oracle_mod.lib()
+    L.cno_hypot_array.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]; L.cno_hypot_array.restype = None
+    libm = C.CDLL("libm.so.6"); libm.hypot.restype = C.c_double; libm.hypot.argtypes = [C.c_double, C.c_double]
+    rng = np.random.default_rng(11)
+    x = np.concatenate([rng.integers(-3000, 3000, 1000000) / 1000.0 - rng.integers(-3000, 3000, 1000000) / 1000.0, rng.uniform(-5, 5, 1000000), [0.0, 3.0, 0.0, -2.5, 1.0]])
+    y = np.concatenate([rng.integers(-3000, 3000, 1000000) / 1000.0 - rng.integers(-3000, 3000, 1000000) / 1000.0, rng.uniform(-5, 5, 1000000), [0.0, 0.0, -1.25, 0.0, 1e-17]])
+    got = np.empty_like(x)
+    L.cno_hypot_array(x.size, x.ctypes.data, y.ctypes.data, got.ctypes.data)
+    assert np.array_equal(got[-5:], [0.0, 3.0, 1.25, 2.5, 1.0])
+    ref = np.hypot(x, y)                                    # numpy's loop calls the C library's hypot
+    assert all(libm.hypot(float(x[i]), float(y[i])) == ref[i] for i in range(0, x.size, 997))
+    assert np.array_equal(got, ref), "this C library's hypot is not glibc 2.35's algorithm: %d of %d differ" % (int((got != ref).sum()), x.size)
+    # and the one the kernel used through round 6, sqrt(fma(a, a, b b)), is NOT that function (why it was replaced)
+    a, b = np.maximum(np.abs(x), np.abs(y)), np.minimum(np.abs(x), np.abs(y))
+    old = np.array([math.sqrt(math.fma(float(a[i]), float(a[i]), float(b[i] * b[i]))) for i in range(0, 20000)]) if hasattr(math, "fma") else None
+    if old is not None:
+        assert (old != ref[:20000]).mean() > 0.02
+
+
 def test_lidar_single_disc_closed_form(oracle_mod):
     cfg = oracle_mod.make_config(n_peds=1, room_half=5.0, lidar_offset_x=0.0)
     d, r = 0.40, cfg.ped_radius
