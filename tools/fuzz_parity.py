@@ -40,6 +40,13 @@ def draw(rng):
               settle_ms=int(rng.choice([0, 50, 100, 100])), ped_cycle_ms=int(rng.choice([0, 300, 700, 1400, 2000])),
               ped_vmax=float(rng.uniform(0.05, 0.5)), min_scan_range=float(rng.choice([0.0, 0.12, 0.12])),
               seed=int(rng.integers(1, 1 << 30)), env_index_base=int(rng.integers(0, 1 << 20)))
+    if rng.random() < 0.5:          # the sensor, the bodies and the goal geometry too (every second world keeps the reference's)
+        kw.update(lidar_max=float(rng.choice([0.6, 0.6, 1.0, 3.5])), max_scan_range=float(rng.choice([0.6, 0.6, 0.5, 1.0])),
+                  lidar_min=float(rng.choice([0.08, 0.08, 0.0, 0.12])), lidar_span=float(rng.choice([6.28, 6.28, 3.14, 4.0])),
+                  lidar_offset_x=float(rng.choice([-0.032, -0.032, 0.0, 0.05])), ped_radius=float(rng.choice([0.0505, 0.0505, 0.1, 0.03])),
+                  robot_clearance=float(rng.choice([0.09, 0.09, 0.15])), waypoint_radius=float(rng.choice([0.3, 0.3, 0.2, 0.5])),
+                  goal_eps=float(rng.choice([0.2, 0.2, 0.1, 0.4])), start_x=float(rng.uniform(-1, 1)), start_y=float(rng.uniform(-1, 1)),
+                  track_capacity=int(rng.choice([0, 0, 64])), ped_stagger_ms=int(rng.choice([100, 100, 50, 200])))
     form = str(rng.choice(["step", "step", "sequence", "policy"]))
     mode = "next" if form != "step" else str(rng.choice(["next", "same"]))
     return kw, form, mode
@@ -182,8 +189,9 @@ def main():
     forms = {}
     while time.time() < t_end:
         kw, form, mode = draw(rng)
+        steps = a.steps if rng.random() < 0.8 else 4 * a.steps       # every fifth world four times as long (tracks persist across resets)
         try:
-            bad, kn, skipped = run_world(kw, form, mode, a.steps)
+            bad, kn, skipped = run_world(kw, form, mode, steps)
         except Exception as ex:                     # cn_create's own validation (the message names the field)
             if "cn_create" not in str(ex):
                 raise
@@ -199,14 +207,14 @@ def main():
             continue
         if skipped == "overflow":
             n_overflow += 1
-            env_steps += kw["n_envs"] * a.steps
+            env_steps += kw["n_envs"] * steps
             if n_overflow <= 3:
                 print("  table overflow (flagged in the status word) %d: %s %s | %s" % (n_overflow, kn, bad[:2], {k: kw[k] for k in ("n_envs", "n_peds", "n_rays", "k_obstacles", "max_steps")}))
             continue
-        env_steps += kw["n_envs"] * a.steps
+        env_steps += kw["n_envs"] * steps
         if bad:
             n_bad += 1
-            print("  bad world %d: %s %s %s %s | --form %s --mode %s --repro \"%r\"" % (n_bad, form, mode, kn, bad[:3], form, mode, kw))
+            print("  bad world %d: %s %s %s %s | --form %s --mode %s --steps %d --repro \"%r\"" % (n_bad, form, mode, kn, bad[:3], form, mode, steps, kw))
     print("fuzz_parity: seed %d, %.0f s: %d worlds (%d more refused by cn_create), %d env-steps compared, %d world(s) with a difference; %d more outgrew the track / confirmed-object tables (status bit raised); cn_rollout_policy refused %d shape(s) for LDS"
           % (a.seed, a.seconds, n_trials, n_refused, env_steps, n_bad, n_overflow, n_form_refused))
     print("  launch forms:", dict(sorted(forms.items())))
