@@ -335,7 +335,7 @@ __device__ __forceinline__ double cn_atan2_t(cn_ktab t, double y, double x)
 }
 
 // hypot() for lengths of a few metres, BIT-EQUAL to the C library's the reference's math.hypot resolves to under Python 2.7 and the
-// goldens were recorded on (ENV:754, UTL:283-284; oracle/cn_oracle.c cno_hypot has the note): glibc 2.35's algorithm -- the square
+// goldens were recorded on (ENV:754, UTL:283-284; DESIGN.md section 4 has the note): glibc 2.35's algorithm -- the square
 // root of the plain sum of squares and one correction step -- restated operation by operation (the build has -ffp-contract=off;
 // cn_sqrt / cn_div are correctly rounded).  Rounds 1-6 used sqrt(fma(a, a, b b)), which differs from it in the last bit on 13 % of
 // the arguments; that was inside every float tolerance, but ENV:826 compares two speeds for EXACT equality (`relative_vel == 0`
