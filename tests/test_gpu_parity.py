@@ -974,14 +974,15 @@ FUZZ_WORLDS = {
 
 @pytest.mark.parametrize("world", sorted(FUZZ_WORLDS))
 def test_worlds_the_fuzzer_found(oracle_mod, world):
-    """The worlds tools/fuzz_parity.py found a difference in (round 6), each through the launch form it was found with and through
-    cn_step: observations, rewards, done flags, indices and counters equal the oracle's over 30 steps."""
+    """The worlds tools/fuzz_parity.py found a difference in (round 6), each through the launch form it was found with (the few-ray
+    worlds through cn_step too): observations, rewards, done flags, indices and counters equal the oracle's over 30 steps."""
     import sys
     from conftest import ROOT
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import fuzz_parity
     form, kw = FUZZ_WORLDS[world]
-    for f in (form, "step"):
+    # (the few-ray worlds also through cn_step; relative_vel_zero only with the actions it was found with -- the step form draws others)
+    for f in ((form,) if world == "relative_vel_zero" else (form, "step")):
         bad, kernel, skipped = fuzz_parity.run_world(dict(kw), f, "next", 30)
         # (relative_vel_zero: the event is env 27's step 11; from step 12 on ANOTHER env of that crowded 1025-ray world has more
         # than track_capacity = 32 tracks -- the documented limit, CN_ST_TRACK_OVERFLOW raised in its status word)
