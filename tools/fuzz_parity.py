@@ -21,6 +21,9 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "drl-based-mapless-crowd-navigation-with-perceived-risk_amd"))
 
 
+HEADLINE_FRAC = 0.0
+
+
 def draw(rng):
     layout = int(rng.choice([0, 0, 0, 1, 2]))
     risk = int(rng.choice([0, 0, 1])) if layout == 0 else 0
@@ -47,6 +50,14 @@ def draw(rng):
                   robot_clearance=float(rng.choice([0.09, 0.09, 0.15])), waypoint_radius=float(rng.choice([0.3, 0.3, 0.2, 0.5])),
                   goal_eps=float(rng.choice([0.2, 0.2, 0.1, 0.4])), start_x=float(rng.uniform(-1, 1)), start_y=float(rng.uniform(-1, 1)),
                   track_capacity=int(rng.choice([0, 0, 64])), ped_stagger_ms=int(rng.choice([100, 100, 50, 200])))
+    if rng.random() < HEADLINE_FRAC:
+        # the two BENCHMARKED shapes, whose kernels are compiled for exactly these sizes (cn_env_kernel[_fair]_s360[_w4|_x2], _seq_s360,
+        # cn_policy_kernel_s360 and the _s720 family): everything that keeps a world on them stays random, and the grid sizes walk
+        # through the selection rules of choose_kernel (two wavefronts per env up to 2048 envs, 4 envs per workgroup up to 4096, ...)
+        dense = rng.random() < 0.3
+        kw.update(n_peds=100 if dense else 20, n_rays=720 if dense else 360, k_obstacles=8, obs_layout=0, risk_mode=0, ped_mode=0, ped_contact=0,
+                  wheel_accel=0.0, sf_tick_ms=0, track_capacity=0, room_half=float(rng.uniform(2.0, 3.2)) if dense else float(rng.uniform(1.0, 3.0)),
+                  n_envs=int(rng.choice([1, 17, 64, 300, 1000, 2100, 4100] if not dense else [1, 17, 64, 300, 1000])))
     form = str(rng.choice(["step", "step", "sequence", "policy"]))
     mode = "next" if form != "step" else str(rng.choice(["next", "same"]))
     return kw, form, mode
@@ -168,6 +179,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--verbose", type=int, default=3)
     ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--headline-frac", type=float, default=0.0, help="fraction of the worlds drawn on the two benchmarked shapes (their specialised kernels)")
     ap.add_argument("--repro", default=None, help="a world as printed by a MISMATCH line: \"{'n_envs': ...}\"; with --form / --mode")
     ap.add_argument("--form", default="step")
     ap.add_argument("--mode", default="next")
@@ -175,6 +187,8 @@ def main():
     a = ap.parse_args()
     from oracle import oracle
     oracle.set_num_threads()
+    global HEADLINE_FRAC
+    HEADLINE_FRAC = a.headline_frac
     if a.repro:
         import ast
         kw = ast.literal_eval(a.repro)
