@@ -58,7 +58,7 @@ def draw(rng):
         kw.update(n_peds=100 if dense else 20, n_rays=720 if dense else 360, k_obstacles=8, obs_layout=0, risk_mode=0, ped_mode=0, ped_contact=0,
                   wheel_accel=0.0, sf_tick_ms=0, track_capacity=0, room_half=float(rng.uniform(2.0, 3.2)) if dense else float(rng.uniform(1.0, 3.0)),
                   n_envs=int(rng.choice([1, 17, 64, 300, 1000, 2100, 4100] if not dense else [1, 17, 64, 300, 1000])))
-    form = str(rng.choice(["step", "step", "sequence", "policy"]))
+    form = str(rng.choice(["step", "step", "sequence", "policy", "manual"]))
     mode = "next" if form != "step" else str(rng.choice(["next", "same"]))
     return kw, form, mode
 
@@ -87,7 +87,7 @@ def run_world(kw, form, mode, T, detail=False, as_steps=False):
     N = cfg.n_envs
     orc = oracle.Oracle(cfg.as_dict())
     env.enable_f64_obs()
-    what = "policy" if form == "policy" else "sequence" if form == "sequence" else "same" if mode == "same" else "step"
+    what = "policy" if form == "policy" else "sequence" if form == "sequence" else "same" if (mode == "same" and form == "step") else "step"
     kn = env.kernel_name(what)
     env.reset(); torch.cuda.synchronize()
     bad, skipped, bad_envs = [], None, set()
@@ -110,6 +110,42 @@ def run_world(kw, form, mode, T, detail=False, as_steps=False):
             check("idx @%d" % t, env.topk_idx.cpu().numpy(), ic)
             if bad:
                 break
+    elif form == "manual":
+        # the reference's own loop (TRAIN:106-166): no auto-reset, an explicit step counter per environment, Env.reset() for the
+        # environments that finished (cn_reset with a mask) -- plus a few that did not (a trainer may cut an episode short)
+        sc = np.zeros(N, dtype=np.int32)
+        for t in range(T):
+            act = np.stack([rng.uniform(0, 0.22, N), rng.uniform(-2, 2, N)], 1).astype(np.float32)
+            env.step(torch.from_numpy(act).cuda(), step_counter=sc, auto_reset=False); torch.cuda.synchronize()
+            oc, rc, dc, ic = orc.step(act.astype(np.float64), step_counter=sc, auto_reset=False)
+            check("obs @%d" % t, env.obs_f64.cpu().numpy(), oc)
+            check("reward @%d" % t, env.reward.cpu().numpy(), rc.astype(np.float32))
+            check("done @%d" % t, env.done.cpu().numpy(), dc)
+            check("idx @%d" % t, env.topk_idx.cpu().numpy(), ic)
+            if bad:
+                break
+            mask = (dc != 0) | (rng.random(N) < 0.02)
+            sc += 1
+            if mask.any():
+                env.reset(mask=mask); torch.cuda.synchronize()
+                orst = orc.reset(mask=mask)
+                full_g, full_c = env.obs_f64.cpu().numpy(), orst
+                rows_bad = np.nonzero(mask & (full_g != full_c).any(1))[0]
+                if len(rows_bad):
+                    bad.append("masked reset @%d" % t); bad_envs.update(int(x) for x in rows_bad)
+                    if detail:
+                        e_ = int(rows_bad[0]); cols_ = np.nonzero(full_g[e_] != full_c[e_])[0]
+                        print("   masked reset @%d: env %d (done before the reset: %d, step counter %d) cols %s\n      gpu %s\n      cpu %s" % (t, e_, int(dc[e_]), int(sc[e_]), cols_[:16], full_g[e_][cols_[:8]], full_c[e_][cols_[:8]]))
+                        dg, dc__ = env.debug_env(e_), orc.debug(e_)
+                        for k_ in ("n_tracks", "n_confirmed", "n_entries", "collision_prob", "ego_score", "status"):
+                            print("      %-14s gpu %r cpu %r" % (k_, dg[k_], dc__[k_]))
+                        print("      track_pose gpu", np.asarray(dg["track_pose"]).tolist(), "\n      track_pose cpu", np.asarray(dc__["track_pose"]).tolist())
+                        print("      track_vel gpu", np.asarray(dg["track_vel"]).tolist(), "\n      track_vel cpu", np.asarray(dc__["track_vel"]).tolist())
+                        print("      track_t gpu", np.asarray(dg["track_t"]).tolist(), "\n      track_t cpu", np.asarray(dc__["track_t"]).tolist())
+                        print("      entry_cp cpu", np.asarray(dc__["entry_cp"]).tolist())
+                sc[mask] = 0
+                if bad:
+                    break
     else:
         Tc = int(rng.choice([1, 5, 12, 20]))
         traj = dict(action=torch.zeros((Tc, N, 2), device="cuda"), obs=torch.zeros((Tc, N, env.D), device="cuda"),
