@@ -392,6 +392,18 @@ class VecEnv:
         _abi.check(self.L.cn_get_returns(self.h, _ptr(self._ret), _ptr(self._run), self._stream()))
         return self._ret, self._run
 
+    STATUS_BITS = {"track_overflow": 1, "ttc_zero": 2, "dt_zero": 4, "conf_overflow": 8}      # include/crowdnav.h CN_ST_*
+
+    def status_counts(self):
+        """How many environments carry each bit of the per-env status word (sticky until the handle is re-created): a host read.
+        track_overflow / conf_overflow: the env outgrew track_capacity (32 / 64 tracks) or the confirmed-object table -- the
+        reference's Python lists are unbounded (its tracker keeps the tracks of earlier episodes and duplicates them at a reset), so
+        from that step on the env's risk features are computed from the tracks that fit and no longer equal the reference's;
+        ttc_zero / dt_zero: a zero time to collision / a repeated time stamp (the reference divides by zero there too)."""
+        st = self.counters()[:, 6]
+        return {k: int(((st & b) != 0).sum().item()) for k, b in self.STATUS_BITS.items()}
+
+
     def debug_env(self, env=0):
         sd = np.zeros(_abi.CN_SD_COUNT); rp = np.zeros(5 + 4 * self.P)
         tr = np.zeros((_abi.CN_MAX_TRACKS, _abi.CN_TF_COUNT)); si = np.zeros(_abi.CN_SI_COUNT, dtype=np.int32)
@@ -653,6 +665,14 @@ class VecEnvGroups:
         cs = [e.counters() for e in self.envs]
         self.join()
         return torch.cat(cs, 0)
+
+    def status_counts(self):
+        """VecEnv.status_counts summed over the groups."""
+        out = {}
+        for e in self.envs:
+            for k, v in e.status_counts().items():
+                out[k] = out.get(k, 0) + v
+        return out
 
     def returns(self):
         """(return of the last finished episode, running return) float32 [N], gathered over the groups."""

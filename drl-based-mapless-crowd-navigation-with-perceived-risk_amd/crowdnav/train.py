@@ -170,6 +170,7 @@ def train(a):
     agent.sync_fused_weights()
     step_s = (env.cfg.dt_ms + env.cfg.scan_latency_ms) / 1000.0
     win = []                                                           # (successes, episodes) of the recent log windows
+    warned_overflow = False
     for it in range(1, a.launches + 1):
         act = agent.act_mfma(obs, add_noise=True)                      # TD3:196-223 as one kernel, sigma = 1.0, clipped
         prev.copy_(obs)
@@ -204,6 +205,14 @@ def train(a):
                 line = "launch %6d  env-steps %10d  updates %9d  episodes %8d  success %.3f  mean return %8.1f  mean steps %6.1f  %.0f s" % (
                     it, env_steps, updates_done, episodes, tot[1] / ne, tot[2] / ne, tot[3] / ne, time.time() - t0)
                 print(line, flush=True); log.write(line + "\n"); log.flush()
+            if not warned_overflow:
+                sc_ = env.status_counts()
+                if sc_["track_overflow"] or sc_["conf_overflow"]:
+                    warned_overflow = True
+                    line = ("WARNING: %d env(s) outgrew the track table and %d the confirmed-object table (status bits CN_ST_TRACK_OVERFLOW / "
+                            "CN_ST_CONF_OVERFLOW): their risk features use the tracks that fit and differ from the reference's unbounded "
+                            "lists from there on; Config(track_capacity=64) doubles the table" % (sc_["track_overflow"], sc_["conf_overflow"]))
+                    print(line, flush=True); log.write(line + "\n"); log.flush()
             if a.csv:
                 stats.append_csv(a.out, "td3_training", resume=resumed)   # incremental: a killed run keeps its rows up to here
             if episodes >= next_ckpt:                                    # TRAIN:150-154 (every 100 episodes there)

@@ -990,6 +990,36 @@ def test_worlds_the_fuzzer_found(oracle_mod, world):
         assert (not bad and not skipped) or late_overflow, (world, f, kernel, bad, skipped)
 
 
+def test_track_table_overflow_is_flagged_and_confined(oracle_mod):
+    """The reference's track list is an unbounded Python list, and its tracker keeps the tracks of earlier episodes and duplicates them
+    at every reset; the kernel's table holds track_capacity tracks.  A world found by tools/fuzz_parity.py whose goal lies within
+    goal_eps of the spawn pose -- every episode ends at its first step, so the resets dominate -- outgrows 32 tracks within a
+    hundred steps: the env raises CN_ST_TRACK_OVERFLOW (sticky; VecEnv.status_counts) and every env WITHOUT the
+    bit still equals the oracle bit for bit; with track_capacity = 64 the same steps overflow in fewer envs (or none)."""
+    import torch
+    kw = dict(n_envs=16, n_peds=16, n_rays=361, k_obstacles=3, max_steps=49, room_half=1.1832673565816718, goal_x=0.565634967637293,
+              goal_y=0.44034573709026004, spawn_x=0.6050993559998654, spawn_y=0.29646458843154355, spawn_yaw=2.8751215535007932, scan_latency_ms=5,
+              settle_ms=50, ped_cycle_ms=1400, ped_vmax=0.2505021742113402, seed=634151950, env_index_base=286355, lidar_min=0.0, ped_radius=0.1,
+              start_x=0.7867724988896705, start_y=-0.895986056152086)
+    n_over = {}
+    for cap in (32, 64):
+        torch_, env, orc = _pair(oracle_mod, track_capacity=cap, **kw)
+        env.reset(); torch.cuda.synchronize(); orc.reset()
+        rng = np.random.default_rng(3)
+        for t in range(160):
+            act = np.stack([rng.uniform(0, 0.22, 16), rng.uniform(-2, 2, 16)], 1).astype(np.float32)
+            env.step(torch.from_numpy(act).cuda(), auto_reset="next"); torch.cuda.synchronize()
+            oc, rc, dc, ic = orc.step(act.astype(np.float64), auto_reset="next")
+            c = env.counters().cpu().numpy()
+            clean = (c[:, 6] & 1) == 0
+            assert np.array_equal(env.obs_f64.cpu().numpy()[clean], oc[clean]), (cap, t)
+            assert np.array_equal(env.topk_idx.cpu().numpy()[clean], ic[clean]) and np.array_equal(env.done.cpu().numpy()[clean], dc[clean]), (cap, t)
+        n_over[cap] = env.status_counts()["track_overflow"]
+        assert n_over[cap] == int((~clean).sum())
+        env.close()
+    assert n_over[32] > 0 and n_over[64] <= n_over[32], n_over
+
+
 def test_graphed_rollout_replays():
     """The actor + env step captured in one HIP graph (rollout.GraphedRollout) advances the envs on replay."""
     import torch

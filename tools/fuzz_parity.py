@@ -260,6 +260,8 @@ def main():
             env_steps += kw["n_envs"] * steps
             if n_overflow <= 3:
                 print("  table overflow (flagged in the status word) %d: %s %s | %s" % (n_overflow, kn, bad[:2], {k: kw[k] for k in ("n_envs", "n_peds", "n_rays", "k_obstacles", "max_steps")}))
+                if a.verbose > 3:
+                    print("     --form %s --mode %s --steps %d --repro \"%r\"" % (form, mode, steps, kw))
             continue
         env_steps += kw["n_envs"] * steps
         if bad:
