@@ -38,7 +38,7 @@ class Config:
     settle_ms: int = 100           # TRAIN:114
     ped_cycle_ms: int = 0          # 0 -> 100 ms x n_peds (CROWD:128-144)
     ped_stagger_ms: int = 100      # CROWD:144
-    track_capacity: int = 0        # tracker slots per env: 0 = auto (32 up to 40 pedestrians, else 64)
+    track_capacity: int = 0        # tracker slots per env: 0 = auto (32 up to 40 pedestrians -- up to 32 with risk_mode 1 --, else 64)
     obs_layout: int = 0            # 0: environment_stage_1_nobonus (366 + 4K); 1: environment_stage_1_original (R-1 + 4);
                                    # 2: environment_stage_1_nobonus_realworld (R-1 + 11; use dt_ms=50, RW:880-883)
     geos_untyped_empty: int = 0    # 1: shapely <= 1.7 / GEOS <= 3.8 empty-result semantics at UTL:279,306 (the reference's platform)

@@ -358,7 +358,9 @@ extern "C" int cn_create(const cn_config* cfg, int device, cn_handle* out)
     const int N = c.n_envs, P = c.n_peds, R = c.n_rays, K = c.k_obstacles;
     h->D = c.obs_layout == CN_LAYOUT_ORIGINAL ? (R - 1) + 4 : (c.obs_layout == CN_LAYOUT_REALWORLD ? (R - 1) + 11 : (R - 1) + 7 + 4 * K);
     h->max_conf = (R - 1) / 4 + 2;
-    h->trk_cap = c.track_capacity ? c.track_capacity : (P <= 40 ? 32 : 64);
+    // (risk_mode gt lists the simulator's own pedestrians in range: up to P entries, so 33-40 pedestrians take the larger table there --
+    // tools/fuzz_parity.py found a 36-pedestrian gt world with more than 32 of them in range)
+    h->trk_cap = c.track_capacity ? c.track_capacity : ((P <= 40 && !(c.risk_mode == CN_RISK_GT && P > 32)) ? 32 : 64);
     h->lds = lds_bytes_impl(R, P, K, h->max_conf, h->trk_cap, cn_near_separate(R, P, K, h->max_conf, h->trk_cap) != 0, c.obs_layout);
     if (c.ped_contact && c.obs_layout != CN_LAYOUT_RISK)
         return fail(CN_ERR_CONFIG, "cn_create: ped_contact is built for the risk observation layout (obs_layout 0) only");

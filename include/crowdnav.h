@@ -63,7 +63,7 @@ typedef struct cn_config {
     int32_t settle_ms;       /* trainer's time.sleep(0.1) after reset (TRAIN:114) -> 100 */
     int32_t ped_cycle_ms;    /* crowd node cycle: 0.1 s x number of obstacles (CROWD:128-144) */
     int32_t ped_stagger_ms;  /* 0.1 s between consecutive obstacles' updates (CROWD:144) -> 100 */
-    int32_t track_capacity;  /* tracker slots per env: 0 = auto (32 for <= 40 pedestrians, else 64), or 32 / 64 */
+    int32_t track_capacity;  /* tracker slots per env: 0 = auto (32 for <= 40 pedestrians -- <= 32 with risk_mode gt --, else 64), or 32 / 64 */
     int32_t obs_layout;      /* CN_LAYOUT_RISK (0): environment_stage_1_nobonus.py, obs = R-1 + 7 + 4K (TD3 / DDPG trainers);
                               * CN_LAYOUT_ORIGINAL (1): environment_stage_1_original.py:278-402, obs = R-1 + 4 =
                               * rounded ranges + heading + distance + rounded (x, y) (SAC / DQN / Q-learning trainers);
@@ -173,7 +173,8 @@ typedef struct cn_step_io {
  * /scan and /odom messages.  The library's own simulator is bypassed; tracker / waypoint / deque state is the
  * handle's.  This is also how the golden runs recorded from the reference are replayed through the kernel. */
 typedef struct cn_external_io {
-    const double* ranges;        /* dev [N,R] LaserScan.ranges as delivered (+inf = no return; ENV:1218,1238) */
+    const double* ranges;        /* dev [N,R] LaserScan.ranges as delivered: finite values >= 0, +inf = no return, NaN (ENV:1218,1238); a negative
+                                  * range is not a LaserScan value and is outside the domain (clip before the call) */
     const double* odom;          /* dev [N,10]: position x, y, yaw, linear_twist.x, angular_twist.z (ENV:239-243),
                                   *   time.time() inside get_state, position x, y at the end of time.sleep (ENV:1208),
                                   *   end_timestep (ENV:1202), reserved */

@@ -100,7 +100,12 @@ def run_world(kw, form, mode, T, detail=False, as_steps=False):
                 diff(tag, g, c)
     check("reset observation", env.obs_f64.cpu().numpy(), orc.reset())
     if form == "step":
+        t_snap = int(rng.integers(1, T)) if rng.random() < 0.4 else -1      # 40 %: snapshot mid-run, continue on a FRESH handle restored from it
         for t in range(T):
+            if t == t_snap:
+                blob = env.snapshot()
+                env2 = VecEnv(cfg); env2.enable_f64_obs(); env2.restore(blob)
+                env.close(); env = env2
             act = np.stack([rng.uniform(0, 0.22, N), rng.uniform(-2, 2, N)], 1).astype(np.float32)
             env.step(torch.from_numpy(act).cuda(), auto_reset=mode); torch.cuda.synchronize()
             oc, rc, dc, ic = orc.step(act.astype(np.float64), auto_reset=mode)
