@@ -701,6 +701,51 @@ def test_reference_scenarios_presets(oracle_mod):
     assert open(path).readline().strip().split(",") == st.HEADERS
 
 
+def test_every_scripted_evaluation_scenario_equals_the_oracle(oracle_mod):
+    """All 29 evaluation scenarios of crowdnav/presets_data.json -- crossing / towards / ahead / random x 4 / 8 / 12 / 20 obstacles and
+    their _fast / _highspeed variants, each in the 5 x 5 m test world with its own obstacle poses and velocity table (row A1, N2) --
+    through the step kernel and the one-launch forms against the oracle: observations, rewards, done flags, indices, counters."""
+    import re
+    import torch
+    from crowdnav import presets
+    from crowdnav.env import VecEnv
+    seen = 0
+    for name in presets.names():
+        m = re.match(r"simulate_(crossing|towards|ahead|random)_(\d+)(?:_(fast|highspeed))?$", name)
+        if not m:
+            continue                                     # simulate_crowd / simulate_crowd_highspeed: the training crowd (presets.training)
+        seen += 1
+        kind, n, variant = m.group(1), int(m.group(2)), m.group(3) or ""
+        cfg, init, vel = presets.evaluation(kind, n, variant, n_envs=6, max_steps=25, seed=100 + seen, k_obstacles=(8, 4, 12)[seen % 3])
+        env = VecEnv(cfg); env.enable_f64_obs(); env.set_ped_init(init)
+        orc = oracle_mod.Oracle(cfg.as_dict()); orc.set_ped_init(init)
+        if vel is not None:
+            env.set_ped_preset_vel(vel); orc.set_ped_preset_vel(vel)
+        env.reset(); torch.cuda.synchronize()
+        assert np.array_equal(env.obs_f64.cpu().numpy(), orc.reset()), name
+        rng = np.random.default_rng(seen)
+        mode = ("next", True)[seen % 2]
+        for t in range(40):
+            act = np.stack([rng.uniform(0.05, 0.22, 6), rng.uniform(-1.0, 1.0, 6)], 1).astype(np.float32)
+            env.step(torch.from_numpy(act).cuda(), auto_reset=mode); torch.cuda.synchronize()
+            oc, rc, dc, ic = orc.step(act.astype(np.float64), auto_reset=mode)
+            assert np.array_equal(env.obs_f64.cpu().numpy(), oc), (name, t)
+            assert np.array_equal(env.reward.cpu().numpy(), rc.astype(np.float32)) and np.array_equal(env.done.cpu().numpy(), dc), (name, t)
+            assert np.array_equal(env.topk_idx.cpu().numpy(), ic), (name, t)
+        # ... and 10 more steps as ONE cn_step_sequence launch into trajectory buffers
+        T = 10
+        A = np.stack([rng.uniform(0.05, 0.22, (T, 6)), rng.uniform(-1.0, 1.0, (T, 6))], 2).astype(np.float32)
+        if mode == "next":
+            traj = dict(obs=torch.zeros((T, 6, env.D), device="cuda"), reward=torch.zeros((T, 6), device="cuda"), done=torch.zeros((T, 6), dtype=torch.uint8, device="cuda"))
+            env.bind_step_sequence(torch.from_numpy(A).cuda(), traj=traj)(); torch.cuda.synchronize()
+            for t in range(T):
+                oc, rc, dc, ic = orc.step(A[t].astype(np.float64), auto_reset="next")
+                assert np.array_equal(traj["obs"][t].cpu().numpy(), oc.astype(np.float32)) and np.array_equal(traj["done"][t].cpu().numpy(), dc), (name, "sequence", t)
+        assert np.array_equal(env.counters().cpu().numpy()[:, :6], orc.counters()), name
+        env.close()
+    assert seen == 29
+
+
 @pytest.mark.parametrize("name", ["train20", "dense100", "eval60", "k4", "geos38", "py2tie", "gazebo20"])
 def test_golden_replay_through_the_kernel(name):
     """The kernel fed with EXACTLY what Gazebo/ROS handed the reference in the golden runs (lidar ranges, odom,
