@@ -778,9 +778,9 @@ def test_golden_replay_through_the_kernel(name):
         # the last bit on 13 % of its arguments and these four lines carried a 1e-12 tolerance)
         assert np.array_equal(d["track_speed"], z["track_speed"][i][:n])
         assert np.array_equal(d["track_vel"], z["track_vel"][i][:n])
-        # (the two CP scalars keep the 1e-12 of the earlier rounds: one call of the py2tie run differs in the last bit of
-        # collision_prob on this external-scan path -- 0.5190766065453384 against ...385; the simulated path compares them exactly in
-        # test_scripted_collision_probability_corner_cases)
+        # (the two CP scalars keep the 1e-12 of the earlier rounds: ONE of the 1 462 recorded calls -- py2tie, call 77 -- differs in the
+        # last bit of the ego score, 0.2860698797573434 against ...4355, hence of collision_prob; the simulated path compares them
+        # exactly in test_scripted_collision_probability_corner_cases)
         assert abs(d["collision_prob"] - z["collision_prob"][i]) <= 1e-12 and abs(d["ego_score"] - z["ego_score"][i]) <= 1e-12
         assert np.array_equal(d["wp"], z["wp"][i]) and d["bb"] == z["bb"][i]
         assert tuple(env.counters()[0, :3].cpu().tolist()) == tuple(int(c) for c in z["counters"][i])
