@@ -42,7 +42,8 @@ def draw(rng):
               dt_ms=int(rng.choice([50, 100, 150, 150, 200])), scan_latency_ms=int(rng.choice([5, 10, 10, 20])),
               settle_ms=int(rng.choice([0, 50, 100, 100])), ped_cycle_ms=int(rng.choice([0, 300, 700, 1400, 2000])),
               ped_vmax=float(rng.uniform(0.05, 0.5)), min_scan_range=float(rng.choice([0.0, 0.12, 0.12])),
-              seed=int(rng.integers(1, 1 << 30)), env_index_base=int(rng.integers(0, 1 << 20)))
+              seed=int(rng.integers(1, 1 << 30)) if rng.random() < 0.8 else int(rng.integers(1 << 40, 1 << 62)),
+              env_index_base=int(rng.integers(0, 1 << 20)) if rng.random() < 0.8 else int(rng.integers(1 << 33, 1 << 45)))
     if rng.random() < 0.5:          # the sensor, the bodies and the goal geometry too (every second world keeps the reference's)
         kw.update(lidar_max=float(rng.choice([0.6, 0.6, 1.0, 3.5])), max_scan_range=float(rng.choice([0.6, 0.6, 0.5, 1.0])),
                   lidar_min=float(rng.choice([0.08, 0.08, 0.0, 0.12])), lidar_span=float(rng.choice([6.28, 6.28, 3.14, 4.0])),
