@@ -2,7 +2,8 @@
 """tools/profc/report.py [--counters gpurun_out/profc/counters_4096.npz] [--asm /tmp/isa/k1.s] [--kernel cn_env_kernel_fair_s360_w4]
 
 The DYNAMIC instruction ledger of the step kernel: every instruction of the PRODUCT's code (assembly with line tables: the same
-instructions as lib/libcrowdnav.so, `tools/isa_ledger.py --rebuild --flags=-DCN_TU=1` writes it) weighted with how often a
+instructions as lib/libcrowdnav.so, `tools/isa_ledger.py --rebuild --flags="-DCN_TU=1 -fdebug-info-for-profiling" --asm /tmp/isa/k1.s` writes it -- the second flag puts the
+unroller's duplication factors into the line table's discriminators, without it unrolled loops are counted several times) weighted with how often a
 wavefront executed the source region it belongs to (clang region counters of the counted build, tools/profc/run.py).
 
   instruction -> its inlining chain of (file, line, column) from the .loc comments
