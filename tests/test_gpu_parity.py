@@ -1035,6 +1035,33 @@ def test_worlds_the_fuzzer_found(oracle_mod, world):
         assert (not bad and not skipped) or late_overflow, (world, f, kernel, bad, skipped)
 
 
+def test_randomised_soak_over_the_configuration_cross_product(oracle_mod):
+    """Twenty seconds of tools/fuzz_parity.py inside the gate (fixed seed: the same sequence of worlds every run, as many of them as
+    the box manages): worlds drawn from every switch cn_create accepts, each through one of the four launch forms, equal to the oracle
+    -- or flagged by the kernel itself as having outgrown a table."""
+    import sys
+    import time
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_parity
+    fuzz_parity.HEADLINE_FRAC = 0.25
+    rng = np.random.default_rng(2026)
+    t_end = time.time() + 20.0
+    n = refused = 0
+    while time.time() < t_end:
+        kw, form, mode = fuzz_parity.draw(rng)
+        try:
+            bad, kernel, skipped = fuzz_parity.run_world(kw, form, mode, 40)
+        except Exception as ex:
+            assert "cn_create" in str(ex), (kw, ex)           # a combination cn_create refuses, with its reason
+            refused += 1
+            continue
+        n += 1
+        assert not bad or skipped == "overflow", (form, mode, kernel, bad, kw)
+    fuzz_parity.HEADLINE_FRAC = 0.0
+    assert n >= 50, (n, refused)
+
+
 def test_track_table_overflow_is_flagged_and_confined(oracle_mod):
     """The reference's track list is an unbounded Python list, and its tracker keeps the tracks of earlier episodes and duplicates them
     at every reset; the kernel's table holds track_capacity tracks.  A world found by tools/fuzz_parity.py whose goal lies within
